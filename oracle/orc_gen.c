@@ -1,0 +1,112 @@
+/*
+ * orc_gen.c -- TEST INFRASTRUCTURE: integer-only synthetic YUV clip generator.
+ *
+ * Stateless: frame t of clip (w,h,subsamp,seed,style) is a pure function of its arguments, so
+ * the golden fixtures, the CPU baseline and the GPU bench all see identical bytes.
+ *   luma   = blend of a 5x5-box-blurred hash-noise texture panning (1.5, 1) px/frame (half-pel
+ *            horizontal motion on odd frames), two triangle-wave ramps, and +-1 per-pixel dither
+ *   chroma = drifting triangle waves + a little texture
+ *   style 1 adds a fast flat square and a flat band whose level changes every frame (these
+ *   provoke intra blocks / forced-intra frames on the reference encoder; style 0 does not).
+ */
+#include <stdlib.h>
+#include <string.h>
+#include "orc.h"
+
+static inline uint32_t mix(uint32_t a)
+{
+    a ^= a >> 16; a *= 0x7feb352du; a ^= a >> 15; a *= 0x846ca68bu; a ^= a >> 16;
+    return a;
+}
+static inline uint32_t hash3(uint32_t x, uint32_t y, uint32_t s)
+{
+    return mix(x * 0x9E3779B1u ^ mix(y * 0x85EBCA77u ^ mix(s)));
+}
+static inline int tri(int v, int period)          /* 0 .. period/2 */
+{
+    int m = v % period;
+    if (m < 0) m += period;
+    int half = period / 2;
+    return m < half ? m : period - m;
+}
+static inline uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
+
+size_t orc_frame_bytes(int w, int h, int subsamp)
+{
+    size_t cw = (size_t)ORC_RSHIFT_UP(w, ORC_HSHIFT(subsamp)), ch = (size_t)ORC_RSHIFT_UP(h, ORC_VSHIFT(subsamp));
+    return (size_t)w * h + 2 * cw * ch;
+}
+
+#define MARGIN 192
+
+void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t, int style)
+{
+    const int TW = w + 2 * MARGIN, TH = h + 2 * MARGIN;
+    uint8_t *noise = (uint8_t *)malloc((size_t)TW * TH);
+    uint8_t *tex = (uint8_t *)malloc((size_t)TW * TH);
+    uint16_t *colsum = (uint16_t *)malloc((size_t)TW * sizeof(uint16_t));
+
+    for (int y = 0; y < TH; y++)
+        for (int x = 0; x < TW; x++)
+            noise[(size_t)y * TW + x] = (uint8_t)(hash3((uint32_t)x, (uint32_t)y, seed) >> 24);
+    /* 5x5 box blur, clamped addressing, rounded */
+    for (int y = 0; y < TH; y++) {
+        for (int x = 0; x < TW; x++) {
+            int s = 0;
+            for (int dy = -2; dy <= 2; dy++) {
+                int yy = y + dy; yy = yy < 0 ? 0 : (yy >= TH ? TH - 1 : yy);
+                s += noise[(size_t)yy * TW + x];
+            }
+            colsum[x] = (uint16_t)s;
+        }
+        for (int x = 0; x < TW; x++) {
+            int s = 0;
+            for (int dx = -2; dx <= 2; dx++) {
+                int xx = x + dx; xx = xx < 0 ? 0 : (xx >= TW ? TW - 1 : xx);
+                s += colsum[xx];
+            }
+            /* stretch contrast a little so the texture survives quantisation */
+            int v = (s + 12) / 25;
+            tex[(size_t)y * TW + x] = sat8(128 + (v - 128) * 3);
+        }
+    }
+
+    const int hx = 3 * t, ypan = t;              /* half-pel x shift, integer y shift */
+    const int xo = hx >> 1, xfrac = hx & 1;
+    uint8_t *Y = out;
+    for (int y = 0; y < h; y++) {
+        const uint8_t *tr = tex + (size_t)((y + ypan) % TH + 0) * TW;
+        for (int x = 0; x < w; x++) {
+            int xi = (x + xo) % (TW - 1);
+            int tv = xfrac ? (tr[xi] + tr[xi + 1] + 1) >> 1 : tr[xi];
+            int ramp = 64 + (tri(x, 74) * 128 / 37 + tri(y, 46) * 128 / 23) / 2;
+            int d = (int)(hash3((uint32_t)x, (uint32_t)y, seed ^ (0xD17Du + (uint32_t)t * 977u)) & 3) - 1;
+            Y[(size_t)y * w + x] = sat8((3 * tv + 2 * ramp) / 5 + d);
+        }
+    }
+    if (style == 1) {
+        int sq = w < 192 ? w / 4 : 96;
+        int sx = (37 * t) % (w - sq), sy = (23 * t) % (h - sq);
+        int lvl = 40 + 15 * t; if (lvl > 250) lvl = 250;
+        for (int y = 0; y < sq; y++) memset(Y + (size_t)(sy + y) * w + sx, lvl, (size_t)sq);
+        int band = h / 8, bl = 100 + 12 * (t % 3);
+        for (int y = h - band; y < h; y++) memset(Y + (size_t)y * w, bl, (size_t)w);
+    }
+
+    const int cw = ORC_RSHIFT_UP(w, ORC_HSHIFT(subsamp)), ch = ORC_RSHIFT_UP(h, ORC_VSHIFT(subsamp));
+    uint8_t *U = out + (size_t)w * h, *V = U + (size_t)cw * ch;
+    for (int y = 0; y < ch; y++)
+        for (int x = 0; x < cw; x++) {
+            int tv = tex[(size_t)((y + MARGIN / 2) % TH) * TW + (x + MARGIN / 2) % TW];
+            U[(size_t)y * cw + x] = sat8(96 + tri(x + 3 * t, 64) * 2 + (tv >> 5) - 4);
+            V[(size_t)y * cw + x] = sat8(104 + tri(y - 2 * t, 48) * 2 + tri(x + y, 90) / 2 + (tv >> 6));
+        }
+    if (style == 1) {
+        int band = ch / 8;
+        for (int y = ch - band; y < ch; y++) {
+            memset(U + (size_t)y * cw, 120 + 6 * (t % 3), (size_t)cw);
+            memset(V + (size_t)y * cw, 136 - 5 * (t % 3), (size_t)cw);
+        }
+    }
+    free(noise); free(tex); free(colsum);
+}

@@ -1,0 +1,243 @@
+"""Pins the oracle (oracle/liborc.so, our restatement) against the REAL reference compiled from
+/root/reference into oracle/_ref/ -- operator by operator and for whole .dsv streams.
+CPU only.  Skipped where oracle/_ref is absent."""
+import ctypes as C
+import tempfile
+
+import numpy as np
+import pytest
+
+import _cabi as A
+
+pytestmark = pytest.mark.ref
+
+
+def rnd_plane(rng, w, h, smooth):
+    if smooth:
+        base = rng.integers(0, 256, size=(h // 8 + 2, w // 8 + 2)).astype(np.float64)
+        img = np.kron(base, np.ones((8, 8)))[:h, :w] + rng.integers(-6, 7, size=(h, w))
+        return np.clip(img, 0, 255).astype(np.uint8)
+    return rng.integers(0, 256, size=(h, w), dtype=np.uint8)
+
+
+def mk_frame_with(rng, w, h, fmt, smooth=True, extend_with=None):
+    f = A.BorderedFrame(w, h, fmt)
+    for i in range(3):
+        pw, ph = f.dims[i]
+        f.plane(i)[:, :] = rnd_plane(rng, pw, ph, smooth)
+    if extend_with is not None:
+        extend_with(f.ptr())
+    return f
+
+
+SBT_SIZES = [(16, 16), (18, 22), (176, 144), (352, 288), (250, 130), (960, 540)]
+
+
+@pytest.mark.parametrize("w,h", SBT_SIZES)
+@pytest.mark.parametrize("isP", [0, 1])
+def test_sbt_roundtrip_matches_ref(ref, orc, w, h, isP):
+    rng = np.random.default_rng(w * 131 + h * 7 + isP)
+    fmt = A.SUBSAMP_444
+    f = mk_frame_with(rng, w, h, fmt, extend_with=ref.dsv_extend_frame)
+    for c in (0, 1):
+        cw, ch = w, h
+        a = np.zeros(cw * ch, dtype=np.int32)
+        b = np.zeros(cw * ch, dtype=np.int32)
+        ca = A.Coefs(A.i32p(a), cw, ch)
+        cb = A.Coefs(A.i32p(b), cw, ch)
+        ref.dsv_fwd_sbt(C.byref(f.c.planes[c]), C.byref(ca), isP)
+        orc.orc_fwd_sbt(C.byref(f.c.planes[c]), C.byref(cb), isP)
+        assert np.array_equal(a, b), "fwd_sbt differs c=%d" % c
+        for q in (40, 313, 1500):
+            a2, b2 = a.copy(), a.copy()
+            # coarse "quantisation" so the smoothing filter has something to do
+            a2[1:] = (a2[1:] // 16) * 16
+            b2[:] = a2
+            fa = A.BorderedFrame(w, h, fmt)
+            fb = A.BorderedFrame(w, h, fmt)
+            ref.dsv_inv_sbt(C.byref(fa.c.planes[c]), C.byref(A.Coefs(A.i32p(a2), cw, ch)), q, isP, c)
+            orc.orc_inv_sbt(C.byref(fb.c.planes[c]), C.byref(A.Coefs(A.i32p(b2), cw, ch)), q, isP, c)
+            assert np.array_equal(fa.plane(c), fb.plane(c)), "inv_sbt differs c=%d q=%d" % (c, q)
+            assert np.array_equal(a2, b2)
+
+
+def _stab(rng, w, h, isP, cur_plane, all_flags=None):
+    bw, bh, nbh, nbv = A.block_dims(w, h)
+    meta = A.Meta(w, h, A.SUBSAMP_420, 30, 1, 1, 1)
+    prm = A.Params(C.pointer(meta), 1, isP, bw, bh, nbh, nbv)
+    sb = rng.integers(0, 4, size=nbh * nbv).astype(np.uint8) if all_flags is None else \
+        np.full(nbh * nbv, all_flags, dtype=np.uint8)
+    st = A.Stability(C.pointer(prm), A.u8p(sb), cur_plane, isP)
+    return st, (meta, prm, sb)
+
+
+@pytest.mark.parametrize("w,h", [(352, 288), (176, 144), (960, 540), (250, 130)])
+@pytest.mark.parametrize("isP", [0, 1])
+@pytest.mark.parametrize("q", [16, 313, 900, 3000])
+def test_hzcc_encode_decode_matches_ref(ref, orc, w, h, isP, q):
+    rng = np.random.default_rng(w + h * 3 + isP * 5 + q)
+    for cur_plane in (0, 1):
+        st, keep = _stab(rng, w * (2 if cur_plane else 1), h * (2 if cur_plane else 1), isP, cur_plane)
+        # laplacian-ish sparse coefficients, bigger near the origin (low bands)
+        co = (rng.laplace(0, 40, size=(h, w))).astype(np.int32)
+        co[: h // 8, : w // 8] *= 16
+        co = co.reshape(-1)
+        a, b = co.copy(), co.copy()
+        bufa = np.zeros(w * h * 8 + 64, dtype=np.uint8)
+        bufb = np.zeros_like(bufa)
+        bsa = A.BS(A.u8p(bufa), 0)
+        bsb = A.BS(A.u8p(bufb), 0)
+        ref.dsv_encode_plane(C.byref(bsa), C.byref(A.Coefs(A.i32p(a), w, h)), q, C.byref(st))
+        orc.orc_encode_plane(C.byref(bsb), C.byref(A.Coefs(A.i32p(b), w, h)), q, C.byref(st))
+        assert bsa.pos == bsb.pos
+        n = bsa.pos // 8
+        assert np.array_equal(bufa[:n], bufb[:n]), "bitstream differs"
+        assert np.array_equal(a, b), "dequantised coefficients differ"
+        # decode: payload starts after the 4-byte length
+        plen = int.from_bytes(bufa[:4].tobytes(), "big")
+        da = np.zeros(w * h, dtype=np.int32)
+        db = np.zeros(w * h, dtype=np.int32)
+        pa = bufa[4:4 + plen + 8].copy()
+        pb = pa.copy()
+        ref.dsv_decode_plane(A.u8p(pa), plen, C.byref(A.Coefs(A.i32p(da), w, h)), q, C.byref(st))
+        orc.orc_decode_plane(A.u8p(pb), plen, C.byref(A.Coefs(A.i32p(db), w, h)), q, C.byref(st))
+        assert np.array_equal(da, db)
+
+
+def rnd_mvs(rng, nbh, nbv, span):
+    mv = np.zeros(nbh * nbv, dtype=A.MV_DTYPE)
+    mv["x"] = rng.integers(-span, span + 1, size=nbh * nbv)
+    mv["y"] = rng.integers(-span, span + 1, size=nbh * nbv)
+    intra = rng.random(nbh * nbv) < 0.3
+    mv["mode"] = intra
+    mv["submask"] = np.where(intra, rng.integers(1, 16, size=nbh * nbv), 0)
+    return mv
+
+
+@pytest.mark.parametrize("w,h,fmt", [(352, 288, A.SUBSAMP_420), (176, 144, A.SUBSAMP_444),
+                                      (360, 200, A.SUBSAMP_422), (352, 288, A.SUBSAMP_411)])
+def test_bmc_matches_ref(ref, orc, w, h, fmt):
+    rng = np.random.default_rng(w * 3 + h + fmt)
+    bw, bh, nbh, nbv = A.block_dims(w, h)
+    meta = A.Meta(w, h, fmt, 30, 1, 1, 1)
+    prm = A.Params(C.pointer(meta), 1, 1, bw, bh, nbh, nbv)
+    reff = mk_frame_with(rng, w, h, fmt, extend_with=ref.dsv_extend_frame)
+    for span in (3, 40, 400):
+        mv = rnd_mvs(rng, nbh, nbv, span)
+        mvp = mv.ctypes.data_as(C.POINTER(A.MV))
+        inp = mk_frame_with(rng, w, h, fmt, extend_with=ref.dsv_extend_frame)
+        ia, ib = A.BorderedFrame(w, h, fmt), A.BorderedFrame(w, h, fmt)
+        ia.buf[:] = inp.buf
+        ib.buf[:] = inp.buf
+        da, db = A.BorderedFrame(w, h, fmt), A.BorderedFrame(w, h, fmt)
+        ref.dsv_sub_pred(mvp, C.byref(prm), da.ptr(), ia.ptr(), reff.ptr())
+        orc.orc_sub_pred(mvp, C.byref(prm), db.ptr(), ib.ptr(), reff.ptr())
+        assert np.array_equal(da.raw(), db.raw()), "prediction differs"
+        assert np.array_equal(ia.raw(), ib.raw()), "residual differs"
+        oa, ob = A.BorderedFrame(w, h, fmt), A.BorderedFrame(w, h, fmt)
+        ref.dsv_add_pred(mvp, C.byref(prm), ia.ptr(), oa.ptr(), reff.ptr())
+        orc.orc_add_pred(mvp, C.byref(prm), ib.ptr(), ob.ptr(), reff.ptr())
+        assert np.array_equal(oa.raw(), ob.raw())
+        ref.dsv_frame_add(ia.ptr(), da.ptr())
+        orc.orc_frame_add(ib.ptr(), db.ptr())
+        assert np.array_equal(ia.raw(), ib.raw())
+
+
+def test_frame_ops_match_ref(ref, orc):
+    rng = np.random.default_rng(5)
+    for (w, h, fmt) in [(352, 288, A.SUBSAMP_420), (101, 77, A.SUBSAMP_420), (64, 48, A.SUBSAMP_444)]:
+        fa = mk_frame_with(rng, w, h, fmt)
+        fb = A.BorderedFrame(w, h, fmt)
+        fb.buf[:] = fa.buf
+        ref.dsv_extend_frame(fa.ptr())
+        orc.orc_frame_extend(fb.ptr())
+        assert np.array_equal(fa.raw(), fb.raw())
+        assert ref.dsv_frame_avg_luma(fa.ptr()) == orc.orc_frame_avg_luma(fb.ptr())
+        w2, h2 = A.rshift_up(w, 1), A.rshift_up(h, 1)
+        da, db = A.BorderedFrame(w2, h2, fmt), A.BorderedFrame(w2, h2, fmt)
+        ref.dsv_ds2x_frame_luma(da.ptr(), fa.ptr())
+        ref.dsv_extend_frame_luma(da.ptr())
+        orc.orc_frame_ds2x_luma(db.ptr(), fb.ptr())
+        orc.orc_frame_extend_luma(db.ptr())
+        assert np.array_equal(da.raw(), db.raw())
+
+
+def build_pyramid(lib_ds, lib_ext, f0, levels):
+    out = [f0]
+    w, h = f0.w, f0.h
+    for i in range(levels):
+        f = A.BorderedFrame(A.rshift_up(w, i + 1), A.rshift_up(h, i + 1), f0.fmt)
+        lib_ds(f.ptr(), out[-1].ptr())
+        lib_ext(f.ptr())
+        out.append(f)
+    return out
+
+
+@pytest.mark.parametrize("w,h,style", [(352, 288, 0), (352, 288, 1), (704, 480, 1)])
+def test_hme_matches_ref(ref, orc, w, h, style):
+    fmt = A.SUBSAMP_420
+    clip = A.gen_clip(w, h, fmt, 0xC1F001 + style, 3, style=style)
+    bw, bh, nbh, nbv = A.block_dims(w, h)
+    meta = A.Meta(w, h, fmt, 30, 1, 1, 1)
+    prm = A.Params(C.pointer(meta), 1, 1, bw, bh, nbh, nbv)
+    levels = 3
+    frames = []
+    for t in range(3):
+        f = A.BorderedFrame(w, h, fmt)
+        f.load_planar(clip[t])
+        ref.dsv_extend_frame(f.ptr())
+        frames.append(build_pyramid(ref.dsv_ds2x_frame_luma, ref.dsv_extend_frame_luma, f, levels))
+    for t in (1, 2):
+        ha, hb = A.HME(), A.HME()
+        for hm in (ha, hb):
+            hm.params = C.pointer(prm)
+            hm.levels = levels
+            for l in range(levels + 1):
+                hm.src[l] = C.pointer(frames[t][l].c)
+                hm.ref[l] = C.pointer(frames[t - 1][l].c)
+        pa = ref.dsv_hme(C.byref(ha))
+        pb = orc.orc_hme_run(C.byref(hb))
+        assert pa == pb
+        for l in range(levels + 1):
+            a = np.ctypeslib.as_array(C.cast(ha.mvf[l], C.POINTER(C.c_uint8)), shape=(nbh * nbv * 12,)).copy()
+            b = np.ctypeslib.as_array(C.cast(hb.mvf[l], C.POINTER(C.c_uint8)), shape=(nbh * nbv * 12,)).copy()
+            a = a.view(A.MV_DTYPE)
+            b = b.view(A.MV_DTYPE)
+            for k in ("x", "y", "mode", "submask", "lo_var", "lo_tex", "high_detail"):
+                assert np.array_equal(a[k], b[k]), "mv field %s differs at level %d frame %d" % (k, l, t)
+            ref.dsv_free(C.cast(ha.mvf[l], C.c_void_p))
+            C.CDLL(None).free(hb.mvf[l])
+
+
+STREAMS = [
+    # (w, h, fmt, nframes, style, cli flags, orc cfg kwargs)
+    (352, 288, A.SUBSAMP_420, 6, 0, ["-gop0", "-qp85", "-rc_mode1"], dict(qp=85, gop=0, rc_mode_cli=1)),
+    (352, 288, A.SUBSAMP_420, 6, 0, ["-gop0", "-qp85"], dict(qp=85, gop=0, rc_mode_cli=0)),
+    (352, 288, A.SUBSAMP_420, 14, 0, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    (352, 288, A.SUBSAMP_420, 14, 1, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    (352, 288, A.SUBSAMP_420, 14, 1, ["-gop12", "-qp60"], dict(qp=60, gop=12, rc_mode_cli=0)),
+    (352, 288, A.SUBSAMP_420, 10, 1, ["-gop5", "-qp30", "-rc_mode1", "-scd0"], dict(qp=30, gop=5, rc_mode_cli=1, scd=0)),
+    (320, 240, A.SUBSAMP_444, 8, 1, ["-gop12", "-qp95", "-rc_mode1"], dict(qp=95, gop=12, rc_mode_cli=1)),
+    (320, 240, A.SUBSAMP_422, 8, 1, ["-gop12", "-qp85", "-kbps800"], dict(qp=85, gop=12, rc_mode_cli=0, kbps=800)),
+    (352, 288, A.SUBSAMP_411, 6, 0, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+]
+
+
+@pytest.mark.parametrize("case", range(len(STREAMS)))
+def test_stream_matches_ref_cli(orc, case):
+    if not A.have_ref():
+        pytest.skip("no reference build")
+    w, h, fmt, n, style, flags, kw = STREAMS[case]
+    clip = A.gen_clip(w, h, fmt, 0xABC000 + case, n, style=style)
+    with tempfile.TemporaryDirectory() as td:
+        want = A.ref_cli_encode(clip, w, h, A.FMT_CLI[fmt], flags, td)
+        got, recs = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw), want_recon=True)
+        assert len(got) == len(want), "stream length %d vs %d" % (len(got), len(want))
+        assert got == want
+        # decoder parity + "decoder output == encoder reconstruction" 
+        dec_ref = A.ref_cli_decode(want, td).reshape(n, -1)
+        dec_orc = A.orc_decode(got, w, h, fmt)
+        assert len(dec_orc) == n
+        for t in range(n):
+            assert np.array_equal(dec_ref[t], dec_orc[t]), "decoded frame %d differs" % t
+            assert np.array_equal(recs[t], dec_orc[t]), "recon != decode at frame %d" % t
