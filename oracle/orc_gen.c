@@ -8,6 +8,9 @@
  *   chroma = drifting triangle waves + a little texture
  *   style 1 adds a fast flat square and a flat band whose level changes every frame (these
  *   provoke intra blocks / forced-intra frames on the reference encoder; style 0 does not).
+ *   style 2: static background (no pan), a fast TEXTURED bright square (blocks it half covers
+ *   become intra with partial sub-block masks) and a global +14 luma step from frame 5 on
+ *   (scene-change detection).
  */
 #include <stdlib.h>
 #include <string.h>
@@ -71,7 +74,7 @@ void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
         }
     }
 
-    const int hx = 3 * t, ypan = t;              /* half-pel x shift, integer y shift */
+    const int hx = style == 2 ? 0 : 3 * t, ypan = style == 2 ? 0 : t;   /* half-pel x shift, integer y shift */
     const int xo = hx >> 1, xfrac = hx & 1;
     uint8_t *Y = out;
     for (int y = 0; y < h; y++) {
@@ -91,6 +94,18 @@ void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
         for (int y = 0; y < sq; y++) memset(Y + (size_t)(sy + y) * w + sx, lvl, (size_t)sq);
         int band = h / 8, bl = 100 + 12 * (t % 3);
         for (int y = h - band; y < h; y++) memset(Y + (size_t)y * w, bl, (size_t)w);
+    }
+
+    if (style == 2) {
+        int sq = w < 192 ? w / 4 : 88;
+        int sx = 9 + (37 * t) % (w - sq - 9), sy = 5 + (23 * t) % (h - sq - 5);
+        for (int y = 0; y < sq; y++)
+            for (int x = 0; x < sq; x++) {
+                int tv = tex[(size_t)(y + 7) * TW + x + 11];
+                Y[(size_t)(sy + y) * w + sx + x] = sat8(70 + tv / 2 + ((x ^ y) & 8 ? 40 : 0));
+            }
+        if (t >= 5)
+            for (size_t i = 0; i < (size_t)w * h; i++) Y[i] = sat8(Y[i] + 14);
     }
 
     const int cw = ORC_RSHIFT_UP(w, ORC_HSHIFT(subsamp)), ch = ORC_RSHIFT_UP(h, ORC_VSHIFT(subsamp));

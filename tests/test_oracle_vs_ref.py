@@ -173,7 +173,7 @@ def build_pyramid(lib_ds, lib_ext, f0, levels):
     return out
 
 
-@pytest.mark.parametrize("w,h,style", [(352, 288, 0), (352, 288, 1), (704, 480, 1)])
+@pytest.mark.parametrize("w,h,style", [(352, 288, 0), (352, 288, 1), (704, 480, 1), (352, 288, 2), (704, 480, 2)])
 def test_hme_matches_ref(ref, orc, w, h, style):
     fmt = A.SUBSAMP_420
     clip = A.gen_clip(w, h, fmt, 0xC1F001 + style, 3, style=style)
@@ -220,6 +220,13 @@ STREAMS = [
     (320, 240, A.SUBSAMP_444, 8, 1, ["-gop12", "-qp95", "-rc_mode1"], dict(qp=95, gop=12, rc_mode_cli=1)),
     (320, 240, A.SUBSAMP_422, 8, 1, ["-gop12", "-qp85", "-kbps800"], dict(qp=85, gop=12, rc_mode_cli=0, kbps=800)),
     (352, 288, A.SUBSAMP_411, 6, 0, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    # style 2: partial intra sub-block masks + scene-change forced I at frame 5
+    (352, 288, A.SUBSAMP_420, 9, 2, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    (704, 480, A.SUBSAMP_420, 7, 2, ["-gop12", "-qp70", "-rc_mode1"], dict(qp=70, gop=12, rc_mode_cli=1)),
+    # forced intra through the intra-block percentage threshold
+    (352, 288, A.SUBSAMP_420, 6, 1, ["-gop12", "-qp85", "-rc_mode1", "-ipct20"], dict(qp=85, gop=12, rc_mode_cli=1, ipct=20)),
+    # GOP longer than the stability refresh (stable_refresh = 14, gop 30) with ABR
+    (176, 144, A.SUBSAMP_420, 34, 2, ["-gop30", "-qp85", "-w176"], dict(qp=85, gop=30, rc_mode_cli=0)),
 ]
 
 
