@@ -1,0 +1,264 @@
+// dsvg_common.hip -- geometry / quantiser derivation and small runtime helpers (host side of the shim).
+#include <stdarg.h>
+#include <stdlib.h>
+#include "dsvg_host.hpp"
+
+static thread_local char g_err[512] = "";
+
+void dsvg_set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char *dsvg_last_error(void) { return g_err; }
+
+extern "C" int dsvg_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+static int g_op_device = 0;
+extern "C" int dsvg_set_device(int device)
+{
+    if (device < 0 || device >= dsvg_device_count()) {
+        dsvg_set_error("no such HIP device %d", device);
+        return DSVG_ERR_NODEVICE;
+    }
+    g_op_device = device;
+    return DSVG_OK;
+}
+int dsvg_op_device() { return g_op_device; }
+
+int lb2u(unsigned n)                                   // dsv_lb2 hzcc.c:437-447
+{
+    unsigned i = 1;
+    int l = 0;
+    while (i < n) { i <<= 1; l++; }
+    return l;
+}
+extern "C" int dsvg_lb2(unsigned n) { return lb2u(n); }
+
+int get_quant(int q, int isP, int level)               // dsv_get_quant hzcc.c:77-92
+{
+    if (isP) q = q * 3 / 2;
+    if (level == 1) q = q * 2 / 3;
+    else if (level == 2) q = q * 3 / 2;
+    return q < 16 ? 16 : q;
+}
+extern "C" int dsvg_get_quant(int q, int isP, int level) { return get_quant(q, isP, level); }
+
+void make_frame_layout(FrameLayout &L, int fmt, int w, int h)
+{
+    memset(&L, 0, sizeof(L));
+    const int ext = DSVG_BORDER;
+    L.hs = fmt_hs(fmt);
+    L.vs = fmt_vs(fmt);
+    const int cw = rsu(w, L.hs), ch = rsu(h, L.vs);
+    size_t off = 0;
+    for (int c = 0; c < 3; c++) {
+        L.w[c] = c ? cw : w;
+        L.h[c] = c ? ch : h;
+        L.stride[c] = (L.w[c] + 2 * ext + 15) & ~15;
+        const size_t len = (size_t)L.stride[c] * (L.h[c] + 2 * ext);
+        L.off[c] = off + (size_t)L.stride[c] * ext + ext;
+        off += len;
+    }
+    L.bytes = off;
+    L.pitch = (off + 255) & ~(size_t)255;
+}
+
+int layout_from_host(FrameLayout &L, const dsvg_frame *f, const uint8_t **base, size_t *bytes)
+{
+    memset(&L, 0, sizeof(L));
+    const uint8_t *b = f->alloc ? f->alloc : f->planes[0].data;
+    size_t end = 0;
+    L.hs = fmt_hs(f->format);
+    L.vs = fmt_vs(f->format);
+    for (int c = 0; c < 3; c++) {
+        const dsvg_plane *p = &f->planes[c];
+        L.w[c] = p->w; L.h[c] = p->h; L.stride[c] = p->stride;
+        if (p->data < b) { dsvg_set_error("plane %d lies before the frame base", c); return DSVG_ERR_ARG; }
+        L.off[c] = (size_t)(p->data - b);
+        const int ext = f->border ? DSVG_BORDER : 0;
+        const size_t e = L.off[c] + (size_t)p->stride * (p->h + ext - 1) + p->w + ext;
+        if (e > end) end = e;
+        if ((size_t)p->len > 0) {
+            const size_t start = L.off[c] - (size_t)p->stride * ext - ext;
+            if (start + (size_t)p->len > end) end = start + (size_t)p->len;
+        }
+    }
+    L.bytes = end;
+    L.pitch = (end + 255) & ~(size_t)255;
+    *base = b;
+    *bytes = end;
+    return DSVG_OK;
+}
+
+void make_coef_layout(CoefLayout &C, int fmt, int w, int h)
+{
+    memset(&C, 0, sizeof(C));
+    const int cw = (rsu(w, fmt_hs(fmt)) + 1) & ~1, ch = (rsu(h, fmt_vs(fmt)) + 1) & ~1;
+    size_t off = 0, o3 = 0, o1 = 0;
+    for (int c = 0; c < 3; c++) {
+        C.w[c] = c ? cw : w;
+        C.h[c] = c ? ch : h;
+        const int mx = C.w[c] > C.h[c] ? C.w[c] : C.h[c];
+        C.lvls[c] = lb2u((unsigned)mx);
+        C.w3[c] = rsu(C.w[c], 3); C.h3[c] = rsu(C.h[c], 3);
+        C.w1[c] = rsu(C.w[c], 1); C.h1[c] = rsu(C.h[c], 1);
+        C.off[c] = off;   off += (size_t)C.w[c] * C.h[c];
+        C.s3off[c] = o3;  o3 += ((size_t)C.w3[c] * C.h3[c] + 3) & ~(size_t)3;
+        C.s1off[c] = o1;  o1 += ((size_t)C.w1[c] * C.h1[c] + 3) & ~(size_t)3;
+    }
+    C.total = off; C.s3total = o3; C.s1total = o1;
+}
+
+void make_sbt_geo(SbtGeo &g, int W, int H, int pw, int ph, int pstride, size_t poff, size_t coff, size_t s3off, size_t s1off)
+{
+    memset(&g, 0, sizeof(g));
+    g.W = W; g.H = H; g.pw = pw; g.ph = ph; g.pstride = pstride;
+    g.poff = poff; g.coff = coff; g.s3off = s3off; g.s1off = s1off;
+    g.lvls = lb2u((unsigned)(W > H ? W : H));
+    g.w3 = rsu(W, 3); g.h3 = rsu(H, 3);
+    g.w1 = rsu(W, 1); g.h1 = rsu(H, 1);
+}
+
+void make_hz_plane(HzPlane &hp, int w, int h, int q, int isP, int cur_plane, int nbh, int nbv)
+{
+    memset(&hp, 0, sizeof(hp));
+    if (cur_plane > 0 && q > 512) q = 512;                     // fix_quant hzcc.c:50-57
+    int n = 0, base = 0;
+    HzRegion *r = hp.r;
+    r[n].x0 = 0; r[n].y0 = 0; r[n].sw = rsu(w, 3); r[n].sh = rsu(h, 3);
+    r[n].level = -1; r[n].qp = get_quant(q, isP, 0); r[n].base = 0;
+    base += r[n].sw * r[n].sh;
+    n++;
+    for (int l = 0; l < 3; l++) {
+        const int sw = rsu(w, 3 - l), sh = rsu(h, 3 - l);
+        int qp = get_quant(q, isP, l), qp_h = 0;
+        if (l == 2) {
+            qp = lb2u((unsigned)qp);
+            qp_h = qp - (isP ? 1 : 3);                         // DSV_QP_P / DSV_QP_I
+            qp_h = qp_h < 1 ? 1 : (qp_h > 24 ? 24 : qp_h);
+        }
+        hp.s_w[l] = sw; hp.s_h[l] = sh;
+        for (int s = 1; s < 4; s++, n++) {
+            r[n].x0 = (s & 1) ? sw : 0;
+            r[n].y0 = (s & 2) ? sh : 0;
+            r[n].sw = sw; r[n].sh = sh;
+            r[n].level = l; r[n].qp = qp; r[n].qp_h = qp_h;
+            r[n].dbx = (nbh << 14) / sw;
+            r[n].dby = (nbv << 14) / sh;
+            r[n].base = base;
+            base += sw * sh;
+        }
+    }
+    hp.nscan = base;
+    hp.nchunks = (base + HZ_CHUNK - 1) / HZ_CHUNK;
+    hp.w = w; hp.h = h; hp.nbh = nbh;
+}
+
+void make_hqp(int hqp[16], int q, int isP)                     // sbt.c:677-696
+{
+    const int llq = get_quant(q, isP, 0) / 2;
+    for (int i = 0; i < 16; i++) {
+        int v;
+        if (i > 3 || i == 0) v = llq;
+        else {
+            v = get_quant(q, isP, 3 - i);
+            if (i == 1) {
+                v = lb2u((unsigned)v);
+                v -= isP ? 1 : 3;
+                v = v < 1 ? 1 : (v > 24 ? 24 : v);
+                v = (1 << v) >> 1;
+            }
+            v /= 2;
+        }
+        hqp[i] = v;
+    }
+}
+
+void block_geometry(int w, int h, int *bw, int *bh, int *nbh, int *nbv)
+{
+    auto s4 = [](int d) {
+        int s = d > 1280 ? 64 : d > 1024 ? 48 : d > 704 ? 32 : d > 352 ? 24 : 16;
+        s &= ~7;
+        return s < 16 ? 16 : (s > 64 ? 64 : s);
+    };
+    *bw = s4(w); *bh = s4(h);
+    *nbh = (w + *bw - 1) / *bw;
+    *nbv = (h + *bh - 1) / *bh;
+}
+
+int auto_pyramid_levels(int w, int h, int nbh, int nbv)
+{
+    int lv = lb2u((unsigned)(w < h ? w : h));
+    const int nb = nbh > nbv ? nbh : nbv;
+    while ((1 << lv) > nb) lv--;
+    return lv < 3 ? 3 : (lv > DSVG_MAX_PYRAMID ? DSVG_MAX_PYRAMID : lv);
+}
+
+int Slab::alloc(size_t n, bool zero)
+{
+    bytes = n;
+    hipError_t e = hipMalloc((void **)&raw, n + 2 * GUARD_BYTES);
+    if (e != hipSuccess) { dsvg_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); return DSVG_ERR_HIP; }
+    if (zero) {
+        e = hipMemset(raw, 0, n + 2 * GUARD_BYTES);
+        if (e != hipSuccess) { dsvg_set_error("hipMemset failed: %s", hipGetErrorString(e)); return DSVG_ERR_HIP; }
+    }
+    p = raw + GUARD_BYTES;
+    return DSVG_OK;
+}
+void Slab::release()
+{
+    if (raw) (void)hipFree(raw);
+    raw = p = nullptr;
+    bytes = 0;
+}
+
+hipEvent_t Prof::get()
+{
+    if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+    hipEvent_t e;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void Prof::begin(hipStream_t st, int fam, double alg_bytes)
+{
+    if (!on) return;
+    Rec r; r.fam = fam; r.a = get(); r.b = get(); r.bytes = alg_bytes;
+    (void)hipEventRecord(r.a, st);
+    recs.push_back(r);
+}
+void Prof::end(hipStream_t st)
+{
+    if (!on || recs.empty()) return;
+    (void)hipEventRecord(recs.back().b, st);
+}
+void Prof::collect()
+{
+    for (auto &r : recs) {
+        (void)hipEventSynchronize(r.b);
+        float t = 0;
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.fam] += t; bytes[r.fam] += r.bytes; launches[r.fam]++; }
+        pool.push_back(r.a); pool.push_back(r.b);
+    }
+    recs.clear();
+}
+void Prof::reset()
+{
+    collect();
+    for (int i = 0; i < 8; i++) { ms[i] = 0; bytes[i] = 0; launches[i] = 0; }
+}
+int prof_family(const char *name)
+{
+    static const char *n[FAM_N] = {"sbt_fwd", "sbt_inv", "hzcc", "bmc", "hme", "frame"};
+    for (int i = 0; i < FAM_N; i++) if (!strcmp(n[i], name)) return i;
+    return -1;
+}

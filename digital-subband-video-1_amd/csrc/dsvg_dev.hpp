@@ -1,0 +1,126 @@
+// dsvg_dev.hpp -- shared device/host structures of the MI355X DSV1 hot path (gfx950 only).
+//
+// Data layout in HBM
+//   * Pixel frames use EXACTLY the reference layout of dsv_mk_frame (frame.c:63-120): one
+//     allocation per frame, planes Y,U,V back to back, 64-px replicated border on every side,
+//     row stride round16(w+128).  Motion search / compensation address up to one pixel beyond
+//     the border; identical linear layout => identical bytes.  Frames of one
+//     kind live in one slab, frame i at base + i*frame_bytes (+ a zeroed guard in front).
+//   * Coefficients use the reference's Mallat layout (dsv_mk_coefs frame.c:29-61): int32,
+//     row-major w x h per plane, three planes back to back, sub-bands in quadrants.
+//   * The top of the pyramid (levels >= 4, <= 160 KB) is transformed inside LDS by one
+//     workgroup; the LL3 band travels between the tiled kernels and that tail kernel through a
+//     small compact scratch plane (s3), the LL1 band of intra pictures through s1.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#define DSVG_RSU(x, s) (((x) + (1 << (s)) - 1) >> (s))   // DSV_ROUND_SHIFT dsv.h:62
+
+struct DMV {                 // == DSV_MV (dsv.h:137-150), 12 bytes
+    int16_t x, y;
+    uint8_t mode, submask, lo_var, lo_tex, high_detail, pad[3];
+};
+static_assert(sizeof(DMV) == 12, "DMV must match DSV_MV");
+
+struct FrameLayout {         // one geometry of the reference frame layout
+    int w[3], h[3], stride[3];
+    int hs, vs;              // chroma shifts
+    size_t off[3];           // byte offset of pixel (0,0) of each plane from the frame base
+    size_t bytes;            // allocation size of one frame (sum of plane lens)
+    size_t pitch;            // distance between consecutive frames in a slab (bytes, padded)
+};
+
+struct CoefLayout {
+    int w[3], h[3];          // coefficient plane dims (chroma rounded up to even, frame.c:41-42)
+    int lvls[3];             // number of transform levels (sbt.c:617-628)
+    int w3[3], h3[3];        // dims of the LL3 band = HZCC "LL" region = LDS tail region
+    int w1[3], h1[3];        // dims of the LL1 band
+    size_t off[3];           // offset of each plane in ints
+    size_t total;            // ints per job
+    size_t s3off[3], s3total;
+    size_t s1off[3], s1total;
+};
+
+// HZCC scan geometry of one plane (hzcc.c:30-48,137-293): ten regions in scan order
+struct HzRegion {
+    int x0, y0, sw, sh;      // rectangle in the coefficient plane
+    int base;                // scan index of its first cell
+    int level;               // -1 "LL", 0..2
+    int qp, qp_h;            // quantiser (level 2: shifts)
+    int dbx, dby;            // 14-bit fixed point block steps (hzcc.c:196-197)
+};
+struct HzPlane {
+    HzRegion r[10];
+    int nscan;               // total scan cells (sum of sw*sh)
+    int nchunks;             // ceil(nscan / HZ_CHUNK)
+    int w, h;                // coefficient plane dims
+    int nbh;                 // nblocks_h
+    int s_w[3], s_h[3];      // region size at level l (for overlap tests)
+    int pad;
+};
+#define HZ_CHUNK 2048        // scan cells per workgroup in the quantise / emit kernels
+
+struct HzChunkSum {          // written by hz_quant per chunk
+    int nnz;                 // non-zero count
+    int first_pos, last_pos; // scan positions of first / last non-zero (-1 if none)
+    int last_val;            // value of the last non-zero
+    unsigned bits_inner;     // bits of all symbols except the chunk's first one
+    // filled by hz_scan:
+    unsigned long long bit_off; // bit offset of the chunk's first symbol in the plane payload
+    int prev_pos, prev_val;  // last non-zero before this chunk (-1 / 0 if none)
+    int nz_base;             // index of the chunk's first non-zero in the whole plane
+    int pad;
+};
+struct HzPlaneSum {          // written by hz_scan per plane
+    unsigned long long total_bits;
+    unsigned nruns;
+    int dc;
+    int overflow;
+    int last_chunk;          // last chunk holding a non-zero (-1 if the plane is empty)
+};
+
+struct JobDev {              // everything a kernel needs to find one picture job's buffers
+    const uint8_t *src;      // source frame (bordered, extended)
+    const uint8_t *ref;      // reference reconstruction (bordered, extended) or nullptr
+    uint8_t *recon;          // where the extended reconstruction is kept, or nullptr
+    uint8_t *xf;             // work frame: residual in, reconstruction out
+    uint8_t *pred;           // prediction frame ("dif" of dsv_sub_pred)
+    int32_t *coef;           // 3 coefficient planes
+    int32_t *s3, *s1;        // LL3 / LL1 scratch
+    const DMV *mvs;          // device motion field
+    const uint8_t *stable;   // device stable_blocks
+    int32_t *nzpos, *nzval;  // per-plane compact non-zero lists (chunk-local slots)
+    HzChunkSum *chunks;      // per plane chunk summaries (3 * max chunks)
+    HzPlaneSum *psum;        // 3 entries
+    uint8_t *bits;           // packed payload, 3 planes at bits_off[c]
+    size_t bits_off[3], bits_cap[3];
+    size_t nz_off[3];        // offsets of each plane in nzpos/nzval (ints)
+    size_t hz_coef_off[3];   // offsets of each plane in coef (ints)
+    int chunk_off[3];
+    int dec_cnt[3];          // decoder: number of (position,value) pairs per plane
+    HzPlane hz[3];
+    int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level
+    int isP;
+    int quant;
+};
+
+struct SbtGeo {              // per-plane constants for the transform kernels
+    int W, H;                // coefficient dims
+    int ph, pstride;         // pixel rows available / row stride of the pixel plane
+    size_t poff;             // byte offset of pixel (0,0) in a frame
+    size_t coff, s3off, s1off; // int offsets of the plane in coef / s3 / s1
+    int lvls;                // total levels
+    int w3, h3, w1, h1;
+    int pw;                  // pixel plane width (recon store guard)
+};
+
+static __device__ __forceinline__ int d_rdiv2(int v) { return v < 0 ? -((1 - v) >> 1) : (v + 1) >> 1; }
+static __device__ __forceinline__ int d_rdiv4(int v) { return v < 0 ? -((2 - v) >> 2) : (v + 2) >> 2; }
+static __device__ __forceinline__ int d_rdiv8(int v) { return v < 0 ? -((4 - v) >> 3) : (v + 4) >> 3; }
+static __device__ __forceinline__ int d_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+static __device__ __forceinline__ int d_sat8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+// C.3.1.1 LL scaling (sbt.c:20-21): C integer division truncates toward zero -- load-bearing
+static __device__ __forceinline__ int d_ll_down(int x) { return x * 4 / 5; }
+static __device__ __forceinline__ int d_ll_up(int x) { return x * 5 / 4; }

@@ -1,0 +1,45 @@
+// dsvg_kernels.hpp -- launcher prototypes and by-value kernel argument blocks.
+#pragma once
+#include "dsvg_dev.hpp"
+
+#define DSVG_BORDER 64
+
+struct SbtGeo3 { SbtGeo g[3]; };
+
+struct McGeo {
+    int blk_w, blk_h, nbh, nbv, hs, vs;
+    int w[3], h[3], stride[3];
+    size_t off[3];
+    int cw_extra[3];         // coefficient plane one column wider than the pixel plane
+};
+
+struct HmeArgs {
+    FrameLayout L[6];        // level 0 = full frames, level i = pyramid level i
+    const uint8_t *slab[6];
+    const int *cur_slots, *ref_slots;
+    DMV *mvf;                // [pair][level][nblk]
+    unsigned *aux_tex;       // [pair][nblk] block texture (for the high_detail pass)
+    int *aux_var;            // [pair][nblk] centre-window variance
+    int levels, nxb, nyb, nblk, blk_w, blk_h;
+};
+
+// k_sbt.hip
+int  sbt_tail_supported(const SbtGeo &g);
+void sbt_set_func_attributes();
+void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src);
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP);
+// k_hzcc.hip
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks);
+void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count);
+int  hz_scan_items_max();
+// k_bmc.hip
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub);
+// k_frame.hip
+void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n);
+void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);
+void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab);
+void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n);
+void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums);
+void launch_frame_add(hipStream_t st, uint8_t *dst, const FrameLayout &DL, const uint8_t *src, const FrameLayout &SL);
+// k_hme.hip
+void launch_hme(hipStream_t st, const HmeArgs &A, int npairs);

@@ -1,0 +1,560 @@
+// dsvg_pipe.hip -- PIPELINE-LEVEL C ABI: device-resident frames, batched over picture jobs.
+//
+// Everything a GOP batch needs stays in HBM: source frames (bordered reference layout) with their
+// luma pyramids, reconstructions, and per-job work buffers (residual/prediction frames, coefficient
+// planes, LL scratch, non-zero lists, packed payloads).  One call enqueues the whole per-picture
+// kernel chain for njobs pictures on one HIP stream; nothing synchronises until the caller fetches
+// results.  The host only ever sees: MV fields, mean luma, per-plane (DC, nruns, payload bytes).
+#include <stdlib.h>
+#include <algorithm>
+#include "dsvg_host.hpp"
+
+#define OPCHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
+
+struct dsvg_ctx {
+    int device = 0;
+    hipStream_t st = nullptr;
+    int w = 0, h = 0, fmt = 0, bw = 0, bh = 0, nbh = 0, nbv = 0, nblk = 0, levels = 0;
+    FrameLayout L[6];
+    CoefLayout CL;
+    SbtGeo3 G;
+    McGeo MG;
+    int n_src = 0, n_recon = 0, max_jobs = 0;
+    Slab src[6], recon, xf, pred;
+    int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *nzpos = nullptr, *nzval = nullptr;
+    HzChunkSum *chunks = nullptr;
+    HzPlaneSum *psum = nullptr;
+    uint8_t *bits = nullptr;
+    DMV *mvs = nullptr;
+    uint8_t *stable = nullptr;
+    JobDev *jobs_d = nullptr, *jobs_h = nullptr;
+    size_t nz_off[3] = {0, 0, 0}, nz_total = 0;
+    int chunk_off[3] = {0, 0, 0}, chunks_per_job = 0, max_chunks = 0;
+    size_t bits_off[3] = {0, 0, 0}, bits_cap[3] = {0, 0, 0}, bits_per_job = 0;
+    // motion estimation
+    DMV *mvf = nullptr;
+    unsigned *aux_tex = nullptr;
+    int *aux_var = nullptr;
+    int *slots_d = nullptr;          // [3 * max_jobs]: cur, ref, recon tables
+    unsigned *luma_sums = nullptr;   // [n_src]
+    // host pinned staging
+    uint8_t *bits_h = nullptr;
+    HzPlaneSum *psum_h = nullptr;
+    DMV *mv_h = nullptr;
+    uint8_t *stable_h = nullptr;
+    int *slots_h = nullptr;
+    unsigned *luma_h = nullptr;
+    int32_t *dec_h = nullptr;        // decoder: parsed (pos,val) staging
+    uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
+    size_t yuv_stage_bytes = 0;
+    std::vector<uint32_t> dirty;     // bytes of each job/plane payload area that may be non-zero
+    std::vector<int> order;          // device job index -> caller job index of the last batch
+    int last_njobs = 0;
+    Prof prof;
+};
+
+static void ctx_free(dsvg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (int i = 0; i < 6; i++) c->src[i].release();
+    c->recon.release(); c->xf.release(); c->pred.release();
+    void *d[] = {c->coef, c->s3, c->s1, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage};
+    for (void *p : d) if (p) (void)hipFree(p);
+    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h};
+    for (void *p : hh) if (p) (void)hipHostFree(p);
+    if (c->st) (void)hipStreamDestroy(c->st);
+    delete c;
+}
+
+template <typename T> static int dmalloc(T **p, size_t n, bool zero)
+{
+    HIPCHK(hipMalloc((void **)p, n * sizeof(T) + 256));
+    if (zero) HIPCHK(hipMemset(*p, 0, n * sizeof(T) + 256));
+    return DSVG_OK;
+}
+template <typename T> static int hmalloc(T **p, size_t n)
+{
+    HIPCHK(hipHostMalloc((void **)p, n * sizeof(T) + 64, hipHostMallocDefault));
+    memset(*p, 0, n * sizeof(T) + 64);
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsamp,
+                               int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs)
+{
+    if (!out || width < 32 || height < 32 || n_src_slots < 1 || n_recon_slots < 1 || max_jobs < 1) {
+        dsvg_set_error("bad ctx_create arguments");
+        return DSVG_ERR_ARG;
+    }
+    if (subsamp != 0x0 && subsamp != 0x4 && subsamp != 0x5 && subsamp != 0x8) { dsvg_set_error("bad subsampling"); return DSVG_ERR_ARG; }
+    if (dsvg_device_count() <= device) { dsvg_set_error("HIP device %d not present", device); return DSVG_ERR_NODEVICE; }
+    HIPCHK(hipSetDevice(device));
+    dsvg_ctx *c = new dsvg_ctx();
+    *out = nullptr;
+    c->device = device;
+    c->w = width; c->h = height; c->fmt = subsamp;
+    c->n_src = n_src_slots; c->n_recon = n_recon_slots; c->max_jobs = max_jobs;
+    block_geometry(width, height, &c->bw, &c->bh, &c->nbh, &c->nbv);
+    c->nblk = c->nbh * c->nbv;
+    c->levels = pyramid_levels > 0 ? std::min(pyramid_levels, DSVG_MAX_PYRAMID) : auto_pyramid_levels(width, height, c->nbh, c->nbv);
+    make_frame_layout(c->L[0], subsamp, width, height);
+    for (int l = 1; l <= c->levels; l++) make_frame_layout(c->L[l], subsamp, rsu(width, l), rsu(height, l));
+    make_coef_layout(c->CL, subsamp, width, height);
+    const CoefLayout &CL = c->CL;
+    for (int p = 0; p < 3; p++) {
+        make_sbt_geo(c->G.g[p], CL.w[p], CL.h[p], c->L[0].w[p], c->L[0].h[p], c->L[0].stride[p], c->L[0].off[p],
+                     CL.off[p], CL.s3off[p], CL.s1off[p]);
+        if (!sbt_tail_supported(c->G.g[p])) {
+            dsvg_set_error("plane %dx%d: LL3 band does not fit the LDS tail kernel", CL.w[p], CL.h[p]);
+            delete c; return DSVG_ERR_UNSUPPORTED;
+        }
+        if (CL.lvls[p] < 4) { dsvg_set_error("plane too small"); delete c; return DSVG_ERR_UNSUPPORTED; }
+    }
+    if ((width | height) & 1) { dsvg_set_error("odd luma dimensions are not supported (intra B4T needs even planes)"); delete c; return DSVG_ERR_UNSUPPORTED; }
+    McGeo &MG = c->MG;
+    memset(&MG, 0, sizeof(MG));
+    MG.blk_w = c->bw; MG.blk_h = c->bh; MG.nbh = c->nbh; MG.nbv = c->nbv; MG.hs = c->L[0].hs; MG.vs = c->L[0].vs;
+    for (int p = 0; p < 3; p++) {
+        MG.w[p] = c->L[0].w[p]; MG.h[p] = c->L[0].h[p]; MG.stride[p] = c->L[0].stride[p]; MG.off[p] = c->L[0].off[p];
+        MG.cw_extra[p] = CL.w[p] > c->L[0].w[p];
+    }
+    // per-plane scan bookkeeping
+    size_t nzo = 0, bo = 0; int cho = 0;
+    for (int p = 0; p < 3; p++) {
+        HzPlane hp; make_hz_plane(hp, CL.w[p], CL.h[p], 100, 0, p, c->nbh, c->nbv);
+        if (hp.nchunks > hz_scan_items_max()) { dsvg_set_error("plane too large for the scan kernel"); delete c; return DSVG_ERR_UNSUPPORTED; }
+        c->nz_off[p] = nzo; nzo += (size_t)hp.nchunks * HZ_CHUNK;
+        c->chunk_off[p] = cho; cho += hp.nchunks;
+        c->max_chunks = std::max(c->max_chunks, hp.nchunks);
+        c->bits_cap[p] = ((size_t)CL.w[p] * CL.h[p] * 2 + 255) & ~(size_t)255;    // 16 bits/coefficient bound
+        c->bits_off[p] = bo; bo += c->bits_cap[p] + 256;
+    }
+    c->nz_total = nzo; c->chunks_per_job = cho; c->bits_per_job = bo;
+
+    int rc = DSVG_OK;
+    auto fail = [&](int r) { ctx_free(c); return r; };
+    if (hipStreamCreate(&c->st) != hipSuccess) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
+    sbt_set_func_attributes();
+    for (int l = 0; l <= c->levels; l++)
+        if ((rc = c->src[l].alloc(c->L[l].pitch * (size_t)n_src_slots + 4096))) return fail(rc);
+    if ((rc = c->recon.alloc(c->L[0].pitch * (size_t)n_recon_slots + 4096))) return fail(rc);
+    if ((rc = c->xf.alloc(c->L[0].pitch * (size_t)max_jobs + 4096))) return fail(rc);
+    if ((rc = c->pred.alloc(c->L[0].pitch * (size_t)max_jobs + 4096))) return fail(rc);
+    const size_t J = (size_t)max_jobs;
+    if ((rc = dmalloc(&c->coef, CL.total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->s3, CL.s3total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->s1, CL.s1total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->nzpos, c->nz_total * J, false))) return fail(rc);
+    if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
+    if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->psum, 3 * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->bits, c->bits_per_job * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->stable, (size_t)c->nblk * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->jobs_d, J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->mvf, (size_t)(c->levels + 1) * c->nblk * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->aux_tex, (size_t)c->nblk * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->aux_var, (size_t)c->nblk * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->slots_d, 3 * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->luma_sums, (size_t)n_src_slots, true))) return fail(rc);
+    if ((rc = hmalloc(&c->jobs_h, J))) return fail(rc);
+    if ((rc = hmalloc(&c->bits_h, c->bits_per_job * J))) return fail(rc);
+    if ((rc = hmalloc(&c->psum_h, 3 * J))) return fail(rc);
+    if ((rc = hmalloc(&c->mv_h, (size_t)c->nblk * J))) return fail(rc);
+    if ((rc = hmalloc(&c->stable_h, (size_t)c->nblk * J))) return fail(rc);
+    if ((rc = hmalloc(&c->slots_h, 3 * J))) return fail(rc);
+    if ((rc = hmalloc(&c->luma_h, (size_t)n_src_slots))) return fail(rc);
+    c->dirty.assign(3 * J, 0);
+    *out = c;
+    return DSVG_OK;
+}
+
+extern "C" void dsvg_ctx_destroy(dsvg_ctx *ctx) { ctx_free(ctx); }
+
+extern "C" int dsvg_ctx_geom(const dsvg_ctx *c, dsvg_geom *g)
+{
+    if (!c || !g) return DSVG_ERR_ARG;
+    memset(g, 0, sizeof(*g));
+    g->width = c->w; g->height = c->h; g->subsamp = c->fmt;
+    g->blk_w = c->bw; g->blk_h = c->bh; g->nblocks_h = c->nbh; g->nblocks_v = c->nbv;
+    g->pyramid_levels = c->levels;
+    g->frame_bytes = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
+    for (int p = 0; p < 3; p++) g->plane_out_cap[p] = c->bits_cap[p];
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_ctx_sync(dsvg_ctx *c)
+{
+    if (!c) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+extern "C" void *dsvg_ctx_stream(dsvg_ctx *c) { return c ? (void *)c->st : nullptr; }
+
+extern "C" int dsvg_dev_alloc(dsvg_ctx *c, void **dptr, size_t bytes)
+{
+    if (!c || !dptr) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMalloc(dptr, bytes + 256));
+    return DSVG_OK;
+}
+extern "C" int dsvg_dev_free(dsvg_ctx *c, void *dptr)
+{
+    if (!c) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipFree(dptr));
+    return DSVG_OK;
+}
+extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t bytes)
+{
+    if (!c) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+    return DSVG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dsvg_load_frames(dsvg_ctx *c, int first_slot, int n, const void *yuv, int yuv_on_device, int with_pyramid)
+{
+    if (!c || !yuv || n < 1 || first_slot < 0 || first_slot + n > c->n_src) { dsvg_set_error("bad load_frames arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t fb = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
+    const uint8_t *dsrc = (const uint8_t *)yuv;
+    if (!yuv_on_device) {
+        if (c->yuv_stage_bytes < fb * n) {
+            if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
+            HIPCHK(hipMalloc((void **)&c->yuv_stage, fb * n + 256));
+            c->yuv_stage_bytes = fb * n;
+        }
+        HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st));
+        dsrc = c->yuv_stage;
+    }
+    const double samples = (double)fb * n;
+    c->prof.begin(c->st, FAM_FRAME, samples * (with_pyramid ? 3.33 : 2.0));
+    launch_unpack(c->st, dsrc, fb, c->src[0].p, c->L[0], first_slot, n);
+    launch_extend(c->st, c->src[0].p, c->L[0], first_slot, n, 3, nullptr);
+    if (with_pyramid) {
+        for (int l = 1; l <= c->levels; l++) {
+            launch_ds2x(c->st, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n);
+            launch_extend(c->st, c->src[l].p, c->L[l], first_slot, n, 1, nullptr);
+        }
+        HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st));
+        launch_luma_sum(c->st, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums);
+    }
+    c->prof.end(c->st);
+    HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_get_avg_luma(dsvg_ctx *c, int first_slot, int n, int *avg_out)
+{
+    if (!c || !avg_out || first_slot < 0 || first_slot + n > c->n_src) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    const FrameLayout &L = c->L[c->levels];
+    for (int i = 0; i < n; i++) avg_out[i] = (int)c->luma_h[i] / (L.w[0] * L.h[0]);     // frame.c:237
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const int *ref_slots, dsvg_mv *mvs_out)
+{
+    if (!c || npairs < 1 || npairs > c->max_jobs || !cur_slots || !ref_slots || !mvs_out) { dsvg_set_error("bad analyse arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < npairs; i++) {
+        if (cur_slots[i] < 0 || cur_slots[i] >= c->n_src || ref_slots[i] < 0 || ref_slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
+        c->slots_h[i] = cur_slots[i];
+        c->slots_h[c->max_jobs + i] = ref_slots[i];
+    }
+    HIPCHK(hipMemcpyAsync(c->slots_d, c->slots_h, sizeof(int) * 2 * c->max_jobs, hipMemcpyHostToDevice, c->st));
+    const size_t per = (size_t)(c->levels + 1) * c->nblk;
+    HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st));
+    HmeArgs A; memset(&A, 0, sizeof(A));
+    for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
+    A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->max_jobs;
+    A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
+    A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
+    c->prof.begin(c->st, FAM_HME, (double)npairs * c->w * c->h * 2.67);
+    launch_hme(c->st, A, npairs);
+    c->prof.end(c->st);
+    HIPCHK(hipMemcpy2DAsync(c->mv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
+                            (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    memcpy(mvs_out, c->mv_h, (size_t)npairs * c->nblk * sizeof(DMV));
+    return DSVG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant)
+{
+    memset(&jb, 0, sizeof(jb));
+    const CoefLayout &CL = c->CL;
+    jb.xf = c->xf.p + (size_t)t * c->L[0].pitch;
+    jb.pred = c->pred.p + (size_t)t * c->L[0].pitch;
+    jb.coef = c->coef + (size_t)t * CL.total;
+    jb.s3 = c->s3 + (size_t)t * CL.s3total;
+    jb.s1 = c->s1 + (size_t)t * CL.s1total;
+    jb.mvs = c->mvs + (size_t)t * c->nblk;
+    jb.stable = c->stable + (size_t)t * c->nblk;
+    jb.nzpos = c->nzpos + (size_t)t * c->nz_total;
+    jb.nzval = c->nzval + (size_t)t * c->nz_total;
+    jb.chunks = c->chunks + (size_t)t * c->chunks_per_job;
+    jb.psum = c->psum + (size_t)t * 3;
+    jb.bits = c->bits + (size_t)t * c->bits_per_job;
+    for (int p = 0; p < 3; p++) {
+        jb.bits_off[p] = c->bits_off[p]; jb.bits_cap[p] = c->bits_cap[p];
+        jb.nz_off[p] = c->nz_off[p]; jb.hz_coef_off[p] = CL.off[p]; jb.chunk_off[p] = c->chunk_off[p];
+        make_hz_plane(jb.hz[p], CL.w[p], CL.h[p], quant, isP, p, c->nbh, c->nbv);
+    }
+    make_hqp(jb.hqp, quant, isP);
+    jb.isP = isP; jb.quant = quant;
+}
+
+// enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
+// border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
+static int enqueue_recon(dsvg_ctx *c, int nI, int n)
+{
+    const double smp = (double)c->CL.total;
+    if (nI > 0) {
+        c->prof.begin(c->st, FAM_SBT_INV, smp * nI * 5.0);
+        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0);
+        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0);
+        c->prof.end(c->st);
+    }
+    if (n > nI) {
+        c->prof.begin(c->st, FAM_SBT_INV, smp * (n - nI) * 6.0);
+        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 0, 1, 1);
+        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 1, 2, 1);
+        c->prof.end(c->st);
+    }
+    c->prof.begin(c->st, FAM_FRAME, 0.0);
+    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->max_jobs);
+    c->prof.end(c->st);
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jobs)
+{
+    if (!c || !jobs || njobs < 1 || njobs > c->max_jobs) { dsvg_set_error("bad code_pictures arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    // device order: intra jobs first, then inter jobs (kernels are specialised per picture type)
+    c->order.clear();
+    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) c->order.push_back(i);
+    const int nI = (int)c->order.size();
+    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) c->order.push_back(i);
+    c->last_njobs = njobs;
+    HIPCHK(hipStreamSynchronize(c->st));           // pinned staging below is reused between batches
+    for (int t = 0; t < njobs; t++) {
+        const dsvg_pic_job &j = jobs[c->order[t]];
+        const int isP = j.ref_recon_slot >= 0;
+        if (j.src_slot < 0 || j.src_slot >= c->n_src || j.ref_recon_slot >= c->n_recon || j.recon_slot >= c->n_recon ||
+            !j.stable_blocks || (isP && !j.mvs)) { dsvg_set_error("bad picture job %d", c->order[t]); return DSVG_ERR_ARG; }
+        JobDev &jb = c->jobs_h[t];
+        fill_job(c, jb, t, isP, j.quant);
+        jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
+        jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
+        jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;
+        c->slots_h[2 * c->max_jobs + t] = j.recon_slot;
+        memcpy(c->stable_h + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
+        if (isP) memcpy(c->mv_h + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+    }
+    HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->stable, c->stable_h, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->max_jobs, c->slots_h + 2 * c->max_jobs, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++) {
+            uint32_t &d = c->dirty[3 * t + p];
+            if (d) HIPCHK(hipMemsetAsync(c->bits + (size_t)t * c->bits_per_job + c->bits_off[p], 0, std::min<size_t>(d + 16, c->bits_cap[p] + 256), c->st));
+            d = 0;
+        }
+    const double smp = (double)c->CL.total;
+    if (nI > 0) {
+        c->prof.begin(c->st, FAM_SBT_FWD, smp * nI * 5.0);
+        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, 1);
+        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, 1);
+        c->prof.end(c->st);
+    }
+    if (njobs > nI) {
+        const int nP = njobs - nI;
+        c->prof.begin(c->st, FAM_BMC, smp * nP * 4.0);
+        launch_mc(c->st, c->jobs_d + nI, nP, c->MG, 1);
+        c->prof.end(c->st);
+        c->prof.begin(c->st, FAM_SBT_FWD, smp * nP * 5.0);
+        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 0, 1, 1, 0);
+        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 1, 2, 1, 0);
+        c->prof.end(c->st);
+    }
+    c->prof.begin(c->st, FAM_HZCC, smp * njobs * 8.0);
+    launch_hz_encode(c->st, c->jobs_d, njobs, c->max_chunks);
+    c->prof.end(c->st);
+    OPCHK(enqueue_recon(c, nI, njobs));
+    HIPCHK(hipMemcpyAsync(c->psum_h, c->psum, sizeof(HzPlaneSum) * 3 * njobs, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int njobs, dsvg_pic_out *outs)
+{
+    if (!c || !outs || njobs != c->last_njobs) { dsvg_set_error("fetch_pictures does not match the last batch"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++) {
+            const HzPlaneSum &ps = c->psum_h[3 * t + p];
+            if (ps.overflow) { dsvg_set_error("packed plane %d of job %d exceeds %zu bytes", p, c->order[t], c->bits_cap[p]); return DSVG_ERR_OVERFLOW; }
+            const size_t nb = (size_t)((ps.total_bits + 7) >> 3);
+            c->dirty[3 * t + p] = (uint32_t)nb;
+            if (nb) HIPCHK(hipMemcpyAsync(c->bits_h + (size_t)t * c->bits_per_job + c->bits_off[p],
+                                          c->bits + (size_t)t * c->bits_per_job + c->bits_off[p], nb, hipMemcpyDeviceToHost, c->st));
+        }
+    HIPCHK(hipStreamSynchronize(c->st));
+    for (int t = 0; t < njobs; t++) {
+        dsvg_pic_out &o = outs[c->order[t]];
+        for (int p = 0; p < 3; p++) {
+            const HzPlaneSum &ps = c->psum_h[3 * t + p];
+            o.dc[p] = ps.dc; o.nruns[p] = ps.nruns;
+            o.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
+            o.payload[p] = c->bits_h + (size_t)t * c->bits_per_job + c->bits_off[p];
+        }
+    }
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_download_recon(dsvg_ctx *c, int recon_slot, uint8_t *yuv_out)
+{
+    if (!c || !yuv_out || recon_slot < 0 || recon_slot >= c->n_recon) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    const size_t fb = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
+    if (c->yuv_stage_bytes < fb) {
+        if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
+        HIPCHK(hipMalloc((void **)&c->yuv_stage, fb + 256));
+        c->yuv_stage_bytes = fb;
+    }
+    launch_pack(c->st, c->yuv_stage, c->recon.p + (size_t)recon_slot * c->L[0].pitch, c->L[0]);
+    HIPCHK(hipMemcpyAsync(yuv_out, c->yuv_stage, fb, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DSVG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Rd {                          // MSB-first reader (bs.c:111-125,148-157,209-219)
+    const uint8_t *p; unsigned pos;
+    unsigned bit() { unsigned b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u; pos++; return b; }
+    unsigned bits(int n) { unsigned v = 0; while (n--) v = (v << 1) | bit(); return v; }
+    unsigned ueg() { unsigned m = 1; while (!bit()) m = (m << 1) | bit(); return m - 1; }
+    int seg() { int v = (int)ueg(); return (v && bit()) ? -v : v; }
+    int neg() { int v = (int)ueg() + 1; return bit() ? -v : v; }
+    void align() { pos = (pos + 7u) & ~7u; }
+};
+}
+
+extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs)
+{
+    if (!c || !jobs || njobs < 1 || njobs > c->max_jobs) { dsvg_set_error("bad decode_pictures arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    std::vector<int> ord;
+    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) ord.push_back(i);
+    const int nI = (int)ord.size();
+    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) ord.push_back(i);
+    HIPCHK(hipStreamSynchronize(c->st));
+    if (!c->dec_h) OPCHK(hmalloc(&c->dec_h, 2 * c->nz_total * (size_t)c->max_jobs));
+    std::vector<int> cuts((size_t)njobs * 3 * 4, 0);
+    const CoefLayout &CL = c->CL;
+    for (int t = 0; t < njobs; t++) {
+        const dsvg_dec_job &j = jobs[ord[t]];
+        const int isP = j.ref_recon_slot >= 0;
+        if (j.recon_slot < 0 || j.recon_slot >= c->n_recon || j.ref_recon_slot >= c->n_recon || !j.stable_blocks || (isP && !j.mvs)) {
+            dsvg_set_error("bad decode job %d", ord[t]); return DSVG_ERR_ARG;
+        }
+        JobDev &jb = c->jobs_h[t];
+        fill_job(c, jb, t, isP, j.quant);
+        jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
+        jb.recon = c->recon.p + (size_t)j.recon_slot * c->L[0].pitch;
+        c->slots_h[2 * c->max_jobs + t] = j.recon_slot;
+        memcpy(c->stable_h + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
+        if (isP) memcpy(c->mv_h + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+        for (int p = 0; p < 3; p++) {
+            // entropy parse on the host (hzcc_dec hzcc.c:295-435) -> (scan position, value) pairs
+            int32_t *pos = c->dec_h + ((size_t)t * 2) * c->nz_total + c->nz_off[p];
+            int32_t *val = c->dec_h + ((size_t)t * 2 + 1) * c->nz_total + c->nz_off[p];
+            const HzPlane &hp = jb.hz[p];
+            Rd rd{j.plane_data[p], 0};
+            int n = 0;
+            pos[n] = 0; val[n] = rd.seg(); n++;           // unquantised DC rides along as entry 0
+            rd.align();
+            int runs = (int)rd.bits(32);
+            rd.align();
+            if (runs-- > 0) {
+                long q = (long)rd.ueg();
+                while (q < hp.nscan) {
+                    long nextrun = -1;
+                    if (runs-- > 0) nextrun = (long)rd.ueg();
+                    const int v = rd.neg();
+                    if ((rd.pos >> 3) >= j.plane_len[p]) break;
+                    pos[n] = (int32_t)q; val[n] = v; n++;
+                    if (nextrun < 0) break;
+                    q += 1 + nextrun;
+                }
+            }
+            jb.dec_cnt[p] = n;
+            int *cut = &cuts[((size_t)t * 3 + p) * 4];
+            cut[0] = 0; cut[1] = cut[2] = cut[3] = n;
+            for (int i = n - 1; i >= 0; i--) {
+                if (pos[i] >= hp.r[7].base) cut[2] = i;
+                if (pos[i] >= hp.r[4].base) cut[1] = i;
+            }
+            if (cut[1] > cut[2]) cut[1] = cut[2];
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->stable, c->stable_h, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->max_jobs, c->slots_h + 2 * c->max_jobs, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemsetAsync(c->coef, 0, CL.total * (size_t)njobs * sizeof(int32_t), c->st));
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++) {
+            const int n = c->jobs_h[t].dec_cnt[p];
+            const int32_t *pos = c->dec_h + ((size_t)t * 2) * c->nz_total + c->nz_off[p];
+            const int32_t *val = c->dec_h + ((size_t)t * 2 + 1) * c->nz_total + c->nz_off[p];
+            HIPCHK(hipMemcpyAsync(c->nzpos + (size_t)t * c->nz_total + c->nz_off[p], pos, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
+            HIPCHK(hipMemcpyAsync(c->nzval + (size_t)t * c->nz_total + c->nz_off[p], val, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
+        }
+    c->prof.begin(c->st, FAM_HZCC, 0.0);
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++) {
+            const int *cut = &cuts[((size_t)t * 3 + p) * 4];
+            for (int ph = 0; ph < 3; ph++) launch_hz_scatter(c->st, c->jobs_d + t, 1, p, cut[ph], cut[ph + 1] - cut[ph]);
+        }
+    c->prof.end(c->st);
+    if (njobs > nI) {
+        c->prof.begin(c->st, FAM_BMC, (double)CL.total * (njobs - nI) * 2.0);
+        launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0);
+        c->prof.end(c->st);
+    }
+    OPCHK(enqueue_recon(c, nI, njobs));
+    HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+extern "C" int dsvg_prof_enable(dsvg_ctx *c, int on) { if (!c) return DSVG_ERR_ARG; c->prof.on = on != 0; return DSVG_OK; }
+extern "C" int dsvg_prof_reset(dsvg_ctx *c) { if (!c) return DSVG_ERR_ARG; c->prof.reset(); return DSVG_OK; }
+extern "C" int dsvg_prof_get(dsvg_ctx *c, const char *family, double *ms, long *launches, double *alg_bytes)
+{
+    if (!c || !family) return DSVG_ERR_ARG;
+    const int f = prof_family(family);
+    if (f < 0) { dsvg_set_error("unknown kernel family %s", family); return DSVG_ERR_ARG; }
+    c->prof.collect();
+    if (ms) *ms = c->prof.ms[f];
+    if (launches) *launches = c->prof.launches[f];
+    if (alg_bytes) *alg_bytes = c->prof.bytes[f];
+    return DSVG_OK;
+}

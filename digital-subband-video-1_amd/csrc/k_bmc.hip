@@ -1,0 +1,157 @@
+// k_bmc.hip -- half-pel block motion compensation for gfx950 (MI355X).  HBM-bound byte work.
+//
+// Replaces compensate (bmc.c:204-302) with hpelL (bmc.c:124-174) / hpel (bmc.c:58-110) / avgval
+// (bmc.c:176-189), fused with subf (bmc.c:43-55): one workgroup per (block, plane, job) stages the
+// (cw+3)x(ch+3) reference window in LDS with aligned dword loads, every thread then produces 4
+// adjacent prediction pixels (one 32-bit coalesced store to the prediction frame and, for the
+// encoder, one to the residual frame:  res = clamp(src - pred + 128)).
+//   luma  : 4-tap (-1,9,9,-1): V / H rounded (+8)>>4, HV = H taps unrounded then V taps, (+128)>>8
+//   chroma: bilinear (a+b+1)>>1, (a+b+c+d+2)>>2
+//   intra : (sub-)block mean of the co-located reference pixels, truncating division
+// Reads reach one pixel beyond the 64-px border exactly like the reference (same frame layout).
+#include "dsvg_dev.hpp"
+#include "dsvg_kernels.hpp"
+
+#define WPITCH 72                       // LDS row pitch in bytes (>= 64+3+3 alignment slack), multiple of 4
+#define WROWS 68
+
+static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
+
+__global__ __launch_bounds__(256) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub)
+{
+    __shared__ __align__(16) uint8_t win[WROWS * WPITCH];
+    __shared__ int s_sum[5];
+    const int blk = blockIdx.x, c = blockIdx.y, job = blockIdx.z;
+    const JobDev &jb = jobs[job];
+    const int tid = threadIdx.x;
+    const int sh = c ? G.hs : 0, sv = c ? G.vs : 0;
+    const int bw = G.blk_w >> sh, bh = G.blk_h >> sv;
+    const int pw = G.w[c], ph = G.h[c], stride = G.stride[c];
+    const int bi = blk % G.nbh, bj = blk / G.nbh;
+    const int x = bi * bw, y = bj * bh;
+    if (x >= pw || y >= ph) return;
+    const int cw = (x + bw >= pw) ? pw - x : bw;
+    const int ch = (y + bh >= ph) ? ph - y : bh;
+    const DMV mv = jb.mvs[blk];
+    const uint8_t *rp = jb.ref + G.off[c];
+
+    int wx, wy, xh = 0, yh = 0;                 // window origin = (wx-1, wy-1)
+    if (mv.mode == 0) {
+        const int dx = mv.x >> sh, dy = mv.y >> sv;
+        wx = d_clamp(x + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1);
+        wy = d_clamp(y + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1);
+        xh = dx & 1; yh = dy & 1;
+    } else {
+        wx = x; wy = y;
+    }
+    // stage rows wy-1 .. wy+ch+1, columns wx-1 .. wx+cw+1 with aligned dword loads
+    const long rowbase = (long)(wy - 1) * stride + (wx - 1);
+    const uint8_t *g0 = rp + rowbase;
+    const int mis = (int)(((uintptr_t)g0) & 3);           // same for every row (stride % 4 == 0)
+    const int ndw = (mis + cw + 3 + 3) >> 2;
+    for (int i = tid; i < (ch + 3) * ndw; i += 256) {
+        const int r = i / ndw, d = i - r * ndw;
+        const unsigned v = *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
+        *reinterpret_cast<unsigned *>(win + r * WPITCH + 4 * d) = v;
+    }
+    if (tid < 5) s_sum[tid] = 0;
+    __syncthreads();
+    // win[(r)*WPITCH + mis + k] = ref(wx-1+k, wy-1+r)
+    const uint8_t *w0 = win + mis + WPITCH + 1;           // -> ref(wx, wy)
+
+    const int qw = cw / 2, qh = ch / 2;
+    int mean_full = 0, mean_q[4] = {0, 0, 0, 0};
+    if (mv.mode != 0) {
+        int acc[5] = {0, 0, 0, 0, 0};
+        for (int p = tid; p < cw * ch; p += 256) {
+            const int yy = p / cw, xx = p - yy * cw;
+            const int v = w0[yy * WPITCH + xx];
+            acc[4] += v;
+            if (xx < 2 * qw && yy < 2 * qh) acc[(xx >= qw) + 2 * (yy >= qh)] += v;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+            int a = acc[k];
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o);
+            if ((tid & 63) == 0) atomicAdd(&s_sum[k], a);
+        }
+        __syncthreads();
+        mean_full = s_sum[4] / (cw * ch);
+        if (qw > 0 && qh > 0) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) mean_q[k] = s_sum[k] / (qw * qh);
+        }
+    }
+
+    uint8_t *pp = jb.pred + G.off[c];
+    uint8_t *xp = jb.xf + G.off[c];
+    const uint8_t *sp = jb.src + G.off[c];
+    const int nq = (cw + 3) >> 2;
+    for (int it = tid; it < nq * ch; it += 256) {
+        const int yy = it / nq, x4 = 4 * (it - yy * nq);
+        int pv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xx = x4 + k;
+            const uint8_t *p = w0 + yy * WPITCH + xx;
+            int v;
+            if (mv.mode == 0) {
+                if (c == 0) {
+                    if (!xh && !yh) v = p[0];
+                    else if (!xh) v = d_sat8((tap4(p[-WPITCH], p[0], p[WPITCH], p[2 * WPITCH]) + 8) >> 4);
+                    else if (!yh) v = d_sat8((tap4(p[-1], p[0], p[1], p[2]) + 8) >> 4);
+                    else {
+                        const int hm = tap4(p[-WPITCH - 1], p[-WPITCH], p[-WPITCH + 1], p[-WPITCH + 2]);
+                        const int h0 = tap4(p[-1], p[0], p[1], p[2]);
+                        const int h1 = tap4(p[WPITCH - 1], p[WPITCH], p[WPITCH + 1], p[WPITCH + 2]);
+                        const int h2 = tap4(p[2 * WPITCH - 1], p[2 * WPITCH], p[2 * WPITCH + 1], p[2 * WPITCH + 2]);
+                        v = d_sat8((tap4(hm, h0, h1, h2) + 128) >> 8);
+                    }
+                } else {
+                    if (!xh && !yh) v = p[0];
+                    else if (!xh) v = (p[0] + p[WPITCH] + 1) >> 1;
+                    else if (!yh) v = (p[0] + p[1] + 1) >> 1;
+                    else v = (p[0] + p[1] + p[WPITCH] + p[WPITCH + 1] + 2) >> 2;
+                }
+            } else if (mv.submask == 0xF) {
+                v = mean_full;
+            } else if (xx < 2 * qw && yy < 2 * qh) {
+                const int q = (xx >= qw) + 2 * (yy >= qh);
+                v = (mv.submask & (1 << q)) ? mean_q[q] : p[0];
+            } else {
+                v = 0;                           // odd-sized edge blocks: untouched (zeroed) in the reference
+            }
+            pv[k] = v & 0xff;
+        }
+        const size_t o = (size_t)(y + yy) * stride + x + x4;
+        if (x4 + 4 <= cw) {
+            const unsigned pk = (unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24);
+            *reinterpret_cast<unsigned *>(pp + o) = pk;
+            if (do_sub) {
+                const unsigned s = *reinterpret_cast<const unsigned *>(sp + o);
+                unsigned r = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    r |= (unsigned)d_sat8((int)((s >> (8 * k)) & 0xff) - pv[k] + 128) << (8 * k);
+                *reinterpret_cast<unsigned *>(xp + o) = r;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (x4 + k < cw) {
+                    pp[o + k] = (uint8_t)pv[k];
+                    if (do_sub) xp[o + k] = (uint8_t)d_sat8((int)sp[o + k] - pv[k] + 128);
+                }
+        }
+        // odd plane width whose coefficient plane is one wider: the transform reads column pw of the
+        // residual frame, which in the reference still holds the replicated source edge (frame.c:199-221)
+        if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
+            xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * stride + pw - 1];
+    }
+}
+
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub)
+{
+    hipLaunchKernelGGL(k_mc, dim3(G.nbh * G.nbv, 3, njobs), dim3(256), 0, st, jobs, G, do_sub);
+}

@@ -1,0 +1,170 @@
+// k_frame.hip -- frame plumbing kernels for gfx950: planar -> bordered layout, border replication,
+// 2x luma box downsample for the motion pyramid, mean luma.  Pure HBM streaming.
+//
+// Replaces dsv_frame_copy/dsv_clone_frame (frame.c:166-221), dsv_extend_frame(_luma)
+// (frame.c:263-327), dsv_ds2x_frame_luma (frame.c:240-261), dsv_frame_avg_luma (frame.c:223-238).
+#include "dsvg_dev.hpp"
+#include "dsvg_kernels.hpp"
+
+// tightly packed planar frames -> interiors of bordered frames (grid.y = plane, grid.z = frame)
+__global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv, size_t yuv_pitch,
+                                                uint8_t *__restrict__ slab, FrameLayout L, int first_slot)
+{
+    const int c = blockIdx.y, f = blockIdx.z;
+    const int w = L.w[c], h = L.h[c];
+    size_t poff = 0;
+    for (int k = 0; k < c; k++) poff += (size_t)L.w[k] * L.h[k];
+    const uint8_t *src = yuv + (size_t)f * yuv_pitch + poff;
+    uint8_t *dst = slab + (size_t)(first_slot + f) * L.pitch + L.off[c];
+    const bool vec = ((w & 15) == 0) && ((((uintptr_t)src) & 15) == 0);
+    if (vec) {
+        const int nv = w >> 4;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nv * h; i += gridDim.x * 256) {
+            const int y = i / nv, x = i - y * nv;
+            reinterpret_cast<uint4 *>(dst + (size_t)y * L.stride[c])[x] =
+                reinterpret_cast<const uint4 *>(src + (size_t)y * w)[x];
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+            const int y = i / w, x = i - y * w;
+            dst[(size_t)y * L.stride[c] + x] = src[(size_t)y * w + x];
+        }
+    }
+}
+
+// bordered interiors -> tightly packed planar (download path)
+__global__ __launch_bounds__(256) void k_pack(uint8_t *__restrict__ yuv, const uint8_t *__restrict__ frame, FrameLayout L)
+{
+    const int c = blockIdx.y;
+    const int w = L.w[c], h = L.h[c];
+    size_t poff = 0;
+    for (int k = 0; k < c; k++) poff += (size_t)L.w[k] * L.h[k];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int y = i / w, x = i - y * w;
+        yuv[poff + (size_t)y * w + x] = frame[L.off[c] + (size_t)y * L.stride[c] + x];
+    }
+}
+
+// border replication of planes [0, nplanes) of frames [first, first+n): every border byte is the
+// nearest interior pixel (identical to the row memsets + row copies of frame.c:278-292)
+__global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, FrameLayout L, int first, int nplanes,
+                                                const int *__restrict__ slot_tab)
+{
+    const int c = blockIdx.y;
+    if (c >= nplanes) return;
+    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
+    if (f < 0) return;
+    const int w = L.w[c], h = L.h[c], s = L.stride[c];
+    uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
+    const int B = DSVG_BORDER;
+    // part 1: left + right borders of all h+2B rows (2B bytes per row), one byte per thread-iteration x4
+    const int n1 = (h + 2 * B) * (2 * B);
+    // part 2: top + bottom B rows over the interior columns
+    const int n2 = 2 * B * w;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += gridDim.x * 256) {
+        int x, y;
+        if (i < n1) {
+            const int r = i / (2 * B), k = i - r * (2 * B);
+            y = r - B;
+            x = k < B ? k - B : w + (k - B);
+        } else {
+            const int j = i - n1;
+            const int r = j / w;
+            x = j - r * w;
+            y = r < B ? r - B : h + (r - B);
+        }
+        const int sx = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
+        const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+        p[(long)y * s + x] = p[(long)sy * s + sx];
+    }
+}
+
+// 2x2 box downsample of the luma plane: (p1+p2+p3+p4+2)>>2 (frame.c:240-261)
+__global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab, FrameLayout SL,
+                                              uint8_t *__restrict__ dslab, FrameLayout DL, int first)
+{
+    const int f = first + blockIdx.z;
+    const uint8_t *sp = sslab + (size_t)f * SL.pitch + SL.off[0];
+    uint8_t *dp = dslab + (size_t)f * DL.pitch + DL.off[0];
+    const int dw = DL.w[0], dh = DL.h[0];
+    const int nq = (dw + 3) >> 2;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < nq * dh; i += gridDim.x * 256) {
+        const int y = i / nq, x4 = 4 * (i - y * nq);
+        const uint8_t *a = sp + (size_t)(2 * y) * SL.stride[0] + 2 * x4;
+        const uint2 r0 = *reinterpret_cast<const uint2 *>(a);
+        const uint2 r1 = *reinterpret_cast<const uint2 *>(a + SL.stride[0]);
+        unsigned out = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned w0 = k < 2 ? r0.x : r0.y, w1 = k < 2 ? r1.x : r1.y;
+            const int shf = 16 * (k & 1);
+            const int v = (int)((w0 >> shf) & 0xff) + (int)((w0 >> (shf + 8)) & 0xff) +
+                          (int)((w1 >> shf) & 0xff) + (int)((w1 >> (shf + 8)) & 0xff);
+            out |= (unsigned)((v + 2) >> 2) << (8 * k);
+        }
+        uint8_t *d = dp + (size_t)y * DL.stride[0] + x4;
+        if (x4 + 4 <= dw) *reinterpret_cast<unsigned *>(d) = out;
+        else
+            for (int k = 0; k < 4; k++)
+                if (x4 + k < dw) d[k] = (uint8_t)(out >> (8 * k));
+    }
+}
+
+// sum of the luma plane of frames [first, first+n) -> sums[first+f] (host divides, frame.c:237)
+__global__ __launch_bounds__(256) void k_luma_sum(const uint8_t *__restrict__ slab, FrameLayout L, int first,
+                                                  unsigned *__restrict__ sums)
+{
+    const int f = first + blockIdx.z;
+    const uint8_t *p = slab + (size_t)f * L.pitch + L.off[0];
+    const int w = L.w[0], h = L.h[0];
+    unsigned acc = 0;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int y = i / w, x = i - y * w;
+        acc += p[(size_t)y * L.stride[0] + x];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0 && acc) atomicAdd(&sums[f], acc);
+}
+
+// dst = clamp(dst + src - 128) over the plane interiors (dsv_frame_add / addf bmc.c:29-41,304-316)
+__global__ __launch_bounds__(256) void k_frame_add(uint8_t *__restrict__ dst, FrameLayout DL,
+                                                   const uint8_t *__restrict__ src, FrameLayout SL)
+{
+    const int c = blockIdx.y;
+    const int w = DL.w[c], h = DL.h[c];
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+        const int y = i / w, x = i - y * w;
+        uint8_t *d = dst + DL.off[c] + (size_t)y * DL.stride[c] + x;
+        const int v = (int)*d + (int)src[SL.off[c] + (size_t)y * SL.stride[c] + x] - 128;
+        *d = (uint8_t)d_sat8(v);
+    }
+}
+
+static inline int nblk(long items, int cap) { long b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
+
+void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n)
+{
+    hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first);
+}
+void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)
+{
+    hipLaunchKernelGGL(k_pack, dim3(nblk((long)L.w[0] * L.h[0], 1024), 3, 1), dim3(256), 0, st, yuv, frame, L);
+}
+void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab)
+{
+    const long items = (long)(L.h[0] + 128) * 128 + 128L * L.w[0];
+    hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
+}
+void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n)
+{
+    hipLaunchKernelGGL(k_ds2x, dim3(nblk((long)DL.w[0] * DL.h[0] / 4, 512), 1, n), dim3(256), 0, st, sslab, SL, dslab, DL, first);
+}
+void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums)
+{
+    hipLaunchKernelGGL(k_luma_sum, dim3(nblk((long)L.w[0] * L.h[0], 64), 1, n), dim3(256), 0, st, slab, L, first, sums);
+}
+void launch_frame_add(hipStream_t st, uint8_t *dst, const FrameLayout &DL, const uint8_t *src, const FrameLayout &SL)
+{
+    hipLaunchKernelGGL(k_frame_add, dim3(nblk((long)DL.w[0] * DL.h[0], 1024), 3, 1), dim3(256), 0, st, dst, DL, src, SL);
+}

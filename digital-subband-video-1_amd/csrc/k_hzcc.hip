@@ -1,0 +1,452 @@
+// k_hzcc.hip -- adaptive dead-zone quantisation + interleaved exp-Golomb coefficient packing for
+// gfx950 (MI355X).  Integer / bit work, HBM-bound on the coefficient plane; no MFMA.
+//
+// Replaces hzcc_enc (hzcc.c:137-293) + the bit writer it drives (bs.c:105-206) and the scatter half
+// of hzcc_dec (hzcc.c:295-435).  The sequential coder
+//     for cell in scan order: if v != 0: UEG(run); NEG(previous non-zero); ...; final NEG(last)
+// is parallelised as
+//   k_hz_quant  one workgroup per 2048 scan cells: quantise, write the DEQUANTISED value back in
+//               place (hzcc.c:172-184), compact the non-zeros in scan order with wave ballots, and
+//               sum the bit lengths of every symbol whose predecessor lies in the same chunk
+//   k_hz_scan   one workgroup per plane: carries (position,value) of the last non-zero across
+//               chunks (max-scan), adds each chunk's first-symbol length, prefix-sums bit offsets
+//   k_hz_emit   one workgroup per chunk: builds each <=92-bit symbol (UEG spread via bit
+//               interleave) and ORs it MSB-first into the zeroed payload (atomicOr on 32-bit words)
+// Scan regions can overlap for some plane sizes (960x540: SURVEY.md Q7); a cell seen by two
+// regions is processed twice exactly like the sequential reference: the later region quantises
+// the earlier region's dequantised value and owns the final store.
+#include "dsvg_dev.hpp"
+#include "dsvg_kernels.hpp"
+
+#define MINQ 16
+
+static __device__ __forceinline__ int q_lo(int v, int q)            // quant hzcc.c:94-112
+{
+    int m = (v < 0 ? -v : v) << 1;
+    if (m <= q) return 0;
+    m = (m + 1) / (q << 1);
+    return v < 0 ? -m : m;
+}
+static __device__ __forceinline__ int dq_lo(int v, int q)           // dequant hzcc.c:121-128
+{
+    return v < 0 ? -((-v * (q << 1) + q) >> 1) : (v * (q << 1) + q) >> 1;
+}
+static __device__ __forceinline__ int q_hi(int v, int sh) { return v < 0 ? -((-v) >> sh) : v >> sh; }
+static __device__ __forceinline__ int dq_hi(int v, int sh) { return (int)((unsigned)v << sh); }
+
+static __device__ __forceinline__ int len_ueg(unsigned v) { return 2 * (31 - __clz((int)(v + 1))) + 1; }
+static __device__ __forceinline__ int len_neg(int v) { return len_ueg((unsigned)(v < 0 ? -v : v) - 1u) + 1; }
+
+// quantiser for cell (x,y) of region r (tmq4pos hzcc.c:64-74, highest level hzcc.c:221-224)
+static __device__ __forceinline__ int cell_tq(const HzRegion &r, const uint8_t *__restrict__ stable, int nbh, int x, int y)
+{
+    if (r.level < 0) return r.qp;
+    const int flag = stable[((y * r.dby) >> 14) * nbh + ((x * r.dbx) >> 14)];
+    if (r.level == 2) return flag ? r.qp_h : r.qp;
+    const int t = (flag & 2) ? r.qp >> 2 : (flag ? r.qp >> 1 : r.qp);
+    return t < MINQ ? MINQ : t;
+}
+static __device__ __forceinline__ int quant_any(const HzRegion &r, int v, int tq)
+{
+    return r.level == 2 ? q_hi(v, tq) : q_lo(v, tq);
+}
+static __device__ __forceinline__ int dequant_any(const HzRegion &r, int v, int tq)
+{
+    return r.level == 2 ? dq_hi(v, tq) : dq_lo(v, tq);
+}
+
+static __device__ __forceinline__ int find_region(const HzPlane &hp, int p)
+{
+    int r = 0;
+#pragma unroll
+    for (int i = 1; i < 10; i++) r += (p >= hp.r[i].base) ? 1 : 0;
+    return r;
+}
+
+// -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ jobs)
+{
+    __shared__ int s_pos[HZ_CHUNK];
+    __shared__ int s_val[HZ_CHUNK];
+    __shared__ int s_wcnt[4];
+    __shared__ unsigned s_bits;
+    const int job = blockIdx.z, c = blockIdx.y, chunk = blockIdx.x;
+    const JobDev &jb = jobs[job];
+    const HzPlane &hp = jb.hz[c];
+    if (chunk >= hp.nchunks) return;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *plane = jb.coef + jb.hz_coef_off[c];
+    const uint8_t *stable = jb.stable;
+    const int W = hp.w;
+    if (tid == 0) s_bits = 0;
+
+    // each wave owns 512 consecutive scan cells -> 8 rounds of 64
+    const int wbase = chunk * HZ_CHUNK + wv * 512;
+    int wcount = 0;
+#pragma unroll 1
+    for (int k = 0; k < 8; k++) {
+        const int p = wbase + k * 64 + lane;
+        int v = 0;
+        if (p < hp.nscan) {
+            const int ri = find_region(hp, p);
+            const HzRegion r = hp.r[ri];
+            const int local = p - r.base;
+            const int y = local / r.sw, x = local - y * r.sw;
+            const int gx = r.x0 + x, gy = r.y0 + y;
+            if (p == 0) {
+                jb.psum[c].dc = plane[0];             // DC travels separately (hzcc.c:161,457-460)
+            } else {
+                int cv = plane[(size_t)gy * W + gx];
+                const int l = r.level;
+                // Cells covered by two regions are processed twice by the sequential reference.
+                // Both passes only READ the original value here (each emits its own symbol); the final
+                // value is stored by hz_fix_overlaps() in the next kernel, so there is no in-place race.
+                bool shared_cell = false;
+                if (l >= 1 && gx < 2 * hp.s_w[l - 1] && gy < 2 * hp.s_h[l - 1]) {
+                    const int rx = gx >= hp.s_w[l - 1], ry = gy >= hp.s_h[l - 1];
+                    if (rx + ry) {              // the previous level's pass ran first on this cell
+                        const HzRegion e = hp.r[1 + 3 * (l - 1) + (rx + 2 * ry) - 1];
+                        const int etq = cell_tq(e, stable, hp.nbh, gx - e.x0, gy - e.y0);
+                        const int ev = quant_any(e, cv, etq);
+                        cv = ev ? dequant_any(e, ev, etq) : 0;
+                        shared_cell = true;
+                    }
+                }
+                if (l >= 0 && l <= 1 && (gx >= hp.s_w[l + 1] || gy >= hp.s_h[l + 1])) shared_cell = true;
+                const int tq = cell_tq(r, stable, hp.nbh, x, y);
+                v = quant_any(r, cv, tq);
+                if (!shared_cell) plane[(size_t)gy * W + gx] = v ? dequant_any(r, v, tq) : 0;
+            }
+        }
+        const unsigned long long m = __ballot(v != 0);
+        if (v != 0) {
+            const int rank = wcount + __popcll(m & ((1ull << lane) - 1ull));
+            s_pos[wv * 512 + rank] = p;
+            s_val[wv * 512 + rank] = v;
+        }
+        wcount += __popcll(m);
+    }
+    if (lane == 0) s_wcnt[wv] = wcount;
+    __syncthreads();
+
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int n = s_wcnt[i];
+        if (i < wv) woff += n;
+        total += n;
+    }
+    // copy this wave's segment to the plane's chunk slot and add up the in-chunk symbol lengths
+    int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    unsigned bits = 0;
+    for (int j = lane; j < wcount; j += 64) {
+        const int pos = s_pos[wv * 512 + j], val = s_val[wv * 512 + j];
+        const int gr = woff + j;
+        gpos[gr] = pos;
+        gval[gr] = val;
+        if (gr > 0) {
+            int ppos, pval;
+            if (j > 0) {
+                ppos = s_pos[wv * 512 + j - 1];
+                pval = s_val[wv * 512 + j - 1];
+            } else {                                   // predecessor = last entry of the nearest non-empty wave
+                int pw = wv - 1;
+                while (s_wcnt[pw] == 0) pw--;
+                ppos = s_pos[pw * 512 + s_wcnt[pw] - 1];
+                pval = s_val[pw * 512 + s_wcnt[pw] - 1];
+            }
+            bits += (unsigned)(len_ueg((unsigned)(pos - ppos - 1)) + len_neg(pval));
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o);
+    if (lane == 0 && bits) atomicAdd(&s_bits, bits);
+    __syncthreads();
+    if (tid == 0) {
+        HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
+        cs.nnz = total;
+        cs.bits_inner = s_bits;
+        int fw = 0, lw = 3;
+        while (fw < 4 && s_wcnt[fw] == 0) fw++;
+        while (lw >= 0 && s_wcnt[lw] == 0) lw--;
+        cs.first_pos = total ? s_pos[fw * 512] : -1;
+        cs.last_pos = total ? s_pos[lw * 512 + s_wcnt[lw] - 1] : -1;
+        cs.last_val = total ? s_val[lw * 512 + s_wcnt[lw] - 1] : 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// block-wide inclusive scans over 1024 threads (16 waves)
+template <typename T, typename Op>
+static __device__ __forceinline__ T block_scan_incl(T v, T identity, Op op, T *s_w /*[16]*/)
+{
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const T n = __shfl_up(v, o);
+        if (lane >= o) v = op(v, n);
+    }
+    __syncthreads();
+    if (lane == 63) s_w[wv] = v;
+    __syncthreads();
+    T pre = identity;
+    for (int i = 0; i < wv; i++) pre = op(pre, s_w[i]);
+    return op(pre, v);
+}
+struct OpAddU64 { __device__ unsigned long long operator()(unsigned long long a, unsigned long long b) const { return a + b; } };
+struct OpAddI   { __device__ int operator()(int a, int b) const { return a + b; } };
+struct OpMaxI   { __device__ int operator()(int a, int b) const { return a > b ? a : b; } };
+
+// final value of every cell shared by two scan regions: quantise/dequantise with the earlier
+// region's rule, then with the later region's (hzcc.c:172-184 applied twice in scan order)
+static __device__ void hz_fix_overlaps(const JobDev &jb, const HzPlane &hp, int c, int nthreads)
+{
+    int32_t *plane = jb.coef + jb.hz_coef_off[c];
+    for (int l = 0; l < 2; l++) {
+        const int cw = 2 * hp.s_w[l], ch = 2 * hp.s_h[l];        // extent covered up to level l
+        const bool col = cw > hp.s_w[l + 1], row = ch > hp.s_h[l + 1];
+        const int ncol = col ? ch : 0, nrow = row ? cw : 0;
+        for (int i = threadIdx.x; i < ncol + nrow; i += nthreads) {
+            int gx, gy;
+            if (i < ncol) { gx = hp.s_w[l + 1]; gy = i; }
+            else {
+                gx = i - ncol; gy = hp.s_h[l + 1];
+                if (col && gx == hp.s_w[l + 1]) continue;          // corner already handled by the column
+            }
+            const int ex = gx >= hp.s_w[l], ey = gy >= hp.s_h[l];
+            if (!(ex + ey)) continue;
+            const HzRegion e = hp.r[1 + 3 * l + (ex + 2 * ey) - 1];
+            const int lx = gx >= hp.s_w[l + 1], ly = gy >= hp.s_h[l + 1];
+            const HzRegion r = hp.r[1 + 3 * (l + 1) + (lx + 2 * ly) - 1];
+            int v = plane[(size_t)gy * hp.w + gx];
+            const int etq = cell_tq(e, jb.stable, hp.nbh, gx - e.x0, gy - e.y0);
+            const int ev = quant_any(e, v, etq);
+            v = ev ? dequant_any(e, ev, etq) : 0;
+            const int tq = cell_tq(r, jb.stable, hp.nbh, gx - r.x0, gy - r.y0);
+            const int rv = quant_any(r, v, tq);
+            plane[(size_t)gy * hp.w + gx] = rv ? dequant_any(r, rv, tq) : 0;
+        }
+    }
+}
+
+#define SCAN_THREADS 1024
+#define SCAN_ITEMS 8            // chunks per thread (<= 8192 chunks = 16.7 M scan cells per plane)
+
+__global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restrict__ jobs)
+{
+    __shared__ unsigned long long s_u64[16];
+    __shared__ int s_i[16];
+    const int job = blockIdx.y, c = blockIdx.x;
+    const JobDev &jb = jobs[job];
+    const HzPlane &hp = jb.hz[c];
+    HzChunkSum *cs = jb.chunks + jb.chunk_off[c];
+    const int n = hp.nchunks;
+    if (n > 0) hz_fix_overlaps(jb, hp, c, SCAN_THREADS);
+    const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;     // host guarantees per <= SCAN_ITEMS
+    const int first = threadIdx.x * per;
+
+    // pass 1: index of the last non-empty chunk at or before each chunk (max-scan), nnz prefix
+    int lastne = -1, nnzsum = 0;
+    for (int i = 0; i < per; i++) {
+        const int ch = first + i;
+        if (ch < n) {
+            const int z = cs[ch].nnz;
+            if (z > 0) lastne = ch;
+            nnzsum += z;
+        }
+    }
+    const int incl_ne = block_scan_incl<int>(lastne, -1, OpMaxI(), s_i);
+    // exclusive: last non-empty chunk strictly before this thread's first chunk
+    int carry_ne = __shfl_up(incl_ne, 1);
+    if ((threadIdx.x & 63) == 0) carry_ne = -1;                // fixed below through shared memory
+    __syncthreads();
+    __shared__ int s_incl_ne[SCAN_THREADS];
+    s_incl_ne[threadIdx.x] = incl_ne;
+    __syncthreads();
+    carry_ne = threadIdx.x ? s_incl_ne[threadIdx.x - 1] : -1;
+
+    const int incl_nnz = block_scan_incl<int>(nnzsum, 0, OpAddI(), s_i);
+    int nzbase = incl_nnz - nnzsum;
+
+    // pass 2: per chunk first-symbol length, chunk bit totals
+    unsigned long long mybits = 0;
+    int prev_ne = carry_ne;
+    unsigned long long cb[SCAN_ITEMS];
+    int pp[SCAN_ITEMS], pvv[SCAN_ITEMS];
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        cb[i] = 0; pp[i] = -1; pvv[i] = 0;
+        const int ch = first + i;
+        if (i < per && ch < n) {
+            const HzChunkSum s = cs[ch];
+            int ppos = -1, pval = 0;
+            if (prev_ne >= 0) { ppos = cs[prev_ne].last_pos; pval = cs[prev_ne].last_val; }
+            pp[i] = ppos; pvv[i] = pval;
+            if (s.nnz > 0) {
+                unsigned b = (unsigned)len_ueg((unsigned)(s.first_pos - ppos - 1));
+                if (prev_ne >= 0) b += (unsigned)len_neg(pval);
+                cb[i] = (unsigned long long)b + s.bits_inner;
+                prev_ne = ch;
+            }
+            mybits += cb[i];
+        }
+    }
+    const unsigned long long incl_bits = block_scan_incl<unsigned long long>(mybits, 0ull, OpAddU64(), s_u64);
+    unsigned long long off = incl_bits - mybits;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; i++) {
+        const int ch = first + i;
+        if (i < per && ch < n) {
+            cs[ch].bit_off = off;
+            cs[ch].prev_pos = pp[i];
+            cs[ch].prev_val = pvv[i];
+            cs[ch].nz_base = nzbase;
+            off += cb[i];
+            nzbase += cs[ch].nnz;
+        }
+    }
+    if (threadIdx.x == SCAN_THREADS - 1) {
+        HzPlaneSum &ps = jb.psum[c];
+        const int lne = incl_ne;                               // last non-empty chunk of the plane
+        unsigned long long tb = incl_bits;
+        if (lne >= 0) tb += (unsigned long long)len_neg(cs[lne].last_val);   // trailing NEG (hzcc.c:283-285)
+        ps.total_bits = tb;
+        ps.nruns = (unsigned)incl_nnz;
+        ps.last_chunk = lne;
+        ps.overflow = ((tb + 7) >> 3) > jb.bits_cap[c] ? 1 : 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ unsigned long long spread_bits(unsigned long long x)   // bit i -> bit 2i
+{
+    x = (x | (x << 16)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x << 8)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x << 4)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x << 2)) & 0x3333333333333333ull;
+    x = (x | (x << 1)) & 0x5555555555555555ull;
+    return x;
+}
+// UEG(v) as an MSB-first integer pattern (bs.c:129-145): k x ('0', bit) then '1'
+static __device__ __forceinline__ unsigned long long pat_ueg(unsigned v, int &len)
+{
+    const unsigned m = v + 1;
+    const int k = 31 - __clz((int)m);
+    len = 2 * k + 1;
+    return (spread_bits((unsigned long long)(m & ((1u << k) - 1u))) << 1) | 1ull;
+}
+static __device__ __forceinline__ unsigned long long pat_neg(int v, int &len)      // bs.c:191-206
+{
+    const unsigned mag = (unsigned)(v < 0 ? -v : v);
+    int l;
+    const unsigned long long u = pat_ueg(mag - 1u, l);
+    len = l + 1;
+    return (u << 1) | (v < 0 ? 1ull : 0ull);
+}
+
+// OR `len` (<= 48) bits of `pat` into the MSB-first byte stream at bit position `pos`
+static __device__ __forceinline__ void or_bits(unsigned *out32, unsigned long long pos, unsigned long long pat, int len)
+{
+    const unsigned long long w = pos >> 5;
+    const int o = (int)(pos & 31);
+    const int sh = 64 - o - len;             // left shift of pat inside the first 64-bit window
+    unsigned long long hi, lo = 0;
+    if (sh >= 0) hi = pat << sh;
+    else { hi = pat >> (-sh); lo = pat << (64 + sh); }
+    const unsigned w0 = (unsigned)(hi >> 32), w1 = (unsigned)hi, w2 = (unsigned)(lo >> 32);
+    if (w0) atomicOr(out32 + w, __builtin_bswap32(w0));
+    if (w1) atomicOr(out32 + w + 1, __builtin_bswap32(w1));
+    if (w2) atomicOr(out32 + w + 2, __builtin_bswap32(w2));
+}
+
+__global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs)
+{
+    __shared__ unsigned s_w[4];
+    __shared__ unsigned s_run;
+    const int job = blockIdx.z, c = blockIdx.y, chunk = blockIdx.x;
+    const JobDev &jb = jobs[job];
+    const HzPlane &hp = jb.hz[c];
+    if (chunk >= hp.nchunks) return;
+    const HzPlaneSum ps = jb.psum[c];
+    if (ps.overflow) return;
+    const HzChunkSum cs = jb.chunks[jb.chunk_off[c] + chunk];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    unsigned *out32 = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
+    const int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    const int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+
+    if (tid == 0) s_run = 0;
+    __syncthreads();
+    for (int base = 0; base < cs.nnz; base += 256) {
+        const int j = base + tid;
+        int l1 = 0, l2 = 0;
+        unsigned long long p1 = 0, p2 = 0;
+        if (j < cs.nnz) {
+            const int pos = gpos[j];
+            const int ppos = j ? gpos[j - 1] : cs.prev_pos;
+            const int pval = j ? gval[j - 1] : cs.prev_val;
+            p1 = pat_ueg((unsigned)(pos - ppos - 1), l1);
+            if (j > 0 || cs.prev_pos >= 0) p2 = pat_neg(pval, l2);
+        }
+        // exclusive prefix of (l1+l2) over the block
+        unsigned len = (unsigned)(l1 + l2), incl = len;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned n = __shfl_up(incl, o);
+            if (lane >= o) incl += n;
+        }
+        if (lane == 63) s_w[wv] = incl;
+        __syncthreads();
+        unsigned pre = s_run;
+        for (int i = 0; i < wv; i++) pre += s_w[i];
+        const unsigned long long at = cs.bit_off + pre + (incl - len);
+        if (l1) or_bits(out32, at, p1, l1);
+        if (l2) or_bits(out32, at + l1, p2, l2);
+        __syncthreads();
+        if (tid == 255) s_run = pre + incl;
+        __syncthreads();
+    }
+    if (tid == 0 && chunk == ps.last_chunk) {       // trailing value of the plane
+        int l;
+        const unsigned long long p = pat_neg(cs.last_val, l);
+        or_bits(out32, ps.total_bits - (unsigned long long)l, p, l);
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// decoder: scatter + dequantise host-parsed (scan position, value) pairs (hzcc.c:330-341,409-424)
+__global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ jobs, int c, int first, int count)
+{
+    const int job = blockIdx.y;
+    const JobDev &jb = jobs[job];
+    const HzPlane &hp = jb.hz[c];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = min(count, jb.dec_cnt[c] - first);
+    if (i >= n) return;
+    const int p = jb.nzpos[jb.nz_off[c] + first + i];
+    const int v = jb.nzval[jb.nz_off[c] + first + i];
+    if (p < 0 || p >= hp.nscan) return;
+    if (p == 0) { (jb.coef + jb.hz_coef_off[c])[0] = v; return; }     // unquantised DC (hzcc.c:495)
+    const HzRegion r = hp.r[find_region(hp, p)];
+    const int local = p - r.base;
+    const int y = local / r.sw, x = local - y * r.sw;
+    const int tq = cell_tq(r, jb.stable, hp.nbh, x, y);
+    (jb.coef + jb.hz_coef_off[c])[(size_t)(r.y0 + y) * hp.w + r.x0 + x] = dequant_any(r, v, tq);
+}
+
+// -------------------------------------------------------------------------------------------------
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks)
+{
+    hipLaunchKernelGGL(k_hz_quant, dim3(max_chunks, 3, njobs), dim3(256), 0, st, jobs);
+    hipLaunchKernelGGL(k_hz_scan, dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
+    hipLaunchKernelGGL(k_hz_emit, dim3(max_chunks, 3, njobs), dim3(256), 0, st, jobs);
+}
+
+void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count)
+{
+    if (count <= 0) return;
+    hipLaunchKernelGGL(k_hz_scatter, dim3((count + 255) / 256, njobs), dim3(256), 0, st, jobs, c, first, count);
+}
+
+int hz_scan_items_max() { return SCAN_ITEMS * SCAN_THREADS; }

@@ -1,0 +1,658 @@
+// k_sbt.hip -- subband transform kernels for gfx950 (MI355X).  HBM-bound integer work: no MFMA.
+//
+// Replaces the reference's sbt.c: dsv_fwd_sbt sbt.c:630-651 (p2sbc :576, fwd :268, fwd_b4t_* :91-251)
+// and dsv_inv_sbt sbt.c:654-714 (inv :438, inv_simple :352, inv_b4t_* :129-265, sbc2int :595).
+//
+// Decomposition (per plane, batched over picture jobs in grid.z):
+//   forward  P : k_fwd_haar_pix   one thread = one 8x8 pixel patch = Haar levels 1..3 in registers
+//                                 (8-byte coalesced row loads, 16/8/4-byte coalesced sub-band stores)
+//            I : k_fwd_b4t        level 1 biorthogonal (1,3,3,1): row pass + column pass per thread on a
+//                                 10x10 neighbourhood, LL1 -> s1;  k_fwd_haar_s1: levels 2..3 from s1
+//            all: k_fwd_tail      levels 4..top inside LDS (<=160 KB) by one 1024-thread workgroup
+//   inverse all: k_inv_tail       levels top..4 inside LDS, LL3 -> s3
+//            P : k_inv_haar_tile  levels 3,2,1 on a 128x64 pixel tile through LDS (halo 2/1/0 cells),
+//                                 fused with sbc2int, the prediction add (dsv_frame_add bmc.c:304) and
+//                                 the store into the reconstruction frame
+//            I : k_inv_haar_tile<..TO_S1> levels 3,2 -> s1, then k_inv_b4t (column pass through LDS,
+//                                 then row pass) fused with sbc2int
+// Every formula keeps the C semantics of the reference: truncating *4/5, *5/4 and /4, rounding
+// helpers round half away from zero, mirrored left/top and clamped right/bottom B4T edges.
+#include "dsvg_dev.hpp"
+#include "dsvg_kernels.hpp"
+
+// --------------------------------------------------------------------------------------------
+// helpers
+// --------------------------------------------------------------------------------------------
+template <int M>
+static __device__ __forceinline__ void store_row(int32_t *p, const int (&v)[M], int n)
+{
+    if (n >= M) {
+        if (M == 4 && (((uintptr_t)p) & 15) == 0) {
+            *reinterpret_cast<int4 *>(p) = make_int4(v[0], v[1 % M], v[2 % M], v[3 % M]);
+            return;
+        }
+        if (M == 2 && (((uintptr_t)p) & 7) == 0) {
+            *reinterpret_cast<int2 *>(p) = make_int2(v[0], v[1 % M]);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) p[i] = v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            if (i < n) p[i] = v[i];
+    }
+}
+
+// One forward Haar level on an NxN register patch whose top-left input sample is cell
+// (2*cx0, 2*cy0) of the level's ws x hs input region.  Missing right/bottom samples are mirrored
+// (equivalent to the edge formulas sbt.c:309-346); sub-bands that do not exist are not stored.
+template <int N>
+static __device__ __forceinline__ void haar_fwd_patch(const int (&in)[N][N], int (&out)[N / 2][N / 2],
+                                                      int cx0, int cy0, int ws, int hs, int W,
+                                                      int wo, int ho, int32_t *__restrict__ coef, bool scaled)
+{
+    constexpr int M = N / 2;
+    const int nR = min(M, max(0, (ws >> 1) - cx0));   // cells of this row that have a right sample
+    const int nC = min(M, max(0, wo - cx0));          // cells of this row that exist
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const int cy = cy0 + j;
+        const bool hasB = 2 * cy + 1 < hs;
+        int lh[M], hl[M], hh[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const bool hasR = 2 * (cx0 + i) + 1 < ws;
+            const int a = in[2 * j][2 * i];
+            const int b = hasR ? in[2 * j][2 * i + 1] : a;
+            const int c = hasB ? in[2 * j + 1][2 * i] : a;
+            const int d = hasB ? (hasR ? in[2 * j + 1][2 * i + 1] : c) : b;
+            const int ll = a + b + c + d;
+            out[j][i] = scaled ? d_ll_down(ll) : ll;
+            lh[i] = a - b + c - d;
+            hl[i] = a + b - c - d;
+            hh[i] = a - b - c + d;
+        }
+        if (2 * cy < hs) {
+            store_row<M>(coef + (size_t)cy * W + wo + cx0, lh, nR);
+            if (hasB) {
+                store_row<M>(coef + (size_t)(ho + cy) * W + cx0, hl, nC);
+                store_row<M>(coef + (size_t)(ho + cy) * W + wo + cx0, hh, nR);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// forward, P pictures: levels 1..3 straight from the 8-bit residual plane
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
+                                                      int from_src)
+{
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    if (I >= g.w3 || J >= g.h3) return;
+    const JobDev &jb = jobs[job];
+    const uint8_t *px = (from_src ? jb.src : jb.xf) + g.poff;
+    int32_t *coef = jb.coef + g.coff;
+
+    int a[8][8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const int y = 8 * J + r;
+        uint2 v = make_uint2(0x80808080u, 0x80808080u);         // rows >= ph stay zero (p2sbc skips them)
+        if (y < g.ph) v = *reinterpret_cast<const uint2 *>(px + (size_t)y * g.pstride + 8 * I);
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            a[r][i] = (int)((v.x >> (8 * i)) & 0xff) - 128;
+            a[r][i + 4] = (int)((v.y >> (8 * i)) & 0xff) - 128;
+        }
+    }
+    const int W = g.W, H = g.H;
+    const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
+    int l1[4][4], l2[2][2], l3[1][1];
+    haar_fwd_patch<8>(a, l1, 4 * I, 4 * J, W, H, W, wo1, ho1, coef, false);      // LVL_TEST: P level 1 unscaled
+    haar_fwd_patch<4>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true);
+    haar_fwd_patch<2>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true);
+    jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
+}
+
+// --------------------------------------------------------------------------------------------
+// forward, I pictures: level 1 = biorthogonal 4-tap, rows then columns (fwd_b4t_2d sbt.c:240-251)
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
+                                                 int from_src)
+{
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const int W = g.W, H = g.H;
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    if (8 * I >= W || 8 * J >= H) return;
+    const JobDev &jb = jobs[job];
+    const uint8_t *px = (from_src ? jb.src : jb.xf) + g.poff;
+    int32_t *coef = jb.coef + g.coff;
+    const int hw = W >> 1, hh = H >> 1;
+
+    int RL[10][4], RH[10][4];       // row-pass outputs of rows 8J-1 .. 8J+8 for cells 4I..4I+3
+#pragma unroll
+    for (int r = 0; r < 10; r++) {
+        int y = 8 * J - 1 + r;
+        y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
+        int v[10];                                          // v[k] = sample at x = 8I-1+k
+        if (y < g.ph) {
+            const uint8_t *row = px + (size_t)y * g.pstride + 8 * I;
+            const uint2 m = *reinterpret_cast<const uint2 *>(row);
+            const unsigned lft = *reinterpret_cast<const unsigned *>(row - 4);
+            const unsigned rgt = *reinterpret_cast<const unsigned *>(row + 8);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                v[1 + i] = (int)((m.x >> (8 * i)) & 0xff) - 128;
+                v[5 + i] = (int)((m.y >> (8 * i)) & 0xff) - 128;
+            }
+            v[0] = (I == 0) ? v[2] : (int)(lft >> 24) - 128;           // left mirror x[-1] = x[1]
+            const int last = W - 1 - 8 * I;                            // index of the last valid sample
+            int edge = v[8];
+            if (last < 7) {                                            // ragged width: pick x[W-1]
+#pragma unroll
+                for (int i = 0; i < 7; i++) edge = (i == last) ? v[1 + i] : edge;
+#pragma unroll
+                for (int i = 1; i < 8; i++) v[1 + i] = (i > last) ? edge : v[1 + i];
+            }
+            v[9] = (8 * I + 8 > W - 1) ? edge : (int)(rgt & 0xff) - 128; // right clamp x[W] = x[W-1]
+        } else {
+#pragma unroll
+            for (int i = 0; i < 10; i++) v[i] = 0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int xm = v[2 * k], x0 = v[2 * k + 1], x1 = v[2 * k + 2], xp = v[2 * k + 3];
+            RL[r][k] = d_rdiv2(3 * x0 + 3 * x1 - xm - xp);
+            RH[r][k] = d_rdiv2(xm - 3 * x0 + 3 * x1 - xp);
+        }
+    }
+    const int nC = min(4, max(0, hw - 4 * I));
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int cy = 4 * J + m;
+        if (cy >= hh) break;
+        int ll[4], lh[4], hl[4], hhv[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int am = RL[2 * m][k], a0 = RL[2 * m + 1][k], a1 = RL[2 * m + 2][k], ap = RL[2 * m + 3][k];
+            const int bm = RH[2 * m][k], b0 = RH[2 * m + 1][k], b1 = RH[2 * m + 2][k], bp = RH[2 * m + 3][k];
+            ll[k] = d_rdiv2(3 * a0 + 3 * a1 - am - ap);
+            hl[k] = d_rdiv2(am - 3 * a0 + 3 * a1 - ap);
+            lh[k] = d_rdiv2(3 * b0 + 3 * b1 - bm - bp);
+            hhv[k] = d_rdiv2(bm - 3 * b0 + 3 * b1 - bp);
+        }
+        store_row<4>(jb.s1 + g.s1off + (size_t)cy * g.w1 + 4 * I, ll, nC);
+        store_row<4>(coef + (size_t)cy * W + hw + 4 * I, lh, nC);
+        store_row<4>(coef + (size_t)(hh + cy) * W + 4 * I, hl, nC);
+        store_row<4>(coef + (size_t)(hh + cy) * W + hw + 4 * I, hhv, nC);
+    }
+}
+
+// forward, I pictures: Haar levels 2..3 from the LL1 scratch plane
+__global__ __launch_bounds__(256) void k_fwd_haar_s1(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    if (I >= g.w3 || J >= g.h3) return;
+    const JobDev &jb = jobs[job];
+    int32_t *coef = jb.coef + g.coff;
+    const int32_t *s1 = jb.s1 + g.s1off;
+    int a[4][4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int x = 4 * I + i, y = 4 * J + r;
+            a[r][i] = (x < g.w1 && y < g.h1) ? s1[(size_t)y * g.w1 + x] : 0;
+        }
+    const int W = g.W, H = g.H;
+    const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
+    int l2[2][2], l3[1][1];
+    haar_fwd_patch<4>(a, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true);   // intra: always scaled
+    haar_fwd_patch<2>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true);
+    jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
+}
+
+// --------------------------------------------------------------------------------------------
+// LDS tails: levels >= 4 of one plane inside one workgroup
+// --------------------------------------------------------------------------------------------
+#define TAIL_THREADS 1024
+#define TAIL_MAXC 12            // cells per thread at the first tail level (host checks)
+
+__global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    extern __shared__ int T[];
+    const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
+    const SbtGeo g = G.g[c];
+    const JobDev &jb = jobs[job];
+    const int w3 = g.w3, h3 = g.h3, n3 = w3 * h3, W = g.W, H = g.H;
+    const int32_t *s3 = jb.s3 + g.s3off;
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) T[i] = s3[i];
+    __syncthreads();
+
+    for (int lvl = 4; lvl <= g.lvls; lvl++) {
+        const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
+        const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
+        const int ncell = wo * ho;
+        int ll[TAIL_MAXC], lh[TAIL_MAXC], hl[TAIL_MAXC], hh[TAIL_MAXC];
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const bool hasR = 2 * cx + 1 < ws, hasB = 2 * cy + 1 < hs;
+                const int *p = T + 2 * cy * w3 + 2 * cx;
+                const int a = p[0];
+                const int b = hasR ? p[1] : a;
+                const int cc = hasB ? p[w3] : a;
+                const int d = hasB ? (hasR ? p[w3 + 1] : cc) : b;
+                ll[k] = d_ll_down(a + b + cc + d);          // levels >= 4 are always scaled
+                lh[k] = a - b + cc - d;
+                hl[k] = a + b - cc - d;
+                hh[k] = a - b - cc + d;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const bool hasR = 2 * cx + 1 < ws, hasB = 2 * cy + 1 < hs;
+                T[cy * w3 + cx] = ll[k];
+                if (hasR) T[cy * w3 + wo + cx] = lh[k];
+                if (hasB) T[(ho + cy) * w3 + cx] = hl[k];
+                if (hasR && hasB) T[(ho + cy) * w3 + wo + cx] = hh[k];
+            }
+        }
+        __syncthreads();
+    }
+    int32_t *coef = jb.coef + g.coff;
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) {
+        const int y = i / w3, x = i - y * w3;
+        coef[(size_t)y * W + x] = T[i];
+    }
+}
+
+// smoothing nudge of the filtered inverse (sbt.c:480-527)
+static __device__ __forceinline__ int d_nudge(int ll, int lp, int ln, int det, int hqp)
+{
+    int mx = ll - ln, mn = lp - ll;
+    if (mn > mx) { const int t = mn; mn = mx; mx = t; }
+    mx = min(mx, 0);
+    mn = max(mn, 0);
+    if (mx != mn) {
+        const int t = d_rdiv4(lp - ln);
+        const int n = d_rdiv2(d_clamp(t, mx, mn) - (det << 1));
+        det += d_clamp(n, -hqp, hqp);
+    }
+    return det;
+}
+
+__global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    extern __shared__ int T[];
+    const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
+    const SbtGeo g = G.g[c];
+    const JobDev &jb = jobs[job];
+    const int w3 = g.w3, h3 = g.h3, n3 = w3 * h3, W = g.W, H = g.H;
+    const int32_t *coef = jb.coef + g.coff;
+    const bool filt = (c == 0);
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) {
+        const int y = i / w3, x = i - y * w3;
+        T[i] = coef[(size_t)y * W + x];
+    }
+    __syncthreads();
+
+    for (int lvl = g.lvls; lvl >= 4; lvl--) {
+        const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
+        const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
+        const int wfull = ws & ~1, hfull = hs & ~1;
+        const int ncell = wo * ho;
+        const int hqp = jb.hqp[lvl];
+        int o0[TAIL_MAXC], o1[TAIL_MAXC], o2[TAIL_MAXC], o3[TAIL_MAXC];
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const int x = 2 * cx, y = 2 * cy;
+                const bool hasR = x + 1 < ws, hasB = y + 1 < hs;
+                const int *pLL = T + cy * w3 + cx;
+                const int LL = d_ll_up(pLL[0]);
+                int LH = hasR ? pLL[wo] : 0;
+                int HL = hasB ? pLL[ho * w3] : 0;
+                const int HH = (hasR && hasB) ? pLL[ho * w3 + wo] : 0;
+                if (filt && hasR && hasB) {
+                    if (x > 0 && x < wfull - 1) LH = d_nudge(LL, d_ll_up(pLL[-1]), d_ll_up(pLL[1]), LH, hqp);
+                    if (y > 0 && y < hfull - 1) HL = d_nudge(LL, d_ll_up(pLL[-w3]), d_ll_up(pLL[w3]), HL, hqp);
+                }
+                o0[k] = (LL + LH + HL + HH) / 4;
+                o1[k] = (LL - LH + HL - HH) / 4;
+                o2[k] = (LL + LH - HL - HH) / 4;
+                o3[k] = (LL - LH - HL + HH) / 4;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const int x = 2 * cx, y = 2 * cy;
+                const bool hasR = x + 1 < ws, hasB = y + 1 < hs;
+                int *o = T + y * w3 + x;
+                o[0] = o0[k];
+                if (hasR) o[1] = o1[k];
+                if (hasB) {
+                    o[w3] = o2[k];
+                    if (hasR) o[w3 + 1] = o3[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    int32_t *s3 = jb.s3 + g.s3off;
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) s3[i] = T[i];
+}
+
+// --------------------------------------------------------------------------------------------
+// inverse levels 3,2,(1) on a tile through LDS
+// --------------------------------------------------------------------------------------------
+struct LvlGeo {
+    int ws, hs, wo, ho, wfull, hfull, hqp;
+    bool scaled;
+};
+static __device__ __forceinline__ LvlGeo mk_lvl(int W, int H, int lvl, int hqp, bool scaled)
+{
+    LvlGeo L;
+    L.ws = DSVG_RSU(W, lvl - 1); L.hs = DSVG_RSU(H, lvl - 1);
+    L.wo = DSVG_RSU(W, lvl);     L.ho = DSVG_RSU(H, lvl);
+    L.wfull = L.ws & ~1;         L.hfull = L.hs & ~1;
+    L.hqp = hqp; L.scaled = scaled;
+    return L;
+}
+
+// inverse of one cell (cx,cy); A = LDS array of this level's LL values, pA -> this cell's LL
+template <bool FILT>
+static __device__ __forceinline__ void inv_cell(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
+                                                const int32_t *__restrict__ coef, int W, int (&o)[4])
+{
+    const int x = 2 * cx, y = 2 * cy;
+    const bool hasR = x + 1 < L.ws, hasB = y + 1 < L.hs;
+    const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
+    int LH = hasR ? coef[(size_t)cy * W + L.wo + cx] : 0;
+    int HL = hasB ? coef[(size_t)(L.ho + cy) * W + cx] : 0;
+    const int HH = (hasR && hasB) ? coef[(size_t)(L.ho + cy) * W + L.wo + cx] : 0;
+    if (FILT && hasR && hasB) {
+        // NOTE (reference quirk, sbt.c:463-527): for an even region the last complete cell still passes
+        // the inX/inY test and its "next LL" is read ACROSS the band boundary: column wo of the same row
+        // (= LH[cy][0]) / row ho of the same column (= HL[0][cx]) of the coefficient plane.
+        if (x > 0 && x < L.wfull - 1) {
+            int lp = pA[-1], ln = (cx + 1 < L.wo) ? pA[1] : coef[(size_t)cy * W + L.wo];
+            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
+            LH = d_nudge(LL, lp, ln, LH, L.hqp);
+        }
+        if (y > 0 && y < L.hfull - 1) {
+            int lp = pA[-astride], ln = (cy + 1 < L.ho) ? pA[astride] : coef[(size_t)L.ho * W + cx];
+            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
+            HL = d_nudge(LL, lp, ln, HL, L.hqp);
+        }
+    }
+    o[0] = (LL + LH + HL + HH) / 4;
+    o[1] = (LL - LH + HL - HH) / 4;
+    o[2] = (LL + LH - HL - HH) / 4;
+    o[3] = (LL - LH - HL + HH) / 4;
+}
+
+#define IT_TX 16     // level-3 cells per tile in x  (=> 128 px)
+#define IT_TY 8      // level-3 cells per tile in y  (=>  64 px)
+#define A3W (IT_TX + 4)
+#define A3H (IT_TY + 4)
+#define A2W (2 * IT_TX + 4)
+#define A2H (2 * IT_TY + 4)
+#define A1W (4 * IT_TX + 4)
+#define A1H (4 * IT_TY + 4)
+
+// TO_PIX: run level 1 as well and emit pixels (P pictures); otherwise stop after level 2 and store
+// the LL1 band to s1 (I pictures, whose level 1 is the B4T kernel below).
+template <bool FILT, bool TO_PIX>
+__global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    __shared__ int A3[A3H * A3W];
+    __shared__ int A2[A2H * A2W];
+    __shared__ int A1[A1H * A1W];
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const JobDev &jb = jobs[job];
+    const int W = g.W, H = g.H;
+    const int32_t *coef = jb.coef + g.coff;
+    const int32_t *s3 = jb.s3 + g.s3off;
+    const int I0 = blockIdx.x * IT_TX, J0 = blockIdx.y * IT_TY;
+    const int tid = threadIdx.x;
+    const bool isP = jb.isP != 0;
+
+    for (int i = tid; i < A3H * A3W; i += 256) {
+        const int ly = i / A3W, lx = i - ly * A3W;
+        const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
+        A3[i] = (cx >= 0 && cy >= 0 && cx < g.w3 && cy < g.h3) ? s3[(size_t)cy * g.w3 + cx] : 0;
+    }
+    __syncthreads();
+    {   // level 3: cells I0-1 .. I0+TX (halo 1)
+        const LvlGeo L = mk_lvl(W, H, 3, jb.hqp[3], true);
+        for (int i = tid; i < (IT_TY + 2) * (IT_TX + 2); i += 256) {
+            const int ly = i / (IT_TX + 2), lx = i - ly * (IT_TX + 2);
+            const int cx = I0 - 1 + lx, cy = J0 - 1 + ly;
+            if (cx < 0 || cy < 0 || cx >= L.wo || cy >= L.ho) continue;
+            int o[4];
+            inv_cell<FILT>(A3 + (ly + 1) * A3W + (lx + 1), A3W, cx, cy, L, coef, W, o);
+            int *d = A2 + (2 * ly) * A2W + 2 * lx;
+            d[0] = o[0]; d[1] = o[1]; d[A2W] = o[2]; d[A2W + 1] = o[3];
+        }
+    }
+    __syncthreads();
+    {   // level 2: cells 2*I0-1 .. 2*I0+2*TX (halo 1)
+        const LvlGeo L = mk_lvl(W, H, 2, jb.hqp[2], true);
+        for (int i = tid; i < (2 * IT_TY + 2) * (2 * IT_TX + 2); i += 256) {
+            const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
+            const int cx = 2 * I0 - 1 + lx, cy = 2 * J0 - 1 + ly;
+            if (cx < 0 || cy < 0 || cx >= L.wo || cy >= L.ho) continue;
+            int o[4];
+            inv_cell<FILT>(A2 + (ly + 1) * A2W + (lx + 1), A2W, cx, cy, L, coef, W, o);
+            int *d = A1 + (2 * ly) * A1W + 2 * lx;
+            d[0] = o[0]; d[1] = o[1]; d[A1W] = o[2]; d[A1W + 1] = o[3];
+        }
+    }
+    __syncthreads();
+
+    if (!TO_PIX) {
+        int32_t *s1 = jb.s1 + g.s1off;
+        for (int i = tid; i < (4 * IT_TY) * (4 * IT_TX); i += 256) {
+            const int ly = i / (4 * IT_TX), lx = i - ly * (4 * IT_TX);
+            const int cx = 4 * I0 + lx, cy = 4 * J0 + ly;
+            if (cx < g.w1 && cy < g.h1) s1[(size_t)cy * g.w1 + cx] = A1[(ly + 2) * A1W + lx + 2];
+        }
+        return;
+    }
+
+    // level 1 + sbc2int (+ prediction add) : each work item = 4 adjacent cells = 8 px x 2 rows
+    const LvlGeo L = mk_lvl(W, H, 1, jb.hqp[1], !isP);        // LVL_TEST: P level 1 unscaled
+    uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
+    const uint8_t *pred = (jb.ref != nullptr) ? jb.pred + g.poff : nullptr;
+    for (int it = tid; it < (4 * IT_TY) * IT_TX; it += 256) {
+        const int ly = it / IT_TX, gx = it - ly * IT_TX;       // gx: group of 4 cells
+        const int cy = 4 * J0 + ly;
+        if (cy >= L.ho) continue;
+        int r0[8], r1[8];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int lx = 4 * gx + k, cx = 4 * I0 + lx;
+            int o[4] = {0, 0, 0, 0};
+            if (cx < L.wo) inv_cell<FILT>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, coef, W, o);
+            r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
+            r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
+        }
+        const int px0 = 2 * (4 * I0 + 4 * gx);                // pixel x of the group
+#pragma unroll
+        for (int rr = 0; rr < 2; rr++) {
+            const int y = 2 * cy + rr;
+            if (y >= g.ph) continue;
+            const int *v = rr ? r1 : r0;
+            uint8_t *dst = outp + (size_t)y * g.pstride + px0;
+            unsigned lo = 0, hi = 0;
+            uint2 pv = make_uint2(0, 0);
+            if (pred) pv = *reinterpret_cast<const uint2 *>(pred + (size_t)y * g.pstride + px0);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                int s = d_sat8(v[i] + 128);
+                if (pred) {
+                    const int p = (int)(((i < 4 ? pv.x : pv.y) >> (8 * (i & 3))) & 0xff);
+                    s = d_sat8(s + p - 128);                   // dsv_frame_add / addf bmc.c:29-41
+                }
+                if (i < 4) lo |= (unsigned)s << (8 * i); else hi |= (unsigned)s << (8 * (i - 4));
+            }
+            if (px0 + 8 <= g.pw) {
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (px0 + i < g.pw) dst[i] = (uint8_t)(((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xff);
+            }
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// inverse, I pictures: level 1 biorthogonal, columns then rows (inv_b4t_2d sbt.c:253-265) + sbc2int
+// --------------------------------------------------------------------------------------------
+#define BT_C 32                 // level-1 cells per tile edge -> 64x64 px
+#define BT_VW (BT_C + 2)        // columns k0-1 .. k0+BT_C of each half
+
+__global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    __shared__ int VL[2 * BT_C][BT_VW];     // column-pass output, low-horizontal half
+    __shared__ int VH[2 * BT_C][BT_VW];     // column-pass output, high-horizontal half
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const JobDev &jb = jobs[job];
+    const int W = g.W, H = g.H, hw = W >> 1, hh = H >> 1;
+    const int32_t *coef = jb.coef + g.coff;
+    const int32_t *s1 = jb.s1 + g.s1off;
+    const int k0 = blockIdx.x * BT_C, m0 = blockIdx.y * BT_C;
+    const int tid = threadIdx.x;
+
+    // phase A: vertical pass for columns k0-1..k0+BT_C (clamped) of both halves, rows 2*m0 .. 2*m0+2*BT_C-1
+    for (int i = tid; i < 2 * BT_VW * BT_C; i += 256) {
+        const int half = i / (BT_VW * BT_C);
+        const int r = i - half * (BT_VW * BT_C);
+        const int ml = r / BT_VW, kl = r - ml * BT_VW;
+        const int m = m0 + ml;
+        if (m >= hh) continue;
+        const int k = d_clamp(k0 - 1 + kl, 0, hw - 1);
+        const int mp = m > 0 ? m - 1 : 0, mn = m < hh - 1 ? m + 1 : hh - 1;
+        int Xp, X0, Xn, Yp, Y0, Yn;
+        if (half == 0) {      // low-horizontal columns: X = LL1 (s1), Y = HL1
+            Xp = s1[(size_t)mp * g.w1 + k]; X0 = s1[(size_t)m * g.w1 + k]; Xn = s1[(size_t)mn * g.w1 + k];
+            Yp = coef[(size_t)(hh + mp) * W + k]; Y0 = coef[(size_t)(hh + m) * W + k]; Yn = coef[(size_t)(hh + mn) * W + k];
+        } else {              // high-horizontal columns: X = LH1, Y = HH1
+            Xp = coef[(size_t)mp * W + hw + k]; X0 = coef[(size_t)m * W + hw + k]; Xn = coef[(size_t)mn * W + hw + k];
+            Yp = coef[(size_t)(hh + mp) * W + hw + k]; Y0 = coef[(size_t)(hh + m) * W + hw + k]; Yn = coef[(size_t)(hh + mn) * W + hw + k];
+        }
+        const int e = d_rdiv8(Xp + 3 * X0 + Yp - 3 * Y0);
+        const int o = d_rdiv8(3 * X0 + Xn + 3 * Y0 - Yn);
+        if (half == 0) { VL[2 * ml][kl] = e; VL[2 * ml + 1][kl] = o; }
+        else           { VH[2 * ml][kl] = e; VH[2 * ml + 1][kl] = o; }
+    }
+    __syncthreads();
+
+    // phase B: horizontal pass, 4 cells (8 px) per work item
+    uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
+    for (int it = tid; it < 2 * BT_C * (BT_C / 4); it += 256) {
+        const int yl = it / (BT_C / 4), gx = it - yl * (BT_C / 4);
+        const int y = 2 * m0 + yl;
+        if (y >= H || y >= g.ph) continue;
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int kl = 4 * gx + q, k = k0 + kl;
+            int e = 0, o = 0;
+            if (k < hw) {
+                // local column index of k is kl+1; neighbours clamp at the plane edges
+                const int cm = (k > 0) ? kl : kl + 1, cp = (k < hw - 1) ? kl + 2 : kl + 1;
+                const int Lp = VL[yl][cm], L0 = VL[yl][kl + 1], Ln = VL[yl][cp];
+                const int Hp = VH[yl][cm], H0 = VH[yl][kl + 1], Hn = VH[yl][cp];
+                e = d_sat8(d_rdiv8(Lp + 3 * L0 + Hp - 3 * H0) + 128);
+                o = d_sat8(d_rdiv8(3 * L0 + Ln + 3 * H0 - Hn) + 128);
+            }
+            if (q < 2) lo |= ((unsigned)e << (16 * q)) | ((unsigned)o << (16 * q + 8));
+            else       hi |= ((unsigned)e << (16 * (q - 2))) | ((unsigned)o << (16 * (q - 2) + 8));
+        }
+        const int px0 = 2 * (k0 + 4 * gx);
+        uint8_t *dst = outp + (size_t)y * g.pstride + px0;
+        if (px0 + 8 <= g.pw) {
+            *reinterpret_cast<uint2 *>(dst) = make_uint2(lo, hi);
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (px0 + i < g.pw) dst[i] = (uint8_t)(((i < 4 ? lo : hi) >> (8 * (i & 3))) & 0xff);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------------
+// host launchers
+// --------------------------------------------------------------------------------------------
+static inline dim3 grid3(int w3, int h3, int nz) { return dim3((w3 + 63) / 64, (h3 + 3) / 4, nz); }
+
+int sbt_tail_supported(const SbtGeo &g)
+{
+    const long n3 = (long)g.w3 * g.h3;
+    if (n3 * 4 > 160 * 1024 - 256) return 0;
+    const long c4 = (long)DSVG_RSU(g.W, 4) * DSVG_RSU(g.H, 4);
+    return c4 <= (long)TAIL_MAXC * TAIL_THREADS;
+}
+
+// forward transform of planes [c0, c0+npl) of njobs jobs (all P or all I)
+void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
+                    int from_src)
+{
+    const SbtGeo &g = G.g[c0];
+    const int nz = njobs * npl;
+    if (isP) {
+        hipLaunchKernelGGL(k_fwd_haar_pix, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+    } else {
+        hipLaunchKernelGGL(k_fwd_b4t, grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        hipLaunchKernelGGL(k_fwd_haar_s1, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    }
+    hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+}
+
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP)
+{
+    const SbtGeo &g = G.g[c0];
+    const int nz = njobs * npl;
+    hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+    const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
+    const bool filt = (c0 == 0);
+    if (isP) {
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+    } else {
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
+        hipLaunchKernelGGL(k_inv_b4t, bg, dim3(256), 0, st, jobs, G, c0, npl);
+    }
+}
+
+void sbt_set_func_attributes()
+{
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_inv_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+}

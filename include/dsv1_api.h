@@ -1,0 +1,164 @@
+/*
+ * dsv1_api.h -- session-level C API of libdsv1_mi355x.so: the drop-in surface behind dsv_main.c.
+ *
+ * Every symbol the reference CLI binds (dsv_main.c:440-557,652-717) is exported with the same name,
+ * argument meaning, ownership and return codes, and the structs callers poke (DSV_ENCODER,
+ * DSV_DECODER, DSV_META, DSV_FRAME, DSV_BUF) keep the reference's field order and sizes
+ * (dsv.h:86-198, dsv_encoder.h:58-110, dsv_decoder.h:27-43).  The per-frame arithmetic runs in the HIP
+ * kernels behind include/dsvg.h; this layer (plain C) keeps GOP / scene-change / rate-control /
+ * stability logic, side-info coding and packet framing on the host.
+ *
+ * Extensions (names of our own): dsv1_batch_* encodes many independent closed GOPs per call with
+ * frames resident in HBM -- the throughput path used by bench.py and by GOP sharding across GPUs.
+ */
+#ifndef DSV1_API_H
+#define DSV1_API_H
+
+#include <limits.h>
+#include <stdint.h>
+#include <stdio.h>
+#include "dsvg.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* packet types (dsv.h:34-43) */
+#define DSV_PT_META 0x00
+#define DSV_PT_PIC  0x04
+#define DSV_PT_EOS  0x10
+#define DSV_PACKET_HDR_SIZE 14
+#define DSV_PACKET_TYPE_OFFSET 5
+#define DSV_PACKET_PREV_OFFSET 6
+#define DSV_PACKET_NEXT_OFFSET 10
+
+#define DSV_SUBSAMP_444 0x0
+#define DSV_SUBSAMP_422 0x4
+#define DSV_SUBSAMP_420 0x5
+#define DSV_SUBSAMP_411 0x8
+
+#define DSV_MAX_QUALITY 2047
+#define DSV_QUALITY_PERCENT(p) (DSV_MAX_QUALITY * (p) / 100)
+#define DSV_GOP_INTRA 0
+#define DSV_GOP_INF INT_MAX
+#define DSV_ENC_NUM_BUFS 0x03
+#define DSV_ENC_FINISHED 0x04
+#define DSV_RATE_CONTROL_CRF 0
+#define DSV_RATE_CONTROL_ABR 1
+#define DSV_MAX_PYRAMID_LEVELS 5
+
+typedef uint32_t DSV_FNUM;
+typedef dsvg_meta   DSV_META;
+typedef dsvg_plane  DSV_PLANE;
+typedef dsvg_frame  DSV_FRAME;
+typedef dsvg_mv     DSV_MV;
+typedef dsvg_params DSV_PARAMS;
+typedef struct { unsigned char *data; unsigned len; } DSV_BUF;
+
+typedef struct {                 /* same fields, order and sizes as dsv_encoder.h:58-110 */
+    int quality;
+    int gop;
+    int do_scd;
+    int rc_mode;
+    int rc_high_motion_nudge;
+    unsigned bitrate;
+    int max_q_step;
+    int min_quality;
+    int max_quality;
+    int min_I_frame_quality;
+    int intra_pct_thresh;
+    int scene_change_delta;
+    unsigned stable_refresh;
+    int pyramid_levels;
+    /* internal state (kept in the public struct by the reference, so kept here) */
+    unsigned rc_quant;
+    unsigned bpf_total;
+    unsigned bpf_reset;
+    int bpf_avg;
+    int total_P_frame_q;
+    int avg_P_frame_q;
+    int last_P_frame_over;
+    int back_into_range;
+    DSV_FNUM next_fnum;
+    void *ref;                   /* reference: DSV_ENCDATA*; here: opaque device session handle */
+    DSV_META vidmeta;
+    int prev_link;
+    int force_metadata;
+    struct DSV_STAB_ACC { signed x : 16; signed y : 16; } *stability;
+    unsigned refresh_ctr;
+    unsigned char *stable_blocks;
+    DSV_FNUM prev_gop;
+    int prev_avg_luma;
+} DSV_ENCODER;
+
+typedef struct {                 /* dsv_decoder.h:35-43 */
+    DSV_META vidmeta;
+    void *ref;                   /* reference: DSV_IMAGE*; here: opaque device session handle */
+    int draw_info;               /* accepted and ignored: debug overlays are out of scope */
+    int got_metadata;
+} DSV_DECODER;
+
+#define DSV_DEC_OK        0
+#define DSV_DEC_ERROR     1
+#define DSV_DEC_EOS       2
+#define DSV_DEC_GOT_META  3
+#define DSV_DEC_NEED_NEXT 4
+
+/* ---- encoder (dsv_encoder.h:112-121) ---- */
+void dsv_enc_init(DSV_ENCODER *enc);
+void dsv_enc_free(DSV_ENCODER *enc);
+void dsv_enc_set_metadata(DSV_ENCODER *enc, DSV_META *md);
+void dsv_enc_force_metadata(DSV_ENCODER *enc);
+void dsv_enc_start(DSV_ENCODER *enc);
+int  dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs);     /* takes ownership of frame */
+void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs);
+
+/* ---- decoder (dsv_decoder.h:51-59) ---- */
+int  dsv_dec(DSV_DECODER *d, DSV_BUF *buf, DSV_FRAME **out, DSV_FNUM *fn); /* frees buf */
+DSV_META *dsv_get_metadata(DSV_DECODER *d);
+void dsv_dec_free(DSV_DECODER *d);
+
+/* ---- frames, buffers, allocator, logging, file helpers (dsv.h:160-247, util.h:31-34) ---- */
+DSV_FRAME *dsv_mk_frame(int format, int width, int height, int border);
+DSV_FRAME *dsv_load_planar_frame(int format, void *data, int width, int height);
+DSV_FRAME *dsv_frame_ref_inc(DSV_FRAME *frame);
+void dsv_frame_ref_dec(DSV_FRAME *frame);
+void dsv_mk_buf(DSV_BUF *buf, int size);
+void dsv_buf_free(DSV_BUF *buf);
+void *dsv_alloc(int size);
+void dsv_free(void *ptr);
+void dsv_memory_report(void);
+void dsv_set_log_level(int level);
+int  dsv_get_log_level(void);
+int  dsv_yuv_write(FILE *out, int fno, DSV_PLANE *planes);
+int  dsv_yuv_read(FILE *in, int fno, uint8_t *o, int w, int h, int subsamp);
+void dsv_movec_pred(DSV_MV *vecs, DSV_PARAMS *p, int x, int y, int *px, int *py);
+unsigned estimate_bitrate(int quality, int gop, DSV_META *md);
+void conv444to422(DSV_PLANE *srcf, DSV_PLANE *dstf);
+void conv422to420(DSV_PLANE *srcf, DSV_PLANE *dstf);
+
+/* ---- extensions: device selection + batched closed-GOP encoding ---- */
+void dsv1_set_device(int device);            /* HIP device used by sessions opened afterwards */
+
+typedef struct dsv1_batch dsv1_batch;
+/* cfg: a DSV_ENCODER filled like dsv_main.c:463-489 would (dsv_enc_init + fields + vidmeta);
+ * nstreams independent streams, frames_per_call frames each per call. */
+int  dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int nstreams, int frames_per_call);
+void dsv1_batch_close(dsv1_batch *b);
+void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
+/* Encode frames_per_call frames of every stream.  yuv: [stream][frame] tightly packed planar frames,
+ * host or device memory.  For each stream s the packets are appended to out[s] (a growing buffer the
+ * caller owns: data = NULL / len = 0 to start; freed with dsv_free).  Returns 0 or a DSVG_ERR_*. */
+int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
+/* append the end-of-stream packet of stream s */
+int  dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out);
+/* Concatenate per-GOP streams (each encoded independently with fnum seeded to its position) into one
+ * .dsv: rewrites the prev_link of every picture/EOS packet exactly as a serial encode would
+ * (set_link_offsets dsv_encoder.c:171-192) and appends an EOS.  Returns dsv_alloc'd buffer. */
+int  dsv1_concat_gops(const DSV_BUF *gops, int ngops, DSV_BUF *out);
+void *dsv1_batch_ctx(dsv1_batch *b);          /* the dsvg_ctx* (profiling hooks) */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,173 @@
+/*
+ * dsvg.h -- C ABI of the MI355X-native DSV1 hot path (libdsv1_mi355x.so).
+ *
+ * Plain C, plain pointers and sizes: this is what a host written in C (the reference's own
+ * language) binds.  Two seams are exported:
+ *
+ *   1. OPERATOR LEVEL (dsvg_op_*): one twin per function of the reference's operator API
+ *      (dsv_internal.h:94-109, dsv.h:169, dsv_encoder.h:132).  Same argument meaning, host
+ *      pointers in and out, results byte-identical; each call stages through HBM and runs the
+ *      HIP kernels.  This is the seam the parity tests drive.
+ *
+ *   2. PIPELINE LEVEL (dsvg_ctx_* / dsvg_load_frames / dsvg_analyse / dsvg_code_pictures /
+ *      dsvg_fetch_pictures): device-resident frames, batched over many closed GOPs, used by the
+ *      session layer (dsv_enc / dsv_enc_gops in dsv1_api.h) and by bench.py.
+ *
+ * All functions return DSVG_OK (0) or a negative DSVG_ERR_* code; nothing here falls back to a
+ * CPU implementation -- if no HIP device is usable the call fails.
+ *
+ * Struct layouts are ABI-identical to the reference's DSV_PLANE / DSV_COEFS / DSV_FRAME /
+ * DSV_MV / DSV_PARAMS / DSV_STABILITY / DSV_BS / DSV_HME (dsv.h:86-198, dsv_internal.h:39-49,
+ * dsv_encoder.h:124-130) so existing callers can pass their own structs.
+ */
+#ifndef DSVG_H
+#define DSVG_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DSVG_OK               0
+#define DSVG_ERR_HIP         (-1)   /* a HIP runtime call or kernel failed (see dsvg_last_error) */
+#define DSVG_ERR_ARG         (-2)   /* bad argument */
+#define DSVG_ERR_UNSUPPORTED (-3)   /* geometry outside what the kernels handle */
+#define DSVG_ERR_OVERFLOW    (-4)   /* packed plane exceeded its output bound */
+#define DSVG_ERR_NODEVICE    (-5)   /* no usable MI355X/HIP device */
+
+#define DSVG_FRAME_BORDER 64        /* DSV_FRAME_BORDER dsv_internal.h:37 */
+#define DSVG_MAX_PYRAMID  5         /* DSV_MAX_PYRAMID_LEVELS dsv_encoder.h:35 */
+
+typedef struct { int width, height, subsamp, fps_num, fps_den, aspect_num, aspect_den; } dsvg_meta; /* DSV_META */
+typedef struct { uint8_t *data; int len, format, stride, w, h, hs, vs; } dsvg_plane;             /* DSV_PLANE */
+typedef struct { int32_t *data; int width, height; } dsvg_coefs;                                 /* DSV_COEFS */
+typedef struct { uint8_t *alloc; dsvg_plane planes[3]; int refcount, format, width, height, border; } dsvg_frame; /* DSV_FRAME */
+typedef struct {                                                                                 /* DSV_MV */
+    union { struct { int16_t x, y; } mv; int32_t all; } u;
+    uint8_t mode, submask, lo_var, lo_tex, high_detail;
+} dsvg_mv;
+typedef struct { dsvg_meta *vidmeta; int is_ref, has_ref, blk_w, blk_h, nblocks_h, nblocks_v; } dsvg_params;     /* DSV_PARAMS */
+typedef struct { dsvg_params *params; unsigned char *stable_blocks; unsigned char cur_plane, isP; } dsvg_stability; /* DSV_STABILITY */
+typedef struct { uint8_t *start; unsigned pos; } dsvg_bs;                                        /* DSV_BS */
+typedef struct {                                                                                 /* DSV_HME */
+    dsvg_params *params;
+    dsvg_frame *src[DSVG_MAX_PYRAMID + 1];
+    dsvg_frame *ref[DSVG_MAX_PYRAMID + 1];
+    dsvg_mv *mvf[DSVG_MAX_PYRAMID + 1];
+    int levels;
+} dsvg_hme;
+
+/* ---------------------------------------------------------------------------------------------
+ * library
+ * ------------------------------------------------------------------------------------------- */
+const char *dsvg_last_error(void);          /* thread-local description of the last failure */
+int dsvg_device_count(void);                /* number of HIP devices (0 = none) */
+int dsvg_set_device(int device);            /* device used by the operator-level calls (default 0) */
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. operator level -- twins of the reference operator API
+ * ------------------------------------------------------------------------------------------- */
+/* dsv_fwd_sbt  sbt.c:630   */ int dsvg_op_fwd_sbt(const dsvg_plane *src, dsvg_coefs *dst, int isP);
+/* dsv_inv_sbt  sbt.c:654   */ int dsvg_op_inv_sbt(dsvg_plane *dst, dsvg_coefs *src, int q, int isP, int c);
+/* dsv_encode_plane hzcc.c:449 */ int dsvg_op_encode_plane(dsvg_bs *bs, dsvg_coefs *src, int q, const dsvg_stability *stab);
+/* dsv_decode_plane hzcc.c:479 */ int dsvg_op_decode_plane(uint8_t *in, unsigned len, dsvg_coefs *dst, int q, const dsvg_stability *stab);
+/* dsv_sub_pred bmc.c:318   */ int dsvg_op_sub_pred(const dsvg_mv *mv, const dsvg_params *p, dsvg_frame *dif, dsvg_frame *inp, const dsvg_frame *ref);
+/* dsv_add_pred bmc.c:333   */ int dsvg_op_add_pred(const dsvg_mv *mv, const dsvg_params *p, dsvg_frame *dif, dsvg_frame *out, const dsvg_frame *ref);
+/* dsv_frame_add bmc.c:304  */ int dsvg_op_frame_add(dsvg_frame *dst, const dsvg_frame *src);
+/* dsv_hme      hme.c:730   */ int dsvg_op_hme(dsvg_hme *hme, int *intra_pct); /* mvf[0..levels] malloc'd, caller frees with free() */
+/* dsv_extend_frame frame.c:263 */ int dsvg_op_extend_frame(dsvg_frame *f);
+/* dsv_extend_frame_luma frame.c:297 */ int dsvg_op_extend_frame_luma(dsvg_frame *f);
+/* dsv_ds2x_frame_luma frame.c:240 */ int dsvg_op_ds2x_frame_luma(dsvg_frame *dst, const dsvg_frame *src);
+/* dsv_frame_avg_luma frame.c:223 */ int dsvg_op_frame_avg_luma(const dsvg_frame *f, int *avg);
+/* dsv_get_quant hzcc.c:77, dsv_lb2 hzcc.c:437: host scalars */
+int dsvg_get_quant(int q, int isP, int level);
+int dsvg_lb2(unsigned n);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. pipeline level -- device-resident, batched
+ * ------------------------------------------------------------------------------------------- */
+typedef struct dsvg_ctx dsvg_ctx;
+
+typedef struct {
+    int width, height, subsamp;
+    int blk_w, blk_h, nblocks_h, nblocks_v;   /* dsv_encoder.c:556-595 */
+    int pyramid_levels;                       /* dsv_encoder.c:602-613 (after auto) */
+    size_t frame_bytes;                       /* tightly packed planar input frame */
+    size_t plane_out_cap[3];                  /* capacity of one packed plane payload */
+} dsvg_geom;
+
+/* n_src_slots source frames (padded + pyramid) and n_recon_slots reconstructions stay resident;
+ * max_jobs = widest batch handed to dsvg_code_pictures / dsvg_analyse in one call. */
+int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsamp,
+                    int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs);
+void dsvg_ctx_destroy(dsvg_ctx *ctx);
+int dsvg_ctx_geom(const dsvg_ctx *ctx, dsvg_geom *g);
+int dsvg_ctx_sync(dsvg_ctx *ctx);
+void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the hipStream_t all pipeline work is enqueued on */
+
+/* device memory helpers for callers that keep the raw clip in HBM (bench.py) */
+int dsvg_dev_alloc(dsvg_ctx *ctx, void **dptr, size_t bytes);
+int dsvg_dev_free(dsvg_ctx *ctx, void *dptr);
+int dsvg_dev_upload(dsvg_ctx *ctx, void *dptr, const void *src, size_t bytes);
+
+/* Tightly packed planar frames -> resident source slots [first_slot, first_slot+n):
+ * copy into the bordered reference layout, replicate borders (dsv_clone_frame/dsv_extend_frame),
+ * build the luma pyramid (mk_pyramid dsv_encoder.c:194-217) and the smallest level's mean luma
+ * (check_scene_change dsv_encoder.c:538-554).  yuv may be a host or a device pointer.  Async. */
+int dsvg_load_frames(dsvg_ctx *ctx, int first_slot, int n, const void *yuv, int yuv_on_device, int with_pyramid);
+int dsvg_get_avg_luma(dsvg_ctx *ctx, int first_slot, int n, int *avg_out);           /* syncs */
+
+/* Hierarchical motion estimation for npairs (current, reference) source-slot pairs
+ * (motion_est dsv_encoder.c:219-254 -> dsv_hme).  mvs_out: npairs * nblocks dsvg_mv on the host. Syncs. */
+int dsvg_analyse(dsvg_ctx *ctx, int npairs, const int *cur_slots, const int *ref_slots, dsvg_mv *mvs_out);
+
+typedef struct {
+    int src_slot;            /* source frame to code */
+    int ref_recon_slot;      /* reconstruction used for prediction, -1 for an I picture */
+    int recon_slot;          /* where to keep this picture's reconstruction, -1 = do not keep */
+    int quant;               /* frame quantiser (quality2quant dsv_encoder.c:165) */
+    const dsvg_mv *mvs;      /* host, nblocks entries (P pictures) */
+    const unsigned char *stable_blocks; /* host, nblocks entries (encode_stable_blocks output) */
+} dsvg_pic_job;
+
+typedef struct {
+    int32_t dc[3];           /* unquantised DC (coefficient [0]) of each plane */
+    uint32_t nruns[3];       /* number of (run,value) pairs */
+    uint32_t nbytes[3];      /* payload length in bytes (bit count rounded up) */
+    const uint8_t *payload[3]; /* host (pinned) pointers, valid until the next dsvg_code_pictures */
+} dsvg_pic_out;
+
+/* Residual coding of njobs pictures in one batch: frame copy, dsv_sub_pred, then per plane
+ * dsv_fwd_sbt / dsv_encode_plane (quantise+dequantise+pack) / dsv_inv_sbt, dsv_frame_add and the
+ * extended reconstruction (encode_one_frame dsv_encoder.c:657-674, encode_picture :518-526).
+ * Enqueues only; results are collected by dsvg_fetch_pictures (which syncs). */
+int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
+int dsvg_fetch_pictures(dsvg_ctx *ctx, int njobs, dsvg_pic_out *outs);
+int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */
+
+/* Decoder side: coefficient (run,value) pairs parsed on the host are scattered + dequantised,
+ * inverse transformed and motion compensated on the device (dsv_dec dsv_decoder.c:379-436). */
+typedef struct {
+    int ref_recon_slot;      /* -1 for an I picture */
+    int recon_slot;          /* output picture slot */
+    int quant;
+    const dsvg_mv *mvs;
+    const unsigned char *stable_blocks;
+    const uint8_t *plane_data[3];   /* host: bytes following the 32-bit plane length */
+    uint32_t plane_len[3];
+} dsvg_dec_job;
+int dsvg_decode_pictures(dsvg_ctx *ctx, int njobs, const dsvg_dec_job *jobs);
+
+/* kernel timing hook for bench.py: HIP-event time (ms) and launch count of the named kernel
+ * family accumulated since the last reset ("sbt_fwd", "sbt_inv", "hzcc", "bmc", "hme", "frame").
+ * Timing is only collected while enabled (it inserts events on the pipeline stream). */
+int dsvg_prof_enable(dsvg_ctx *ctx, int on);
+int dsvg_prof_reset(dsvg_ctx *ctx);
+int dsvg_prof_get(dsvg_ctx *ctx, const char *family, double *ms, long *launches, double *alg_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

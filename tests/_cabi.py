@@ -254,6 +254,44 @@ def load_orc():
     return _libs["orc"]
 
 
+def load_prod():
+    """the product library; fails loudly if it is missing (no fallback)"""
+    if "prod" not in _libs:
+        if not os.path.exists(PROD_SO):
+            raise RuntimeError("product library %s is not built (run python -c 'import __graft_entry__ as g; g.build()')" % PROD_SO)
+        L = C.CDLL(PROD_SO)
+        L.dsvg_last_error.restype = C.c_char_p
+        L.dsvg_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.dsvg_ctx_destroy.argtypes = [C.c_void_p]
+        _libs["prod"] = L
+    return _libs["prod"]
+
+
+def chk(L, rc):
+    if rc != 0:
+        raise RuntimeError("dsvg call failed rc=%d: %s" % (rc, L.dsvg_last_error().decode()))
+
+
+def assert_same(name, got, want, shape=None):
+    """bit-exact comparison with a useful report"""
+    got = np.asarray(got)
+    want = np.asarray(want)
+    assert got.shape == want.shape, "%s: shape %s vs %s" % (name, got.shape, want.shape)
+    if np.array_equal(got, want):
+        return
+    g = got.reshape(-1)
+    w = want.reshape(-1)
+    bad = np.nonzero(g != w)[0]
+    msg = ["%s: %d of %d elements differ" % (name, bad.size, g.size)]
+    for i in bad[:12]:
+        where = str(np.unravel_index(i, shape)) if shape is not None else str(i)
+        msg.append("  at %s: got %s want %s" % (where, g[i], w[i]))
+    if shape is not None and bad.size:
+        ys, xs = np.unravel_index(bad, shape)
+        msg.append("  bbox rows %d..%d cols %d..%d" % (ys.min(), ys.max(), xs.min(), xs.max()))
+    raise AssertionError("\n".join(msg))
+
+
 def gen_clip(w, h, fmt, seed, nframes, style=0, start=0):
     """synthetic clip (nframes, frame_bytes) via the integer generator oracle/orc_gen.c"""
     L = load_orc()
