@@ -1,14 +1,43 @@
 """MI355X-native DSV1 hot path: thin ctypes binding over the C ABI (include/dsvg.h, include/dsv1_api.h).
 
 The product is libdsv1_mi355x.so (HIP kernels for gfx950 + the C session layer).  This module only
-loads it; there is no Python or CPU fallback -- if the library is missing, or no HIP device is
-usable, calls fail loudly."""
+loads it and marshals arguments; there is no Python or CPU fallback -- if the library is missing,
+or no HIP device is usable, calls fail loudly."""
 import ctypes as _C
 import os as _os
+
+import numpy as _np
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
 SO_PATH = _os.path.join(_HERE, "libdsv1_mi355x.so")
 _lib = None
+
+SUBSAMP_444, SUBSAMP_422, SUBSAMP_420, SUBSAMP_411 = 0x0, 0x4, 0x5, 0x8
+MAX_QUALITY = 2047
+
+
+class Meta(_C.Structure):
+    _fields_ = [("width", _C.c_int), ("height", _C.c_int), ("subsamp", _C.c_int), ("fps_num", _C.c_int),
+                ("fps_den", _C.c_int), ("aspect_num", _C.c_int), ("aspect_den", _C.c_int)]
+
+
+class Encoder(_C.Structure):
+    """DSV_ENCODER (dsv_encoder.h:58-110 field order)"""
+    _fields_ = [("quality", _C.c_int), ("gop", _C.c_int), ("do_scd", _C.c_int), ("rc_mode", _C.c_int),
+                ("rc_high_motion_nudge", _C.c_int), ("bitrate", _C.c_uint), ("max_q_step", _C.c_int),
+                ("min_quality", _C.c_int), ("max_quality", _C.c_int), ("min_I_frame_quality", _C.c_int),
+                ("intra_pct_thresh", _C.c_int), ("scene_change_delta", _C.c_int), ("stable_refresh", _C.c_uint),
+                ("pyramid_levels", _C.c_int),
+                ("rc_quant", _C.c_uint), ("bpf_total", _C.c_uint), ("bpf_reset", _C.c_uint), ("bpf_avg", _C.c_int),
+                ("total_P_frame_q", _C.c_int), ("avg_P_frame_q", _C.c_int), ("last_P_frame_over", _C.c_int),
+                ("back_into_range", _C.c_int), ("next_fnum", _C.c_uint32), ("ref", _C.c_void_p), ("vidmeta", Meta),
+                ("prev_link", _C.c_int), ("force_metadata", _C.c_int), ("stability", _C.c_void_p),
+                ("refresh_ctr", _C.c_uint), ("stable_blocks", _C.c_void_p), ("prev_gop", _C.c_uint32),
+                ("prev_avg_luma", _C.c_int)]
+
+
+class Buf(_C.Structure):
+    _fields_ = [("data", _C.POINTER(_C.c_uint8)), ("len", _C.c_uint)]
 
 
 def lib():
@@ -16,6 +45,176 @@ def lib():
     if _lib is None:
         if not _os.path.exists(SO_PATH):
             raise RuntimeError("HIP extension %s is not built; run __graft_entry__.build()" % SO_PATH)
-        _lib = _C.CDLL(SO_PATH)
-        _lib.dsvg_last_error.restype = _C.c_char_p
+        L = _C.CDLL(SO_PATH)
+        L.dsvg_last_error.restype = _C.c_char_p
+        L.dsv1_batch_open.argtypes = [_C.POINTER(_C.c_void_p), _C.POINTER(Encoder), _C.c_int, _C.c_int, _C.c_int]
+        L.dsv1_batch_close.argtypes = [_C.c_void_p]
+        L.dsv1_batch_set_fnum.argtypes = [_C.c_void_p, _C.c_int, _C.c_uint32]
+        L.dsv1_batch_encode.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
+        L.dsv1_batch_eos.argtypes = [_C.c_void_p, _C.c_int, _C.POINTER(Buf)]
+        L.dsv1_concat_gops.argtypes = [_C.POINTER(Buf), _C.c_int, _C.POINTER(Buf)]
+        L.dsv1_batch_ctx.restype = _C.c_void_p
+        L.dsv1_batch_ctx.argtypes = [_C.c_void_p]
+        L.dsv_free.argtypes = [_C.c_void_p]
+        L.estimate_bitrate.restype = _C.c_uint
+        L.estimate_bitrate.argtypes = [_C.c_int, _C.c_int, _C.POINTER(Meta)]
+        L.dsvg_dev_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
+        L.dsvg_dev_free.argtypes = [_C.c_void_p, _C.c_void_p]
+        L.dsvg_dev_upload.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
+        L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
+        L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_int]
+        L.dsvg_prof_reset.argtypes = [_C.c_void_p]
+        L.dsvg_prof_get.argtypes = [_C.c_void_p, _C.c_char_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_long),
+                                    _C.POINTER(_C.c_double)]
+        _lib = L
     return _lib
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("%s failed rc=%d: %s" % (what, rc, lib().dsvg_last_error().decode()))
+
+
+def make_encoder_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1, kbps=0, scd=1, ipct=50, pyrlevels=0, stabref=0,
+                     fps_num=30, fps_den=1):
+    """fill a DSV_ENCODER exactly like the reference CLI does for these flags (dsv_main.c:423-489):
+    rc_mode_cli 0 = ABR, 1 = CRF (CLI numbering); kbps 0 = auto; stabref 0 = auto"""
+    L = lib()
+    e = Encoder()
+    L.dsv_enc_init(_C.byref(e))
+    e.vidmeta = Meta(w, h, fmt, fps_num, fps_den, 1, 1)
+    e.gop = gop
+    e.scene_change_delta = 4
+    e.do_scd = scd
+    e.intra_pct_thresh = ipct
+    e.quality = MAX_QUALITY * qp // 100
+    e.rc_mode = 0 if rc_mode_cli == 1 else 1
+    e.bitrate = kbps * 1024 if kbps else L.estimate_bitrate(e.quality * 100 // MAX_QUALITY, gop, _C.byref(e.vidmeta))
+    if e.rc_mode == 1:
+        e.quality = min(max(e.quality * 3 // 2, 0), MAX_QUALITY)
+    e.max_q_step = MAX_QUALITY // 200
+    e.min_quality = MAX_QUALITY * 1 // 100
+    e.max_quality = MAX_QUALITY
+    e.min_I_frame_quality = MAX_QUALITY * 5 // 100
+    e.rc_high_motion_nudge = 1
+    e.pyramid_levels = pyrlevels
+    e.stable_refresh = stabref if stabref else min(max(gop - 1, 1), 14)
+    return e
+
+
+def _take(buf):
+    data = _C.string_at(buf.data, buf.len) if buf.len else b""
+    if buf.data:
+        lib().dsv_free(_C.cast(buf.data, _C.c_void_p))
+    return data
+
+
+class Batch:
+    """nstreams independent encoder streams, frames_per_call frames each per encode() call"""
+
+    def __init__(self, cfg, nstreams, frames_per_call, device=0):
+        self.L = lib()
+        self.h = _C.c_void_p(None)
+        self.nstreams, self.F = nstreams, frames_per_call
+        _chk(self.L.dsv1_batch_open(_C.byref(self.h), _C.byref(cfg), device, nstreams, frames_per_call), "dsv1_batch_open")
+        self.ctx = self.L.dsv1_batch_ctx(self.h)
+        self._dev = []
+
+    def set_fnum(self, stream, fnum):
+        self.L.dsv1_batch_set_fnum(self.h, stream, fnum)
+
+    def upload(self, clip):
+        """keep a raw clip (numpy uint8, any shape) resident in HBM; returns the device pointer"""
+        a = _np.ascontiguousarray(clip, dtype=_np.uint8)
+        p = _C.c_void_p(None)
+        _chk(self.L.dsvg_dev_alloc(self.ctx, _C.byref(p), a.nbytes), "dsvg_dev_alloc")
+        _chk(self.L.dsvg_dev_upload(self.ctx, p, a.ctypes.data, a.nbytes), "dsvg_dev_upload")
+        self._dev.append(p)
+        return p
+
+    def encode(self, yuv, on_device=False, eos=False):
+        """yuv: numpy [nstreams][F][frame_bytes] (host) or a device pointer from upload();
+        returns one bytes object per stream"""
+        bufs = (Buf * self.nstreams)()
+        if on_device:
+            ptr = yuv
+        else:
+            a = _np.ascontiguousarray(yuv, dtype=_np.uint8)
+            ptr = a.ctypes.data
+        _chk(self.L.dsv1_batch_encode(self.h, ptr, 1 if on_device else 0, bufs), "dsv1_batch_encode")
+        if eos:
+            for s in range(self.nstreams):
+                _chk(self.L.dsv1_batch_eos(self.h, s, _C.byref(bufs[s])), "dsv1_batch_eos")
+        return [_take(bufs[s]) for s in range(self.nstreams)]
+
+    def sync(self):
+        _chk(self.L.dsvg_ctx_sync(self.ctx), "dsvg_ctx_sync")
+
+    def prof(self, enable=True):
+        self.L.dsvg_prof_enable(self.ctx, 1 if enable else 0)
+        self.L.dsvg_prof_reset(self.ctx)
+
+    def prof_get(self, family):
+        ms, n, by = _C.c_double(0), _C.c_long(0), _C.c_double(0)
+        _chk(self.L.dsvg_prof_get(self.ctx, family.encode(), _C.byref(ms), _C.byref(n), _C.byref(by)), "dsvg_prof_get")
+        return ms.value, n.value, by.value
+
+    def close(self):
+        if self.h:
+            for p in self._dev:
+                self.L.dsvg_dev_free(self.ctx, p)
+            self._dev = []
+            self.L.dsv1_batch_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def encode_clip(clip, w, h, fmt, device=0, eos=True, start_fnum=0, **cli):
+    """one serial stream on the GPU: the whole clip in one batch call -> .dsv bytes"""
+    cfg = make_encoder_cfg(w, h, fmt, **cli)
+    n = clip.shape[0]
+    b = Batch(cfg, 1, n, device)
+    try:
+        if start_fnum:
+            b.set_fnum(0, start_fnum)
+        return b.encode(clip.reshape(1, n, -1), eos=eos)[0]
+    finally:
+        b.close()
+
+
+def concat_gops(streams):
+    """join independently encoded closed GOPs exactly as one serial encode would have linked them"""
+    L = lib()
+    arr = (Buf * len(streams))()
+    keep = []
+    for i, s in enumerate(streams):
+        a = _np.frombuffer(s, dtype=_np.uint8).copy()
+        keep.append(a)
+        arr[i].data = a.ctypes.data_as(_C.POINTER(_C.c_uint8))
+        arr[i].len = a.size
+    out = Buf()
+    _chk(L.dsv1_concat_gops(arr, len(streams), _C.byref(out)), "dsv1_concat_gops")
+    return _take(out)
+
+
+def encode_gops(clip, w, h, fmt, gop, device=0, **cli):
+    """GOP-sharded encode: clip (N frames, N % gop == 0) -> N/gop independent closed GOPs in ONE batch,
+    each seeded with its frame number, then joined.  Bit-exact with the serial stream when GOPs are
+    independent (CRF, stable_refresh == gop-1, no forced-intra P frames: SURVEY.md 8e)."""
+    n = clip.shape[0]
+    assert n % gop == 0
+    g = n // gop
+    cfg = make_encoder_cfg(w, h, fmt, gop=gop, **cli)
+    b = Batch(cfg, g, gop, device)
+    try:
+        for s in range(g):
+            b.set_fnum(s, s * gop)
+        parts = b.encode(clip.reshape(g, gop, -1))
+    finally:
+        b.close()
+    return concat_gops(parts)

@@ -19,7 +19,7 @@ struct dsvg_ctx {
     CoefLayout CL;
     SbtGeo3 G;
     McGeo MG;
-    int n_src = 0, n_recon = 0, max_jobs = 0;
+    int n_src = 0, n_recon = 0, max_jobs = 0, out_slots = 0, nwin = 0, win = 0, calls_since_sync = 0;
     Slab src[6], recon, xf, pred;
     int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *nzpos = nullptr, *nzval = nullptr;
     HzChunkSum *chunks = nullptr;
@@ -47,9 +47,7 @@ struct dsvg_ctx {
     int32_t *dec_h = nullptr;        // decoder: parsed (pos,val) staging
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
-    std::vector<uint32_t> dirty;     // bytes of each job/plane payload area that may be non-zero
-    std::vector<int> order;          // device job index -> caller job index of the last batch
-    int last_njobs = 0;
+    std::vector<uint32_t> dirty;     // bytes of each out-slot/plane payload area that may be non-zero
     Prof prof;
 };
 
@@ -82,8 +80,9 @@ template <typename T> static int hmalloc(T **p, size_t n)
 }
 
 extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsamp,
-                               int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs)
+                               int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots)
 {
+    if (out_slots < max_jobs) out_slots = max_jobs;
     if (!out || width < 32 || height < 32 || n_src_slots < 1 || n_recon_slots < 1 || max_jobs < 1) {
         dsvg_set_error("bad ctx_create arguments");
         return DSVG_ERR_ARG;
@@ -95,7 +94,8 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     *out = nullptr;
     c->device = device;
     c->w = width; c->h = height; c->fmt = subsamp;
-    c->n_src = n_src_slots; c->n_recon = n_recon_slots; c->max_jobs = max_jobs;
+    c->n_src = n_src_slots; c->n_recon = n_recon_slots; c->max_jobs = max_jobs; c->out_slots = out_slots;
+    c->nwin = (out_slots + max_jobs - 1) / max_jobs + 1;
     block_geometry(width, height, &c->bw, &c->bh, &c->nbh, &c->nbv);
     c->nblk = c->nbh * c->nbv;
     c->levels = pyramid_levels > 0 ? std::min(pyramid_levels, DSVG_MAX_PYRAMID) : auto_pyramid_levels(width, height, c->nbh, c->nbv);
@@ -142,31 +142,32 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = c->recon.alloc(c->L[0].pitch * (size_t)n_recon_slots + 4096))) return fail(rc);
     if ((rc = c->xf.alloc(c->L[0].pitch * (size_t)max_jobs + 4096))) return fail(rc);
     if ((rc = c->pred.alloc(c->L[0].pitch * (size_t)max_jobs + 4096))) return fail(rc);
-    const size_t J = (size_t)max_jobs;
+    const size_t J = (size_t)max_jobs, O = (size_t)out_slots, S = J * (size_t)c->nwin;
     if ((rc = dmalloc(&c->coef, CL.total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->s3, CL.s3total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->s1, CL.s1total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->nzpos, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->psum, 3 * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->bits, c->bits_per_job * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->stable, (size_t)c->nblk * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->jobs_d, J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->mvf, (size_t)(c->levels + 1) * c->nblk * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->aux_tex, (size_t)c->nblk * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->aux_var, (size_t)c->nblk * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->slots_d, 3 * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->mvf, (size_t)(c->levels + 1) * c->nblk * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->aux_tex, (size_t)c->nblk * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->aux_var, (size_t)c->nblk * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->slots_d, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->luma_sums, (size_t)n_src_slots, true))) return fail(rc);
-    if ((rc = hmalloc(&c->jobs_h, J))) return fail(rc);
-    if ((rc = hmalloc(&c->bits_h, c->bits_per_job * J))) return fail(rc);
-    if ((rc = hmalloc(&c->psum_h, 3 * J))) return fail(rc);
-    if ((rc = hmalloc(&c->mv_h, (size_t)c->nblk * J))) return fail(rc);
-    if ((rc = hmalloc(&c->stable_h, (size_t)c->nblk * J))) return fail(rc);
-    if ((rc = hmalloc(&c->slots_h, 3 * J))) return fail(rc);
+    if ((rc = hmalloc(&c->jobs_h, S))) return fail(rc);
+    if ((rc = hmalloc(&c->bits_h, c->bits_per_job * O))) return fail(rc);
+    if ((rc = hmalloc(&c->psum_h, 3 * O))) return fail(rc);
+    if ((rc = hmalloc(&c->mv_h, (size_t)c->nblk * std::max(S, O)))) return fail(rc);
+    if ((rc = hmalloc(&c->stable_h, (size_t)c->nblk * S))) return fail(rc);
+    if ((rc = hmalloc(&c->slots_h, 3 * std::max(S, O)))) return fail(rc);
     if ((rc = hmalloc(&c->luma_h, (size_t)n_src_slots))) return fail(rc);
-    c->dirty.assign(3 * J, 0);
+    (void)J;
+    c->dirty.assign(3 * O, 0);
     *out = c;
     return DSVG_OK;
 }
@@ -218,6 +219,26 @@ extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t 
 }
 
 // ------------------------------------------------------------------------------------------------
+static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid)
+{
+    const size_t fb = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
+    const double samples = (double)fb * n;
+    c->prof.begin(c->st, FAM_FRAME, samples * (with_pyramid ? 3.33 : 2.0));
+    launch_unpack(c->st, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n);
+    launch_extend(c->st, c->src[0].p, c->L[0], first_slot, n, 3, nullptr);
+    if (with_pyramid) {
+        for (int l = 1; l <= c->levels; l++) {
+            launch_ds2x(c->st, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n);
+            launch_extend(c->st, c->src[l].p, c->L[l], first_slot, n, 1, nullptr);
+        }
+        HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st));
+        launch_luma_sum(c->st, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums);
+    }
+    c->prof.end(c->st);
+    HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+
 extern "C" int dsvg_load_frames(dsvg_ctx *c, int first_slot, int n, const void *yuv, int yuv_on_device, int with_pyramid)
 {
     if (!c || !yuv || n < 1 || first_slot < 0 || first_slot + n > c->n_src) { dsvg_set_error("bad load_frames arguments"); return DSVG_ERR_ARG; }
@@ -233,20 +254,24 @@ extern "C" int dsvg_load_frames(dsvg_ctx *c, int first_slot, int n, const void *
         HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st));
         dsrc = c->yuv_stage;
     }
-    const double samples = (double)fb * n;
-    c->prof.begin(c->st, FAM_FRAME, samples * (with_pyramid ? 3.33 : 2.0));
-    launch_unpack(c->st, dsrc, fb, c->src[0].p, c->L[0], first_slot, n);
-    launch_extend(c->st, c->src[0].p, c->L[0], first_slot, n, 3, nullptr);
-    if (with_pyramid) {
-        for (int l = 1; l <= c->levels; l++) {
-            launch_ds2x(c->st, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n);
-            launch_extend(c->st, c->src[l].p, c->L[l], first_slot, n, 1, nullptr);
-        }
-        HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st));
-        launch_luma_sum(c->st, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums);
-    }
-    c->prof.end(c->st);
-    HIPCHK(hipGetLastError());
+    return load_core(c, first_slot, n, dsrc, fb, with_pyramid);
+}
+
+extern "C" int dsvg_load_frames_strided(dsvg_ctx *c, int first_slot, int n, const void *yuv_dev, size_t frame_pitch, int with_pyramid)
+{
+    if (!c || !yuv_dev || n < 1 || first_slot < 0 || first_slot + n > c->n_src) { dsvg_set_error("bad load_frames arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    return load_core(c, first_slot, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid);
+}
+
+extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *sums_out)
+{
+    if (!c || !sums_out || first_slot < 0 || first_slot + n > c->n_src) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    c->calls_since_sync = 0;
+    memcpy(sums_out, c->luma_h, sizeof(unsigned) * n);
     return DSVG_OK;
 }
 
@@ -263,19 +288,21 @@ extern "C" int dsvg_get_avg_luma(dsvg_ctx *c, int first_slot, int n, int *avg_ou
 
 extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const int *ref_slots, dsvg_mv *mvs_out)
 {
-    if (!c || npairs < 1 || npairs > c->max_jobs || !cur_slots || !ref_slots || !mvs_out) { dsvg_set_error("bad analyse arguments"); return DSVG_ERR_ARG; }
+    if (!c || npairs < 1 || npairs > c->out_slots || !cur_slots || !ref_slots || !mvs_out) { dsvg_set_error("bad analyse arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->st));       // slots_h / mv_h staging is shared with code_pictures
+    c->calls_since_sync = 0;
     for (int i = 0; i < npairs; i++) {
         if (cur_slots[i] < 0 || cur_slots[i] >= c->n_src || ref_slots[i] < 0 || ref_slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
         c->slots_h[i] = cur_slots[i];
-        c->slots_h[c->max_jobs + i] = ref_slots[i];
+        c->slots_h[c->out_slots + i] = ref_slots[i];
     }
-    HIPCHK(hipMemcpyAsync(c->slots_d, c->slots_h, sizeof(int) * 2 * c->max_jobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d, c->slots_h, sizeof(int) * 2 * c->out_slots, hipMemcpyHostToDevice, c->st));
     const size_t per = (size_t)(c->levels + 1) * c->nblk;
     HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st));
     HmeArgs A; memset(&A, 0, sizeof(A));
     for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
-    A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->max_jobs;
+    A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
     c->prof.begin(c->st, FAM_HME, (double)npairs * c->w * c->h * 2.67);
@@ -284,6 +311,7 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     HIPCHK(hipMemcpy2DAsync(c->mv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
                             (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
+    c->calls_since_sync = 0;
     HIPCHK(hipGetLastError());
     memcpy(mvs_out, c->mv_h, (size_t)npairs * c->nblk * sizeof(DMV));
     return DSVG_OK;
@@ -333,7 +361,7 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n)
         c->prof.end(c->st);
     }
     c->prof.begin(c->st, FAM_FRAME, 0.0);
-    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->max_jobs);
+    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots);
     c->prof.end(c->st);
     return DSVG_OK;
 }
@@ -342,37 +370,47 @@ extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jo
 {
     if (!c || !jobs || njobs < 1 || njobs > c->max_jobs) { dsvg_set_error("bad code_pictures arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
+    // pinned staging is a ring of nwin windows (one per call); never lap the device
+    if (c->calls_since_sync >= c->nwin - 1) { HIPCHK(hipStreamSynchronize(c->st)); c->calls_since_sync = 0; }
+    const int win = c->win;
+    c->win = (c->win + 1) % c->nwin;
+    c->calls_since_sync++;
+    JobDev *jh = c->jobs_h + (size_t)win * c->max_jobs;
+    DMV *mvh = c->mv_h + (size_t)win * c->max_jobs * c->nblk;
+    uint8_t *sth = c->stable_h + (size_t)win * c->max_jobs * c->nblk;
+    int *slh = c->slots_h + (size_t)win * c->max_jobs;
     // device order: intra jobs first, then inter jobs (kernels are specialised per picture type)
-    c->order.clear();
-    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) c->order.push_back(i);
-    const int nI = (int)c->order.size();
-    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) c->order.push_back(i);
-    c->last_njobs = njobs;
-    HIPCHK(hipStreamSynchronize(c->st));           // pinned staging below is reused between batches
+    std::vector<int> order;
+    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) order.push_back(i);
+    const int nI = (int)order.size();
+    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) order.push_back(i);
     for (int t = 0; t < njobs; t++) {
-        const dsvg_pic_job &j = jobs[c->order[t]];
+        const dsvg_pic_job &j = jobs[order[t]];
         const int isP = j.ref_recon_slot >= 0;
         if (j.src_slot < 0 || j.src_slot >= c->n_src || j.ref_recon_slot >= c->n_recon || j.recon_slot >= c->n_recon ||
-            !j.stable_blocks || (isP && !j.mvs)) { dsvg_set_error("bad picture job %d", c->order[t]); return DSVG_ERR_ARG; }
-        JobDev &jb = c->jobs_h[t];
+            j.out_slot < 0 || j.out_slot >= c->out_slots || !j.stable_blocks || (isP && !j.mvs)) {
+            dsvg_set_error("bad picture job %d", order[t]); return DSVG_ERR_ARG;
+        }
+        JobDev &jb = jh[t];
         fill_job(c, jb, t, isP, j.quant);
+        jb.psum = c->psum + (size_t)j.out_slot * 3;
+        jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
         jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
         jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
         jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;
-        c->slots_h[2 * c->max_jobs + t] = j.recon_slot;
-        memcpy(c->stable_h + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
-        if (isP) memcpy(c->mv_h + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
-    }
-    HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->stable, c->stable_h, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->max_jobs, c->slots_h + 2 * c->max_jobs, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
-    for (int t = 0; t < njobs; t++)
+        slh[t] = j.recon_slot;
+        memcpy(sth + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
+        if (isP) memcpy(mvh + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
         for (int p = 0; p < 3; p++) {
-            uint32_t &d = c->dirty[3 * t + p];
-            if (d) HIPCHK(hipMemsetAsync(c->bits + (size_t)t * c->bits_per_job + c->bits_off[p], 0, std::min<size_t>(d + 16, c->bits_cap[p] + 256), c->st));
-            d = 0;
+            uint32_t &d = c->dirty[3 * (size_t)j.out_slot + p];
+            if (d) HIPCHK(hipMemsetAsync(jb.bits + c->bits_off[p], 0, std::min<size_t>((size_t)d + 16, c->bits_cap[p] + 256), c->st));
+            d = (uint32_t)c->bits_cap[p];                 // unknown until fetched: assume fully dirty
         }
+    }
+    HIPCHK(hipMemcpyAsync(c->jobs_d, jh, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->stable, sth, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->mvs, mvh, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, slh, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     const double smp = (double)c->CL.total;
     if (nI > 0) {
         c->prof.begin(c->st, FAM_SBT_FWD, smp * nI * 5.0);
@@ -394,34 +432,44 @@ extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jo
     launch_hz_encode(c->st, c->jobs_d, njobs, c->max_chunks);
     c->prof.end(c->st);
     OPCHK(enqueue_recon(c, nI, njobs));
-    HIPCHK(hipMemcpyAsync(c->psum_h, c->psum, sizeof(HzPlaneSum) * 3 * njobs, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipGetLastError());
     return DSVG_OK;
 }
 
-extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int njobs, dsvg_pic_out *outs)
+extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsvg_pic_out *outs)
 {
-    if (!c || !outs || njobs != c->last_njobs) { dsvg_set_error("fetch_pictures does not match the last batch"); return DSVG_ERR_ARG; }
+    if (!c || !outs || !out_slots || n < 1) { dsvg_set_error("bad fetch_pictures arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+        if (out_slots[i] < 0 || out_slots[i] >= c->out_slots) { dsvg_set_error("out slot out of range"); return DSVG_ERR_ARG; }
+    // plane summaries first (sizes), then exactly the used payload bytes
+    int lo = out_slots[0], hi = out_slots[0];
+    for (int i = 1; i < n; i++) { lo = std::min(lo, out_slots[i]); hi = std::max(hi, out_slots[i]); }
+    HIPCHK(hipMemcpyAsync(c->psum_h + 3 * (size_t)lo, c->psum + 3 * (size_t)lo, sizeof(HzPlaneSum) * 3 * (size_t)(hi - lo + 1),
+                          hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
+    c->calls_since_sync = 0;
     HIPCHK(hipGetLastError());
-    for (int t = 0; t < njobs; t++)
+    for (int i = 0; i < n; i++) {
+        const int o = out_slots[i];
         for (int p = 0; p < 3; p++) {
-            const HzPlaneSum &ps = c->psum_h[3 * t + p];
-            if (ps.overflow) { dsvg_set_error("packed plane %d of job %d exceeds %zu bytes", p, c->order[t], c->bits_cap[p]); return DSVG_ERR_OVERFLOW; }
+            const HzPlaneSum &ps = c->psum_h[3 * (size_t)o + p];
+            if (ps.overflow) { dsvg_set_error("packed plane %d of out slot %d exceeds %zu bytes", p, o, c->bits_cap[p]); return DSVG_ERR_OVERFLOW; }
             const size_t nb = (size_t)((ps.total_bits + 7) >> 3);
-            c->dirty[3 * t + p] = (uint32_t)nb;
-            if (nb) HIPCHK(hipMemcpyAsync(c->bits_h + (size_t)t * c->bits_per_job + c->bits_off[p],
-                                          c->bits + (size_t)t * c->bits_per_job + c->bits_off[p], nb, hipMemcpyDeviceToHost, c->st));
+            c->dirty[3 * (size_t)o + p] = (uint32_t)nb;
+            if (nb) HIPCHK(hipMemcpyAsync(c->bits_h + (size_t)o * c->bits_per_job + c->bits_off[p],
+                                          c->bits + (size_t)o * c->bits_per_job + c->bits_off[p], nb, hipMemcpyDeviceToHost, c->st));
         }
+    }
     HIPCHK(hipStreamSynchronize(c->st));
-    for (int t = 0; t < njobs; t++) {
-        dsvg_pic_out &o = outs[c->order[t]];
+    for (int i = 0; i < n; i++) {
+        const int o = out_slots[i];
+        dsvg_pic_out &po = outs[i];
         for (int p = 0; p < 3; p++) {
-            const HzPlaneSum &ps = c->psum_h[3 * t + p];
-            o.dc[p] = ps.dc; o.nruns[p] = ps.nruns;
-            o.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
-            o.payload[p] = c->bits_h + (size_t)t * c->bits_per_job + c->bits_off[p];
+            const HzPlaneSum &ps = c->psum_h[3 * (size_t)o + p];
+            po.dc[p] = ps.dc; po.nruns[p] = ps.nruns;
+            po.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
+            po.payload[p] = c->bits_h + (size_t)o * c->bits_per_job + c->bits_off[p];
         }
     }
     return DSVG_OK;
@@ -465,6 +513,7 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     const int nI = (int)ord.size();
     for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) ord.push_back(i);
     HIPCHK(hipStreamSynchronize(c->st));
+    c->calls_since_sync = 0;
     if (!c->dec_h) OPCHK(hmalloc(&c->dec_h, 2 * c->nz_total * (size_t)c->max_jobs));
     std::vector<int> cuts((size_t)njobs * 3 * 4, 0);
     const CoefLayout &CL = c->CL;
@@ -478,7 +527,7 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         fill_job(c, jb, t, isP, j.quant);
         jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
         jb.recon = c->recon.p + (size_t)j.recon_slot * c->L[0].pitch;
-        c->slots_h[2 * c->max_jobs + t] = j.recon_slot;
+        c->slots_h[t] = j.recon_slot;
         memcpy(c->stable_h + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
         if (isP) memcpy(c->mv_h + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
         for (int p = 0; p < 3; p++) {
@@ -517,7 +566,7 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable, c->stable_h, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->max_jobs, c->slots_h + 2 * c->max_jobs, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemsetAsync(c->coef, 0, CL.total * (size_t)njobs * sizeof(int32_t), c->st));
     for (int t = 0; t < njobs; t++)
         for (int p = 0; p < 3; p++) {

@@ -1,0 +1,655 @@
+/* dsv1_enc.c -- encoder session layer in plain C on top of the device pipeline (include/dsvg.h).
+ *
+ * Keeps the reference's semantics for everything that is NOT per-pixel work: GOP / forced-intra /
+ * scene-change decisions (dsv_encoder.c:538-554,624-653), CRF/ABR quantiser control
+ * (dsv_encoder.c:70-168,816-848), the stability accumulators and side-info coding
+ * (dsv_encoder.c:257-408), packet framing and link offsets (dsv_encoder.c:171-192,410-536,766-778).
+ *
+ * Structure differs from the reference on purpose: frames live in HBM, and all source-only analysis
+ * (padding, pyramid, mean luma, motion estimation -- SURVEY.md fact 3) of a whole batch
+ * (streams x frames) runs first, then the reconstruction-dependent residual chain is enqueued frame
+ * step by frame step across all streams without host synchronisation (CRF), and packets are
+ * assembled once at the end.  ABR needs each packet's size before the next quantiser, so it runs
+ * the same code one frame step at a time. */
+#include <stdio.h>
+#include "dsv1_host.h"
+
+typedef struct {
+    DSV_FNUM fnum;
+    int gop_start, is_ref, has_ref, forced_intra, isP, quant;
+    int cur_slot, ref_slot, out_slot;
+    DSV_MV *mvs;
+    unsigned char *stable;
+    uint8_t *prefix;            /* packet bytes up to (not including) the 11-bit quantiser */
+    unsigned prefix_len;
+} pic_t;
+
+struct dsv1_batch {
+    dsvg_ctx *ctx;
+    dsvg_geom g;
+    int nstreams, F, own_enc, ring, nblk, prefix_cap, small_w, small_h;
+    DSV_ENCODER *enc;
+    pic_t *pics;
+    DSV_MV *mvpool;
+    unsigned char *stabpool;
+    uint8_t *prefixpool;
+    void *yuv_dev;
+    size_t yuv_dev_bytes;
+    int *slots_cur, *slots_ref, *pair_pic, *out_slots;
+    unsigned *luma;
+    DSV_MV *mv_tmp;
+    dsvg_pic_job *jobs;
+    dsvg_pic_out *outs;
+    uint8_t *pkt;
+    size_t pkt_cap;
+};
+
+static int slot_of(const dsv1_batch *b, int s, int k) { return ((b->ring + k) % (b->F + 1)) * b->nstreams + s; }
+
+void *dsv1_batch_ctx(dsv1_batch *b) { return b ? (void *)b->ctx : NULL; }
+
+void dsv1_batch_close(dsv1_batch *b)
+{
+    if (!b) return;
+    if (b->yuv_dev) dsvg_dev_free(b->ctx, b->yuv_dev);
+    if (b->ctx) dsvg_ctx_destroy(b->ctx);
+    if (b->own_enc && b->enc) {
+        int s;
+        for (s = 0; s < b->nstreams; s++) {
+            if (b->enc[s].stability) dsv_free(b->enc[s].stability);
+            if (b->enc[s].stable_blocks) dsv_free(b->enc[s].stable_blocks);
+        }
+        free(b->enc);
+    }
+    free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
+    free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
+    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->pkt);
+    free(b);
+}
+
+static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int device, int nstreams, int F)
+{
+    dsv1_batch *b;
+    const DSV_META *m = &encs[0].vidmeta;
+    int rc, i, np;
+    if (!out || nstreams < 1 || F < 1) return DSVG_ERR_ARG;
+    b = (dsv1_batch *)calloc(1, sizeof(*b));
+    b->nstreams = nstreams; b->F = F; b->enc = encs; b->own_enc = own;
+    np = nstreams * F;
+    rc = dsvg_ctx_create(&b->ctx, device, m->width, m->height, m->subsamp, encs[0].pyramid_levels,
+                         (F + 1) * nstreams, nstreams, nstreams, np);
+    if (rc) { b->enc = NULL; dsv1_batch_close(b); return rc; }       /* the caller still owns encs */
+    dsvg_ctx_geom(b->ctx, &b->g);
+    b->nblk = b->g.nblocks_h * b->g.nblocks_v;
+    b->small_w = (m->width + (1 << b->g.pyramid_levels) - 1) >> b->g.pyramid_levels;
+    b->small_h = (m->height + (1 << b->g.pyramid_levels) - 1) >> b->g.pyramid_levels;
+    b->prefix_cap = 128 + b->nblk * 24;
+    b->pics = (pic_t *)calloc((size_t)np, sizeof(pic_t));
+    b->mvpool = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
+    b->stabpool = (unsigned char *)calloc((size_t)np * b->nblk, 1);
+    b->prefixpool = (uint8_t *)calloc((size_t)np, (size_t)b->prefix_cap);
+    b->slots_cur = (int *)calloc((size_t)np, sizeof(int));
+    b->slots_ref = (int *)calloc((size_t)np, sizeof(int));
+    b->pair_pic = (int *)calloc((size_t)np, sizeof(int));
+    b->out_slots = (int *)calloc((size_t)np, sizeof(int));
+    b->luma = (unsigned *)calloc((size_t)(F + 1) * nstreams, sizeof(unsigned));
+    b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
+    b->jobs = (dsvg_pic_job *)calloc((size_t)nstreams, sizeof(dsvg_pic_job));
+    b->outs = (dsvg_pic_out *)calloc((size_t)np, sizeof(dsvg_pic_out));
+    b->pkt_cap = (size_t)b->prefix_cap + b->g.plane_out_cap[0] + 2 * b->g.plane_out_cap[1] + 256;
+    b->pkt = (uint8_t *)malloc(b->pkt_cap);
+    for (i = 0; i < np; i++) {
+        b->pics[i].mvs = b->mvpool + (size_t)i * b->nblk;
+        b->pics[i].stable = b->stabpool + (size_t)i * b->nblk;
+        b->pics[i].prefix = b->prefixpool + (size_t)i * b->prefix_cap;
+    }
+    *out = b;
+    return DSVG_OK;
+}
+
+int dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int nstreams, int frames_per_call)
+{
+    DSV_ENCODER *encs;
+    int s, rc;
+    if (!cfg || nstreams < 1) return DSVG_ERR_ARG;
+    encs = (DSV_ENCODER *)calloc((size_t)nstreams, sizeof(DSV_ENCODER));
+    for (s = 0; s < nstreams; s++) {
+        encs[s] = *cfg;
+        encs[s].ref = NULL; encs[s].stability = NULL; encs[s].stable_blocks = NULL;
+        dsv_enc_start(&encs[s]);
+    }
+    rc = batch_open_on(out, encs, 1, device, nstreams, frames_per_call);
+    if (rc) free(encs);
+    return rc;
+}
+
+void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum)
+{
+    if (b && stream >= 0 && stream < b->nstreams) b->enc[stream].next_fnum = next_fnum;
+}
+
+/* ---- rate control (quality2quant dsv_encoder.c:70-168) ------------------------------------------ */
+static int pick_quant(DSV_ENCODER *e, int isP, int forced_intra)
+{
+    int q = (int)e->rc_quant;
+    if (e->rc_mode != DSV_RATE_CONTROL_CRF) {
+        const DSV_META *vm = &e->vidmeta;
+        int fps = (vm->fps_num << 5) / vm->fps_den, need, bpf, dir, delta, nudged = 0, cap, low_p, minq;
+        if (fps == 0) fps = 1;
+        need = (int)(((e->bitrate << 5) / (unsigned)fps) >> 3);
+        bpf = e->bpf_avg ? e->bpf_avg : need;
+        dir = (bpf - need) > 0 ? -1 : 1;
+        delta = (abs(bpf - need) << 9) / need;
+        if (dir == 1) delta *= 2;
+        if (e->rc_high_motion_nudge) {
+            if (isP && e->last_P_frame_over) { delta = (delta + 1) * 2; dir = -1; nudged = 1; }
+            else if (e->back_into_range)     { delta = (delta + 1) * 2; dir = 1;  nudged = 1; }
+        }
+        delta = (q * delta) >> 9;
+        e->max_q_step = CLAMPI(e->max_q_step, 1, DSV_MAX_QUALITY);
+        cap = nudged ? e->max_q_step * 16 : e->max_q_step;
+        if (delta > cap) delta = cap;
+        q += delta * dir;
+        low_p = CLAMPI(e->avg_P_frame_q - DSV_QUALITY_PERCENT(4), e->min_quality, e->max_quality);
+        minq = isP ? low_p : e->min_I_frame_quality;
+        if (forced_intra) {
+            if (q < DSV_QUALITY_PERCENT(60)) q += DSV_QUALITY_PERCENT(15);
+            else if (q < DSV_QUALITY_PERCENT(70)) q += DSV_QUALITY_PERCENT(8);
+            else if (q < DSV_QUALITY_PERCENT(75)) q += DSV_QUALITY_PERCENT(3);
+            q = CLAMPI(q, 0, e->max_quality - DSV_QUALITY_PERCENT(5));
+        }
+        q = CLAMPI(q, minq, e->max_quality);
+        q = CLAMPI(q, 0, DSV_MAX_QUALITY);
+    } else {
+        q = e->quality;
+    }
+    e->rc_quant = (unsigned)q;
+    return DSV_MAX_QUALITY - ((DSV_MAX_QUALITY - 5) * q / DSV_MAX_QUALITY);
+}
+
+static void rc_after_packet(DSV_ENCODER *e, int isP, unsigned pkt_len)        /* dsv_encoder.c:816-848 */
+{
+    if (e->rc_mode == DSV_RATE_CONTROL_CRF) return;
+    e->bpf_total += pkt_len;
+    e->bpf_reset++;
+    if (isP) {
+        unsigned fps, need;
+        int under, over;
+        e->total_P_frame_q += (int)e->rc_quant;
+        e->avg_P_frame_q = (int)((unsigned)e->total_P_frame_q / e->bpf_reset);
+        fps = (unsigned)(e->vidmeta.fps_num << 5) / (unsigned)e->vidmeta.fps_den;
+        if (fps == 0) fps = 1;
+        need = ((e->bitrate << 5) / fps) >> 3;
+        under = pkt_len < (need * 3 / 4);
+        need = need * 7 / 8;
+        over = pkt_len > need;
+        e->back_into_range = (e->last_P_frame_over && under);
+        e->last_P_frame_over = over;
+    } else {
+        e->last_P_frame_over = 0;
+        e->back_into_range = 0;
+    }
+    e->bpf_avg = (int)(e->bpf_total / e->bpf_reset);
+    if (e->bpf_reset >= 256) {
+        e->bpf_total = (unsigned)e->bpf_avg;
+        e->total_P_frame_q = (int)((unsigned)e->total_P_frame_q / e->bpf_reset);
+        e->bpf_reset = 1;
+    }
+}
+
+/* ---- side information --------------------------------------------------------------------------- */
+static void write_pkt_hdr(bitw *w, int type)
+{
+    bw_bits(w, 8, 'D'); bw_bits(w, 8, 'S'); bw_bits(w, 8, 'V'); bw_bits(w, 8, '1');
+    bw_bits(w, 8, 0);
+    bw_bits(w, 8, (unsigned)type);
+    bw_bits(w, 32, 0);
+    bw_bits(w, 32, 0);
+}
+
+/* stability flags of one picture: updates the per-stream accumulators in coding order
+ * (encode_stable_blocks dsv_encoder.c:330-408) and appends the ZBRLE block to the packet prefix */
+static void stability_pass(DSV_ENCODER *e, pic_t *pc, int nblk, bitw *w, uint8_t *tmp)
+{
+    zrle z;
+    int i, div, bytes;
+    memset(tmp, 0, (size_t)nblk * 4 + 16);
+    zr_init(&z, tmp);
+    if (e->refresh_ctr >= e->stable_refresh) {
+        e->refresh_ctr = 0;
+        memset(e->stability, 0, sizeof(*e->stability) * (size_t)nblk);
+    }
+    div = (int)e->refresh_ctr;
+    if (div <= 0) div = 1;
+    for (i = 0; i < nblk; i++) {
+        int stable = 0, intra = 0;
+        if (pc->isP) {
+            const DSV_MV *mv = &pc->mvs[i];
+            if (mv->mode == 0) {
+                e->stability[i].x += abs(mv->u.mv.x) >> 2;
+                e->stability[i].y += abs(mv->u.mv.y) >> 2;
+                stable = mv->high_detail;
+                stable |= (e->stability[i].x / div == 0 && e->stability[i].y / div == 0 && !mv->lo_tex && !mv->lo_var);
+            } else {
+                intra = 1;
+            }
+            if (mv->lo_tex || mv->lo_var) {
+                e->stability[i].x = 0x3fff;
+                e->stability[i].y = 0x3fff;
+            }
+        } else {
+            stable = (e->stability[i].x / div == 0 && e->stability[i].y / div == 0);
+        }
+        e->stable_blocks[i] = (unsigned char)(stable | (intra << 1));
+        zr_put(&z, e->stable_blocks[i] & 1);
+    }
+    memcpy(pc->stable, e->stable_blocks, (size_t)nblk);
+    bw_align(w);
+    bytes = zr_end(&z);
+    bw_ueg(w, (unsigned)bytes);
+    bw_align(w);
+    bw_bytes_in(w, tmp, (unsigned)bytes);
+}
+
+/* block modes (ZBRLE), MV residuals against the neighbour predictor (SEG), intra sub-block masks
+ * (encode_motion dsv_encoder.c:257-327) */
+static void motion_pass(const dsv1_batch *b, pic_t *pc, bitw *w, uint8_t *tmp)
+{
+    const int nbh = b->g.nblocks_h, nbv = b->g.nblocks_v;
+    const size_t cap = (size_t)b->nblk * 8 + 64;
+    bitw sub[4];
+    zrle modes;
+    DSV_PARAMS prm;
+    int i, j, k;
+    memset(tmp, 0, cap * 4);
+    for (k = 0; k < 4; k++) bw_init(&sub[k], tmp + cap * k);
+    zr_init(&modes, tmp);
+    memset(&prm, 0, sizeof(prm));
+    prm.nblocks_h = nbh; prm.nblocks_v = nbv;
+    for (j = 0; j < nbv; j++)
+        for (i = 0; i < nbh; i++) {
+            DSV_MV *mv = &pc->mvs[i + j * nbh];
+            zr_put(&modes, mv->mode);
+            if (mv->mode == 0) {
+                int px, py;
+                dsv_movec_pred(pc->mvs, &prm, i, j, &px, &py);
+                bw_seg(&sub[1], mv->u.mv.x - px);
+                bw_seg(&sub[2], mv->u.mv.y - py);
+            } else if (mv->submask == 0xF) {
+                bw_bit(&sub[3], 1);
+            } else {
+                bw_bit(&sub[3], 0);
+                bw_bits(&sub[3], 4, mv->submask);
+            }
+        }
+    for (k = 0; k < 4; k++) {
+        int bytes;
+        bw_align(w);
+        if (k == 0) bytes = zr_end(&modes);
+        else { bw_align(&sub[k]); bytes = (int)bw_bytes(&sub[k]); }
+        bw_ueg(w, (unsigned)bytes);
+        bw_align(w);
+        bw_bytes_in(w, tmp + cap * k, (unsigned)bytes);
+    }
+}
+
+static unsigned write_meta_packet(const DSV_ENCODER *e, uint8_t *buf)       /* encode_metadata :427-461 */
+{
+    bitw w;
+    const DSV_META *m = &e->vidmeta;
+    unsigned n;
+    memset(buf, 0, 64);
+    bw_init(&w, buf);
+    write_pkt_hdr(&w, DSV_PT_META);
+    bw_ueg(&w, (unsigned)m->width); bw_ueg(&w, (unsigned)m->height); bw_ueg(&w, (unsigned)m->subsamp);
+    bw_ueg(&w, (unsigned)m->fps_num); bw_ueg(&w, (unsigned)m->fps_den);
+    bw_ueg(&w, (unsigned)m->aspect_num); bw_ueg(&w, (unsigned)m->aspect_den);
+    bw_align(&w);
+    n = bw_bytes(&w);
+    put_be32(buf + DSV_PACKET_NEXT_OFFSET, n);
+    return n;
+}
+
+static void link_packet(DSV_ENCODER *e, uint8_t *pkt, unsigned len, int eos)   /* set_link_offsets :171-192 */
+{
+    const unsigned next = eos ? 0 : len;
+    put_be32(pkt + DSV_PACKET_PREV_OFFSET, (unsigned)e->prev_link);
+    put_be32(pkt + DSV_PACKET_NEXT_OFFSET, next);
+    e->prev_link = (int)next;
+}
+
+/* picture packet = prefix + quantiser + three framed planes (encode_picture :518-536,
+ * dsv_encode_plane hzcc.c:449-476); then metadata-first emission and RC statistics (dsv_enc :804-853) */
+static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV_BUF *out)
+{
+    DSV_ENCODER *e = &b->enc[s];
+    bitw w;
+    unsigned len;
+    int p;
+    size_t need = (size_t)pc->prefix_len + 64;
+    for (p = 0; p < 3; p++) need += po->nbytes[p] + 32;
+    if (need > b->pkt_cap) { b->pkt_cap = need * 2; b->pkt = (uint8_t *)realloc(b->pkt, b->pkt_cap); }
+    memset(b->pkt, 0, need);
+    memcpy(b->pkt, pc->prefix, pc->prefix_len);
+    bw_init(&w, b->pkt);
+    w.pos = pc->prefix_len * 8;
+    bw_bits(&w, 11, (unsigned)pc->quant);
+    for (p = 0; p < 3; p++) {
+        unsigned startp, endp;
+        bw_align(&w);
+        startp = bw_bytes(&w);
+        bw_bits(&w, 32, 0);
+        bw_seg(&w, po->dc[p]);
+        bw_align(&w);
+        bw_bits(&w, 32, po->nruns[p]);
+        bw_align(&w);
+        bw_bytes_in(&w, po->payload[p], po->nbytes[p]);
+        bw_bits(&w, 8, 0x55);
+        bw_align(&w);
+        endp = bw_bytes(&w);
+        put_be32(b->pkt + startp, endp - startp - 4);
+    }
+    bw_align(&w);
+    len = bw_bytes(&w);
+
+    if (pc->gop_start) {
+        uint8_t mb[64];
+        const unsigned n = write_meta_packet(e, mb);
+        if (dsv1_buf_append(out, mb, n)) return DSVG_ERR_ARG;
+    }
+    rc_after_packet(e, pc->isP, len);
+    link_packet(e, b->pkt, len, 0);
+    return dsv1_buf_append(out, b->pkt, len) ? DSVG_ERR_ARG : DSVG_OK;
+}
+
+int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
+{
+    int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0;
+    size_t fb;
+    const DSV_ENCODER *e0;
+    const uint8_t *dyuv = (const uint8_t *)yuv;
+    uint8_t *tmp;
+
+    if (!b || !yuv || !out) return DSVG_ERR_ARG;
+    S = b->nstreams; F = b->F; nblk = b->nblk; fb = b->g.frame_bytes;
+    e0 = &b->enc[0];
+    with_pyr = e0->gop != DSV_GOP_INTRA;
+    if (!yuv_on_device) {
+        const size_t total = fb * (size_t)S * F;
+        if (b->yuv_dev_bytes < total) {
+            if (b->yuv_dev) dsvg_dev_free(b->ctx, b->yuv_dev);
+            b->yuv_dev = NULL;
+            if ((rc = dsvg_dev_alloc(b->ctx, &b->yuv_dev, total))) return rc;
+            b->yuv_dev_bytes = total;
+        }
+        if ((rc = dsvg_dev_upload(b->ctx, b->yuv_dev, yuv, total))) return rc;
+        dyuv = (const uint8_t *)b->yuv_dev;
+    }
+    /* 1. source-only preparation for every frame: bordered layout, pyramid, mean luma */
+    for (k = 1; k <= F; k++)
+        if ((rc = dsvg_load_frames_strided(b->ctx, slot_of(b, 0, k), S, dyuv + (size_t)(k - 1) * fb, fb * F, with_pyr)))
+            return rc;
+    if (with_pyr && e0->do_scd)
+        if ((rc = dsvg_get_luma_sums(b->ctx, 0, (F + 1) * S, b->luma))) return rc;
+
+    /* 2. per stream, in coding order: GOP / scene-change decisions; collect ME pairs */
+    for (s = 0; s < S; s++) {
+        DSV_ENCODER *e = &b->enc[s];
+        if (!e->stability) {
+            e->stability = (struct DSV_STAB_ACC *)dsv_alloc((int)(sizeof(*e->stability) * nblk));
+            e->stable_blocks = (unsigned char *)dsv_alloc(nblk);
+        }
+        if (e->pyramid_levels == 0) e->pyramid_levels = b->g.pyramid_levels;
+        for (t = 0; t < F; t++) {
+            pic_t *pc = &b->pics[s * F + t];
+            pc->fnum = e->next_fnum++;
+            pc->cur_slot = slot_of(b, s, t + 1);
+            pc->ref_slot = slot_of(b, s, t);
+            pc->out_slot = t * S + s;
+            pc->gop_start = 0; pc->forced_intra = 0;
+            if (e->force_metadata || (DSV_FNUM)(e->prev_gop + (DSV_FNUM)e->gop) <= pc->fnum) {
+                pc->gop_start = 1;
+                e->prev_gop = pc->fnum;
+                e->force_metadata = 0;
+            }
+            if (e->gop == DSV_GOP_INTRA) {
+                pc->is_ref = 0; pc->has_ref = 0;
+            } else {
+                pc->is_ref = 1;
+                pc->has_ref = !pc->gop_start;
+                if (e->do_scd) {
+                    const int al = (int)b->luma[pc->cur_slot] / (b->small_w * b->small_h);
+                    if (abs(e->prev_avg_luma - al) > e->scene_change_delta) { pc->has_ref = 0; pc->forced_intra = 1; }
+                    e->prev_avg_luma = al;
+                }
+            }
+            if (pc->has_ref) {
+                b->slots_cur[npairs] = pc->cur_slot;
+                b->slots_ref[npairs] = pc->ref_slot;
+                b->pair_pic[npairs] = s * F + t;
+                npairs++;
+            }
+        }
+    }
+    /* 3. motion estimation for every inter candidate of the batch in one go */
+    if (npairs) {
+        if ((rc = dsvg_analyse(b->ctx, npairs, b->slots_cur, b->slots_ref, (dsvg_mv *)b->mv_tmp))) return rc;
+        for (k = 0; k < npairs; k++)
+            memcpy(b->pics[b->pair_pic[k]].mvs, b->mv_tmp + (size_t)k * nblk, (size_t)nblk * sizeof(DSV_MV));
+    }
+    /* 4. per stream, in coding order: forced intra, stability + motion side info -> packet prefix */
+    tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
+    for (s = 0; s < S; s++) {
+        DSV_ENCODER *e = &b->enc[s];
+        for (t = 0; t < F; t++) {
+            pic_t *pc = &b->pics[s * F + t];
+            bitw w;
+            if (pc->has_ref) {
+                int nintra = 0, i;
+                for (i = 0; i < nblk; i++) nintra += pc->mvs[i].mode != 0;
+                pc->forced_intra = 0;
+                if (nintra * 100 / nblk > e->intra_pct_thresh) { pc->has_ref = 0; pc->forced_intra = 1; }
+            }
+            pc->isP = pc->has_ref;
+            memset(pc->prefix, 0, (size_t)b->prefix_cap);
+            bw_init(&w, pc->prefix);
+            write_pkt_hdr(&w, DSV_PT_PIC | (pc->is_ref << 1) | pc->has_ref);
+            bw_align(&w);
+            bw_bits(&w, 32, pc->fnum);
+            bw_align(&w);
+            bw_ueg(&w, (unsigned)b->g.blk_w >> 2);
+            bw_ueg(&w, (unsigned)b->g.blk_h >> 2);
+            bw_align(&w);
+            stability_pass(e, pc, nblk, &w, tmp);
+            if (pc->isP) e->refresh_ctr++;               /* dsv_enc dsv_encoder.c:812-814 */
+            if (pc->has_ref) {
+                bw_align(&w);
+                motion_pass(b, pc, &w, tmp);
+            }
+            bw_align(&w);
+            pc->prefix_len = bw_bytes(&w);
+        }
+    }
+    free(tmp);
+    /* 5. residual coding, frame step by frame step across all streams */
+    {
+        const int serial = e0->rc_mode != DSV_RATE_CONTROL_CRF;
+        for (t = 0; t < F; t++) {
+            for (s = 0; s < S; s++) {
+                pic_t *pc = &b->pics[s * F + t];
+                dsvg_pic_job *j = &b->jobs[s];
+                pc->quant = pick_quant(&b->enc[s], pc->isP, pc->forced_intra);
+                j->src_slot = pc->cur_slot;
+                j->ref_recon_slot = pc->isP ? s : -1;
+                j->recon_slot = pc->is_ref ? s : -1;
+                j->quant = pc->quant;
+                j->mvs = (const dsvg_mv *)pc->mvs;
+                j->stable_blocks = pc->stable;
+                j->out_slot = pc->out_slot;
+            }
+            if ((rc = dsvg_code_pictures(b->ctx, S, b->jobs))) return rc;
+            if (serial) {
+                for (s = 0; s < S; s++) b->out_slots[s] = b->pics[s * F + t].out_slot;
+                if ((rc = dsvg_fetch_pictures(b->ctx, S, b->out_slots, b->outs))) return rc;
+                for (s = 0; s < S; s++)
+                    if ((rc = assemble(b, s, &b->pics[s * F + t], &b->outs[s], &out[s]))) return rc;
+            }
+        }
+        if (!serial) {
+            for (k = 0; k < S * F; k++) b->out_slots[k] = b->pics[k].out_slot;
+            if ((rc = dsvg_fetch_pictures(b->ctx, S * F, b->out_slots, b->outs))) return rc;
+            for (s = 0; s < S; s++)
+                for (t = 0; t < F; t++)
+                    if ((rc = assemble(b, s, &b->pics[s * F + t], &b->outs[s * F + t], &out[s]))) return rc;
+        }
+    }
+    b->ring = (b->ring + F) % (F + 1);
+    return DSVG_OK;
+}
+
+int dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out)
+{
+    DSV_BUF tmp;
+    int rc;
+    if (!b || stream < 0 || stream >= b->nstreams || !out) return DSVG_ERR_ARG;
+    dsv_enc_end_of_stream(&b->enc[stream], &tmp);
+    rc = dsv1_buf_append(out, tmp.data, tmp.len);
+    dsv_buf_free(&tmp);
+    return rc ? DSVG_ERR_ARG : DSVG_OK;
+}
+
+/* Join independently encoded closed GOPs into one stream.  A serial encode differs from the
+ * concatenation only in the prev_link of picture/EOS packets (metadata packets carry 0): each is
+ * the length of the previous picture packet (set_link_offsets dsv_encoder.c:171-192). */
+int dsv1_concat_gops(const DSV_BUF *gops, int ngops, DSV_BUF *out)
+{
+    unsigned prev = 0;
+    int g;
+    uint8_t eos[DSV_PACKET_HDR_SIZE];
+    bitw w;
+    out->data = NULL; out->len = 0;
+    for (g = 0; g < ngops; g++) {
+        unsigned o = 0;
+        const unsigned start = out->len;
+        if (dsv1_buf_append(out, gops[g].data, gops[g].len)) return DSVG_ERR_ARG;
+        while (o + DSV_PACKET_HDR_SIZE <= gops[g].len) {
+            uint8_t *pk = out->data + start + o;
+            const unsigned next = get_be32(pk + DSV_PACKET_NEXT_OFFSET);
+            const int type = pk[DSV_PACKET_TYPE_OFFSET];
+            if (memcmp(pk, "DSV1", 4)) return DSVG_ERR_ARG;
+            if (type == DSV_PT_EOS) {                 /* drop per-GOP EOS packets */
+                out->len = start + o;
+                break;
+            }
+            if (type & DSV_PT_PIC) {
+                put_be32(pk + DSV_PACKET_PREV_OFFSET, prev);
+                prev = next;
+            }
+            if (next == 0) break;
+            o += next;
+        }
+    }
+    memset(eos, 0, sizeof(eos));
+    bw_init(&w, eos);
+    write_pkt_hdr(&w, DSV_PT_EOS);
+    put_be32(eos + DSV_PACKET_PREV_OFFSET, prev);
+    return dsv1_buf_append(out, eos, sizeof(eos)) ? DSVG_ERR_ARG : DSVG_OK;
+}
+
+/* =================================================================================================
+ * drop-in frame-at-a-time API (dsv_encoder.h:112-121)
+ * ================================================================================================= */
+void dsv_enc_init(DSV_ENCODER *enc)                        /* dsv_encoder.c:696-722 */
+{
+    memset(enc, 0, sizeof(*enc));
+    enc->prev_gop = (DSV_FNUM)-1;
+    enc->quality = DSV_QUALITY_PERCENT(85);
+    enc->gop = 24;
+    enc->rc_mode = DSV_RATE_CONTROL_CRF;
+    enc->bitrate = INT_MAX;
+    enc->max_q_step = DSV_MAX_QUALITY / 200;
+    enc->min_quality = DSV_QUALITY_PERCENT(1);
+    enc->max_quality = DSV_QUALITY_PERCENT(95);
+    enc->min_I_frame_quality = DSV_QUALITY_PERCENT(5);
+    enc->rc_high_motion_nudge = 1;
+    enc->intra_pct_thresh = 50;
+    enc->stable_refresh = 14;
+    enc->scene_change_delta = 4;
+    enc->do_scd = 1;
+}
+
+void dsv_enc_start(DSV_ENCODER *enc)                       /* dsv_encoder.c:724-734 */
+{
+    enc->quality = CLAMPI(enc->quality, 0, DSV_MAX_QUALITY);
+    if (enc->rc_mode != DSV_RATE_CONTROL_CRF) {
+        enc->rc_quant = (unsigned)enc->quality;
+        enc->avg_P_frame_q = enc->quality * 4 / 5;
+    }
+    enc->force_metadata = 1;
+}
+
+void dsv_enc_set_metadata(DSV_ENCODER *enc, DSV_META *md) { memcpy(&enc->vidmeta, md, sizeof(DSV_META)); }
+void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
+
+void dsv_enc_free(DSV_ENCODER *enc)
+{
+    if (enc->ref) {
+        dsv1_batch *b = (dsv1_batch *)enc->ref;
+        b->enc = NULL;                                  /* the caller owns the DSV_ENCODER */
+        dsv1_batch_close(b);
+        enc->ref = NULL;
+    }
+    if (enc->stability) { dsv_free(enc->stability); enc->stability = NULL; }
+    if (enc->stable_blocks) { dsv_free(enc->stable_blocks); enc->stable_blocks = NULL; }
+}
+
+void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:766-778 */
+{
+    bitw w;
+    dsv_mk_buf(&bufs[0], DSV_PACKET_HDR_SIZE);
+    bw_init(&w, bufs[0].data);
+    write_pkt_hdr(&w, DSV_PT_EOS);
+    link_packet(enc, bufs[0].data, bufs[0].len, 1);
+}
+
+int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
+{
+    dsv1_batch *b;
+    DSV_BUF acc = {NULL, 0};
+    uint8_t *packed, *o;
+    int c, y, rc, nbuf = 0;
+    unsigned off = 0;
+
+    if (!bufs) { dsv1_log(1, "null buffer list passed to encoder!"); return 0; }
+    if (!enc->ref) {
+        if ((rc = batch_open_on(&b, enc, 0, dsv1_device, 1, 1))) {
+            dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
+            dsv_frame_ref_dec(frame);
+            return 0;
+        }
+        enc->ref = b;
+    }
+    b = (dsv1_batch *)enc->ref;
+    packed = (uint8_t *)malloc(b->g.frame_bytes);
+    o = packed;
+    for (c = 0; c < 3; c++)
+        for (y = 0; y < frame->planes[c].h; y++, o += frame->planes[c].w)
+            memcpy(o, frame->planes[c].data + (size_t)y * frame->planes[c].stride, (size_t)frame->planes[c].w);
+    rc = dsv1_batch_encode(b, packed, 0, &acc);
+    free(packed);
+    dsv_frame_ref_dec(frame);                           /* the encoder owns the frame (dsv_encoder.c:38-40) */
+    if (rc) {
+        dsv1_log(1, "GPU encode failed: %s", dsvg_last_error());
+        dsv_buf_free(&acc);
+        return 0;
+    }
+    while (off + DSV_PACKET_HDR_SIZE <= acc.len && nbuf < 2) {
+        const unsigned n = get_be32(acc.data + off + DSV_PACKET_NEXT_OFFSET);
+        dsv_mk_buf(&bufs[nbuf], (int)n);
+        memcpy(bufs[nbuf].data, acc.data + off, n);
+        nbuf++;
+        off += n;
+    }
+    dsv_buf_free(&acc);
+    return nbuf;
+}

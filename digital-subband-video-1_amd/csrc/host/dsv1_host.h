@@ -1,0 +1,75 @@
+/* dsv1_host.h -- private helpers of the C session layer: MSB-first bit writer/reader with the
+ * interleaved exp-Golomb codes (bs.c:28-267 semantics: the writer ORs into a zeroed buffer) and a
+ * growable output buffer.  Host-only scalar code for headers and side information; the coefficient
+ * payloads themselves are packed on the GPU. */
+#ifndef DSV1_HOST_H
+#define DSV1_HOST_H
+
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include "../../../include/dsv1_api.h"
+
+typedef struct { uint8_t *p; unsigned pos; } bitw;
+
+static inline void bw_init(bitw *b, uint8_t *buf) { b->p = buf; b->pos = 0; }
+static inline void bw_align(bitw *b) { b->pos = (b->pos + 7u) & ~7u; }
+static inline unsigned bw_bytes(const bitw *b) { return b->pos >> 3; }
+static inline void bw_bit(bitw *b, unsigned one)
+{
+    if (one) b->p[b->pos >> 3] |= (uint8_t)(0x80u >> (b->pos & 7));
+    b->pos++;
+}
+static inline void bw_bits(bitw *b, int n, unsigned v) { while (n--) bw_bit(b, (v >> n) & 1u); }
+static inline void bw_ueg(bitw *b, unsigned v)
+{
+    const unsigned m = v + 1;
+    int k = 31 - __builtin_clz(m);
+    while (k-- > 0) { b->pos++; bw_bit(b, (m >> k) & 1u); }
+    bw_bit(b, 1);
+}
+static inline void bw_seg(bitw *b, int v)
+{
+    const unsigned m = v < 0 ? (unsigned)-v : (unsigned)v;
+    bw_ueg(b, m);
+    if (m) bw_bit(b, v < 0);
+}
+static inline void bw_bytes_in(bitw *b, const uint8_t *src, unsigned n)
+{
+    memcpy(b->p + (b->pos >> 3), src, n);
+    b->pos += n * 8u;
+}
+
+static inline unsigned br_bit(bitw *b) { unsigned v = (b->p[b->pos >> 3] >> (7 - (b->pos & 7))) & 1u; b->pos++; return v; }
+static inline unsigned br_bits(bitw *b, int n) { unsigned v = 0; while (n--) v = (v << 1) | br_bit(b); return v; }
+static inline unsigned br_ueg(bitw *b) { unsigned m = 1; while (!br_bit(b)) m = (m << 1) | br_bit(b); return m - 1; }
+static inline int br_seg(bitw *b) { int v = (int)br_ueg(b); return (v && br_bit(b)) ? -v : v; }
+
+/* zero-bit run-length coder (bs.c:222-267) */
+typedef struct { bitw b; int nz; } zrle;
+static inline void zr_init(zrle *z, uint8_t *buf) { bw_init(&z->b, buf); z->nz = 0; }
+static inline void zr_put(zrle *z, int bit) { if (bit) { bw_ueg(&z->b, (unsigned)z->nz); z->nz = 0; } else z->nz++; }
+static inline int zr_end(zrle *z) { bw_ueg(&z->b, (unsigned)z->nz); z->nz = 0; bw_align(&z->b); return (int)bw_bytes(&z->b); }
+static inline int zr_get(zrle *z)
+{
+    if (z->nz == 0) z->nz = (int)br_ueg(&z->b); else z->nz--;
+    return z->nz == 0;
+}
+
+static inline void put_be32(uint8_t *p, unsigned v)
+{
+    p[0] = (uint8_t)(v >> 24); p[1] = (uint8_t)(v >> 16); p[2] = (uint8_t)(v >> 8); p[3] = (uint8_t)v;
+}
+static inline unsigned get_be32(const uint8_t *p)
+{
+    return ((unsigned)p[0] << 24) | ((unsigned)p[1] << 16) | ((unsigned)p[2] << 8) | p[3];
+}
+
+/* append n bytes to a dsv_alloc-backed growing DSV_BUF (capacity kept in a hidden word before data) */
+int  dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n);
+void dsv1_log(int level, const char *fmt, ...);
+extern int dsv1_device;
+
+#define CLAMPI(v, lo, hi) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
+
+#endif

@@ -1,0 +1,253 @@
+/* dsv1_util.c -- host glue the drop-in API needs around the GPU hot path: counting allocator
+ * (dsv.c:41-96: zeroed, 16-byte header), log level (dsv.c:19-39), DSV_BUF (dsv.c:172-187), host frame
+ * containers in the reference layout (frame.c:63-197), planar YUV file access (dsv.c:98-170), the
+ * motion-vector predictor (dsv.c:189-231) and the two CLI helpers of util.c.  None of this is hot. */
+#include <stdarg.h>
+#include <stdio.h>
+#include "dsv1_host.h"
+
+static int g_level = 1;
+static unsigned g_nalloc, g_nfree, g_balloc, g_bfree;
+int dsv1_device = 0;
+
+void dsv_set_log_level(int level) { g_level = level; }
+int dsv_get_log_level(void) { return g_level; }
+void dsv1_set_device(int device) { dsv1_device = device; }
+
+void dsv1_log(int level, const char *fmt, ...)
+{
+    static const char *names[5] = {"NONE", "ERROR", "WARNING", "INFO", "DEBUG"};
+    va_list ap;
+    if (level > g_level) return;
+    printf("[DSV][%s] ", names[level < 0 ? 0 : (level > 4 ? 4 : level)]);
+    va_start(ap, fmt);
+    vprintf(fmt, ap);
+    va_end(ap);
+    printf("\n");
+}
+
+void *dsv_alloc(int size)
+{
+    uint8_t *p = (uint8_t *)calloc(1, (size_t)size + 16);
+    if (!p) return NULL;
+    *(int32_t *)p = size;
+    g_nalloc++;
+    g_balloc += (unsigned)size;
+    return p + 16;
+}
+
+void dsv_free(void *ptr)
+{
+    uint8_t *p;
+    if (!ptr) return;
+    p = (uint8_t *)ptr - 16;
+    g_nfree++;
+    g_bfree += (unsigned)*(int32_t *)p;
+    free(p);
+}
+
+void dsv_memory_report(void)
+{
+    dsv1_log(4, "n alloc: %u  n freed: %u  alloc bytes: %u  freed bytes: %u  not freed: %d",
+             g_nalloc, g_nfree, g_balloc, g_bfree, (int)(g_balloc - g_bfree));
+}
+
+void dsv_mk_buf(DSV_BUF *buf, int size)
+{
+    memset(buf, 0, sizeof(*buf));
+    buf->data = (unsigned char *)dsv_alloc(size);
+    buf->len = (unsigned)size;
+}
+
+void dsv_buf_free(DSV_BUF *buf)
+{
+    if (buf && buf->data) {
+        dsv_free(buf->data);
+        buf->data = NULL;
+    }
+}
+
+int dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n)
+{
+    unsigned cap = b->data ? (unsigned)*(int32_t *)(b->data - 16) : 0;
+    if (b->len + n > cap) {
+        unsigned ncap = cap ? cap * 2 : (1u << 16);
+        unsigned char *nd;
+        while (ncap < b->len + n) ncap *= 2;
+        nd = (unsigned char *)dsv_alloc((int)ncap);
+        if (!nd) return -1;
+        if (b->data) {
+            memcpy(nd, b->data, b->len);
+            dsv_free(b->data);
+        }
+        b->data = nd;
+    }
+    memcpy(b->data + b->len, src, n);
+    b->len += n;
+    return 0;
+}
+
+/* ---- host frames ---------------------------------------------------------------------------- */
+static DSV_FRAME *frame_shell(int format, int w, int h)
+{
+    DSV_FRAME *f = (DSV_FRAME *)dsv_alloc((int)sizeof(*f));
+    f->refcount = 1;
+    f->format = format;
+    f->width = w;
+    f->height = h;
+    return f;
+}
+
+DSV_FRAME *dsv_mk_frame(int format, int width, int height, int border)
+{
+    DSV_FRAME *f = frame_shell(format, width, height);
+    const int ext = border ? DSVG_FRAME_BORDER : 0;
+    const int hs = (format >> 2) & 3, vs = format & 3;
+    int c, total = 0, off = 0;
+    f->border = !!border;
+    for (c = 0; c < 3; c++) {
+        DSV_PLANE *p = &f->planes[c];
+        p->format = format;
+        p->w = c ? (width + (1 << hs) - 1) >> hs : width;
+        p->h = c ? (height + (1 << vs) - 1) >> vs : height;
+        p->hs = c ? hs : 0;
+        p->vs = c ? vs : 0;
+        p->stride = (p->w + 2 * ext + 15) & ~15;
+        p->len = p->stride * (p->h + 2 * ext);
+        total += p->len;
+    }
+    f->alloc = (uint8_t *)dsv_alloc(total);
+    for (c = 0; c < 3; c++) {
+        DSV_PLANE *p = &f->planes[c];
+        p->data = f->alloc + off + p->stride * ext + ext;
+        off += p->len;
+    }
+    return f;
+}
+
+DSV_FRAME *dsv_load_planar_frame(int format, void *data, int width, int height)
+{
+    DSV_FRAME *f = frame_shell(format, width, height);
+    const int hs = (format >> 2) & 3, vs = format & 3;
+    uint8_t *d = (uint8_t *)data;
+    int c;
+    for (c = 0; c < 3; c++) {
+        DSV_PLANE *p = &f->planes[c];
+        p->format = format;
+        p->w = c ? (width + (1 << hs) - 1) >> hs : width;
+        p->h = c ? (height + (1 << vs) - 1) >> vs : height;
+        p->hs = c ? hs : 0;
+        p->vs = c ? vs : 0;
+        p->stride = p->w;
+        p->len = p->stride * p->h;
+        p->data = d;
+        d += p->len;
+    }
+    return f;
+}
+
+DSV_FRAME *dsv_frame_ref_inc(DSV_FRAME *frame)
+{
+    frame->refcount++;
+    return frame;
+}
+
+void dsv_frame_ref_dec(DSV_FRAME *frame)
+{
+    if (!frame || frame->refcount <= 0) {
+        dsv1_log(1, "assert: frame refcount");
+        exit(-1);
+    }
+    if (--frame->refcount == 0) {
+        if (frame->alloc) dsv_free(frame->alloc);
+        dsv_free(frame);
+    }
+}
+
+/* ---- planar YUV files ------------------------------------------------------------------------- */
+int dsv_yuv_write(FILE *out, int fno, DSV_PLANE *p)
+{
+    size_t fsz;
+    int c, y;
+    if (!out || fno < 0) return -1;
+    fsz = (size_t)p[0].w * p[0].h + (size_t)p[1].w * p[1].h + (size_t)p[2].w * p[2].h;
+    if (fseek(out, (long)(fno * fsz), SEEK_SET)) return -1;
+    for (c = 0; c < 3; c++)
+        for (y = 0; y < p[c].h; y++)
+            if (fwrite(p[c].data + (size_t)y * p[c].stride, (size_t)p[c].w, 1, out) != 1) return -1;
+    return 0;
+}
+
+int dsv_yuv_read(FILE *in, int fno, uint8_t *o, int w, int h, int subsamp)
+{
+    size_t npix = (size_t)w * h, chr, off;
+    if (!in || fno < 0) return -1;
+    switch (subsamp) {
+        case DSV_SUBSAMP_444: off = fno * npix * 3; chr = npix; break;
+        case DSV_SUBSAMP_422: off = fno * npix * 2; chr = (size_t)(w / 2) * h; break;
+        case DSV_SUBSAMP_420:
+        case DSV_SUBSAMP_411: off = fno * npix * 3 / 2; chr = npix / 4; break;
+        default: dsv1_log(1, "unsupported format"); exit(-1);
+    }
+    if (fseek(in, (long)off, SEEK_SET)) return -1;
+    return fread(o, 1, npix + 2 * chr, in) == npix + 2 * chr ? 0 : -1;
+}
+
+/* ---- motion vector predictor -------------------------------------------------------------------- */
+static int mvp_pick(int left, int top, int topleft)
+{
+    const int g = left + top - topleft;
+    return abs(g - left) < abs(g - top) ? left : top;
+}
+
+void dsv_movec_pred(DSV_MV *vecs, DSV_PARAMS *p, int x, int y, int *px, int *py)
+{
+    const int W = p->nblocks_h;
+    int vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0}, k;
+    const DSV_MV *nb[3];
+    nb[0] = x > 0 ? &vecs[y * W + x - 1] : NULL;
+    nb[1] = y > 0 ? &vecs[(y - 1) * W + x] : NULL;
+    nb[2] = (x > 0 && y > 0) ? &vecs[(y - 1) * W + x - 1] : NULL;
+    for (k = 0; k < 3; k++)
+        if (nb[k] && nb[k]->mode == 0) { vx[k] = nb[k]->u.mv.x; vy[k] = nb[k]->u.mv.y; }
+    *px = mvp_pick(vx[0], vx[1], vx[2]);
+    *py = mvp_pick(vy[0], vy[1], vy[2]);
+}
+
+/* ---- CLI helpers (util.c) ---------------------------------------------------------------------- */
+unsigned estimate_bitrate(int quality, int gop, DSV_META *md)
+{
+    const int fps = (md->fps_num + md->fps_den / 2) / md->fps_den;
+    int bpf = 352 * 288 * 3 / 2, ratio;
+    if (md->subsamp == DSV_SUBSAMP_444) bpf = 352 * 288 * 3;
+    else if (md->subsamp == DSV_SUBSAMP_422) bpf = 352 * 288 * 2;
+    if (gop == DSV_GOP_INTRA) bpf *= 4;
+    if (md->width < 320 && md->height < 240) bpf /= 4;
+    ratio = (((md->width + md->height) / 2) << 8) / 352;
+    bpf = bpf * ratio >> 8;
+    return (unsigned)(((bpf * fps) / (26 - quality / 4)) * 3 / 2);
+}
+
+void conv444to422(DSV_PLANE *s, DSV_PLANE *d)
+{
+    int x, y;
+    for (y = 0; y < s->h; y++) {
+        const uint8_t *a = s->data + (size_t)y * s->stride;
+        uint8_t *o = d->data + (size_t)y * d->stride;
+        for (x = 0; x < s->w; x += 2) {
+            const int n = x < s->w - 1 ? x + 1 : s->w - 1;
+            o[x >> 1] = (uint8_t)((a[x] + a[n] + 1) >> 1);
+        }
+    }
+}
+
+void conv422to420(DSV_PLANE *s, DSV_PLANE *d)
+{
+    int x, y;
+    for (x = 0; x < s->w; x++)
+        for (y = 0; y < s->h; y += 2) {
+            const int n = y < s->h - 1 ? y + 1 : s->h - 1;
+            d->data[(size_t)d->stride * (y >> 1) + x] =
+                (uint8_t)((s->data[(size_t)s->stride * y + x] + s->data[(size_t)s->stride * n + x] + 1) >> 1);
+        }
+}

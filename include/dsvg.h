@@ -99,9 +99,12 @@ typedef struct {
 } dsvg_geom;
 
 /* n_src_slots source frames (padded + pyramid) and n_recon_slots reconstructions stay resident;
- * max_jobs = widest batch handed to dsvg_code_pictures / dsvg_analyse in one call. */
+ * max_jobs = widest batch handed to dsvg_code_pictures in one call (sizes the per-step work
+ * buffers); out_slots = number of coded pictures whose packed planes stay resident until fetched
+ * (>= max_jobs; a whole GOP batch = streams x frames can be enqueued without a host sync) and the
+ * largest number of frame pairs one dsvg_analyse call may carry. */
 int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsamp,
-                    int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs);
+                    int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots);
 void dsvg_ctx_destroy(dsvg_ctx *ctx);
 int dsvg_ctx_geom(const dsvg_ctx *ctx, dsvg_geom *g);
 int dsvg_ctx_sync(dsvg_ctx *ctx);
@@ -117,6 +120,9 @@ int dsvg_dev_upload(dsvg_ctx *ctx, void *dptr, const void *src, size_t bytes);
  * build the luma pyramid (mk_pyramid dsv_encoder.c:194-217) and the smallest level's mean luma
  * (check_scene_change dsv_encoder.c:538-554).  yuv may be a host or a device pointer.  Async. */
 int dsvg_load_frames(dsvg_ctx *ctx, int first_slot, int n, const void *yuv, int yuv_on_device, int with_pyramid);
+/* same, frame i read from yuv + i*frame_pitch bytes (device pointer only) */
+int dsvg_load_frames_strided(dsvg_ctx *ctx, int first_slot, int n, const void *yuv_dev, size_t frame_pitch, int with_pyramid);
+int dsvg_get_luma_sums(dsvg_ctx *ctx, int first_slot, int n, unsigned *sums_out);   /* raw sums, syncs */
 int dsvg_get_avg_luma(dsvg_ctx *ctx, int first_slot, int n, int *avg_out);           /* syncs */
 
 /* Hierarchical motion estimation for npairs (current, reference) source-slot pairs
@@ -130,13 +136,14 @@ typedef struct {
     int quant;               /* frame quantiser (quality2quant dsv_encoder.c:165) */
     const dsvg_mv *mvs;      /* host, nblocks entries (P pictures) */
     const unsigned char *stable_blocks; /* host, nblocks entries (encode_stable_blocks output) */
+    int out_slot;            /* where the packed planes wait for dsvg_fetch_pictures */
 } dsvg_pic_job;
 
 typedef struct {
     int32_t dc[3];           /* unquantised DC (coefficient [0]) of each plane */
     uint32_t nruns[3];       /* number of (run,value) pairs */
     uint32_t nbytes[3];      /* payload length in bytes (bit count rounded up) */
-    const uint8_t *payload[3]; /* host (pinned) pointers, valid until the next dsvg_code_pictures */
+    const uint8_t *payload[3]; /* host (pinned) pointers, valid until the slot is coded again */
 } dsvg_pic_out;
 
 /* Residual coding of njobs pictures in one batch: frame copy, dsv_sub_pred, then per plane
@@ -144,7 +151,7 @@ typedef struct {
  * extended reconstruction (encode_one_frame dsv_encoder.c:657-674, encode_picture :518-526).
  * Enqueues only; results are collected by dsvg_fetch_pictures (which syncs). */
 int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
-int dsvg_fetch_pictures(dsvg_ctx *ctx, int njobs, dsvg_pic_out *outs);
+int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */
 
 /* Decoder side: coefficient (run,value) pairs parsed on the host are scattered + dequantised,
