@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py -- encoded Mpixels/s of the MI355X-native DSV1 hot path, 1080p 4:2:0 GOP=12 (BASELINE.json).
+
+A "step" = one pass of the whole per-frame hot path (pad/pyramid, HME, BMC, forward SBT, HZCC
+quantise+pack, inverse SBT, reconstruction) PLUS the host session layer (side info, packet framing)
+over one batch of synthetic input: --gops closed GOPs x 12 frames of 1920x1080 4:2:0, raw frames
+already resident in HBM when the timed region starts; the output of a step is the finished .dsv bytes
+of every GOP.  GOPs are independent (closed, CRF) so N GPUs shard them with no collective ("weak").
+
+One JSON line on rank 0, see the keys at the bottom.  The CPU baseline is the REAL reference encoder
+(oracle/_ref, compiled from /root/reference where it exists; otherwise our scalar port in oracle/),
+single thread, on a bounded sample of the same clips, and is only a reported number.
+"""
+import argparse
+import ctypes as C
+import hashlib
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+W, H, FMT, GOP = 1920, 1080, 0x5, 12
+QP = 85
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def cpu_baseline(clips, pkg, A):
+    """time the reference encoder (1 thread) on `clips` [g][GOP][bytes]; returns dict + list of streams"""
+    kind = "reference" if A.have_ref() else "port"
+    streams = []
+    t0 = time.perf_counter()
+    if kind == "reference":
+        L = C.CDLL(A.REF_SO)
+        L.dsv_load_planar_frame.restype = C.c_void_p
+        L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+        L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.estimate_bitrate.restype = C.c_uint
+        for g in range(clips.shape[0]):
+            enc = pkg.make_encoder_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1)     # same struct layout
+            enc.next_fnum = g * GOP
+            L.dsv_enc_start(C.byref(enc))
+            out = b""
+            bufs = (pkg.Buf * 4)()
+            for t in range(GOP):
+                fr = L.dsv_load_planar_frame(FMT, clips[g, t].ctypes.data, W, H)
+                nb = L.dsv_enc(C.byref(enc), fr, bufs) & 3
+                for i in range(nb):
+                    out += C.string_at(bufs[i].data, bufs[i].len)
+                    L.dsv_buf_free(C.byref(bufs[i]))
+            L.dsv_enc_free(C.byref(enc))
+            streams.append(out)
+    else:
+        for g in range(clips.shape[0]):
+            s, _ = A.orc_encode(clips[g], A.orc_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1), start_fnum=g * GOP, eos=False)
+            streams.append(s)
+    dt = time.perf_counter() - t0
+    mpix = clips.shape[0] * GOP * W * H / 1e6
+    return {"value": round(mpix / dt, 2), "unit": "Mpix/s", "cores": 1, "kind": kind,
+            "sample": "%d GOPs x %d frames 1920x1080 4:2:0 -gop12 -qp85 -rc_mode1, %.1f s" % (clips.shape[0], GOP, dt)}, streams
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--gops", type=int, default=16, help="closed GOPs per GPU per step")
+    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
+    ap.add_argument("--cpu-gops", type=int, default=4, help="GOPs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = local_rank
+    torch.cuda.set_device(dev)
+
+    import _cabi as A
+    pkg = importlib.import_module("digital-subband-video-1_amd")
+    L = pkg.lib()                                   # raises if the HIP extension is missing
+    if L.dsvg_device_count() < 1:
+        raise RuntimeError("no HIP device: the product path has no CPU fallback")
+
+    # synthetic input (integer generator, throughput style: pan + texture)
+    nd = max(1, min(args.distinct, args.gops))
+    fb = A.frame_bytes(W, H, FMT)
+    distinct = np.empty((nd, GOP, fb), dtype=np.uint8)
+    for g in range(nd):
+        distinct[g] = A.gen_clip(W, H, FMT, 0x10800003 + 977 * rank + g, GOP, style=0)
+    batch_in = np.empty((args.gops, GOP, fb), dtype=np.uint8)
+    for s in range(args.gops):
+        batch_in[s] = distinct[s % nd]
+
+    cfg = pkg.make_encoder_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1)
+    b = pkg.Batch(cfg, args.gops, GOP, device=dev)
+    dptr = b.upload(batch_in)                       # raw clip resident in HBM before any timing
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        b.sync()
+        torch.cuda.synchronize()
+
+    outs = None
+    for _ in range(args.warmup):
+        outs = b.encode(dptr, on_device=True)
+    # pick the kernel to time: one untimed step with every kernel bracketed, take the largest total
+    names = b.kernel_names()
+    table = {}
+    prof_kernel = args.prof_kernel
+    if rank == 0:
+        b.prof_enable(names)
+        b.encode(dptr, on_device=True)
+        b.sync()
+        table = {k: b.prof_get(k) for k in names}
+        if prof_kernel == "auto":
+            prof_kernel = max(table, key=lambda k: table[k][0])
+        b.prof_enable([prof_kernel])
+    sync_all()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        outs = b.encode(dptr, on_device=True)
+    sync_all()
+    dt = time.perf_counter() - t0
+    kinfo = None
+    if rank == 0:
+        ms, nl, by = b.prof_get(prof_kernel)
+        b.prof_enable([])
+        ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        kinfo = {"kernel": prof_kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                 "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": nl,
+                 "avg_launch_us": round(1000.0 * ms / max(nl, 1), 2),
+                 "alg_bytes_per_launch": round(by / max(nl, 1)),
+                 "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]}}
+
+    tmax = dt
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    pix_per_step = args.gops * GOP * W * H
+    value = world * pix_per_step * args.steps / tmax / 1e6
+
+    # parity spot check + CPU baseline on rank 0 only
+    cpu = None
+    bit_exact = None
+    if rank == 0:
+        ncpu = min(args.cpu_gops, nd) if world == 1 else min(1, nd)
+        if ncpu > 0:
+            # fresh GPU streams for the same GOP clips with the same frame numbers as the CPU run
+            chk = pkg.Batch(cfg, ncpu, GOP, device=dev)
+            for s in range(ncpu):
+                chk.set_fnum(s, s * GOP)
+            gpu_streams = chk.encode(distinct[:ncpu])
+            chk.close()
+            cpu, cpu_streams = cpu_baseline(distinct[:ncpu], pkg, A)
+            bit_exact = all(a == c for a, c in zip(gpu_streams, cpu_streams))
+        out_bytes = sum(len(o) for o in outs)
+        res = {
+            "metric": "encoded Mpixels/sec, 1080p 4:2:0 GOP=12, bit-exact .dsv",
+            "value": round(value, 2),
+            "unit": "Mpix/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * tmax / args.steps, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u8/int32",
+            "data": "synthetic",
+            "config": {"workload": "1920x1080 4:2:0 GOP=12 CRF qp85, %d closed GOPs (x12 frames) per GPU per step, raw frames resident in HBM, output = finished .dsv packets" % args.gops,
+                       "gops_per_gpu": args.gops, "frames_per_step": args.gops * GOP * world,
+                       "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world},
+            "bit_exact_vs_cpu": bit_exact,
+            "roofline": kinfo,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(res))
+    b.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -62,10 +62,11 @@ def lib():
         L.dsvg_dev_free.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsvg_dev_upload.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
-        L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_int]
+        L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_ulonglong]
         L.dsvg_prof_reset.argtypes = [_C.c_void_p]
-        L.dsvg_prof_get.argtypes = [_C.c_void_p, _C.c_char_p, _C.POINTER(_C.c_double), _C.POINTER(_C.c_long),
+        L.dsvg_prof_get.argtypes = [_C.c_void_p, _C.c_int, _C.POINTER(_C.c_double), _C.POINTER(_C.c_long),
                                     _C.POINTER(_C.c_double)]
+        L.dsvg_prof_kernel_name.restype = _C.c_char_p
         _lib = L
     return _lib
 
@@ -150,13 +151,23 @@ class Batch:
     def sync(self):
         _chk(self.L.dsvg_ctx_sync(self.ctx), "dsvg_ctx_sync")
 
-    def prof(self, enable=True):
-        self.L.dsvg_prof_enable(self.ctx, 1 if enable else 0)
-        self.L.dsvg_prof_reset(self.ctx)
+    def kernel_names(self):
+        return [self.L.dsvg_prof_kernel_name(i).decode() for i in range(self.L.dsvg_prof_kernels())]
 
-    def prof_get(self, family):
+    def prof_enable(self, kernels):
+        """kernels: iterable of kernel names whose launches get HIP-event brackets (empty = off)"""
+        names = self.kernel_names()
+        mask = 0
+        for k in kernels:
+            mask |= 1 << names.index(k)
+        _chk(self.L.dsvg_prof_enable(self.ctx, mask), "dsvg_prof_enable")
+        _chk(self.L.dsvg_prof_reset(self.ctx), "dsvg_prof_reset")
+
+    def prof_get(self, kernel):
+        """(total ms, launches, algorithmic bytes) of one kernel since the last prof_enable"""
+        kid = self.kernel_names().index(kernel)
         ms, n, by = _C.c_double(0), _C.c_long(0), _C.c_double(0)
-        _chk(self.L.dsvg_prof_get(self.ctx, family.encode(), _C.byref(ms), _C.byref(n), _C.byref(by)), "dsvg_prof_get")
+        _chk(self.L.dsvg_prof_get(self.ctx, kid, _C.byref(ms), _C.byref(n), _C.byref(by)), "dsvg_prof_get")
         return ms.value, n.value, by.value
 
     def close(self):

@@ -229,24 +229,27 @@ hipEvent_t Prof::get()
     (void)hipEventCreate(&e);
     return e;
 }
-void Prof::begin(hipStream_t st, int fam, double alg_bytes)
+void Prof::begin(hipStream_t st, int kid, double alg_bytes)
 {
-    if (!on) return;
-    Rec r; r.fam = fam; r.a = get(); r.b = get(); r.bytes = alg_bytes;
+    open = false;
+    if (!want(kid)) return;
+    Rec r; r.kid = kid; r.a = get(); r.b = get(); r.bytes = alg_bytes;
     (void)hipEventRecord(r.a, st);
     recs.push_back(r);
+    open = true;
 }
 void Prof::end(hipStream_t st)
 {
-    if (!on || recs.empty()) return;
+    if (!open) return;
     (void)hipEventRecord(recs.back().b, st);
+    open = false;
 }
 void Prof::collect()
 {
     for (auto &r : recs) {
         (void)hipEventSynchronize(r.b);
         float t = 0;
-        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.fam] += t; bytes[r.fam] += r.bytes; launches[r.fam]++; }
+        if (hipEventElapsedTime(&t, r.a, r.b) == hipSuccess) { ms[r.kid] += t; bytes[r.kid] += r.bytes; launches[r.kid]++; }
         pool.push_back(r.a); pool.push_back(r.b);
     }
     recs.clear();
@@ -254,11 +257,13 @@ void Prof::collect()
 void Prof::reset()
 {
     collect();
-    for (int i = 0; i < 8; i++) { ms[i] = 0; bytes[i] = 0; launches[i] = 0; }
+    for (int i = 0; i < KID_N; i++) { ms[i] = 0; bytes[i] = 0; launches[i] = 0; }
 }
-int prof_family(const char *name)
+const char *kid_name(int kid)
 {
-    static const char *n[FAM_N] = {"sbt_fwd", "sbt_inv", "hzcc", "bmc", "hme", "frame"};
-    for (int i = 0; i < FAM_N; i++) if (!strcmp(n[i], name)) return i;
-    return -1;
+    static const char *n[KID_N] = {"k_unpack", "k_extend", "k_ds2x", "k_luma_sum", "k_hme_level", "k_hme_level0", "k_hme_detail",
+                                   "k_mc", "k_fwd_haar_pix", "k_fwd_b4t", "k_fwd_haar_s1", "k_fwd_tail",
+                                   "k_hz_quant", "k_hz_scan", "k_hz_emit", "k_hz_scatter",
+                                   "k_inv_tail", "k_inv_haar_tile", "k_inv_b4t"};
+    return (kid >= 0 && kid < KID_N) ? n[kid] : "?";
 }

@@ -49,19 +49,30 @@ struct Slab {
     void release();
 };
 
-// kernel-family timing (HIP events on the pipeline stream)
+// per-kernel timing with HIP events on the pipeline stream (bench.py roofline leg).  Only kernels whose
+// bit is set in `mask` are bracketed, so the timed region pays for the events of one kernel only.
+enum {
+    KID_UNPACK = 0, KID_EXTEND, KID_DS2X, KID_LUMA_SUM,
+    KID_HME_LEVEL, KID_HME_LEVEL0, KID_HME_DETAIL,
+    KID_MC,
+    KID_FWD_HAAR_PIX, KID_FWD_B4T, KID_FWD_HAAR_S1, KID_FWD_TAIL,
+    KID_HZ_QUANT, KID_HZ_SCAN, KID_HZ_EMIT, KID_HZ_SCATTER,
+    KID_INV_TAIL, KID_INV_HAAR_TILE, KID_INV_B4T,
+    KID_N
+};
+const char *kid_name(int kid);
 struct Prof {
-    bool on = false;
-    struct Rec { int fam; hipEvent_t a, b; double bytes; };
+    unsigned long long mask = 0;
+    struct Rec { int kid; hipEvent_t a, b; double bytes; };
     std::vector<Rec> recs;
     std::vector<hipEvent_t> pool;
-    double ms[8] = {0}, bytes[8] = {0};
-    long launches[8] = {0};
+    double ms[KID_N] = {0}, bytes[KID_N] = {0};
+    long launches[KID_N] = {0};
+    bool open = false;
     hipEvent_t get();
-    void begin(hipStream_t st, int fam, double alg_bytes);
+    inline bool want(int kid) const { return (mask >> kid) & 1ull; }
+    void begin(hipStream_t st, int kid, double alg_bytes);
     void end(hipStream_t st);
     void collect();
     void reset();
 };
-enum { FAM_SBT_FWD = 0, FAM_SBT_INV, FAM_HZCC, FAM_BMC, FAM_HME, FAM_FRAME, FAM_N };
-int prof_family(const char *name);

@@ -4,6 +4,7 @@
 
 #define DSVG_BORDER 64
 
+struct Prof;
 struct SbtGeo3 { SbtGeo g[3]; };
 
 struct McGeo {
@@ -26,20 +27,21 @@ struct HmeArgs {
 // k_sbt.hip
 int  sbt_tail_supported(const SbtGeo &g);
 void sbt_set_func_attributes();
-void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src);
-void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP);
+void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr);
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr);
 // k_hzcc.hip
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks);
-void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count);
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf = nullptr, double samples = 0);
+void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count, Prof *pf = nullptr);
 int  hz_scan_items_max();
+void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);
 // k_bmc.hip
-void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub);
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr);
 // k_frame.hip
-void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n);
+void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr);
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);
-void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab);
-void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n);
-void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums);
+void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf = nullptr);
+void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr);
+void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums, Prof *pf = nullptr, const int *slot_tab = nullptr);
 void launch_frame_add(hipStream_t st, uint8_t *dst, const FrameLayout &DL, const uint8_t *src, const FrameLayout &SL);
 // k_hme.hip
-void launch_hme(hipStream_t st, const HmeArgs &A, int npairs);
+void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf = nullptr);

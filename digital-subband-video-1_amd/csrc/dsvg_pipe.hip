@@ -47,7 +47,10 @@ struct dsvg_ctx {
     int32_t *dec_h = nullptr;        // decoder: parsed (pos,val) staging
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
-    std::vector<uint32_t> dirty;     // bytes of each out-slot/plane payload area that may be non-zero
+    int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
+    unsigned long long *gtab_d = nullptr, *gtab_h = nullptr;   // gather table (3 words per plane payload)
+    uint8_t *gath_d = nullptr, *gath_h = nullptr;              // compacted payloads (device / pinned host)
+    size_t gath_cap = 0;
     Prof prof;
 };
 
@@ -58,9 +61,9 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d};
     for (void *p : d) if (p) (void)hipFree(p);
-    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h};
+    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
     delete c;
@@ -160,14 +163,14 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->slots_d, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->luma_sums, (size_t)n_src_slots, true))) return fail(rc);
     if ((rc = hmalloc(&c->jobs_h, S))) return fail(rc);
-    if ((rc = hmalloc(&c->bits_h, c->bits_per_job * O))) return fail(rc);
+    if ((rc = dmalloc(&c->gtab_d, 9 * O, true))) return fail(rc);
+    if ((rc = hmalloc(&c->gtab_h, 9 * O))) return fail(rc);
     if ((rc = hmalloc(&c->psum_h, 3 * O))) return fail(rc);
     if ((rc = hmalloc(&c->mv_h, (size_t)c->nblk * std::max(S, O)))) return fail(rc);
     if ((rc = hmalloc(&c->stable_h, (size_t)c->nblk * S))) return fail(rc);
     if ((rc = hmalloc(&c->slots_h, 3 * std::max(S, O)))) return fail(rc);
     if ((rc = hmalloc(&c->luma_h, (size_t)n_src_slots))) return fail(rc);
     (void)J;
-    c->dirty.assign(3 * O, 0);
     *out = c;
     return DSVG_OK;
 }
@@ -219,22 +222,19 @@ extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t 
 }
 
 // ------------------------------------------------------------------------------------------------
-static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid)
+static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d)
 {
-    const size_t fb = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
-    const double samples = (double)fb * n;
-    c->prof.begin(c->st, FAM_FRAME, samples * (with_pyramid ? 3.33 : 2.0));
-    launch_unpack(c->st, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n);
-    launch_extend(c->st, c->src[0].p, c->L[0], first_slot, n, 3, nullptr);
+    launch_unpack(c->st, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d);
+    launch_extend(c->st, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
-            launch_ds2x(c->st, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n);
-            launch_extend(c->st, c->src[l].p, c->L[l], first_slot, n, 1, nullptr);
+            launch_ds2x(c->st, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d);
+            launch_extend(c->st, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof);
         }
-        HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st));
-        launch_luma_sum(c->st, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums);
+        if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st));
+        else       HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st));
+        launch_luma_sum(c->st, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums, &c->prof, tab_d);
     }
-    c->prof.end(c->st);
     HIPCHK(hipGetLastError());
     return DSVG_OK;
 }
@@ -254,14 +254,25 @@ extern "C" int dsvg_load_frames(dsvg_ctx *c, int first_slot, int n, const void *
         HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st));
         dsrc = c->yuv_stage;
     }
-    return load_core(c, first_slot, n, dsrc, fb, with_pyramid);
+    return load_core(c, first_slot, n, dsrc, fb, with_pyramid, nullptr);
 }
 
 extern "C" int dsvg_load_frames_strided(dsvg_ctx *c, int first_slot, int n, const void *yuv_dev, size_t frame_pitch, int with_pyramid)
 {
     if (!c || !yuv_dev || n < 1 || first_slot < 0 || first_slot + n > c->n_src) { dsvg_set_error("bad load_frames arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    return load_core(c, first_slot, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid);
+    return load_core(c, first_slot, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, nullptr);
+}
+
+extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid)
+{
+    if (!c || !yuv_dev || !slots || n < 1 || n > c->n_src) { dsvg_set_error("bad load_frames arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
+    if (!c->ltab_d) HIPCHK(hipMalloc((void **)&c->ltab_d, sizeof(int) * (size_t)c->n_src + 64));
+    HIPCHK(hipMemcpyAsync(c->ltab_d, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st));   // pageable: staged by the runtime
+    return load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d);
 }
 
 extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *sums_out)
@@ -305,9 +316,7 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
-    c->prof.begin(c->st, FAM_HME, (double)npairs * c->w * c->h * 2.67);
-    launch_hme(c->st, A, npairs);
-    c->prof.end(c->st);
+    launch_hme(c->st, A, npairs, &c->prof);
     HIPCHK(hipMemcpy2DAsync(c->mv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
                             (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
@@ -347,22 +356,15 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant)
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
 static int enqueue_recon(dsvg_ctx *c, int nI, int n)
 {
-    const double smp = (double)c->CL.total;
     if (nI > 0) {
-        c->prof.begin(c->st, FAM_SBT_INV, smp * nI * 5.0);
-        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0);
-        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0);
-        c->prof.end(c->st);
+        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, &c->prof);
+        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, &c->prof);
     }
     if (n > nI) {
-        c->prof.begin(c->st, FAM_SBT_INV, smp * (n - nI) * 6.0);
-        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 0, 1, 1);
-        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 1, 2, 1);
-        c->prof.end(c->st);
+        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 0, 1, 1, &c->prof);
+        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 1, 2, 1, &c->prof);
     }
-    c->prof.begin(c->st, FAM_FRAME, 0.0);
-    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots);
-    c->prof.end(c->st);
+    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots, &c->prof);
     return DSVG_OK;
 }
 
@@ -401,36 +403,22 @@ extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jo
         slh[t] = j.recon_slot;
         memcpy(sth + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
         if (isP) memcpy(mvh + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
-        for (int p = 0; p < 3; p++) {
-            uint32_t &d = c->dirty[3 * (size_t)j.out_slot + p];
-            if (d) HIPCHK(hipMemsetAsync(jb.bits + c->bits_off[p], 0, std::min<size_t>((size_t)d + 16, c->bits_cap[p] + 256), c->st));
-            d = (uint32_t)c->bits_cap[p];                 // unknown until fetched: assume fully dirty
-        }
     }
     HIPCHK(hipMemcpyAsync(c->jobs_d, jh, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable, sth, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs, mvh, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, slh, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
-    const double smp = (double)c->CL.total;
     if (nI > 0) {
-        c->prof.begin(c->st, FAM_SBT_FWD, smp * nI * 5.0);
-        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, 1);
-        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, 1);
-        c->prof.end(c->st);
+        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, 1, &c->prof);
+        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, 1, &c->prof);
     }
     if (njobs > nI) {
         const int nP = njobs - nI;
-        c->prof.begin(c->st, FAM_BMC, smp * nP * 4.0);
-        launch_mc(c->st, c->jobs_d + nI, nP, c->MG, 1);
-        c->prof.end(c->st);
-        c->prof.begin(c->st, FAM_SBT_FWD, smp * nP * 5.0);
-        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 0, 1, 1, 0);
-        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 1, 2, 1, 0);
-        c->prof.end(c->st);
+        launch_mc(c->st, c->jobs_d + nI, nP, c->MG, 1, &c->prof);
+        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 0, 1, 1, 0, &c->prof);
+        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 1, 2, 1, 0, &c->prof);
     }
-    c->prof.begin(c->st, FAM_HZCC, smp * njobs * 8.0);
-    launch_hz_encode(c->st, c->jobs_d, njobs, c->max_chunks);
-    c->prof.end(c->st);
+    launch_hz_encode(c->st, c->jobs_d, njobs, c->max_chunks, &c->prof, (double)c->CL.total * njobs);
     OPCHK(enqueue_recon(c, nI, njobs));
     HIPCHK(hipGetLastError());
     return DSVG_OK;
@@ -438,11 +426,11 @@ extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jo
 
 extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsvg_pic_out *outs)
 {
-    if (!c || !outs || !out_slots || n < 1) { dsvg_set_error("bad fetch_pictures arguments"); return DSVG_ERR_ARG; }
+    if (!c || !outs || !out_slots || n < 1 || n > c->out_slots) { dsvg_set_error("bad fetch_pictures arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < n; i++)
         if (out_slots[i] < 0 || out_slots[i] >= c->out_slots) { dsvg_set_error("out slot out of range"); return DSVG_ERR_ARG; }
-    // plane summaries first (sizes), then exactly the used payload bytes
+    // 1. plane summaries (sizes)
     int lo = out_slots[0], hi = out_slots[0];
     for (int i = 1; i < n; i++) { lo = std::min(lo, out_slots[i]); hi = std::max(hi, out_slots[i]); }
     HIPCHK(hipMemcpyAsync(c->psum_h + 3 * (size_t)lo, c->psum + 3 * (size_t)lo, sizeof(HzPlaneSum) * 3 * (size_t)(hi - lo + 1),
@@ -450,18 +438,34 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
     HIPCHK(hipStreamSynchronize(c->st));
     c->calls_since_sync = 0;
     HIPCHK(hipGetLastError());
+    // 2. compact every payload into one buffer on the device, then ONE device-to-host copy
+    size_t total = 0;
     for (int i = 0; i < n; i++) {
         const int o = out_slots[i];
         for (int p = 0; p < 3; p++) {
             const HzPlaneSum &ps = c->psum_h[3 * (size_t)o + p];
             if (ps.overflow) { dsvg_set_error("packed plane %d of out slot %d exceeds %zu bytes", p, o, c->bits_cap[p]); return DSVG_ERR_OVERFLOW; }
             const size_t nb = (size_t)((ps.total_bits + 7) >> 3);
-            c->dirty[3 * (size_t)o + p] = (uint32_t)nb;
-            if (nb) HIPCHK(hipMemcpyAsync(c->bits_h + (size_t)o * c->bits_per_job + c->bits_off[p],
-                                          c->bits + (size_t)o * c->bits_per_job + c->bits_off[p], nb, hipMemcpyDeviceToHost, c->st));
+            unsigned long long *t = c->gtab_h + 3 * (3 * (size_t)i + p);
+            t[0] = (size_t)o * c->bits_per_job + c->bits_off[p];
+            t[1] = total;
+            t[2] = nb;
+            total += (nb + 15) & ~(size_t)15;
         }
     }
+    if (total + 64 > c->gath_cap) {
+        if (c->gath_d) (void)hipFree(c->gath_d);
+        if (c->gath_h) (void)hipHostFree(c->gath_h);
+        c->gath_d = nullptr; c->gath_h = nullptr;
+        c->gath_cap = total * 2 + (1u << 20);
+        HIPCHK(hipMalloc((void **)&c->gath_d, c->gath_cap));
+        HIPCHK(hipHostMalloc((void **)&c->gath_h, c->gath_cap, hipHostMallocDefault));
+    }
+    HIPCHK(hipMemcpyAsync(c->gtab_d, c->gtab_h, sizeof(unsigned long long) * 9 * (size_t)n, hipMemcpyHostToDevice, c->st));
+    launch_gather_bits(c->st, c->bits, c->gtab_d, 3 * n, c->gath_d);
+    if (total) HIPCHK(hipMemcpyAsync(c->gath_h, c->gath_d, total, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
     for (int i = 0; i < n; i++) {
         const int o = out_slots[i];
         dsvg_pic_out &po = outs[i];
@@ -469,7 +473,7 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
             const HzPlaneSum &ps = c->psum_h[3 * (size_t)o + p];
             po.dc[p] = ps.dc; po.nruns[p] = ps.nruns;
             po.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
-            po.payload[p] = c->bits_h + (size_t)o * c->bits_per_job + c->bits_off[p];
+            po.payload[p] = c->gath_h + c->gtab_h[3 * (3 * (size_t)i + p) + 1];
         }
     }
     return DSVG_OK;
@@ -576,17 +580,13 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
             HIPCHK(hipMemcpyAsync(c->nzpos + (size_t)t * c->nz_total + c->nz_off[p], pos, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
             HIPCHK(hipMemcpyAsync(c->nzval + (size_t)t * c->nz_total + c->nz_off[p], val, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
         }
-    c->prof.begin(c->st, FAM_HZCC, 0.0);
     for (int t = 0; t < njobs; t++)
         for (int p = 0; p < 3; p++) {
             const int *cut = &cuts[((size_t)t * 3 + p) * 4];
-            for (int ph = 0; ph < 3; ph++) launch_hz_scatter(c->st, c->jobs_d + t, 1, p, cut[ph], cut[ph + 1] - cut[ph]);
+            for (int ph = 0; ph < 3; ph++) launch_hz_scatter(c->st, c->jobs_d + t, 1, p, cut[ph], cut[ph + 1] - cut[ph], &c->prof);
         }
-    c->prof.end(c->st);
     if (njobs > nI) {
-        c->prof.begin(c->st, FAM_BMC, (double)CL.total * (njobs - nI) * 2.0);
-        launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0);
-        c->prof.end(c->st);
+        launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }
     OPCHK(enqueue_recon(c, nI, njobs));
     HIPCHK(hipGetLastError());
@@ -594,16 +594,22 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
 }
 
 // ------------------------------------------------------------------------------------------------
-extern "C" int dsvg_prof_enable(dsvg_ctx *c, int on) { if (!c) return DSVG_ERR_ARG; c->prof.on = on != 0; return DSVG_OK; }
-extern "C" int dsvg_prof_reset(dsvg_ctx *c) { if (!c) return DSVG_ERR_ARG; c->prof.reset(); return DSVG_OK; }
-extern "C" int dsvg_prof_get(dsvg_ctx *c, const char *family, double *ms, long *launches, double *alg_bytes)
+extern "C" int dsvg_prof_kernels(void) { return KID_N; }
+extern "C" const char *dsvg_prof_kernel_name(int kid) { return kid_name(kid); }
+extern "C" int dsvg_prof_enable(dsvg_ctx *c, unsigned long long kernel_mask)
 {
-    if (!c || !family) return DSVG_ERR_ARG;
-    const int f = prof_family(family);
-    if (f < 0) { dsvg_set_error("unknown kernel family %s", family); return DSVG_ERR_ARG; }
+    if (!c) return DSVG_ERR_ARG;
     c->prof.collect();
-    if (ms) *ms = c->prof.ms[f];
-    if (launches) *launches = c->prof.launches[f];
-    if (alg_bytes) *alg_bytes = c->prof.bytes[f];
+    c->prof.mask = kernel_mask;
+    return DSVG_OK;
+}
+extern "C" int dsvg_prof_reset(dsvg_ctx *c) { if (!c) return DSVG_ERR_ARG; c->prof.reset(); return DSVG_OK; }
+extern "C" int dsvg_prof_get(dsvg_ctx *c, int kid, double *ms, long *launches, double *alg_bytes)
+{
+    if (!c || kid < 0 || kid >= KID_N) return DSVG_ERR_ARG;
+    c->prof.collect();
+    if (ms) *ms = c->prof.ms[kid];
+    if (launches) *launches = c->prof.launches[kid];
+    if (alg_bytes) *alg_bytes = c->prof.bytes[kid];
     return DSVG_OK;
 }

@@ -386,9 +386,9 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
         dyuv = (const uint8_t *)b->yuv_dev;
     }
     /* 1. source-only preparation for every frame: bordered layout, pyramid, mean luma */
-    for (k = 1; k <= F; k++)
-        if ((rc = dsvg_load_frames_strided(b->ctx, slot_of(b, 0, k), S, dyuv + (size_t)(k - 1) * fb, fb * F, with_pyr)))
-            return rc;
+    for (s = 0; s < S; s++)
+        for (t = 0; t < F; t++) b->slots_cur[s * F + t] = slot_of(b, s, t + 1);
+    if ((rc = dsvg_load_frames_map(b->ctx, S * F, b->slots_cur, dyuv, fb, with_pyr))) return rc;
     if (with_pyr && e0->do_scd)
         if ((rc = dsvg_get_luma_sums(b->ctx, 0, (F + 1) * S, b->luma))) return rc;
 

@@ -11,6 +11,7 @@
 // Reads reach one pixel beyond the 64-px border exactly like the reference (same frame layout).
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
+#include "dsvg_host.hpp"
 
 #define WPITCH 72                       // LDS row pitch in bytes (>= 64+3+3 alignment slack), multiple of 4
 #define WROWS 68
@@ -151,7 +152,11 @@ __global__ __launch_bounds__(256) void k_mc(const JobDev *__restrict__ jobs, McG
     }
 }
 
-void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub)
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf)
 {
+    double smp = 0;
+    for (int c = 0; c < 3; c++) smp += (double)G.w[c] * G.h[c];
+    if (pf) pf->begin(st, KID_MC, smp * njobs * (do_sub ? 4.0 : 2.0));   // ref + src in, pred + residual out
     hipLaunchKernelGGL(k_mc, dim3(G.nbh * G.nbv, 3, njobs), dim3(256), 0, st, jobs, G, do_sub);
+    if (pf) pf->end(st);
 }

@@ -5,17 +5,20 @@
 // (frame.c:263-327), dsv_ds2x_frame_luma (frame.c:240-261), dsv_frame_avg_luma (frame.c:223-238).
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
+#include "dsvg_host.hpp"
 
 // tightly packed planar frames -> interiors of bordered frames (grid.y = plane, grid.z = frame)
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv, size_t yuv_pitch,
-                                                uint8_t *__restrict__ slab, FrameLayout L, int first_slot)
+                                                uint8_t *__restrict__ slab, FrameLayout L, int first_slot,
+                                                const int *__restrict__ slot_tab)
 {
     const int c = blockIdx.y, f = blockIdx.z;
+    const int slot = slot_tab ? slot_tab[f] : first_slot + f;
     const int w = L.w[c], h = L.h[c];
     size_t poff = 0;
     for (int k = 0; k < c; k++) poff += (size_t)L.w[k] * L.h[k];
     const uint8_t *src = yuv + (size_t)f * yuv_pitch + poff;
-    uint8_t *dst = slab + (size_t)(first_slot + f) * L.pitch + L.off[c];
+    uint8_t *dst = slab + (size_t)slot * L.pitch + L.off[c];
     const bool vec = ((w & 15) == 0) && ((((uintptr_t)src) & 15) == 0);
     if (vec) {
         const int nv = w >> 4;
@@ -81,9 +84,10 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
 
 // 2x2 box downsample of the luma plane: (p1+p2+p3+p4+2)>>2 (frame.c:240-261)
 __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab, FrameLayout SL,
-                                              uint8_t *__restrict__ dslab, FrameLayout DL, int first)
+                                              uint8_t *__restrict__ dslab, FrameLayout DL, int first,
+                                              const int *__restrict__ slot_tab)
 {
-    const int f = first + blockIdx.z;
+    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
     const uint8_t *sp = sslab + (size_t)f * SL.pitch + SL.off[0];
     uint8_t *dp = dslab + (size_t)f * DL.pitch + DL.off[0];
     const int dw = DL.w[0], dh = DL.h[0];
@@ -112,9 +116,9 @@ __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab,
 
 // sum of the luma plane of frames [first, first+n) -> sums[first+f] (host divides, frame.c:237)
 __global__ __launch_bounds__(256) void k_luma_sum(const uint8_t *__restrict__ slab, FrameLayout L, int first,
-                                                  unsigned *__restrict__ sums)
+                                                  unsigned *__restrict__ sums, const int *__restrict__ slot_tab)
 {
-    const int f = first + blockIdx.z;
+    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
     const uint8_t *p = slab + (size_t)f * L.pitch + L.off[0];
     const int w = L.w[0], h = L.h[0];
     unsigned acc = 0;
@@ -143,26 +147,34 @@ __global__ __launch_bounds__(256) void k_frame_add(uint8_t *__restrict__ dst, Fr
 
 static inline int nblk(long items, int cap) { long b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 
-void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n)
+void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab)
 {
-    hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first);
+    if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]));
+    hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab);
+    if (pf) pf->end(st);
 }
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)
 {
     hipLaunchKernelGGL(k_pack, dim3(nblk((long)L.w[0] * L.h[0], 1024), 3, 1), dim3(256), 0, st, yuv, frame, L);
 }
-void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab)
+void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf)
 {
     const long items = (long)(L.h[0] + 128) * 128 + 128L * L.w[0];
+    if (pf) pf->begin(st, KID_EXTEND, 2.0 * items * n);
     hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
+    if (pf) pf->end(st);
 }
-void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n)
+void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf, const int *slot_tab)
 {
-    hipLaunchKernelGGL(k_ds2x, dim3(nblk((long)DL.w[0] * DL.h[0] / 4, 512), 1, n), dim3(256), 0, st, sslab, SL, dslab, DL, first);
+    if (pf) pf->begin(st, KID_DS2X, 5.0 * n * (double)DL.w[0] * DL.h[0]);
+    hipLaunchKernelGGL(k_ds2x, dim3(nblk((long)DL.w[0] * DL.h[0] / 4, 512), 1, n), dim3(256), 0, st, sslab, SL, dslab, DL, first, slot_tab);
+    if (pf) pf->end(st);
 }
-void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums)
+void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums, Prof *pf, const int *slot_tab)
 {
-    hipLaunchKernelGGL(k_luma_sum, dim3(nblk((long)L.w[0] * L.h[0], 64), 1, n), dim3(256), 0, st, slab, L, first, sums);
+    if (pf) pf->begin(st, KID_LUMA_SUM, 1.0 * n * (double)L.w[0] * L.h[0]);
+    hipLaunchKernelGGL(k_luma_sum, dim3(nblk((long)L.w[0] * L.h[0], 64), 1, n), dim3(256), 0, st, slab, L, first, sums, slot_tab);
+    if (pf) pf->end(st);
 }
 void launch_frame_add(hipStream_t st, uint8_t *dst, const FrameLayout &DL, const uint8_t *src, const FrameLayout &SL)
 {

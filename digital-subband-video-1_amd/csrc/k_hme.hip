@@ -14,6 +14,7 @@
 // resolved by the second tiny kernel k_hme_detail.
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
+#include "dsvg_host.hpp"
 
 #define WIN 14
 #define LAT 32
@@ -450,13 +451,18 @@ __global__ __launch_bounds__(256) void k_hme_detail(HmeArgs A)
     mf[b].high_detail = (tex > thr_tex && var > thr_var) ? 1 : 0;
 }
 
-void launch_hme(hipStream_t st, const HmeArgs &A, int npairs)
+void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
 {
     for (int level = A.levels; level >= 0; level--) {
         const int step = 1 << level;
         const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
+        const double px = 2.0 * npairs * (double)A.L[level].w[0] * A.L[level].h[0];     // src + ref luma once
+        if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
         if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(nvx * nvy, npairs), dim3(256), 0, st, A, level);
         else           hipLaunchKernelGGL((k_hme_level<true>), dim3(nvx * nvy, npairs), dim3(256), 0, st, A, level);
+        if (pf) pf->end(st);
     }
+    if (pf) pf->begin(st, KID_HME_DETAIL, 0.0);
     hipLaunchKernelGGL(k_hme_detail, dim3((A.nblk + 255) / 256, npairs), dim3(256), 0, st, A);
+    if (pf) pf->end(st);
 }

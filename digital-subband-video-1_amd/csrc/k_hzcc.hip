@@ -17,6 +17,7 @@
 // the earlier region's dequantised value and owns the final store.
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
+#include "dsvg_host.hpp"
 
 #define MINQ 16
 
@@ -306,6 +307,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
             nzbase += cs[ch].nnz;
         }
     }
+    __shared__ unsigned long long s_total;
     if (threadIdx.x == SCAN_THREADS - 1) {
         HzPlaneSum &ps = jb.psum[c];
         const int lne = incl_ne;                               // last non-empty chunk of the plane
@@ -315,7 +317,26 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
         ps.nruns = (unsigned)incl_nnz;
         ps.last_chunk = lne;
         ps.overflow = ((tb + 7) >> 3) > jb.bits_cap[c] ? 1 : 0;
+        s_total = ps.overflow ? 0ull : tb;
     }
+    __syncthreads();
+    // the emit kernel ORs into the payload (bs.c:50-63 semantics): clear exactly the words it will touch
+    unsigned *out32 = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
+    const unsigned nwords = (unsigned)((s_total + 31) >> 5) + 4;
+    for (unsigned i = threadIdx.x; i < nwords; i += SCAN_THREADS) out32[i] = 0;
+}
+
+// compact the packed planes of many pictures into one contiguous buffer (one D2H instead of 3 per picture)
+__global__ __launch_bounds__(256) void k_gather_bits(const uint8_t *__restrict__ bits, size_t bits_per_job,
+                                                     const unsigned long long *__restrict__ tab, uint8_t *__restrict__ dst)
+{
+    // tab[3*i+0] = source offset inside `bits`, tab[3*i+1] = destination offset, tab[3*i+2] = byte count (mult. of 4 ok)
+    const unsigned long long so = tab[3 * blockIdx.y], d0 = tab[3 * blockIdx.y + 1], n = tab[3 * blockIdx.y + 2];
+    const unsigned *s32 = reinterpret_cast<const unsigned *>(bits + so);
+    unsigned *d32 = reinterpret_cast<unsigned *>(dst + d0);
+    const unsigned long long nw = (n + 3) >> 2;
+    for (unsigned long long i = blockIdx.x * 256ull + threadIdx.x; i < nw; i += (unsigned long long)gridDim.x * 256ull) d32[i] = s32[i];
+    (void)bits_per_job;
 }
 
 // -------------------------------------------------------------------------------------------------
@@ -436,17 +457,34 @@ __global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ j
 }
 
 // -------------------------------------------------------------------------------------------------
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks)
+#define PB(kid, bytes) do { if (pf) pf->begin(st, kid, bytes); } while (0)
+#define PE() do { if (pf) pf->end(st); } while (0)
+
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf, double samples)
 {
+    PB(KID_HZ_QUANT, samples * 8.0);           // 4 B/sample in, 4 B/sample dequantised back
     hipLaunchKernelGGL(k_hz_quant, dim3(max_chunks, 3, njobs), dim3(256), 0, st, jobs);
+    PE();
+    PB(KID_HZ_SCAN, 0.0);
     hipLaunchKernelGGL(k_hz_scan, dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
+    PE();
+    PB(KID_HZ_EMIT, 0.0);
     hipLaunchKernelGGL(k_hz_emit, dim3(max_chunks, 3, njobs), dim3(256), 0, st, jobs);
+    PE();
 }
 
-void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count)
+void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count, Prof *pf)
 {
     if (count <= 0) return;
+    PB(KID_HZ_SCATTER, 0.0);
     hipLaunchKernelGGL(k_hz_scatter, dim3((count + 255) / 256, njobs), dim3(256), 0, st, jobs, c, first, count);
+    PE();
+}
+
+void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst)
+{
+    if (nitems <= 0) return;
+    hipLaunchKernelGGL(k_gather_bits, dim3(8, nitems), dim3(256), 0, st, bits, (size_t)0, tab, dst);
 }
 
 int hz_scan_items_max() { return SCAN_ITEMS * SCAN_THREADS; }

@@ -19,6 +19,7 @@
 // helpers round half away from zero, mirrored left/top and clamped right/bottom B4T edges.
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
+#include "dsvg_host.hpp"
 
 // --------------------------------------------------------------------------------------------
 // helpers
@@ -619,35 +620,56 @@ int sbt_tail_supported(const SbtGeo &g)
 }
 
 // forward transform of planes [c0, c0+npl) of njobs jobs (all P or all I)
+#define PB(kid, bytes) do { if (pf) pf->begin(st, kid, bytes); } while (0)
+#define PE() do { if (pf) pf->end(st); } while (0)
+
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
-                    int from_src)
+                    int from_src, Prof *pf)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
+    const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
     if (isP) {
+        PB(KID_FWD_HAAR_PIX, smp * 5.0);       // 1 B/sample in, 4 B/sample out (details + LL3)
         hipLaunchKernelGGL(k_fwd_haar_pix, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        PE();
     } else {
+        PB(KID_FWD_B4T, smp * 5.0);
         hipLaunchKernelGGL(k_fwd_b4t, grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        PE();
+        PB(KID_FWD_HAAR_S1, smp * 2.0);        // LL1 (1/4) in, levels 2..3 out
         hipLaunchKernelGGL(k_fwd_haar_s1, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+        PE();
     }
+    PB(KID_FWD_TAIL, s3 * 8.0);
     hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+    PE();
 }
 
-void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP)
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
+    const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
+    PB(KID_INV_TAIL, s3 * 8.0);
     hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+    PE();
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
     const bool filt = (c0 == 0);
     if (isP) {
+        PB(KID_INV_HAAR_TILE, smp * 6.0);      // 4 B/sample coefficients + 1 B prediction in, 1 B out
         if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         else      hipLaunchKernelGGL((k_inv_haar_tile<false, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        PE();
     } else {
+        PB(KID_INV_HAAR_TILE, smp * 2.0);
         if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         else      hipLaunchKernelGGL((k_inv_haar_tile<false, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
+        PB(KID_INV_B4T, smp * 5.0);
         hipLaunchKernelGGL(k_inv_b4t, bg, dim3(256), 0, st, jobs, G, c0, npl);
+        PE();
     }
 }
 

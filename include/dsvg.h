@@ -122,6 +122,8 @@ int dsvg_dev_upload(dsvg_ctx *ctx, void *dptr, const void *src, size_t bytes);
 int dsvg_load_frames(dsvg_ctx *ctx, int first_slot, int n, const void *yuv, int yuv_on_device, int with_pyramid);
 /* same, frame i read from yuv + i*frame_pitch bytes (device pointer only) */
 int dsvg_load_frames_strided(dsvg_ctx *ctx, int first_slot, int n, const void *yuv_dev, size_t frame_pitch, int with_pyramid);
+/* same, frame i (at yuv_dev + i*frame_pitch) goes to source slot slots[i]: one launch set for a whole batch */
+int dsvg_load_frames_map(dsvg_ctx *ctx, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid);
 int dsvg_get_luma_sums(dsvg_ctx *ctx, int first_slot, int n, unsigned *sums_out);   /* raw sums, syncs */
 int dsvg_get_avg_luma(dsvg_ctx *ctx, int first_slot, int n, int *avg_out);           /* syncs */
 
@@ -143,7 +145,7 @@ typedef struct {
     int32_t dc[3];           /* unquantised DC (coefficient [0]) of each plane */
     uint32_t nruns[3];       /* number of (run,value) pairs */
     uint32_t nbytes[3];      /* payload length in bytes (bit count rounded up) */
-    const uint8_t *payload[3]; /* host (pinned) pointers, valid until the slot is coded again */
+    const uint8_t *payload[3]; /* host (pinned) pointers, valid until the next dsvg_fetch_pictures */
 } dsvg_pic_out;
 
 /* Residual coding of njobs pictures in one batch: frame copy, dsv_sub_pred, then per plane
@@ -167,12 +169,16 @@ typedef struct {
 } dsvg_dec_job;
 int dsvg_decode_pictures(dsvg_ctx *ctx, int njobs, const dsvg_dec_job *jobs);
 
-/* kernel timing hook for bench.py: HIP-event time (ms) and launch count of the named kernel
- * family accumulated since the last reset ("sbt_fwd", "sbt_inv", "hzcc", "bmc", "hme", "frame").
- * Timing is only collected while enabled (it inserts events on the pipeline stream). */
-int dsvg_prof_enable(dsvg_ctx *ctx, int on);
+/* Kernel timing hook for bench.py: every launch of the kernels selected by `kernel_mask` (bit i =
+ * kernel id i, names from dsvg_prof_kernel_name) is bracketed by HIP events on the pipeline stream.
+ * dsvg_prof_get returns the summed event time (ms), launch count and the ALGORITHMIC bytes those
+ * launches moved (compulsory traffic: each input read once, each output written once; the per-sample
+ * figures are listed in DESIGN.md) since the last reset. */
+int dsvg_prof_kernels(void);
+const char *dsvg_prof_kernel_name(int kid);
+int dsvg_prof_enable(dsvg_ctx *ctx, unsigned long long kernel_mask);
 int dsvg_prof_reset(dsvg_ctx *ctx);
-int dsvg_prof_get(dsvg_ctx *ctx, const char *family, double *ms, long *launches, double *alg_bytes);
+int dsvg_prof_get(dsvg_ctx *ctx, int kid, double *ms, long *launches, double *alg_bytes);
 
 #ifdef __cplusplus
 }
