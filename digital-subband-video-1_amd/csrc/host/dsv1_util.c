@@ -6,6 +6,10 @@
 #include <stdio.h>
 #include "dsv1_host.h"
 
+/* dsv.h:221 of the reference: the logging macros of callers compiled against the reference headers
+ * (dsv_main.c) index this table directly */
+char *dsv_lvlname[5] = {"NONE", "ERROR", "WARNING", "INFO", "DEBUG"};
+
 static int g_level = 1;
 static unsigned g_nalloc, g_nfree, g_balloc, g_bfree;
 int dsv1_device = 0;
@@ -16,10 +20,9 @@ void dsv1_set_device(int device) { dsv1_device = device; }
 
 void dsv1_log(int level, const char *fmt, ...)
 {
-    static const char *names[5] = {"NONE", "ERROR", "WARNING", "INFO", "DEBUG"};
     va_list ap;
     if (level > g_level) return;
-    printf("[DSV][%s] ", names[level < 0 ? 0 : (level > 4 ? 4 : level)]);
+    printf("[DSV][%s] ", dsv_lvlname[level < 0 ? 0 : (level > 4 ? 4 : level)]);
     va_start(ap, fmt);
     vprintf(fmt, ap);
     va_end(ap);

@@ -1,0 +1,162 @@
+"""Definitions of the golden-vector cases shared by tools/make_goldens.py (which runs them on the REAL
+reference, in the build container) and the tests (which run them on the oracle and on the HIP path and
+compare with the committed hashes in tests/golden/)."""
+import ctypes as C
+import hashlib
+
+import numpy as np
+
+import _cabi as A
+
+# name -> (w, h, fmt, frames, style, seed, reference CLI flags, kwargs for orc_cfg / make_encoder_cfg)
+STREAM_CASES = {
+    # BASELINE config 1: CIF intra-only with the CLI defaults (ABR!) and with CRF
+    "cfg1_cif_intra_abr": (352, 288, A.SUBSAMP_420, 8, 0, 0x00C1F001, ["-gop0", "-qp85"], dict(qp=85, gop=0, rc_mode_cli=0)),
+    "cfg1_cif_intra_crf": (352, 288, A.SUBSAMP_420, 8, 0, 0x00C1F001, ["-gop0", "-qp85", "-rc_mode1"], dict(qp=85, gop=0, rc_mode_cli=1)),
+    "cif_gop12_style2": (352, 288, A.SUBSAMP_420, 6, 2, 0x00C1F002, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    "cif_gop12_style1_abr": (352, 288, A.SUBSAMP_420, 14, 1, 0x00C1F003, ["-gop12", "-qp60"], dict(qp=60, gop=12, rc_mode_cli=0)),
+    "cif_forced_intra": (352, 288, A.SUBSAMP_420, 6, 1, 0x00C1F004, ["-gop12", "-qp85", "-rc_mode1", "-ipct20"], dict(qp=85, gop=12, rc_mode_cli=1, ipct=20)),
+    "qvga_444": (320, 240, A.SUBSAMP_444, 6, 2, 0x00C1F005, ["-gop12", "-qp95", "-rc_mode1"], dict(qp=95, gop=12, rc_mode_cli=1)),
+    "qvga_422_abr": (320, 240, A.SUBSAMP_422, 6, 1, 0x00C1F006, ["-gop12", "-qp85", "-kbps800"], dict(qp=85, gop=12, rc_mode_cli=0, kbps=800)),
+    "cif_411": (352, 288, A.SUBSAMP_411, 4, 0, 0x00C1F007, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    "lowq_chroma_cap": (352, 288, A.SUBSAMP_420, 5, 2, 0x00C1F008, ["-gop12", "-qp10", "-rc_mode1"], dict(qp=10, gop=12, rc_mode_cli=1)),
+    # BASELINE config 2 / 3 shapes, short
+    "cfg2_1080p_intra": (1920, 1080, A.SUBSAMP_420, 2, 1, 0x10800001, ["-gop0", "-qp85", "-rc_mode1"], dict(qp=85, gop=0, rc_mode_cli=1)),
+    "cfg3_1080p_gop12": (1920, 1080, A.SUBSAMP_420, 13, 0, 0x10800003, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    "cfg3_1080p_gop12_style2": (1920, 1080, A.SUBSAMP_420, 4, 2, 0x10800004, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+}
+
+# operator-level known answers: name -> dict describing a seeded input
+OP_CASES = {
+    "sbt_352x288_P": dict(op="sbt", w=352, h=288, isP=1, seed=11),
+    "sbt_352x288_I": dict(op="sbt", w=352, h=288, isP=0, seed=12),
+    "sbt_250x130_P": dict(op="sbt", w=250, h=130, isP=1, seed=13),
+    "sbt_960x540_I": dict(op="sbt", w=960, h=540, isP=0, seed=14),
+    "sbt_1920x1080_P": dict(op="sbt", w=1920, h=1080, isP=1, seed=15),
+    "hzcc_960x540_overlap": dict(op="hzcc", w=960, h=540, isP=1, q=313, cur_plane=1, seed=21),
+    "hzcc_250x130_overlap2": dict(op="hzcc", w=250, h=130, isP=0, q=100, cur_plane=0, seed=22),
+    "hzcc_352x288_minq": dict(op="hzcc", w=352, h=288, isP=1, q=16, cur_plane=0, seed=23),
+    "bmc_352x288_420": dict(op="bmc", w=352, h=288, fmt=A.SUBSAMP_420, span=40, seed=31),
+    "bmc_360x200_422_far": dict(op="bmc", w=360, h=200, fmt=A.SUBSAMP_422, span=400, seed=32),
+    "hme_352x288_style2": dict(op="hme", w=352, h=288, style=2, levels=3, seed=0xC1F041),
+    "hme_704x480_style1": dict(op="hme", w=704, h=480, style=1, levels=3, seed=0xC1F042),
+}
+
+
+def _sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _plane(rng, w, h):
+    base = rng.integers(0, 256, size=(h // 8 + 2, w // 8 + 2)).astype(np.float64)
+    img = np.kron(base, np.ones((8, 8)))[:h, :w] + rng.integers(-6, 7, size=(h, w))
+    return np.clip(img, 0, 255).astype(np.uint8)
+
+
+def _frame(rng, w, h, fmt, extend):
+    f = A.BorderedFrame(w, h, fmt)
+    for i in range(3):
+        f.plane(i)[:, :] = _plane(rng, *f.dims[i])
+    extend(f.ptr())
+    return f
+
+
+def run_op_case(case, impl, L, orc=None):
+    """run one operator case with implementation `impl` in {"ref","orc","prod"}; returns {name: sha256}.
+    Inputs are built with numpy only (identical everywhere); border extension uses the oracle/ref."""
+    fn = {
+        "ref": dict(fwd="dsv_fwd_sbt", inv="dsv_inv_sbt", enc="dsv_encode_plane", sub="dsv_sub_pred", hme="dsv_hme",
+                    ext="dsv_extend_frame", ds="dsv_ds2x_frame_luma", extl="dsv_extend_frame_luma"),
+        "orc": dict(fwd="orc_fwd_sbt", inv="orc_inv_sbt", enc="orc_encode_plane", sub="orc_sub_pred", hme="orc_hme_run",
+                    ext="orc_frame_extend", ds="orc_frame_ds2x_luma", extl="orc_frame_extend_luma"),
+        "prod": dict(fwd="dsvg_op_fwd_sbt", inv="dsvg_op_inv_sbt", enc="dsvg_op_encode_plane", sub="dsvg_op_sub_pred",
+                     hme="dsvg_op_hme"),
+    }[impl]
+    helper = L if impl != "prod" else orc          # input preparation (extend / pyramid) never uses the product
+    hfn = fn if impl != "prod" else {"ext": "orc_frame_extend", "ds": "orc_frame_ds2x_luma", "extl": "orc_frame_extend_luma"}
+    rng = np.random.default_rng(case["seed"])
+    out = {}
+    if case["op"] == "sbt":
+        w, h, isP = case["w"], case["h"], case["isP"]
+        f = _frame(rng, w, h, A.SUBSAMP_444, getattr(helper, hfn["ext"]))
+        co = np.zeros(w * h, dtype=np.int32)
+        getattr(L, fn["fwd"])(C.byref(f.c.planes[0]), C.byref(A.Coefs(A.i32p(co), w, h)), isP)
+        out["coefs"] = _sha(co)
+        q = 313
+        co2 = co.copy()
+        co2[1:] = (co2[1:] // 24) * 24
+        for c in (0, 1):
+            o = A.BorderedFrame(w, h, A.SUBSAMP_444)
+            tmp = co2.copy()
+            getattr(L, fn["inv"])(C.byref(o.c.planes[c]), C.byref(A.Coefs(A.i32p(tmp), w, h)), q, isP, c)
+            out["inv_c%d" % c] = _sha(o.plane(c))
+    elif case["op"] == "hzcc":
+        w, h, isP, q, cp = case["w"], case["h"], case["isP"], case["q"], case["cur_plane"]
+        fw, fh = (w * 2, h * 2) if cp else (w, h)
+        bw, bh, nbh, nbv = A.block_dims(fw, fh)
+        meta = A.Meta(fw, fh, A.SUBSAMP_420, 30, 1, 1, 1)
+        prm = A.Params(C.pointer(meta), 1, isP, bw, bh, nbh, nbv)
+        sb = rng.integers(0, 4, size=nbh * nbv).astype(np.uint8)
+        st = A.Stability(C.pointer(prm), A.u8p(sb), cp, isP)
+        co = rng.laplace(0, 40, size=(h, w)).astype(np.int32)
+        co[: h // 8, : w // 8] *= 16
+        co = co.reshape(-1).copy()
+        buf = np.zeros(w * h * 8 + 64, dtype=np.uint8)
+        bs = A.BS(A.u8p(buf), 0)
+        getattr(L, fn["enc"])(C.byref(bs), C.byref(A.Coefs(A.i32p(co), w, h)), q, C.byref(st))
+        out["bits"] = _sha(buf[: bs.pos // 8])
+        out["dequant"] = _sha(co)
+    elif case["op"] == "bmc":
+        w, h, fmt, span = case["w"], case["h"], case["fmt"], case["span"]
+        bw, bh, nbh, nbv = A.block_dims(w, h)
+        meta = A.Meta(w, h, fmt, 30, 1, 1, 1)
+        prm = A.Params(C.pointer(meta), 1, 1, bw, bh, nbh, nbv)
+        ext = getattr(helper, hfn["ext"])
+        reff = _frame(rng, w, h, fmt, ext)
+        inp = _frame(rng, w, h, fmt, ext)
+        mv = np.zeros(nbh * nbv, dtype=A.MV_DTYPE)
+        mv["x"] = rng.integers(-span, span + 1, size=nbh * nbv)
+        mv["y"] = rng.integers(-span, span + 1, size=nbh * nbv)
+        intra = rng.random(nbh * nbv) < 0.3
+        mv["mode"] = intra
+        mv["submask"] = np.where(intra, rng.integers(1, 16, size=nbh * nbv), 0)
+        dif = A.BorderedFrame(w, h, fmt)
+        getattr(L, fn["sub"])(mv.ctypes.data_as(C.POINTER(A.MV)), C.byref(prm), dif.ptr(), inp.ptr(), reff.ptr())
+        out["pred"] = _sha(dif.raw())
+        out["resid"] = _sha(inp.raw())
+    elif case["op"] == "hme":
+        w, h, levels = case["w"], case["h"], case["levels"]
+        fmt = A.SUBSAMP_420
+        clip = A.gen_clip(w, h, fmt, case["seed"], 2, style=case["style"])
+        bw, bh, nbh, nbv = A.block_dims(w, h)
+        meta = A.Meta(w, h, fmt, 30, 1, 1, 1)
+        prm = A.Params(C.pointer(meta), 1, 1, bw, bh, nbh, nbv)
+        pyr = []
+        for t in range(2):
+            f = A.BorderedFrame(w, h, fmt)
+            f.load_planar(clip[t])
+            getattr(helper, hfn["ext"])(f.ptr())
+            lv = [f]
+            for i in range(levels):
+                g = A.BorderedFrame(A.rshift_up(w, i + 1), A.rshift_up(h, i + 1), fmt)
+                getattr(helper, hfn["ds"])(g.ptr(), lv[-1].ptr())
+                getattr(helper, hfn["extl"])(g.ptr())
+                lv.append(g)
+            pyr.append(lv)
+        hm = A.HME()
+        hm.params = C.pointer(prm)
+        hm.levels = levels
+        for l in range(levels + 1):
+            hm.src[l] = C.pointer(pyr[1][l].c)
+            hm.ref[l] = C.pointer(pyr[0][l].c)
+        if impl == "prod":
+            pct = C.c_int(0)
+            rc = L.dsvg_op_hme(C.byref(hm), C.byref(pct))
+            assert rc == 0, L.dsvg_last_error()
+        else:
+            getattr(L, fn["hme"])(C.byref(hm))
+        for l in range(levels + 1):
+            a = np.ctypeslib.as_array(C.cast(hm.mvf[l], C.POINTER(C.c_uint8)), shape=(nbh * nbv * 12,)).copy().view(A.MV_DTYPE)
+            fields = np.stack([a[k].astype(np.int32) for k in ("x", "y", "mode", "submask", "lo_var", "lo_tex", "high_detail")])
+            out["mv_level%d" % l] = _sha(fields)
+    return out

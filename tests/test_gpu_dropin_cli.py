@@ -1,0 +1,45 @@
+"""Drop-in proof on the GPU: the reference's own, unmodified CLI driver (dsv_main.c) linked against
+libdsv1_mi355x.so (oracle/_ref/dsv1_dropin, built by oracle/Makefile where /root/reference exists) must
+write the same .dsv and decode the same frames as the all-reference CLI (oracle/_ref/dsv1)."""
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+import pytest
+
+import _cabi as A
+
+pytestmark = pytest.mark.gpu
+DROPIN = os.path.join(A.ROOT, "oracle", "_ref", "dsv1_dropin")
+
+
+def run(binary, args, env=None):
+    r = subprocess.run([binary] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, env=env, timeout=600)
+    return r.returncode, r.stdout.decode(errors="replace")
+
+
+@pytest.mark.parametrize("flags", [["-gop12", "-qp85", "-rc_mode1"], ["-gop12", "-qp70"], ["-gop0", "-qp85"]])
+def test_reference_cli_on_gpu_library(flags):
+    if not (os.path.exists(DROPIN) and os.path.exists(A.REF_CLI)):
+        pytest.skip("oracle/_ref binaries were not built (no /root/reference at build time)")
+    w, h, fmt, n = 352, 288, A.SUBSAMP_420, 9
+    clip = A.gen_clip(w, h, fmt, 0xD801, n, style=2)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = A.PKG_DIR + ":" + env.get("LD_LIBRARY_PATH", "")
+    with tempfile.TemporaryDirectory() as td:
+        inp = os.path.join(td, "in.yuv")
+        clip.tofile(inp)
+        common = ["-y", "-inp_" + inp, "-w%d" % w, "-h%d" % h, "-fmt2"] + flags
+        rc1, log1 = run(A.REF_CLI, ["e", "-out_" + os.path.join(td, "ref.dsv")] + common)
+        rc2, log2 = run(DROPIN, ["e", "-out_" + os.path.join(td, "gpu.dsv")] + common, env)
+        assert rc2 == 0, log2
+        a = open(os.path.join(td, "ref.dsv"), "rb").read()
+        b = open(os.path.join(td, "gpu.dsv"), "rb").read()
+        assert a == b, "drop-in CLI stream differs (%d vs %d bytes)\n%s" % (len(b), len(a), log2[-400:])
+        rc3, log3 = run(A.REF_CLI, ["d", "-y", "-inp_" + os.path.join(td, "ref.dsv"), "-out_" + os.path.join(td, "ref_dec.yuv")])
+        rc4, log4 = run(DROPIN, ["d", "-y", "-inp_" + os.path.join(td, "ref.dsv"), "-out_" + os.path.join(td, "gpu_dec.yuv")], env)
+        assert rc4 == 0, log4
+        x = np.fromfile(os.path.join(td, "ref_dec.yuv"), dtype=np.uint8)
+        y = np.fromfile(os.path.join(td, "gpu_dec.yuv"), dtype=np.uint8)
+        A.assert_same("decoded yuv", y, x)

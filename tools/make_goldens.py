@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/ from the REAL reference (oracle/_ref, compiled from /root/reference).
+
+Run in the build container only (the reference does not exist on the GPU box):
+    make -C oracle ref && python tools/make_goldens.py
+
+A fixture is data: inputs come from the committed integer generator (oracle/orc_gen.c, regenerated at
+test time from (w,h,fmt,seed,style)), expected outputs are produced here by the reference:
+  * streams.json   -- for each stream case: CLI flags, sha256 + length of the whole .dsv, sha256 of every
+                      packet, sha256 of every decoded frame (reference decoder)
+  * cif_gop12.dsv  -- one complete small stream kept verbatim (config-1 size, 6 frames)
+  * ops.json       -- operator-level known answers: sha256 of dsv_fwd_sbt / dsv_inv_sbt / dsv_encode_plane
+                      / dsv_sub_pred / dsv_hme outputs on seeded inputs
+"""
+import ctypes as C
+import hashlib
+import json
+import os
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _cabi as A  # noqa: E402
+import golden_cases as G  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def sha(b):
+    return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def main():
+    assert A.have_ref(), "build oracle/_ref first (make -C oracle ref)"
+    os.makedirs(OUT, exist_ok=True)
+    ref = A.load_ref()
+    streams = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, (w, h, fmt, n, style, seed, flags, kw) in G.STREAM_CASES.items():
+            clip = A.gen_clip(w, h, fmt, seed, n, style=style)
+            dsv = A.ref_cli_encode(clip, w, h, A.FMT_CLI[fmt], flags, td)
+            dec = A.ref_cli_decode(dsv, td).reshape(n, -1)
+            streams[name] = {
+                "len": len(dsv), "sha256": sha(dsv),
+                "packets": [sha(p) for p in A.split_packets(dsv)],
+                "decoded": [sha(dec[t]) for t in range(n)],
+            }
+            if name == "cif_gop12_style2":
+                with open(os.path.join(OUT, "cif_gop12.dsv"), "wb") as f:
+                    f.write(dsv)
+            print(name, len(dsv), streams[name]["sha256"][:16])
+    with open(os.path.join(OUT, "streams.json"), "w") as f:
+        json.dump(streams, f, indent=1, sort_keys=True)
+
+    ops = {}
+    for name, case in G.OP_CASES.items():
+        ops[name] = G.run_op_case(case, "ref", ref)
+        print(name, {k: v[:12] for k, v in ops[name].items()})
+    with open(os.path.join(OUT, "ops.json"), "w") as f:
+        json.dump(ops, f, indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()
