@@ -1,16 +1,21 @@
 // k_hme.hip -- hierarchical motion estimation + level-0 mode decision for gfx950 (MI355X).
 //
 // Replaces dsv_hme / refine_level (hme.c:378-741).  One launch per pyramid level (coarse -> fine),
-// one 256-thread workgroup per visited block and frame pair.  The source block and each reference
-// window are staged in LDS with aligned dword loads; SADs are per-thread partial sums folded with
-// wave shuffles (ds_swizzle/DPP on gfx950) and a small LDS stage; every decision that depends on
-// candidate ORDER (first minimum wins, hme.c:503-506,531-534,572-575; last candidate is the
-// fallback, hme.c:482-509) is taken by one lane in the reference's order.
-// Level 0 adds: the 32x32 half-pel lattice of the centred 16x16 reference patch (hpel hme.c:350-376)
-// and the 8-point half-pel search on the 14x14 window (hme.c:551-591), the block statistics with
-// 32-bit unsigned wrap-around (hme.c:181-300), the intra tests (hme.c:652-682), the
-// representability veto (hme.c:147-179) and the 4-quadrant vote (hme.c:89-134, 689-716).
-// high_detail needs the left/top/top-left neighbours' final flags (hme.c:621-648) and is
+// one 256-thread workgroup per visited block and frame pair, threads laid out 16 column groups (4 px,
+// one dword) x 16 row groups -- no integer divisions on the hot loops.
+//   * the source block lives in registers (one dword per thread-row); every SAD is
+//     v_alignbyte_b32 (re-align the reference dwords) + v_sad_u8 (4 pixels per instruction);
+//   * inherited candidates are evaluated straight from global memory (no reuse => no LDS staging) and
+//     reduced together in ONE workgroup reduction; the 9-point +-1 search reads a (bw+2)x(bh+2) window
+//     staged in LDS as aligned dwords (each window dword feeds 3 candidates);
+//   * every decision that depends on candidate ORDER (first minimum wins, hme.c:503-506,531-534,
+//     572-575; the last candidate is the fallback, hme.c:482-509) is evaluated identically by all lanes
+//     from the reduced sums, in the reference's order.
+// Level 0 adds: the 32x32 half-pel lattice of the centred 16x16 reference patch (hpel hme.c:350-376),
+// the 8-point half-pel search on the 14x14 window (hme.c:551-591), the block statistics with 32-bit
+// unsigned wrap-around (hme.c:181-300; v_dot4_u32_u8 for the sums of squares), the intra tests
+// (hme.c:652-682), the representability veto (hme.c:147-179) and the 4-quadrant vote (hme.c:89-134,
+// 689-716).  high_detail needs the left/top/top-left neighbours' final flags (hme.c:621-648) and is
 // resolved by the second tiny kernel k_hme_detail.
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
@@ -18,14 +23,14 @@
 
 #define WIN 14
 #define LAT 32
-#define SP 64              // pitch of the source block in LDS
-#define RP 72              // pitch of reference windows in LDS
+#define SP 64              // pitch of the source block in LDS (bytes)
+#define RP 72              // pitch of reference windows in LDS (bytes, 18 dwords)
 #define RROWS 67
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
-// stage rows [oy,oy+nh) x cols [ox,ox+nw) of a plane into LDS (pitch P); returns the byte shift
-// `mis` such that dst[r*P + mis + k] == plane(ox+k, oy+r)
+// stage rows [oy,oy+nh) x cols [ox,ox+nw) of a plane into LDS (pitch P) as ALIGNED dwords; returns the
+// byte shift `mis` such that dst[r*P + mis + k] == plane(ox+k, oy+r)
 static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_t *plane, int stride,
                                                int ox, int oy, int nw, int nh)
 {
@@ -40,15 +45,45 @@ static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_
     return mis;
 }
 
-// sum over the workgroup, result visible to all threads (s_red: 4 words, s_out: 1 word)
-static __device__ __forceinline__ unsigned block_sum(unsigned v, unsigned *s_red)
+// unaligned dword from global memory: bytes p[0..3]
+static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
+{
+    const unsigned sh = (unsigned)(((uintptr_t)p) & 3);
+    const unsigned *a = reinterpret_cast<const unsigned *>(p - sh);
+    const unsigned lo = a[0], hi = a[1];
+    return __builtin_amdgcn_alignbyte(hi, lo, sh);
+}
+
+struct HmeShared {
+    __attribute__((aligned(16))) uint8_t src[64 * SP];
+    __attribute__((aligned(16))) uint8_t ref[RROWS * RP];
+    __attribute__((aligned(16))) uint8_t patch[20 * 24];
+    __attribute__((aligned(16))) uint8_t lat[LAT * LAT];
+    __attribute__((aligned(16))) uint8_t swin[WIN * 24];
+    __attribute__((aligned(16))) uint8_t rwin[WIN * 16];
+    unsigned part[4][9];
+    int par[5];
+    int cand[8];
+    int ncand;
+};
+
+// sum N values over the workgroup; every thread receives all totals (2 barriers)
+template <int N>
+static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*part)[9])
 {
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    for (int i = 0; i < N; i++) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o);
+    }
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int i = 0; i < N; i++) part[threadIdx.x >> 6][i] = v[i];
+    }
     __syncthreads();
-    return s_red[0] + s_red[1] + s_red[2] + s_red[3];
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
 }
 
 static __device__ __forceinline__ int frame_invalid(int fw, int fh, int x, int y, int w, int h)   // invalid_block
@@ -57,38 +92,23 @@ static __device__ __forceinline__ int frame_invalid(int fw, int fh, int x, int y
     return x < -b || y < -b || x + w > fw + b || y + h > fh + b;
 }
 
-struct HmeShared {
-    uint8_t src[64 * SP];
-    __attribute__((aligned(16))) uint8_t ref[RROWS * RP];
-    __attribute__((aligned(16))) uint8_t patch[20 * 24];
-    uint8_t lat[LAT * LAT];
-    __attribute__((aligned(16))) uint8_t swin[WIN * 24];
-    uint8_t rwin[WIN * WIN];
-    unsigned red[4];
-    unsigned part[4][9];
-    int cand[8];
-    int ncand, pick, best, bestk;
-    int mvx, mvy;
-    int any;
-};
-
 static __device__ const int FP_X[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1};
 static __device__ const int FP_Y[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};
 static __device__ const int HP_X[8] = {1, -1, 0, 0, -1, 1, -1, 1};
 static __device__ const int HP_Y[8] = {0, 0, 1, -1, -1, -1, 1, 1};
 
-// gradient / moment sums of a w x h byte block held in LDS (pitch P)
-static __device__ __forceinline__ void stat_partial(const uint8_t *p, int P, int w, int h,
-                                                    unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
+// gradient / moment partial sums of a 14x14 byte window in LDS (pitch P), one pixel per thread (tid < 196)
+static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
 {
     gh = gv = s1 = s2 = 0;
-    for (int i = threadIdx.x; i < w * h; i += 256) {
-        const int y = i / w, x = i - y * w;
+    const int t = threadIdx.x;
+    if (t < WIN * WIN) {
+        const int y = t / WIN, x = t - y * WIN;
         const int px = p[y * P + x];
-        if (x + 1 < w) gh += (unsigned)abs(px - (int)p[y * P + x + 1]);
-        if (y > 0) gv += (unsigned)abs(px - (int)p[(y - 1) * P + x]);
-        s1 += (unsigned)px;
-        s2 += (unsigned)(px * px);
+        if (x + 1 < WIN) gh = (unsigned)abs(px - (int)p[y * P + x + 1]);
+        if (y > 0) gv = (unsigned)abs(px - (int)p[(y - 1) * P + x]);
+        s1 = (unsigned)px;
+        s2 = (unsigned)(px * px);
     }
 }
 
@@ -97,6 +117,7 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
 {
     __shared__ HmeShared S;
     const int tid = threadIdx.x;
+    const int cg = tid & 15, rg = tid >> 4;             // column group (4 px) / row group
     const int pair = blockIdx.y;
     const int step = 1 << level;
     const int nvx = (A.nxb + step - 1) / step;
@@ -114,100 +135,129 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     DMV *mf = A.mvf + ((size_t)pair * (A.levels + 1) + level) * A.nblk;
     const DMV *parent = level < A.levels ? A.mvf + ((size_t)pair * (A.levels + 1) + level + 1) * A.nblk : nullptr;
 
-    // source block -> LDS
-    for (int q = tid; q < bh * ((bw + 3) >> 2); q += 256) {
-        const int r = q / ((bw + 3) >> 2), d = q - r * ((bw + 3) >> 2);
-        *reinterpret_cast<unsigned *>(S.src + r * SP + 4 * d) =
-            *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + 4 * d);
+    // this thread's pixels: columns 4cg..4cg+3 of rows rg, rg+16, rg+32, rg+48
+    const int xcol = 4 * cg;
+    const unsigned cmask = xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u));
+    unsigned srcw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int r = rg + 16 * k;
+        srcw[k] = 0;
+        if (cmask && r < bh) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
+        if (LEVEL0 && r < bh && xcol < ((bw + 3) & ~3)) *reinterpret_cast<unsigned *>(S.src + r * SP + xcol) = srcw[k];
+        srcw[k] &= cmask;
     }
-    if (tid == 0) {
-        int n = 0;
-        S.cand[n++] = 0;
+    // parents (hme.c:452-480): 5 lanes fetch, lane 0 de-duplicates in the reference's order
+    if (tid < 5) {
+        int v = 0;
         if (parent) {
             const unsigned pmask = ~(unsigned)((step << 1) - 1);
             const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
-            const int ox[5] = {0, -2, 2, 0, 0}, oy[5] = {0, 0, 0, -2, 2};
-            for (int m = 0; m < 5; m++) {
-                const int x = pi + ox[m] * step, y = pj + oy[m] * step;
-                if (x < 0 || x >= A.nxb || y < 0 || y >= A.nyb) continue;
+            const int ox = tid == 1 ? -2 : (tid == 2 ? 2 : 0), oy = tid == 3 ? -2 : (tid == 4 ? 2 : 0);
+            const int x = pi + ox * step, y = pj + oy * step;
+            if (x >= 0 && x < A.nxb && y >= 0 && y < A.nyb) {
                 const DMV pv = parent[x + y * A.nxb];
-                const int all = (int)(((unsigned)(uint16_t)pv.x) | ((unsigned)(uint16_t)pv.y << 16));
-                if (!all) continue;
-                bool dup = false;
-                for (int k = 0; k < n; k++) dup |= (S.cand[k] == all);
-                if (!dup) S.cand[n++] = all;
+                v = (int)(((unsigned)(uint16_t)pv.x) | ((unsigned)(uint16_t)pv.y << 16));
             }
         }
+        S.par[tid] = v;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int n = 0;
+        S.cand[n++] = 0;
+        for (int m = 0; m < 5; m++) {
+            const int all = S.par[m];
+            if (!all) continue;
+            bool dup = false;
+            for (int k = 0; k < n; k++) dup |= (S.cand[k] == all);
+            if (!dup) S.cand[n++] = all;
+        }
         S.ncand = n;
-        S.pick = n - 1;
-        S.best = 0x7fffffff;
     }
     __syncthreads();
     const int n = S.ncand;
 
+    // best inherited candidate by SAD, all candidates in one pass, reference pixels straight from HBM/L2
+    int pick = n - 1;
     if (n > 1) {
-        for (int k = 0; k < n; k++) {
-            const int all = S.cand[k];
-            const int dx = ((int)(int16_t)(all & 0xffff)) >> level, dy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
-            if (frame_invalid(fw, fh, bx, by, bw, bh)) continue;
-            if (frame_invalid(fw, fh, bx + dx, by + dy, bw, bh)) continue;
-            __syncthreads();
-            const int mis = load_win(S.ref, RP, rp, stride, bx + dx, by + dy, bw, bh);
-            __syncthreads();
-            unsigned acc = 0;
-            for (int q = tid; q < bw * bh; q += 256) {
-                const int y = q / bw, x = q - y * bw;
-                acc += (unsigned)abs((int)S.src[y * SP + x] - (int)S.ref[y * RP + mis + x]);
+        unsigned acc[6];
+        unsigned validmask = 0;
+        const bool src_ok = !frame_invalid(fw, fh, bx, by, bw, bh);
+#pragma unroll
+        for (int k = 0; k < 6; k++) {
+            acc[k] = 0;
+            if (k < n) {
+                const int all = S.cand[k];
+                const int cdx = ((int)(int16_t)(all & 0xffff)) >> level, cdy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
+                if (src_ok && !frame_invalid(fw, fh, bx + cdx, by + cdy, bw, bh)) {
+                    validmask |= 1u << k;
+                    if (cmask) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; kk++) {
+                            const int r = rg + 16 * kk;
+                            if (r < bh) {
+                                const unsigned rw = ldg_u32_unaligned(rp + (long)(by + cdy + r) * stride + bx + cdx + xcol);
+                                acc[k] = __builtin_amdgcn_sad_u8(srcw[kk], rw & cmask, acc[k]);
+                            }
+                        }
+                    }
+                }
             }
-            const int sc = (int)block_sum(acc, S.red);
-            if (tid == 0 && S.best > sc) { S.best = sc; S.pick = k; }
         }
-        __syncthreads();
+        block_sum_n<6>(acc, S.part);
+        int best_score = 0x7fffffff;
+#pragma unroll
+        for (int k = 0; k < 6; k++)
+            if (k < n && ((validmask >> k) & 1u) && best_score > (int)acc[k]) { best_score = (int)acc[k]; pick = k; }
     }
     int dx, dy;
     {
-        const int all = S.cand[S.pick];
+        const int all = S.cand[pick];
         dx = ((int)(int16_t)(all & 0xffff)) >> level;
         dy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
         dx = d_clamp(dx, -bw - bx, fw - bx);
         dy = d_clamp(dy, -bh - by, fh - by);
     }
-    __syncthreads();
-    // 9-point +-1 search around (dx,dy): window (bw+2)x(bh+2) at (bx+dx-1, by+dy-1)
+    // 9-point +-1 search around (dx,dy): window (bw+2)x(bh+2) at (bx+dx-1, by+dy-1) staged as aligned dwords
+    int best, bestk;
     {
         const int mis = load_win(S.ref, RP, rp, stride, bx + dx - 1, by + dy - 1, bw + 2, bh + 2);
         __syncthreads();
         unsigned acc[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) acc[k] = 0;
-        for (int q = tid; q < bw * bh; q += 256) {
-            const int y = q / bw, x = q - y * bw;
-            const int s = S.src[y * SP + x];
-            const uint8_t *r = S.ref + (y + 1) * RP + mis + x + 1;
+        if (cmask) {
 #pragma unroll
-            for (int k = 0; k < 9; k++) acc[k] += (unsigned)abs(s - (int)r[FP_Y[k] * RP + FP_X[k]]);
-        }
+            for (int kk = 0; kk < 4; kk++) {
+                const int r = rg + 16 * kk;
+                if (r < bh) {
+                    unsigned v[3][3];           // v[row][ox]: reference dword at window (r+row, ox + 4cg)
 #pragma unroll
-        for (int k = 0; k < 9; k++) {
-            unsigned v = acc[k];
+                    for (int rr = 0; rr < 3; rr++) {
+                        const unsigned *w = reinterpret_cast<const unsigned *>(S.ref + (r + rr) * RP) + cg;
+                        const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
 #pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if ((tid & 63) == 0) S.part[tid >> 6][k] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int best = 0x7fffffff, m = 0;
-            for (int k = 0; k < 9; k++) {
-                const int sc = (int)(S.part[0][k] + S.part[1][k] + S.part[2][k] + S.part[3][k]);
-                if (best > sc) { best = sc; m = k; }
+                        for (int ox = 0; ox < 3; ox++) {
+                            const int s = mis + ox;
+                            v[rr][ox] = (s < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (unsigned)s)
+                                               : __builtin_amdgcn_alignbyte(d2, d1, (unsigned)(s - 4))) & cmask;
+                        }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 9; k++)
+                        acc[k] = __builtin_amdgcn_sad_u8(srcw[kk], v[1 + FP_Y[k]][1 + FP_X[k]], acc[k]);
+                }
             }
-            S.best = best;
-            S.bestk = m;
         }
-        __syncthreads();
+        block_sum_n<9>(acc, S.part);
+        best = 0x7fffffff; bestk = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++)
+            if (best > (int)acc[k]) { best = (int)acc[k]; bestk = k; }
     }
-    dx += FP_X[S.bestk];
-    dy += FP_Y[S.bestk];
+    dx += FP_X[bestk];
+    dy += FP_Y[bestk];
     int mvx = (int)(int16_t)(dx << level), mvy = (int)(int16_t)(dy << level);
     DMV out;
     out.x = (int16_t)mvx; out.y = (int16_t)mvy;
@@ -219,20 +269,22 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     }
 
     // ------------------------------------------------------------------ level 0 only
-    int best = S.best;
     const unsigned yarea = (unsigned)(bw * bh), yareasq = yarea * yarea;
     const int wx = bx + ((bw >> 1) - WIN / 2), wy = by + ((bh >> 1) - WIN / 2);
+    const bool do_hp = best > BW * BH;
+    // stage: source 14x14 window, and either the 19x20 patch for the lattice or the full-pel 14x14 window
     const int smis = load_win(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
+    int pmis;
+    if (do_hp) pmis = load_win(S.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
+    else       pmis = load_win(S.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
+    __syncthreads();
     bool have_hp = false;
-    if (best > BW * BH) {
-        // 16x16 patch at (wx+mvx-1, wy+mvy-1) plus the filter margins: rows -1..18, cols -1..17
-        const int pmis = load_win(S.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
-        __syncthreads();
+    if (do_hp) {
         {   // one lattice cell (j,i) per thread: F, H, V, D
             const int lj = tid >> 4, li = tid & 15;
             const uint8_t *p = S.patch + (lj + 1) * 24 + pmis + li + 1;       // -> patch sample (li, lj)
             const int F = p[0];
-            const int H = d_sat8((tap4(p[-1], p[0], p[1], p[2]) + 8) >> 4);
+            const int Hh = d_sat8((tap4(p[-1], p[0], p[1], p[2]) + 8) >> 4);
             const int V = d_sat8((tap4(p[-24], p[0], p[24], p[48]) + 8) >> 4);
             const int hm = tap4(p[-24 - 1], p[-24], p[-24 + 1], p[-24 + 2]);
             const int h0 = tap4(p[-1], p[0], p[1], p[2]);
@@ -240,7 +292,7 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
             const int h2 = tap4(p[48 - 1], p[48], p[48 + 1], p[48 + 2]);
             const int D = d_sat8((tap4(hm, h0, h1, h2) + 128) >> 8);
             uint8_t *e = S.lat + (2 * lj) * LAT + 2 * li;
-            e[0] = (uint8_t)F; e[1] = (uint8_t)H; e[LAT] = (uint8_t)V; e[LAT + 1] = (uint8_t)D;
+            e[0] = (uint8_t)F; e[1] = (uint8_t)Hh; e[LAT] = (uint8_t)V; e[LAT + 1] = (uint8_t)D;
         }
         __syncthreads();
         unsigned acc[8];
@@ -253,35 +305,21 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
 #pragma unroll
             for (int k = 0; k < 8; k++) acc[k] = (unsigned)abs(s - (int)c[HP_X[k] + HP_Y[k] * LAT]);
         }
+        block_sum_n<8>(acc, S.part);
+        int best_hp = (int)((unsigned)(best * (WIN * WIN)) / yarea);
+        int hm = -1;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            unsigned v = acc[k];
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
-            if ((tid & 63) == 0) S.part[tid >> 6][k] = v;
-        }
-        __syncthreads();
-        if (tid == 0) {
-            int best_hp = (int)((unsigned)(best * (WIN * WIN)) / yarea);
-            int hm = -1;
-            for (int k = 0; k < 8; k++) {
-                const int sc = (int)(S.part[0][k] + S.part[1][k] + S.part[2][k] + S.part[3][k]);
-                if (best_hp > sc) { best_hp = sc; hm = k; }
-            }
-            S.bestk = hm;
-            S.best = hm >= 0 ? (int)((unsigned)best_hp * yarea / (WIN * WIN)) : best;
-        }
-        __syncthreads();
-        const int hm = S.bestk;
-        best = S.best;
+        for (int k = 0; k < 8; k++)
+            if (best_hp > (int)acc[k]) { best_hp = (int)acc[k]; hm = k; }
         mvx = (int)(int16_t)(mvx << 1);
         mvy = (int)(int16_t)(mvy << 1);
         if (hm >= 0) {
+            best = (int)((unsigned)best_hp * yarea / (WIN * WIN));
             mvx = (int)(int16_t)(mvx + HP_X[hm]);
             mvy = (int)(int16_t)(mvy + HP_Y[hm]);
             if (tid < WIN * WIN) {
                 const int y = tid / WIN, x = tid - y * WIN;
-                S.rwin[tid] = S.lat[2 + 2 * LAT + HP_X[hm] + HP_Y[hm] * LAT + 2 * x + y * 2 * LAT];
+                S.rwin[y * 16 + x] = S.lat[2 + 2 * LAT + HP_X[hm] + HP_Y[hm] * LAT + 2 * x + y * 2 * LAT];
             }
             have_hp = true;
         }
@@ -289,49 +327,68 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
         mvx = (int)(int16_t)(mvx << 1);
         mvy = (int)(int16_t)(mvy << 1);
     }
-    __syncthreads();
     if (!have_hp) {
-        const int rm = load_win(S.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
-        __syncthreads();
+        if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
+            __syncthreads();
+            pmis = load_win(S.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
+            __syncthreads();
+        }
         if (tid < WIN * WIN) {
             const int y = tid / WIN, x = tid - y * WIN;
-            S.rwin[tid] = S.patch[y * 24 + rm + x];
+            S.rwin[y * 16 + x] = S.patch[y * 24 + pmis + x];
         }
     }
+    // zero-motion reference block -> LDS (needed by the variance test, the veto and the quadrant votes)
     __syncthreads();
-
-    // ---- statistics
-    unsigned gh, gv, s1, s2;
-    stat_partial(S.src, SP, bw, bh, gh, gv, s1, s2);
-    gh = block_sum(gh, S.red); gv = block_sum(gv, S.red); s1 = block_sum(s1, S.red); s2 = block_sum(s2, S.red);
-    const unsigned luma_tex = ((gh + gv) / 2) / yarea;
-    const unsigned luma_var = s2 - (s1 * s1) / yarea;
-
-    stat_partial(S.swin + smis, 24, WIN, WIN, gh, gv, s1, s2);
-    gh = block_sum(gh, S.red); gv = block_sum(gv, S.red); s1 = block_sum(s1, S.red); s2 = block_sum(s2, S.red);
-    const int src_tex = (int)(((gh + gv) / 2) / (WIN * WIN));
-    const int src_avg = (int)(s1 / (WIN * WIN));
-    const int src_var = (int)(s2 - (s1 * s1) / (WIN * WIN));
-
-    stat_partial(S.rwin, WIN, WIN, WIN, gh, gv, s1, s2);
-    gh = block_sum(gh, S.red); gv = block_sum(gv, S.red); s1 = block_sum(s1, S.red); s2 = block_sum(s2, S.red);
-    const int ref_tex = (int)(((gh + gv) / 2) / (WIN * WIN));
-    const int ref_avg = (int)(s1 / (WIN * WIN));
-    const int ref_var = (int)(s2 - (s1 * s1) / (WIN * WIN));
-
-    // zero-motion reference block -> LDS
-    __syncthreads();
-    const int zmis = load_win(S.ref, RP, rp, stride, bx, by, bw, bh);
+    const int zmis = load_win(S.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
     __syncthreads();
     const uint8_t *zref = S.ref + zmis;
-    unsigned zs1 = 0, zs2 = 0;
-    for (int q = tid; q < bw * bh; q += 256) {
-        const int y = q / bw, x = q - y * bw;
-        const unsigned px = zref[y * RP + x];
-        zs1 += px; zs2 += px * px;
+
+    // ---- statistics: one fused pass + one 8-value and one 10-value reduction
+    unsigned st[8];                 // src block gh,gv,s1,s2 ; zref s1,s2 ; spare
+#pragma unroll
+    for (int k = 0; k < 8; k++) st[k] = 0;
+    if (cmask) {
+#pragma unroll
+        for (int kk = 0; kk < 4; kk++) {
+            const int r = rg + 16 * kk;
+            if (r < bh) {
+                const unsigned curw = srcw[kk];
+                // horizontal neighbours: bytes x+1..x+4 of the same row (next dword supplies the 4th)
+                const unsigned nxt = *reinterpret_cast<const unsigned *>(S.src + r * SP + xcol + 4);
+                const unsigned right = __builtin_amdgcn_alignbyte(nxt, *reinterpret_cast<const unsigned *>(S.src + r * SP + xcol), 1u);
+                // pairs (x,x+1) count only while x+1 < bw
+                const int npair = min(4, bw - 1 - xcol);
+                const unsigned pm = npair <= 0 ? 0u : (npair >= 4 ? 0xffffffffu : ((1u << (8 * npair)) - 1u));
+                st[0] = __builtin_amdgcn_sad_u8(curw & pm, right & pm, st[0]);
+                if (r > 0) {
+                    const unsigned up = *reinterpret_cast<const unsigned *>(S.src + (r - 1) * SP + xcol) & cmask;
+                    st[1] = __builtin_amdgcn_sad_u8(curw, up, st[1]);
+                }
+                st[2] = __builtin_amdgcn_sad_u8(curw, 0u, st[2]);
+                st[3] = __builtin_amdgcn_udot4(curw, curw, st[3], false);
+                const unsigned zw = *reinterpret_cast<const unsigned *>(zref + r * RP + xcol) & cmask;
+                st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
+                st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
+            }
+        }
     }
-    zs1 = block_sum(zs1, S.red); zs2 = block_sum(zs2, S.red);
-    const unsigned zvar = zs2 - (zs1 * zs1) / yarea;
+    block_sum_n<8>(st, S.part);
+    const unsigned luma_tex = ((st[0] + st[1]) / 2) / yarea;
+    const unsigned luma_var = st[3] - (st[2] * st[2]) / yarea;
+    const unsigned zs1 = st[4];
+    const unsigned zvar = st[5] - (st[4] * st[4]) / yarea;
+
+    unsigned ws[8];
+    win_partial(S.swin + smis, 24, ws[0], ws[1], ws[2], ws[3]);
+    win_partial(S.rwin, 16, ws[4], ws[5], ws[6], ws[7]);
+    block_sum_n<8>(ws, S.part);
+    const int src_tex = (int)(((ws[0] + ws[1]) / 2) / (WIN * WIN));
+    const int src_avg = (int)(ws[2] / (WIN * WIN));
+    const int src_var = (int)(ws[3] - (ws[2] * ws[2]) / (WIN * WIN));
+    const int ref_tex = (int)(((ws[4] + ws[5]) / 2) / (WIN * WIN));
+    const int ref_avg = (int)(ws[6] / (WIN * WIN));
+    const int ref_var = (int)(ws[7] - (ws[6] * ws[6]) / (WIN * WIN));
 
     out.x = (int16_t)mvx; out.y = (int16_t)mvy;
     out.lo_tex = (luma_tex <= 2);
@@ -344,75 +401,88 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     else if (abs(src_avg - ref_avg) > 8) want_intra = true;
     else if (luma_tex <= 10 && (unsigned)best > yareasq / 16) want_intra = true;
     else {
-        // chroma variance test (c_maxvar hme.c:269-300) straight from HBM (level-0 frames carry chroma)
+        // chroma variance test (c_maxvar hme.c:269-300): the four chroma blocks straight from HBM, one reduction
         const FrameLayout &L0 = A.L[0];
         const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
         const int cbw = bw >> L0.hs, cbh = bh >> L0.vs;
-        unsigned mv_[2] = {0, 0};
-        for (int side = 0; side < 2; side++) {
-            const uint8_t *fb = A.slab[0] + (size_t)(side ? rf : cur) * L0.pitch;
-            unsigned best_v = 0;
-            for (int pl = 1; pl <= 2; pl++) {
-                const uint8_t *cp = fb + L0.off[pl] + (long)cby * L0.stride[pl] + cbx;
-                unsigned a1 = 0, a2 = 0;
-                for (int q = tid; q < cbw * cbh; q += 256) {
-                    const int y = q / cbw, x = q - y * cbw;
-                    const unsigned px = cp[(long)y * L0.stride[pl] + x];
-                    a1 += px; a2 += px * px;
+        unsigned cs[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) cs[k] = 0;
+        const int ndw = (cbw + 3) >> 2;
+        for (int q = tid; q < ndw * cbh; q += 256) {
+            const int y = q / ndw, xd = 4 * (q - y * ndw);
+            const int nb = min(4, cbw - xd);
+            const unsigned m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
+#pragma unroll
+            for (int side = 0; side < 2; side++) {
+                const uint8_t *fb = A.slab[0] + (size_t)(side ? rf : cur) * L0.pitch;
+#pragma unroll
+                for (int pl = 1; pl <= 2; pl++) {
+                    const unsigned w = ldg_u32_unaligned(fb + L0.off[pl] + (long)(cby + y) * L0.stride[pl] + cbx + xd) & m;
+                    const int o = side * 4 + (pl - 1) * 2;
+                    cs[o] = __builtin_amdgcn_sad_u8(w, 0u, cs[o]);
+                    cs[o + 1] = __builtin_amdgcn_udot4(w, w, cs[o + 1], false);
                 }
-                a1 = block_sum(a1, S.red); a2 = block_sum(a2, S.red);
-                const unsigned var = a2 - (a1 * a1) / (unsigned)(cbw * cbh);
-                best_v = var > best_v ? var : best_v;
             }
-            mv_[side] = best_v;
         }
-        if (mv_[1] > 4 * mv_[0]) want_intra = true;
+        block_sum_n<8>(cs, S.part);
+        const unsigned carea = (unsigned)(cbw * cbh);
+        const unsigned vsu = cs[1] - (cs[0] * cs[0]) / carea, vsv = cs[3] - (cs[2] * cs[2]) / carea;
+        const unsigned vru = cs[5] - (cs[4] * cs[4]) / carea, vrv = cs[7] - (cs[6] * cs[6]) / carea;
+        const unsigned cvs = vsu > vsv ? vsu : vsv, cvr = vru > vrv ? vru : vrv;
+        if (cvr > 4 * cvs) want_intra = true;
     }
 
     if (want_intra) {
-        // representability veto: mean of the zero-motion block + clamped residual must reproduce src
+        // representability veto + the four quadrant votes in one pass, one 9-value reduction
         const int mean = (int)zs1 / (bw * bh);
-        unsigned bad = 0;
-        for (int q = tid; q < bw * bh; q += 256) {
-            const int y = q / bw, x = q - y * bw;
-            const int px = S.src[y * SP + x];
-            const int back = d_sat8(mean + d_sat8(px - mean + 128) - 128);
-            bad += (back != px);
+        const int qw = bw / 2, qh = bh / 2;
+        unsigned qv[9];                 // [0] bad count, [1+2q] good, [2+2q] evil
+#pragma unroll
+        for (int k = 0; k < 9; k++) qv[k] = 0;
+        for (int kk = 0; kk < 4; kk++) {
+            const int r = rg + 16 * kk;
+            if (r >= bh) continue;
+#pragma unroll
+            for (int b4 = 0; b4 < 4; b4++) {
+                const int x = xcol + b4;
+                if (x >= bw) continue;
+                const int pa = S.src[r * SP + x], pb = zref[r * RP + x];
+                const int back = d_sat8(mean + d_sat8(pa - mean + 128) - 128);
+                qv[0] += (back != pa);
+                if (x < 2 * qw && r < 2 * qh) {
+                    const int qx = x >= qw, qy = r >= qh;
+                    const int lx = x - qx * qw, ly = r - qy * qh;        // position inside the quadrant
+                    const int la = lx ? S.src[r * SP + x - 1] : pa, lb = lx ? zref[r * RP + x - 1] : pb;
+                    const int ua = ly ? S.src[(r - 1) * SP + x] : pa, ub = ly ? zref[(r - 1) * RP + x] : pb;
+                    const int dif = abs(pa - pb);
+                    unsigned good = (unsigned)(abs(pa - la) + abs(pa - ua) + abs(pb - lb) + abs(pb - ub));
+                    unsigned evil = 0;
+                    if (dif == 0) good += 192;
+                    else if (dif == 1) good += 128;
+                    else if (dif == 2) good += 96;
+                    else evil = (unsigned)dif;
+                    const int q = qx + 2 * qy;
+#pragma unroll
+                    for (int qq = 0; qq < 4; qq++) {
+                        qv[1 + 2 * qq] += (q == qq) ? good : 0u;
+                        qv[2 + 2 * qq] += (q == qq) ? evil : 0u;
+                    }
+                }
+            }
         }
-        bad = block_sum(bad, S.red);
-        if (!bad) {
+        block_sum_n<9>(qv, S.part);
+        if (!qv[0]) {
             int submask = 0xF;
             if (src_tex > 1) {
-                const int qw = bw / 2, qh = bh / 2;
-                for (int k = 0; k < 4; k++) {
-                    const int ox = (k & 1) ? qw : 0, oy = (k & 2) ? qh : 0;
-                    unsigned good = 0, evil = 0;
-                    for (int q = tid; q < qw * qh; q += 256) {
-                        const int y = q / qw, x = q - y * qw;
-                        const uint8_t *ra = S.src + (oy + y) * SP + ox + x;
-                        const uint8_t *rb = zref + (oy + y) * RP + ox + x;
-                        const int pa = ra[0], pb = rb[0];
-                        const int la = x ? ra[-1] : pa, lb = x ? rb[-1] : pb;
-                        const int ua = y ? ra[-SP] : pa, ub = y ? rb[-RP] : pb;
-                        const int dif = abs(pa - pb);
-                        good += (unsigned)(abs(pa - la) + abs(pa - ua) + abs(pb - lb) + abs(pb - ub));
-                        if (dif == 0) good += 192;
-                        else if (dif == 1) good += 128;
-                        else if (dif == 2) good += 96;
-                        else evil += (unsigned)dif;
-                    }
-                    good = block_sum(good, S.red);
-                    evil = block_sum(evil, S.red);
-                    if (good >= (unsigned)((qw + qh) >> 1) * evil) submask &= ~(1 << k);
-                }
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (qv[1 + 2 * k] >= (unsigned)((qw + qh) >> 1) * qv[2 + 2 * k]) submask &= ~(1 << k);
             }
             if (submask) {
                 out.submask = (uint8_t)submask;
                 out.mode = 1;
-            } else {
-                out.submask = 0;
             }
-            // note: the reference leaves submask = 0xF & ~votes even when it ends up inter (0)
         }
     }
     if (tid == 0) {
