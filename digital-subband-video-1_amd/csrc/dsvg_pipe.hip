@@ -356,13 +356,14 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant)
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
 static int enqueue_recon(dsvg_ctx *c, int nI, int n)
 {
+    launch_sbt_tail(c->st, c->jobs_d, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
     if (nI > 0) {
-        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, &c->prof);
-        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, &c->prof);
+        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, &c->prof, 0);
+        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, &c->prof, 0);
     }
     if (n > nI) {
-        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 0, 1, 1, &c->prof);
-        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 1, 2, 1, &c->prof);
+        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0);
+        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0);
     }
     launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots, &c->prof);
     return DSVG_OK;
@@ -409,15 +410,16 @@ extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jo
     HIPCHK(hipMemcpyAsync(c->mvs, mvh, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, slh, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     if (nI > 0) {
-        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, 1, &c->prof);
-        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, 1, &c->prof);
+        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, 1, &c->prof, 0);
+        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, 1, &c->prof, 0);
     }
     if (njobs > nI) {
         const int nP = njobs - nI;
         launch_mc(c->st, c->jobs_d + nI, nP, c->MG, 1, &c->prof);
-        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 0, 1, 1, 0, &c->prof);
-        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 1, 2, 1, 0, &c->prof);
+        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0);
+        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0);
     }
+    launch_sbt_tail(c->st, c->jobs_d, njobs, c->G, 0, 3, 0, &c->prof);
     launch_hz_encode(c->st, c->jobs_d, njobs, c->max_chunks, &c->prof, (double)c->CL.total * njobs);
     OPCHK(enqueue_recon(c, nI, njobs));
     HIPCHK(hipGetLastError());

@@ -65,6 +65,40 @@ static __device__ __forceinline__ int find_region(const HzPlane &hp, int p)
 }
 
 // -------------------------------------------------------------------------------------------------
+// one scan cell, general path: region lookup, overlap handling, in-place dequantised store
+static __device__ __forceinline__ int hz_cell(const JobDev &jb, const HzPlane &hp, int c, int32_t *plane, int p)
+{
+    const HzRegion r = hp.r[find_region(hp, p)];
+    const int local = p - r.base;
+    const int y = local / r.sw, x = local - y * r.sw;
+    const int gx = r.x0 + x, gy = r.y0 + y;
+    if (p == 0) {
+        jb.psum[c].dc = plane[0];                     // DC travels separately (hzcc.c:161,457-460)
+        return 0;
+    }
+    int cv = plane[(size_t)gy * hp.w + gx];
+    const int l = r.level;
+    // Cells covered by two regions are processed twice by the sequential reference.
+    // Both passes only READ the original value here (each emits its own symbol); the final
+    // value is stored by hz_fix_overlaps() in the next kernel, so there is no in-place race.
+    bool shared_cell = false;
+    if (l >= 1 && gx < 2 * hp.s_w[l - 1] && gy < 2 * hp.s_h[l - 1]) {
+        const int rx = gx >= hp.s_w[l - 1], ry = gy >= hp.s_h[l - 1];
+        if (rx + ry) {                                // the previous level's pass ran first on this cell
+            const HzRegion e = hp.r[1 + 3 * (l - 1) + (rx + 2 * ry) - 1];
+            const int etq = cell_tq(e, jb.stable, hp.nbh, gx - e.x0, gy - e.y0);
+            const int ev = quant_any(e, cv, etq);
+            cv = ev ? dequant_any(e, ev, etq) : 0;
+            shared_cell = true;
+        }
+    }
+    if (l >= 0 && l <= 1 && (gx >= hp.s_w[l + 1] || gy >= hp.s_h[l + 1])) shared_cell = true;
+    const int tq = cell_tq(r, jb.stable, hp.nbh, x, y);
+    const int v = quant_any(r, cv, tq);
+    if (!shared_cell) plane[(size_t)gy * hp.w + gx] = v ? dequant_any(r, v, tq) : 0;
+    return v;
+}
+
 __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ jobs)
 {
     __shared__ int s_pos[HZ_CHUNK];
@@ -79,53 +113,59 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
     int32_t *plane = jb.coef + jb.hz_coef_off[c];
     const uint8_t *stable = jb.stable;
     const int W = hp.w;
+    // any region overlap in this plane?  (then rows/columns touching it take the general path)
+    const bool any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+                        (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
     if (tid == 0) s_bits = 0;
 
-    // each wave owns 512 consecutive scan cells -> 8 rounds of 64
+    // each wave owns 512 consecutive scan cells: 2 rounds of 256, four adjacent cells per lane
     const int wbase = chunk * HZ_CHUNK + wv * 512;
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
     int wcount = 0;
 #pragma unroll 1
-    for (int k = 0; k < 8; k++) {
-        const int p = wbase + k * 64 + lane;
-        int v = 0;
-        if (p < hp.nscan) {
-            const int ri = find_region(hp, p);
-            const HzRegion r = hp.r[ri];
-            const int local = p - r.base;
+    for (int k = 0; k < 2; k++) {
+        const int p0 = wbase + k * 256 + 4 * lane;
+        int v[4] = {0, 0, 0, 0};
+        if (p0 < hp.nscan) {
+            const HzRegion r = hp.r[find_region(hp, p0)];
+            const int local = p0 - r.base;
             const int y = local / r.sw, x = local - y * r.sw;
-            const int gx = r.x0 + x, gy = r.y0 + y;
-            if (p == 0) {
-                jb.psum[c].dc = plane[0];             // DC travels separately (hzcc.c:161,457-460)
-            } else {
-                int cv = plane[(size_t)gy * W + gx];
-                const int l = r.level;
-                // Cells covered by two regions are processed twice by the sequential reference.
-                // Both passes only READ the original value here (each emits its own symbol); the final
-                // value is stored by hz_fix_overlaps() in the next kernel, so there is no in-place race.
-                bool shared_cell = false;
-                if (l >= 1 && gx < 2 * hp.s_w[l - 1] && gy < 2 * hp.s_h[l - 1]) {
-                    const int rx = gx >= hp.s_w[l - 1], ry = gy >= hp.s_h[l - 1];
-                    if (rx + ry) {              // the previous level's pass ran first on this cell
-                        const HzRegion e = hp.r[1 + 3 * (l - 1) + (rx + 2 * ry) - 1];
-                        const int etq = cell_tq(e, stable, hp.nbh, gx - e.x0, gy - e.y0);
-                        const int ev = quant_any(e, cv, etq);
-                        cv = ev ? dequant_any(e, ev, etq) : 0;
-                        shared_cell = true;
-                    }
+            const size_t idx = (size_t)(r.y0 + y) * W + r.x0 + x;
+            bool fast = (p0 != 0) && (x + 3 < r.sw) && ((idx & 3) == 0);
+            if (fast && any_ov) {
+                const int l = r.level, gx = r.x0 + x, gy = r.y0 + y;
+                if (l >= 1 && gx < 2 * hp.s_w[l - 1] && gy < 2 * hp.s_h[l - 1]) fast = false;
+                if (l >= 0 && l <= 1 && (gx + 3 >= hp.s_w[l + 1] || gy >= hp.s_h[l + 1])) fast = false;
+            }
+            if (fast) {
+                // fast path: 4 cells of one region row, 16-byte load and store
+                int4 cv = *reinterpret_cast<const int4 *>(plane + idx);
+                int in[4] = {cv.x, cv.y, cv.z, cv.w}, out[4];
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    const int tq = cell_tq(r, stable, hp.nbh, x + j, y);
+                    v[j] = quant_any(r, in[j], tq);
+                    out[j] = v[j] ? dequant_any(r, v[j], tq) : 0;
                 }
-                if (l >= 0 && l <= 1 && (gx >= hp.s_w[l + 1] || gy >= hp.s_h[l + 1])) shared_cell = true;
-                const int tq = cell_tq(r, stable, hp.nbh, x, y);
-                v = quant_any(r, cv, tq);
-                if (!shared_cell) plane[(size_t)gy * W + gx] = v ? dequant_any(r, v, tq) : 0;
+                *reinterpret_cast<int4 *>(plane + idx) = make_int4(out[0], out[1], out[2], out[3]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+                    if (p0 + j < hp.nscan) v[j] = hz_cell(jb, hp, c, plane, p0 + j);
             }
         }
-        const unsigned long long m = __ballot(v != 0);
-        if (v != 0) {
-            const int rank = wcount + __popcll(m & ((1ull << lane) - 1ull));
-            s_pos[wv * 512 + rank] = p;
-            s_val[wv * 512 + rank] = v;
-        }
-        wcount += __popcll(m);
+        // compact the non-zeros in scan order: lanes in order, the 4 cells of a lane in order
+        const unsigned long long b0 = __ballot(v[0] != 0), b1 = __ballot(v[1] != 0);
+        const unsigned long long b2 = __ballot(v[2] != 0), b3 = __ballot(v[3] != 0);
+        int rank = wcount + __popcll(b0 & ltmask) + __popcll(b1 & ltmask) + __popcll(b2 & ltmask) + __popcll(b3 & ltmask);
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (v[j] != 0) {
+                s_pos[wv * 512 + rank] = p0 + j;
+                s_val[wv * 512 + rank] = v[j];
+                rank++;
+            }
+        wcount += __popcll(b0) + __popcll(b1) + __popcll(b2) + __popcll(b3);
     }
     if (lane == 0) s_wcnt[wv] = wcount;
     __syncthreads();

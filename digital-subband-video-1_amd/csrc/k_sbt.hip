@@ -18,6 +18,7 @@
 // Every formula keeps the C semantics of the reference: truncating *4/5, *5/4 and /4, rounding
 // helpers round half away from zero, mirrored left/top and clamped right/bottom B4T edges.
 #include "dsvg_dev.hpp"
+#include <algorithm>
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
 
@@ -624,7 +625,7 @@ int sbt_tail_supported(const SbtGeo &g)
 #define PE() do { if (pf) pf->end(st); } while (0)
 
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
-                    int from_src, Prof *pf)
+                    int from_src, Prof *pf, int with_tail)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
@@ -641,19 +642,38 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         hipLaunchKernelGGL(k_fwd_haar_s1, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
         PE();
     }
-    PB(KID_FWD_TAIL, s3 * 8.0);
-    hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+    if (with_tail) {
+        PB(KID_FWD_TAIL, s3 * 8.0);
+        hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+        PE();
+    }
+}
+
+// the LDS tails of planes [c0, c0+npl) of all jobs in ONE launch (dynamic LDS sized for the largest plane)
+void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf)
+{
+    size_t lds = 0;
+    double s3 = 0;
+    for (int c = c0; c < c0 + npl; c++) {
+        lds = std::max(lds, (size_t)G.g[c].w3 * G.g[c].h3 * 4);
+        s3 += (double)G.g[c].w3 * G.g[c].h3 * njobs;
+    }
+    PB(inverse ? KID_INV_TAIL : KID_FWD_TAIL, s3 * 8.0);
+    if (inverse) hipLaunchKernelGGL(k_inv_tail, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
+    else         hipLaunchKernelGGL(k_fwd_tail, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
     PE();
 }
 
-void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf)
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
-    PB(KID_INV_TAIL, s3 * 8.0);
-    hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
-    PE();
+    if (with_tail) {
+        PB(KID_INV_TAIL, s3 * 8.0);
+        hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+        PE();
+    }
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
     const bool filt = (c0 == 0);
     if (isP) {
