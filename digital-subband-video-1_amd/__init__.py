@@ -51,6 +51,8 @@ def lib():
         L.dsv1_batch_close.argtypes = [_C.c_void_p]
         L.dsv1_batch_set_fnum.argtypes = [_C.c_void_p, _C.c_int, _C.c_uint32]
         L.dsv1_batch_encode.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
+        L.dsv1_batch_submit.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
+        L.dsv1_batch_collect.argtypes = [_C.c_void_p, _C.POINTER(Buf)]
         L.dsv1_batch_eos.argtypes = [_C.c_void_p, _C.c_int, _C.POINTER(Buf)]
         L.dsv1_concat_gops.argtypes = [_C.POINTER(Buf), _C.c_int, _C.POINTER(Buf)]
         L.dsv1_batch_ctx.restype = _C.c_void_p
@@ -146,6 +148,26 @@ class Batch:
         if eos:
             for s in range(self.nstreams):
                 _chk(self.L.dsv1_batch_eos(self.h, s, _C.byref(bufs[s])), "dsv1_batch_eos")
+        return [_take(bufs[s]) for s in range(self.nstreams)]
+
+    def submit(self, yuv, on_device=False):
+        """pipelined form: enqueue one batch (returns while its residual coding still runs on the GPU).
+        At most two batches may be in flight: steady state is submit(i+1); collect(i)."""
+        if on_device:
+            ptr = yuv
+        else:
+            self._keep = _np.ascontiguousarray(yuv, dtype=_np.uint8)
+            ptr = self._keep.ctypes.data
+        if not hasattr(self, "_abr"):
+            self._abr = []
+        bufs = (Buf * self.nstreams)()
+        _chk(self.L.dsv1_batch_submit(self.h, ptr, 1 if on_device else 0, bufs), "dsv1_batch_submit")
+        self._abr.append(bufs)
+
+    def collect(self):
+        """fetch + assemble the oldest submitted batch -> one bytes object per stream"""
+        bufs = self._abr.pop(0)
+        _chk(self.L.dsv1_batch_collect(self.h, bufs), "dsv1_batch_collect")
         return [_take(bufs[s]) for s in range(self.nstreams)]
 
     def sync(self):

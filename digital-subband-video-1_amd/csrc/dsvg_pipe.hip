@@ -13,7 +13,13 @@
 
 struct dsvg_ctx {
     int device = 0;
-    hipStream_t st = nullptr;
+    hipStream_t st = nullptr;        // residual-coding stream
+    hipEvent_t ev_a = nullptr;       // analysis -> coding dependency
+    hipStream_t st_c = nullptr;      // fetch stream (gather + D2H of finished pictures)
+    std::vector<hipEvent_t> ev_coded;  // ring: completion of each dsvg_code_pictures call
+    std::vector<int> slot_ev;          // out slot -> index into ev_coded of the call that produces it
+    long ncalls = 0;
+    hipStream_t st_a = nullptr;      // analysis stream (frame load, pyramid, HME): overlaps coding of the previous batch
     int w = 0, h = 0, fmt = 0, bw = 0, bh = 0, nbh = 0, nbv = 0, nblk = 0, levels = 0;
     FrameLayout L[6];
     CoefLayout CL;
@@ -43,6 +49,8 @@ struct dsvg_ctx {
     DMV *mv_h = nullptr;
     uint8_t *stable_h = nullptr;
     int *slots_h = nullptr;
+    int *aslots_h = nullptr;         // analysis-stream staging (pair tables)
+    DMV *amv_h = nullptr;            // analysis-stream staging (motion fields)
     unsigned *luma_h = nullptr;
     int32_t *dec_h = nullptr;        // decoder: parsed (pos,val) staging
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
@@ -63,9 +71,13 @@ static void ctx_free(dsvg_ctx *c)
     void *d[] = {c->coef, c->s3, c->s1, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
                  c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d};
     for (void *p : d) if (p) (void)hipFree(p);
-    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h};
+    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
+    if (c->st_a) (void)hipStreamDestroy(c->st_a);
+    if (c->ev_a) (void)hipEventDestroy(c->ev_a);
+    if (c->st_c) (void)hipStreamDestroy(c->st_c);
+    for (hipEvent_t e : c->ev_coded) (void)hipEventDestroy(e);
     delete c;
 }
 
@@ -138,7 +150,13 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
 
     int rc = DSVG_OK;
     auto fail = [&](int r) { ctx_free(c); return r; };
-    if (hipStreamCreate(&c->st) != hipSuccess) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
+    if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st_a) != hipSuccess) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
+    if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
+    if (hipStreamCreate(&c->st_c) != hipSuccess) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
+    c->ev_coded.resize((size_t)2 * c->nwin + 2);
+    for (auto &e : c->ev_coded)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
+    c->slot_ev.assign((size_t)out_slots, -1);
     sbt_set_func_attributes();
     for (int l = 0; l <= c->levels; l++)
         if ((rc = c->src[l].alloc(c->L[l].pitch * (size_t)n_src_slots + 4096))) return fail(rc);
@@ -154,22 +172,24 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
-    if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->stable, (size_t)c->nblk * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->jobs_d, J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->stable, (size_t)c->nblk * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->jobs_d, O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvf, (size_t)(c->levels + 1) * c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->aux_tex, (size_t)c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->aux_var, (size_t)c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->slots_d, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->luma_sums, (size_t)n_src_slots, true))) return fail(rc);
-    if ((rc = hmalloc(&c->jobs_h, S))) return fail(rc);
+    if ((rc = hmalloc(&c->jobs_h, std::max(S, O)))) return fail(rc);
     if ((rc = dmalloc(&c->gtab_d, 9 * O, true))) return fail(rc);
     if ((rc = hmalloc(&c->gtab_h, 9 * O))) return fail(rc);
     if ((rc = hmalloc(&c->psum_h, 3 * O))) return fail(rc);
     if ((rc = hmalloc(&c->mv_h, (size_t)c->nblk * std::max(S, O)))) return fail(rc);
-    if ((rc = hmalloc(&c->stable_h, (size_t)c->nblk * S))) return fail(rc);
+    if ((rc = hmalloc(&c->stable_h, (size_t)c->nblk * std::max(S, O)))) return fail(rc);
     if ((rc = hmalloc(&c->slots_h, 3 * std::max(S, O)))) return fail(rc);
     if ((rc = hmalloc(&c->luma_h, (size_t)n_src_slots))) return fail(rc);
+    if ((rc = hmalloc(&c->aslots_h, 2 * O))) return fail(rc);
+    if ((rc = hmalloc(&c->amv_h, (size_t)c->nblk * O))) return fail(rc);
     (void)J;
     *out = c;
     return DSVG_OK;
@@ -193,7 +213,10 @@ extern "C" int dsvg_ctx_sync(dsvg_ctx *c)
 {
     if (!c) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipStreamSynchronize(c->st_a));
     HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipStreamSynchronize(c->st_c));
+    c->calls_since_sync = 0;
     HIPCHK(hipGetLastError());
     return DSVG_OK;
 }
@@ -224,16 +247,16 @@ extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t 
 // ------------------------------------------------------------------------------------------------
 static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d)
 {
-    launch_unpack(c->st, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d);
-    launch_extend(c->st, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof);
+    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d);
+    launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
-            launch_ds2x(c->st, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d);
-            launch_extend(c->st, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof);
+            launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d);
+            launch_extend(c->st_a, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof);
         }
-        if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st));
-        else       HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st));
-        launch_luma_sum(c->st, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums, &c->prof, tab_d);
+        if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st_a));
+        else       HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st_a));
+        launch_luma_sum(c->st_a, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums, &c->prof, tab_d);
     }
     HIPCHK(hipGetLastError());
     return DSVG_OK;
@@ -247,11 +270,11 @@ extern "C" int dsvg_load_frames(dsvg_ctx *c, int first_slot, int n, const void *
     const uint8_t *dsrc = (const uint8_t *)yuv;
     if (!yuv_on_device) {
         if (c->yuv_stage_bytes < fb * n) {
-            if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
+            if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st_a)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
             HIPCHK(hipMalloc((void **)&c->yuv_stage, fb * n + 256));
             c->yuv_stage_bytes = fb * n;
         }
-        HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st));
+        HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st_a));
         dsrc = c->yuv_stage;
     }
     return load_core(c, first_slot, n, dsrc, fb, with_pyramid, nullptr);
@@ -271,7 +294,7 @@ extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const 
     for (int i = 0; i < n; i++)
         if (slots[i] < 0 || slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
     if (!c->ltab_d) HIPCHK(hipMalloc((void **)&c->ltab_d, sizeof(int) * (size_t)c->n_src + 64));
-    HIPCHK(hipMemcpyAsync(c->ltab_d, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st));   // pageable: staged by the runtime
+    HIPCHK(hipMemcpyAsync(c->ltab_d, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_a));   // pageable: staged by the runtime
     return load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d);
 }
 
@@ -279,9 +302,8 @@ extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *
 {
     if (!c || !sums_out || first_slot < 0 || first_slot + n > c->n_src) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    c->calls_since_sync = 0;
+    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st_a));
+    HIPCHK(hipStreamSynchronize(c->st_a));
     memcpy(sums_out, c->luma_h, sizeof(unsigned) * n);
     return DSVG_OK;
 }
@@ -290,8 +312,8 @@ extern "C" int dsvg_get_avg_luma(dsvg_ctx *c, int first_slot, int n, int *avg_ou
 {
     if (!c || !avg_out || first_slot < 0 || first_slot + n > c->n_src) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st_a));
+    HIPCHK(hipStreamSynchronize(c->st_a));
     const FrameLayout &L = c->L[c->levels];
     for (int i = 0; i < n; i++) avg_out[i] = (int)c->luma_h[i] / (L.w[0] * L.h[0]);     // frame.c:237
     return DSVG_OK;
@@ -301,34 +323,33 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
 {
     if (!c || npairs < 1 || npairs > c->out_slots || !cur_slots || !ref_slots || !mvs_out) { dsvg_set_error("bad analyse arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipStreamSynchronize(c->st));       // slots_h / mv_h staging is shared with code_pictures
-    c->calls_since_sync = 0;
+    HIPCHK(hipStreamSynchronize(c->st_a));       // aslots_h / amv_h staging reuse
     for (int i = 0; i < npairs; i++) {
         if (cur_slots[i] < 0 || cur_slots[i] >= c->n_src || ref_slots[i] < 0 || ref_slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
-        c->slots_h[i] = cur_slots[i];
-        c->slots_h[c->out_slots + i] = ref_slots[i];
+        c->aslots_h[i] = cur_slots[i];
+        c->aslots_h[c->out_slots + i] = ref_slots[i];
     }
-    HIPCHK(hipMemcpyAsync(c->slots_d, c->slots_h, sizeof(int) * 2 * c->out_slots, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d, c->aslots_h, sizeof(int) * 2 * c->out_slots, hipMemcpyHostToDevice, c->st_a));
     const size_t per = (size_t)(c->levels + 1) * c->nblk;
-    HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st));
+    HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st_a));
     HmeArgs A; memset(&A, 0, sizeof(A));
     for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
-    launch_hme(c->st, A, npairs, &c->prof);
-    HIPCHK(hipMemcpy2DAsync(c->mv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
-                            (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    c->calls_since_sync = 0;
+    launch_hme(c->st_a, A, npairs, &c->prof);
+    HIPCHK(hipMemcpy2DAsync(c->amv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
+                            (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st_a));
+    HIPCHK(hipStreamSynchronize(c->st_a));
     HIPCHK(hipGetLastError());
-    memcpy(mvs_out, c->mv_h, (size_t)npairs * c->nblk * sizeof(DMV));
+    memcpy(mvs_out, c->amv_h, (size_t)npairs * c->nblk * sizeof(DMV));
     return DSVG_OK;
 }
 
 // ------------------------------------------------------------------------------------------------
-static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant)
+static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d = -1)
 {
+    if (d < 0) d = t;
     memset(&jb, 0, sizeof(jb));
     const CoefLayout &CL = c->CL;
     jb.xf = c->xf.p + (size_t)t * c->L[0].pitch;
@@ -336,8 +357,8 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant)
     jb.coef = c->coef + (size_t)t * CL.total;
     jb.s3 = c->s3 + (size_t)t * CL.s3total;
     jb.s1 = c->s1 + (size_t)t * CL.s1total;
-    jb.mvs = c->mvs + (size_t)t * c->nblk;
-    jb.stable = c->stable + (size_t)t * c->nblk;
+    jb.mvs = c->mvs + (size_t)d * c->nblk;
+    jb.stable = c->stable + (size_t)d * c->nblk;
     jb.nzpos = c->nzpos + (size_t)t * c->nz_total;
     jb.nzval = c->nzval + (size_t)t * c->nz_total;
     jb.chunks = c->chunks + (size_t)t * c->chunks_per_job;
@@ -354,76 +375,107 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant)
 
 // enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
-static int enqueue_recon(dsvg_ctx *c, int nI, int n)
+static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0)
 {
-    launch_sbt_tail(c->st, c->jobs_d, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
+    const JobDev *jd = c->jobs_d + d0;
+    launch_sbt_tail(c->st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
     if (nI > 0) {
-        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, &c->prof, 0);
-        launch_inv_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, &c->prof, 0);
+        launch_inv_sbt(c->st, jd, nI, c->G, 0, 1, 0, &c->prof, 0);
+        launch_inv_sbt(c->st, jd, nI, c->G, 1, 2, 0, &c->prof, 0);
     }
     if (n > nI) {
-        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0);
-        launch_inv_sbt(c->st, c->jobs_d + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0);
+        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0);
+        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0);
     }
-    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots, &c->prof);
+    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
+    return DSVG_OK;
+}
+
+// Enqueue nsteps frame steps of njobs pictures each (jobs[step*njobs + j]); step k+1 may use the
+// reconstructions step k produces.  All host-built tables of the whole call travel in ONE set of
+// host-to-device copies up front, then the kernel chains of the steps follow back to back.
+// The out slots of the call must form one contiguous block (they also index the device tables).
+extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_job *jobs)
+{
+    if (!c || !jobs || nsteps < 1 || njobs < 1 || njobs > c->max_jobs || nsteps * njobs > c->out_slots) {
+        dsvg_set_error("bad code_batch arguments"); return DSVG_ERR_ARG;
+    }
+    HIPCHK(hipSetDevice(c->device));
+    const int total = nsteps * njobs;
+    int base = jobs[0].out_slot;
+    for (int i = 1; i < total; i++) base = std::min(base, jobs[i].out_slot);
+    if (base < 0 || base + total > c->out_slots) { dsvg_set_error("out slots of a batch must be a contiguous block"); return DSVG_ERR_ARG; }
+    // source frames are produced on the analysis stream: make the coding stream wait for them
+    HIPCHK(hipEventRecord(c->ev_a, c->st_a));
+    HIPCHK(hipStreamWaitEvent(c->st, c->ev_a, 0));
+    // the staging block [base, base+total) was last used when these out slots were coded before; that
+    // call completed long ago if its results were fetched -- make sure anyway
+    const long call = c->ncalls++;
+    for (int i = 0; i < total; i++) {
+        const int e = c->slot_ev[base + i];
+        if (e >= 0) { HIPCHK(hipEventSynchronize(c->ev_coded[e])); break; }
+    }
+    std::vector<int> nIs(nsteps);
+    for (int t = 0; t < nsteps; t++) {
+        const dsvg_pic_job *js = jobs + (size_t)t * njobs;
+        // device order inside a step: intra jobs first, then inter jobs (kernels are specialised per type)
+        std::vector<int> order;
+        for (int i = 0; i < njobs; i++) if (js[i].ref_recon_slot < 0) order.push_back(i);
+        nIs[t] = (int)order.size();
+        for (int i = 0; i < njobs; i++) if (js[i].ref_recon_slot >= 0) order.push_back(i);
+        for (int k = 0; k < njobs; k++) {
+            const dsvg_pic_job &j = js[order[k]];
+            const int isP = j.ref_recon_slot >= 0;
+            const int d = base + t * njobs + k;
+            if (j.src_slot < 0 || j.src_slot >= c->n_src || j.ref_recon_slot >= c->n_recon || j.recon_slot >= c->n_recon ||
+                j.out_slot < base || j.out_slot >= base + total || !j.stable_blocks || (isP && !j.mvs)) {
+                dsvg_set_error("bad picture job (step %d job %d)", t, order[k]); return DSVG_ERR_ARG;
+            }
+            JobDev &jb = c->jobs_h[d];
+            fill_job(c, jb, k, isP, j.quant, d);
+            jb.psum = c->psum + (size_t)j.out_slot * 3;
+            jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
+            jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
+            jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
+            jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;
+            c->slots_h[d] = j.recon_slot;
+            memcpy(c->stable_h + (size_t)d * c->nblk, j.stable_blocks, (size_t)c->nblk);
+            if (isP) memcpy(c->mv_h + (size_t)d * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+        }
+    }
+    HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->mvs + (size_t)base * c->nblk, c->mv_h + (size_t)base * c->nblk, (size_t)c->nblk * total * sizeof(DMV), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots + base, c->slots_h + base, sizeof(int) * total, hipMemcpyHostToDevice, c->st));
+    for (int t = 0; t < nsteps; t++) {
+        const int d0 = base + t * njobs, nI = nIs[t];
+        const JobDev *jd = c->jobs_d + d0;
+        if (nI > 0) {
+            launch_fwd_sbt(c->st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0);
+            launch_fwd_sbt(c->st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0);
+        }
+        if (njobs > nI) {
+            const int nP = njobs - nI;
+            launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof);
+            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0);
+            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0);
+        }
+        launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
+        launch_hz_encode(c->st, jd, njobs, c->max_chunks, &c->prof, (double)c->CL.total * njobs);
+        OPCHK(enqueue_recon(c, nI, njobs, d0));
+    }
+    {   // completion marker of this call; fetch waits on it from its own stream
+        const int e = (int)(call % (long)c->ev_coded.size());
+        HIPCHK(hipEventRecord(c->ev_coded[e], c->st));
+        for (int i = 0; i < total; i++) c->slot_ev[base + i] = e;
+    }
+    HIPCHK(hipGetLastError());
     return DSVG_OK;
 }
 
 extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jobs)
 {
-    if (!c || !jobs || njobs < 1 || njobs > c->max_jobs) { dsvg_set_error("bad code_pictures arguments"); return DSVG_ERR_ARG; }
-    HIPCHK(hipSetDevice(c->device));
-    // pinned staging is a ring of nwin windows (one per call); never lap the device
-    if (c->calls_since_sync >= c->nwin - 1) { HIPCHK(hipStreamSynchronize(c->st)); c->calls_since_sync = 0; }
-    const int win = c->win;
-    c->win = (c->win + 1) % c->nwin;
-    c->calls_since_sync++;
-    JobDev *jh = c->jobs_h + (size_t)win * c->max_jobs;
-    DMV *mvh = c->mv_h + (size_t)win * c->max_jobs * c->nblk;
-    uint8_t *sth = c->stable_h + (size_t)win * c->max_jobs * c->nblk;
-    int *slh = c->slots_h + (size_t)win * c->max_jobs;
-    // device order: intra jobs first, then inter jobs (kernels are specialised per picture type)
-    std::vector<int> order;
-    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) order.push_back(i);
-    const int nI = (int)order.size();
-    for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) order.push_back(i);
-    for (int t = 0; t < njobs; t++) {
-        const dsvg_pic_job &j = jobs[order[t]];
-        const int isP = j.ref_recon_slot >= 0;
-        if (j.src_slot < 0 || j.src_slot >= c->n_src || j.ref_recon_slot >= c->n_recon || j.recon_slot >= c->n_recon ||
-            j.out_slot < 0 || j.out_slot >= c->out_slots || !j.stable_blocks || (isP && !j.mvs)) {
-            dsvg_set_error("bad picture job %d", order[t]); return DSVG_ERR_ARG;
-        }
-        JobDev &jb = jh[t];
-        fill_job(c, jb, t, isP, j.quant);
-        jb.psum = c->psum + (size_t)j.out_slot * 3;
-        jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
-        jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
-        jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
-        jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;
-        slh[t] = j.recon_slot;
-        memcpy(sth + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
-        if (isP) memcpy(mvh + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
-    }
-    HIPCHK(hipMemcpyAsync(c->jobs_d, jh, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->stable, sth, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->mvs, mvh, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, slh, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
-    if (nI > 0) {
-        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 0, 1, 0, 1, &c->prof, 0);
-        launch_fwd_sbt(c->st, c->jobs_d, nI, c->G, 1, 2, 0, 1, &c->prof, 0);
-    }
-    if (njobs > nI) {
-        const int nP = njobs - nI;
-        launch_mc(c->st, c->jobs_d + nI, nP, c->MG, 1, &c->prof);
-        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0);
-        launch_fwd_sbt(c->st, c->jobs_d + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0);
-    }
-    launch_sbt_tail(c->st, c->jobs_d, njobs, c->G, 0, 3, 0, &c->prof);
-    launch_hz_encode(c->st, c->jobs_d, njobs, c->max_chunks, &c->prof, (double)c->CL.total * njobs);
-    OPCHK(enqueue_recon(c, nI, njobs));
-    HIPCHK(hipGetLastError());
-    return DSVG_OK;
+    return dsvg_code_batch(c, 1, njobs, jobs);
 }
 
 extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsvg_pic_out *outs)
@@ -432,13 +484,21 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < n; i++)
         if (out_slots[i] < 0 || out_slots[i] >= c->out_slots) { dsvg_set_error("out slot out of range"); return DSVG_ERR_ARG; }
+    // wait (on the fetch stream only) for the coding calls that produce these slots -- later batches
+    // already enqueued on the coding stream keep running
+    {
+        std::vector<char> seen(c->ev_coded.size(), 0);
+        for (int i = 0; i < n; i++) {
+            const int e = c->slot_ev[out_slots[i]];
+            if (e >= 0 && !seen[e]) { seen[e] = 1; HIPCHK(hipStreamWaitEvent(c->st_c, c->ev_coded[e], 0)); }
+        }
+    }
     // 1. plane summaries (sizes)
     int lo = out_slots[0], hi = out_slots[0];
     for (int i = 1; i < n; i++) { lo = std::min(lo, out_slots[i]); hi = std::max(hi, out_slots[i]); }
     HIPCHK(hipMemcpyAsync(c->psum_h + 3 * (size_t)lo, c->psum + 3 * (size_t)lo, sizeof(HzPlaneSum) * 3 * (size_t)(hi - lo + 1),
-                          hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
-    c->calls_since_sync = 0;
+                          hipMemcpyDeviceToHost, c->st_c));
+    HIPCHK(hipStreamSynchronize(c->st_c));
     HIPCHK(hipGetLastError());
     // 2. compact every payload into one buffer on the device, then ONE device-to-host copy
     size_t total = 0;
@@ -463,10 +523,10 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
         HIPCHK(hipMalloc((void **)&c->gath_d, c->gath_cap));
         HIPCHK(hipHostMalloc((void **)&c->gath_h, c->gath_cap, hipHostMallocDefault));
     }
-    HIPCHK(hipMemcpyAsync(c->gtab_d, c->gtab_h, sizeof(unsigned long long) * 9 * (size_t)n, hipMemcpyHostToDevice, c->st));
-    launch_gather_bits(c->st, c->bits, c->gtab_d, 3 * n, c->gath_d);
-    if (total) HIPCHK(hipMemcpyAsync(c->gath_h, c->gath_d, total, hipMemcpyDeviceToHost, c->st));
-    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipMemcpyAsync(c->gtab_d, c->gtab_h, sizeof(unsigned long long) * 9 * (size_t)n, hipMemcpyHostToDevice, c->st_c));
+    launch_gather_bits(c->st_c, c->bits, c->gtab_d, 3 * n, c->gath_d);
+    if (total) HIPCHK(hipMemcpyAsync(c->gath_h, c->gath_d, total, hipMemcpyDeviceToHost, c->st_c));
+    HIPCHK(hipStreamSynchronize(c->st_c));
     HIPCHK(hipGetLastError());
     for (int i = 0; i < n; i++) {
         const int o = out_slots[i];

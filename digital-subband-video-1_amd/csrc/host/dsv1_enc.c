@@ -27,9 +27,13 @@ typedef struct {
 struct dsv1_batch {
     dsvg_ctx *ctx;
     dsvg_geom g;
-    int nstreams, F, own_enc, ring, nblk, prefix_cap, small_w, small_h;
+    int nstreams, F, own_enc, nblk, prefix_cap, small_w, small_h;
+    int rows;                   /* source-slot ring: rows x nstreams slots, rows = 2F+1 */
+    unsigned gcount;            /* frames submitted so far per stream (ring position) */
+    int parity;                 /* which half of the double-buffered per-batch state the next submit uses */
+    int pending[2];             /* batch submitted (device work enqueued) but not yet collected */
     DSV_ENCODER *enc;
-    pic_t *pics;
+    pic_t *pics;                /* [2][nstreams*F] */
     DSV_MV *mvpool;
     unsigned char *stabpool;
     uint8_t *prefixpool;
@@ -44,7 +48,8 @@ struct dsv1_batch {
     size_t pkt_cap;
 };
 
-static int slot_of(const dsv1_batch *b, int s, int k) { return ((b->ring + k) % (b->F + 1)) * b->nstreams + s; }
+/* source slot of frame number g (per-stream counter) of stream s */
+static int slot_of(const dsv1_batch *b, int s, unsigned g) { return (int)(g % (unsigned)b->rows) * b->nstreams + s; }
 
 void *dsv1_batch_ctx(dsv1_batch *b) { return b ? (void *)b->ctx : NULL; }
 
@@ -76,29 +81,30 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b = (dsv1_batch *)calloc(1, sizeof(*b));
     b->nstreams = nstreams; b->F = F; b->enc = encs; b->own_enc = own;
     np = nstreams * F;
+    b->rows = 2 * F + 1;
     rc = dsvg_ctx_create(&b->ctx, device, m->width, m->height, m->subsamp, encs[0].pyramid_levels,
-                         (F + 1) * nstreams, nstreams, nstreams, np);
+                         b->rows * nstreams, nstreams, nstreams, 2 * np);
     if (rc) { b->enc = NULL; dsv1_batch_close(b); return rc; }       /* the caller still owns encs */
     dsvg_ctx_geom(b->ctx, &b->g);
     b->nblk = b->g.nblocks_h * b->g.nblocks_v;
     b->small_w = (m->width + (1 << b->g.pyramid_levels) - 1) >> b->g.pyramid_levels;
     b->small_h = (m->height + (1 << b->g.pyramid_levels) - 1) >> b->g.pyramid_levels;
     b->prefix_cap = 128 + b->nblk * 24;
-    b->pics = (pic_t *)calloc((size_t)np, sizeof(pic_t));
-    b->mvpool = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
-    b->stabpool = (unsigned char *)calloc((size_t)np * b->nblk, 1);
-    b->prefixpool = (uint8_t *)calloc((size_t)np, (size_t)b->prefix_cap);
+    b->pics = (pic_t *)calloc((size_t)2 * np, sizeof(pic_t));
+    b->mvpool = (DSV_MV *)calloc((size_t)2 * np * b->nblk, sizeof(DSV_MV));
+    b->stabpool = (unsigned char *)calloc((size_t)2 * np * b->nblk, 1);
+    b->prefixpool = (uint8_t *)calloc((size_t)2 * np, (size_t)b->prefix_cap);
     b->slots_cur = (int *)calloc((size_t)np, sizeof(int));
     b->slots_ref = (int *)calloc((size_t)np, sizeof(int));
     b->pair_pic = (int *)calloc((size_t)np, sizeof(int));
     b->out_slots = (int *)calloc((size_t)np, sizeof(int));
-    b->luma = (unsigned *)calloc((size_t)(F + 1) * nstreams, sizeof(unsigned));
+    b->luma = (unsigned *)calloc((size_t)b->rows * nstreams, sizeof(unsigned));
     b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
-    b->jobs = (dsvg_pic_job *)calloc((size_t)nstreams, sizeof(dsvg_pic_job));
+    b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
     b->outs = (dsvg_pic_out *)calloc((size_t)np, sizeof(dsvg_pic_out));
     b->pkt_cap = (size_t)b->prefix_cap + b->g.plane_out_cap[0] + 2 * b->g.plane_out_cap[1] + 256;
     b->pkt = (uint8_t *)malloc(b->pkt_cap);
-    for (i = 0; i < np; i++) {
+    for (i = 0; i < 2 * np; i++) {
         b->pics[i].mvs = b->mvpool + (size_t)i * b->nblk;
         b->pics[i].stable = b->stabpool + (size_t)i * b->nblk;
         b->pics[i].prefix = b->prefixpool + (size_t)i * b->prefix_cap;
@@ -362,35 +368,46 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     return dsv1_buf_append(out, b->pkt, len) ? DSVG_ERR_ARG : DSVG_OK;
 }
 
-int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
+/* Submit one batch: all source-only analysis now (analysis stream), per-stream decisions and side info
+ * on the host, then the residual chain of every frame step enqueued on the coding stream.  CRF returns
+ * without waiting for the coding work; dsv1_batch_collect() fetches and assembles the packets.  ABR
+ * (each quantiser needs the previous packet size) runs frame step by frame step and leaves nothing
+ * pending except the already assembled packets. */
+static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out)
 {
-    int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0;
+    int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0, par;
     size_t fb;
     const DSV_ENCODER *e0;
     const uint8_t *dyuv = (const uint8_t *)yuv;
     uint8_t *tmp;
+    pic_t *pics;
 
-    if (!b || !yuv || !out) return DSVG_ERR_ARG;
+    if (!b || !yuv) return DSVG_ERR_ARG;
     S = b->nstreams; F = b->F; nblk = b->nblk; fb = b->g.frame_bytes;
     e0 = &b->enc[0];
     with_pyr = e0->gop != DSV_GOP_INTRA;
+    par = b->parity;
+    if (b->pending[par]) { dsv1_log(1, "batch submitted twice without collect"); return DSVG_ERR_ARG; }
+    pics = b->pics + (size_t)par * S * F;
     if (!yuv_on_device) {
         const size_t total = fb * (size_t)S * F;
         if (b->yuv_dev_bytes < total) {
+            if ((rc = dsvg_ctx_sync(b->ctx))) return rc;
             if (b->yuv_dev) dsvg_dev_free(b->ctx, b->yuv_dev);
             b->yuv_dev = NULL;
             if ((rc = dsvg_dev_alloc(b->ctx, &b->yuv_dev, total))) return rc;
             b->yuv_dev_bytes = total;
         }
+        if ((rc = dsvg_ctx_sync(b->ctx))) return rc;          /* the staging copy below is reused */
         if ((rc = dsvg_dev_upload(b->ctx, b->yuv_dev, yuv, total))) return rc;
         dyuv = (const uint8_t *)b->yuv_dev;
     }
     /* 1. source-only preparation for every frame: bordered layout, pyramid, mean luma */
     for (s = 0; s < S; s++)
-        for (t = 0; t < F; t++) b->slots_cur[s * F + t] = slot_of(b, s, t + 1);
+        for (t = 0; t < F; t++) b->slots_cur[s * F + t] = slot_of(b, s, b->gcount + (unsigned)t);
     if ((rc = dsvg_load_frames_map(b->ctx, S * F, b->slots_cur, dyuv, fb, with_pyr))) return rc;
     if (with_pyr && e0->do_scd)
-        if ((rc = dsvg_get_luma_sums(b->ctx, 0, (F + 1) * S, b->luma))) return rc;
+        if ((rc = dsvg_get_luma_sums(b->ctx, 0, b->rows * S, b->luma))) return rc;
 
     /* 2. per stream, in coding order: GOP / scene-change decisions; collect ME pairs */
     for (s = 0; s < S; s++) {
@@ -401,11 +418,11 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
         }
         if (e->pyramid_levels == 0) e->pyramid_levels = b->g.pyramid_levels;
         for (t = 0; t < F; t++) {
-            pic_t *pc = &b->pics[s * F + t];
+            pic_t *pc = &pics[s * F + t];
             pc->fnum = e->next_fnum++;
-            pc->cur_slot = slot_of(b, s, t + 1);
-            pc->ref_slot = slot_of(b, s, t);
-            pc->out_slot = t * S + s;
+            pc->cur_slot = slot_of(b, s, b->gcount + (unsigned)t);
+            pc->ref_slot = slot_of(b, s, b->gcount + (unsigned)t + (unsigned)b->rows - 1u);
+            pc->out_slot = par * S * F + t * S + s;
             pc->gop_start = 0; pc->forced_intra = 0;
             if (e->force_metadata || (DSV_FNUM)(e->prev_gop + (DSV_FNUM)e->gop) <= pc->fnum) {
                 pc->gop_start = 1;
@@ -435,14 +452,14 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
     if (npairs) {
         if ((rc = dsvg_analyse(b->ctx, npairs, b->slots_cur, b->slots_ref, (dsvg_mv *)b->mv_tmp))) return rc;
         for (k = 0; k < npairs; k++)
-            memcpy(b->pics[b->pair_pic[k]].mvs, b->mv_tmp + (size_t)k * nblk, (size_t)nblk * sizeof(DSV_MV));
+            memcpy(pics[b->pair_pic[k]].mvs, b->mv_tmp + (size_t)k * nblk, (size_t)nblk * sizeof(DSV_MV));
     }
     /* 4. per stream, in coding order: forced intra, stability + motion side info -> packet prefix */
     tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
     for (s = 0; s < S; s++) {
         DSV_ENCODER *e = &b->enc[s];
         for (t = 0; t < F; t++) {
-            pic_t *pc = &b->pics[s * F + t];
+            pic_t *pc = &pics[s * F + t];
             bitw w;
             if (pc->has_ref) {
                 int nintra = 0, i;
@@ -474,10 +491,11 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
     /* 5. residual coding, frame step by frame step across all streams */
     {
         const int serial = e0->rc_mode != DSV_RATE_CONTROL_CRF;
+        if (serial && !abr_out) return DSVG_ERR_ARG;
         for (t = 0; t < F; t++) {
             for (s = 0; s < S; s++) {
-                pic_t *pc = &b->pics[s * F + t];
-                dsvg_pic_job *j = &b->jobs[s];
+                pic_t *pc = &pics[s * F + t];
+                dsvg_pic_job *j = &b->jobs[(serial ? 0 : t * S) + s];
                 pc->quant = pick_quant(&b->enc[s], pc->isP, pc->forced_intra);
                 j->src_slot = pc->cur_slot;
                 j->ref_recon_slot = pc->isP ? s : -1;
@@ -487,24 +505,56 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
                 j->stable_blocks = pc->stable;
                 j->out_slot = pc->out_slot;
             }
-            if ((rc = dsvg_code_pictures(b->ctx, S, b->jobs))) return rc;
             if (serial) {
-                for (s = 0; s < S; s++) b->out_slots[s] = b->pics[s * F + t].out_slot;
+                if ((rc = dsvg_code_pictures(b->ctx, S, b->jobs))) return rc;
+                for (s = 0; s < S; s++) b->out_slots[s] = pics[s * F + t].out_slot;
                 if ((rc = dsvg_fetch_pictures(b->ctx, S, b->out_slots, b->outs))) return rc;
                 for (s = 0; s < S; s++)
-                    if ((rc = assemble(b, s, &b->pics[s * F + t], &b->outs[s], &out[s]))) return rc;
+                    if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s]))) return rc;
             }
         }
-        if (!serial) {
-            for (k = 0; k < S * F; k++) b->out_slots[k] = b->pics[k].out_slot;
-            if ((rc = dsvg_fetch_pictures(b->ctx, S * F, b->out_slots, b->outs))) return rc;
-            for (s = 0; s < S; s++)
-                for (t = 0; t < F; t++)
-                    if ((rc = assemble(b, s, &b->pics[s * F + t], &b->outs[s * F + t], &out[s]))) return rc;
-        }
+        if (!serial && (rc = dsvg_code_batch(b->ctx, F, S, b->jobs))) return rc;   /* whole batch, one upload */
+        b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
     }
-    b->ring = (b->ring + F) % (F + 1);
+    b->gcount += (unsigned)F;
+    b->parity ^= 1;
     return DSVG_OK;
+}
+
+int dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
+{
+    return batch_submit_impl(b, yuv, yuv_on_device, out);
+}
+
+/* Collect the OLDEST submitted batch: one gathered device-to-host copy, then packet assembly in
+ * stream order.  The packets of stream s are appended to out[s]. */
+int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
+{
+    int par, S, F, k, s, t, rc;
+    pic_t *pics;
+    if (!b || !out) return DSVG_ERR_ARG;
+    S = b->nstreams; F = b->F;
+    par = b->pending[b->parity] ? b->parity : (b->parity ^ 1);   /* oldest first */
+    if (!b->pending[par]) { dsv1_log(1, "nothing to collect"); return DSVG_ERR_ARG; }
+    pics = b->pics + (size_t)par * S * F;
+    if (b->pending[par] == 1) {
+        for (k = 0; k < S * F; k++) b->out_slots[k] = pics[k].out_slot;
+        if ((rc = dsvg_fetch_pictures(b->ctx, S * F, b->out_slots, b->outs))) return rc;
+        for (s = 0; s < S; s++)
+            for (t = 0; t < F; t++)
+                if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s * F + t], &out[s]))) return rc;
+    }
+    b->pending[par] = 0;
+    return DSVG_OK;
+}
+
+int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
+{
+    int rc;
+    if (!b || !out) return DSVG_ERR_ARG;
+    if (b->pending[0] || b->pending[1]) { dsv1_log(1, "dsv1_batch_encode with batches in flight"); return DSVG_ERR_ARG; }
+    if ((rc = batch_submit_impl(b, yuv, yuv_on_device, out))) return rc;
+    return dsv1_batch_collect(b, out);
 }
 
 int dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out)

@@ -150,6 +150,14 @@ void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
  * host or device memory.  For each stream s the packets are appended to out[s] (a growing buffer the
  * caller owns: data = NULL / len = 0 to start; freed with dsv_free).  Returns 0 or a DSVG_ERR_*. */
 int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
+/* Pipelined form (CRF): submit enqueues a batch and returns while its residual coding still runs on
+ * the device; collect fetches + assembles the OLDEST submitted batch.  At most two batches may be in
+ * flight, so the steady state is  submit(i+1); collect(i);  -- the analysis of batch i+1 (frame load,
+ * pyramid, motion estimation: source pixels only) then overlaps the residual coding of batch i on a
+ * second HIP stream, and the host packet assembly overlaps both.  With ABR, submit already assembles
+ * into out (each quantiser needs the previous packet size) and collect only releases the slot. */
+int  dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
+int  dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out);
 /* append the end-of-stream packet of stream s */
 int  dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out);
 /* Concatenate per-GOP streams (each encoded independently with fnum seeded to its position) into one

@@ -153,6 +153,10 @@ typedef struct {
  * extended reconstruction (encode_one_frame dsv_encoder.c:657-674, encode_picture :518-526).
  * Enqueues only; results are collected by dsvg_fetch_pictures (which syncs). */
 int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
+/* nsteps consecutive frame steps of njobs pictures each (jobs[step*njobs + j]) in one call: one upload of
+ * all tables, kernel chains back to back; step k+1 may predict from the reconstructions of step k.  The out
+ * slots of the call must form one contiguous block. */
+int dsvg_code_batch(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */
 

@@ -97,6 +97,30 @@ def test_gop_sharding_matches_serial_cif(pkg, orc):
     assert got == want, explain(got, want)
 
 
+def test_pipelined_submit_collect_equals_plain_encode(pkg, orc):
+    """software-pipelined batches (two HIP streams, two batches in flight) give the same bytes"""
+    w, h, fmt, gop, S, nb = 352, 288, A.SUBSAMP_420, 6, 3, 4
+    clips = [A.gen_clip(w, h, fmt, 0x7100 + s, gop * nb, style=s % 3) for s in range(S)]
+    cfg = pkg.make_encoder_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1)
+    want = []
+    for s in range(S):
+        st, _ = A.orc_encode(clips[s], A.orc_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1), eos=False)
+        want.append(st)
+    b = pkg.Batch(cfg, S, gop)
+    got = [b""] * S
+    batches = [np.stack([clips[s][i * gop:(i + 1) * gop] for s in range(S)]) for i in range(nb)]
+    b.submit(batches[0])
+    for i in range(1, nb):
+        b.submit(batches[i])
+        part = b.collect()
+        got = [g + p for g, p in zip(got, part)]
+    part = b.collect()
+    got = [g + p for g, p in zip(got, part)]
+    b.close()
+    for s in range(S):
+        assert got[s] == want[s], "stream %d: %s" % (s, explain(got[s], want[s]))
+
+
 def test_drop_in_dsv_enc_api(pkg, orc):
     """frame-at-a-time dsv_enc_* API (dsv_encoder.h:112-121), as dsv_main.c drives it"""
     L = pkg.lib()
