@@ -1,8 +1,8 @@
 // k_hme.hip -- hierarchical motion estimation + level-0 mode decision for gfx950 (MI355X).
 //
 // Replaces dsv_hme / refine_level (hme.c:378-741).  One launch per pyramid level (coarse -> fine),
-// one 256-thread workgroup per visited block and frame pair, threads laid out 16 column groups (4 px,
-// one dword) x 16 row groups -- no integer divisions on the hot loops.
+// one 128-thread workgroup per visited block and frame pair, threads laid out 16 column groups (4 px,
+// one dword) x 8 row groups (9.6 KB LDS => 16 blocks in flight per CU) -- no divisions on the hot loops.
 //   * the source block lives in registers (one dword per thread-row); every SAD is
 //     v_alignbyte_b32 (re-align the reference dwords) + v_sad_u8 (4 pixels per instruction);
 //   * inherited candidates are evaluated straight from global memory (no reuse => no LDS staging) and
@@ -21,6 +21,10 @@
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
 
+#define NT 128             // threads per workgroup: 16 column groups x 8 row groups (more blocks in flight per CU)
+#define NRG (NT / 16)
+#define NK (64 / NRG)       // rows per thread
+#define NW (NT / 64)        // waves per workgroup
 #define WIN 14
 #define LAT 32
 #define SP 64              // pitch of the source block in LDS (bytes)
@@ -37,7 +41,7 @@ static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_
     const uint8_t *g0 = plane + (long)oy * stride + ox;
     const int mis = (int)(((uintptr_t)g0) & 3);
     const int ndw = (mis + nw + 3) >> 2;
-    for (int i = threadIdx.x; i < nh * ndw; i += 256) {
+    for (int i = threadIdx.x; i < nh * ndw; i += NT) {
         const int r = i / ndw, d = i - r * ndw;
         *reinterpret_cast<unsigned *>(dst + r * P + 4 * d) =
             *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
@@ -56,12 +60,18 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 
 struct HmeShared {
     __attribute__((aligned(16))) uint8_t src[64 * SP];
-    __attribute__((aligned(16))) uint8_t ref[RROWS * RP];
-    __attribute__((aligned(16))) uint8_t patch[20 * 24];
-    __attribute__((aligned(16))) uint8_t lat[LAT * LAT];
+    // the 9-point window is dead once its SADs are reduced; the half-pel patch + lattice reuse its space
+    // until the zero-motion block is staged there for the statistics
+    union {
+        __attribute__((aligned(16))) uint8_t ref[RROWS * RP];
+        struct {
+            __attribute__((aligned(16))) uint8_t patch[20 * 24];
+            __attribute__((aligned(16))) uint8_t lat[LAT * LAT];
+        } hp;
+    } u;
     __attribute__((aligned(16))) uint8_t swin[WIN * 24];
     __attribute__((aligned(16))) uint8_t rwin[WIN * 16];
-    unsigned part[4][9];
+    unsigned part[NW][9];
     int par[5];
     int cand[8];
     int ncand;
@@ -83,7 +93,12 @@ static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*
     }
     __syncthreads();
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] = part[0][i] + part[1][i] + part[2][i] + part[3][i];
+    for (int i = 0; i < N; i++) {
+        unsigned t = 0;
+#pragma unroll
+        for (int w = 0; w < NW; w++) t += part[w][i];
+        v[i] = t;
+    }
 }
 
 static __device__ __forceinline__ int frame_invalid(int fw, int fh, int x, int y, int w, int h)   // invalid_block
@@ -101,19 +116,18 @@ static __device__ const int HP_Y[8] = {0, 0, 1, -1, -1, -1, 1, 1};
 static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
 {
     gh = gv = s1 = s2 = 0;
-    const int t = threadIdx.x;
-    if (t < WIN * WIN) {
+    for (int t = threadIdx.x; t < WIN * WIN; t += NT) {
         const int y = t / WIN, x = t - y * WIN;
         const int px = p[y * P + x];
-        if (x + 1 < WIN) gh = (unsigned)abs(px - (int)p[y * P + x + 1]);
-        if (y > 0) gv = (unsigned)abs(px - (int)p[(y - 1) * P + x]);
-        s1 = (unsigned)px;
-        s2 = (unsigned)(px * px);
+        if (x + 1 < WIN) gh += (unsigned)abs(px - (int)p[y * P + x + 1]);
+        if (y > 0) gv += (unsigned)abs(px - (int)p[(y - 1) * P + x]);
+        s1 += (unsigned)px;
+        s2 += (unsigned)(px * px);
     }
 }
 
 template <bool LEVEL0>
-__global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
+__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
 {
     __shared__ HmeShared S;
     const int tid = threadIdx.x;
@@ -135,13 +149,13 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     DMV *mf = A.mvf + ((size_t)pair * (A.levels + 1) + level) * A.nblk;
     const DMV *parent = level < A.levels ? A.mvf + ((size_t)pair * (A.levels + 1) + level + 1) * A.nblk : nullptr;
 
-    // this thread's pixels: columns 4cg..4cg+3 of rows rg, rg+16, rg+32, rg+48
+    // this thread's pixels: columns 4cg..4cg+3 of rows rg, rg+NRG, rg+2*NRG, ...
     const int xcol = 4 * cg;
     const unsigned cmask = xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u));
-    unsigned srcw[4];
+    unsigned srcw[NK];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int r = rg + 16 * k;
+    for (int k = 0; k < NK; k++) {
+        const int r = rg + NRG * k;
         srcw[k] = 0;
         if (cmask && r < bh) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
         if (LEVEL0 && r < bh && xcol < ((bw + 3) & ~3)) *reinterpret_cast<unsigned *>(S.src + r * SP + xcol) = srcw[k];
@@ -194,8 +208,8 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
                     validmask |= 1u << k;
                     if (cmask) {
 #pragma unroll
-                        for (int kk = 0; kk < 4; kk++) {
-                            const int r = rg + 16 * kk;
+                        for (int kk = 0; kk < NK; kk++) {
+                            const int r = rg + NRG * kk;
                             if (r < bh) {
                                 const unsigned rw = ldg_u32_unaligned(rp + (long)(by + cdy + r) * stride + bx + cdx + xcol);
                                 acc[k] = __builtin_amdgcn_sad_u8(srcw[kk], rw & cmask, acc[k]);
@@ -222,20 +236,20 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     // 9-point +-1 search around (dx,dy): window (bw+2)x(bh+2) at (bx+dx-1, by+dy-1) staged as aligned dwords
     int best, bestk;
     {
-        const int mis = load_win(S.ref, RP, rp, stride, bx + dx - 1, by + dy - 1, bw + 2, bh + 2);
+        const int mis = load_win(S.u.ref, RP, rp, stride, bx + dx - 1, by + dy - 1, bw + 2, bh + 2);
         __syncthreads();
         unsigned acc[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) acc[k] = 0;
         if (cmask) {
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) {
-                const int r = rg + 16 * kk;
+            for (int kk = 0; kk < NK; kk++) {
+                const int r = rg + NRG * kk;
                 if (r < bh) {
                     unsigned v[3][3];           // v[row][ox]: reference dword at window (r+row, ox + 4cg)
 #pragma unroll
                     for (int rr = 0; rr < 3; rr++) {
-                        const unsigned *w = reinterpret_cast<const unsigned *>(S.ref + (r + rr) * RP) + cg;
+                        const unsigned *w = reinterpret_cast<const unsigned *>(S.u.ref + (r + rr) * RP) + cg;
                         const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
 #pragma unroll
                         for (int ox = 0; ox < 3; ox++) {
@@ -275,14 +289,14 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     // stage: source 14x14 window, and either the 19x20 patch for the lattice or the full-pel 14x14 window
     const int smis = load_win(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
     int pmis;
-    if (do_hp) pmis = load_win(S.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
-    else       pmis = load_win(S.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
+    if (do_hp) pmis = load_win(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
+    else       pmis = load_win(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
     __syncthreads();
     bool have_hp = false;
     if (do_hp) {
-        {   // one lattice cell (j,i) per thread: F, H, V, D
-            const int lj = tid >> 4, li = tid & 15;
-            const uint8_t *p = S.patch + (lj + 1) * 24 + pmis + li + 1;       // -> patch sample (li, lj)
+        for (int cell = tid; cell < 256; cell += NT) {   // lattice cells (j,i): F, H, V, D
+            const int lj = cell >> 4, li = cell & 15;
+            const uint8_t *p = S.u.hp.patch + (lj + 1) * 24 + pmis + li + 1;       // -> patch sample (li, lj)
             const int F = p[0];
             const int Hh = d_sat8((tap4(p[-1], p[0], p[1], p[2]) + 8) >> 4);
             const int V = d_sat8((tap4(p[-24], p[0], p[24], p[48]) + 8) >> 4);
@@ -291,19 +305,19 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
             const int h1 = tap4(p[24 - 1], p[24], p[24 + 1], p[24 + 2]);
             const int h2 = tap4(p[48 - 1], p[48], p[48 + 1], p[48 + 2]);
             const int D = d_sat8((tap4(hm, h0, h1, h2) + 128) >> 8);
-            uint8_t *e = S.lat + (2 * lj) * LAT + 2 * li;
+            uint8_t *e = S.u.hp.lat + (2 * lj) * LAT + 2 * li;
             e[0] = (uint8_t)F; e[1] = (uint8_t)Hh; e[LAT] = (uint8_t)V; e[LAT + 1] = (uint8_t)D;
         }
         __syncthreads();
         unsigned acc[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) acc[k] = 0;
-        if (tid < WIN * WIN) {
-            const int y = tid / WIN, x = tid - y * WIN;
+        for (int t = tid; t < WIN * WIN; t += NT) {
+            const int y = t / WIN, x = t - y * WIN;
             const int s = S.swin[y * 24 + smis + x];
-            const uint8_t *c = S.lat + 2 + 2 * LAT + 2 * x + y * 2 * LAT;
+            const uint8_t *c = S.u.hp.lat + 2 + 2 * LAT + 2 * x + y * 2 * LAT;
 #pragma unroll
-            for (int k = 0; k < 8; k++) acc[k] = (unsigned)abs(s - (int)c[HP_X[k] + HP_Y[k] * LAT]);
+            for (int k = 0; k < 8; k++) acc[k] += (unsigned)abs(s - (int)c[HP_X[k] + HP_Y[k] * LAT]);
         }
         block_sum_n<8>(acc, S.part);
         int best_hp = (int)((unsigned)(best * (WIN * WIN)) / yarea);
@@ -317,9 +331,9 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
             best = (int)((unsigned)best_hp * yarea / (WIN * WIN));
             mvx = (int)(int16_t)(mvx + HP_X[hm]);
             mvy = (int)(int16_t)(mvy + HP_Y[hm]);
-            if (tid < WIN * WIN) {
-                const int y = tid / WIN, x = tid - y * WIN;
-                S.rwin[y * 16 + x] = S.lat[2 + 2 * LAT + HP_X[hm] + HP_Y[hm] * LAT + 2 * x + y * 2 * LAT];
+            for (int t = tid; t < WIN * WIN; t += NT) {
+                const int y = t / WIN, x = t - y * WIN;
+                S.rwin[y * 16 + x] = S.u.hp.lat[2 + 2 * LAT + HP_X[hm] + HP_Y[hm] * LAT + 2 * x + y * 2 * LAT];
             }
             have_hp = true;
         }
@@ -330,19 +344,19 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     if (!have_hp) {
         if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
             __syncthreads();
-            pmis = load_win(S.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
+            pmis = load_win(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
             __syncthreads();
         }
-        if (tid < WIN * WIN) {
-            const int y = tid / WIN, x = tid - y * WIN;
-            S.rwin[y * 16 + x] = S.patch[y * 24 + pmis + x];
+        for (int t = tid; t < WIN * WIN; t += NT) {
+            const int y = t / WIN, x = t - y * WIN;
+            S.rwin[y * 16 + x] = S.u.hp.patch[y * 24 + pmis + x];
         }
     }
     // zero-motion reference block -> LDS (needed by the variance test, the veto and the quadrant votes)
     __syncthreads();
-    const int zmis = load_win(S.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
+    const int zmis = load_win(S.u.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
     __syncthreads();
-    const uint8_t *zref = S.ref + zmis;
+    const uint8_t *zref = S.u.ref + zmis;
 
     // ---- statistics: one fused pass + one 8-value and one 10-value reduction
     unsigned st[8];                 // src block gh,gv,s1,s2 ; zref s1,s2 ; spare
@@ -350,8 +364,8 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
     for (int k = 0; k < 8; k++) st[k] = 0;
     if (cmask) {
 #pragma unroll
-        for (int kk = 0; kk < 4; kk++) {
-            const int r = rg + 16 * kk;
+        for (int kk = 0; kk < NK; kk++) {
+            const int r = rg + NRG * kk;
             if (r < bh) {
                 const unsigned curw = srcw[kk];
                 // horizontal neighbours: bytes x+1..x+4 of the same row (next dword supplies the 4th)
@@ -409,7 +423,7 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
 #pragma unroll
         for (int k = 0; k < 8; k++) cs[k] = 0;
         const int ndw = (cbw + 3) >> 2;
-        for (int q = tid; q < ndw * cbh; q += 256) {
+        for (int q = tid; q < ndw * cbh; q += NT) {
             const int y = q / ndw, xd = 4 * (q - y * ndw);
             const int nb = min(4, cbw - xd);
             const unsigned m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
@@ -440,8 +454,8 @@ __global__ __launch_bounds__(256) void k_hme_level(HmeArgs A, int level)
         unsigned qv[9];                 // [0] bad count, [1+2q] good, [2+2q] evil
 #pragma unroll
         for (int k = 0; k < 9; k++) qv[k] = 0;
-        for (int kk = 0; kk < 4; kk++) {
-            const int r = rg + 16 * kk;
+        for (int kk = 0; kk < NK; kk++) {
+            const int r = rg + NRG * kk;
             if (r >= bh) continue;
 #pragma unroll
             for (int b4 = 0; b4 < 4; b4++) {
@@ -528,8 +542,8 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
         const double px = 2.0 * npairs * (double)A.L[level].w[0] * A.L[level].h[0];     // src + ref luma once
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
-        if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(nvx * nvy, npairs), dim3(256), 0, st, A, level);
-        else           hipLaunchKernelGGL((k_hme_level<true>), dim3(nvx * nvy, npairs), dim3(256), 0, st, A, level);
+        if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(nvx * nvy, npairs), dim3(NT), 0, st, A, level);
+        else           hipLaunchKernelGGL((k_hme_level<true>), dim3(nvx * nvy, npairs), dim3(NT), 0, st, A, level);
         if (pf) pf->end(st);
     }
     if (pf) pf->begin(st, KID_HME_DETAIL, 0.0);
