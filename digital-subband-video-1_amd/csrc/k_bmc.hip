@@ -15,10 +15,11 @@
 
 #define WPITCH 72                       // LDS row pitch in bytes (>= 64+3+3 alignment slack), multiple of 4
 #define WROWS 68
+#define MC_NT 128                       // threads per workgroup (4.9 KB LDS => 16+ blocks in flight per CU)
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
-__global__ __launch_bounds__(256) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub)
+__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub)
 {
     __shared__ __align__(16) uint8_t win[WROWS * WPITCH];
     __shared__ int s_sum[5];
@@ -50,7 +51,7 @@ __global__ __launch_bounds__(256) void k_mc(const JobDev *__restrict__ jobs, McG
     const uint8_t *g0 = rp + rowbase;
     const int mis = (int)(((uintptr_t)g0) & 3);           // same for every row (stride % 4 == 0)
     const int ndw = (mis + cw + 3 + 3) >> 2;
-    for (int i = tid; i < (ch + 3) * ndw; i += 256) {
+    for (int i = tid; i < (ch + 3) * ndw; i += MC_NT) {
         const int r = i / ndw, d = i - r * ndw;
         const unsigned v = *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
         *reinterpret_cast<unsigned *>(win + r * WPITCH + 4 * d) = v;
@@ -64,7 +65,7 @@ __global__ __launch_bounds__(256) void k_mc(const JobDev *__restrict__ jobs, McG
     int mean_full = 0, mean_q[4] = {0, 0, 0, 0};
     if (mv.mode != 0) {
         int acc[5] = {0, 0, 0, 0, 0};
-        for (int p = tid; p < cw * ch; p += 256) {
+        for (int p = tid; p < cw * ch; p += MC_NT) {
             const int yy = p / cw, xx = p - yy * cw;
             const int v = w0[yy * WPITCH + xx];
             acc[4] += v;
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void k_mc(const JobDev *__restrict__ jobs, McG
     uint8_t *xp = jb.xf + G.off[c];
     const uint8_t *sp = jb.src + G.off[c];
     const int nq = (cw + 3) >> 2;
-    for (int it = tid; it < nq * ch; it += 256) {
+    for (int it = tid; it < nq * ch; it += MC_NT) {
         const int yy = it / nq, x4 = 4 * (it - yy * nq);
         int pv[4];
 #pragma unroll
@@ -157,6 +158,6 @@ void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, in
     double smp = 0;
     for (int c = 0; c < 3; c++) smp += (double)G.w[c] * G.h[c];
     if (pf) pf->begin(st, KID_MC, smp * njobs * (do_sub ? 4.0 : 2.0));   // ref + src in, pred + residual out
-    hipLaunchKernelGGL(k_mc, dim3(G.nbh * G.nbv, 3, njobs), dim3(256), 0, st, jobs, G, do_sub);
+    hipLaunchKernelGGL(k_mc, dim3(G.nbh * G.nbv, 3, njobs), dim3(MC_NT), 0, st, jobs, G, do_sub);
     if (pf) pf->end(st);
 }

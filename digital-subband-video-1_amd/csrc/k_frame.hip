@@ -48,8 +48,9 @@ __global__ __launch_bounds__(256) void k_pack(uint8_t *__restrict__ yuv, const u
     }
 }
 
-// border replication of planes [0, nplanes) of frames [first, first+n): every border byte is the
-// nearest interior pixel (identical to the row memsets + row copies of frame.c:278-292)
+// border replication of planes [0, nplanes) of frames: every border byte is the nearest interior pixel
+// (identical to the row memsets + row copies of frame.c:278-292).  One dword per thread-iteration:
+// the 64-byte left/right borders of all h+128 rows, then the top/bottom 64 rows over the interior.
 __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, FrameLayout L, int first, int nplanes,
                                                 const int *__restrict__ slot_tab)
 {
@@ -60,25 +61,35 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
     const int B = DSVG_BORDER;
-    // part 1: left + right borders of all h+2B rows (2B bytes per row), one byte per thread-iteration x4
-    const int n1 = (h + 2 * B) * (2 * B);
-    // part 2: top + bottom B rows over the interior columns
-    const int n2 = 2 * B * w;
+    const bool al = (w & 3) == 0;                     // right border / interior rows dword-aligned
+    // part 1: side borders: (h + 2B) rows x 32 dwords (16 left, 16 right)
+    const int n1 = (h + 2 * B) * 32;
+    // part 2: top + bottom B rows over the interior columns, ceil(w/4) dwords per row
+    const int wq = (w + 3) >> 2;
+    const int n2 = 2 * B * wq;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += gridDim.x * 256) {
-        int x, y;
         if (i < n1) {
-            const int r = i / (2 * B), k = i - r * (2 * B);
-            y = r - B;
-            x = k < B ? k - B : w + (k - B);
+            const int r = i >> 5, k = i & 31;
+            const int y = r - B;
+            const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            if (k < 16) {
+                const unsigned v = p[(long)sy * s] * 0x01010101u;
+                *reinterpret_cast<unsigned *>(p + (long)y * s - B + 4 * k) = v;
+            } else {
+                const unsigned v = p[(long)sy * s + w - 1] * 0x01010101u;
+                uint8_t *d = p + (long)y * s + w + 4 * (k - 16);
+                if (al) *reinterpret_cast<unsigned *>(d) = v;
+                else { d[0] = (uint8_t)v; d[1] = (uint8_t)v; d[2] = (uint8_t)v; d[3] = (uint8_t)v; }
+            }
         } else {
             const int j = i - n1;
-            const int r = j / w;
-            x = j - r * w;
-            y = r < B ? r - B : h + (r - B);
+            const int r = j / wq, x = 4 * (j - r * wq);
+            const int y = r < B ? r - B : h + (r - B);
+            const uint8_t *src = p + (long)(r < B ? 0 : h - 1) * s + x;
+            uint8_t *d = p + (long)y * s + x;
+            if (x + 4 <= w) *reinterpret_cast<unsigned *>(d) = *reinterpret_cast<const unsigned *>(src);
+            else for (int q = 0; x + q < w; q++) d[q] = src[q];
         }
-        const int sx = x < 0 ? 0 : (x > w - 1 ? w - 1 : x);
-        const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-        p[(long)y * s + x] = p[(long)sy * s + sx];
     }
 }
 
@@ -159,8 +170,8 @@ void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const Frame
 }
 void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf)
 {
-    const long items = (long)(L.h[0] + 128) * 128 + 128L * L.w[0];
-    if (pf) pf->begin(st, KID_EXTEND, 2.0 * items * n);
+    const long items = (long)(L.h[0] + 128) * 32 + 32L * L.w[0];
+    if (pf) pf->begin(st, KID_EXTEND, 8.0 * items * n);
     hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
     if (pf) pf->end(st);
 }
