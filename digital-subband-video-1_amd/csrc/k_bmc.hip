@@ -13,7 +13,7 @@
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
 
-#define WPITCH 72                       // LDS row pitch in bytes (>= 64+3+3 alignment slack), multiple of 4
+#define WPITCH 76                       // LDS row pitch in bytes: 64+3 window + 3 misalignment, +1 spare dword for ROW8
 #define WROWS 68
 #define MC_NT 128                       // threads per workgroup (4.9 KB LDS => 16+ blocks in flight per CU)
 
@@ -90,41 +90,70 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     uint8_t *xp = jb.xf + G.off[c];
     const uint8_t *sp = jb.src + G.off[c];
     const int nq = (cw + 3) >> 2;
+    // 8 reference bytes b0..b7 = ref(wx + x4 - 1 .. wx + x4 + 6) of window row rr as two dwords (the window
+    // is stored as aligned dwords; `mis` is the same for every row, so one v_alignbyte pair re-aligns it)
+#define ROW8(rr, lo, hi)                                                                     \
+    do {                                                                                     \
+        const unsigned *W_ = reinterpret_cast<const unsigned *>(win + (rr) * WPITCH) + ((mis + x4) >> 2); \
+        const unsigned a_ = W_[0], b_ = W_[1], c_ = W_[2];                                   \
+        lo = __builtin_amdgcn_alignbyte(b_, a_, (unsigned)((mis + x4) & 3));                  \
+        hi = __builtin_amdgcn_alignbyte(c_, b_, (unsigned)((mis + x4) & 3));                  \
+    } while (0)
+#define BYTE(lo, hi, k) ((int)((((k) < 4 ? (lo) : (hi)) >> (8 * ((k) & 3))) & 0xff))
     for (int it = tid; it < nq * ch; it += MC_NT) {
         const int yy = it / nq, x4 = 4 * (it - yy * nq);
         int pv[4];
+        if (mv.mode == 0) {
+            if (c == 0) {
+                if (!xh && !yh) {
+                    unsigned lo, hi; ROW8(yy + 1, lo, hi);
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int xx = x4 + k;
-            const uint8_t *p = w0 + yy * WPITCH + xx;
-            int v;
-            if (mv.mode == 0) {
-                if (c == 0) {
-                    if (!xh && !yh) v = p[0];
-                    else if (!xh) v = d_sat8((tap4(p[-WPITCH], p[0], p[WPITCH], p[2 * WPITCH]) + 8) >> 4);
-                    else if (!yh) v = d_sat8((tap4(p[-1], p[0], p[1], p[2]) + 8) >> 4);
-                    else {
-                        const int hm = tap4(p[-WPITCH - 1], p[-WPITCH], p[-WPITCH + 1], p[-WPITCH + 2]);
-                        const int h0 = tap4(p[-1], p[0], p[1], p[2]);
-                        const int h1 = tap4(p[WPITCH - 1], p[WPITCH], p[WPITCH + 1], p[WPITCH + 2]);
-                        const int h2 = tap4(p[2 * WPITCH - 1], p[2 * WPITCH], p[2 * WPITCH + 1], p[2 * WPITCH + 2]);
-                        v = d_sat8((tap4(hm, h0, h1, h2) + 128) >> 8);
-                    }
+                    for (int k = 0; k < 4; k++) pv[k] = BYTE(lo, hi, k + 1);
+                } else if (!xh) {
+                    unsigned l0, h0, l1, h1, l2, h2, l3, h3;
+                    ROW8(yy, l0, h0); ROW8(yy + 1, l1, h1); ROW8(yy + 2, l2, h2); ROW8(yy + 3, l3, h3);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        pv[k] = d_sat8((tap4(BYTE(l0, h0, k + 1), BYTE(l1, h1, k + 1), BYTE(l2, h2, k + 1), BYTE(l3, h3, k + 1)) + 8) >> 4);
+                } else if (!yh) {
+                    unsigned lo, hi; ROW8(yy + 1, lo, hi);
+#pragma unroll
+                    for (int k = 0; k < 4; k++)
+                        pv[k] = d_sat8((tap4(BYTE(lo, hi, k), BYTE(lo, hi, k + 1), BYTE(lo, hi, k + 2), BYTE(lo, hi, k + 3)) + 8) >> 4);
                 } else {
-                    if (!xh && !yh) v = p[0];
-                    else if (!xh) v = (p[0] + p[WPITCH] + 1) >> 1;
-                    else if (!yh) v = (p[0] + p[1] + 1) >> 1;
-                    else v = (p[0] + p[1] + p[WPITCH] + p[WPITCH + 1] + 2) >> 2;
+                    unsigned l0, h0, l1, h1, l2, h2, l3, h3;
+                    ROW8(yy, l0, h0); ROW8(yy + 1, l1, h1); ROW8(yy + 2, l2, h2); ROW8(yy + 3, l3, h3);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int hm = tap4(BYTE(l0, h0, k), BYTE(l0, h0, k + 1), BYTE(l0, h0, k + 2), BYTE(l0, h0, k + 3));
+                        const int hc = tap4(BYTE(l1, h1, k), BYTE(l1, h1, k + 1), BYTE(l1, h1, k + 2), BYTE(l1, h1, k + 3));
+                        const int hn = tap4(BYTE(l2, h2, k), BYTE(l2, h2, k + 1), BYTE(l2, h2, k + 2), BYTE(l2, h2, k + 3));
+                        const int hp = tap4(BYTE(l3, h3, k), BYTE(l3, h3, k + 1), BYTE(l3, h3, k + 2), BYTE(l3, h3, k + 3));
+                        pv[k] = d_sat8((tap4(hm, hc, hn, hp) + 128) >> 8);
+                    }
                 }
-            } else if (mv.submask == 0xF) {
-                v = mean_full;
-            } else if (xx < 2 * qw && yy < 2 * qh) {
-                const int q = (xx >= qw) + 2 * (yy >= qh);
-                v = (mv.submask & (1 << q)) ? mean_q[q] : p[0];
             } else {
-                v = 0;                           // odd-sized edge blocks: untouched (zeroed) in the reference
+                unsigned l1, h1, l2, h2;
+                ROW8(yy + 1, l1, h1);
+                ROW8(yy + 2, l2, h2);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int a = BYTE(l1, h1, k + 1), bq = BYTE(l1, h1, k + 2), cq = BYTE(l2, h2, k + 1), dq = BYTE(l2, h2, k + 2);
+                    pv[k] = (!xh && !yh) ? a : (!xh ? (a + cq + 1) >> 1 : (!yh ? (a + bq + 1) >> 1 : (a + bq + cq + dq + 2) >> 2));
+                }
             }
-            pv[k] = v & 0xff;
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int xx = x4 + k;
+                int v;
+                if (mv.submask == 0xF) v = mean_full;
+                else if (xx < 2 * qw && yy < 2 * qh) {
+                    const int q = (xx >= qw) + 2 * (yy >= qh);
+                    v = (mv.submask & (1 << q)) ? mean_q[q] : (int)w0[yy * WPITCH + xx];
+                } else v = 0;                    // odd-sized edge blocks: untouched (zeroed) in the reference
+                pv[k] = v & 0xff;
+            }
         }
         const size_t o = (size_t)(y + yy) * stride + x + x4;
         if (x4 + 4 <= cw) {

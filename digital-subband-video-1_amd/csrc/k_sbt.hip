@@ -413,6 +413,31 @@ static __device__ __forceinline__ void inv_cell(const int *pA, int astride, int 
     o[3] = (LL - LH - HL + HH) / 4;
 }
 
+// same as inv_cell for a COMPLETE cell whose three details were already fetched (vector loads)
+template <bool FILT>
+static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
+                                                     const int32_t *__restrict__ coef, int W, int LH, int HL, int HH, int (&o)[4])
+{
+    const int x = 2 * cx, y = 2 * cy;
+    const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
+    if (FILT) {
+        if (x > 0 && x < L.wfull - 1) {
+            int lp = pA[-1], ln = (cx + 1 < L.wo) ? pA[1] : coef[(size_t)cy * W + L.wo];
+            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
+            LH = d_nudge(LL, lp, ln, LH, L.hqp);
+        }
+        if (y > 0 && y < L.hfull - 1) {
+            int lp = pA[-astride], ln = (cy + 1 < L.ho) ? pA[astride] : coef[(size_t)L.ho * W + cx];
+            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
+            HL = d_nudge(LL, lp, ln, HL, L.hqp);
+        }
+    }
+    o[0] = (LL + LH + HL + HH) / 4;
+    o[1] = (LL - LH + HL - HH) / 4;
+    o[2] = (LL + LH - HL - HH) / 4;
+    o[3] = (LL - LH - HL + HH) / 4;
+}
+
 #define IT_TX 16     // level-3 cells per tile in x  (=> 128 px)
 #define IT_TY 8      // level-3 cells per tile in y  (=>  64 px)
 #define A3W (IT_TX + 4)
@@ -485,6 +510,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
 
     // level 1 + sbc2int (+ prediction add) : each work item = 4 adjacent cells = 8 px x 2 rows
     const LvlGeo L = mk_lvl(W, H, 1, jb.hqp[1], !isP);        // LVL_TEST: P level 1 unscaled
+    const bool vec_ok = (((W | L.wo) & 3) == 0) && ((g.coff & 3) == 0) && ((((uintptr_t)jb.coef) & 15) == 0);
     uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
     const uint8_t *pred = (jb.ref != nullptr) ? jb.pred + g.poff : nullptr;
     for (int it = tid; it < (4 * IT_TY) * IT_TX; it += 256) {
@@ -492,13 +518,29 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         const int cy = 4 * J0 + ly;
         if (cy >= L.ho) continue;
         int r0[8], r1[8];
+        const int cx0 = 4 * I0 + 4 * gx;
+        // fast path: four complete cells, details fetched as three 16-byte loads
+        if (vec_ok && cx0 + 3 < (L.ws >> 1) && 2 * cy + 1 < L.hs) {
+            const int4 lh = *reinterpret_cast<const int4 *>(coef + (size_t)cy * W + L.wo + cx0);
+            const int4 hl = *reinterpret_cast<const int4 *>(coef + (size_t)(L.ho + cy) * W + cx0);
+            const int4 hh = *reinterpret_cast<const int4 *>(coef + (size_t)(L.ho + cy) * W + L.wo + cx0);
+            const int lhv[4] = {lh.x, lh.y, lh.z, lh.w}, hlv[4] = {hl.x, hl.y, hl.z, hl.w}, hhv[4] = {hh.x, hh.y, hh.z, hh.w};
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int lx = 4 * gx + k, cx = 4 * I0 + lx;
-            int o[4] = {0, 0, 0, 0};
-            if (cx < L.wo) inv_cell<FILT>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, coef, W, o);
-            r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
-            r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
+            for (int k = 0; k < 4; k++) {
+                int o[4];
+                inv_cell_vals<FILT>(A1 + (ly + 2) * A1W + (4 * gx + k + 2), A1W, cx0 + k, cy, L, coef, W, lhv[k], hlv[k], hhv[k], o);
+                r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
+                r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int lx = 4 * gx + k, cx = 4 * I0 + lx;
+                int o[4] = {0, 0, 0, 0};
+                if (cx < L.wo) inv_cell<FILT>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, coef, W, o);
+                r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
+                r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
+            }
         }
         const int px0 = 2 * (4 * I0 + 4 * gx);                // pixel x of the group
 #pragma unroll
