@@ -103,7 +103,7 @@ void make_coef_layout(CoefLayout &C, int fmt, int w, int h)
 {
     memset(&C, 0, sizeof(C));
     const int cw = (rsu(w, fmt_hs(fmt)) + 1) & ~1, ch = (rsu(h, fmt_vs(fmt)) + 1) & ~1;
-    size_t off = 0, o3 = 0, o1 = 0;
+    size_t off = 0, o3 = 0, o1 = 0, o5 = 0;
     for (int c = 0; c < 3; c++) {
         C.w[c] = c ? cw : w;
         C.h[c] = c ? ch : h;
@@ -114,18 +114,21 @@ void make_coef_layout(CoefLayout &C, int fmt, int w, int h)
         C.off[c] = off;   off += (size_t)C.w[c] * C.h[c];
         C.s3off[c] = o3;  o3 += ((size_t)C.w3[c] * C.h3[c] + 3) & ~(size_t)3;
         C.s1off[c] = o1;  o1 += ((size_t)C.w1[c] * C.h1[c] + 3) & ~(size_t)3;
+        C.w5[c] = rsu(C.w[c], 5); C.h5[c] = rsu(C.h[c], 5);
+        C.s5off[c] = o5;  o5 += ((size_t)C.w5[c] * C.h5[c] + 3) & ~(size_t)3;
     }
-    C.total = off; C.s3total = o3; C.s1total = o1;
+    C.total = off; C.s3total = o3; C.s1total = o1; C.s5total = o5;
 }
 
-void make_sbt_geo(SbtGeo &g, int W, int H, int pw, int ph, int pstride, size_t poff, size_t coff, size_t s3off, size_t s1off)
+void make_sbt_geo(SbtGeo &g, int W, int H, int pw, int ph, int pstride, size_t poff, size_t coff, size_t s3off, size_t s1off, size_t s5off)
 {
     memset(&g, 0, sizeof(g));
     g.W = W; g.H = H; g.pw = pw; g.ph = ph; g.pstride = pstride;
-    g.poff = poff; g.coff = coff; g.s3off = s3off; g.s1off = s1off;
+    g.poff = poff; g.coff = coff; g.s3off = s3off; g.s1off = s1off; g.s5off = s5off;
     g.lvls = lb2u((unsigned)(W > H ? W : H));
     g.w3 = rsu(W, 3); g.h3 = rsu(H, 3);
     g.w1 = rsu(W, 1); g.h1 = rsu(H, 1);
+    g.w5 = rsu(W, 5); g.h5 = rsu(H, 5);
 }
 
 void make_hz_plane(HzPlane &hp, int w, int h, int q, int isP, int cur_plane, int nbh, int nbv)

@@ -8,9 +8,9 @@
 //     kind live in one slab, frame i at base + i*frame_bytes (+ a zeroed guard in front).
 //   * Coefficients use the reference's Mallat layout (dsv_mk_coefs frame.c:29-61): int32,
 //     row-major w x h per plane, three planes back to back, sub-bands in quadrants.
-//   * The top of the pyramid (levels >= 4, <= 160 KB) is transformed inside LDS by one
-//     workgroup; the LL3 band travels between the tiled kernels and that tail kernel through a
-//     small compact scratch plane (s3), the LL1 band of intra pictures through s1.
+//   * The top of the pyramid (levels >= 6, a 60x34 band at 1080p) is transformed inside LDS by one
+//     workgroup; levels 4-5 run in multi-workgroup "mid" kernels.  The LL3 / LL5 bands travel between
+//     the stages through small compact scratch planes (s3, s5), the LL1 band of intra pictures through s1.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -41,6 +41,8 @@ struct CoefLayout {
     size_t total;            // ints per job
     size_t s3off[3], s3total;
     size_t s1off[3], s1total;
+    int w5[3], h5[3];        // dims of the LL5 band (what the LDS tail works on)
+    size_t s5off[3], s5total;
 };
 
 // HZCC scan geometry of one plane (hzcc.c:30-48,137-293): ten regions in scan order
@@ -88,7 +90,7 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     uint8_t *xf;             // work frame: residual in, reconstruction out
     uint8_t *pred;           // prediction frame ("dif" of dsv_sub_pred)
     int32_t *coef;           // 3 coefficient planes
-    int32_t *s3, *s1;        // LL3 / LL1 scratch
+    int32_t *s3, *s1, *s5;   // LL3 / LL1 / LL5 scratch
     const DMV *mvs;          // device motion field
     const uint8_t *stable;   // device stable_blocks
     int32_t *nzpos, *nzval;  // per-plane compact non-zero lists (chunk-local slots)
@@ -110,9 +112,9 @@ struct SbtGeo {              // per-plane constants for the transform kernels
     int W, H;                // coefficient dims
     int ph, pstride;         // pixel rows available / row stride of the pixel plane
     size_t poff;             // byte offset of pixel (0,0) in a frame
-    size_t coff, s3off, s1off; // int offsets of the plane in coef / s3 / s1
+    size_t coff, s3off, s1off, s5off; // int offsets of the plane in coef / s3 / s1 / s5
     int lvls;                // total levels
-    int w3, h3, w1, h1;
+    int w3, h3, w1, h1, w5, h5;
     int pw;                  // pixel plane width (recon store guard)
 };
 

@@ -33,7 +33,7 @@ int  layout_from_host(FrameLayout &L, const dsvg_frame *f, const uint8_t **base,
 void make_coef_layout(CoefLayout &C, int fmt, int w, int h);
 int  lb2u(unsigned n);
 int  get_quant(int q, int isP, int level);
-void make_sbt_geo(SbtGeo &g, int W, int H, int pw, int ph, int pstride, size_t poff, size_t coff, size_t s3off, size_t s1off);
+void make_sbt_geo(SbtGeo &g, int W, int H, int pw, int ph, int pstride, size_t poff, size_t coff, size_t s3off, size_t s1off, size_t s5off = 0);
 // HZCC scan geometry + quantisers of one plane (hzcc.c:30-57,77-92,186-212)
 void make_hz_plane(HzPlane &hp, int w, int h, int q, int isP, int cur_plane, int nbh, int nbv);
 void make_hqp(int hqp[16], int q, int isP);

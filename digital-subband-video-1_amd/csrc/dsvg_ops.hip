@@ -71,13 +71,13 @@ int download_frame(OpScope &S, dsvg_frame *f, const FrameLayout &L, const uint8_
 
 int check_plane_dims(int W, int H, int isP)
 {
-    if (W < 16 || H < 16) { dsvg_set_error("plane %dx%d too small (min 16x16)", W, H); return DSVG_ERR_UNSUPPORTED; }
+    if (W < 16 || H < 16 || (W <= 32 && H <= 32)) { dsvg_set_error("plane %dx%d too small (needs >= 6 transform levels)", W, H); return DSVG_ERR_UNSUPPORTED; }
     if (!isP && ((W | H) & 1)) {
         dsvg_set_error("intra transform needs even plane dims (reference leaves stale temp words for odd n)");
         return DSVG_ERR_UNSUPPORTED;
     }
     SbtGeo g; make_sbt_geo(g, W, H, W, H, W, 0, 0, 0, 0);
-    if (!sbt_tail_supported(g)) { dsvg_set_error("plane %dx%d: LL3 band exceeds the LDS tail", W, H); return DSVG_ERR_UNSUPPORTED; }
+    if (!sbt_tail_supported(g)) { dsvg_set_error("plane %dx%d: outside the LDS tail limits", W, H); return DSVG_ERR_UNSUPPORTED; }
     return DSVG_OK;
 }
 
@@ -114,12 +114,13 @@ extern "C" int dsvg_op_fwd_sbt(const dsvg_plane *src, dsvg_coefs *dst, int isP)
     uint8_t *dpx; OPCHK(S.slab(&dpx, (size_t)dstride * (ph + 8) + 4096));
     HIPCHK(hipMemcpy2DAsync(dpx, (size_t)dstride, src->data, (size_t)src->stride, (size_t)W, (size_t)ph,
                             hipMemcpyHostToDevice, S.st));
-    int32_t *dco, *ds3, *ds1;
+    int32_t *dco, *ds3, *ds1, *ds5;
     OPCHK(S.dev(&dco, (size_t)W * H));
     OPCHK(S.dev(&ds3, (size_t)rsu(W, 3) * rsu(H, 3) + 8));
     OPCHK(S.dev(&ds1, (size_t)rsu(W, 1) * rsu(H, 1) + 8));
+    OPCHK(S.dev(&ds5, (size_t)rsu(W, 5) * rsu(H, 5) + 8));
     JobDev jb; memset(&jb, 0, sizeof(jb));
-    jb.src = dpx; jb.xf = dpx; jb.coef = dco; jb.s3 = ds3; jb.s1 = ds1; jb.isP = isP;
+    jb.src = dpx; jb.xf = dpx; jb.coef = dco; jb.s3 = ds3; jb.s1 = ds1; jb.s5 = ds5; jb.isP = isP;
     JobDev *djb; OPCHK(S.dev(&djb, 1, false));
     HIPCHK(hipMemcpyAsync(djb, &jb, sizeof(jb), hipMemcpyHostToDevice, S.st));
     SbtGeo3 G; memset(&G, 0, sizeof(G));
@@ -139,13 +140,14 @@ extern "C" int dsvg_op_inv_sbt(dsvg_plane *dst, dsvg_coefs *src, int q, int isP,
     const int ph = dst->h < H ? dst->h : H, pw = dst->w < W ? dst->w : W;
     const int dstride = (W + 15) & ~15;
     uint8_t *dpx; OPCHK(S.slab(&dpx, (size_t)dstride * (H + 8) + 4096));
-    int32_t *dco, *ds3, *ds1;
+    int32_t *dco, *ds3, *ds1, *ds5;
     OPCHK(S.dev(&dco, (size_t)W * H, false));
     OPCHK(S.dev(&ds3, (size_t)rsu(W, 3) * rsu(H, 3) + 8));
     OPCHK(S.dev(&ds1, (size_t)rsu(W, 1) * rsu(H, 1) + 8));
+    OPCHK(S.dev(&ds5, (size_t)rsu(W, 5) * rsu(H, 5) + 8));
     HIPCHK(hipMemcpyAsync(dco, src->data, (size_t)W * H * 4, hipMemcpyHostToDevice, S.st));
     JobDev jb; memset(&jb, 0, sizeof(jb));
-    jb.xf = dpx; jb.coef = dco; jb.s3 = ds3; jb.s1 = ds1; jb.isP = isP; jb.quant = q;
+    jb.xf = dpx; jb.coef = dco; jb.s3 = ds3; jb.s1 = ds1; jb.s5 = ds5; jb.isP = isP; jb.quant = q;
     make_hqp(jb.hqp, q, isP);
     JobDev *djb; OPCHK(S.dev(&djb, 1, false));
     HIPCHK(hipMemcpyAsync(djb, &jb, sizeof(jb), hipMemcpyHostToDevice, S.st));

@@ -27,7 +27,7 @@ struct dsvg_ctx {
     McGeo MG;
     int n_src = 0, n_recon = 0, max_jobs = 0, out_slots = 0, nwin = 0, win = 0, calls_since_sync = 0;
     Slab src[6], recon, xf, pred;
-    int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *nzpos = nullptr, *nzval = nullptr;
+    int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *s5 = nullptr, *nzpos = nullptr, *nzval = nullptr;
     HzChunkSum *chunks = nullptr;
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
@@ -68,7 +68,7 @@ static void ctx_free(dsvg_ctx *c)
     (void)hipSetDevice(c->device);
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
-    void *d[] = {c->coef, c->s3, c->s1, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
+    void *d[] = {c->coef, c->s3, c->s1, c->s5, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
                  c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
@@ -120,12 +120,12 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     const CoefLayout &CL = c->CL;
     for (int p = 0; p < 3; p++) {
         make_sbt_geo(c->G.g[p], CL.w[p], CL.h[p], c->L[0].w[p], c->L[0].h[p], c->L[0].stride[p], c->L[0].off[p],
-                     CL.off[p], CL.s3off[p], CL.s1off[p]);
+                     CL.off[p], CL.s3off[p], CL.s1off[p], CL.s5off[p]);
         if (!sbt_tail_supported(c->G.g[p])) {
-            dsvg_set_error("plane %dx%d: LL3 band does not fit the LDS tail kernel", CL.w[p], CL.h[p]);
+            dsvg_set_error("plane %dx%d: LL5 band does not fit the LDS tail kernel", CL.w[p], CL.h[p]);
             delete c; return DSVG_ERR_UNSUPPORTED;
         }
-        if (CL.lvls[p] < 4) { dsvg_set_error("plane too small"); delete c; return DSVG_ERR_UNSUPPORTED; }
+        if (CL.lvls[p] < 6) { dsvg_set_error("plane too small (needs >= 6 transform levels)"); delete c; return DSVG_ERR_UNSUPPORTED; }
     }
     if ((width | height) & 1) { dsvg_set_error("odd luma dimensions are not supported (intra B4T needs even planes)"); delete c; return DSVG_ERR_UNSUPPORTED; }
     McGeo &MG = c->MG;
@@ -167,6 +167,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->coef, CL.total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->s3, CL.s3total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->s1, CL.s1total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->s5, CL.s5total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->nzpos, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
@@ -357,6 +358,7 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
     jb.coef = c->coef + (size_t)t * CL.total;
     jb.s3 = c->s3 + (size_t)t * CL.s3total;
     jb.s1 = c->s1 + (size_t)t * CL.s1total;
+    jb.s5 = c->s5 + (size_t)t * CL.s5total;
     jb.mvs = c->mvs + (size_t)d * c->nblk;
     jb.stable = c->stable + (size_t)d * c->nblk;
     jb.nzpos = c->nzpos + (size_t)t * c->nz_total;

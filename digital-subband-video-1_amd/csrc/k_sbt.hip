@@ -7,9 +7,9 @@
 //   forward  P : k_fwd_haar_pix   one thread = one 8x8 pixel patch = Haar levels 1..3 in registers
 //                                 (8-byte coalesced row loads, 16/8/4-byte coalesced sub-band stores)
 //            I : k_fwd_b4t        level 1 biorthogonal (1,3,3,1): row pass + column pass per thread on a
-//                                 10x10 neighbourhood, LL1 -> s1;  k_fwd_haar_s1: levels 2..3 from s1
-//            all: k_fwd_tail      levels 4..top inside LDS (<=160 KB) by one 1024-thread workgroup
-//   inverse all: k_inv_tail       levels top..4 inside LDS, LL3 -> s3
+//                                 10x10 neighbourhood, LL1 -> s1;  k_fwd_haar_mid<2>: levels 2..3 from s1
+//            all: k_fwd_haar_mid<4> levels 4..5 (LL3 -> LL5);  k_fwd_tail: levels 6..top inside LDS by one workgroup
+//   inverse all: k_inv_tail       levels top..6 inside LDS, LL5 -> s5;  k_inv_haar_tile<.,2>: levels 5,4 -> s3
 //            P : k_inv_haar_tile  levels 3,2,1 on a 128x64 pixel tile through LDS (halo 2/1/0 cells),
 //                                 fused with sbc2int, the prediction add (dsv_frame_add bmc.c:304) and
 //                                 the store into the reconstruction frame
@@ -195,37 +195,43 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
     }
 }
 
-// forward, I pictures: Haar levels 2..3 from the LL1 scratch plane
-__global__ __launch_bounds__(256) void k_fwd_haar_s1(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+// forward: two Haar levels (LV, LV+1) from a compact LL band.  LV = 2: intra pictures, LL1 (s1) -> levels
+// 2..3, LL3 -> s3.  LV = 4: every picture, LL3 (s3) -> levels 4..5, LL5 -> s5 (the band the LDS tail takes).
+template <int LV>
+__global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
     const SbtGeo g = G.g[c];
+    const int W = g.W, H = g.H;
+    const int ow = DSVG_RSU(W, LV + 1), oh = DSVG_RSU(H, LV + 1);           // output LL band
     const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
-    if (I >= g.w3 || J >= g.h3) return;
+    if (I >= ow || J >= oh) return;
     const JobDev &jb = jobs[job];
     int32_t *coef = jb.coef + g.coff;
-    const int32_t *s1 = jb.s1 + g.s1off;
+    const int iw = DSVG_RSU(W, LV - 1), ih = DSVG_RSU(H, LV - 1);           // input LL band
+    const int32_t *in = (LV == 2) ? jb.s1 + g.s1off : jb.s3 + g.s3off;
+    int32_t *out = (LV == 2) ? jb.s3 + g.s3off : jb.s5 + g.s5off;
     int a[4][4];
 #pragma unroll
     for (int r = 0; r < 4; r++)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int x = 4 * I + i, y = 4 * J + r;
-            a[r][i] = (x < g.w1 && y < g.h1) ? s1[(size_t)y * g.w1 + x] : 0;
+            a[r][i] = (x < iw && y < ih) ? in[(size_t)y * iw + x] : 0;
         }
-    const int W = g.W, H = g.H;
-    const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
+    const int wo1 = DSVG_RSU(W, LV), ho1 = DSVG_RSU(H, LV);
     int l2[2][2], l3[1][1];
-    haar_fwd_patch<4>(a, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true);   // intra: always scaled
-    haar_fwd_patch<2>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true);
-    jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
+    haar_fwd_patch<4>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true);     // levels >= 2 are always scaled
+    haar_fwd_patch<2>(l2, l3, I, J, wo1, ho1, W, ow, oh, coef, true);
+    out[(size_t)J * ow + I] = l3[0][0];
 }
 
 // --------------------------------------------------------------------------------------------
 // LDS tails: levels >= 4 of one plane inside one workgroup
 // --------------------------------------------------------------------------------------------
 #define TAIL_THREADS 1024
-#define TAIL_MAXC 12            // cells per thread at the first tail level (host checks)
+#define TAIL_MAXC 4             // cells per thread at the first tail level (host checks)
+#define TAIL_LV 6               // first level handled inside LDS
 
 __global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
@@ -233,12 +239,12 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(const JobDev *__restr
     const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
-    const int w3 = g.w3, h3 = g.h3, n3 = w3 * h3, W = g.W, H = g.H;
-    const int32_t *s3 = jb.s3 + g.s3off;
+    const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
+    const int32_t *s3 = jb.s5 + g.s5off;
     for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) T[i] = s3[i];
     __syncthreads();
 
-    for (int lvl = 4; lvl <= g.lvls; lvl++) {
+    for (int lvl = TAIL_LV; lvl <= g.lvls; lvl++) {
         const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
         const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
         const int ncell = wo * ho;
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(const JobDev *__restr
                 const int b = hasR ? p[1] : a;
                 const int cc = hasB ? p[w3] : a;
                 const int d = hasB ? (hasR ? p[w3 + 1] : cc) : b;
-                ll[k] = d_ll_down(a + b + cc + d);          // levels >= 4 are always scaled
+                ll[k] = d_ll_down(a + b + cc + d);          // levels >= 2 are always scaled
                 lh[k] = a - b + cc - d;
                 hl[k] = a + b - cc - d;
                 hh[k] = a - b - cc + d;
@@ -303,7 +309,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restr
     const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
-    const int w3 = g.w3, h3 = g.h3, n3 = w3 * h3, W = g.W, H = g.H;
+    const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
     const int32_t *coef = jb.coef + g.coff;
     const bool filt = (c == 0);
     for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) {
@@ -312,7 +318,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restr
     }
     __syncthreads();
 
-    for (int lvl = g.lvls; lvl >= 4; lvl--) {
+    for (int lvl = g.lvls; lvl >= TAIL_LV; lvl--) {
         const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
         const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
         const int wfull = ws & ~1, hfull = hs & ~1;
@@ -360,8 +366,8 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restr
         }
         __syncthreads();
     }
-    int32_t *s3 = jb.s3 + g.s3off;
-    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) s3[i] = T[i];
+    int32_t *s5 = jb.s5 + g.s5off;
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) s5[i] = T[i];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -447,11 +453,14 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
 #define A1W (4 * IT_TX + 4)
 #define A1H (4 * IT_TY + 4)
 
-// TO_PIX: run level 1 as well and emit pixels (P pictures); otherwise stop after level 2 and store
-// the LL1 band to s1 (I pictures, whose level 1 is the B4T kernel below).
-template <bool FILT, bool TO_PIX>
+// MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
+// whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
+// other two modes).  The tile is IT_TX x IT_TY cells of the mode's top level.
+template <bool FILT, int MODE>
 __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
+    constexpr bool TO_PIX = (MODE == 0);
+    constexpr int TOP = (MODE == 2) ? 5 : 3;
     __shared__ int A3[A3H * A3W];
     __shared__ int A2[A2H * A2W];
     __shared__ int A1[A1H * A1W];
@@ -460,7 +469,8 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     const JobDev &jb = jobs[job];
     const int W = g.W, H = g.H;
     const int32_t *coef = jb.coef + g.coff;
-    const int32_t *s3 = jb.s3 + g.s3off;
+    const int inw = DSVG_RSU(W, TOP), inh = DSVG_RSU(H, TOP);
+    const int32_t *s3 = (MODE == 2) ? jb.s5 + g.s5off : jb.s3 + g.s3off;       // LL band of level TOP
     const int I0 = blockIdx.x * IT_TX, J0 = blockIdx.y * IT_TY;
     const int tid = threadIdx.x;
     const bool isP = jb.isP != 0;
@@ -468,11 +478,11 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     for (int i = tid; i < A3H * A3W; i += 256) {
         const int ly = i / A3W, lx = i - ly * A3W;
         const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
-        A3[i] = (cx >= 0 && cy >= 0 && cx < g.w3 && cy < g.h3) ? s3[(size_t)cy * g.w3 + cx] : 0;
+        A3[i] = (cx >= 0 && cy >= 0 && cx < inw && cy < inh) ? s3[(size_t)cy * inw + cx] : 0;
     }
     __syncthreads();
-    {   // level 3: cells I0-1 .. I0+TX (halo 1)
-        const LvlGeo L = mk_lvl(W, H, 3, jb.hqp[3], true);
+    {   // level TOP: cells I0-1 .. I0+TX (halo 1)
+        const LvlGeo L = mk_lvl(W, H, TOP, jb.hqp[TOP], true);
         for (int i = tid; i < (IT_TY + 2) * (IT_TX + 2); i += 256) {
             const int ly = i / (IT_TX + 2), lx = i - ly * (IT_TX + 2);
             const int cx = I0 - 1 + lx, cy = J0 - 1 + ly;
@@ -484,8 +494,8 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         }
     }
     __syncthreads();
-    {   // level 2: cells 2*I0-1 .. 2*I0+2*TX (halo 1)
-        const LvlGeo L = mk_lvl(W, H, 2, jb.hqp[2], true);
+    {   // level TOP-1: cells 2*I0-1 .. 2*I0+2*TX (halo 1)
+        const LvlGeo L = mk_lvl(W, H, TOP - 1, jb.hqp[TOP - 1], true);
         for (int i = tid; i < (2 * IT_TY + 2) * (2 * IT_TX + 2); i += 256) {
             const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
             const int cx = 2 * I0 - 1 + lx, cy = 2 * J0 - 1 + ly;
@@ -499,11 +509,12 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     __syncthreads();
 
     if (!TO_PIX) {
-        int32_t *s1 = jb.s1 + g.s1off;
+        int32_t *s1 = (MODE == 2) ? jb.s3 + g.s3off : jb.s1 + g.s1off;         // LL band of level TOP-2
+        const int ow = DSVG_RSU(W, TOP - 2), oh = DSVG_RSU(H, TOP - 2);
         for (int i = tid; i < (4 * IT_TY) * (4 * IT_TX); i += 256) {
             const int ly = i / (4 * IT_TX), lx = i - ly * (4 * IT_TX);
             const int cx = 4 * I0 + lx, cy = 4 * J0 + ly;
-            if (cx < g.w1 && cy < g.h1) s1[(size_t)cy * g.w1 + cx] = A1[(ly + 2) * A1W + lx + 2];
+            if (cx < ow && cy < oh) s1[(size_t)cy * ow + cx] = A1[(ly + 2) * A1W + lx + 2];
         }
         return;
     }
@@ -656,10 +667,11 @@ static inline dim3 grid3(int w3, int h3, int nz) { return dim3((w3 + 63) / 64, (
 
 int sbt_tail_supported(const SbtGeo &g)
 {
-    const long n3 = (long)g.w3 * g.h3;
-    if (n3 * 4 > 160 * 1024 - 256) return 0;
-    const long c4 = (long)DSVG_RSU(g.W, 4) * DSVG_RSU(g.H, 4);
-    return c4 <= (long)TAIL_MAXC * TAIL_THREADS;
+    const long n5 = (long)g.w5 * g.h5;
+    if (n5 * 4 > 160 * 1024 - 256) return 0;
+    if (g.lvls < TAIL_LV) return 0;
+    const long c6 = (long)DSVG_RSU(g.W, TAIL_LV) * DSVG_RSU(g.H, TAIL_LV);
+    return c6 <= (long)TAIL_MAXC * TAIL_THREADS;
 }
 
 // forward transform of planes [c0, c0+npl) of njobs jobs (all P or all I)
@@ -681,12 +693,16 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         hipLaunchKernelGGL(k_fwd_b4t, grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
         PB(KID_FWD_HAAR_S1, smp * 2.0);        // LL1 (1/4) in, levels 2..3 out
-        hipLaunchKernelGGL(k_fwd_haar_s1, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+        hipLaunchKernelGGL((k_fwd_haar_mid<2>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
         PE();
     }
+    // levels 4..5 (LL3 -> LL5) for every picture type
+    PB(KID_FWD_HAAR_S1, s3 * 8.0);
+    hipLaunchKernelGGL((k_fwd_haar_mid<4>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    PE();
     if (with_tail) {
-        PB(KID_FWD_TAIL, s3 * 8.0);
-        hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+        PB(KID_FWD_TAIL, (double)g.w5 * g.h5 * nz * 8.0);
+        hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w5 * g.h5 * 4, st, jobs, G, c0, npl);
         PE();
     }
 }
@@ -697,8 +713,8 @@ void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
     size_t lds = 0;
     double s3 = 0;
     for (int c = c0; c < c0 + npl; c++) {
-        lds = std::max(lds, (size_t)G.g[c].w3 * G.g[c].h3 * 4);
-        s3 += (double)G.g[c].w3 * G.g[c].h3 * njobs;
+        lds = std::max(lds, (size_t)G.g[c].w5 * G.g[c].h5 * 4);
+        s3 += (double)G.g[c].w5 * G.g[c].h5 * njobs;
     }
     PB(inverse ? KID_INV_TAIL : KID_FWD_TAIL, s3 * 8.0);
     if (inverse) hipLaunchKernelGGL(k_inv_tail, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
@@ -711,22 +727,29 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
+    const bool filt = (c0 == 0);
     if (with_tail) {
+        PB(KID_INV_TAIL, (double)g.w5 * g.h5 * nz * 8.0);
+        hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w5 * g.h5 * 4, st, jobs, G, c0, npl);
+        PE();
+    }
+    {   // levels 5..4 (LL5 -> LL3) for every picture type
+        const dim3 mg((g.w5 + IT_TX - 1) / IT_TX, (g.h5 + IT_TY - 1) / IT_TY, nz);
         PB(KID_INV_TAIL, s3 * 8.0);
-        hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w3 * g.h3 * 4, st, jobs, G, c0, npl);
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2>), mg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 2>), mg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
     }
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
-    const bool filt = (c0 == 0);
     if (isP) {
         PB(KID_INV_HAAR_TILE, smp * 6.0);      // 4 B/sample coefficients + 1 B prediction in, 1 B out
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
     } else {
         PB(KID_INV_HAAR_TILE, smp * 2.0);
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
         PB(KID_INV_B4T, smp * 5.0);

@@ -36,7 +36,7 @@ def mk_frame(rng, w, h, fmt, orc, smooth=True):
     return f
 
 
-SBT_CASES = [(16, 16), (32, 48), (176, 144), (352, 288), (250, 130), (960, 540), (1920, 1080), (100, 36)]
+SBT_CASES = [(40, 36), (32, 48), (176, 144), (352, 288), (250, 130), (960, 540), (1920, 1080), (100, 36)]
 
 
 @pytest.mark.parametrize("w,h", SBT_CASES)
