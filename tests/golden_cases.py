@@ -24,6 +24,9 @@ STREAM_CASES = {
     "cfg2_1080p_intra": (1920, 1080, A.SUBSAMP_420, 2, 1, 0x10800001, ["-gop0", "-qp85", "-rc_mode1"], dict(qp=85, gop=0, rc_mode_cli=1)),
     "cfg3_1080p_gop12": (1920, 1080, A.SUBSAMP_420, 13, 0, 0x10800003, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
     "cfg3_1080p_gop12_style2": (1920, 1080, A.SUBSAMP_420, 4, 2, 0x10800004, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    # BASELINE config 4 / 5 shapes (3840x2160), short
+    "cfg4_4k_gop12": (3840, 2160, A.SUBSAMP_420, 3, 0, 0x21600004, ["-gop12", "-qp85", "-rc_mode1", "-scd0"], dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
+    "cfg5_4k_444_abr": (3840, 2160, A.SUBSAMP_444, 3, 0, 0x21600005, ["-gop30", "-qp85", "-kbps20000"], dict(qp=85, gop=30, rc_mode_cli=0, kbps=20000)),
 }
 
 # operator-level known answers: name -> dict describing a seeded input
@@ -33,6 +36,7 @@ OP_CASES = {
     "sbt_250x130_P": dict(op="sbt", w=250, h=130, isP=1, seed=13),
     "sbt_960x540_I": dict(op="sbt", w=960, h=540, isP=0, seed=14),
     "sbt_1920x1080_P": dict(op="sbt", w=1920, h=1080, isP=1, seed=15),
+    "sbt_3840x2160_I": dict(op="sbt", w=3840, h=2160, isP=0, seed=16),
     "hzcc_960x540_overlap": dict(op="hzcc", w=960, h=540, isP=1, q=313, cur_plane=1, seed=21),
     "hzcc_250x130_overlap2": dict(op="hzcc", w=250, h=130, isP=0, q=100, cur_plane=0, seed=22),
     "hzcc_352x288_minq": dict(op="hzcc", w=352, h=288, isP=1, q=16, cur_plane=0, seed=23),
