@@ -102,6 +102,8 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     size_t hz_coef_off[3];   // offsets of each plane in coef (ints)
     int chunk_off[3];
     int dec_cnt[3];          // decoder: number of (position,value) pairs per plane
+    int16_t *sym;            // fused quantiser: quantised symbol of every detail scan cell, indexed nz_off[c] + scan position
+    int fused;               // 1: forward transform already quantised the detail bands (P pictures)
     HzPlane hz[3];
     int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level
     int isP;
@@ -126,3 +128,30 @@ static __device__ __forceinline__ int d_sat8(int v) { return v < 0 ? 0 : (v > 25
 // C.3.1.1 LL scaling (sbt.c:20-21): C integer division truncates toward zero -- load-bearing
 static __device__ __forceinline__ int d_ll_down(int x) { return x * 4 / 5; }
 static __device__ __forceinline__ int d_ll_up(int x) { return x * 5 / 4; }
+
+// ---- HZCC quantiser arithmetic shared by the transform-fused path (k_sbt.hip) and k_hzcc.hip -----------
+#define HZ_MINQ 16
+static __device__ __forceinline__ int hzq_lo(int v, int q)            // quant hzcc.c:94-112
+{
+    int m = (v < 0 ? -v : v) << 1;
+    if (m <= q) return 0;
+    m = (m + 1) / (q << 1);
+    return v < 0 ? -m : m;
+}
+static __device__ __forceinline__ int hzdq_lo(int v, int q)           // dequant hzcc.c:121-128
+{
+    return v < 0 ? -((-v * (q << 1) + q) >> 1) : (v * (q << 1) + q) >> 1;
+}
+static __device__ __forceinline__ int hzq_hi(int v, int sh) { return v < 0 ? -((-v) >> sh) : v >> sh; }
+static __device__ __forceinline__ int hzdq_hi(int v, int sh) { return (int)((unsigned)v << sh); }
+// quantiser for cell (x,y) of region r (tmq4pos hzcc.c:64-74, highest level hzcc.c:221-224)
+static __device__ __forceinline__ int hz_cell_tq(const HzRegion &r, const uint8_t *__restrict__ stable, int nbh, int x, int y)
+{
+    if (r.level < 0) return r.qp;
+    const int flag = stable[((y * r.dby) >> 14) * nbh + ((x * r.dbx) >> 14)];
+    if (r.level == 2) return flag ? r.qp_h : r.qp;
+    const int t = (flag & 2) ? r.qp >> 2 : (flag ? r.qp >> 1 : r.qp);
+    return t < HZ_MINQ ? HZ_MINQ : t;
+}
+static __device__ __forceinline__ int hz_quant_any(const HzRegion &r, int v, int tq) { return r.level == 2 ? hzq_hi(v, tq) : hzq_lo(v, tq); }
+static __device__ __forceinline__ int hz_dequant_any(const HzRegion &r, int v, int tq) { return r.level == 2 ? hzdq_hi(v, tq) : hzdq_lo(v, tq); }

@@ -56,7 +56,7 @@ enum {
     KID_HME_LEVEL, KID_HME_LEVEL0, KID_HME_DETAIL,
     KID_MC,
     KID_FWD_HAAR_PIX, KID_FWD_B4T, KID_FWD_HAAR_S1, KID_FWD_TAIL,
-    KID_HZ_QUANT, KID_HZ_SCAN, KID_HZ_EMIT, KID_HZ_SCATTER,
+    KID_HZ_QUANT, KID_HZ_COLLECT, KID_HZ_SCAN, KID_HZ_EMIT, KID_HZ_SCATTER,
     KID_INV_TAIL, KID_INV_HAAR_TILE, KID_INV_B4T,
     KID_N
 };

@@ -27,11 +27,12 @@ struct HmeArgs {
 // k_sbt.hip
 int  sbt_tail_supported(const SbtGeo &g);
 void sbt_set_func_attributes();
-void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr, int with_tail = 1);
+void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr, int with_tail = 1, int fused = 0);
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1);
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
 // k_hzcc.hip
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf = nullptr, double samples = 0);
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf = nullptr, double samples = 0,
+                      int nplain = -1);
 void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count, Prof *pf = nullptr);
 int  hz_scan_items_max();
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);

@@ -29,6 +29,7 @@ struct dsvg_ctx {
     Slab src[6], recon, xf, pred;
     int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *s5 = nullptr, *nzpos = nullptr, *nzval = nullptr;
     HzChunkSum *chunks = nullptr;
+    int16_t *sym = nullptr;          // fused quantiser: per work job, scan-order symbol planes (same indexing as nzpos)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
     DMV *mvs = nullptr;
@@ -68,7 +69,7 @@ static void ctx_free(dsvg_ctx *c)
     (void)hipSetDevice(c->device);
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
-    void *d[] = {c->coef, c->s3, c->s1, c->s5, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
+    void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
                  c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
@@ -171,6 +172,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->nzpos, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->sym, c->nz_total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
@@ -364,6 +366,7 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
     jb.nzpos = c->nzpos + (size_t)t * c->nz_total;
     jb.nzval = c->nzval + (size_t)t * c->nz_total;
     jb.chunks = c->chunks + (size_t)t * c->chunks_per_job;
+    jb.sym = c->sym + (size_t)t * c->nz_total;
     jb.psum = c->psum + (size_t)t * 3;
     jb.bits = c->bits + (size_t)t * c->bits_per_job;
     for (int p = 0; p < 3; p++) {
@@ -435,6 +438,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             }
             JobDev &jb = c->jobs_h[d];
             fill_job(c, jb, k, isP, j.quant, d);
+            jb.fused = isP ? 1 : 0;            // P pictures: quantisation fused into the forward transform
             jb.psum = c->psum + (size_t)j.out_slot * 3;
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
@@ -459,11 +463,11 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         if (njobs > nI) {
             const int nP = njobs - nI;
             launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof);
-            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0);
-            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0);
+            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
+            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
         }
         launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
-        launch_hz_encode(c->st, jd, njobs, c->max_chunks, &c->prof, (double)c->CL.total * njobs);
+        launch_hz_encode(c->st, jd, njobs, c->max_chunks, &c->prof, (double)c->CL.total, nI);
         OPCHK(enqueue_recon(c, nI, njobs, d0));
     }
     {   // completion marker of this call; fetch waits on it from its own stream

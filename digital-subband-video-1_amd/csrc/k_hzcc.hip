@@ -19,42 +19,17 @@
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
 
-#define MINQ 16
-
-static __device__ __forceinline__ int q_lo(int v, int q)            // quant hzcc.c:94-112
-{
-    int m = (v < 0 ? -v : v) << 1;
-    if (m <= q) return 0;
-    m = (m + 1) / (q << 1);
-    return v < 0 ? -m : m;
-}
-static __device__ __forceinline__ int dq_lo(int v, int q)           // dequant hzcc.c:121-128
-{
-    return v < 0 ? -((-v * (q << 1) + q) >> 1) : (v * (q << 1) + q) >> 1;
-}
-static __device__ __forceinline__ int q_hi(int v, int sh) { return v < 0 ? -((-v) >> sh) : v >> sh; }
-static __device__ __forceinline__ int dq_hi(int v, int sh) { return (int)((unsigned)v << sh); }
+#define MINQ HZ_MINQ
+#define q_lo hzq_lo
+#define dq_lo hzdq_lo
+#define q_hi hzq_hi
+#define dq_hi hzdq_hi
+#define cell_tq hz_cell_tq
+#define quant_any hz_quant_any
+#define dequant_any hz_dequant_any
 
 static __device__ __forceinline__ int len_ueg(unsigned v) { return 2 * (31 - __clz((int)(v + 1))) + 1; }
 static __device__ __forceinline__ int len_neg(int v) { return len_ueg((unsigned)(v < 0 ? -v : v) - 1u) + 1; }
-
-// quantiser for cell (x,y) of region r (tmq4pos hzcc.c:64-74, highest level hzcc.c:221-224)
-static __device__ __forceinline__ int cell_tq(const HzRegion &r, const uint8_t *__restrict__ stable, int nbh, int x, int y)
-{
-    if (r.level < 0) return r.qp;
-    const int flag = stable[((y * r.dby) >> 14) * nbh + ((x * r.dbx) >> 14)];
-    if (r.level == 2) return flag ? r.qp_h : r.qp;
-    const int t = (flag & 2) ? r.qp >> 2 : (flag ? r.qp >> 1 : r.qp);
-    return t < MINQ ? MINQ : t;
-}
-static __device__ __forceinline__ int quant_any(const HzRegion &r, int v, int tq)
-{
-    return r.level == 2 ? q_hi(v, tq) : q_lo(v, tq);
-}
-static __device__ __forceinline__ int dequant_any(const HzRegion &r, int v, int tq)
-{
-    return r.level == 2 ? dq_hi(v, tq) : dq_lo(v, tq);
-}
 
 static __device__ __forceinline__ int find_region(const HzPlane &hp, int p)
 {
@@ -99,6 +74,9 @@ static __device__ __forceinline__ int hz_cell(const JobDev &jb, const HzPlane &h
     return v;
 }
 
+// SYM: the detail regions were already quantised by the forward transform (k_fwd_haar_pix<true>), which left
+// their symbols in jb.sym in scan order; only the LL region (scan cells below r[1].base) is still quantised here.
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ jobs)
 {
     __shared__ int s_pos[HZ_CHUNK];
@@ -126,7 +104,16 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
     for (int k = 0; k < 2; k++) {
         const int p0 = wbase + k * 256 + 4 * lane;
         int v[4] = {0, 0, 0, 0};
-        if (p0 < hp.nscan) {
+        if (SYM && p0 >= hp.r[1].base) {
+            if (p0 < hp.nscan) {                       // nz_off and the scan size are multiples of 4 cells (see fill_job)
+                const uint2 sv = *reinterpret_cast<const uint2 *>(jb.sym + jb.nz_off[c] + p0);
+                v[0] = (int16_t)(sv.x & 0xffff); v[1] = (int)sv.x >> 16;
+                v[2] = (int16_t)(sv.y & 0xffff); v[3] = (int)sv.y >> 16;
+#pragma unroll
+                for (int j = 1; j < 4; j++)
+                    if (p0 + j >= hp.nscan) v[j] = 0;
+            }
+        } else if (p0 < hp.nscan) {
             const HzRegion r = hp.r[find_region(hp, p0)];
             const int local = p0 - r.base;
             const int y = local / r.sw, x = local - y * r.sw;
@@ -151,7 +138,9 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
             } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
-                    if (p0 + j < hp.nscan) v[j] = hz_cell(jb, hp, c, plane, p0 + j);
+                    if (p0 + j < hp.nscan)
+                        v[j] = (SYM && p0 + j >= hp.r[1].base) ? (int)jb.sym[jb.nz_off[c] + p0 + j]
+                                                               : hz_cell(jb, hp, c, plane, p0 + j);
             }
         }
         // compact the non-zeros in scan order: lanes in order, the 4 cells of a lane in order
@@ -283,7 +272,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
     const HzPlane &hp = jb.hz[c];
     HzChunkSum *cs = jb.chunks + jb.chunk_off[c];
     const int n = hp.nchunks;
-    if (n > 0) hz_fix_overlaps(jb, hp, c, SCAN_THREADS);
+    if (n > 0 && !jb.fused) hz_fix_overlaps(jb, hp, c, SCAN_THREADS);   // the fused path stores final values itself
     const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;     // host guarantees per <= SCAN_ITEMS
     const int first = threadIdx.x * per;
 
@@ -500,11 +489,21 @@ __global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ j
 #define PB(kid, bytes) do { if (pf) pf->begin(st, kid, bytes); } while (0)
 #define PE() do { if (pf) pf->end(st); } while (0)
 
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf, double samples)
+// jobs [0, nplain) take the full quantiser; jobs [nplain, njobs) were quantised by the forward transform
+// (JobDev.fused) and only have their symbol planes compacted.  samples = coefficients per job.
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf, double samples, int nplain)
 {
-    PB(KID_HZ_QUANT, samples * 8.0);           // 4 B/sample in, 4 B/sample dequantised back
-    hipLaunchKernelGGL(k_hz_quant, dim3(max_chunks, 3, njobs), dim3(256), 0, st, jobs);
-    PE();
+    if (nplain < 0 || nplain > njobs) nplain = njobs;
+    if (nplain > 0) {
+        PB(KID_HZ_QUANT, samples * nplain * 8.0);          // 4 B/sample in, 4 B/sample dequantised back
+        hipLaunchKernelGGL((k_hz_quant<false>), dim3(max_chunks, 3, nplain), dim3(256), 0, st, jobs);
+        PE();
+    }
+    if (njobs > nplain) {
+        PB(KID_HZ_COLLECT, samples * (njobs - nplain) * 2.0);   // 2 B/sample of symbols in
+        hipLaunchKernelGGL((k_hz_quant<true>), dim3(max_chunks, 3, njobs - nplain), dim3(256), 0, st, jobs + nplain);
+        PE();
+    }
     PB(KID_HZ_SCAN, 0.0);
     hipLaunchKernelGGL(k_hz_scan, dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
     PE();

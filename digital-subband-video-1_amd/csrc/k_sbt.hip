@@ -46,6 +46,115 @@ static __device__ __forceinline__ void store_row(int32_t *p, const int (&v)[M], 
     }
 }
 
+// ---- quantisation fused into the forward transform (P pictures) -------------------------------------------
+// Every detail coefficient is quantised + dequantised the moment it is produced (hzcc.c:172-184 arithmetic):
+// the dequantised value goes to the coefficient plane (what the inverse transform reads) and the quantised
+// symbol (fits 16 bits for levels 1..3 of an 8-bit residual) to a symbol plane indexed by SCAN position, which
+// k_hz_quant<SYM> then only has to compact.  A coefficient that two scan regions cover physically
+// belongs to the later region's sub-band, so its producer writes both symbols.
+struct QCtx {
+    const HzPlane *hp;
+    const uint8_t *stable;
+    int16_t *sym;
+    bool any_ov;
+};
+// wave-uniform constants of one scan level: its LH/HL/HH regions differ only in origin and scan base
+struct QLevel {
+    int qp;                // levels 0,1: quantiser max(qp >> class, 16), class {none, stable, flag&2} (tmq4pos hzcc.c:64-74)
+    int sh0, sh1;          // level 2: shift by flag class {none, any} (hzcc.c:221-224)
+    int dbx, dby, sw, base0, base1, base2;
+};
+template <int HZL>
+static __device__ __forceinline__ QLevel q_level(const HzPlane &hp)
+{
+    const HzRegion &r = hp.r[1 + 3 * HZL];
+    QLevel L;
+    L.qp = r.qp; L.sh0 = r.qp; L.sh1 = r.qp_h;
+    L.dbx = r.dbx; L.dby = r.dby; L.sw = r.sw;
+    L.base0 = r.base; L.base1 = hp.r[2 + 3 * HZL].base; L.base2 = hp.r[3 + 3 * HZL].base;
+    return L;
+}
+// flag class of each cell of an MxM patch: one byte load when the whole patch sits in one block (the usual case)
+template <int HZL, int M>
+static __device__ __forceinline__ void q_flags(const QCtx &q, const QLevel &L, int cx0, int cy0, int wo, int ho, int (&cls)[M][M])
+{
+    const int nbh = q.hp->nbh;
+    const int bx0 = (cx0 * L.dbx) >> 14, bx1 = ((cx0 + M - 1) * L.dbx) >> 14;
+    const int by0 = (cy0 * L.dby) >> 14, by1 = ((cy0 + M - 1) * L.dby) >> 14;
+    if (bx0 == bx1 && by0 == by1) {
+        const int f = q.stable[by0 * nbh + bx0];
+        const int k = HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0));
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i < M; i++) cls[j][i] = k;
+    } else {
+#pragma unroll
+        for (int j = 0; j < M; j++)
+#pragma unroll
+            for (int i = 0; i < M; i++) {
+                int f = 0;
+                if (cx0 + i < wo && cy0 + j < ho) f = q.stable[(((cy0 + j) * L.dby) >> 14) * nbh + (((cx0 + i) * L.dbx) >> 14)];
+                cls[j][i] = HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0));
+            }
+    }
+}
+// quantise + dequantise one coefficient with quantiser qq (levels 0,1; rc ~ 1/(2 qq)) or shift qq (level 2):
+// returns the dequantised value, sym = the symbol
+template <int HZL>
+static __device__ __forceinline__ int q_coef(int qq, float rc, int v, int &sym)
+{
+    if (HZL == 2) {
+        const int t = (v < 0 ? -v : v) >> qq;
+        sym = v < 0 ? -t : t;
+        return (int)((unsigned)sym << qq);
+    }
+    const int m = (v < 0 ? -v : v) << 1;
+    const int n = m + 1, d = qq << 1;                    // (m + 1) / (2q), exact: float estimate, then +-1
+    int t = (int)((float)n * rc);
+    const int rem = n - t * d;
+    t += (rem >= d) - (rem < 0);
+    const int dq = (t * d + qq) >> 1;
+    const bool z = t == 0;                               // covers m <= q (q >= 16) and the q < m < 2q - 1 gap
+    sym = z ? 0 : (v < 0 ? -t : t);
+    return z ? 0 : (v < 0 ? -dq : dq);
+}
+// the earlier (level HZL-1) scan pass over a shared cell: writes its symbol, returns what the later pass sees
+static __device__ int q_chain(const QCtx &q, int l, int gx, int gy, int val)
+{
+    const HzPlane &hp = *q.hp;
+    if (!(gx < 2 * hp.s_w[l - 1] && gy < 2 * hp.s_h[l - 1])) return val;
+    const int rx = gx >= hp.s_w[l - 1], ry = gy >= hp.s_h[l - 1];
+    if (!(rx + ry)) return val;
+    const HzRegion &e = hp.r[1 + 3 * (l - 1) + (rx + 2 * ry) - 1];
+    const int ex = gx - e.x0, ey = gy - e.y0;
+    const int etq = hz_cell_tq(e, q.stable, hp.nbh, ex, ey);
+    const int ev = hz_quant_any(e, val, etq);
+    q.sym[e.base + ey * e.sw + ex] = (int16_t)ev;
+    return ev ? hz_dequant_any(e, ev, etq) : 0;
+}
+template <int M>
+static __device__ __forceinline__ void store_sym_row(int16_t *p, const int (&v)[M], int n)
+{
+    if (n >= M) {
+        if (M == 4 && (((uintptr_t)p) & 7) == 0) {
+            *reinterpret_cast<uint2 *>(p) = make_uint2((v[0] & 0xffff) | ((unsigned)v[1 % M] << 16),
+                                                       (v[2 % M] & 0xffff) | ((unsigned)v[3 % M] << 16));
+            return;
+        }
+        if (M == 2 && (((uintptr_t)p) & 3) == 0) {
+            *reinterpret_cast<unsigned *>(p) = (v[0] & 0xffff) | ((unsigned)v[1 % M] << 16);
+            return;
+        }
+#pragma unroll
+        for (int i = 0; i < M; i++) p[i] = (int16_t)v[i];
+    } else {
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            if (i < n) p[i] = (int16_t)v[i];
+    }
+}
+
 // One forward Haar level on an NxN register patch whose top-left input sample is cell
 // (2*cx0, 2*cy0) of the level's ws x hs input region.  Missing right/bottom samples are mirrored
 // (equivalent to the edge formulas sbt.c:309-346); sub-bands that do not exist are not stored.
@@ -85,9 +194,71 @@ static __device__ __forceinline__ void haar_fwd_patch(const int (&in)[N][N], int
     }
 }
 
+// the same level with the quantiser of scan level HZL applied to the three detail bands
+template <int N, int HZL>
+static __device__ __forceinline__ void haar_fwd_patch_q(const int (&in)[N][N], int (&out)[N / 2][N / 2],
+                                                        int cx0, int cy0, int ws, int hs, int W,
+                                                        int wo, int ho, int32_t *__restrict__ coef, bool scaled,
+                                                        const QCtx &q)
+{
+    constexpr int M = N / 2;
+    const int nR = min(M, max(0, (ws >> 1) - cx0));
+    const int nC = min(M, max(0, wo - cx0));
+    const HzPlane &hp = *q.hp;
+    const QLevel L = q_level<HZL>(hp);
+    int cls[M][M];
+    q_flags<HZL, M>(q, L, cx0, cy0, wo, ho, cls);
+    const bool chx = HZL >= 1 && q.any_ov && cx0 == 0, chy = HZL >= 1 && q.any_ov && cy0 == 0;
+#pragma unroll
+    for (int j = 0; j < M; j++) {
+        const int cy = cy0 + j;
+        const bool hasB = 2 * cy + 1 < hs;
+        const bool rowok = 2 * cy < hs;
+        int lh[M], hl[M], hh[M], slh[M], shl[M], shh[M];
+#pragma unroll
+        for (int i = 0; i < M; i++) {
+            const bool hasR = 2 * (cx0 + i) + 1 < ws;
+            const int a = in[2 * j][2 * i];
+            const int b = hasR ? in[2 * j][2 * i + 1] : a;
+            const int c = hasB ? in[2 * j + 1][2 * i] : a;
+            const int d = hasB ? (hasR ? in[2 * j + 1][2 * i + 1] : c) : b;
+            const int ll = a + b + c + d;
+            out[j][i] = scaled ? d_ll_down(ll) : ll;
+            int vlh = a - b + c - d, vhl = a + b - c - d, vhh = a - b - c + d;
+            if (HZL >= 1) {                             // shared cells sit on the first column / row of the bands
+                if (i == 0 && chx && rowok && nR > 0) {
+                    vlh = q_chain(q, HZL, wo, cy, vlh);
+                    if (hasB) vhh = q_chain(q, HZL, wo, ho + cy, vhh);
+                }
+                if (j == 0 && chy && hasB) {
+                    if (i < nC) vhl = q_chain(q, HZL, cx0 + i, ho, vhl);
+                    if (i < nR && !(i == 0 && chx)) vhh = q_chain(q, HZL, wo + cx0 + i, ho, vhh);
+                }
+            }
+            const int k = cls[j][i];
+            const int qq = HZL == 2 ? (k ? L.sh1 : L.sh0) : max(L.qp >> k, HZ_MINQ);
+            const float rc = HZL == 2 ? 0.f : __builtin_amdgcn_rcpf((float)(qq << 1));
+            lh[i] = q_coef<HZL>(qq, rc, vlh, slh[i]);
+            hl[i] = q_coef<HZL>(qq, rc, vhl, shl[i]);
+            hh[i] = q_coef<HZL>(qq, rc, vhh, shh[i]);
+        }
+        if (rowok) {
+            store_row<M>(coef + (size_t)cy * W + wo + cx0, lh, nR);
+            store_sym_row<M>(q.sym + L.base0 + cy * L.sw + cx0, slh, nR);     // scan position = base + cy * sw + cx
+            if (hasB) {
+                store_row<M>(coef + (size_t)(ho + cy) * W + cx0, hl, nC);
+                store_row<M>(coef + (size_t)(ho + cy) * W + wo + cx0, hh, nR);
+                store_sym_row<M>(q.sym + L.base1 + cy * L.sw + cx0, shl, nC);
+                store_sym_row<M>(q.sym + L.base2 + cy * L.sw + cx0, shh, nR);
+            }
+        }
+    }
+}
+
 // --------------------------------------------------------------------------------------------
 // forward, P pictures: levels 1..3 straight from the 8-bit residual plane
 // --------------------------------------------------------------------------------------------
+template <bool Q>
 __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
                                                       int from_src)
 {
@@ -114,9 +285,24 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
     const int W = g.W, H = g.H;
     const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
     int l1[4][4], l2[2][2], l3[1][1];
-    haar_fwd_patch<8>(a, l1, 4 * I, 4 * J, W, H, W, wo1, ho1, coef, false);      // LVL_TEST: P level 1 unscaled
-    haar_fwd_patch<4>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true);
-    haar_fwd_patch<2>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true);
+    QCtx q;
+    if (Q) {
+        const HzPlane &hp = jb.hz[c];
+        q.hp = &hp; q.stable = jb.stable;
+        q.sym = jb.sym + jb.nz_off[c];
+        q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+                   (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+    }
+    // transform level 1,2,3 <-> scan level 2,1,0
+    if (Q) {
+        haar_fwd_patch_q<8, 2>(a, l1, 4 * I, 4 * J, W, H, W, wo1, ho1, coef, false, q);
+        haar_fwd_patch_q<4, 1>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true, q);
+        haar_fwd_patch_q<2, 0>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true, q);
+    } else {
+        haar_fwd_patch<8>(a, l1, 4 * I, 4 * J, W, H, W, wo1, ho1, coef, false);      // LVL_TEST: P level 1 unscaled
+        haar_fwd_patch<4>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true);
+        haar_fwd_patch<2>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true);
+    }
     jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
 }
 
@@ -679,14 +865,15 @@ int sbt_tail_supported(const SbtGeo &g)
 #define PE() do { if (pf) pf->end(st); } while (0)
 
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
-                    int from_src, Prof *pf, int with_tail)
+                    int from_src, Prof *pf, int with_tail, int fused)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
     if (isP) {
         PB(KID_FWD_HAAR_PIX, smp * 5.0);       // 1 B/sample in, 4 B/sample out (details + LL3)
-        hipLaunchKernelGGL(k_fwd_haar_pix, grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        if (fused) hipLaunchKernelGGL((k_fwd_haar_pix<true>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        else       hipLaunchKernelGGL((k_fwd_haar_pix<false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
     } else {
         PB(KID_FWD_B4T, smp * 5.0);
