@@ -74,6 +74,18 @@ static __device__ __forceinline__ int hz_cell(const JobDev &jb, const HzPlane &h
     return v;
 }
 
+// flat chunk index of a job -> plane c and chunk inside the plane (planes with nchunks == 0 are skipped)
+static __device__ __forceinline__ bool flat_chunk(const JobDev &jb, int fc, int &c, int &chunk)
+{
+#pragma unroll
+    for (int p = 0; p < 3; p++) {
+        const int n = jb.hz[p].nchunks;
+        if (fc < n) { c = p; chunk = fc; return true; }
+        fc -= n;
+    }
+    return false;
+}
+
 // SYM: the detail regions were already quantised by the forward transform (k_fwd_haar_pix<true>), which left
 // their symbols in jb.sym in scan order; only the LL region (scan cells below r[1].base) is still quantised here.
 template <bool SYM>
@@ -83,10 +95,11 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
     __shared__ int s_val[HZ_CHUNK];
     __shared__ int s_wcnt[4];
     __shared__ unsigned s_bits;
-    const int job = blockIdx.z, c = blockIdx.y, chunk = blockIdx.x;
+    const int job = blockIdx.y;
     const JobDev &jb = jobs[job];
+    int c, chunk;
+    if (!flat_chunk(jb, blockIdx.x, c, chunk)) return;
     const HzPlane &hp = jb.hz[c];
-    if (chunk >= hp.nchunks) return;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *plane = jb.coef + jb.hz_coef_off[c];
     const uint8_t *stable = jb.stable;
@@ -410,26 +423,45 @@ static __device__ __forceinline__ void or_bits(unsigned *out32, unsigned long lo
     if (w2) atomicOr(out32 + w + 2, __builtin_bswap32(w2));
 }
 
+// OR `len` (<= 48) bits of `pat` into a word array held MSB-first per 32-bit VALUE (no byte swap) at bit `pos`
+static __device__ __forceinline__ void or_bits_lds(unsigned *w32, unsigned pos, unsigned long long pat, int len)
+{
+    const unsigned w = pos >> 5;
+    const int o = (int)(pos & 31);
+    const int sh = 64 - o - len;
+    unsigned long long hi, lo = 0;
+    if (sh >= 0) hi = pat << sh;
+    else { hi = pat >> (-sh); lo = pat << (64 + sh); }
+    const unsigned w0 = (unsigned)(hi >> 32), w1 = (unsigned)hi, w2 = (unsigned)(lo >> 32);
+    if (w0) atomicOr(w32 + w, w0);
+    if (w1) atomicOr(w32 + w + 1, w1);
+    if (w2) atomicOr(w32 + w + 2, w2);
+}
+
+// One WAVE per chunk (most chunks of a P picture hold a few dozen symbols), four chunks per workgroup.
+// Each round of 64 symbols is assembled in the wave's LDS window with LDS atomics and flushed with plain
+// coalesced stores; only the first and last word of a round can be shared (with the neighbouring round or
+// chunk) and go out as global atomicOr -- an I picture would otherwise issue ~2.5 global atomics per symbol.
+#define EMIT_STAGE_WORDS 200            // 64 symbols x (<= 47 + 49 bits) = 6144 bits = 192 words, + straddle
 __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs)
 {
-    __shared__ unsigned s_w[4];
-    __shared__ unsigned s_run;
-    const int job = blockIdx.z, c = blockIdx.y, chunk = blockIdx.x;
+    __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
+    const int job = blockIdx.y;
     const JobDev &jb = jobs[job];
-    const HzPlane &hp = jb.hz[c];
-    if (chunk >= hp.nchunks) return;
+    const int lane = threadIdx.x & 63;
+    unsigned *stg = s_stage[threadIdx.x >> 6];
+    int c, chunk;
+    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
     const HzPlaneSum ps = jb.psum[c];
     if (ps.overflow) return;
     const HzChunkSum cs = jb.chunks[jb.chunk_off[c] + chunk];
-    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     unsigned *out32 = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
     const int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
     const int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
 
-    if (tid == 0) s_run = 0;
-    __syncthreads();
-    for (int base = 0; base < cs.nnz; base += 256) {
-        const int j = base + tid;
+    unsigned long long at0 = cs.bit_off;
+    for (int base = 0; base < cs.nnz; base += 64) {
+        const int j = base + lane;
         int l1 = 0, l2 = 0;
         unsigned long long p1 = 0, p2 = 0;
         if (j < cs.nnz) {
@@ -439,25 +471,37 @@ __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs
             p1 = pat_ueg((unsigned)(pos - ppos - 1), l1);
             if (j > 0 || cs.prev_pos >= 0) p2 = pat_neg(pval, l2);
         }
-        // exclusive prefix of (l1+l2) over the block
-        unsigned len = (unsigned)(l1 + l2), incl = len;
+        const unsigned len = (unsigned)(l1 + l2);
+        unsigned incl = len;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned n = __shfl_up(incl, o);
             if (lane >= o) incl += n;
         }
-        if (lane == 63) s_w[wv] = incl;
-        __syncthreads();
-        unsigned pre = s_run;
-        for (int i = 0; i < wv; i++) pre += s_w[i];
-        const unsigned long long at = cs.bit_off + pre + (incl - len);
-        if (l1) or_bits(out32, at, p1, l1);
-        if (l2) or_bits(out32, at + l1, p2, l2);
-        __syncthreads();
-        if (tid == 255) s_run = pre + incl;
-        __syncthreads();
+        const unsigned tot = __shfl(incl, 63);
+        const unsigned long long w0 = at0 >> 5;                       // first word of this round
+        const unsigned o0 = (unsigned)(at0 & 31);
+        const int nw = (int)((o0 + tot + 31) >> 5);                   // words touched, <= 193
+        for (int i = lane; i < nw + 2; i += 64) stg[i] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const unsigned rel = o0 + (incl - len);
+        if (l1) or_bits_lds(stg, rel, p1, l1);
+        if (l2) or_bits_lds(stg, rel + l1, p2, l2);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < nw; i += 64) {
+            const unsigned v = stg[i];
+            if (v) {
+                if (i == 0 || i == nw - 1) atomicOr(out32 + w0 + i, __builtin_bswap32(v));
+                else out32[w0 + i] = __builtin_bswap32(v);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        at0 += tot;
     }
-    if (tid == 0 && chunk == ps.last_chunk) {       // trailing value of the plane
+    if (lane == 0 && chunk == ps.last_chunk) {       // trailing value of the plane
         int l;
         const unsigned long long p = pat_neg(cs.last_val, l);
         or_bits(out32, ps.total_bits - (unsigned long long)l, p, l);
@@ -490,25 +534,26 @@ __global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ j
 #define PE() do { if (pf) pf->end(st); } while (0)
 
 // jobs [0, nplain) take the full quantiser; jobs [nplain, njobs) were quantised by the forward transform
-// (JobDev.fused) and only have their symbol planes compacted.  samples = coefficients per job.
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int max_chunks, Prof *pf, double samples, int nplain)
+// (JobDev.fused) and only have their symbol planes compacted.  samples = coefficients per job, job_chunks = scan
+// chunks of one job over its three planes.
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain)
 {
     if (nplain < 0 || nplain > njobs) nplain = njobs;
     if (nplain > 0) {
         PB(KID_HZ_QUANT, samples * nplain * 8.0);          // 4 B/sample in, 4 B/sample dequantised back
-        hipLaunchKernelGGL((k_hz_quant<false>), dim3(max_chunks, 3, nplain), dim3(256), 0, st, jobs);
+        hipLaunchKernelGGL((k_hz_quant<false>), dim3(job_chunks, nplain), dim3(256), 0, st, jobs);
         PE();
     }
     if (njobs > nplain) {
         PB(KID_HZ_COLLECT, samples * (njobs - nplain) * 2.0);   // 2 B/sample of symbols in
-        hipLaunchKernelGGL((k_hz_quant<true>), dim3(max_chunks, 3, njobs - nplain), dim3(256), 0, st, jobs + nplain);
+        hipLaunchKernelGGL((k_hz_quant<true>), dim3(job_chunks, njobs - nplain), dim3(256), 0, st, jobs + nplain);
         PE();
     }
     PB(KID_HZ_SCAN, 0.0);
     hipLaunchKernelGGL(k_hz_scan, dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
     PE();
     PB(KID_HZ_EMIT, 0.0);
-    hipLaunchKernelGGL(k_hz_emit, dim3(max_chunks, 3, njobs), dim3(256), 0, st, jobs);
+    hipLaunchKernelGGL(k_hz_emit, dim3((job_chunks + 3) / 4, njobs), dim3(256), 0, st, jobs);
     PE();
 }
 
