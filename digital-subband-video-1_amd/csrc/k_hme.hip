@@ -34,18 +34,20 @@
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
 // stage rows [oy,oy+nh) x cols [ox,ox+nw) of a plane into LDS (pitch P) as ALIGNED dwords; returns the
-// byte shift `mis` such that dst[r*P + mis + k] == plane(ox+k, oy+r)
+// byte shift `mis` such that dst[r*P + mis + k] == plane(ox+k, oy+r).  TPR threads share a row (the window
+// must span <= TPR dwords), NT/TPR rows are in flight per pass.
+template <int TPR>
 static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_t *plane, int stride,
                                                int ox, int oy, int nw, int nh)
 {
     const uint8_t *g0 = plane + (long)oy * stride + ox;
     const int mis = (int)(((uintptr_t)g0) & 3);
     const int ndw = (mis + nw + 3) >> 2;
-    for (int i = threadIdx.x; i < nh * ndw; i += NT) {
-        const int r = i / ndw, d = i - r * ndw;
-        *reinterpret_cast<unsigned *>(dst + r * P + 4 * d) =
-            *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
-    }
+    const int d = threadIdx.x & (TPR - 1);
+    if (d < ndw)
+        for (int r = threadIdx.x / TPR; r < nh; r += NT / TPR)
+            *reinterpret_cast<unsigned *>(dst + r * P + 4 * d) =
+                *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
     return mis;
 }
 
@@ -71,34 +73,64 @@ struct HmeShared {
     } u;
     __attribute__((aligned(16))) uint8_t swin[WIN * 24];
     __attribute__((aligned(16))) uint8_t rwin[WIN * 16];
-    unsigned part[NW][9];
+    unsigned part[2][NW][9];
     int par[5];
     int cand[8];
     int ncand;
 };
 
-// sum N values over the workgroup; every thread receives all totals (2 barriers)
-template <int N>
-static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*part)[9])
+// wave64 sum through DPP (no LDS traffic); the result is wave-uniform (SGPR)
+static __device__ __forceinline__ unsigned wave_sum(unsigned v)
 {
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror
+    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);    // row_mirror: every lane = its row's sum
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+
+// sum N values over the workgroup; every thread receives all totals (wave-uniform).  `part` is double
+// buffered by the caller-maintained phase bit, so one barrier per reduction suffices.
+template <int N>
+static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*part)[NW][9], int &phase)
+{
+    // step-major over the N independent chains: a DPP read needs two wait states after the write it consumes
 #pragma unroll
-    for (int i = 0; i < N; i++) {
+    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0xB1, 0xf, 0xf, true);
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) v[i] += __shfl_down(v[i], o);
-    }
-    __syncthreads();
+    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0x4E, 0xf, 0xf, true);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0x141, 0xf, 0xf, true);
+#pragma unroll
+    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0x140, 0xf, 0xf, true);
+#pragma unroll
+    for (int i = 0; i < N; i++)
+        v[i] = (unsigned)__builtin_amdgcn_readlane((int)v[i], 0) + (unsigned)__builtin_amdgcn_readlane((int)v[i], 16) +
+               (unsigned)__builtin_amdgcn_readlane((int)v[i], 32) + (unsigned)__builtin_amdgcn_readlane((int)v[i], 48);
+    if (NW == 1) return;
+    unsigned (*pb)[9] = part[phase];
+    phase ^= 1;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int i = 0; i < N; i++) part[threadIdx.x >> 6][i] = v[i];
+        for (int i = 0; i < N; i++) pb[threadIdx.x >> 6][i] = v[i];
     }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < N; i++) {
         unsigned t = 0;
 #pragma unroll
-        for (int w = 0; w < NW; w++) t += part[w][i];
-        v[i] = t;
+        for (int w = 0; w < NW; w++) t += pb[w][i];
+        v[i] = (unsigned)__builtin_amdgcn_readfirstlane((int)t);
     }
+}
+
+// n / d for 32-bit unsigned n and d < 2^13 with rd = 1.0 / d: the double product is within 2^-19 of the true
+// quotient and a non-integer quotient is >= 2^-13 away from the next integer, so the 2^-16 bias makes
+// the truncation exact.
+static __device__ __forceinline__ unsigned udiv_rd(unsigned n, double rd)
+{
+    return (unsigned)__builtin_fma((double)n, rd, 0x1p-16);
 }
 
 static __device__ __forceinline__ int frame_invalid(int fw, int fh, int x, int y, int w, int h)   // invalid_block
@@ -191,6 +223,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
     }
     __syncthreads();
     const int n = S.ncand;
+    int phase = 0;
 
     // best inherited candidate by SAD, all candidates in one pass, reference pixels straight from HBM/L2
     int pick = n - 1;
@@ -219,7 +252,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
                 }
             }
         }
-        block_sum_n<6>(acc, S.part);
+        block_sum_n<6>(acc, S.part, phase);
         int best_score = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < 6; k++)
@@ -236,7 +269,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
     // 9-point +-1 search around (dx,dy): window (bw+2)x(bh+2) at (bx+dx-1, by+dy-1) staged as aligned dwords
     int best, bestk;
     {
-        const int mis = load_win(S.u.ref, RP, rp, stride, bx + dx - 1, by + dy - 1, bw + 2, bh + 2);
+        const int mis = load_win<32>(S.u.ref, RP, rp, stride, bx + dx - 1, by + dy - 1, bw + 2, bh + 2);
         __syncthreads();
         unsigned acc[9];
 #pragma unroll
@@ -264,7 +297,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
                 }
             }
         }
-        block_sum_n<9>(acc, S.part);
+        block_sum_n<9>(acc, S.part, phase);
         best = 0x7fffffff; bestk = 0;
 #pragma unroll
         for (int k = 0; k < 9; k++)
@@ -284,13 +317,14 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
 
     // ------------------------------------------------------------------ level 0 only
     const unsigned yarea = (unsigned)(bw * bh), yareasq = yarea * yarea;
+    const double ryarea = 1.0 / (double)yarea;
     const int wx = bx + ((bw >> 1) - WIN / 2), wy = by + ((bh >> 1) - WIN / 2);
     const bool do_hp = best > BW * BH;
     // stage: source 14x14 window, and either the 19x20 patch for the lattice or the full-pel 14x14 window
-    const int smis = load_win(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
+    const int smis = load_win<8>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
     int pmis;
-    if (do_hp) pmis = load_win(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
-    else       pmis = load_win(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
+    if (do_hp) pmis = load_win<8>(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
+    else       pmis = load_win<8>(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
     __syncthreads();
     bool have_hp = false;
     if (do_hp) {
@@ -319,8 +353,8 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
 #pragma unroll
             for (int k = 0; k < 8; k++) acc[k] += (unsigned)abs(s - (int)c[HP_X[k] + HP_Y[k] * LAT]);
         }
-        block_sum_n<8>(acc, S.part);
-        int best_hp = (int)((unsigned)(best * (WIN * WIN)) / yarea);
+        block_sum_n<8>(acc, S.part, phase);
+        int best_hp = (int)udiv_rd((unsigned)(best * (WIN * WIN)), ryarea);
         int hm = -1;
 #pragma unroll
         for (int k = 0; k < 8; k++)
@@ -344,7 +378,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
     if (!have_hp) {
         if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
             __syncthreads();
-            pmis = load_win(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
+            pmis = load_win<8>(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
             __syncthreads();
         }
         for (int t = tid; t < WIN * WIN; t += NT) {
@@ -354,7 +388,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
     }
     // zero-motion reference block -> LDS (needed by the variance test, the veto and the quadrant votes)
     __syncthreads();
-    const int zmis = load_win(S.u.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
+    const int zmis = load_win<32>(S.u.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
     __syncthreads();
     const uint8_t *zref = S.u.ref + zmis;
 
@@ -387,16 +421,16 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
             }
         }
     }
-    block_sum_n<8>(st, S.part);
-    const unsigned luma_tex = ((st[0] + st[1]) / 2) / yarea;
-    const unsigned luma_var = st[3] - (st[2] * st[2]) / yarea;
+    block_sum_n<8>(st, S.part, phase);
+    const unsigned luma_tex = udiv_rd((st[0] + st[1]) / 2, ryarea);
+    const unsigned luma_var = st[3] - udiv_rd(st[2] * st[2], ryarea);
     const unsigned zs1 = st[4];
-    const unsigned zvar = st[5] - (st[4] * st[4]) / yarea;
+    const unsigned zvar = st[5] - udiv_rd(st[4] * st[4], ryarea);
 
     unsigned ws[8];
     win_partial(S.swin + smis, 24, ws[0], ws[1], ws[2], ws[3]);
     win_partial(S.rwin, 16, ws[4], ws[5], ws[6], ws[7]);
-    block_sum_n<8>(ws, S.part);
+    block_sum_n<8>(ws, S.part, phase);
     const int src_tex = (int)(((ws[0] + ws[1]) / 2) / (WIN * WIN));
     const int src_avg = (int)(ws[2] / (WIN * WIN));
     const int src_var = (int)(ws[3] - (ws[2] * ws[2]) / (WIN * WIN));
@@ -439,17 +473,18 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
                 }
             }
         }
-        block_sum_n<8>(cs, S.part);
+        block_sum_n<8>(cs, S.part, phase);
         const unsigned carea = (unsigned)(cbw * cbh);
-        const unsigned vsu = cs[1] - (cs[0] * cs[0]) / carea, vsv = cs[3] - (cs[2] * cs[2]) / carea;
-        const unsigned vru = cs[5] - (cs[4] * cs[4]) / carea, vrv = cs[7] - (cs[6] * cs[6]) / carea;
+        const double rcarea = 1.0 / (double)carea;
+        const unsigned vsu = cs[1] - udiv_rd(cs[0] * cs[0], rcarea), vsv = cs[3] - udiv_rd(cs[2] * cs[2], rcarea);
+        const unsigned vru = cs[5] - udiv_rd(cs[4] * cs[4], rcarea), vrv = cs[7] - udiv_rd(cs[6] * cs[6], rcarea);
         const unsigned cvs = vsu > vsv ? vsu : vsv, cvr = vru > vrv ? vru : vrv;
         if (cvr > 4 * cvs) want_intra = true;
     }
 
     if (want_intra) {
         // representability veto + the four quadrant votes in one pass, one 9-value reduction
-        const int mean = (int)zs1 / (bw * bh);
+        const int mean = (int)udiv_rd(zs1, ryarea);
         const int qw = bw / 2, qh = bh / 2;
         unsigned qv[9];                 // [0] bad count, [1+2q] good, [2+2q] evil
 #pragma unroll
@@ -485,7 +520,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
                 }
             }
         }
-        block_sum_n<9>(qv, S.part);
+        block_sum_n<9>(qv, S.part, phase);
         if (!qv[0]) {
             int submask = 0xF;
             if (src_tex > 1) {
