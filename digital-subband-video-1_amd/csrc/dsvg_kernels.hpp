@@ -28,7 +28,8 @@ struct HmeArgs {
 int  sbt_tail_supported(const SbtGeo &g);
 void sbt_set_func_attributes();
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr, int with_tail = 1, int fused = 0);
-void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1);
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1,
+                    int insym = 0);
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
 // k_hzcc.hip
 void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf = nullptr, double samples = 0,

@@ -380,7 +380,7 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
 
 // enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
-static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0)
+static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0)
 {
     const JobDev *jd = c->jobs_d + d0;
     launch_sbt_tail(c->st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
@@ -389,8 +389,8 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0)
         launch_inv_sbt(c->st, jd, nI, c->G, 1, 2, 0, &c->prof, 0);
     }
     if (n > nI) {
-        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0);
-        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0);
+        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, insym);
+        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, insym);
     }
     launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
     return DSVG_OK;
@@ -468,7 +468,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         }
         launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
         launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, nI);
-        OPCHK(enqueue_recon(c, nI, njobs, d0));
+        OPCHK(enqueue_recon(c, nI, njobs, d0, 1));      // P pictures: straight from the symbol planes
     }
     {   // completion marker of this call; fetch waits on it from its own stream
         const int e = (int)(call % (long)c->ev_coded.size());

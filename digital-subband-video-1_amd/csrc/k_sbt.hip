@@ -242,12 +242,11 @@ static __device__ __forceinline__ void haar_fwd_patch_q(const int (&in)[N][N], i
             hl[i] = q_coef<HZL>(qq, rc, vhl, shl[i]);
             hh[i] = q_coef<HZL>(qq, rc, vhh, shh[i]);
         }
+        // only the symbols leave the chip: the inverse transform (k_inv_haar_tile<.,0,SYM>) dequantises them again
+        (void)lh; (void)hl; (void)hh; (void)coef; (void)W;
         if (rowok) {
-            store_row<M>(coef + (size_t)cy * W + wo + cx0, lh, nR);
             store_sym_row<M>(q.sym + L.base0 + cy * L.sw + cx0, slh, nR);     // scan position = base + cy * sw + cx
             if (hasB) {
-                store_row<M>(coef + (size_t)(ho + cy) * W + cx0, hl, nC);
-                store_row<M>(coef + (size_t)(ho + cy) * W + wo + cx0, hh, nR);
                 store_sym_row<M>(q.sym + L.base1 + cy * L.sw + cx0, shl, nC);
                 store_sym_row<M>(q.sym + L.base2 + cy * L.sw + cx0, shh, nR);
             }
@@ -573,32 +572,93 @@ static __device__ __forceinline__ LvlGeo mk_lvl(int W, int H, int lvl, int hqp, 
     return L;
 }
 
+// Where the three detail bands of one level come from:
+//   Det<false,.>: the int32 coefficient plane (I pictures, the decoder, operator-level calls);
+//   Det<true,HZL>: the scan-order SYMBOL plane the fused forward transform left behind (P pictures of the
+//                  encoder) -- dequantised here (hzcc.c:121-128,221-224), so the dequantised coefficients
+//                  never exist in HBM.  The value of a cell two scan regions share is the later region's
+//                  dequantised symbol, which is the region of the band the cell physically sits in.
+template <bool SYM, int HZL> struct Det;
+template <int HZL> struct Det<false, HZL> {
+    const int32_t *coef; int W, wo, ho;
+    __device__ __forceinline__ int lh(int cx, int cy) const { return coef[(size_t)cy * W + wo + cx]; }
+    __device__ __forceinline__ int hl(int cx, int cy) const { return coef[(size_t)(ho + cy) * W + cx]; }
+    __device__ __forceinline__ void get3(int cx, int cy, bool hasR, bool hasB, int &LH, int &HL, int &HH) const
+    {
+        LH = hasR ? coef[(size_t)cy * W + wo + cx] : 0;
+        HL = hasB ? coef[(size_t)(ho + cy) * W + cx] : 0;
+        HH = (hasR && hasB) ? coef[(size_t)(ho + cy) * W + wo + cx] : 0;
+    }
+};
+template <int HZL> struct Det<true, HZL> {
+    const int16_t *sym; const uint8_t *stable; int nbh; QLevel L;
+    __device__ __forceinline__ int cls(int cx, int cy) const
+    {
+        const int f = stable[((cy * L.dby) >> 14) * nbh + ((cx * L.dbx) >> 14)];
+        return HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0));
+    }
+    __device__ __forceinline__ int dq(int v, int k) const
+    {
+        if (HZL == 2) return (int)((unsigned)v << (k ? L.sh1 : L.sh0));
+        const int q = max(L.qp >> k, HZ_MINQ);
+        const int m = ((v < 0 ? -v : v) * (q << 1) + q) >> 1;
+        return v ? (v < 0 ? -m : m) : 0;
+    }
+    __device__ __forceinline__ int lh(int cx, int cy) const { return dq(sym[L.base0 + cy * L.sw + cx], cls(cx, cy)); }
+    __device__ __forceinline__ int hl(int cx, int cy) const { return dq(sym[L.base1 + cy * L.sw + cx], cls(cx, cy)); }
+    __device__ __forceinline__ void get3(int cx, int cy, bool hasR, bool hasB, int &LH, int &HL, int &HH) const
+    {
+        const int k = cls(cx, cy), o = cy * L.sw + cx;
+        LH = hasR ? dq(sym[L.base0 + o], k) : 0;
+        HL = hasB ? dq(sym[L.base1 + o], k) : 0;
+        HH = (hasR && hasB) ? dq(sym[L.base2 + o], k) : 0;
+    }
+};
+template <bool SYM, int HZL>
+static __device__ __forceinline__ Det<SYM, HZL> mk_det(const JobDev &jb, int c, const int32_t *coef, int W, const LvlGeo &L)
+{
+    Det<SYM, HZL> D;
+    if constexpr (SYM) {
+        const HzPlane &hp = jb.hz[c];
+        D.sym = jb.sym + jb.nz_off[c]; D.stable = jb.stable; D.nbh = hp.nbh; D.L = q_level<HZL>(hp);
+    } else {
+        D.coef = coef; D.W = W; D.wo = L.wo; D.ho = L.ho;
+    }
+    return D;
+}
+
+// the low-pass nudges of a complete cell (sbt.c:463-527)
+// NOTE (reference quirk): for an even region the last complete cell still passes the inX/inY test and its
+// "next LL" is read ACROSS the band boundary: column wo of the same row (= LH[cy][0]) / row ho of the same
+// column (= HL[0][cx]) of the coefficient plane.
+template <typename DET>
+static __device__ __forceinline__ void inv_nudge(const int *pA, int astride, int cx, int cy, const LvlGeo &L, const DET &D,
+                                                 int LL, int &LH, int &HL)
+{
+    const int x = 2 * cx, y = 2 * cy;
+    if (x > 0 && x < L.wfull - 1) {
+        int lp = pA[-1], ln = (cx + 1 < L.wo) ? pA[1] : D.lh(0, cy);
+        if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
+        LH = d_nudge(LL, lp, ln, LH, L.hqp);
+    }
+    if (y > 0 && y < L.hfull - 1) {
+        int lp = pA[-astride], ln = (cy + 1 < L.ho) ? pA[astride] : D.hl(cx, 0);
+        if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
+        HL = d_nudge(LL, lp, ln, HL, L.hqp);
+    }
+}
+
 // inverse of one cell (cx,cy); A = LDS array of this level's LL values, pA -> this cell's LL
-template <bool FILT>
+template <bool FILT, typename DET>
 static __device__ __forceinline__ void inv_cell(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
-                                                const int32_t *__restrict__ coef, int W, int (&o)[4])
+                                                const DET &D, int (&o)[4])
 {
     const int x = 2 * cx, y = 2 * cy;
     const bool hasR = x + 1 < L.ws, hasB = y + 1 < L.hs;
     const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
-    int LH = hasR ? coef[(size_t)cy * W + L.wo + cx] : 0;
-    int HL = hasB ? coef[(size_t)(L.ho + cy) * W + cx] : 0;
-    const int HH = (hasR && hasB) ? coef[(size_t)(L.ho + cy) * W + L.wo + cx] : 0;
-    if (FILT && hasR && hasB) {
-        // NOTE (reference quirk, sbt.c:463-527): for an even region the last complete cell still passes
-        // the inX/inY test and its "next LL" is read ACROSS the band boundary: column wo of the same row
-        // (= LH[cy][0]) / row ho of the same column (= HL[0][cx]) of the coefficient plane.
-        if (x > 0 && x < L.wfull - 1) {
-            int lp = pA[-1], ln = (cx + 1 < L.wo) ? pA[1] : coef[(size_t)cy * W + L.wo];
-            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
-            LH = d_nudge(LL, lp, ln, LH, L.hqp);
-        }
-        if (y > 0 && y < L.hfull - 1) {
-            int lp = pA[-astride], ln = (cy + 1 < L.ho) ? pA[astride] : coef[(size_t)L.ho * W + cx];
-            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
-            HL = d_nudge(LL, lp, ln, HL, L.hqp);
-        }
-    }
+    int LH, HL, HH;
+    D.get3(cx, cy, hasR, hasB, LH, HL, HH);
+    if (FILT && hasR && hasB) inv_nudge(pA, astride, cx, cy, L, D, LL, LH, HL);
     o[0] = (LL + LH + HL + HH) / 4;
     o[1] = (LL - LH + HL - HH) / 4;
     o[2] = (LL + LH - HL - HH) / 4;
@@ -606,24 +666,12 @@ static __device__ __forceinline__ void inv_cell(const int *pA, int astride, int 
 }
 
 // same as inv_cell for a COMPLETE cell whose three details were already fetched (vector loads)
-template <bool FILT>
+template <bool FILT, typename DET>
 static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
-                                                     const int32_t *__restrict__ coef, int W, int LH, int HL, int HH, int (&o)[4])
+                                                     const DET &D, int LH, int HL, int HH, int (&o)[4])
 {
-    const int x = 2 * cx, y = 2 * cy;
     const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
-    if (FILT) {
-        if (x > 0 && x < L.wfull - 1) {
-            int lp = pA[-1], ln = (cx + 1 < L.wo) ? pA[1] : coef[(size_t)cy * W + L.wo];
-            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
-            LH = d_nudge(LL, lp, ln, LH, L.hqp);
-        }
-        if (y > 0 && y < L.hfull - 1) {
-            int lp = pA[-astride], ln = (cy + 1 < L.ho) ? pA[astride] : coef[(size_t)L.ho * W + cx];
-            if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
-            HL = d_nudge(LL, lp, ln, HL, L.hqp);
-        }
-    }
+    if (FILT) inv_nudge(pA, astride, cx, cy, L, D, LL, LH, HL);
     o[0] = (LL + LH + HL + HH) / 4;
     o[1] = (LL - LH + HL - HH) / 4;
     o[2] = (LL + LH - HL - HH) / 4;
@@ -642,9 +690,10 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
 // MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
 // whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
 // other two modes).  The tile is IT_TX x IT_TY cells of the mode's top level.
-template <bool FILT, int MODE>
+template <bool FILT, int MODE, bool SYM>
 __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
+    static_assert(!SYM || MODE == 0, "symbol-plane input is the encoder's P-picture path");
     constexpr bool TO_PIX = (MODE == 0);
     constexpr int TOP = (MODE == 2) ? 5 : 3;
     __shared__ int A3[A3H * A3W];
@@ -669,12 +718,13 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     __syncthreads();
     {   // level TOP: cells I0-1 .. I0+TX (halo 1)
         const LvlGeo L = mk_lvl(W, H, TOP, jb.hqp[TOP], true);
+        const auto D = mk_det<SYM, 0>(jb, c, coef, W, L);
         for (int i = tid; i < (IT_TY + 2) * (IT_TX + 2); i += 256) {
             const int ly = i / (IT_TX + 2), lx = i - ly * (IT_TX + 2);
             const int cx = I0 - 1 + lx, cy = J0 - 1 + ly;
             if (cx < 0 || cy < 0 || cx >= L.wo || cy >= L.ho) continue;
             int o[4];
-            inv_cell<FILT>(A3 + (ly + 1) * A3W + (lx + 1), A3W, cx, cy, L, coef, W, o);
+            inv_cell<FILT>(A3 + (ly + 1) * A3W + (lx + 1), A3W, cx, cy, L, D, o);
             int *d = A2 + (2 * ly) * A2W + 2 * lx;
             d[0] = o[0]; d[1] = o[1]; d[A2W] = o[2]; d[A2W + 1] = o[3];
         }
@@ -682,12 +732,13 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     __syncthreads();
     {   // level TOP-1: cells 2*I0-1 .. 2*I0+2*TX (halo 1)
         const LvlGeo L = mk_lvl(W, H, TOP - 1, jb.hqp[TOP - 1], true);
+        const auto D = mk_det<SYM, 1>(jb, c, coef, W, L);
         for (int i = tid; i < (2 * IT_TY + 2) * (2 * IT_TX + 2); i += 256) {
             const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
             const int cx = 2 * I0 - 1 + lx, cy = 2 * J0 - 1 + ly;
             if (cx < 0 || cy < 0 || cx >= L.wo || cy >= L.ho) continue;
             int o[4];
-            inv_cell<FILT>(A2 + (ly + 1) * A2W + (lx + 1), A2W, cx, cy, L, coef, W, o);
+            inv_cell<FILT>(A2 + (ly + 1) * A2W + (lx + 1), A2W, cx, cy, L, D, o);
             int *d = A1 + (2 * ly) * A1W + 2 * lx;
             d[0] = o[0]; d[1] = o[1]; d[A1W] = o[2]; d[A1W + 1] = o[3];
         }
@@ -707,7 +758,10 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
 
     // level 1 + sbc2int (+ prediction add) : each work item = 4 adjacent cells = 8 px x 2 rows
     const LvlGeo L = mk_lvl(W, H, 1, jb.hqp[1], !isP);        // LVL_TEST: P level 1 unscaled
-    const bool vec_ok = (((W | L.wo) & 3) == 0) && ((g.coff & 3) == 0) && ((((uintptr_t)jb.coef) & 15) == 0);
+    const auto D = mk_det<SYM, 2>(jb, c, coef, W, L);
+    bool vec_ok;
+    if constexpr (SYM) vec_ok = ((D.L.sw | D.L.base0 | D.L.base1 | D.L.base2) & 3) == 0;
+    else vec_ok = (((W | L.wo) & 3) == 0) && ((g.coff & 3) == 0) && ((((uintptr_t)jb.coef) & 15) == 0);
     uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
     const uint8_t *pred = (jb.ref != nullptr) ? jb.pred + g.poff : nullptr;
     for (int it = tid; it < (4 * IT_TY) * IT_TX; it += 256) {
@@ -716,16 +770,42 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         if (cy >= L.ho) continue;
         int r0[8], r1[8];
         const int cx0 = 4 * I0 + 4 * gx;
-        // fast path: four complete cells, details fetched as three 16-byte loads
+        // fast path: four complete cells, details fetched as three vector loads
         if (vec_ok && cx0 + 3 < (L.ws >> 1) && 2 * cy + 1 < L.hs) {
-            const int4 lh = *reinterpret_cast<const int4 *>(coef + (size_t)cy * W + L.wo + cx0);
-            const int4 hl = *reinterpret_cast<const int4 *>(coef + (size_t)(L.ho + cy) * W + cx0);
-            const int4 hh = *reinterpret_cast<const int4 *>(coef + (size_t)(L.ho + cy) * W + L.wo + cx0);
-            const int lhv[4] = {lh.x, lh.y, lh.z, lh.w}, hlv[4] = {hl.x, hl.y, hl.z, hl.w}, hhv[4] = {hh.x, hh.y, hh.z, hh.w};
+            int lhv[4], hlv[4], hhv[4];
+            if constexpr (SYM) {
+                const int o = cy * D.L.sw + cx0;
+                const uint2 a = *reinterpret_cast<const uint2 *>(D.sym + D.L.base0 + o);
+                const uint2 b = *reinterpret_cast<const uint2 *>(D.sym + D.L.base1 + o);
+                const uint2 d = *reinterpret_cast<const uint2 *>(D.sym + D.L.base2 + o);
+                int k[4];
+                const int by = ((cy * D.L.dby) >> 14) * D.nbh;
+                const int bx0 = (cx0 * D.L.dbx) >> 14, bx3 = ((cx0 + 3) * D.L.dbx) >> 14;
+                k[0] = D.stable[by + bx0] != 0;
+                if (bx0 == bx3) k[1] = k[2] = k[3] = k[0];
+                else {
+                    k[1] = D.stable[by + (((cx0 + 1) * D.L.dbx) >> 14)] != 0;
+                    k[2] = D.stable[by + (((cx0 + 2) * D.L.dbx) >> 14)] != 0;
+                    k[3] = D.stable[by + bx3] != 0;
+                }
+                lhv[0] = D.dq((int16_t)(a.x & 0xffff), k[0]); lhv[1] = D.dq((int)a.x >> 16, k[1]);
+                lhv[2] = D.dq((int16_t)(a.y & 0xffff), k[2]); lhv[3] = D.dq((int)a.y >> 16, k[3]);
+                hlv[0] = D.dq((int16_t)(b.x & 0xffff), k[0]); hlv[1] = D.dq((int)b.x >> 16, k[1]);
+                hlv[2] = D.dq((int16_t)(b.y & 0xffff), k[2]); hlv[3] = D.dq((int)b.y >> 16, k[3]);
+                hhv[0] = D.dq((int16_t)(d.x & 0xffff), k[0]); hhv[1] = D.dq((int)d.x >> 16, k[1]);
+                hhv[2] = D.dq((int16_t)(d.y & 0xffff), k[2]); hhv[3] = D.dq((int)d.y >> 16, k[3]);
+            } else {
+                const int4 lh = *reinterpret_cast<const int4 *>(coef + (size_t)cy * W + L.wo + cx0);
+                const int4 hl = *reinterpret_cast<const int4 *>(coef + (size_t)(L.ho + cy) * W + cx0);
+                const int4 hh = *reinterpret_cast<const int4 *>(coef + (size_t)(L.ho + cy) * W + L.wo + cx0);
+                lhv[0] = lh.x; lhv[1] = lh.y; lhv[2] = lh.z; lhv[3] = lh.w;
+                hlv[0] = hl.x; hlv[1] = hl.y; hlv[2] = hl.z; hlv[3] = hl.w;
+                hhv[0] = hh.x; hhv[1] = hh.y; hhv[2] = hh.z; hhv[3] = hh.w;
+            }
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int o[4];
-                inv_cell_vals<FILT>(A1 + (ly + 2) * A1W + (4 * gx + k + 2), A1W, cx0 + k, cy, L, coef, W, lhv[k], hlv[k], hhv[k], o);
+                inv_cell_vals<FILT>(A1 + (ly + 2) * A1W + (4 * gx + k + 2), A1W, cx0 + k, cy, L, D, lhv[k], hlv[k], hhv[k], o);
                 r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
                 r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
             }
@@ -734,7 +814,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
             for (int k = 0; k < 4; k++) {
                 const int lx = 4 * gx + k, cx = 4 * I0 + lx;
                 int o[4] = {0, 0, 0, 0};
-                if (cx < L.wo) inv_cell<FILT>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, coef, W, o);
+                if (cx < L.wo) inv_cell<FILT>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, D, o);
                 r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
                 r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
             }
@@ -871,7 +951,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
     if (isP) {
-        PB(KID_FWD_HAAR_PIX, smp * 5.0);       // 1 B/sample in, 4 B/sample out (details + LL3)
+        PB(KID_FWD_HAAR_PIX, smp * (fused ? 3.0 : 5.0));   // 1 B/sample in, 4 B/sample out (details + LL3); fused: 2 B symbols
         if (fused) hipLaunchKernelGGL((k_fwd_haar_pix<true>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         else       hipLaunchKernelGGL((k_fwd_haar_pix<false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
@@ -909,7 +989,8 @@ void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
     PE();
 }
 
-void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail)
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail,
+                    int insym)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
@@ -923,20 +1004,26 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     {   // levels 5..4 (LL5 -> LL3) for every picture type
         const dim3 mg((g.w5 + IT_TX - 1) / IT_TX, (g.h5 + IT_TY - 1) / IT_TY, nz);
         PB(KID_INV_TAIL, s3 * 8.0);
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2>), mg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 2>), mg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
     }
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
     if (isP) {
-        PB(KID_INV_HAAR_TILE, smp * 6.0);      // 4 B/sample coefficients + 1 B prediction in, 1 B out
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        // 4 B/sample coefficients (2 B/sample symbols when insym) + 1 B prediction in, 1 B out
+        PB(KID_INV_HAAR_TILE, smp * (insym ? 4.0 : 6.0));
+        if (insym) {
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        } else {
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        }
         PE();
     } else {
         PB(KID_INV_HAAR_TILE, smp * 2.0);
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
         PB(KID_INV_B4T, smp * 5.0);
