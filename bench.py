@@ -71,7 +71,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--gops", type=int, default=16, help="closed GOPs per GPU per step")
+    ap.add_argument("--gops", type=int, default=32, help="closed GOPs per GPU per step")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
     ap.add_argument("--cpu-gops", type=int, default=4, help="GOPs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events")
@@ -152,6 +152,16 @@ def main():
                  "avg_launch_us": round(1000.0 * ms / max(nl, 1), 2),
                  "alg_bytes_per_launch": round(by / max(nl, 1)),
                  "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]}}
+        # HBM traffic of that kernel: PMC counters cannot be read from inside this process, so the figure comes
+        # from the committed rocprofv3 --pmc passes over this same command (tools/collect_profiles.sh ->
+        # tools/make_pmc_traffic.py -> profiles/pmc_traffic.json), scaled to this run's GOPs per step.
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            T = json.load(open(tp))
+            e = T.get("kernels", {}).get(prof_kernel)
+            if e:
+                kinfo["traffic"] = round(e["hbm_bytes_per_launch"] * args.gops / T["gops"])
+                kinfo["traffic_source"] = T.get("source", "profiles/pmc_traffic.json")
 
     tmax = dt
     if world > 1:

@@ -264,9 +264,10 @@ void Prof::reset()
 }
 const char *kid_name(int kid)
 {
-    static const char *n[KID_N] = {"k_unpack", "k_extend", "k_ds2x", "k_luma_sum", "k_hme_level", "k_hme_level0", "k_hme_detail",
-                                   "k_mc", "k_fwd_haar_pix", "k_fwd_b4t", "k_fwd_haar_s1", "k_fwd_tail",
-                                   "k_hz_quant", "k_hz_collect", "k_hz_scan", "k_hz_emit", "k_hz_scatter",
-                                   "k_inv_tail", "k_inv_haar_tile", "k_inv_b4t"};
+    static const char *n[KID_N] = {
+#define X(id, name) name,
+        DSVG_KERNEL_IDS(X)
+#undef X
+    };
     return (kid >= 0 && kid < KID_N) ? n[kid] : "?";
 }

@@ -51,13 +51,27 @@ struct Slab {
 
 // per-kernel timing with HIP events on the pipeline stream (bench.py roofline leg).  Only kernels whose
 // bit is set in `mask` are bracketed, so the timed region pays for the events of one kernel only.
+// One id per kernel SYMBOL, named exactly as rocprofv3 prints it (up to the parameter list), so a bench.py
+// roofline entry can be held against the committed --kernel-trace --stats summary line by line.
+#define DSVG_KERNEL_IDS(X) \
+    X(KID_UNPACK, "k_unpack") X(KID_EXTEND, "k_extend") X(KID_DS2X, "k_ds2x") X(KID_LUMA_SUM, "k_luma_sum") \
+    X(KID_HME_LEVEL, "void k_hme_level<false>") X(KID_HME_LEVEL0, "void k_hme_level<true>") X(KID_HME_DETAIL, "k_hme_detail") \
+    X(KID_MC, "k_mc") \
+    X(KID_FWD_HAAR_PIX, "void k_fwd_haar_pix<false>") X(KID_FWD_HAAR_PIX_Q, "void k_fwd_haar_pix<true>") \
+    X(KID_FWD_B4T, "k_fwd_b4t") X(KID_FWD_HAAR_MID2, "void k_fwd_haar_mid<2>") X(KID_FWD_HAAR_MID4, "void k_fwd_haar_mid<4>") \
+    X(KID_FWD_TAIL, "k_fwd_tail") \
+    X(KID_HZ_QUANT, "void k_hz_quant<false>") X(KID_HZ_COLLECT, "void k_hz_quant<true>") X(KID_HZ_SCAN, "k_hz_scan") \
+    X(KID_HZ_EMIT, "k_hz_emit") X(KID_HZ_SCATTER, "k_hz_scatter") \
+    X(KID_INV_TAIL, "k_inv_tail") \
+    X(KID_INV_TILE_54_F, "void k_inv_haar_tile<true, 2, false>") X(KID_INV_TILE_54, "void k_inv_haar_tile<false, 2, false>") \
+    X(KID_INV_TILE_PIX_SYM_F, "void k_inv_haar_tile<true, 0, true>") X(KID_INV_TILE_PIX_SYM, "void k_inv_haar_tile<false, 0, true>") \
+    X(KID_INV_TILE_PIX_F, "void k_inv_haar_tile<true, 0, false>") X(KID_INV_TILE_PIX, "void k_inv_haar_tile<false, 0, false>") \
+    X(KID_INV_TILE_S1_F, "void k_inv_haar_tile<true, 1, false>") X(KID_INV_TILE_S1, "void k_inv_haar_tile<false, 1, false>") \
+    X(KID_INV_B4T, "k_inv_b4t")
 enum {
-    KID_UNPACK = 0, KID_EXTEND, KID_DS2X, KID_LUMA_SUM,
-    KID_HME_LEVEL, KID_HME_LEVEL0, KID_HME_DETAIL,
-    KID_MC,
-    KID_FWD_HAAR_PIX, KID_FWD_B4T, KID_FWD_HAAR_S1, KID_FWD_TAIL,
-    KID_HZ_QUANT, KID_HZ_COLLECT, KID_HZ_SCAN, KID_HZ_EMIT, KID_HZ_SCATTER,
-    KID_INV_TAIL, KID_INV_HAAR_TILE, KID_INV_B4T,
+#define X(id, name) id,
+    DSVG_KERNEL_IDS(X)
+#undef X
     KID_N
 };
 const char *kid_name(int kid);

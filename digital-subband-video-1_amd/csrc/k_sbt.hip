@@ -951,7 +951,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
     if (isP) {
-        PB(KID_FWD_HAAR_PIX, smp * (fused ? 3.0 : 5.0));   // 1 B/sample in, 4 B/sample out (details + LL3); fused: 2 B symbols
+        PB(fused ? KID_FWD_HAAR_PIX_Q : KID_FWD_HAAR_PIX, smp * (fused ? 3.0 : 5.0));   // 1 B/sample in, 4 B/sample out (details + LL3); fused: 2 B symbols
         if (fused) hipLaunchKernelGGL((k_fwd_haar_pix<true>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         else       hipLaunchKernelGGL((k_fwd_haar_pix<false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
@@ -959,12 +959,12 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         PB(KID_FWD_B4T, smp * 5.0);
         hipLaunchKernelGGL(k_fwd_b4t, grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
-        PB(KID_FWD_HAAR_S1, smp * 2.0);        // LL1 (1/4) in, levels 2..3 out
+        PB(KID_FWD_HAAR_MID2, smp * 2.0);        // LL1 (1/4) in, levels 2..3 out
         hipLaunchKernelGGL((k_fwd_haar_mid<2>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
         PE();
     }
     // levels 4..5 (LL3 -> LL5) for every picture type
-    PB(KID_FWD_HAAR_S1, s3 * 8.0);
+    PB(KID_FWD_HAAR_MID4, s3 * 8.0);
     hipLaunchKernelGGL((k_fwd_haar_mid<4>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
     PE();
     if (with_tail) {
@@ -1003,7 +1003,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     }
     {   // levels 5..4 (LL5 -> LL3) for every picture type
         const dim3 mg((g.w5 + IT_TX - 1) / IT_TX, (g.h5 + IT_TY - 1) / IT_TY, nz);
-        PB(KID_INV_TAIL, s3 * 8.0);
+        PB(filt ? KID_INV_TILE_54_F : KID_INV_TILE_54, s3 * 8.0);
         if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl);
         else      hipLaunchKernelGGL((k_inv_haar_tile<false, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
@@ -1011,7 +1011,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
     if (isP) {
         // 4 B/sample coefficients (2 B/sample symbols when insym) + 1 B prediction in, 1 B out
-        PB(KID_INV_HAAR_TILE, smp * (insym ? 4.0 : 6.0));
+        PB(insym ? (filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM) : (filt ? KID_INV_TILE_PIX_F : KID_INV_TILE_PIX), smp * (insym ? 4.0 : 6.0));
         if (insym) {
             if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
             else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
@@ -1021,7 +1021,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         }
         PE();
     } else {
-        PB(KID_INV_HAAR_TILE, smp * 2.0);
+        PB(filt ? KID_INV_TILE_S1_F : KID_INV_TILE_S1, smp * 2.0);
         if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();

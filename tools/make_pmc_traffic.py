@@ -1,0 +1,25 @@
+#!/usr/bin/env python3
+"""profiles/pmc_traffic.json from the per-kernel PMC summary of tools/collect_profiles.sh.
+
+HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KiB, and on gfx950
+FETCH_SIZE tallies the 128-byte requests of a wide coalesced read at 64 bytes (MI355X_MICROARCH.md, HBM), so
+the read side is doubled.  That calibration is for 16 B/lane streams; narrower accesses may be over-corrected,
+which the file says in `source`.
+usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json>"""
+import csv
+import json
+import sys
+
+rows = list(csv.DictReader(open(sys.argv[1])))
+out = {"gops": int(sys.argv[2]),
+       "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --gops %s --steps 1`; "
+                 "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, read side doubled per the gfx950 correction "
+                 "(calibrated for 16 B/lane streams)" % sys.argv[2],
+       "kernels": {}}
+for r in rows:
+    f = float(r.get("FETCH_SIZE_per_launch", 0) or 0)
+    w = float(r.get("WRITE_SIZE_per_launch", 0) or 0)
+    out["kernels"][r["kernel"]] = {"launches": int(r["launches"]), "fetch_kib_per_launch": f, "write_kib_per_launch": w,
+                                   "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
+json.dump(out, open(sys.argv[3], "w"), indent=1)
+print("wrote", sys.argv[3], len(out["kernels"]), "kernels")

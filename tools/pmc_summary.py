@@ -14,7 +14,8 @@ for pat in sys.argv[1:]:
             acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
             nl[k].add(r["Dispatch_Id"])
 names = sorted({c for v in acc.values() for c in v})
-print("kernel,launches," + ",".join(n + "_per_launch" for n in names))
+w = csv.writer(sys.stdout)
+w.writerow(["kernel", "launches"] + [n + "_per_launch" for n in names])
 for k in sorted(acc, key=lambda k: -sum(acc[k].values())):
     n = max(1, len(nl[k]))
-    print(f"{k[:60]},{n}," + ",".join(f"{acc[k].get(c, 0.0) / n:.4g}" for c in names))
+    w.writerow([k[:60], n] + [f"{acc[k].get(c, 0.0) / n:.4g}" for c in names])
