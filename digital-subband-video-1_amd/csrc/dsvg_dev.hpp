@@ -129,6 +129,17 @@ static __device__ __forceinline__ int d_sat8(int v) { return v < 0 ? 0 : (v > 25
 static __device__ __forceinline__ int d_ll_down(int x) { return x * 4 / 5; }
 static __device__ __forceinline__ int d_ll_up(int x) { return x * 5 / 4; }
 
+// XCD-aware work mapping: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so
+// workgroup `lin` takes the logical item (lin % 8) * ceil(total / 8) + lin / 8 -- every XCD then walks ONE contiguous
+// range of items and neighbouring blocks share their halo lines in the same L2.  Launch 8 * ceil(total / 8)
+// workgroups; the caller drops logical ids >= total.
+static __device__ __forceinline__ int d_xcd_remap(int lin, int total)
+{
+    const int per = (total + 7) >> 3;
+    return (lin & 7) * per + (lin >> 3);
+}
+static inline int xcd_grid(int total) { return 8 * ((total + 7) / 8); }
+
 // ---- HZCC quantiser arithmetic shared by the transform-fused path (k_sbt.hip) and k_hzcc.hip -----------
 #define HZ_MINQ 16
 static __device__ __forceinline__ int hzq_lo(int v, int q)            // quant hzcc.c:94-112

@@ -19,11 +19,15 @@
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
-__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub)
+__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub, int njobs)
 {
     __shared__ __align__(16) uint8_t win[WROWS * WPITCH];
     __shared__ int s_sum[5];
-    const int blk = blockIdx.x, c = blockIdx.y, job = blockIdx.z;
+    // logical order: job, plane, block -- one XCD's L2 sees whole neighbouring block rows of one plane
+    const int nblk = G.nbh * G.nbv;
+    const int item = d_xcd_remap(blockIdx.x, nblk * 3 * njobs);
+    if (item >= nblk * 3 * njobs) return;
+    const int job = item / (3 * nblk), c = (item - job * 3 * nblk) / nblk, blk = item - (job * 3 + c) * nblk;
     const JobDev &jb = jobs[job];
     const int tid = threadIdx.x;
     const int sh = c ? G.hs : 0, sv = c ? G.vs : 0;
@@ -187,6 +191,6 @@ void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, in
     double smp = 0;
     for (int c = 0; c < 3; c++) smp += (double)G.w[c] * G.h[c];
     if (pf) pf->begin(st, KID_MC, smp * njobs * (do_sub ? 4.0 : 2.0));   // ref + src in, pred + residual out
-    hipLaunchKernelGGL(k_mc, dim3(G.nbh * G.nbv, 3, njobs), dim3(MC_NT), 0, st, jobs, G, do_sub);
+    hipLaunchKernelGGL(k_mc, dim3(xcd_grid(G.nbh * G.nbv * 3 * njobs)), dim3(MC_NT), 0, st, jobs, G, do_sub, njobs);
     if (pf) pf->end(st);
 }

@@ -159,15 +159,17 @@ static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, unsi
 }
 
 template <bool LEVEL0>
-__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level)
+__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs)
 {
     __shared__ HmeShared S;
     const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;             // column group (4 px) / row group
-    const int pair = blockIdx.y;
     const int step = 1 << level;
-    const int nvx = (A.nxb + step - 1) / step;
-    const int vi = blockIdx.x % nvx, vj = blockIdx.x / nvx;
+    const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
+    const int item = d_xcd_remap(blockIdx.x, nvx * nvy * npairs);
+    if (item >= nvx * nvy * npairs) return;
+    const int pair = item / (nvx * nvy), vb = item - pair * (nvx * nvy);
+    const int vi = vb % nvx, vj = vb / nvx;
     const int i = vi * step, j = vj * step;
     const FrameLayout &L = A.L[level];
     const int fw = L.w[0], fh = L.h[0], stride = L.stride[0];
@@ -577,8 +579,8 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
         const double px = 2.0 * npairs * (double)A.L[level].w[0] * A.L[level].h[0];     // src + ref luma once
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
-        if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(nvx * nvy, npairs), dim3(NT), 0, st, A, level);
-        else           hipLaunchKernelGGL((k_hme_level<true>), dim3(nvx * nvy, npairs), dim3(NT), 0, st, A, level);
+        if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(xcd_grid(nvx * nvy * npairs)), dim3(NT), 0, st, A, level, npairs);
+        else           hipLaunchKernelGGL((k_hme_level<true>), dim3(xcd_grid(nvx * nvy * npairs)), dim3(NT), 0, st, A, level, npairs);
         if (pf) pf->end(st);
     }
     if (pf) pf->begin(st, KID_HME_DETAIL, 0.0);
