@@ -93,6 +93,38 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
     }
 }
 
+// same, 16 bytes per thread-iteration, for planes whose width is a multiple of 16 (every store aligned)
+__global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, FrameLayout L, int first, int nplanes,
+                                                  const int *__restrict__ slot_tab)
+{
+    const int c = blockIdx.y;
+    if (c >= nplanes) return;
+    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
+    if (f < 0) return;
+    const int w = L.w[c], h = L.h[c], s = L.stride[c];
+    uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
+    const int B = DSVG_BORDER;
+    const int n1 = (h + 2 * B) * 8;                   // side borders: 4 + 4 x 16 bytes per row
+    const int wq = w >> 4;
+    const int n2 = 2 * B * wq;                        // top + bottom rows over the interior
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += gridDim.x * 256) {
+        if (i < n1) {
+            const int r = i >> 3, k = i & 7;
+            const int y = r - B;
+            const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+            const unsigned v = p[(long)sy * s + (k < 4 ? 0 : w - 1)] * 0x01010101u;
+            uint8_t *d = p + (long)y * s + (k < 4 ? -B + 16 * k : w + 16 * (k - 4));
+            *reinterpret_cast<uint4 *>(d) = make_uint4(v, v, v, v);
+        } else {
+            const int j = i - n1;
+            const int r = j / wq, x = 16 * (j - r * wq);
+            const int y = r < B ? r - B : h + (r - B);
+            *reinterpret_cast<uint4 *>(p + (long)y * s + x) =
+                *reinterpret_cast<const uint4 *>(p + (long)(r < B ? 0 : h - 1) * s + x);
+        }
+    }
+}
+
 // 2x2 box downsample of the luma plane: (p1+p2+p3+p4+2)>>2 (frame.c:240-261)
 __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab, FrameLayout SL,
                                               uint8_t *__restrict__ dslab, FrameLayout DL, int first,
@@ -170,9 +202,12 @@ void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const Frame
 }
 void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf)
 {
-    const long items = (long)(L.h[0] + 128) * 32 + 32L * L.w[0];
-    if (pf) pf->begin(st, KID_EXTEND, 8.0 * items * n);
-    hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
+    const long items = (long)(L.h[0] + 128) * 32 + 32L * L.w[0];        // dwords of the luma border
+    bool v16 = (L.pitch % 16) == 0;
+    for (int c = 0; c < nplanes; c++) v16 = v16 && (L.w[c] % 16) == 0 && (L.stride[c] % 16) == 0 && (L.off[c] % 16) == 0;
+    if (pf) pf->begin(st, v16 ? KID_EXTEND16 : KID_EXTEND, 8.0 * items * n);
+    if (v16) hipLaunchKernelGGL(k_extend16, dim3(nblk(items / 4, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
+    else     hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
     if (pf) pf->end(st);
 }
 void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf, const int *slot_tab)
