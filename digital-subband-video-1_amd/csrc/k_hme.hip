@@ -36,18 +36,40 @@ static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 
 // stage rows [oy,oy+nh) x cols [ox,ox+nw) of a plane into LDS (pitch P) as ALIGNED dwords; returns the
 // byte shift `mis` such that dst[r*P + mis + k] == plane(ox+k, oy+r).  TPR threads share a row (the window
 // must span <= TPR dwords), NT/TPR rows are in flight per pass.
-template <int TPR>
+template <int TPR, int MAXROWS>
 static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_t *plane, int stride,
                                                int ox, int oy, int nw, int nh)
 {
+    constexpr int RPP = NT / TPR;                       // rows per pass
+    constexpr int NIT = (MAXROWS + RPP - 1) / RPP;
     const uint8_t *g0 = plane + (long)oy * stride + ox;
     const int mis = (int)(((uintptr_t)g0) & 3);
     const int ndw = (mis + nw + 3) >> 2;
-    const int d = threadIdx.x & (TPR - 1);
-    if (d < ndw)
-        for (int r = threadIdx.x / TPR; r < nh; r += NT / TPR)
-            *reinterpret_cast<unsigned *>(dst + r * P + 4 * d) =
-                *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
+    const int d = threadIdx.x & (TPR - 1), rb = threadIdx.x / TPR;
+    if (d < ndw) {
+        // loads are issued in batches of up to 9 before their stores: a memory round trip per batch, not per row
+        constexpr int BATCH = 9;
+#pragma unroll
+        for (int b0 = 0; b0 < NIT; b0 += BATCH) {
+            unsigned v[BATCH];
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                if (b0 + u < NIT) {
+                    const int r = min(rb + (b0 + u) * RPP, nh - 1);
+                    v[u] = *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < BATCH; u++) {
+                if (b0 + u < NIT) {
+                    const int r = rb + (b0 + u) * RPP;
+                    if (r < nh) *reinterpret_cast<unsigned *>(dst + r * P + 4 * d) = v[u];
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
     return mis;
 }
 
@@ -73,10 +95,7 @@ struct HmeShared {
     } u;
     __attribute__((aligned(16))) uint8_t swin[WIN * 24];
     __attribute__((aligned(16))) uint8_t rwin[WIN * 16];
-    unsigned part[2][NW][9];
-    int par[5];
-    int cand[8];
-    int ncand;
+    unsigned part[2][NW][14];
 };
 
 // wave64 sum through DPP (no LDS traffic); the result is wave-uniform (SGPR)
@@ -93,7 +112,7 @@ static __device__ __forceinline__ unsigned wave_sum(unsigned v)
 // sum N values over the workgroup; every thread receives all totals (wave-uniform).  `part` is double
 // buffered by the caller-maintained phase bit, so one barrier per reduction suffices.
 template <int N>
-static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*part)[NW][9], int &phase)
+static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*part)[NW][14], int &phase)
 {
     // step-major over the N independent chains: a DPP read needs two wait states after the write it consumes
 #pragma unroll
@@ -109,7 +128,7 @@ static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*
         v[i] = (unsigned)__builtin_amdgcn_readlane((int)v[i], 0) + (unsigned)__builtin_amdgcn_readlane((int)v[i], 16) +
                (unsigned)__builtin_amdgcn_readlane((int)v[i], 32) + (unsigned)__builtin_amdgcn_readlane((int)v[i], 48);
     if (NW == 1) return;
-    unsigned (*pb)[9] = part[phase];
+    unsigned (*pb)[14] = part[phase];
     phase ^= 1;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
@@ -183,50 +202,52 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     DMV *mf = A.mvf + ((size_t)pair * (A.levels + 1) + level) * A.nblk;
     const DMV *parent = level < A.levels ? A.mvf + ((size_t)pair * (A.levels + 1) + level + 1) * A.nblk : nullptr;
 
-    // this thread's pixels: columns 4cg..4cg+3 of rows rg, rg+NRG, rg+2*NRG, ...
+    // this thread's pixels: columns 4cg..4cg+3 of the nkb ADJACENT rows rg*nkb .. rg*nkb+nkb-1 (adjacent rows let the
+    // +-1 search reuse every reference row for three source rows)
+    const int nkb = (bh + NRG - 1) / NRG;
+    const int r0 = rg * nkb;
+#define ROWOK(k) ((k) < nkb && r0 + (k) < bh)
     const int xcol = 4 * cg;
     const unsigned cmask = xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u));
     unsigned srcw[NK];
 #pragma unroll
     for (int k = 0; k < NK; k++) {
-        const int r = rg + NRG * k;
+        const int r = r0 + k;
         srcw[k] = 0;
-        if (cmask && r < bh) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
-        if (LEVEL0 && r < bh && xcol < ((bw + 3) & ~3)) *reinterpret_cast<unsigned *>(S.src + r * SP + xcol) = srcw[k];
+        if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
+        if (LEVEL0 && ROWOK(k) && xcol < ((bw + 3) & ~3)) *reinterpret_cast<unsigned *>(S.src + r * SP + xcol) = srcw[k];
         srcw[k] &= cmask;
     }
-    // parents (hme.c:452-480): 5 lanes fetch, lane 0 de-duplicates in the reference's order
-    if (tid < 5) {
-        int v = 0;
-        if (parent) {
-            const unsigned pmask = ~(unsigned)((step << 1) - 1);
-            const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
-            const int ox = tid == 1 ? -2 : (tid == 2 ? 2 : 0), oy = tid == 3 ? -2 : (tid == 4 ? 2 : 0);
+    // parents (hme.c:452-480): every lane reads the same five vectors (wave-uniform addresses -> SGPRs) and
+    // de-duplicates them in registers in the reference's order -- no LDS hand-off, no barrier
+    int cand[6] = {0, 0, 0, 0, 0, 0};
+    int n = 1;                                          // cand[0] = the zero vector
+    if (parent) {
+        const unsigned pmask = ~(unsigned)((step << 1) - 1);
+        const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
+        int par[5];
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
             const int x = pi + ox * step, y = pj + oy * step;
-            if (x >= 0 && x < A.nxb && y >= 0 && y < A.nyb) {
-                const DMV pv = parent[x + y * A.nxb];
-                v = (int)(((unsigned)(uint16_t)pv.x) | ((unsigned)(uint16_t)pv.y << 16));
+            par[m] = 0;
+            if (x >= 0 && x < A.nxb && y >= 0 && y < A.nyb)      // DMV starts with int16 x, y: one dword = x | y << 16
+                par[m] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(parent + x + y * A.nxb));
+        }
+#pragma unroll
+        for (int m = 0; m < 5; m++) {
+            const int all = par[m];
+            bool dup = (all == 0);
+#pragma unroll
+            for (int k = 1; k < 6; k++) dup |= (cand[k] == all);   // unused slots hold 0 and all != 0 here
+            if (!dup) {
+#pragma unroll
+                for (int k = 1; k < 6; k++) cand[k] = (k == n) ? all : cand[k];
+                n++;
             }
         }
-        S.par[tid] = v;
     }
-    __syncthreads();
-    if (tid == 0) {
-        int n = 0;
-        S.cand[n++] = 0;
-        for (int m = 0; m < 5; m++) {
-            const int all = S.par[m];
-            if (!all) continue;
-            bool dup = false;
-            for (int k = 0; k < n; k++) dup |= (S.cand[k] == all);
-            if (!dup) S.cand[n++] = all;
-        }
-        S.ncand = n;
-    }
-    __syncthreads();
-    const int n = S.ncand;
     int phase = 0;
-
     // best inherited candidate by SAD, all candidates in one pass, reference pixels straight from HBM/L2
     int pick = n - 1;
     if (n > 1) {
@@ -237,18 +258,28 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
         for (int k = 0; k < 6; k++) {
             acc[k] = 0;
             if (k < n) {
-                const int all = S.cand[k];
+                const int all = cand[k];
                 const int cdx = ((int)(int16_t)(all & 0xffff)) >> level, cdy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
                 if (src_ok && !frame_invalid(fw, fh, bx + cdx, by + cdy, bw, bh)) {
                     validmask |= 1u << k;
-                    if (cmask) {
+                    if (cmask && r0 < bh) {
+                        // the candidate's rows are fetched back to back, then scored
+                        const uint8_t *p0 = rp + (long)(by + cdy + r0) * stride + bx + cdx + xcol;
+                        const unsigned sh = (unsigned)(((uintptr_t)p0) & 3);
+                        const unsigned *pa = reinterpret_cast<const unsigned *>(p0 - sh);
+                        const int sdw = stride >> 2;
+                        unsigned lo[NK], hi[NK];
 #pragma unroll
                         for (int kk = 0; kk < NK; kk++) {
-                            const int r = rg + NRG * kk;
-                            if (r < bh) {
-                                const unsigned rw = ldg_u32_unaligned(rp + (long)(by + cdy + r) * stride + bx + cdx + xcol);
-                                acc[k] = __builtin_amdgcn_sad_u8(srcw[kk], rw & cmask, acc[k]);
-                            }
+                            const long o = (long)min(kk, nkb - 1) * sdw;
+                            lo[kk] = pa[o]; hi[kk] = pa[o + 1];
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int kk = 0; kk < NK; kk++) {
+                            const unsigned rw = __builtin_amdgcn_alignbyte(hi[kk], lo[kk], sh) & cmask;
+                            const unsigned a6 = __builtin_amdgcn_sad_u8(srcw[kk], rw, acc[k]);
+                            acc[k] = ROWOK(kk) ? a6 : acc[k];
                         }
                     }
                 }
@@ -262,41 +293,63 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     }
     int dx, dy;
     {
-        const int all = S.cand[pick];
+        int all = cand[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) all = (pick == k) ? cand[k] : all;
         dx = ((int)(int16_t)(all & 0xffff)) >> level;
         dy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
         dx = d_clamp(dx, -bw - bx, fw - bx);
         dy = d_clamp(dy, -bh - by, fh - by);
     }
-    // 9-point +-1 search around (dx,dy): window (bw+2)x(bh+2) at (bx+dx-1, by+dy-1) staged as aligned dwords
+    // 9-point +-1 search around (dx,dy).  The thread walks reference rows r0-1 .. r0+nkb of the (bw+2)x(bh+2)
+    // window at (bx+dx-1, by+dy-1) straight from global memory (three aligned dwords per row -> the three
+    // horizontal offsets by v_alignbyte); every reference row serves the source rows above, at and below it.
     int best, bestk;
     {
-        const int mis = load_win<32>(S.u.ref, RP, rp, stride, bx + dx - 1, by + dy - 1, bw + 2, bh + 2);
-        __syncthreads();
+        constexpr int FX[9] = {0, 1, -1, 0, 0, -1, 1, -1, 1}, FY[9] = {0, 0, 0, 1, -1, -1, -1, 1, 1};   // = FP_X, FP_Y
         unsigned acc[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) acc[k] = 0;
-        if (cmask) {
+        if (cmask && r0 < bh) {
+            const uint8_t *g0 = rp + (long)(by + dy - 1 + r0) * stride + (bx + dx - 1 + xcol);
+            const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
+            const unsigned *ga = reinterpret_cast<const unsigned *>(g0 - mis);
+            const int sdw = stride >> 2;
+            // all row loads are issued back to back (no branch in between: one memory round trip, not NK+2);
+            // rows past the thread's last reference row re-read that row
+            // two batches of five row loads, each issued back to back (one memory round trip per batch instead of
+            // one per row) -- a single batch of ten would cost two waves of occupancy in registers
+            unsigned v[3][3];                                      // rolling: v[t % 3][ox] = reference row t, offset ox
 #pragma unroll
-            for (int kk = 0; kk < NK; kk++) {
-                const int r = rg + NRG * kk;
-                if (r < bh) {
-                    unsigned v[3][3];           // v[row][ox]: reference dword at window (r+row, ox + 4cg)
+            for (int half = 0; half < 2; half++) {
+                constexpr int HB = (NK + 2) / 2;
+                unsigned d[HB][3];
 #pragma unroll
-                    for (int rr = 0; rr < 3; rr++) {
-                        const unsigned *w = reinterpret_cast<const unsigned *>(S.u.ref + (r + rr) * RP) + cg;
-                        const unsigned d0 = w[0], d1 = w[1], d2 = w[2];
+                for (int u = 0; u < HB; u++) {
+                    const long o = (long)min(half * HB + u, nkb + 1) * sdw;
+                    d[u][0] = ga[o]; d[u][1] = ga[o + 1]; d[u][2] = ga[o + 2];
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // keep the scheduler from sinking loads between the SADs
 #pragma unroll
-                        for (int ox = 0; ox < 3; ox++) {
-                            const int s = mis + ox;
-                            v[rr][ox] = (s < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (unsigned)s)
-                                               : __builtin_amdgcn_alignbyte(d2, d1, (unsigned)(s - 4))) & cmask;
+                for (int u = 0; u < HB; u++) {
+                    const int t = half * HB + u;
+                    const unsigned lo = __builtin_amdgcn_alignbyte(d[u][1], d[u][0], mis);   // window bytes 0..3 of the row
+                    const unsigned hi = __builtin_amdgcn_alignbyte(d[u][2], d[u][1], mis);   //              4..7
+                    v[t % 3][0] = lo & cmask;
+                    v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u) & cmask;
+                    v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u) & cmask;
+                    const int k = t - 2;                           // source row whose three reference rows are now complete
+                    if (k >= 0) {
+                        const unsigned sw = srcw[k];
+                        const bool ok = ROWOK(k);
+#pragma unroll
+                        for (int c9 = 0; c9 < 9; c9++) {
+                            const unsigned a9 = __builtin_amdgcn_sad_u8(sw, v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
+                            acc[c9] = ok ? a9 : acc[c9];
                         }
                     }
-#pragma unroll
-                    for (int k = 0; k < 9; k++)
-                        acc[k] = __builtin_amdgcn_sad_u8(srcw[kk], v[1 + FP_Y[k]][1 + FP_X[k]], acc[k]);
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
         }
         block_sum_n<9>(acc, S.part, phase);
@@ -316,17 +369,16 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
         if (tid == 0) mf[i + j * A.nxb] = out;
         return;
     }
-
     // ------------------------------------------------------------------ level 0 only
     const unsigned yarea = (unsigned)(bw * bh), yareasq = yarea * yarea;
     const double ryarea = 1.0 / (double)yarea;
     const int wx = bx + ((bw >> 1) - WIN / 2), wy = by + ((bh >> 1) - WIN / 2);
     const bool do_hp = best > BW * BH;
     // stage: source 14x14 window, and either the 19x20 patch for the lattice or the full-pel 14x14 window
-    const int smis = load_win<8>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
+    const int smis = load_win<8, WIN>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
     int pmis;
-    if (do_hp) pmis = load_win<8>(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
-    else       pmis = load_win<8>(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
+    if (do_hp) pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
+    else       pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
     __syncthreads();
     bool have_hp = false;
     if (do_hp) {
@@ -380,7 +432,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     if (!have_hp) {
         if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
             __syncthreads();
-            pmis = load_win<8>(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
+            pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
             __syncthreads();
         }
         for (int t = tid; t < WIN * WIN; t += NT) {
@@ -390,7 +442,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     }
     // zero-motion reference block -> LDS (needed by the variance test, the veto and the quadrant votes)
     __syncthreads();
-    const int zmis = load_win<32>(S.u.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
+    const int zmis = load_win<32, RROWS>(S.u.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
     __syncthreads();
     const uint8_t *zref = S.u.ref + zmis;
 
@@ -401,8 +453,8 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     if (cmask) {
 #pragma unroll
         for (int kk = 0; kk < NK; kk++) {
-            const int r = rg + NRG * kk;
-            if (r < bh) {
+            const int r = r0 + kk;
+            if (ROWOK(kk)) {
                 const unsigned curw = srcw[kk];
                 // horizontal neighbours: bytes x+1..x+4 of the same row (next dword supplies the 4th)
                 const unsigned nxt = *reinterpret_cast<const unsigned *>(S.src + r * SP + xcol + 4);
@@ -423,23 +475,25 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
             }
         }
     }
-    block_sum_n<8>(st, S.part, phase);
+    // block statistics and the two 14x14 window statistics share one reduction
+    unsigned ws[14];
+    win_partial(S.swin + smis, 24, ws[0], ws[1], ws[2], ws[3]);
+    win_partial(S.rwin, 16, ws[4], ws[5], ws[6], ws[7]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) ws[8 + k] = st[k];
+    block_sum_n<14>(ws, S.part, phase);
+#pragma unroll
+    for (int k = 0; k < 6; k++) st[k] = ws[8 + k];
     const unsigned luma_tex = udiv_rd((st[0] + st[1]) / 2, ryarea);
     const unsigned luma_var = st[3] - udiv_rd(st[2] * st[2], ryarea);
     const unsigned zs1 = st[4];
     const unsigned zvar = st[5] - udiv_rd(st[4] * st[4], ryarea);
-
-    unsigned ws[8];
-    win_partial(S.swin + smis, 24, ws[0], ws[1], ws[2], ws[3]);
-    win_partial(S.rwin, 16, ws[4], ws[5], ws[6], ws[7]);
-    block_sum_n<8>(ws, S.part, phase);
     const int src_tex = (int)(((ws[0] + ws[1]) / 2) / (WIN * WIN));
     const int src_avg = (int)(ws[2] / (WIN * WIN));
     const int src_var = (int)(ws[3] - (ws[2] * ws[2]) / (WIN * WIN));
     const int ref_tex = (int)(((ws[4] + ws[5]) / 2) / (WIN * WIN));
     const int ref_avg = (int)(ws[6] / (WIN * WIN));
     const int ref_var = (int)(ws[7] - (ws[6] * ws[6]) / (WIN * WIN));
-
     out.x = (int16_t)mvx; out.y = (int16_t)mvy;
     out.lo_tex = (luma_tex <= 2);
     out.lo_var = (luma_var < yareasq);
