@@ -33,7 +33,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
 // k_hzcc.hip
 void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf = nullptr, double samples = 0,
-                      int nplain = -1);
+                      int nplain = -1, int ll_chunks = 1);
 void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count, Prof *pf = nullptr);
 int  hz_scan_items_max();
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);

@@ -467,7 +467,8 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
         }
         launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
-        launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, nI);
+        launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, nI,
+                         (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
         OPCHK(enqueue_recon(c, nI, njobs, d0, 1));      // P pictures: straight from the symbol planes
     }
     {   // completion marker of this call; fetch waits on it from its own stream

@@ -89,7 +89,7 @@ static __device__ __forceinline__ bool flat_chunk(const JobDev &jb, int fc, int 
 // SYM: the detail regions were already quantised by the forward transform (k_fwd_haar_pix<true>), which left
 // their symbols in jb.sym in scan order; only the LL region (scan cells below r[1].base) is still quantised here.
 template <bool SYM>
-__global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ jobs)
+__global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ jobs, int ll_chunks)
 {
     __shared__ int s_pos[HZ_CHUNK];
     __shared__ int s_val[HZ_CHUNK];
@@ -98,7 +98,10 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
     const int job = blockIdx.y;
     const JobDev &jb = jobs[job];
     int c, chunk;
-    if (!flat_chunk(jb, blockIdx.x, c, chunk)) return;
+    if (SYM) {                      // grid.x = 3 x ll_chunks: only the chunks that reach into the LL region
+        c = blockIdx.x / ll_chunks; chunk = blockIdx.x - c * ll_chunks;
+        if (chunk >= jb.hz[c].nchunks || chunk * HZ_CHUNK >= jb.hz[c].r[1].base) return;
+    } else if (!flat_chunk(jb, blockIdx.x, c, chunk)) return;
     const HzPlane &hp = jb.hz[c];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int32_t *plane = jb.coef + jb.hz_coef_off[c];
@@ -216,6 +219,105 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
         cs.first_pos = total ? s_pos[fw * 512] : -1;
         cs.last_pos = total ? s_pos[lw * 512 + s_wcnt[lw] - 1] : -1;
         cs.last_val = total ? s_val[lw * 512 + s_wcnt[lw] - 1] : 0;
+    }
+}
+
+// -------------------------------------------------------------------------------------------------
+// P pictures of the encoder: the forward transform already left every detail symbol in jb.sym in scan order
+// (k_fwd_haar_pix<true>); what remains is the compaction.  One WAVE per 2048-cell chunk, four chunks per
+// workgroup, no LDS and no barrier: the chunk is read as 4 rounds of 16 bytes (8 symbols) per lane, all four
+// loads issued up front, and the non-zeros go straight to the chunk's ordered list.  The few chunks that
+// reach into the LL region (scan cells below r[1].base) are left to k_hz_quant<true>.
+__global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ jobs)
+{
+    const JobDev &jb = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63;
+    int c, chunk;
+    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
+    const HzPlane &hp = jb.hz[c];
+    const int ll_end = hp.r[1].base, nscan = hp.nscan;
+    const int16_t *sym = jb.sym + jb.nz_off[c];
+    int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    const int cbase = chunk * HZ_CHUNK;
+    if (cbase < ll_end) return;     // chunks that reach into the LL region belong to k_hz_quant<true>
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+
+    uint4 raw[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p0 = cbase + k * 512 + 8 * lane;
+        raw[k] = make_uint4(0, 0, 0, 0);
+        if (p0 < nscan) raw[k] = *reinterpret_cast<const uint4 *>(sym + p0);   // the planes are padded to whole chunks
+    }
+    int run = 0;                    // entries written so far
+    int cpos = -1, cval = 0;        // last entry so far (wave-uniform)
+    int first_pos = -1;
+    unsigned bits = 0;              // per-lane partial of bits_inner
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p0 = cbase + k * 512 + 8 * lane;
+        const uint4 rw = raw[k];
+        int v[8];
+        v[0] = (int16_t)(rw.x & 0xffff); v[1] = (int)rw.x >> 16; v[2] = (int16_t)(rw.y & 0xffff); v[3] = (int)rw.y >> 16;
+        v[4] = (int16_t)(rw.z & 0xffff); v[5] = (int)rw.z >> 16; v[6] = (int16_t)(rw.w & 0xffff); v[7] = (int)rw.w >> 16;
+        if (p0 + 8 > nscan) {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (p0 + j >= nscan) v[j] = 0;
+        }
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) cnt += (v[j] != 0);
+        const unsigned long long have = __ballot(cnt != 0);
+        if (have == 0ull) continue;                               // wave-uniform: a round of zeros costs nothing more
+        int incl = cnt;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int nb = __shfl_up(incl, o);
+            if (lane >= o) incl += nb;
+        }
+        // this lane's last entry, for the lanes after it
+        int lpos = -1, lval = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+            if (v[j] != 0) { lpos = p0 + j; lval = v[j]; }
+        // predecessor of this lane's first entry: the nearest earlier lane with entries, else the carry
+        const unsigned long long before = have & ltmask;
+        const int src = before ? 63 - __clzll(before) : 0;
+        int ppos = __shfl(lpos, src), pval = __shfl(lval, src);
+        if (!before) { ppos = cpos; pval = cval; }
+        int at = run + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (v[j] != 0) {
+                gpos[at] = p0 + j;
+                gval[at] = v[j];
+                if (at > 0) bits += (unsigned)(len_ueg((unsigned)(p0 + j - ppos - 1)) + len_neg(pval));
+                ppos = p0 + j; pval = v[j];
+                at++;
+            }
+        }
+        const int lastl = 63 - __clzll(have), firstl = __ffsll((long long)have) - 1;
+        if (first_pos < 0) {                                      // first entry of the chunk = first entry of lane firstl
+            int fp = -1;
+#pragma unroll
+            for (int j = 7; j >= 0; j--)
+                if (v[j] != 0) fp = p0 + j;
+            first_pos = __shfl(fp, firstl);
+        }
+        cpos = __shfl(lpos, lastl); cval = __shfl(lval, lastl);
+        run += __shfl(incl, 63);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o);
+    if (lane == 0) {
+        HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
+        cs.nnz = run;
+        cs.bits_inner = bits;
+        cs.first_pos = run ? first_pos : -1;
+        cs.last_pos = run ? cpos : -1;
+        cs.last_val = run ? cval : 0;
     }
 }
 
@@ -536,17 +638,21 @@ __global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ j
 // jobs [0, nplain) take the full quantiser; jobs [nplain, njobs) were quantised by the forward transform
 // (JobDev.fused) and only have their symbol planes compacted.  samples = coefficients per job, job_chunks = scan
 // chunks of one job over its three planes.
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain)
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain,
+                      int ll_chunks)
 {
     if (nplain < 0 || nplain > njobs) nplain = njobs;
     if (nplain > 0) {
         PB(KID_HZ_QUANT, samples * nplain * 8.0);          // 4 B/sample in, 4 B/sample dequantised back
-        hipLaunchKernelGGL((k_hz_quant<false>), dim3(job_chunks, nplain), dim3(256), 0, st, jobs);
+        hipLaunchKernelGGL((k_hz_quant<false>), dim3(job_chunks, nplain), dim3(256), 0, st, jobs, 0);
         PE();
     }
     if (njobs > nplain) {
+        PB(KID_HZ_QUANT_LL, 0.0);
+        hipLaunchKernelGGL((k_hz_quant<true>), dim3(3 * ll_chunks, njobs - nplain), dim3(256), 0, st, jobs + nplain, ll_chunks);
+        PE();
         PB(KID_HZ_COLLECT, samples * (njobs - nplain) * 2.0);   // 2 B/sample of symbols in
-        hipLaunchKernelGGL((k_hz_quant<true>), dim3(job_chunks, njobs - nplain), dim3(256), 0, st, jobs + nplain);
+        hipLaunchKernelGGL(k_hz_collect, dim3((job_chunks + 3) / 4, njobs - nplain), dim3(256), 0, st, jobs + nplain);
         PE();
     }
     PB(KID_HZ_SCAN, 0.0);

@@ -55,28 +55,10 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     const uint8_t *g0 = rp + rowbase;
     const int mis = (int)(((uintptr_t)g0) & 3);           // same for every row (stride % 4 == 0)
     const int ndw = (mis + cw + 3 + 3) >> 2;
-    {   // TPR threads share a row (ndw <= TPR), loads in batches of up to 7 issued back to back before their LDS
-        // stores: a memory round trip per batch, not per row
-        const int ltpr = ndw > 16 ? 5 : 4;
-        const int d = tid & ((1 << ltpr) - 1), rb = tid >> ltpr, rpp = MC_NT >> ltpr;
-        const int nh = ch + 3;
-        if (d < ndw) {
-#pragma unroll 1
-            for (int rbase = rb; rbase < nh; rbase += 7 * rpp) {
-                unsigned v[7];
-#pragma unroll
-                for (int u = 0; u < 7; u++) {
-                    const int r = min(rbase + u * rpp, nh - 1);
-                    v[u] = *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
-                }
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 7; u++) {
-                    const int r = rbase + u * rpp;
-                    if (r < nh) *reinterpret_cast<unsigned *>(win + r * WPITCH + 4 * d) = v[u];
-                }
-            }
-        }
+    for (int i = tid; i < (ch + 3) * ndw; i += MC_NT) {
+        const int r = i / ndw, d = i - r * ndw;
+        const unsigned v = *reinterpret_cast<const unsigned *>(g0 - mis + (long)r * stride + 4 * d);
+        *reinterpret_cast<unsigned *>(win + r * WPITCH + 4 * d) = v;
     }
     if (tid < 5) s_sum[tid] = 0;
     __syncthreads();
@@ -122,19 +104,8 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
         hi = __builtin_amdgcn_alignbyte(c_, b_, (unsigned)((mis + x4) & 3));                  \
     } while (0)
 #define BYTE(lo, hi, k) ((int)((((k) < 4 ? (lo) : (hi)) >> (8 * ((k) & 3))) & 0xff))
-    // 2^lq threads share a row of 4-pixel groups (lq from the nominal block width), MC_NT >> lq rows per pass
-    const int lq = bw > 32 ? 4 : (bw > 16 ? 3 : 2);
-    const int x4 = 4 * (tid & ((1 << lq) - 1));
-    if (x4 >= 4 * nq) return;
-    // the source dword of the NEXT row pass is requested before this pass is computed (the subtraction would
-    // otherwise sit behind a full memory round trip in every pass)
-    const bool full4 = x4 + 4 <= cw;
-    unsigned s_cur = 0;
-    if (do_sub && full4 && (tid >> lq) < ch) s_cur = *reinterpret_cast<const unsigned *>(sp + (size_t)(y + (tid >> lq)) * stride + x + x4);
-    for (int yy = tid >> lq; yy < ch; yy += MC_NT >> lq) {
-        unsigned s_next = 0;
-        if (do_sub && full4 && yy + (MC_NT >> lq) < ch)
-            s_next = *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy + (MC_NT >> lq)) * stride + x + x4);
+    for (int it = tid; it < nq * ch; it += MC_NT) {
+        const int yy = it / nq, x4 = 4 * (it - yy * nq);
         int pv[4];
         if (mv.mode == 0) {
             if (c == 0) {
@@ -193,7 +164,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
             const unsigned pk = (unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24);
             *reinterpret_cast<unsigned *>(pp + o) = pk;
             if (do_sub) {
-                const unsigned s = s_cur;
+                const unsigned s = *reinterpret_cast<const unsigned *>(sp + o);
                 unsigned r = 0;
 #pragma unroll
                 for (int k = 0; k < 4; k++)
@@ -212,7 +183,6 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
         // residual frame, which in the reference still holds the replicated source edge (frame.c:199-221)
         if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
             xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * stride + pw - 1];
-        s_cur = s_next;
     }
 }
 
