@@ -776,7 +776,7 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
 // whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
 // other two modes).  The tile is IT_TX x IT_TY cells of the mode's top level.
 template <bool FILT, int MODE, bool SYM>
-__global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+__global__ __launch_bounds__(256, 7) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     static_assert(!SYM || MODE == 0, "symbol-plane input is the encoder's P-picture path");
     constexpr bool TO_PIX = (MODE == 0);
