@@ -635,11 +635,14 @@ __global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ j
 #define PB(kid, bytes) do { if (pf) pf->begin(st, kid, bytes); } while (0)
 #define PE() do { if (pf) pf->end(st); } while (0)
 
-// jobs [0, nplain) take the full quantiser; jobs [nplain, njobs) were quantised by the forward transform
-// (JobDev.fused) and only have their symbol planes compacted.  samples = coefficients per job, job_chunks = scan
-// chunks of one job over its three planes.
-void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain,
-                      int ll_chunks)
+// The entropy stage in two halves, so a pipeline can put them on different streams.
+// launch_hz_quant: everything the RECONSTRUCTION depends on -- jobs [0, nplain) take the full quantiser
+// (k_hz_quant<false>); jobs [nplain, njobs) were quantised by the forward transform (JobDev.fused) and only
+// their LL region is quantised here.  launch_hz_pack: symbol compaction of the fused jobs, the plane-wide
+// scan (which also fixes up the shared cells of non-fused jobs) and the bit emission.
+// samples = coefficients per job, job_chunks = scan chunks of one job over its three planes, ll_chunks = chunks
+// that reach into the largest plane's LL region.
+void launch_hz_quant(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ll_chunks)
 {
     if (nplain < 0 || nplain > njobs) nplain = njobs;
     if (nplain > 0) {
@@ -651,6 +654,12 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
         PB(KID_HZ_QUANT_LL, 0.0);
         hipLaunchKernelGGL((k_hz_quant<true>), dim3(3 * ll_chunks, njobs - nplain), dim3(256), 0, st, jobs + nplain, ll_chunks);
         PE();
+    }
+}
+void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain)
+{
+    if (nplain < 0 || nplain > njobs) nplain = njobs;
+    if (njobs > nplain) {
         PB(KID_HZ_COLLECT, samples * (njobs - nplain) * 2.0);   // 2 B/sample of symbols in
         hipLaunchKernelGGL(k_hz_collect, dim3((job_chunks + 3) / 4, njobs - nplain), dim3(256), 0, st, jobs + nplain);
         PE();
@@ -661,6 +670,12 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
     PB(KID_HZ_EMIT, 0.0);
     hipLaunchKernelGGL(k_hz_emit, dim3((job_chunks + 3) / 4, njobs), dim3(256), 0, st, jobs);
     PE();
+}
+void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain,
+                      int ll_chunks)
+{
+    launch_hz_quant(st, jobs, njobs, job_chunks, pf, samples, nplain, ll_chunks);
+    launch_hz_pack(st, jobs, njobs, job_chunks, pf, samples, nplain);
 }
 
 void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count, Prof *pf)
