@@ -5,7 +5,9 @@ HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports b
 FETCH_SIZE tallies the 128-byte requests of a wide coalesced read at 64 bytes (MI355X_MICROARCH.md, HBM), so
 the read side is doubled.  That calibration is for 16 B/lane streams; narrower accesses may be over-corrected,
 which the file says in `source`.
-usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json>"""
+If the SQ summary is given too, the VALU instruction count per launch is added (bench.py turns it into an issue
+utilisation: one wave64 VALU instruction occupies its SIMD for 4 cycles).
+usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json> [pmc_sq_per_kernel.csv]"""
 import csv
 import json
 import sys
@@ -21,5 +23,11 @@ for r in rows:
     w = float(r.get("WRITE_SIZE_per_launch", 0) or 0)
     out["kernels"][r["kernel"]] = {"launches": int(r["launches"]), "fetch_kib_per_launch": f, "write_kib_per_launch": w,
                                    "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
+if len(sys.argv) > 4:
+    for r in csv.DictReader(open(sys.argv[4])):
+        e = out["kernels"].setdefault(r["kernel"], {"launches": int(r["launches"])})
+        e["valu_insts_per_launch"] = float(r.get("SQ_INSTS_VALU_per_launch", 0) or 0)
+        e["salu_insts_per_launch"] = float(r.get("SQ_INSTS_SALU_per_launch", 0) or 0)
+        e["waves_per_launch"] = float(r.get("SQ_WAVES_per_launch", 0) or 0)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out["kernels"]), "kernels")
