@@ -21,7 +21,7 @@
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
 
-#define NT 128             // threads per workgroup: 16 column groups x 8 row groups (more blocks in flight per CU)
+#define NT 64              // threads per workgroup = ONE wave per block: 16 column groups x 4 row groups, no cross-wave exchange
 #define NRG (NT / 16)
 #define NK (64 / NRG)       // rows per thread
 #define NW (NT / 64)        // waves per workgroup
@@ -83,7 +83,6 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 }
 
 struct HmeShared {
-    __attribute__((aligned(16))) uint8_t src[64 * SP];
     // the 9-point window is dead once its SADs are reduced; the half-pel patch + lattice reuse its space
     // until the zero-motion block is staged there for the statistics
     union {
@@ -215,7 +214,6 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
         const int r = r0 + k;
         srcw[k] = 0;
         if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
-        if (LEVEL0 && ROWOK(k) && xcol < ((bw + 3) & ~3)) *reinterpret_cast<unsigned *>(S.src + r * SP + xcol) = srcw[k];
         srcw[k] &= cmask;
     }
     // parents (hme.c:452-480): every lane reads the same five vectors (wave-uniform addresses -> SGPRs) and
@@ -450,29 +448,33 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     unsigned st[8];                 // src block gh,gv,s1,s2 ; zref s1,s2 ; spare
 #pragma unroll
     for (int k = 0; k < 8; k++) st[k] = 0;
-    if (cmask) {
+    {
+        // the row above this thread's first row belongs to the previous row group: lane - 16, its last row
+        unsigned lastw = srcw[0];
+#pragma unroll
+        for (int k = 1; k < NK; k++) lastw = (k == nkb - 1) ? srcw[k] : lastw;
+        unsigned upw = (unsigned)__shfl_up((int)lastw, 16);
 #pragma unroll
         for (int kk = 0; kk < NK; kk++) {
             const int r = r0 + kk;
-            if (ROWOK(kk)) {
-                const unsigned curw = srcw[kk];
-                // horizontal neighbours: bytes x+1..x+4 of the same row (next dword supplies the 4th)
-                const unsigned nxt = *reinterpret_cast<const unsigned *>(S.src + r * SP + xcol + 4);
-                const unsigned right = __builtin_amdgcn_alignbyte(nxt, *reinterpret_cast<const unsigned *>(S.src + r * SP + xcol), 1u);
+            const unsigned curw = srcw[kk];
+            // horizontal neighbours: bytes x+1..x+4 of the same row; the 4th comes from the next column group = lane + 1
+            // of the same 16-lane row (DPP row_shl:1, zero past the row's end -- masked by pm there anyway)
+            const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)curw, 0x101, 0xf, 0xf, true);
+            if (cmask && ROWOK(kk)) {
+                const unsigned right = __builtin_amdgcn_alignbyte(nxt, curw, 1u);
                 // pairs (x,x+1) count only while x+1 < bw
                 const int npair = min(4, bw - 1 - xcol);
                 const unsigned pm = npair <= 0 ? 0u : (npair >= 4 ? 0xffffffffu : ((1u << (8 * npair)) - 1u));
                 st[0] = __builtin_amdgcn_sad_u8(curw & pm, right & pm, st[0]);
-                if (r > 0) {
-                    const unsigned up = *reinterpret_cast<const unsigned *>(S.src + (r - 1) * SP + xcol) & cmask;
-                    st[1] = __builtin_amdgcn_sad_u8(curw, up, st[1]);
-                }
+                if (r > 0) st[1] = __builtin_amdgcn_sad_u8(curw, upw, st[1]);
                 st[2] = __builtin_amdgcn_sad_u8(curw, 0u, st[2]);
                 st[3] = __builtin_amdgcn_udot4(curw, curw, st[3], false);
                 const unsigned zw = *reinterpret_cast<const unsigned *>(zref + r * RP + xcol) & cmask;
                 st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
                 st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
             }
+            upw = curw;
         }
     }
     // block statistics and the two 14x14 window statistics share one reduction
@@ -552,14 +554,15 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
             for (int b4 = 0; b4 < 4; b4++) {
                 const int x = xcol + b4;
                 if (x >= bw) continue;
-                const int pa = S.src[r * SP + x], pb = zref[r * RP + x];
+                const uint8_t *sx = sp + (size_t)(by + r) * stride + bx + x;     // rare path: source pixels straight from global
+                const int pa = sx[0], pb = zref[r * RP + x];
                 const int back = d_sat8(mean + d_sat8(pa - mean + 128) - 128);
                 qv[0] += (back != pa);
                 if (x < 2 * qw && r < 2 * qh) {
                     const int qx = x >= qw, qy = r >= qh;
                     const int lx = x - qx * qw, ly = r - qy * qh;        // position inside the quadrant
-                    const int la = lx ? S.src[r * SP + x - 1] : pa, lb = lx ? zref[r * RP + x - 1] : pb;
-                    const int ua = ly ? S.src[(r - 1) * SP + x] : pa, ub = ly ? zref[(r - 1) * RP + x] : pb;
+                    const int la = lx ? sx[-1] : pa, lb = lx ? zref[r * RP + x - 1] : pb;
+                    const int ua = ly ? sx[-stride] : pa, ub = ly ? zref[(r - 1) * RP + x] : pb;
                     const int dif = abs(pa - pb);
                     unsigned good = (unsigned)(abs(pa - la) + abs(pa - ua) + abs(pb - lb) + abs(pb - ub));
                     unsigned evil = 0;
