@@ -101,7 +101,9 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     size_t nz_off[3];        // offsets of each plane in nzpos/nzval (ints)
     size_t hz_coef_off[3];   // offsets of each plane in coef (ints)
     int chunk_off[3];
-    int dec_cnt[3];          // decoder: number of (position,value) pairs per plane
+    int dec_cnt[3];          // decoder: number of (position,value) pairs per plane (written by k_hz_parse)
+    int dec_runs[3], dec_len[3], dec_dc[3];   // decoder: run count / byte length / DC of the plane header (host)
+    long long dec_bitpos[3]; // decoder: bit offset of the first code inside the uploaded payload
     int16_t *sym;            // fused quantiser: quantised symbol of every detail scan cell, indexed nz_off[c] + scan position
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
     HzPlane hz[3];

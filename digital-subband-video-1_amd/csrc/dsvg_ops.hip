@@ -231,44 +231,22 @@ extern "C" int dsvg_op_decode_plane(uint8_t *in, unsigned len, dsvg_coefs *dst, 
     OPCHK(make_plane_job(S, jb, dst, q, stab, &dco));
     const HzPlane &hp = jb.hz[c];
 
-    // entropy parse on the host (hzcc_dec hzcc.c:295-435): positions in scan order + values
+    // the host reads the plane header only (SEG(DC), run count); the code chain is parsed on the device
     HostBits hb{in, 0};
     const int dc = hb.seg();
     hb.align();
-    int runs = (int)hb.bits(32);
+    const int runs = (int)hb.bits(32);
     hb.align();
-    std::vector<int32_t> pos, val;
-    if (runs-- > 0) {
-        long p = (long)hb.ueg();
-        while (p < hp.nscan) {
-            long nextrun = -1;
-            if (runs-- > 0) nextrun = (long)hb.ueg();
-            const int v = hb.neg();
-            if ((hb.pos >> 3) >= len) break;                   // hzcc.c:337-339
-            pos.push_back((int32_t)p);
-            val.push_back(v);
-            if (nextrun < 0) break;
-            p += 1 + nextrun;
-        }
-    }
-    const int n = (int)pos.size();
-    OPCHK(S.dev(&jb.nzpos, (size_t)n + 4, false));
-    OPCHK(S.dev(&jb.nzval, (size_t)n + 4, false));
-    if (n) {
-        HIPCHK(hipMemcpyAsync(jb.nzpos, pos.data(), (size_t)n * 4, hipMemcpyHostToDevice, S.st));
-        HIPCHK(hipMemcpyAsync(jb.nzval, val.data(), (size_t)n * 4, hipMemcpyHostToDevice, S.st));
-    }
-    jb.dec_cnt[c] = n;
+    jb.dec_dc[c] = dc; jb.dec_runs[c] = runs; jb.dec_len[c] = (int)len; jb.dec_bitpos[c] = (long long)hb.pos;
+    uint8_t *dpay; OPCHK(S.dev(&dpay, (size_t)len + 64, true));
+    HIPCHK(hipMemcpyAsync(dpay, in, len, hipMemcpyHostToDevice, S.st));
+    jb.bits = dpay; jb.bits_off[c] = 0;
+    OPCHK(S.dev(&jb.nzpos, (size_t)hp.nchunks * HZ_CHUNK, false));
+    OPCHK(S.dev(&jb.nzval, (size_t)hp.nchunks * HZ_CHUNK, false));
     JobDev *djb; OPCHK(S.dev(&djb, 1, false));
     HIPCHK(hipMemcpyAsync(djb, &jb, sizeof(jb), hipMemcpyHostToDevice, S.st));
-    // three ordered phases so that a later region's non-zero overwrites an earlier one
-    int cut[4] = {0, n, n, n};
-    for (int i = 0; i < n; i++) {
-        if (pos[i] < hp.r[4].base) cut[1] = i + 1;
-        if (pos[i] < hp.r[7].base) cut[2] = i + 1;
-    }
-    if (cut[2] < cut[1]) cut[2] = cut[1];
-    for (int ph = 0; ph < 3; ph++) launch_hz_scatter(S.st, djb, 1, c, cut[ph], cut[ph + 1] - cut[ph]);
+    // parse, then three ordered scatter phases so that a later region's non-zero overwrites an earlier one
+    launch_hz_parse_scatter(S.st, djb, 1, c, std::min(std::max(runs, 0), hp.nchunks * HZ_CHUNK - 1) + 1);
     HIPCHK(hipMemcpyAsync(dst->data, dco, (size_t)dst->width * dst->height * 4, hipMemcpyDeviceToHost, S.st));
     OPCHK(S.sync());
     dst->data[0] = dc;

@@ -53,7 +53,8 @@ struct dsvg_ctx {
     int *aslots_h = nullptr;         // analysis-stream staging (pair tables)
     DMV *amv_h = nullptr;            // analysis-stream staging (motion fields)
     unsigned *luma_h = nullptr;
-    int32_t *dec_h = nullptr;        // decoder: parsed (pos,val) staging
+    uint8_t *dec_h = nullptr;        // decoder: pinned staging of the plane payloads of one call
+    size_t dec_stage = 0;            //          bytes per staged plane
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
     int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
@@ -587,8 +588,12 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) ord.push_back(i);
     HIPCHK(hipStreamSynchronize(c->st));
     c->calls_since_sync = 0;
-    if (!c->dec_h) OPCHK(hmalloc(&c->dec_h, 2 * c->nz_total * (size_t)c->max_jobs));
-    std::vector<int> cuts((size_t)njobs * 3 * 4, 0);
+    if (!c->dec_h) {        // pinned staging for the plane payloads of one call
+        c->dec_stage = 0;
+        for (int p = 0; p < 3; p++) c->dec_stage = std::max(c->dec_stage, c->bits_cap[p]);
+        OPCHK(hmalloc(&c->dec_h, c->dec_stage * 3 * (size_t)c->max_jobs));
+    }
+    int max_entries[3] = {0, 0, 0};
     const CoefLayout &CL = c->CL;
     for (int t = 0; t < njobs; t++) {
         const dsvg_dec_job &j = jobs[ord[t]];
@@ -604,56 +609,33 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         memcpy(c->stable_h + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
         if (isP) memcpy(c->mv_h + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
         for (int p = 0; p < 3; p++) {
-            // entropy parse on the host (hzcc_dec hzcc.c:295-435) -> (scan position, value) pairs
-            int32_t *pos = c->dec_h + ((size_t)t * 2) * c->nz_total + c->nz_off[p];
-            int32_t *val = c->dec_h + ((size_t)t * 2 + 1) * c->nz_total + c->nz_off[p];
-            const HzPlane &hp = jb.hz[p];
+            // the host reads only the plane header (hzcc.c:479-483,307-311): SEG(DC), the 32-bit run count; the
+            // code chain is parsed on the device (k_hz_parse) from the uploaded bytes
+            if (!j.plane_data[p] || (size_t)j.plane_len[p] + 64 > c->bits_cap[p]) { dsvg_set_error("plane %d of decode job %d: bad length", p, ord[t]); return DSVG_ERR_ARG; }
             Rd rd{j.plane_data[p], 0};
-            int n = 0;
-            pos[n] = 0; val[n] = rd.seg(); n++;           // unquantised DC rides along as entry 0
+            jb.dec_dc[p] = rd.seg();
             rd.align();
-            int runs = (int)rd.bits(32);
+            jb.dec_runs[p] = (int)rd.bits(32);
             rd.align();
-            if (runs-- > 0) {
-                long q = (long)rd.ueg();
-                while (q < hp.nscan) {
-                    long nextrun = -1;
-                    if (runs-- > 0) nextrun = (long)rd.ueg();
-                    const int v = rd.neg();
-                    if ((rd.pos >> 3) >= j.plane_len[p]) break;
-                    pos[n] = (int32_t)q; val[n] = v; n++;
-                    if (nextrun < 0) break;
-                    q += 1 + nextrun;
-                }
-            }
-            jb.dec_cnt[p] = n;
-            int *cut = &cuts[((size_t)t * 3 + p) * 4];
-            cut[0] = 0; cut[1] = cut[2] = cut[3] = n;
-            for (int i = n - 1; i >= 0; i--) {
-                if (pos[i] >= hp.r[7].base) cut[2] = i;
-                if (pos[i] >= hp.r[4].base) cut[1] = i;
-            }
-            if (cut[1] > cut[2]) cut[1] = cut[2];
+            jb.dec_bitpos[p] = (long long)rd.pos;
+            jb.dec_len[p] = (int)j.plane_len[p];
+            jb.dec_cnt[p] = 0;
+            max_entries[p] = std::max(max_entries[p], std::min(jb.dec_runs[p], jb.hz[p].nchunks * HZ_CHUNK - 1) + 1);
+            uint8_t *stage = c->dec_h + ((size_t)t * 3 + p) * c->dec_stage + 0;
+            memcpy(stage, j.plane_data[p], j.plane_len[p]);
+            memset(stage + j.plane_len[p], 0, 64);
         }
     }
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++)
+            HIPCHK(hipMemcpyAsync(c->bits + (size_t)t * c->bits_per_job + c->bits_off[p], c->dec_h + ((size_t)t * 3 + p) * c->dec_stage,
+                                  (size_t)c->jobs_h[t].dec_len[p] + 64, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable, c->stable_h, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemsetAsync(c->coef, 0, CL.total * (size_t)njobs * sizeof(int32_t), c->st));
-    for (int t = 0; t < njobs; t++)
-        for (int p = 0; p < 3; p++) {
-            const int n = c->jobs_h[t].dec_cnt[p];
-            const int32_t *pos = c->dec_h + ((size_t)t * 2) * c->nz_total + c->nz_off[p];
-            const int32_t *val = c->dec_h + ((size_t)t * 2 + 1) * c->nz_total + c->nz_off[p];
-            HIPCHK(hipMemcpyAsync(c->nzpos + (size_t)t * c->nz_total + c->nz_off[p], pos, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
-            HIPCHK(hipMemcpyAsync(c->nzval + (size_t)t * c->nz_total + c->nz_off[p], val, (size_t)n * 4, hipMemcpyHostToDevice, c->st));
-        }
-    for (int t = 0; t < njobs; t++)
-        for (int p = 0; p < 3; p++) {
-            const int *cut = &cuts[((size_t)t * 3 + p) * 4];
-            for (int ph = 0; ph < 3; ph++) launch_hz_scatter(c->st, c->jobs_d + t, 1, p, cut[ph], cut[ph + 1] - cut[ph], &c->prof);
-        }
+    for (int p = 0; p < 3; p++) launch_hz_parse_scatter(c->st, c->jobs_d, njobs, p, max_entries[p], &c->prof);
     if (njobs > nI) {
         launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }

@@ -611,18 +611,249 @@ __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs
 }
 
 // -------------------------------------------------------------------------------------------------
-// decoder: scatter + dequantise host-parsed (scan position, value) pairs (hzcc.c:330-341,409-424)
-__global__ __launch_bounds__(256) void k_hz_scatter(const JobDev *__restrict__ jobs, int c, int first, int count)
+// decoder: entropy PARSE on the device (hzcc_dec hzcc.c:295-435, bit reader bs.c:148-219).
+// After the plane header (SEG(DC), 32-bit run count -- read by the host) the payload is a chain of interleaved
+// exp-Golomb codes   U(run_1) | U(run_2) N(v_1) | U(run_3) N(v_2) | ... | U(run_n) N(v_{n-1}) | N(v_n)
+// with U = k x ('0', bit) then '1' and N = U(|v|-1) + sign bit.  Where a code starts depends on every bit
+// before it, so the bits are walked by a 5-state machine {U flag, U data, N flag, N data, sign} whose per-chunk
+// transition maps compose associatively: one workgroup per plane, every thread owns 128 bits per pass,
+//   1. per thread: the state map of its 16 bytes from a byte table in LDS (5 states in parallel);
+//   2. workgroup scan of the maps -> the state each thread really enters with; one more table walk gives the
+//      code-end bit mask of the chunk, its count and its last end; prefix sum / max scan of those;
+//   3. each thread decodes the codes that END in its chunk (their start is the previous code end) straight into
+//      the run / value arrays; the pass carries state, code count and last end to the next pass;
+// then a prefix sum of (run + 1) turns runs into scan positions.  After U(run_1), which thread 0 reads serially,
+// the chain alternates U,N strictly except for the last code, an N where a U would be due: its U part ends where
+// the machine says, the sign bit is the next bit.
+#define PARSE_THREADS 1024
+#define PARSE_BITS 128
+static __device__ __forceinline__ unsigned long long bits_at(const uint8_t *p, unsigned long long bitpos)
+{   // 64 bits of the MSB-first stream starting at bitpos (reads 9 bytes; the payload buffer has slack)
+    const uint8_t *q = p + (bitpos >> 3);
+    unsigned long long w = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w = (w << 8) | q[i];
+    const unsigned sh = (unsigned)(bitpos & 7);
+    return sh ? (w << sh) | ((unsigned long long)q[8] >> (8 - sh)) : w;
+}
+static __device__ __forceinline__ unsigned compress_bits(unsigned long long x)      // bit 2i -> bit i (inverse of spread_bits)
 {
-    const int job = blockIdx.y;
-    const JobDev &jb = jobs[job];
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    x = (x | (x >> 4)) & 0x00FF00FF00FF00FFull;
+    x = (x | (x >> 8)) & 0x0000FFFF0000FFFFull;
+    x = (x | (x >> 16)) & 0x00000000FFFFFFFFull;
+    return (unsigned)x;
+}
+// value of the U code occupying the top `len` (= 2k+1, <= 63) bits of w
+static __device__ __forceinline__ unsigned ueg_value(unsigned long long w, int len)
+{
+    const int k = (len - 1) >> 1;
+    if (k <= 0) return 0u;
+    const unsigned long long body = w >> (64 - (len - 1));          // k pairs ('0', bit), the data bit is the low bit of each pair
+    return ((1u << k) | compress_bits(body)) - 1u;
+}
+// one step of the machine: state x bit -> state; *end = a code ends with this bit
+static __device__ __forceinline__ int parse_step(int st, int b, bool &end)
+{
+    end = false;
+    switch (st) {
+    case 0: if (b) { end = true; return 2; } return 1;               // U flag
+    case 1: return 0;                                                // U data
+    case 2: return b ? 4 : 3;                                        // N flag
+    case 3: return 2;                                                // N data
+    default: end = true; return 0;                                   // sign bit
+    }
+}
+
+__global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__ jobs, int c)
+{
+    __shared__ uint8_t s_tab[5][256];               // [state][byte] -> exit state | (code ends << 3)
+    __shared__ unsigned s_wmap[16];                 // per-wave inclusive state maps (5 x 3 bits)
+    __shared__ int s_wcnt[16], s_wlast[16];
+    __shared__ int s_state, s_ncode, s_first_bad;
+    __shared__ long long s_lastend;
+    __shared__ unsigned long long s_q;
+    JobDev &jb = jobs[blockIdx.x];
+    const HzPlane &hp = jb.hz[c];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const uint8_t *pay = jb.bits + jb.bits_off[c];
+    int32_t *R = jb.nzpos + jb.nz_off[c];           // [0] = DC position, [m] = run_m, then scan position of entry m
+    int32_t *V = jb.nzval + jb.nz_off[c];
+    const long long endbits = 8ll * jb.dec_len[c];
+    const int cap = hp.nchunks * HZ_CHUNK - 1;
+    const int n = min(jb.dec_runs[c], cap);         // entries announced by the header
+    if (tid == 0) { R[0] = 0; V[0] = jb.dec_dc[c]; }
+    if (n <= 0) { if (tid == 0) jb.dec_cnt[c] = 1; return; }
+
+    for (int i = tid; i < 5 * 256; i += PARSE_THREADS) {
+        int st = i >> 8, cnt = 0;
+        const int byte = i & 255;
+#pragma unroll
+        for (int b = 7; b >= 0; b--) { bool e; st = parse_step(st, (byte >> b) & 1, e); cnt += e; }
+        s_tab[i >> 8][byte] = (uint8_t)(st | (cnt << 3));
+    }
+    const long long start0 = jb.dec_bitpos[c];
+    if (tid == 0) {                                 // U(run_1), serially
+        const unsigned long long w = bits_at(pay, (unsigned long long)start0);
+        const int k = w ? __clzll((long long)(w & 0xAAAAAAAAAAAAAAAAull)) >> 1 : 31;   // first '1' at an even offset = the stop flag
+        const int len = 2 * k + 1;
+        R[1] = (int32_t)ueg_value(w, len);
+        s_state = 0; s_ncode = 0; s_first_bad = 0x7fffffff;
+        s_lastend = start0 + len;
+    }
+    __syncthreads();
+    const int ncodes = 2 * n - 1;
+    const long long S0 = s_lastend;                 // first bit of the alternating chain
+
+    for (long long pbase = S0; pbase < endbits && s_ncode < ncodes; pbase += (long long)PARSE_THREADS * PARSE_BITS) {
+        const long long B = pbase + (long long)tid * PARSE_BITS;
+        unsigned long long w0 = 0, w1 = 0;
+        if (B < endbits) { w0 = bits_at(pay, (unsigned long long)B); w1 = bits_at(pay, (unsigned long long)B + 64); }
+        // bits past the end of the plane data read as zero
+        if (B + 128 > endbits) {
+            const long long keep = endbits - B;                       // < 128
+            if (keep <= 0) { w0 = 0; w1 = 0; }
+            else if (keep < 64) { w0 &= ~0ull << (64 - keep); w1 = 0; }
+            else if (keep < 128) { w1 = keep == 64 ? 0ull : (w1 & (~0ull << (128 - keep))); }
+        }
+        // 1. state map of the chunk: exit state for each of the 5 entry states
+        unsigned map = 0;
+#pragma unroll
+        for (int s0 = 0; s0 < 5; s0++) {
+            int st = s0;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                const unsigned byte = (unsigned)((k < 8 ? w0 >> (56 - 8 * k) : w1 >> (56 - 8 * (k - 8))) & 0xff);
+                st = s_tab[st][byte] & 7;
+            }
+            map |= (unsigned)st << (3 * s0);
+        }
+        // inclusive scan of the maps (compose: first a, then b)
+        unsigned inc = map;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned prev = (unsigned)__shfl_up((int)inc, o);
+            if (lane >= o) {
+                unsigned cmp = 0;
+#pragma unroll
+                for (int s0 = 0; s0 < 5; s0++) cmp |= ((inc >> (3 * ((prev >> (3 * s0)) & 7))) & 7) << (3 * s0);
+                inc = cmp;
+            }
+        }
+        if (lane == 63) s_wmap[wv] = inc;
+        __syncthreads();
+        int st_in = s_state;                                              // state at the start of the pass
+        for (int w = 0; w < wv; w++) st_in = (int)((s_wmap[w] >> (3 * st_in)) & 7);
+        {
+            const unsigned excl = (unsigned)__shfl_up((int)inc, 1);
+            if (lane > 0) st_in = (int)((excl >> (3 * st_in)) & 7);
+        }
+        // 2. the chunk again from its real entry state: code-end mask (bit 127-i of {m0,m1} = a code ends with chunk bit i)
+        unsigned long long m0 = 0, m1 = 0;
+        int st = st_in;
+#pragma unroll 4
+        for (int i = 0; i < 64; i++) { bool e; st = parse_step(st, (int)((w0 >> (63 - i)) & 1), e); if (e) m0 |= 1ull << (63 - i); }
+#pragma unroll 4
+        for (int i = 0; i < 64; i++) { bool e; st = parse_step(st, (int)((w1 >> (63 - i)) & 1), e); if (e) m1 |= 1ull << (63 - i); }
+        const int cnt = __popcll(m0) + __popcll(m1);
+        const int lastoff = m1 ? 127 - (__ffsll((long long)m1) - 1) : (m0 ? 63 - (__ffsll((long long)m0) - 1) : -1);   // chunk bit of the last end
+        // exclusive prefix sum of counts, exclusive max-scan of last ends
+        int csum = cnt, lmax = lastoff >= 0 ? tid * PARSE_BITS + lastoff : -1;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const int a = __shfl_up(csum, o), b = __shfl_up(lmax, o);
+            if (lane >= o) { csum += a; lmax = max(lmax, b); }
+        }
+        if (lane == 63) { s_wcnt[wv] = csum; s_wlast[wv] = lmax; }
+        __syncthreads();
+        int cbase = s_ncode, lbefore = -1;
+        for (int w = 0; w < wv; w++) { cbase += s_wcnt[w]; lbefore = max(lbefore, s_wlast[w]); }
+        {
+            const int a = __shfl_up(csum, 1), b = __shfl_up(lmax, 1);
+            if (lane > 0) { cbase += a; lbefore = max(lbefore, b); }
+        }
+        long long prev_end = lbefore >= 0 ? pbase + lbefore + 1 : s_lastend;    // bit after the previous code
+        // 3. decode the codes that end in this chunk
+        int j = cbase;
+        for (int half = 0; half < 2 && j < ncodes; half++) {
+            unsigned long long m = half ? m1 : m0;
+            while (m && j < ncodes) {
+                const int hb = 63 - __clzll((long long)m);               // highest set bit = earliest end
+                m &= ~(1ull << hb);
+                const long long endp = B + half * 64 + (63 - hb) + 1;     // bit after the code
+                const int len = (int)min(endp - prev_end, 63ll);
+                const unsigned long long w = bits_at(pay, (unsigned long long)prev_end);
+                if (j == ncodes - 1) {                                    // the final N: U part here, sign = the next bit
+                    const unsigned mag = ueg_value(w, len) + 1u;
+                    const int sign = (int)((bits_at(pay, (unsigned long long)endp) >> 63) & 1);
+                    V[n] = sign ? -(int)mag : (int)mag;
+                    if (((endp + 1) >> 3) >= jb.dec_len[c]) atomicMin(&s_first_bad, n);
+                } else if ((j & 1) == 0) {
+                    R[j / 2 + 2] = (int32_t)ueg_value(w, len);            // U(run_{j/2+2})
+                } else {
+                    const unsigned mag = ueg_value(w, len - 1) + 1u;      // N(v_{(j+1)/2}): U part + sign
+                    const int sign = (int)((w >> (64 - len)) & 1);
+                    const int mi = (j + 1) / 2;
+                    V[mi] = sign ? -(int)mag : (int)mag;
+                    if ((endp >> 3) >= jb.dec_len[c]) atomicMin(&s_first_bad, mi);   // hzcc.c:337-339
+                }
+                prev_end = endp;
+                j++;
+            }
+        }
+        __syncthreads();
+        if (tid == PARSE_THREADS - 1) {                                   // carry to the next pass
+            s_state = st;
+            s_ncode = cbase + cnt;
+            const int l = max(lbefore, lastoff >= 0 ? tid * PARSE_BITS + lastoff : -1);
+            if (l >= 0) s_lastend = pbase + l + 1;
+        }
+        __syncthreads();
+    }
+    // entries actually usable: announced, fully inside the data, and (below) inside the scan
+    const int nent = s_ncode >= ncodes ? min(n, s_first_bad - 1) : min(s_ncode / 2, s_first_bad - 1);   // truncated data: whole pairs only
+    // runs -> scan positions: q_1 = run_1, q_m = q_{m-1} + 1 + run_m
+    if (tid == 0) s_q = 0ull;
+    __syncthreads();
+    int count = 0;
+    for (int base = 1; base <= nent; base += PARSE_THREADS) {
+        const int m = base + tid;
+        unsigned long long v = m <= nent ? (unsigned long long)(unsigned)R[m] + (m > 1 ? 1ull : 0ull) : 0ull;
+        unsigned long long inc = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            const unsigned long long a = __shfl_up(inc, o);
+            if (lane >= o) inc += a;
+        }
+        __shared__ unsigned long long s_w64[16];
+        if (lane == 63) s_w64[wv] = inc;
+        __syncthreads();
+        unsigned long long q = s_q + inc;
+        for (int w = 0; w < wv; w++) q += s_w64[w];
+        const bool ok = m <= nent && q < (unsigned long long)hp.nscan;
+        if (ok) R[m] = (int32_t)q;
+        count += __syncthreads_count(ok);
+        if (tid == PARSE_THREADS - 1) s_q = q;
+        __syncthreads();
+    }
+    if (tid == 0) jb.dec_cnt[c] = 1 + count;      // positions are increasing: the valid entries are a prefix
+}
+
+// scatter of one level group of the parsed entries (the groups go in order: a cell two scan regions share takes the
+// later region's value): phase 0 = LL + level 0, 1 = level 1, 2 = level 2
+__global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict__ jobs, int c, int phase)
+{
+    const JobDev &jb = jobs[blockIdx.y];
     const HzPlane &hp = jb.hz[c];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    const int n = min(count, jb.dec_cnt[c] - first);
-    if (i >= n) return;
-    const int p = jb.nzpos[jb.nz_off[c] + first + i];
-    const int v = jb.nzval[jb.nz_off[c] + first + i];
+    if (i >= jb.dec_cnt[c]) return;
+    const int p = jb.nzpos[jb.nz_off[c] + i];
+    const int v = jb.nzval[jb.nz_off[c] + i];
     if (p < 0 || p >= hp.nscan) return;
+    const int ph = p >= hp.r[7].base ? 2 : (p >= hp.r[4].base ? 1 : 0);
+    if (ph != phase) return;
     if (p == 0) { (jb.coef + jb.hz_coef_off[c])[0] = v; return; }     // unquantised DC (hzcc.c:495)
     const HzRegion r = hp.r[find_region(hp, p)];
     const int local = p - r.base;
@@ -678,12 +909,19 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
     launch_hz_pack(st, jobs, njobs, job_chunks, pf, samples, nplain);
 }
 
-void launch_hz_scatter(hipStream_t st, const JobDev *jobs, int njobs, int c, int first, int count, Prof *pf)
+// decoder: parse the uploaded plane payloads of `njobs` jobs (plane c) and scatter the entries; max_entries = largest
+// announced run count + 1 over the jobs (sizes the scatter grids)
+void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int max_entries, Prof *pf)
 {
-    if (count <= 0) return;
-    PB(KID_HZ_SCATTER, 0.0);
-    hipLaunchKernelGGL(k_hz_scatter, dim3((count + 255) / 256, njobs), dim3(256), 0, st, jobs, c, first, count);
+    PB(KID_HZ_PARSE, 0.0);
+    hipLaunchKernelGGL(k_hz_parse, dim3(njobs), dim3(PARSE_THREADS), 0, st, jobs, c);
     PE();
+    if (max_entries <= 0) return;
+    for (int ph = 0; ph < 3; ph++) {
+        PB(KID_HZ_SCATTER, 0.0);
+        hipLaunchKernelGGL(k_hz_scatter_lv, dim3((max_entries + 255) / 256, njobs), dim3(256), 0, st, jobs, c, ph);
+        PE();
+    }
 }
 
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst)

@@ -178,6 +178,30 @@ def test_encode_decode_plane(prod, orc, w, h, cur_plane, isP, q):
     A.assert_same("decoded coefficients", db, da, (h, w))
 
 
+@pytest.mark.parametrize("w,h,q", [(352, 288, 16), (960, 540, 313)])
+def test_decode_plane_truncated(prod, orc, w, h, q):
+    """plane data cut short: the decoder stops at the first value whose bits reach the end (hzcc.c:337-339);
+    the device-side parser must stop at the same entry for every cut, down to a few bytes"""
+    rng = np.random.default_rng(w + q)
+    st, keep = stab_for(rng, w, h, 1, 0)
+    co = rng.laplace(0, 60, size=w * h).astype(np.int32)
+    buf = np.zeros(w * h * 8 + 64, dtype=np.uint8)
+    bs = A.BS(A.u8p(buf), 0)
+    work = co.copy()
+    orc.orc_encode_plane(C.byref(bs), C.byref(A.Coefs(A.i32p(work), w, h)), q, C.byref(st))
+    plen = int.from_bytes(buf[:4].tobytes(), "big")
+    for cut in (plen, plen - 1, plen - 2, plen // 2, plen // 3 + 1, 4097, 64, 12, 9):
+        if cut > plen:
+            continue
+        pa = buf[4:4 + plen + 8].copy()
+        pb = pa.copy()
+        da = np.zeros(w * h, dtype=np.int32)
+        db = np.zeros(w * h, dtype=np.int32)
+        orc.orc_decode_plane(A.u8p(pa), cut, C.byref(A.Coefs(A.i32p(da), w, h)), q, C.byref(st))
+        A.chk(prod, prod.dsvg_op_decode_plane(A.u8p(pb), cut, C.byref(A.Coefs(A.i32p(db), w, h)), q, C.byref(st)))
+        A.assert_same("decoded coefficients, %d of %d bytes" % (cut, plen), db, da, (h, w))
+
+
 def test_encode_plane_empty_and_dense(prod, orc):
     """nruns == 0 planes and very long zero runs (UEG > 16 bits), every coefficient non-zero"""
     rng = np.random.default_rng(9)

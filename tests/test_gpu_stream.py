@@ -154,9 +154,19 @@ class Decoder(C.Structure):
 
 @pytest.mark.parametrize("case", [1, 3, 6, 8, 9])
 def test_gpu_decoder_matches_oracle(pkg, orc, case):
-    L = pkg.lib()
     w, h, fmt, n, style, kw = CASES[case]
-    clip = A.gen_clip(w, h, fmt, 0xABC000 + case, n, style=style)
+    _decode_and_compare(pkg, w, h, fmt, n, style, kw, 0xABC000 + case)
+
+
+@pytest.mark.parametrize("kw,n,style", [(dict(qp=95, gop=0, rc_mode_cli=1), 2, 1), (dict(qp=85, gop=12, rc_mode_cli=1), 3, 2)])
+def test_gpu_decoder_1080p(pkg, orc, kw, n, style):
+    """plane payloads far beyond one pass of the device-side entropy parser (16 KB), intra and inter"""
+    _decode_and_compare(pkg, 1920, 1080, A.SUBSAMP_420, n, style, kw, 0xABD001 + n)
+
+
+def _decode_and_compare(pkg, w, h, fmt, n, style, kw, seed):
+    L = pkg.lib()
+    clip = A.gen_clip(w, h, fmt, seed, n, style=style)
     stream, recs = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw), want_recon=True)
     want = A.orc_decode(stream, w, h, fmt)
     L.dsv_alloc.restype = C.c_void_p
