@@ -19,6 +19,30 @@
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
+// store 4 prediction pixels of row `o` (+ the residual clamp(src - pred + 128), bmc.c:43-55); n = pixels that exist
+static __device__ __forceinline__ void mc_store4(uint8_t *pp, uint8_t *xp, const uint8_t *sp, size_t o, const int (&pv)[4], int n,
+                                                 int do_sub, unsigned s)
+{
+    if (n >= 4) {
+        const unsigned pk = (unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24);
+        *reinterpret_cast<unsigned *>(pp + o) = pk;
+        if (do_sub) {
+            unsigned r = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                r |= (unsigned)d_sat8((int)((s >> (8 * k)) & 0xff) - pv[k] + 128) << (8 * k);
+            *reinterpret_cast<unsigned *>(xp + o) = r;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < n) {
+                pp[o + k] = (uint8_t)pv[k];
+                if (do_sub) xp[o + k] = (uint8_t)d_sat8((int)sp[o + k] - pv[k] + 128);
+            }
+    }
+}
+
 __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub, int njobs)
 {
     __shared__ __align__(16) uint8_t win[WROWS * WPITCH];
@@ -49,6 +73,60 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
         xh = dx & 1; yh = dy & 1;
     } else {
         wx = x; wy = y;
+    }
+    if (mv.mode == 0 && !yh) {
+        // Copy and horizontal half-pel blocks use ONE reference row per output row: nothing to share through LDS.
+        // Every thread fetches its 8 reference bytes (x4-1 .. x4+6) and its source dword for up to 8 row passes back
+        // to back (one memory round trip), then filters, subtracts and stores.
+        uint8_t *pp = jb.pred + G.off[c];
+        uint8_t *xp = jb.xf + G.off[c];
+        const uint8_t *sp = jb.src + G.off[c];
+        const int nq = (cw + 3) >> 2;
+        const int lq = bw > 32 ? 4 : (bw > 16 ? 3 : 2);
+        const int x4 = 4 * (tid & ((1 << lq) - 1)), rpp = MC_NT >> lq;
+        if (x4 >= 4 * nq) return;
+        const uint8_t *gr = rp + (long)wy * stride + (wx + x4 - 1);
+        const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
+        const unsigned *ga = reinterpret_cast<const unsigned *>(gr - shb);
+        const int sdw = stride >> 2;
+        const bool full4 = x4 + 4 <= cw;
+#pragma unroll 1
+        for (int y0 = tid >> lq; y0 < ch; y0 += 4 * rpp) {
+            unsigned d0[4], d1[4], d2[4], sv4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int yy = min(y0 + u * rpp, ch - 1);
+                const long ro = (long)yy * sdw;
+                d0[u] = ga[ro]; d1[u] = ga[ro + 1]; d2[u] = ga[ro + 2];
+                sv4[u] = (do_sub && full4) ? *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy) * stride + x + x4) : 0u;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int yy = y0 + u * rpp;
+                if (yy >= ch) break;
+                const unsigned lo = __builtin_amdgcn_alignbyte(d1[u], d0[u], shb), hi = __builtin_amdgcn_alignbyte(d2[u], d1[u], shb);
+                int pv[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int a = (int)(((k + 1 < 4 ? lo : hi) >> (8 * ((k + 1) & 3))) & 0xff);       // ref(x4 + k)
+                    if (!xh) pv[k] = a;
+                    else if (c == 0) {
+                        const int m = (int)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xff);
+                        const int b = (int)(((k + 2 < 4 ? lo : hi) >> (8 * ((k + 2) & 3))) & 0xff);
+                        const int q = (int)(((k + 3 < 4 ? lo : hi) >> (8 * ((k + 3) & 3))) & 0xff);
+                        pv[k] = d_sat8((tap4(m, a, b, q) + 8) >> 4);
+                    } else {
+                        const int b = (int)(((k + 2 < 4 ? lo : hi) >> (8 * ((k + 2) & 3))) & 0xff);
+                        pv[k] = (a + b + 1) >> 1;
+                    }
+                }
+                mc_store4(pp, xp, sp, (size_t)(y + yy) * stride + x + x4, pv, cw - x4, do_sub, sv4[u]);
+                if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
+                    xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * stride + pw - 1];
+            }
+        }
+        return;
     }
     // stage rows wy-1 .. wy+ch+1, columns wx-1 .. wx+cw+1 with aligned dword loads
     const long rowbase = (long)(wy - 1) * stride + (wx - 1);
@@ -189,25 +267,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
             }
         }
         const size_t o = (size_t)(y + yy) * stride + x + x4;
-        if (x4 + 4 <= cw) {
-            const unsigned pk = (unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24);
-            *reinterpret_cast<unsigned *>(pp + o) = pk;
-            if (do_sub) {
-                const unsigned s = s_cur;
-                unsigned r = 0;
-#pragma unroll
-                for (int k = 0; k < 4; k++)
-                    r |= (unsigned)d_sat8((int)((s >> (8 * k)) & 0xff) - pv[k] + 128) << (8 * k);
-                *reinterpret_cast<unsigned *>(xp + o) = r;
-            }
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (x4 + k < cw) {
-                    pp[o + k] = (uint8_t)pv[k];
-                    if (do_sub) xp[o + k] = (uint8_t)d_sat8((int)sp[o + k] - pv[k] + 128);
-                }
-        }
+        mc_store4(pp, xp, sp, o, pv, cw - x4, do_sub, s_cur);
         // odd plane width whose coefficient plane is one wider: the transform reads column pw of the
         // residual frame, which in the reference still holds the replicated source edge (frame.c:199-221)
         if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
