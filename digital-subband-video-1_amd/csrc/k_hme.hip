@@ -85,8 +85,7 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 struct HmeShared {
     // the 9-point window is dead once its SADs are reduced; the half-pel patch + lattice reuse its space
     // until the zero-motion block is staged there for the statistics
-    union {
-        __attribute__((aligned(16))) uint8_t ref[RROWS * RP];
+    struct {
         struct {
             __attribute__((aligned(16))) uint8_t patch[20 * 24];
             __attribute__((aligned(16))) uint8_t lat[LAT * LAT];
@@ -163,16 +162,29 @@ static __device__ const int HP_X[8] = {1, -1, 0, 0, -1, 1, -1, 1};
 static __device__ const int HP_Y[8] = {0, 0, 1, -1, -1, -1, 1, 1};
 
 // gradient / moment partial sums of a 14x14 byte window in LDS (pitch P), one pixel per thread (tid < 196)
-static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
+// gradient / moment partial sums of a 14x14 byte window in LDS (pitch P bytes, first pixel at byte `mis` of the
+// row): one dword (4 px) per lane -- lane = 4 * row + dword -- with v_sad_u8 / v_dot4 instead of per-pixel loops
+static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, int mis, unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
 {
     gh = gv = s1 = s2 = 0;
-    for (int t = threadIdx.x; t < WIN * WIN; t += NT) {
-        const int y = t / WIN, x = t - y * WIN;
-        const int px = p[y * P + x];
-        if (x + 1 < WIN) gh += (unsigned)abs(px - (int)p[y * P + x + 1]);
-        if (y > 0) gv += (unsigned)abs(px - (int)p[(y - 1) * P + x]);
-        s1 += (unsigned)px;
-        s2 += (unsigned)(px * px);
+    const int r = threadIdx.x >> 2, d = threadIdx.x & 3;
+    if (threadIdx.x < 4 * WIN) {
+        const unsigned sh = (unsigned)(mis & 3);
+        const unsigned *w = reinterpret_cast<const unsigned *>(p + r * P) + (mis >> 2) + d;
+        const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
+        const unsigned m = d == 3 ? 0xffffu : 0xffffffffu;          // pixels 12,13 only in the last dword
+        const unsigned pm = d == 3 ? 0xffu : 0xffffffffu;           // pairs (x, x+1) exist while x + 1 < 14
+        const unsigned cur = __builtin_amdgcn_alignbyte(w1, w0, sh);
+        const unsigned nxt = __builtin_amdgcn_alignbyte(w2, w1, sh);
+        const unsigned right = __builtin_amdgcn_alignbyte(nxt, cur, 1u);
+        gh = __builtin_amdgcn_sad_u8(cur & pm, right & pm, 0u);
+        if (r > 0) {
+            const unsigned *u = reinterpret_cast<const unsigned *>(p + (r - 1) * P) + (mis >> 2) + d;
+            const unsigned up = __builtin_amdgcn_alignbyte(u[1], u[0], sh);
+            gv = __builtin_amdgcn_sad_u8(cur & m, up & m, 0u);
+        }
+        s1 = __builtin_amdgcn_sad_u8(cur & m, 0u, 0u);
+        s2 = __builtin_amdgcn_udot4(cur & m, cur & m, 0u, false);
     }
 }
 
@@ -443,12 +455,16 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
             S.rwin[y * 16 + x] = S.u.hp.patch[y * 24 + pmis + x];
         }
     }
-    // zero-motion reference block -> LDS (needed by the variance test, the veto and the quadrant votes)
-    __syncthreads();
-    const int zmis = load_win<32, RROWS>(S.u.ref, RP, rp, stride, bx, by, bw, bh);       // bx is 4-aligned => zmis == 0
-    __syncthreads();
-    const uint8_t *zref = S.u.ref + zmis;
-
+    // the zero-motion reference block (variance test, veto, quadrant votes) is read straight from global memory:
+    // bx + 4cg is dword aligned, every thread takes the rows it owns
+    __syncthreads();                                    // rwin complete
+    unsigned zrow[NK];
+    {
+        const unsigned *zp = reinterpret_cast<const unsigned *>(rp + (long)(by + r0) * stride + bx + xcol);
+        const int sdw = stride >> 2;
+#pragma unroll
+        for (int kk = 0; kk < NK; kk++) zrow[kk] = (cmask && r0 < bh) ? zp[(long)min(kk, nkb - 1) * sdw] : 0u;
+    }
     // ---- statistics: one fused pass + one 8-value and one 10-value reduction
     unsigned st[8];                 // src block gh,gv,s1,s2 ; zref s1,s2 ; spare
 #pragma unroll
@@ -475,7 +491,7 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
                 if (r > 0) st[1] = __builtin_amdgcn_sad_u8(curw, upw, st[1]);
                 st[2] = __builtin_amdgcn_sad_u8(curw, 0u, st[2]);
                 st[3] = __builtin_amdgcn_udot4(curw, curw, st[3], false);
-                const unsigned zw = *reinterpret_cast<const unsigned *>(zref + r * RP + xcol) & cmask;
+                const unsigned zw = zrow[kk] & cmask;
                 st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
                 st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
             }
@@ -484,8 +500,8 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     }
     // block statistics and the two 14x14 window statistics share one reduction
     unsigned ws[14];
-    win_partial(S.swin + smis, 24, ws[0], ws[1], ws[2], ws[3]);
-    win_partial(S.rwin, 16, ws[4], ws[5], ws[6], ws[7]);
+    win_partial(S.swin, 24, smis, ws[0], ws[1], ws[2], ws[3]);
+    win_partial(S.rwin, 16, 0, ws[4], ws[5], ws[6], ws[7]);
 #pragma unroll
     for (int k = 0; k < 6; k++) ws[8 + k] = st[k];
     block_sum_n<14>(ws, S.part, phase);
@@ -560,14 +576,15 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
                 const int x = xcol + b4;
                 if (x >= bw) continue;
                 const uint8_t *sx = sp + (size_t)(by + r) * stride + bx + x;     // rare path: source pixels straight from global
-                const int pa = sx[0], pb = zref[r * RP + x];
+                const uint8_t *zx = rp + (size_t)(by + r) * stride + bx + x;     // and the co-located reference pixels
+                const int pa = sx[0], pb = zx[0];
                 const int back = d_sat8(mean + d_sat8(pa - mean + 128) - 128);
                 qv[0] += (back != pa);
                 if (x < 2 * qw && r < 2 * qh) {
                     const int qx = x >= qw, qy = r >= qh;
                     const int lx = x - qx * qw, ly = r - qy * qh;        // position inside the quadrant
-                    const int la = lx ? sx[-1] : pa, lb = lx ? zref[r * RP + x - 1] : pb;
-                    const int ua = ly ? sx[-stride] : pa, ub = ly ? zref[(r - 1) * RP + x] : pb;
+                    const int la = lx ? sx[-1] : pa, lb = lx ? zx[-1] : pb;
+                    const int ua = ly ? sx[-stride] : pa, ub = ly ? zx[-stride] : pb;
                     const int dif = abs(pa - pb);
                     unsigned good = (unsigned)(abs(pa - la) + abs(pa - ua) + abs(pb - lb) + abs(pb - ub));
                     unsigned evil = 0;

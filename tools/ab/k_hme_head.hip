@@ -266,18 +266,23 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
                         const unsigned sh = (unsigned)(((uintptr_t)p0) & 3);
                         const unsigned *pa = reinterpret_cast<const unsigned *>(p0 - sh);
                         const int sdw = stride >> 2;
-                        unsigned lo[NK], hi[NK];
+                        constexpr int CB = 8;                      // rows per batch (registers)
 #pragma unroll
-                        for (int kk = 0; kk < NK; kk++) {
-                            const long o = (long)min(kk, nkb - 1) * sdw;
-                            lo[kk] = pa[o]; hi[kk] = pa[o + 1];
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
+                        for (int b0 = 0; b0 < NK; b0 += CB) {
+                            unsigned lo[CB], hi[CB];
 #pragma unroll
-                        for (int kk = 0; kk < NK; kk++) {
-                            const unsigned rw = __builtin_amdgcn_alignbyte(hi[kk], lo[kk], sh) & cmask;
-                            const unsigned a6 = __builtin_amdgcn_sad_u8(srcw[kk], rw, acc[k]);
-                            acc[k] = ROWOK(kk) ? a6 : acc[k];
+                            for (int u = 0; u < CB; u++) {
+                                const long o = (long)min(b0 + u, nkb - 1) * sdw;
+                                lo[u] = pa[o]; hi[u] = pa[o + 1];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < CB; u++) {
+                                const unsigned rw = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh) & cmask;
+                                const unsigned a6 = __builtin_amdgcn_sad_u8(srcw[b0 + u], rw, acc[k]);
+                                acc[k] = ROWOK(b0 + u) ? a6 : acc[k];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 }
@@ -315,12 +320,12 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
             const int sdw = stride >> 2;
             // all row loads are issued back to back (no branch in between: one memory round trip, not NK+2);
             // rows past the thread's last reference row re-read that row
-            // two batches of five row loads, each issued back to back (one memory round trip per batch instead of
-            // one per row) -- a single batch of ten would cost two waves of occupancy in registers
+            // three batches of six row loads, each issued back to back (one memory round trip per batch instead of
+            // one per row) -- a single batch would cost occupancy in registers
             unsigned v[3][3];                                      // rolling: v[t % 3][ox] = reference row t, offset ox
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                constexpr int HB = (NK + 2) / 2;
+            for (int half = 0; half < 3; half++) {
+                constexpr int HB = (NK + 2) / 3;
                 unsigned d[HB][3];
 #pragma unroll
                 for (int u = 0; u < HB; u++) {
