@@ -165,6 +165,8 @@ def main():
             e = T.get("kernels", {}).get(prof_kernel)
             if e and "hbm_bytes_per_launch" in e:
                 kinfo["traffic"] = round(e["hbm_bytes_per_launch"] * args.gops / T["gops"])
+                if "hbm_bytes_per_launch_raw" in e:      # FETCH_SIZE + WRITE_SIZE as reported, no read-side doubling
+                    kinfo["traffic_raw"] = round(e["hbm_bytes_per_launch_raw"] * args.gops / T["gops"])
                 kinfo["traffic_source"] = T.get("source", "profiles/pmc_traffic.json")
             if e and e.get("valu_insts_per_launch") and ms > 0:
                 # integer/byte kernels can be bound by VALU issue rather than HBM: a wave64 VALU instruction holds

@@ -22,7 +22,8 @@ for r in rows:
     f = float(r.get("FETCH_SIZE_per_launch", 0) or 0)
     w = float(r.get("WRITE_SIZE_per_launch", 0) or 0)
     out["kernels"][r["kernel"]] = {"launches": int(r["launches"]), "fetch_kib_per_launch": f, "write_kib_per_launch": w,
-                                   "hbm_bytes_per_launch": round((2 * f + w) * 1024)}
+                                   "hbm_bytes_per_launch": round((2 * f + w) * 1024),
+                                   "hbm_bytes_per_launch_raw": round((f + w) * 1024)}
 if len(sys.argv) > 4:
     for r in csv.DictReader(open(sys.argv[4])):
         e = out["kernels"].setdefault(r["kernel"], {"launches": int(r["launches"])})
