@@ -71,7 +71,7 @@ int download_frame(OpScope &S, dsvg_frame *f, const FrameLayout &L, const uint8_
 
 int check_plane_dims(int W, int H, int isP)
 {
-    if (W < 16 || H < 16 || (W <= 32 && H <= 32)) { dsvg_set_error("plane %dx%d too small (needs >= 6 transform levels)", W, H); return DSVG_ERR_UNSUPPORTED; }
+    if (W < 8 || H < 8) { dsvg_set_error("plane %dx%d too small (needs >= 3 transform levels)", W, H); return DSVG_ERR_UNSUPPORTED; }
     if (!isP && ((W | H) & 1)) {
         dsvg_set_error("intra transform needs even plane dims (reference leaves stale temp words for odd n)");
         return DSVG_ERR_UNSUPPORTED;

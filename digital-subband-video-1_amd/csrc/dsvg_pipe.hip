@@ -127,7 +127,6 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
             dsvg_set_error("plane %dx%d: LL5 band does not fit the LDS tail kernel", CL.w[p], CL.h[p]);
             delete c; return DSVG_ERR_UNSUPPORTED;
         }
-        if (CL.lvls[p] < 6) { dsvg_set_error("plane too small (needs >= 6 transform levels)"); delete c; return DSVG_ERR_UNSUPPORTED; }
     }
     if ((width | height) & 1) { dsvg_set_error("odd luma dimensions are not supported (intra B4T needs even planes)"); delete c; return DSVG_ERR_UNSUPPORTED; }
     McGeo &MG = c->MG;

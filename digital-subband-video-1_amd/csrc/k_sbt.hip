@@ -406,7 +406,11 @@ __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__
         }
     const int wo1 = DSVG_RSU(W, LV), ho1 = DSVG_RSU(H, LV);
     int l2[2][2], l3[1][1];
+    // tiny planes (<= 16 samples a side) have fewer levels than this kernel covers: the band is 1x1 by then and the
+    // absent levels pass it through unchanged (sbt.c:617-628 stops at lvls)
+    if (LV > g.lvls) { out[0] = a[0][0]; return; }
     haar_fwd_patch<4>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true);     // levels >= 2 are always scaled
+    if (LV + 1 > g.lvls) { out[0] = l2[0][0]; return; }
     haar_fwd_patch<2>(l2, l3, I, J, wo1, ho1, W, ow, oh, coef, true);
     out[(size_t)J * ow + I] = l3[0][0];
 }
@@ -795,6 +799,24 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     const int tid = threadIdx.x;
     const bool isP = jb.isP != 0;
 
+    if (MODE == 2 && g.lvls < 5) {
+        // tiny planes (<= 16 samples a side): level 5 (and 4) do not exist, the 1x1 band passes through
+        if (blockIdx.x | blockIdx.y | tid) return;
+        int32_t *s3o = jb.s3 + g.s3off;
+        const int ll = s3[0];
+        if (g.lvls == 4) {
+            const LvlGeo L4 = mk_lvl(W, H, 4, jb.hqp[4], true);
+            const auto D4 = mk_det<false, 0>(jb, c, coef, W, L4);
+            int o[4];
+            inv_cell<FILT>(&ll, 1, 0, 0, L4, D4, o);
+            const int w3o = DSVG_RSU(W, 3), h3o = DSVG_RSU(H, 3);
+            s3o[0] = o[0];
+            if (w3o > 1) s3o[1] = o[1];
+            if (h3o > 1) s3o[w3o] = o[2];
+            if (w3o > 1 && h3o > 1) s3o[w3o + 1] = o[3];
+        } else s3o[0] = ll;
+        return;
+    }
     // ---- phase 0: EVERY global load of the tile is issued here, before the first barrier, so the three level
     // phases below only wait on LDS: one memory round trip per workgroup instead of one per phase and loop pass.
     static_assert(A3H * A3W <= 256 && (IT_TY + 2) * (IT_TX + 2) <= 256, "one pass per thread");
@@ -1033,7 +1055,7 @@ int sbt_tail_supported(const SbtGeo &g)
 {
     const long n5 = (long)g.w5 * g.h5;
     if (n5 * 4 > 160 * 1024 - 256) return 0;
-    if (g.lvls < TAIL_LV) return 0;
+    if (g.lvls < 3) return 0;                       // planes of at most 4 samples a side do not occur (luma >= 32)
     const long c6 = (long)DSVG_RSU(g.W, TAIL_LV) * DSVG_RSU(g.H, TAIL_LV);
     return c6 <= (long)TAIL_MAXC * TAIL_THREADS;
 }

@@ -89,6 +89,7 @@ void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
     }
     if (style == 1) {
         int sq = w < 192 ? w / 4 : 96;
+        if (sq > h - 8) sq = h - 8;                   /* very flat frames: keep the square inside */
         int sx = (37 * t) % (w - sq), sy = (23 * t) % (h - sq);
         int lvl = 40 + 15 * t; if (lvl > 250) lvl = 250;
         for (int y = 0; y < sq; y++) memset(Y + (size_t)(sy + y) * w + sx, lvl, (size_t)sq);
@@ -98,6 +99,7 @@ void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
 
     if (style == 2) {
         int sq = w < 192 ? w / 4 : 88;
+        if (sq > h - 8) sq = h - 8;
         int sx = 9 + (37 * t) % (w - sq - 9), sy = 5 + (23 * t) % (h - sq - 5);
         for (int y = 0; y < sq; y++)
             for (int x = 0; x < sq; x++) {

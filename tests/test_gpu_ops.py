@@ -36,7 +36,8 @@ def mk_frame(rng, w, h, fmt, orc, smooth=True):
     return f
 
 
-SBT_CASES = [(40, 36), (32, 48), (176, 144), (352, 288), (250, 130), (960, 540), (1920, 1080), (100, 36)]
+SBT_CASES = [(40, 36), (32, 48), (176, 144), (352, 288), (250, 130), (960, 540), (1920, 1080), (100, 36),
+             (20, 30), (16, 16), (8, 32), (16, 10), (32, 32), (8, 8)]      # planes with 5, 4 and 3 transform levels
 
 
 @pytest.mark.parametrize("w,h", SBT_CASES)
@@ -141,7 +142,7 @@ def explain_plane_diff(got, want):
     return "; ".join(msg)
 
 
-HZ_CASES = [(352, 288, 0), (176, 144, 1), (960, 540, 1), (250, 130, 0), (1920, 1080, 0), (64, 64, 0)]
+HZ_CASES = [(352, 288, 0), (176, 144, 1), (960, 540, 1), (250, 130, 0), (1920, 1080, 0), (64, 64, 0), (16, 16, 1), (20, 30, 0), (8, 8, 1)]
 
 
 @pytest.mark.parametrize("w,h,cur_plane", HZ_CASES)
