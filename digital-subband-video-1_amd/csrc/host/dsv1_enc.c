@@ -24,6 +24,7 @@ typedef struct {
     unsigned prefix_len;
 } pic_t;
 
+typedef struct { uint8_t *pkt; size_t cap; } pkt_scratch;   /* packet staging buffer (one per assembling thread) */
 struct dsv1_batch {
     dsvg_ctx *ctx;
     dsvg_geom g;
@@ -44,17 +45,72 @@ struct dsv1_batch {
     DSV_MV *mv_tmp;
     dsvg_pic_job *jobs;
     dsvg_pic_out *outs;
-    uint8_t *pkt;
-    size_t pkt_cap;
+    pkt_scratch sc0;                 /* packet staging of the serial (ABR / single-frame) path */
 };
 
 /* source slot of frame number g (per-stream counter) of stream s */
+/* host-side phase timing (DSV1_HOST_PROF=1): where a batch's wall time goes inside submit / collect */
+#include <time.h>
+enum { HP_LOAD, HP_DECIDE, HP_ANALYSE, HP_SIDEINFO, HP_ENQUEUE, HP_FETCH, HP_ASSEMBLE, HP_N };
+static double hp_acc[HP_N];
+static long hp_batches;
+static int hp_on = -1;
+static double hp_now(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec * 1e3 + (double)ts.tv_nsec * 1e-6;
+}
+#define HP_BEGIN() double hp_t0_ = hp_on > 0 ? hp_now() : 0.0
+#define HP_MARK(k) do { if (hp_on > 0) { const double n_ = hp_now(); hp_acc[k] += n_ - hp_t0_; hp_t0_ = n_; } } while (0)
+static void hp_report(void)
+{
+    static const char *nm[HP_N] = {"load+pyramid (enqueue, luma sums wait)", "GOP / scene-change decisions", "motion search (enqueue + GPU wait + D2H)",
+                                   "stability + motion side info", "job tables + coding enqueue", "fetch (GPU wait + gather + D2H)", "packet assembly"};
+    int k;
+    if (hp_on <= 0 || !hp_batches) return;
+    for (k = 0; k < HP_N; k++) fprintf(stderr, "[dsv1 host] %-44s %8.3f ms / batch\n", nm[k], hp_acc[k] / (double)hp_batches);
+}
+
+/* The per-stream host phases (side info, packet assembly) are independent across streams: a plain pthread
+ * fork/join over them.  Threads: DSV1_HOST_THREADS (default 6), never more than streams. */
+#include <pthread.h>
+typedef void (*par_fn)(void *ctx, int s, int tid);
+typedef struct { par_fn fn; void *ctx; int tid, nthr, S; } par_arg;
+static void *par_main(void *p)
+{
+    par_arg *a = (par_arg *)p;
+    int s;
+    for (s = a->tid; s < a->S; s += a->nthr) a->fn(a->ctx, s, a->tid);
+    return NULL;
+}
+static int par_threads(int S)
+{
+    static int n = 0;
+    if (!n) { const char *e = getenv("DSV1_HOST_THREADS"); n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 64) n = 64; }
+    return n < S ? n : S;
+}
+static void par_for_streams(int S, par_fn fn, void *ctx)
+{
+    const int nthr = par_threads(S);
+    pthread_t th[64];
+    par_arg a[64];
+    int i, started = 0;
+    for (i = 0; i < nthr; i++) { a[i].fn = fn; a[i].ctx = ctx; a[i].tid = i; a[i].nthr = nthr; a[i].S = S; }
+    for (i = 1; i < nthr; i++, started++)
+        if (pthread_create(&th[i], NULL, par_main, &a[i]) != 0) break;
+    par_main(&a[0]);
+    for (i = started + 1; i < nthr; i++) { int s; for (s = i; s < S; s += nthr) fn(ctx, s, 0); }   /* threads that did not start */
+    for (i = 1; i <= started; i++) pthread_join(th[i], NULL);
+}
+
 static int slot_of(const dsv1_batch *b, int s, unsigned g) { return (int)(g % (unsigned)b->rows) * b->nstreams + s; }
 
 void *dsv1_batch_ctx(dsv1_batch *b) { return b ? (void *)b->ctx : NULL; }
 
 void dsv1_batch_close(dsv1_batch *b)
 {
+    hp_report();
     if (!b) return;
     if (b->yuv_dev) dsvg_dev_free(b->ctx, b->yuv_dev);
     if (b->ctx) dsvg_ctx_destroy(b->ctx);
@@ -68,7 +124,7 @@ void dsv1_batch_close(dsv1_batch *b)
     }
     free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
-    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->pkt);
+    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt);
     free(b);
 }
 
@@ -102,8 +158,8 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
     b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
     b->outs = (dsvg_pic_out *)calloc((size_t)np, sizeof(dsvg_pic_out));
-    b->pkt_cap = (size_t)b->prefix_cap + b->g.plane_out_cap[0] + 2 * b->g.plane_out_cap[1] + 256;
-    b->pkt = (uint8_t *)malloc(b->pkt_cap);
+    b->sc0.cap = (size_t)b->prefix_cap + b->g.plane_out_cap[0] + 2 * b->g.plane_out_cap[1] + 256;
+    b->sc0.pkt = (uint8_t *)malloc(b->sc0.cap);
     for (i = 0; i < 2 * np; i++) {
         b->pics[i].mvs = b->mvpool + (size_t)i * b->nblk;
         b->pics[i].stable = b->stabpool + (size_t)i * b->nblk;
@@ -326,7 +382,7 @@ static void link_packet(DSV_ENCODER *e, uint8_t *pkt, unsigned len, int eos)   /
 
 /* picture packet = prefix + quantiser + three framed planes (encode_picture :518-536,
  * dsv_encode_plane hzcc.c:449-476); then metadata-first emission and RC statistics (dsv_enc :804-853) */
-static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV_BUF *out)
+static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV_BUF *out, pkt_scratch *sc)
 {
     DSV_ENCODER *e = &b->enc[s];
     bitw w;
@@ -334,10 +390,10 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     int p;
     size_t need = (size_t)pc->prefix_len + 64;
     for (p = 0; p < 3; p++) need += po->nbytes[p] + 32;
-    if (need > b->pkt_cap) { b->pkt_cap = need * 2; b->pkt = (uint8_t *)realloc(b->pkt, b->pkt_cap); }
-    memset(b->pkt, 0, need);
-    memcpy(b->pkt, pc->prefix, pc->prefix_len);
-    bw_init(&w, b->pkt);
+    if (need > sc->cap) { sc->cap = need * 2; sc->pkt = (uint8_t *)realloc(sc->pkt, sc->cap); }
+    memset(sc->pkt, 0, need);
+    memcpy(sc->pkt, pc->prefix, pc->prefix_len);
+    bw_init(&w, sc->pkt);
     w.pos = pc->prefix_len * 8;
     bw_bits(&w, 11, (unsigned)pc->quant);
     for (p = 0; p < 3; p++) {
@@ -353,7 +409,7 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
         bw_bits(&w, 8, 0x55);
         bw_align(&w);
         endp = bw_bytes(&w);
-        put_be32(b->pkt + startp, endp - startp - 4);
+        put_be32(sc->pkt + startp, endp - startp - 4);
     }
     bw_align(&w);
     len = bw_bytes(&w);
@@ -364,8 +420,73 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
         if (dsv1_buf_append(out, mb, n)) return DSVG_ERR_ARG;
     }
     rc_after_packet(e, pc->isP, len);
-    link_packet(e, b->pkt, len, 0);
-    return dsv1_buf_append(out, b->pkt, len) ? DSVG_ERR_ARG : DSVG_OK;
+    link_packet(e, sc->pkt, len, 0);
+    return dsv1_buf_append(out, sc->pkt, len) ? DSVG_ERR_ARG : DSVG_OK;
+}
+
+typedef struct { dsv1_batch *b; pic_t *pics; } side_ctx;
+static void side_stream(void *ctx, int s, int tid)
+{
+    side_ctx *c = (side_ctx *)ctx;
+    dsv1_batch *b = c->b;
+    const int F = b->F, nblk = b->nblk;
+    DSV_ENCODER *e = &b->enc[s];
+    uint8_t *tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
+    int t;
+    (void)tid;
+    for (t = 0; t < F; t++) {
+        pic_t *pc = &c->pics[s * F + t];
+        bitw w;
+        if (pc->has_ref) {
+            int nintra = 0, i;
+            for (i = 0; i < nblk; i++) nintra += pc->mvs[i].mode != 0;
+            pc->forced_intra = 0;
+            if (nintra * 100 / nblk > e->intra_pct_thresh) { pc->has_ref = 0; pc->forced_intra = 1; }
+        }
+        pc->isP = pc->has_ref;
+        memset(pc->prefix, 0, (size_t)b->prefix_cap);
+        bw_init(&w, pc->prefix);
+        write_pkt_hdr(&w, DSV_PT_PIC | (pc->is_ref << 1) | pc->has_ref);
+        bw_align(&w);
+        bw_bits(&w, 32, pc->fnum);
+        bw_align(&w);
+        bw_ueg(&w, (unsigned)b->g.blk_w >> 2);
+        bw_ueg(&w, (unsigned)b->g.blk_h >> 2);
+        bw_align(&w);
+        stability_pass(e, pc, nblk, &w, tmp);
+        if (pc->isP) e->refresh_ctr++;               /* dsv_enc dsv_encoder.c:812-814 */
+        if (pc->has_ref) {
+            bw_align(&w);
+            motion_pass(b, pc, &w, tmp);
+        }
+        bw_align(&w);
+        pc->prefix_len = bw_bytes(&w);
+    }
+    free(tmp);
+}
+
+/* packet assembly of one stream of a collected batch (its own staging buffer per thread) */
+typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc; } asm_ctx;
+static void asm_stream(void *ctx, int s, int tid)
+{
+    asm_ctx *c = (asm_ctx *)ctx;
+    dsv1_batch *b = c->b;
+    const int F = b->F;
+    pkt_scratch sc = {NULL, 0};
+    size_t need = 0;
+    int t, p;
+    (void)tid;
+    for (t = 0; t < F; t++) {
+        const dsvg_pic_out *po = &b->outs[s * F + t];
+        need += (size_t)c->pics[s * F + t].prefix_len + 192;
+        for (p = 0; p < 3; p++) need += po->nbytes[p] + 32;
+    }
+    if (dsv1_buf_reserve(&c->out[s], (unsigned)need)) { c->rc = DSVG_ERR_ARG; return; }
+    for (t = 0; t < F; t++) {
+        const int rc = assemble(b, s, &c->pics[s * F + t], &b->outs[s * F + t], &c->out[s], &sc);
+        if (rc) { c->rc = rc; break; }
+    }
+    free(sc.pkt);
 }
 
 /* Submit one batch: all source-only analysis now (analysis stream), per-stream decisions and side info
@@ -379,10 +500,11 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     size_t fb;
     const DSV_ENCODER *e0;
     const uint8_t *dyuv = (const uint8_t *)yuv;
-    uint8_t *tmp;
     pic_t *pics;
 
     if (!b || !yuv) return DSVG_ERR_ARG;
+    if (hp_on < 0) hp_on = getenv("DSV1_HOST_PROF") != NULL;
+    HP_BEGIN();
     S = b->nstreams; F = b->F; nblk = b->nblk; fb = b->g.frame_bytes;
     e0 = &b->enc[0];
     with_pyr = e0->gop != DSV_GOP_INTRA;
@@ -409,6 +531,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     if (with_pyr && e0->do_scd)
         if ((rc = dsvg_get_luma_sums(b->ctx, 0, b->rows * S, b->luma))) return rc;
 
+    HP_MARK(HP_LOAD);
     /* 2. per stream, in coding order: GOP / scene-change decisions; collect ME pairs */
     for (s = 0; s < S; s++) {
         DSV_ENCODER *e = &b->enc[s];
@@ -448,46 +571,21 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
             }
         }
     }
+    HP_MARK(HP_DECIDE);
     /* 3. motion estimation for every inter candidate of the batch in one go */
     if (npairs) {
         if ((rc = dsvg_analyse(b->ctx, npairs, b->slots_cur, b->slots_ref, (dsvg_mv *)b->mv_tmp))) return rc;
         for (k = 0; k < npairs; k++)
             memcpy(pics[b->pair_pic[k]].mvs, b->mv_tmp + (size_t)k * nblk, (size_t)nblk * sizeof(DSV_MV));
     }
+    HP_MARK(HP_ANALYSE);
     /* 4. per stream, in coding order: forced intra, stability + motion side info -> packet prefix */
-    tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
-    for (s = 0; s < S; s++) {
-        DSV_ENCODER *e = &b->enc[s];
-        for (t = 0; t < F; t++) {
-            pic_t *pc = &pics[s * F + t];
-            bitw w;
-            if (pc->has_ref) {
-                int nintra = 0, i;
-                for (i = 0; i < nblk; i++) nintra += pc->mvs[i].mode != 0;
-                pc->forced_intra = 0;
-                if (nintra * 100 / nblk > e->intra_pct_thresh) { pc->has_ref = 0; pc->forced_intra = 1; }
-            }
-            pc->isP = pc->has_ref;
-            memset(pc->prefix, 0, (size_t)b->prefix_cap);
-            bw_init(&w, pc->prefix);
-            write_pkt_hdr(&w, DSV_PT_PIC | (pc->is_ref << 1) | pc->has_ref);
-            bw_align(&w);
-            bw_bits(&w, 32, pc->fnum);
-            bw_align(&w);
-            bw_ueg(&w, (unsigned)b->g.blk_w >> 2);
-            bw_ueg(&w, (unsigned)b->g.blk_h >> 2);
-            bw_align(&w);
-            stability_pass(e, pc, nblk, &w, tmp);
-            if (pc->isP) e->refresh_ctr++;               /* dsv_enc dsv_encoder.c:812-814 */
-            if (pc->has_ref) {
-                bw_align(&w);
-                motion_pass(b, pc, &w, tmp);
-            }
-            bw_align(&w);
-            pc->prefix_len = bw_bytes(&w);
-        }
+    {
+        side_ctx sc_;
+        sc_.b = b; sc_.pics = pics;
+        par_for_streams(S, side_stream, &sc_);
     }
-    free(tmp);
+    HP_MARK(HP_SIDEINFO);
     /* 5. residual coding, frame step by frame step across all streams */
     {
         const int serial = e0->rc_mode != DSV_RATE_CONTROL_CRF;
@@ -510,12 +608,14 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                 for (s = 0; s < S; s++) b->out_slots[s] = pics[s * F + t].out_slot;
                 if ((rc = dsvg_fetch_pictures(b->ctx, S, b->out_slots, b->outs))) return rc;
                 for (s = 0; s < S; s++)
-                    if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s]))) return rc;
+                    if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s], &b->sc0))) return rc;
             }
         }
         if (!serial && (rc = dsvg_code_batch(b->ctx, F, S, b->jobs))) return rc;   /* whole batch, one upload */
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
     }
+    HP_MARK(HP_ENQUEUE);
+    hp_batches++;
     b->gcount += (unsigned)F;
     b->parity ^= 1;
     return DSVG_OK;
@@ -530,7 +630,7 @@ int dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
  * stream order.  The packets of stream s are appended to out[s]. */
 int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
 {
-    int par, S, F, k, s, t, rc;
+    int par, S, F, k, rc;
     pic_t *pics;
     if (!b || !out) return DSVG_ERR_ARG;
     S = b->nstreams; F = b->F;
@@ -538,11 +638,17 @@ int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
     if (!b->pending[par]) { dsv1_log(1, "nothing to collect"); return DSVG_ERR_ARG; }
     pics = b->pics + (size_t)par * S * F;
     if (b->pending[par] == 1) {
+        HP_BEGIN();
         for (k = 0; k < S * F; k++) b->out_slots[k] = pics[k].out_slot;
         if ((rc = dsvg_fetch_pictures(b->ctx, S * F, b->out_slots, b->outs))) return rc;
-        for (s = 0; s < S; s++)
-            for (t = 0; t < F; t++)
-                if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s * F + t], &out[s]))) return rc;
+        HP_MARK(HP_FETCH);
+        {
+            asm_ctx ac;
+            ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK;
+            par_for_streams(S, asm_stream, &ac);
+            if (ac.rc) return ac.rc;
+        }
+        HP_MARK(HP_ASSEMBLE);
     }
     b->pending[par] = 0;
     return DSVG_OK;

@@ -67,6 +67,7 @@ static inline unsigned get_be32(const uint8_t *p)
 
 /* append n bytes to a dsv_alloc-backed growing DSV_BUF (capacity kept in a hidden word before data) */
 int  dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n);
+int  dsv1_buf_reserve(DSV_BUF *b, unsigned n);
 void dsv1_log(int level, const char *fmt, ...);
 extern int dsv1_device;
 

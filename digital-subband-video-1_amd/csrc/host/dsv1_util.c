@@ -34,8 +34,8 @@ void *dsv_alloc(int size)
     uint8_t *p = (uint8_t *)calloc(1, (size_t)size + 16);
     if (!p) return NULL;
     *(int32_t *)p = size;
-    g_nalloc++;
-    g_balloc += (unsigned)size;
+    __atomic_fetch_add(&g_nalloc, 1u, __ATOMIC_RELAXED);       /* the batch encoder allocates from worker threads */
+    __atomic_fetch_add(&g_balloc, (unsigned)size, __ATOMIC_RELAXED);
     return p + 16;
 }
 
@@ -44,8 +44,8 @@ void dsv_free(void *ptr)
     uint8_t *p;
     if (!ptr) return;
     p = (uint8_t *)ptr - 16;
-    g_nfree++;
-    g_bfree += (unsigned)*(int32_t *)p;
+    __atomic_fetch_add(&g_nfree, 1u, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&g_bfree, (unsigned)*(int32_t *)p, __ATOMIC_RELAXED);
     free(p);
 }
 
@@ -68,6 +68,22 @@ void dsv_buf_free(DSV_BUF *buf)
         dsv_free(buf->data);
         buf->data = NULL;
     }
+}
+
+/* make room for n more bytes (one allocation instead of a chain of doublings) */
+int dsv1_buf_reserve(DSV_BUF *b, unsigned n)
+{
+    unsigned cap = b->data ? (unsigned)*(int32_t *)(b->data - 16) : 0;
+    if (b->len + n > cap) {
+        unsigned char *nd = (unsigned char *)dsv_alloc((int)(b->len + n + 64));
+        if (!nd) return -1;
+        if (b->data) {
+            memcpy(nd, b->data, b->len);
+            dsv_free(b->data);
+        }
+        b->data = nd;
+    }
+    return 0;
 }
 
 int dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n)
