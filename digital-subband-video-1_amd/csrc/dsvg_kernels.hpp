@@ -40,7 +40,8 @@ void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int
 int  hz_scan_items_max();
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);
 // k_bmc.hip
-void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr);
+// mvs0: the jobs' vector arrays when they are contiguous (job j at mvs0 + j * nblocks), else null (JobDev.mvs is used)
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr, const DMV *mvs0 = nullptr);
 // k_frame.hip
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr);
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);

@@ -462,7 +462,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         }
         if (njobs > nI) {
             const int nP = njobs - nI;
-            launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof);
+            launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof, c->mvs + (size_t)(d0 + nI) * c->nblk);
             launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
             launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
         }

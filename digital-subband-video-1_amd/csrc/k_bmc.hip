@@ -43,7 +43,7 @@ static __device__ __forceinline__ void mc_store4(uint8_t *pp, uint8_t *xp, const
     }
 }
 
-__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub, int njobs)
+__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub, int njobs, const DMV *__restrict__ mvs0)
 {
     __shared__ __align__(16) uint8_t win[WROWS * WPITCH];
     __shared__ int s_sum[5];
@@ -62,8 +62,21 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     if (x >= pw || y >= ph) return;
     const int cw = (x + bw >= pw) ? pw - x : bw;
     const int ch = (y + bh >= ph) ? ph - y : bh;
+    // Every workgroup starts with a chain of dependent memory round trips (kernel arguments -> job table -> motion
+    // vector -> reference pixels) and lives only a few microseconds, so the chain is kept short: the vector comes
+    // from a kernel-argument base when the jobs' vector arrays are contiguous (mvs0), and the source pixels of the
+    // first row passes -- which depend on neither -- are requested before the vector is waited for.
+    const int lq0 = bw > 32 ? 4 : (bw > 16 ? 3 : 2);
+    const int x40 = 4 * (tid & ((1 << lq0) - 1)), rpp0 = MC_NT >> lq0;
+    unsigned s_pre[4] = {0u, 0u, 0u, 0u};
+    if (do_sub && x40 + 4 <= cw) {
+        const uint8_t *sp0 = jb.src + G.off[c];
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+            s_pre[u] = *reinterpret_cast<const unsigned *>(sp0 + (size_t)(y + min((tid >> lq0) + u * rpp0, ch - 1)) * stride + x + x40);
+    }
     // one vector per block: make its fields wave-uniform (SGPRs) so that the path selection below is scalar branching
-    DMV mv = jb.mvs[blk];
+    DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
     mv.x = (int16_t)__builtin_amdgcn_readfirstlane((int)mv.x);
     mv.y = (int16_t)__builtin_amdgcn_readfirstlane((int)mv.y);
     mv.mode = (uint8_t)__builtin_amdgcn_readfirstlane((int)mv.mode);
@@ -103,7 +116,8 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
                 const int yy = min(y0 + u * rpp, ch - 1);
                 const long ro = (long)yy * sdw;
                 d0[u] = ga[ro]; d1[u] = ga[ro + 1]; d2[u] = ga[ro + 2];
-                sv4[u] = (do_sub && full4) ? *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy) * stride + x + x4) : 0u;
+                sv4[u] = y0 == (tid >> lq) ? s_pre[u]
+                                           : ((do_sub && full4) ? *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy) * stride + x + x4) : 0u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -210,8 +224,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     // the source dword of the NEXT row pass is requested before this pass is computed (the subtraction would
     // otherwise sit behind a full memory round trip in every pass)
     const bool full4 = x4 + 4 <= cw;
-    unsigned s_cur = 0;
-    if (do_sub && full4 && (tid >> lq) < ch) s_cur = *reinterpret_cast<const unsigned *>(sp + (size_t)(y + (tid >> lq)) * stride + x + x4);
+    unsigned s_cur = s_pre[0];
     for (int yy = tid >> lq; yy < ch; yy += MC_NT >> lq) {
         unsigned s_next = 0;
         if (do_sub && full4 && yy + (MC_NT >> lq) < ch)
@@ -279,11 +292,11 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     }
 }
 
-void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf)
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf, const DMV *mvs0)
 {
     double smp = 0;
     for (int c = 0; c < 3; c++) smp += (double)G.w[c] * G.h[c];
     if (pf) pf->begin(st, KID_MC, smp * njobs * (do_sub ? 4.0 : 2.0));   // ref + src in, pred + residual out
-    hipLaunchKernelGGL(k_mc, dim3(xcd_grid(G.nbh * G.nbv * 3 * njobs)), dim3(MC_NT), 0, st, jobs, G, do_sub, njobs);
+    hipLaunchKernelGGL(k_mc, dim3(xcd_grid(G.nbh * G.nbv * 3 * njobs)), dim3(MC_NT), 0, st, jobs, G, do_sub, njobs, mvs0);
     if (pf) pf->end(st);
 }

@@ -62,7 +62,12 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     if (x >= pw || y >= ph) return;
     const int cw = (x + bw >= pw) ? pw - x : bw;
     const int ch = (y + bh >= ph) ? ph - y : bh;
-    const DMV mv = jb.mvs[blk];
+    // one vector per block: make its fields wave-uniform (SGPRs) so that the path selection below is scalar branching
+    DMV mv = jb.mvs[blk];
+    mv.x = (int16_t)__builtin_amdgcn_readfirstlane((int)mv.x);
+    mv.y = (int16_t)__builtin_amdgcn_readfirstlane((int)mv.y);
+    mv.mode = (uint8_t)__builtin_amdgcn_readfirstlane((int)mv.mode);
+    mv.submask = (uint8_t)__builtin_amdgcn_readfirstlane((int)mv.submask);
     const uint8_t *rp = jb.ref + G.off[c];
 
     int wx, wy, xh = 0, yh = 0;                 // window origin = (wx-1, wy-1)
@@ -107,20 +112,18 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
                 if (yy >= ch) break;
                 const unsigned lo = __builtin_amdgcn_alignbyte(d1[u], d0[u], shb), hi = __builtin_amdgcn_alignbyte(d2[u], d1[u], shb);
                 int pv[4];
+#define RB(k) ((int)((((k) < 4 ? lo : hi) >> (8 * ((k) & 3))) & 0xff))          /* reference byte x4 - 1 + k */
+                if (!xh) {
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int a = (int)(((k + 1 < 4 ? lo : hi) >> (8 * ((k + 1) & 3))) & 0xff);       // ref(x4 + k)
-                    if (!xh) pv[k] = a;
-                    else if (c == 0) {
-                        const int m = (int)(((k < 4 ? lo : hi) >> (8 * (k & 3))) & 0xff);
-                        const int b = (int)(((k + 2 < 4 ? lo : hi) >> (8 * ((k + 2) & 3))) & 0xff);
-                        const int q = (int)(((k + 3 < 4 ? lo : hi) >> (8 * ((k + 3) & 3))) & 0xff);
-                        pv[k] = d_sat8((tap4(m, a, b, q) + 8) >> 4);
-                    } else {
-                        const int b = (int)(((k + 2 < 4 ? lo : hi) >> (8 * ((k + 2) & 3))) & 0xff);
-                        pv[k] = (a + b + 1) >> 1;
-                    }
+                    for (int k = 0; k < 4; k++) pv[k] = RB(k + 1);
+                } else if (c == 0) {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pv[k] = d_sat8((tap4(RB(k), RB(k + 1), RB(k + 2), RB(k + 3)) + 8) >> 4);
+                } else {
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pv[k] = (RB(k + 1) + RB(k + 2) + 1) >> 1;
                 }
+#undef RB
                 mc_store4(pp, xp, sp, (size_t)(y + yy) * stride + x + x4, pv, cw - x4, do_sub, sv4[u]);
                 if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
                     xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * stride + pw - 1];
