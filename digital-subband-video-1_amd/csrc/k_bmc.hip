@@ -15,7 +15,7 @@
 
 #define WPITCH 76                       // LDS row pitch in bytes: 64+3 window + 3 misalignment, +1 spare dword for ROW8
 #define WROWS 68
-#define MC_NT 128                       // threads per workgroup (4.9 KB LDS => 16+ blocks in flight per CU)
+#define MC_NT 64                        // threads per workgroup: ONE wave per block (A/B: 256 -> 3.7, 128 -> 2.7, 64 -> 2.5 ms/step)
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
