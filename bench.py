@@ -86,11 +86,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     import torch
     import torch.distributed as dist
-    if world > 1:
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = local_rank
+    # debugging aid for boxes with fewer GPUs than ranks (never set by the driver): all ranks share device 0 and the
+    # two collectives of this script (barrier, MAX of the elapsed time) go over gloo
+    shared = os.environ.get("DSV1_BENCH_DEBUG_SHARED_GPU") == "1"
+    dev = 0 if shared else local_rank
     torch.cuda.set_device(dev)
+    if world > 1:
+        if shared:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import _cabi as A
     pkg = importlib.import_module("digital-subband-video-1_amd")
@@ -177,7 +182,7 @@ def main():
 
     tmax = dt
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         tmax = float(t.item())
     pix_per_step = args.gops * GOP * W * H
