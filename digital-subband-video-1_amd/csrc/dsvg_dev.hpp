@@ -122,14 +122,24 @@ struct SbtGeo {              // per-plane constants for the transform kernels
     int pw;                  // pixel plane width (recon store guard)
 };
 
-static __device__ __forceinline__ int d_rdiv2(int v) { return v < 0 ? -((1 - v) >> 1) : (v + 1) >> 1; }
-static __device__ __forceinline__ int d_rdiv4(int v) { return v < 0 ? -((2 - v) >> 2) : (v + 2) >> 2; }
-static __device__ __forceinline__ int d_rdiv8(int v) { return v < 0 ? -((4 - v) >> 3) : (v + 4) >> 3; }
+// round-half-away-from-zero divisions (sbt.c:63-88: v < 0 ? -((h - v) >> k) : (v + h) >> k), branch-free:
+// (v + h + (v >> 31)) >> k gives the same value for every int (checked exhaustively over +-2*10^5, tools note in DESIGN)
+static __device__ __forceinline__ int d_rdiv2(int v) { return (v + 1 + (v >> 31)) >> 1; }
+static __device__ __forceinline__ int d_rdiv4(int v) { return (v + 2 + (v >> 31)) >> 2; }
+static __device__ __forceinline__ int d_rdiv8(int v) { return (v + 4 + (v >> 31)) >> 3; }
+// C's truncating x / 4.  SMALL: |x| < 2^30 is known (transform levels 1..3 of 8-bit video: < 2^20) -- bits 31:30 are
+// then 11 for negative x and 00 otherwise, one v_bfe_u32 instead of shift + mask
+template <bool SMALL>
+static __device__ __forceinline__ int d_div4(int x)
+{
+    return SMALL ? (x + (int)__builtin_amdgcn_ubfe((unsigned)x, 30u, 2u)) >> 2 : (x + ((x >> 31) & 3)) >> 2;
+}
 static __device__ __forceinline__ int d_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
 static __device__ __forceinline__ int d_sat8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 // C.3.1.1 LL scaling (sbt.c:20-21): C integer division truncates toward zero -- load-bearing
 static __device__ __forceinline__ int d_ll_down(int x) { return x * 4 / 5; }
 static __device__ __forceinline__ int d_ll_up(int x) { return x * 5 / 4; }
+template <bool SMALL> static __device__ __forceinline__ int d_ll_up_t(int x) { return d_div4<SMALL>(x * 5); }
 
 // XCD-aware work mapping: consecutive workgroup ids are dealt round-robin to the 8 XCDs (each with its own L2), so
 // workgroup `lin` takes the logical item (lin % 8) * ceil(total / 8) + lin / 8 -- every XCD then walks ONE contiguous

@@ -530,10 +530,10 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restr
                     if (x > 0 && x < wfull - 1) LH = d_nudge(LL, d_ll_up(pLL[-1]), d_ll_up(pLL[1]), LH, hqp);
                     if (y > 0 && y < hfull - 1) HL = d_nudge(LL, d_ll_up(pLL[-w3]), d_ll_up(pLL[w3]), HL, hqp);
                 }
-                o0[k] = d_div4<false>(LL + LH + HL + HH);
-                o1[k] = d_div4<false>(LL - LH + HL - HH);
-                o2[k] = d_div4<false>(LL + LH - HL - HH);
-                o3[k] = d_div4<false>(LL - LH - HL + HH);
+                o0[k] = (LL + LH + HL + HH) / 4;
+                o1[k] = (LL - LH + HL - HH) / 4;
+                o2[k] = (LL + LH - HL - HH) / 4;
+                o3[k] = (LL - LH - HL + HH) / 4;
             }
         }
         __syncthreads();
@@ -704,67 +704,67 @@ static __device__ __forceinline__ Det<SYM, HZL> mk_det(const JobDev &jb, int c, 
 // NOTE (reference quirk): for an even region the last complete cell still passes the inX/inY test and its
 // "next LL" is read ACROSS the band boundary: column wo of the same row (= LH[cy][0]) / row ho of the same
 // column (= HL[0][cx]) of the coefficient plane.
-template <bool SMALL, typename DET>
+template <typename DET>
 static __device__ __forceinline__ void inv_nudge(const int *pA, int astride, int cx, int cy, const LvlGeo &L, const DET &D,
                                                  int LL, int &LH, int &HL)
 {
     const int x = 2 * cx, y = 2 * cy;
     if (x > 0 && x < L.wfull - 1) {
         int lp = pA[-1], ln = (cx + 1 < L.wo) ? pA[1] : D.lh(0, cy);
-        if (L.scaled) { lp = d_ll_up_t<SMALL>(lp); ln = d_ll_up_t<SMALL>(ln); }
+        if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
         LH = d_nudge(LL, lp, ln, LH, L.hqp);
     }
     if (y > 0 && y < L.hfull - 1) {
         int lp = pA[-astride], ln = (cy + 1 < L.ho) ? pA[astride] : D.hl(cx, 0);
-        if (L.scaled) { lp = d_ll_up_t<SMALL>(lp); ln = d_ll_up_t<SMALL>(ln); }
+        if (L.scaled) { lp = d_ll_up(lp); ln = d_ll_up(ln); }
         HL = d_nudge(LL, lp, ln, HL, L.hqp);
     }
 }
 
 // inverse of one cell (cx,cy); A = LDS array of this level's LL values, pA -> this cell's LL
-template <bool FILT, bool SMALL, typename DET>
+template <bool FILT, typename DET>
 static __device__ __forceinline__ void inv_cell(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
                                                 const DET &D, int (&o)[4])
 {
     const int x = 2 * cx, y = 2 * cy;
     const bool hasR = x + 1 < L.ws, hasB = y + 1 < L.hs;
-    const int LL = L.scaled ? d_ll_up_t<SMALL>(pA[0]) : pA[0];
+    const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
     int LH, HL, HH;
     D.get3(cx, cy, hasR, hasB, LH, HL, HH);
-    if (FILT && hasR && hasB) inv_nudge<SMALL>(pA, astride, cx, cy, L, D, LL, LH, HL);
-    o[0] = d_div4<SMALL>(LL + LH + HL + HH);
-    o[1] = d_div4<SMALL>(LL - LH + HL - HH);
-    o[2] = d_div4<SMALL>(LL + LH - HL - HH);
-    o[3] = d_div4<SMALL>(LL - LH - HL + HH);
+    if (FILT && hasR && hasB) inv_nudge(pA, astride, cx, cy, L, D, LL, LH, HL);
+    o[0] = (LL + LH + HL + HH) / 4;
+    o[1] = (LL - LH + HL - HH) / 4;
+    o[2] = (LL + LH - HL - HH) / 4;
+    o[3] = (LL - LH - HL + HH) / 4;
 }
 
 // inverse of one cell whose raw details were fetched earlier (Det::fetch)
-template <bool FILT, bool SMALL, typename DET>
+template <bool FILT, typename DET>
 static __device__ __forceinline__ void inv_cell_raw(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
                                                     const DET &D, const Raw3 &raw, int (&o)[4])
 {
     const bool hasR = 2 * cx + 1 < L.ws, hasB = 2 * cy + 1 < L.hs;
-    const int LL = L.scaled ? d_ll_up_t<SMALL>(pA[0]) : pA[0];
+    const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
     int LH, HL, HH;
     D.finish(raw, LH, HL, HH);
-    if (FILT && hasR && hasB) inv_nudge<SMALL>(pA, astride, cx, cy, L, D, LL, LH, HL);
-    o[0] = d_div4<SMALL>(LL + LH + HL + HH);
-    o[1] = d_div4<SMALL>(LL - LH + HL - HH);
-    o[2] = d_div4<SMALL>(LL + LH - HL - HH);
-    o[3] = d_div4<SMALL>(LL - LH - HL + HH);
+    if (FILT && hasR && hasB) inv_nudge(pA, astride, cx, cy, L, D, LL, LH, HL);
+    o[0] = (LL + LH + HL + HH) / 4;
+    o[1] = (LL - LH + HL - HH) / 4;
+    o[2] = (LL + LH - HL - HH) / 4;
+    o[3] = (LL - LH - HL + HH) / 4;
 }
 
 // same as inv_cell for a COMPLETE cell whose three details were already fetched (vector loads)
-template <bool FILT, bool SMALL, typename DET>
+template <bool FILT, typename DET>
 static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride, int cx, int cy, const LvlGeo &L,
                                                      const DET &D, int LH, int HL, int HH, int (&o)[4])
 {
-    const int LL = L.scaled ? d_ll_up_t<SMALL>(pA[0]) : pA[0];
-    if (FILT) inv_nudge<SMALL>(pA, astride, cx, cy, L, D, LL, LH, HL);
-    o[0] = d_div4<SMALL>(LL + LH + HL + HH);
-    o[1] = d_div4<SMALL>(LL - LH + HL - HH);
-    o[2] = d_div4<SMALL>(LL + LH - HL - HH);
-    o[3] = d_div4<SMALL>(LL - LH - HL + HH);
+    const int LL = L.scaled ? d_ll_up(pA[0]) : pA[0];
+    if (FILT) inv_nudge(pA, astride, cx, cy, L, D, LL, LH, HL);
+    o[0] = (LL + LH + HL + HH) / 4;
+    o[1] = (LL - LH + HL - HH) / 4;
+    o[2] = (LL + LH - HL - HH) / 4;
+    o[3] = (LL - LH - HL + HH) / 4;
 }
 
 #define IT_TX 16     // level-3 cells per tile in x  (=> 128 px)
@@ -808,7 +808,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
             const LvlGeo L4 = mk_lvl(W, H, 4, jb.hqp[4], true);
             const auto D4 = mk_det<false, 0>(jb, c, coef, W, L4);
             int o[4];
-            inv_cell<FILT, false>(&ll, 1, 0, 0, L4, D4, o);
+            inv_cell<FILT>(&ll, 1, 0, 0, L4, D4, o);
             const int w3o = DSVG_RSU(W, 3), h3o = DSVG_RSU(H, 3);
             s3o[0] = o[0];
             if (w3o > 1) s3o[1] = o[1];
@@ -881,7 +881,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     if (ok3) {      // level TOP: cells I0-1 .. I0+TX (halo 1)
         const int ly = tid / (IT_TX + 2), lx = tid - ly * (IT_TX + 2);
         int o[4];
-        inv_cell_raw<FILT, MODE != 2>(A3 + (ly + 1) * A3W + (lx + 1), A3W, I0 - 1 + lx, J0 - 1 + ly, L3, D3, q3, o);
+        inv_cell_raw<FILT>(A3 + (ly + 1) * A3W + (lx + 1), A3W, I0 - 1 + lx, J0 - 1 + ly, L3, D3, q3, o);
         int *d = A2 + (2 * ly) * A2W + 2 * lx;
         d[0] = o[0]; d[1] = o[1]; d[A2W] = o[2]; d[A2W + 1] = o[3];
     }
@@ -892,7 +892,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         const int i = tid + 256 * u;
         const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
         int o[4];
-        inv_cell_raw<FILT, MODE != 2>(A2 + (ly + 1) * A2W + (lx + 1), A2W, 2 * I0 - 1 + lx, 2 * J0 - 1 + ly, L2, D2, q2[u], o);
+        inv_cell_raw<FILT>(A2 + (ly + 1) * A2W + (lx + 1), A2W, 2 * I0 - 1 + lx, 2 * J0 - 1 + ly, L2, D2, q2[u], o);
         int *d = A1 + (2 * ly) * A1W + 2 * lx;
         d[0] = o[0]; d[1] = o[1]; d[A1W] = o[2]; d[A1W + 1] = o[3];
     }
@@ -926,7 +926,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 int o[4];
-                inv_cell_vals<FILT, true>(A1 + (ly + 2) * A1W + (4 * gx + k + 2), A1W, cx0 + k, cy, L, D, lhv[k], hlv[k], hhv[k], o);
+                inv_cell_vals<FILT>(A1 + (ly + 2) * A1W + (4 * gx + k + 2), A1W, cx0 + k, cy, L, D, lhv[k], hlv[k], hhv[k], o);
                 r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
                 r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
             }
@@ -935,7 +935,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
             for (int k = 0; k < 4; k++) {
                 const int lx = 4 * gx + k, cx = 4 * I0 + lx;
                 int o[4] = {0, 0, 0, 0};
-                if (cx < L.wo) inv_cell<FILT, true>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, D, o);
+                if (cx < L.wo) inv_cell<FILT>(A1 + (ly + 2) * A1W + (lx + 2), A1W, cx, cy, L, D, o);
                 r0[2 * k] = o[0]; r0[2 * k + 1] = o[1];
                 r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
             }
