@@ -1,10 +1,12 @@
 // k_bmc.hip -- half-pel block motion compensation for gfx950 (MI355X).  HBM-bound byte work.
 //
 // Replaces compensate (bmc.c:204-302) with hpelL (bmc.c:124-174) / hpel (bmc.c:58-110) / avgval
-// (bmc.c:176-189), fused with subf (bmc.c:43-55): one workgroup per (block, plane, job) stages the
-// (cw+3)x(ch+3) reference window in LDS with aligned dword loads, every thread then produces 4
-// adjacent prediction pixels (one 32-bit coalesced store to the prediction frame and, for the
-// encoder, one to the residual frame:  res = clamp(src - pred + 128)).
+// (bmc.c:176-189), fused with subf (bmc.c:43-55): one wave per (block, plane, job) in an XCD-aware order;
+// every lane produces 4 adjacent prediction pixels per row pass (one 32-bit coalesced store to the
+// prediction frame and, for the encoder, one to the residual frame:  res = clamp(src - pred + 128)).
+// Copy / horizontal half-pel blocks read their reference bytes straight from global memory (one
+// reference row per output row: nothing to share); vertical / diagonal / intra blocks stage the
+// (cw+3)x(ch+3) window in LDS with batched aligned dword loads.
 //   luma  : 4-tap (-1,9,9,-1): V / H rounded (+8)>>4, HV = H taps unrounded then V taps, (+128)>>8
 //   chroma: bilinear (a+b+1)>>1, (a+b+c+d+2)>>2
 //   intra : (sub-)block mean of the co-located reference pixels, truncating division

@@ -1,13 +1,14 @@
 // k_hme.hip -- hierarchical motion estimation + level-0 mode decision for gfx950 (MI355X).
 //
-// Replaces dsv_hme / refine_level (hme.c:378-741).  One launch per pyramid level (coarse -> fine),
-// one 128-thread workgroup per visited block and frame pair, threads laid out 16 column groups (4 px,
-// one dword) x 8 row groups (9.6 KB LDS => 16 blocks in flight per CU) -- no divisions on the hot loops.
-//   * the source block lives in registers (one dword per thread-row); every SAD is
-//     v_alignbyte_b32 (re-align the reference dwords) + v_sad_u8 (4 pixels per instruction);
-//   * inherited candidates are evaluated straight from global memory (no reuse => no LDS staging) and
-//     reduced together in ONE workgroup reduction; the 9-point +-1 search reads a (bw+2)x(bh+2) window
-//     staged in LDS as aligned dwords (each window dword feeds 3 candidates);
+// Replaces dsv_hme / refine_level (hme.c:378-741).  One launch per pyramid level (coarse -> fine), ONE WAVE
+// (64-thread workgroup) per visited block and frame pair in an XCD-aware order: 16 column groups (4 px, one dword)
+// x 4 row groups, every lane owning a run of adjacent rows.  No cross-wave exchange, 2.4 KB LDS, VALU-issue bound.
+//   * the source block lives in registers (one dword per lane-row); every SAD is v_alignbyte_b32 (re-align
+//     the reference dwords) + v_sad_u8 (4 pixels per instruction);
+//   * inherited candidates and the rows of the 9-point +-1 search are read straight from global memory in
+//     back-to-back batches (a memory round trip per batch, not per row); each reference row of the +-1 search
+//     serves the three source rows around it;
+//   * reductions are DPP wave sums; parents are fetched wave-uniformly and de-duplicated in registers;
 //   * every decision that depends on candidate ORDER (first minimum wins, hme.c:503-506,531-534,
 //     572-575; the last candidate is the fallback, hme.c:482-509) is evaluated identically by all lanes
 //     from the reduced sums, in the reference's order.

@@ -5,13 +5,16 @@
 // of hzcc_dec (hzcc.c:295-435).  The sequential coder
 //     for cell in scan order: if v != 0: UEG(run); NEG(previous non-zero); ...; final NEG(last)
 // is parallelised as
-//   k_hz_quant  one workgroup per 2048 scan cells: quantise, write the DEQUANTISED value back in
-//               place (hzcc.c:172-184), compact the non-zeros in scan order with wave ballots, and
-//               sum the bit lengths of every symbol whose predecessor lies in the same chunk
+//   k_hz_quant<false>  one workgroup per 2048 scan cells: quantise, write the DEQUANTISED value back in place
+//               (hzcc.c:172-184), compact the non-zeros in scan order with wave ballots, and sum the bit
+//               lengths of every symbol whose predecessor lies in the same chunk (I pictures, operator calls)
+//   k_hz_quant<true> + k_hz_collect  the same for P pictures whose detail bands were already quantised by the
+//               forward transform (k_fwd_haar_pix<true>): LL chunks / wave-per-chunk compaction of the symbols
 //   k_hz_scan   one workgroup per plane: carries (position,value) of the last non-zero across
 //               chunks (max-scan), adds each chunk's first-symbol length, prefix-sums bit offsets
-//   k_hz_emit   one workgroup per chunk: builds each <=92-bit symbol (UEG spread via bit
-//               interleave) and ORs it MSB-first into the zeroed payload (atomicOr on 32-bit words)
+//   k_hz_emit   one wave per chunk: builds each <=92-bit symbol (UEG spread via bit interleave), assembles
+//               rounds of 64 symbols in LDS and flushes them with plain stores (atomicOr only on shared words)
+//   k_hz_parse  the decoder's entropy parse (state-machine scan) + k_hz_scatter_lv
 // Scan regions can overlap for some plane sizes (960x540: SURVEY.md Q7); a cell seen by two
 // regions is processed twice exactly like the sequential reference: the later region quantises
 // the earlier region's dequantised value and owns the final store.
