@@ -767,6 +767,43 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
     o[3] = d_div4<SMALL>(LL - LH - HL + HH);
 }
 
+// ---- two level-1 cells per instruction (v_pk_*_i16): the encoder's P-picture luma inverse ----------------------
+// Level 1 of a P picture is unscaled and works on an 8-bit residual: |LL1| <= 512, the dequantised details are no
+// larger than the coefficients they came from, every intermediate of the nudge and of the outputs stays far inside
+// int16.  (Only the encoder takes this path: its symbols come from real residuals.  The decoder, which must follow
+// the reference on arbitrary streams, keeps the 32-bit cells.)
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ s16x2 pk2(int a, int b) { return s16x2{(short)a, (short)b}; }
+static __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+static __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+static __device__ __forceinline__ s16x2 pk_rdiv2(s16x2 v) { return (v + (short)1 + (v >> 15)) >> 1; }
+static __device__ __forceinline__ s16x2 pk_rdiv4(s16x2 v) { return (v + (short)2 + (v >> 15)) >> 2; }
+static __device__ __forceinline__ s16x2 pk_div4(s16x2 v) { return (v + ((v >> 15) & (short)3)) >> 2; }
+static __device__ __forceinline__ s16x2 pk_nudge(s16x2 ll, s16x2 lp, s16x2 ln, s16x2 det, short hqp)      // d_nudge x 2
+{
+    const s16x2 a = ll - ln, b = lp - ll, z = {0, 0};
+    const s16x2 mx = pk_min(pk_max(a, b), z), mn = pk_max(pk_min(a, b), z);
+    const s16x2 t = pk_rdiv4(lp - ln);
+    const s16x2 n = pk_rdiv2(pk_min(pk_max(t, mx), mn) - (det << 1));
+    const s16x2 h = {hqp, hqp}, nh = {(short)-hqp, (short)-hqp};
+    const s16x2 dl = pk_min(pk_max(n, nh), h);
+    const s16x2 mask = (z - (mn - mx)) >> 15;               // all ones where mx != mn (mx <= 0 <= mn)
+    return det + (dl & mask);
+}
+// pixels of two cells: even/odd output columns e, o (int16 pairs) -> sbc2int (+ prediction), packed back to bytes
+static __device__ __forceinline__ unsigned pk_pixels(s16x2 e, s16x2 o, bool has_pred, unsigned predw)
+{
+    const s16x2 z = {0, 0}, m255 = {255, 255}, c128 = {128, 128};
+    e = pk_min(pk_max(e + c128, z), m255);
+    o = pk_min(pk_max(o + c128, z), m255);
+    if (has_pred) {                                         // dsv_frame_add / addf bmc.c:29-41
+        const unsigned pe = predw & 0x00ff00ffu, po = (predw >> 8) & 0x00ff00ffu;
+        e = pk_min(pk_max(e + __builtin_bit_cast(s16x2, pe) - c128, z), m255);
+        o = pk_min(pk_max(o + __builtin_bit_cast(s16x2, po) - c128, z), m255);
+    }
+    return __builtin_bit_cast(unsigned, e) | (__builtin_bit_cast(unsigned, o) << 8);
+}
+
 #define IT_TX 16     // level-3 cells per tile in x  (=> 128 px)
 #define IT_TY 8      // level-3 cells per tile in y  (=>  64 px)
 #define A3W (IT_TX + 4)
@@ -920,6 +957,39 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         if (cy >= L.ho) continue;
         int r0[8], r1[8];
         const int cx0 = 4 * I0 + 4 * gx;
+        const int px0 = 2 * (4 * I0 + 4 * gx);                // pixel x of the group
+        bool done = false;
+        if constexpr (FILT && SYM) {
+            // packed path: four complete interior cells (every cell takes the horizontal nudge with in-band
+            // neighbours; the row takes the vertical nudge or, on the first row, none), both output rows inside the
+            // plane, 8 whole pixels
+            const bool hx = cx0 > 0 && 2 * (cx0 + 3) < L.wfull - 1 && cx0 + 4 < L.wo;
+            const bool vy = 2 * cy > 0 && 2 * cy < L.hfull - 1;
+            if (fast1[u] && hx && (!vy || cy + 1 < L.ho) && 2 * cy + 1 < g.ph && px0 + 8 <= g.pw) {
+                int lhv[4], hlv[4], hhv[4];
+                D.finish4(q1[u], lhv, hlv, hhv);
+                const int *rc = A1 + (ly + 2) * A1W + (4 * gx + 2);
+                const short hq = (short)L.hqp;
+                unsigned row0[2], row1[2];
+#pragma unroll
+                for (int h2 = 0; h2 < 2; h2++) {             // cells (0,1) then (2,3)
+                    const int k = 2 * h2;
+                    const s16x2 C = pk2(rc[k], rc[k + 1]);
+                    s16x2 LH = pk2(lhv[k], lhv[k + 1]), HL = pk2(hlv[k], hlv[k + 1]);
+                    const s16x2 HH = pk2(hhv[k], hhv[k + 1]);
+                    LH = pk_nudge(C, pk2(rc[k - 1], rc[k]), pk2(rc[k + 1], rc[k + 2]), LH, hq);
+                    if (vy) HL = pk_nudge(C, pk2(rc[k - A1W], rc[k + 1 - A1W]), pk2(rc[k + A1W], rc[k + 1 + A1W]), HL, hq);
+                    const s16x2 sA = C + HL, sB = LH + HH, sC = C - HL, sD = LH - HH;
+                    row0[h2] = pk_pixels(pk_div4(sA + sB), pk_div4(sA - sB), pred != nullptr, h2 ? pv1[u][0].y : pv1[u][0].x);
+                    row1[h2] = pk_pixels(pk_div4(sC + sD), pk_div4(sC - sD), pred != nullptr, h2 ? pv1[u][1].y : pv1[u][1].x);
+                }
+                uint8_t *dst = outp + (size_t)(2 * cy) * g.pstride + px0;
+                *reinterpret_cast<uint2 *>(dst) = make_uint2(row0[0], row0[1]);
+                *reinterpret_cast<uint2 *>(dst + g.pstride) = make_uint2(row1[0], row1[1]);
+                done = true;
+            }
+        }
+        if (done) continue;
         if (fast1[u]) {     // four complete cells whose details came in as three vector loads
             int lhv[4], hlv[4], hhv[4];
             D.finish4(q1[u], lhv, hlv, hhv);
@@ -940,7 +1010,6 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
                 r1[2 * k] = o[2]; r1[2 * k + 1] = o[3];
             }
         }
-        const int px0 = 2 * (4 * I0 + 4 * gx);                // pixel x of the group
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
             const int y = 2 * cy + rr;
