@@ -112,6 +112,35 @@ def _take(buf):
     return data
 
 
+class StreamBytes:
+    """The finished packets of one stream exactly where the library assembled them (a dsv_alloc'd host buffer): no copy
+    into a Python bytes object.  len(), bytes(), memoryview() work; the buffer is freed with the object."""
+
+    def __init__(self, buf):
+        self._ptr = _C.cast(buf.data, _C.c_void_p).value
+        self._len = int(buf.len) if self._ptr else 0
+
+    def __len__(self):
+        return self._len
+
+    def __bytes__(self):
+        return _C.string_at(self._ptr, self._len) if self._len else b""
+
+    def view(self):
+        return memoryview((_C.c_ubyte * self._len).from_address(self._ptr)) if self._len else memoryview(b"")
+
+    def __eq__(self, other):
+        return bytes(self) == bytes(other)
+
+    def __del__(self):
+        if getattr(self, "_ptr", None):
+            try:
+                lib().dsv_free(_C.c_void_p(self._ptr))
+            except Exception:      # interpreter shutdown
+                pass
+            self._ptr = None
+
+
 class Batch:
     """nstreams independent encoder streams, frames_per_call frames each per encode() call"""
 
@@ -164,10 +193,13 @@ class Batch:
         _chk(self.L.dsv1_batch_submit(self.h, ptr, 1 if on_device else 0, bufs), "dsv1_batch_submit")
         self._abr.append(bufs)
 
-    def collect(self):
-        """fetch + assemble the oldest submitted batch -> one bytes object per stream"""
+    def collect(self, copy=True):
+        """fetch + assemble the oldest submitted batch -> one bytes object per stream (copy=False: StreamBytes
+        objects that keep the packets in the buffers the library assembled them in)"""
         bufs = self._abr.pop(0)
         _chk(self.L.dsv1_batch_collect(self.h, bufs), "dsv1_batch_collect")
+        if not copy:
+            return [StreamBytes(bufs[s]) for s in range(self.nstreams)]
         return [_take(bufs[s]) for s in range(self.nstreams)]
 
     def sync(self):

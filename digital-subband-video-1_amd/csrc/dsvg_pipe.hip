@@ -8,6 +8,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include "dsvg_host.hpp"
+#include <ctime>
 
 #define OPCHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -500,6 +501,9 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
             if (e >= 0 && !seen[e]) { seen[e] = 1; HIPCHK(hipStreamWaitEvent(c->st_c, c->ev_coded[e], 0)); }
         }
     }
+    static const bool fprof = getenv("DSV1_HOST_PROF") != nullptr;
+    const auto tnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tf0 = fprof ? tnow() : 0.0;
     // 1. plane summaries (sizes)
     int lo = out_slots[0], hi = out_slots[0];
     for (int i = 1; i < n; i++) { lo = std::min(lo, out_slots[i]); hi = std::max(hi, out_slots[i]); }
@@ -507,6 +511,7 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
                           hipMemcpyDeviceToHost, c->st_c));
     HIPCHK(hipStreamSynchronize(c->st_c));
     HIPCHK(hipGetLastError());
+    const double tf1 = fprof ? tnow() : 0.0;
     // 2. compact every payload into one buffer on the device, then ONE device-to-host copy
     size_t total = 0;
     for (int i = 0; i < n; i++) {
@@ -532,8 +537,11 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
     }
     HIPCHK(hipMemcpyAsync(c->gtab_d, c->gtab_h, sizeof(unsigned long long) * 9 * (size_t)n, hipMemcpyHostToDevice, c->st_c));
     launch_gather_bits(c->st_c, c->bits, c->gtab_d, 3 * n, c->gath_d);
+    if (fprof) HIPCHK(hipStreamSynchronize(c->st_c));
+    const double tf2 = fprof ? tnow() : 0.0;
     if (total) HIPCHK(hipMemcpyAsync(c->gath_h, c->gath_d, total, hipMemcpyDeviceToHost, c->st_c));
     HIPCHK(hipStreamSynchronize(c->st_c));
+    if (fprof) fprintf(stderr, "[dsvg fetch] wait for coding + sizes %.2f ms, gather %.2f ms, D2H of %.1f MB %.2f ms\n", tf1 - tf0, tf2 - tf1, total / 1e6, tnow() - tf2);
     HIPCHK(hipGetLastError());
     for (int i = 0; i < n; i++) {
         const int o = out_slots[i];

@@ -388,40 +388,47 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     bitw w;
     unsigned len;
     int p;
+    uint8_t *pkt;
     size_t need = (size_t)pc->prefix_len + 64;
-    for (p = 0; p < 3; p++) need += po->nbytes[p] + 32;
-    if (need > sc->cap) { sc->cap = need * 2; sc->pkt = (uint8_t *)realloc(sc->pkt, sc->cap); }
-    memset(sc->pkt, 0, need);
-    memcpy(sc->pkt, pc->prefix, pc->prefix_len);
-    bw_init(&w, sc->pkt);
+    (void)sc;
+    for (p = 0; p < 3; p++) need += po->nbytes[p] + 48;
+    if (pc->gop_start) {
+        uint8_t mb[64];
+        const unsigned n = write_meta_packet(e, mb);
+        if (dsv1_buf_append(out, mb, n)) return DSVG_ERR_ARG;
+    }
+    /* the packet is built in place at the end of the stream buffer: the payloads (the bulk) are copied once, straight
+     * from the fetch buffer; only the few header bytes the bit writer ORs into are cleared first */
+    if (dsv1_buf_reserve(out, (unsigned)need)) return DSVG_ERR_ARG;
+    pkt = out->data + out->len;
+    memcpy(pkt, pc->prefix, pc->prefix_len);
+    memset(pkt + pc->prefix_len, 0, 8);
+    bw_init(&w, pkt);
     w.pos = pc->prefix_len * 8;
     bw_bits(&w, 11, (unsigned)pc->quant);
     for (p = 0; p < 3; p++) {
         unsigned startp, endp;
         bw_align(&w);
         startp = bw_bytes(&w);
+        memset(pkt + startp, 0, 24);
         bw_bits(&w, 32, 0);
         bw_seg(&w, po->dc[p]);
         bw_align(&w);
         bw_bits(&w, 32, po->nruns[p]);
         bw_align(&w);
         bw_bytes_in(&w, po->payload[p], po->nbytes[p]);
+        memset(pkt + bw_bytes(&w), 0, 8);
         bw_bits(&w, 8, 0x55);
         bw_align(&w);
         endp = bw_bytes(&w);
-        put_be32(sc->pkt + startp, endp - startp - 4);
+        put_be32(pkt + startp, endp - startp - 4);
     }
     bw_align(&w);
     len = bw_bytes(&w);
-
-    if (pc->gop_start) {
-        uint8_t mb[64];
-        const unsigned n = write_meta_packet(e, mb);
-        if (dsv1_buf_append(out, mb, n)) return DSVG_ERR_ARG;
-    }
     rc_after_packet(e, pc->isP, len);
-    link_packet(e, sc->pkt, len, 0);
-    return dsv1_buf_append(out, sc->pkt, len) ? DSVG_ERR_ARG : DSVG_OK;
+    link_packet(e, pkt, len, 0);
+    out->len += len;
+    return DSVG_OK;
 }
 
 typedef struct { dsv1_batch *b; pic_t *pics; } side_ctx;
