@@ -58,7 +58,8 @@ struct Slab {
     X(KID_HME_LEVEL, "void k_hme_level<false>") X(KID_HME_LEVEL0, "void k_hme_level<true>") X(KID_HME_DETAIL, "k_hme_detail") \
     X(KID_MC, "k_mc") \
     X(KID_FWD_HAAR_PIX, "void k_fwd_haar_pix<false>") X(KID_FWD_HAAR_PIX_Q, "void k_fwd_haar_pix<true>") \
-    X(KID_FWD_B4T, "k_fwd_b4t") X(KID_FWD_HAAR_MID2, "void k_fwd_haar_mid<2>") X(KID_FWD_HAAR_MID4, "void k_fwd_haar_mid<4>") \
+    X(KID_FWD_B4T, "void k_fwd_b4t<false>") X(KID_FWD_B4T_Q, "void k_fwd_b4t<true>") \
+    X(KID_FWD_HAAR_MID2, "void k_fwd_haar_mid<2, false>") X(KID_FWD_HAAR_MID2_Q, "void k_fwd_haar_mid<2, true>") X(KID_FWD_HAAR_MID4, "void k_fwd_haar_mid<4, false>") \
     X(KID_FWD_TAIL, "k_fwd_tail") \
     X(KID_HZ_QUANT, "void k_hz_quant<false>") X(KID_HZ_QUANT_LL, "void k_hz_quant<true>") X(KID_HZ_COLLECT, "k_hz_collect") X(KID_HZ_SCAN, "k_hz_scan") \
     X(KID_HZ_EMIT, "k_hz_emit") X(KID_HZ_PARSE, "k_hz_parse") X(KID_HZ_SCATTER, "k_hz_scatter_lv") \
@@ -67,6 +68,7 @@ struct Slab {
     X(KID_INV_TILE_PIX_SYM_F, "void k_inv_haar_tile<true, 0, true>") X(KID_INV_TILE_PIX_SYM, "void k_inv_haar_tile<false, 0, true>") \
     X(KID_INV_TILE_PIX_F, "void k_inv_haar_tile<true, 0, false>") X(KID_INV_TILE_PIX, "void k_inv_haar_tile<false, 0, false>") \
     X(KID_INV_TILE_S1_F, "void k_inv_haar_tile<true, 1, false>") X(KID_INV_TILE_S1, "void k_inv_haar_tile<false, 1, false>") \
+    X(KID_INV_TILE_S1_SYM_F, "void k_inv_haar_tile<true, 1, true>") X(KID_INV_TILE_S1_SYM, "void k_inv_haar_tile<false, 1, true>") \
     X(KID_INV_B4T, "k_inv_b4t")
 enum {
 #define X(id, name) id,

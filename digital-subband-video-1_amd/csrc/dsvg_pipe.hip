@@ -386,8 +386,8 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0)
     const JobDev *jd = c->jobs_d + d0;
     launch_sbt_tail(c->st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
     if (nI > 0) {
-        launch_inv_sbt(c->st, jd, nI, c->G, 0, 1, 0, &c->prof, 0);
-        launch_inv_sbt(c->st, jd, nI, c->G, 1, 2, 0, &c->prof, 0);
+        launch_inv_sbt(c->st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym);
+        launch_inv_sbt(c->st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym);
     }
     if (n > nI) {
         launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, insym);
@@ -439,7 +439,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             }
             JobDev &jb = c->jobs_h[d];
             fill_job(c, jb, k, isP, j.quant, d);
-            jb.fused = isP ? 1 : 0;            // P pictures: quantisation fused into the forward transform
+            jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
             jb.psum = c->psum + (size_t)j.out_slot * 3;
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
@@ -458,8 +458,8 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         const int d0 = base + t * njobs, nI = nIs[t];
         const JobDev *jd = c->jobs_d + d0;
         if (nI > 0) {
-            launch_fwd_sbt(c->st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0);
-            launch_fwd_sbt(c->st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0);
+            launch_fwd_sbt(c->st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0, 1);
+            launch_fwd_sbt(c->st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0, 1);
         }
         if (njobs > nI) {
             const int nP = njobs - nI;
@@ -468,7 +468,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
         }
         launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
-        launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, nI,
+        launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
                          (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
         OPCHK(enqueue_recon(c, nI, njobs, d0, 1));      // P pictures: straight from the symbol planes
     }

@@ -308,6 +308,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
 // --------------------------------------------------------------------------------------------
 // forward, I pictures: level 1 = biorthogonal 4-tap, rows then columns (fwd_b4t_2d sbt.c:240-251)
 // --------------------------------------------------------------------------------------------
+template <bool Q>
 __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
                                                  int from_src)
 {
@@ -359,11 +360,29 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
         }
     }
     const int nC = min(4, max(0, hw - 4 * I));
+    // Q: the level-1 detail bands (scan level 2, shift quantiser) are quantised here; the DEQUANTISED values go to the
+    // coefficient plane (k_inv_b4t reads them) and the symbols to the symbol plane (k_hz_collect compacts them), so the
+    // separate quantiser pass over the plane (k_hz_quant<false>: 8 B per coefficient) disappears for I pictures too.
+    QCtx q;
+    QLevel Lq;
+    int cls[4][4];
+    bool chx = false, chy = false;
+    if (Q) {
+        const HzPlane &hp = jb.hz[c];
+        q.hp = &hp; q.stable = jb.stable;
+        q.sym = jb.sym + jb.nz_off[c];
+        q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+                   (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+        Lq = q_level<2>(hp);
+        q_flags<2, 4>(q, Lq, 4 * I, 4 * J, hw, hh, cls);
+        chx = q.any_ov && I == 0; chy = q.any_ov && J == 0;
+    }
 #pragma unroll
     for (int m = 0; m < 4; m++) {
         const int cy = 4 * J + m;
         if (cy >= hh) break;
         int ll[4], lh[4], hl[4], hhv[4];
+        int slh[4], shl[4], shh[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int am = RL[2 * m][k], a0 = RL[2 * m + 1][k], a1 = RL[2 * m + 2][k], ap = RL[2 * m + 3][k];
@@ -372,6 +391,30 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
             hl[k] = d_rdiv2(am - 3 * a0 + 3 * a1 - ap);
             lh[k] = d_rdiv2(3 * b0 + 3 * b1 - bm - bp);
             hhv[k] = d_rdiv2(bm - 3 * b0 + 3 * b1 - bp);
+            if (Q) {
+                slh[k] = shl[k] = shh[k] = 0;
+                if (k < nC) {
+                    // cells two scan regions share sit on the first column / row of the bands (as in haar_fwd_patch_q)
+                    if (k == 0 && chx) {
+                        lh[k] = q_chain(q, 2, hw, cy, lh[k]);
+                        hhv[k] = q_chain(q, 2, hw, hh + cy, hhv[k]);
+                    }
+                    if (m == 0 && chy) {
+                        hl[k] = q_chain(q, 2, 4 * I + k, hh, hl[k]);
+                        if (!(k == 0 && chx)) hhv[k] = q_chain(q, 2, hw + 4 * I + k, hh, hhv[k]);
+                    }
+                    const int sh = cls[m][k] ? Lq.sh1 : Lq.sh0;
+                    lh[k] = q_coef<2>(sh, 0.f, lh[k], slh[k]);
+                    hl[k] = q_coef<2>(sh, 0.f, hl[k], shl[k]);
+                    hhv[k] = q_coef<2>(sh, 0.f, hhv[k], shh[k]);
+                }
+            }
+        }
+        if (Q) {
+            const int o = cy * Lq.sw + 4 * I;
+            store_sym_row<4>(q.sym + Lq.base0 + o, slh, nC);
+            store_sym_row<4>(q.sym + Lq.base1 + o, shl, nC);
+            store_sym_row<4>(q.sym + Lq.base2 + o, shh, nC);
         }
         store_row<4>(jb.s1 + g.s1off + (size_t)cy * g.w1 + 4 * I, ll, nC);
         store_row<4>(coef + (size_t)cy * W + hw + 4 * I, lh, nC);
@@ -382,7 +425,7 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
 
 // forward: two Haar levels (LV, LV+1) from a compact LL band.  LV = 2: intra pictures, LL1 (s1) -> levels
 // 2..3, LL3 -> s3.  LV = 4: every picture, LL3 (s3) -> levels 4..5, LL5 -> s5 (the band the LDS tail takes).
-template <int LV>
+template <int LV, bool Q>
 __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
@@ -409,6 +452,20 @@ __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__
     // tiny planes (<= 16 samples a side) have fewer levels than this kernel covers: the band is 1x1 by then and the
     // absent levels pass it through unchanged (sbt.c:617-628 stops at lvls)
     if (LV > g.lvls) { out[0] = a[0][0]; return; }
+    if constexpr (Q) {
+        // levels 2,3 of a fused I picture: quantised on the spot, symbols only (scan levels 1, 0)
+        static_assert(LV == 2, "only transform levels 1..3 have per-level scan regions");
+        const HzPlane &hp = jb.hz[c];
+        QCtx q;
+        q.hp = &hp; q.stable = jb.stable;
+        q.sym = jb.sym + jb.nz_off[c];
+        q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+                   (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+        haar_fwd_patch_q<4, 1>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true, q);
+        haar_fwd_patch_q<2, 0>(l2, l3, I, J, wo1, ho1, W, ow, oh, coef, true, q);
+        out[(size_t)J * ow + I] = l3[0][0];
+        return;
+    }
     haar_fwd_patch<4>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true);     // levels >= 2 are always scaled
     if (LV + 1 > g.lvls) { out[0] = l2[0][0]; return; }
     haar_fwd_patch<2>(l2, l3, I, J, wo1, ho1, W, ow, oh, coef, true);
@@ -819,7 +876,7 @@ static __device__ __forceinline__ unsigned pk_pixels(s16x2 e, s16x2 o, bool has_
 template <bool FILT, int MODE, bool SYM>
 __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
-    static_assert(!SYM || MODE == 0, "symbol-plane input is the encoder's P-picture path");
+    static_assert(!SYM || MODE != 2, "levels >= 4 live in the LL region: int32 coefficients");
     constexpr bool TO_PIX = (MODE == 0);
     constexpr int TOP = (MODE == 2) ? 5 : 3;
     __shared__ int A3[A3H * A3W];
@@ -1145,16 +1202,18 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         else       hipLaunchKernelGGL((k_fwd_haar_pix<false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
     } else {
-        PB(KID_FWD_B4T, smp * 5.0);
-        hipLaunchKernelGGL(k_fwd_b4t, grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        PB(fused ? KID_FWD_B4T_Q : KID_FWD_B4T, smp * (fused ? 6.5 : 5.0));   // fused: + 2 B symbols on the 3/4 detail cells
+        if (fused) hipLaunchKernelGGL((k_fwd_b4t<true>), grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
+        else       hipLaunchKernelGGL((k_fwd_b4t<false>), grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
-        PB(KID_FWD_HAAR_MID2, smp * 2.0);        // LL1 (1/4) in, levels 2..3 out
-        hipLaunchKernelGGL((k_fwd_haar_mid<2>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+        PB(fused ? KID_FWD_HAAR_MID2_Q : KID_FWD_HAAR_MID2, smp * (fused ? 1.4 : 2.0));        // LL1 (1/4) in, levels 2..3 out
+        if (fused) hipLaunchKernelGGL((k_fwd_haar_mid<2, true>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+        else       hipLaunchKernelGGL((k_fwd_haar_mid<2, false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
         PE();
     }
     // levels 4..5 (LL3 -> LL5) for every picture type
     PB(KID_FWD_HAAR_MID4, s3 * 8.0);
-    hipLaunchKernelGGL((k_fwd_haar_mid<4>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    hipLaunchKernelGGL((k_fwd_haar_mid<4, false>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
     PE();
     if (with_tail) {
         PB(KID_FWD_TAIL, (double)g.w5 * g.h5 * nz * 8.0);
@@ -1210,9 +1269,14 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         }
         PE();
     } else {
-        PB(filt ? KID_INV_TILE_S1_F : KID_INV_TILE_S1, smp * 2.0);
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        PB(insym ? (filt ? KID_INV_TILE_S1_SYM_F : KID_INV_TILE_S1_SYM) : (filt ? KID_INV_TILE_S1_F : KID_INV_TILE_S1), smp * (insym ? 1.4 : 2.0));
+        if (insym) {
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        } else {
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        }
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
         PB(KID_INV_B4T, smp * 5.0);
