@@ -18,7 +18,6 @@
 // (hme.c:652-682), the representability veto (hme.c:147-179) and the 4-quadrant vote (hme.c:89-134,
 // 689-716).  high_detail needs the left/top/top-left neighbours' final flags (hme.c:621-648) and is
 // resolved by the second tiny kernel k_hme_detail.
-#include <type_traits>
 #include "dsvg_dev.hpp"
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
@@ -220,7 +219,6 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     const int nkb = (bh + NRG - 1) / NRG;
     const int r0 = rg * nkb;
 #define ROWOK(k) ((k) < nkb && r0 + (k) < bh)
-    const bool uni = (bh % NRG) == 0;                   // every lane owns exactly nkb rows
     const int xcol = 4 * cg;
     const unsigned cmask = xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u));
     unsigned srcw[NK];
@@ -282,31 +280,23 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
                         const unsigned *pa = reinterpret_cast<const unsigned *>(p0 - sh);
                         const int sdw = stride >> 2;
                         constexpr int CB = 8;                      // rows per batch (registers)
-                        // uni: bh is a multiple of the row groups, so "row k exists" is the wave-uniform k < nkb -- rows past
-                        // nkb are skipped by scalar branches and no per-lane select is needed
-                        auto score = [&](auto UNI) {
 #pragma unroll
-                            for (int b0 = 0; b0 < NK; b0 += CB) {
-                                if (decltype(UNI)::value && b0 >= nkb) break;
-                                unsigned lo[CB], hi[CB];
+                        for (int b0 = 0; b0 < NK; b0 += CB) {
+                            unsigned lo[CB], hi[CB];
 #pragma unroll
-                                for (int u = 0; u < CB; u++) {
-                                    const long o = (long)min(b0 + u, nkb - 1) * sdw;
-                                    lo[u] = pa[o]; hi[u] = pa[o + 1];
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int u = 0; u < CB; u++) {
-                                    if (decltype(UNI)::value && b0 + u >= nkb) break;
-                                    const unsigned rw = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh) & cmask;
-                                    const unsigned a6 = __builtin_amdgcn_sad_u8(srcw[b0 + u], rw, acc[k]);
-                                    if (decltype(UNI)::value) acc[k] = a6;
-                                    else acc[k] = ROWOK(b0 + u) ? a6 : acc[k];
-                                }
-                                __builtin_amdgcn_sched_barrier(0);
+                            for (int u = 0; u < CB; u++) {
+                                const long o = (long)min(b0 + u, nkb - 1) * sdw;
+                                lo[u] = pa[o]; hi[u] = pa[o + 1];
                             }
-                        };
-                        if (uni) score(std::true_type{}); else score(std::false_type{});
+                            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                            for (int u = 0; u < CB; u++) {
+                                const unsigned rw = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh) & cmask;
+                                const unsigned a6 = __builtin_amdgcn_sad_u8(srcw[b0 + u], rw, acc[k]);
+                                acc[k] = ROWOK(b0 + u) ? a6 : acc[k];
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
                     }
                 }
             }
@@ -345,44 +335,38 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
             // rows past the thread's last reference row re-read that row
             // three batches of six row loads, each issued back to back (one memory round trip per batch instead of
             // one per row) -- a single batch would cost occupancy in registers
-            auto nine = [&](auto UNI) {
-                unsigned v[3][3];                                  // rolling: v[t % 3][ox] = reference row t, offset ox
+            unsigned v[3][3];                                      // rolling: v[t % 3][ox] = reference row t, offset ox
 #pragma unroll
-                for (int half = 0; half < 3; half++) {
-                    constexpr int HB = (NK + 2) / 3;
-                    if (decltype(UNI)::value && half * HB >= nkb + 2) break;
-                    unsigned d[HB][3];
+            for (int half = 0; half < 3; half++) {
+                constexpr int HB = (NK + 2) / 3;
+                unsigned d[HB][3];
 #pragma unroll
-                    for (int u = 0; u < HB; u++) {
-                        const long o = (long)min(half * HB + u, nkb + 1) * sdw;
-                        d[u][0] = ga[o]; d[u][1] = ga[o + 1]; d[u][2] = ga[o + 2];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);             // keep the scheduler from sinking loads between the SADs
+                for (int u = 0; u < HB; u++) {
+                    const long o = (long)min(half * HB + u, nkb + 1) * sdw;
+                    d[u][0] = ga[o]; d[u][1] = ga[o + 1]; d[u][2] = ga[o + 2];
+                }
+                __builtin_amdgcn_sched_barrier(0);                 // keep the scheduler from sinking loads between the SADs
 #pragma unroll
-                    for (int u = 0; u < HB; u++) {
-                        const int t = half * HB + u;
-                        if (decltype(UNI)::value && t >= nkb + 2) break;
-                        const unsigned lo = __builtin_amdgcn_alignbyte(d[u][1], d[u][0], mis);   // window bytes 0..3 of the row
-                        const unsigned hi = __builtin_amdgcn_alignbyte(d[u][2], d[u][1], mis);   //              4..7
-                        v[t % 3][0] = lo & cmask;
-                        v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u) & cmask;
-                        v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u) & cmask;
-                        const int k = t - 2;                       // source row whose three reference rows are now complete
-                        if (k >= 0) {
-                            const unsigned sw = srcw[k];
-                            const bool ok = ROWOK(k);
+                for (int u = 0; u < HB; u++) {
+                    const int t = half * HB + u;
+                    const unsigned lo = __builtin_amdgcn_alignbyte(d[u][1], d[u][0], mis);   // window bytes 0..3 of the row
+                    const unsigned hi = __builtin_amdgcn_alignbyte(d[u][2], d[u][1], mis);   //              4..7
+                    v[t % 3][0] = lo & cmask;
+                    v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u) & cmask;
+                    v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u) & cmask;
+                    const int k = t - 2;                           // source row whose three reference rows are now complete
+                    if (k >= 0) {
+                        const unsigned sw = srcw[k];
+                        const bool ok = ROWOK(k);
 #pragma unroll
-                            for (int c9 = 0; c9 < 9; c9++) {
-                                const unsigned a9 = __builtin_amdgcn_sad_u8(sw, v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
-                                if (decltype(UNI)::value) acc[c9] = a9;
-                                else acc[c9] = ok ? a9 : acc[c9];
-                            }
+                        for (int c9 = 0; c9 < 9; c9++) {
+                            const unsigned a9 = __builtin_amdgcn_sad_u8(sw, v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
+                            acc[c9] = ok ? a9 : acc[c9];
                         }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
-            };
-            if (uni) nine(std::true_type{}); else nine(std::false_type{});
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
         block_sum_n<9>(acc, S.part, phase);
         best = 0x7fffffff; bestk = 0;
