@@ -114,19 +114,35 @@ static __device__ __forceinline__ unsigned wave_sum(unsigned v)
 template <int N>
 static __device__ __forceinline__ void block_sum_n(unsigned (&v)[N], unsigned (*part)[NW][14], int &phase)
 {
-    // step-major over the N independent chains: a DPP read needs two wait states after the write it consumes
+    // Four values per pass (gfx950 v_permlane32_swap / v_permlane16_swap, checked in tools/ubench/permlane_swap.hip):
+    // swap32 + add folds the two 32-lane halves of a PAIR of values into one register (lanes 0-31: first value,
+    // 32-63: second); swap16 + add folds two such registers into one whose four 16-lane rows hold the values
+    // a, c, b, d; four DPP steps finish the rows; one v_readlane per value.  14 VALU per 4 values instead of 32.
 #pragma unroll
-    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0xB1, 0xf, 0xf, true);
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0x4E, 0xf, 0xf, true);
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0x141, 0xf, 0xf, true);
-#pragma unroll
-    for (int i = 0; i < N; i++) v[i] += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v[i], 0x140, 0xf, 0xf, true);
-#pragma unroll
-    for (int i = 0; i < N; i++)
-        v[i] = (unsigned)__builtin_amdgcn_readlane((int)v[i], 0) + (unsigned)__builtin_amdgcn_readlane((int)v[i], 16) +
-               (unsigned)__builtin_amdgcn_readlane((int)v[i], 32) + (unsigned)__builtin_amdgcn_readlane((int)v[i], 48);
+    for (int i = 0; i + 1 < N; i += 4) {
+        unsigned a = v[i], b = v[i + 1], c = i + 2 < N ? v[i + 2] : 0u, d = i + 3 < N ? v[i + 3] : 0u;
+        const auto p = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+        const auto q = __builtin_amdgcn_permlane32_swap(c, d, false, false);
+        const auto r = __builtin_amdgcn_permlane16_swap(p[0] + p[1], q[0] + q[1], false, false);
+        unsigned t = r[0] + r[1];
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xf, 0xf, true);
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, true);
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x141, 0xf, 0xf, true);
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x140, 0xf, 0xf, true);
+        v[i] = (unsigned)__builtin_amdgcn_readlane((int)t, 0);
+        v[i + 1] = (unsigned)__builtin_amdgcn_readlane((int)t, 32);
+        if (i + 2 < N) v[i + 2] = (unsigned)__builtin_amdgcn_readlane((int)t, 16);
+        if (i + 3 < N) v[i + 3] = (unsigned)__builtin_amdgcn_readlane((int)t, 48);
+    }
+    if (N % 4 == 1) {       // a single left-over value: the plain DPP chain
+        unsigned t = v[N - 1];
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xf, 0xf, true);
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, true);
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x141, 0xf, 0xf, true);
+        t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x140, 0xf, 0xf, true);
+        v[N - 1] = (unsigned)__builtin_amdgcn_readlane((int)t, 0) + (unsigned)__builtin_amdgcn_readlane((int)t, 16) +
+                   (unsigned)__builtin_amdgcn_readlane((int)t, 32) + (unsigned)__builtin_amdgcn_readlane((int)t, 48);
+    }
     if (NW == 1) return;
     unsigned (*pb)[14] = part[phase];
     phase ^= 1;
