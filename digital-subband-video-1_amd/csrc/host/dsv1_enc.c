@@ -73,8 +73,9 @@ static void hp_report(void)
 }
 
 /* The per-stream host phases (side info, packet assembly) are independent across streams: a plain pthread
- * fork/join over them.  Threads: DSV1_HOST_THREADS (default 6), never more than streams. */
+ * fork/join over them.  Threads: DSV1_HOST_THREADS, else min(6, cores / ranks on the node / 2); never more than streams. */
 #include <pthread.h>
+#include <unistd.h>
 typedef void (*par_fn)(void *ctx, int s, int tid);
 typedef struct { par_fn fn; void *ctx; int tid, nthr, S; } par_arg;
 static void *par_main(void *p)
@@ -87,7 +88,22 @@ static void *par_main(void *p)
 static int par_threads(int S)
 {
     static int n = 0;
-    if (!n) { const char *e = getenv("DSV1_HOST_THREADS"); n = e ? atoi(e) : 6; if (n < 1) n = 1; if (n > 64) n = 64; }
+    if (!n) {
+        const char *e = getenv("DSV1_HOST_THREADS");
+        if (e) n = atoi(e);
+        else {
+            /* default: up to 6, but never more than half of this process's share of the host's cores (one process per
+             * GPU: LOCAL_WORLD_SIZE of the launcher tells how many share the node) */
+            const char *lw = getenv("LOCAL_WORLD_SIZE");
+            long cores = sysconf(_SC_NPROCESSORS_ONLN), ranks = lw ? atol(lw) : 1;
+            if (ranks < 1) ranks = 1;
+            if (cores < 1) cores = 1;
+            n = (int)(cores / ranks / 2);
+            if (n > 6) n = 6;
+        }
+        if (n < 1) n = 1;
+        if (n > 64) n = 64;
+    }
     return n < S ? n : S;
 }
 static void par_for_streams(int S, par_fn fn, void *ctx)
