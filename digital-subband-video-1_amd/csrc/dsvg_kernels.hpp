@@ -43,7 +43,9 @@ void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long
 // mvs0: the jobs' vector arrays when they are contiguous (job j at mvs0 + j * nblocks), else null (JobDev.mvs is used)
 void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr, const DMV *mvs0 = nullptr);
 // k_frame.hip
-void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr);
+int  unpack_fuses_level1(const FrameLayout &L);
+void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr,
+                   uint8_t *slab1 = nullptr, const FrameLayout *L1 = nullptr);
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);
 void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf = nullptr);
 void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr);

@@ -251,11 +251,14 @@ extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t 
 // ------------------------------------------------------------------------------------------------
 static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d)
 {
-    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d);
+    // the first pyramid level comes out of the unpack kernel when the luma plane allows it (one read of the frame less)
+    const bool fuse1 = with_pyramid && c->levels >= 1 && unpack_fuses_level1(c->L[0]);
+    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr);
     launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
-            launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d);
+            if (!(l == 1 && fuse1))
+                launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d);
             launch_extend(c->st_a, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof);
         }
         if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st_a));

@@ -10,7 +10,7 @@
 // tightly packed planar frames -> interiors of bordered frames (grid.y = plane, grid.z = frame)
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv, size_t yuv_pitch,
                                                 uint8_t *__restrict__ slab, FrameLayout L, int first_slot,
-                                                const int *__restrict__ slot_tab)
+                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1)
 {
     const int c = blockIdx.y, f = blockIdx.z;
     const int slot = slot_tab ? slot_tab[f] : first_slot + f;
@@ -20,6 +20,30 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
     const uint8_t *src = yuv + (size_t)f * yuv_pitch + poff;
     uint8_t *dst = slab + (size_t)slot * L.pitch + L.off[c];
     const bool vec = ((w & 15) == 0) && ((((uintptr_t)src) & 15) == 0);
+    if (vec && c == 0 && slab1 && (h & 1) == 0) {
+        // luma with the first pyramid level fused in (dsv_ds2x_frame_luma frame.c:240-261: (p1+p2+p3+p4+2)>>2): two rows x 16
+        // pixels per thread, so the bordered frame is not read again for the 2x2 means (even dims: no border pixel enters)
+        uint8_t *dst1 = slab1 + (size_t)slot * L1.pitch + L1.off[0];
+        const int nv = w >> 4, hr = h >> 1;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nv * hr; i += gridDim.x * 256) {
+            const int y2 = i / nv, x = i - y2 * nv;
+            const uint4 r0 = reinterpret_cast<const uint4 *>(src + (size_t)(2 * y2) * w)[x];
+            const uint4 r1 = reinterpret_cast<const uint4 *>(src + (size_t)(2 * y2 + 1) * w)[x];
+            reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2) * L.stride[0])[x] = r0;
+            reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2 + 1) * L.stride[0])[x] = r1;
+            const unsigned a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
+            unsigned o[2] = {0u, 0u};
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const unsigned wa = a[k >> 1], wb = b[k >> 1];
+                const int sh = 16 * (k & 1);
+                const unsigned sum = ((wa >> sh) & 0xff) + ((wa >> (sh + 8)) & 0xff) + ((wb >> sh) & 0xff) + ((wb >> (sh + 8)) & 0xff);
+                o[k >> 2] |= ((sum + 2) >> 2) << (8 * (k & 3));
+            }
+            *reinterpret_cast<uint2 *>(dst1 + (size_t)y2 * L1.stride[0] + 8 * x) = make_uint2(o[0], o[1]);
+        }
+        return;
+    }
     if (vec) {
         const int nv = w >> 4;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < nv * h; i += gridDim.x * 256) {
@@ -190,10 +214,16 @@ __global__ __launch_bounds__(256) void k_frame_add(uint8_t *__restrict__ dst, Fr
 
 static inline int nblk(long items, int cap) { long b = (items + 255) / 256; return (int)(b < 1 ? 1 : (b > cap ? cap : b)); }
 
-void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab)
+// slab1 / L1: when given (and the luma plane qualifies, see unpack_fuses_level1) the first pyramid level is produced
+// by the same kernel
+int unpack_fuses_level1(const FrameLayout &L) { return (L.w[0] & 15) == 0 && (L.h[0] & 1) == 0; }
+void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
+                   uint8_t *slab1, const FrameLayout *L1)
 {
-    if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]));
-    hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab);
+    FrameLayout dummy = L;
+    if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0));
+    hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
+                       slab1, L1 ? *L1 : dummy);
     if (pf) pf->end(st);
 }
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)
