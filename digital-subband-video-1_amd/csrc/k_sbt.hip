@@ -825,10 +825,11 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
 }
 
 // ---- two level-1 cells per instruction (v_pk_*_i16): the encoder's P-picture luma inverse ----------------------
-// Level 1 of a P picture is unscaled and works on an 8-bit residual: |LL1| <= 512, the dequantised details are no
-// larger than the coefficients they came from, every intermediate of the nudge and of the outputs stays far inside
-// int16.  (Only the encoder takes this path: its symbols come from real residuals.  The decoder, which must follow
-// the reference on arbitrary streams, keeps the 32-bit cells.)
+// Level 1 of a P picture is unscaled and works on an 8-bit residual.  Worst-case magnitudes in the ENCODER (symbols
+// come from our own forward transform; a dequantised value is at most twice the coefficient it came from): level-1
+// details <= 1020, reconstructed LL1 (the level-2 outputs in A1) <= ~7000, so lp - ln <= 14000, mn - mx <= 28000 and
+// the output sums <= 10100 -- all inside int16.  The decoder, which must follow the reference on arbitrary streams,
+// keeps the 32-bit cells.
 typedef short s16x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ s16x2 pk2(int a, int b) { return s16x2{(short)a, (short)b}; }
 static __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
