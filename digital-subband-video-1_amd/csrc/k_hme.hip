@@ -98,17 +98,6 @@ struct HmeShared {
     unsigned part[2][NW][14];
 };
 
-// wave64 sum through DPP (no LDS traffic); the result is wave-uniform (SGPR)
-static __device__ __forceinline__ unsigned wave_sum(unsigned v)
-{
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xf, 0xf, true);     // quad_perm [1,0,3,2]
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xf, 0xf, true);     // quad_perm [2,3,0,1]
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xf, 0xf, true);    // row_half_mirror
-    v += (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xf, 0xf, true);    // row_mirror: every lane = its row's sum
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
-           (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-}
-
 // sum N values over the workgroup; every thread receives all totals (wave-uniform).  `part` is double
 // buffered by the caller-maintained phase bit, so one barrier per reduction suffices.
 template <int N>
