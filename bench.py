@@ -79,6 +79,9 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events")
+    ap.add_argument("--input", choices=["hbm", "host", "pinned"], default="hbm",
+                    help="where the raw frames are when a step starts: hbm (the metric), or host memory (pageable / pinned) "
+                         "uploaded over PCIe inside the timed region (diagnostic, DESIGN.md section 7)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -115,7 +118,14 @@ def main():
 
     cfg = pkg.make_encoder_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1)
     b = pkg.Batch(cfg, args.gops, GOP, device=dev)
-    dptr = b.upload(batch_in)                       # raw clip resident in HBM before any timing
+    if args.input == "hbm":
+        src, ondev = b.upload(batch_in), True       # raw clip resident in HBM before any timing
+    else:
+        if args.input == "pinned":
+            host = b.pinned(batch_in.shape)
+            host[...] = batch_in
+            batch_in = host
+        src, ondev = batch_in, False
 
     def sync_all():
         if world > 1:
@@ -129,24 +139,28 @@ def main():
     # region boundaries (its device part is synchronised on both sides).
     outs = None
     for _ in range(max(args.warmup, 1)):
-        outs = b.encode(dptr, on_device=True)
+        outs = b.encode(src, on_device=ondev)
     # pick the kernel to time: one untimed step with every kernel bracketed, take the largest total
     names = b.kernel_names()
     table = {}
     prof_kernel = args.prof_kernel
     if rank == 0:
         b.prof_enable(names)
-        b.encode(dptr, on_device=True)
+        b.encode(src, on_device=ondev)
         b.sync()
         table = {k: b.prof_get(k) for k in names}
         if prof_kernel == "auto":
             prof_kernel = max(table, key=lambda k: table[k][0])
         b.prof_enable([prof_kernel])
-    b.submit(dptr, on_device=True)                  # fill the pipeline
+    b.submit(src, on_device=ondev)                  # fill the pipeline
     sync_all()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        b.submit(dptr, on_device=True)
+    if not ondev:
+        b.stage(src)                                # host input: K uploads inside the timed region, queued back to back
+    for i in range(args.steps):
+        if not ondev and i + 1 < args.steps:
+            b.stage(src)                            # the next step's upload follows this one's on the copy stream
+        b.submit(src, on_device=ondev)
         outs = b.collect(copy=False)                # the finished packets stay in the buffers they were assembled in
     sync_all()
     dt = time.perf_counter() - t0
@@ -219,7 +233,9 @@ def main():
             "vs_baseline": None,
             "dtype": "u8/int32",
             "data": "synthetic",
-            "config": {"workload": "1920x1080 4:2:0 GOP=12 CRF qp85, %d closed GOPs (x12 frames) per GPU per step, raw frames resident in HBM, output = finished .dsv packets" % args.gops,
+            "config": {"workload": "1920x1080 4:2:0 GOP=12 CRF qp85, %d closed GOPs (x12 frames) per GPU per step, %s, output = finished .dsv packets"
+                       % (args.gops, {"hbm": "raw frames resident in HBM", "host": "raw frames uploaded from pageable host memory each step (PCIe inclusive, diagnostic)",
+                                      "pinned": "raw frames uploaded from pinned host memory each step (PCIe inclusive, diagnostic)"}[args.input]),
                        "gops_per_gpu": args.gops, "frames_per_step": args.gops * GOP * world,
                        "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world},
             "bit_exact_vs_cpu": bit_exact,

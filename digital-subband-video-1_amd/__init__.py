@@ -64,6 +64,9 @@ def lib():
         L.dsvg_dev_free.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsvg_dev_upload.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
+        L.dsvg_host_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
+        L.dsvg_host_free.argtypes = [_C.c_void_p, _C.c_void_p]
+        L.dsv1_batch_stage.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_ulonglong]
         L.dsvg_prof_reset.argtypes = [_C.c_void_p]
         L.dsvg_prof_get.argtypes = [_C.c_void_p, _C.c_int, _C.POINTER(_C.c_double), _C.POINTER(_C.c_long),
@@ -151,6 +154,7 @@ class Batch:
         _chk(self.L.dsv1_batch_open(_C.byref(self.h), _C.byref(cfg), device, nstreams, frames_per_call), "dsv1_batch_open")
         self.ctx = self.L.dsv1_batch_ctx(self.h)
         self._dev = []
+        self._pin = []
 
     def set_fnum(self, stream, fnum):
         self.L.dsv1_batch_set_fnum(self.h, stream, fnum)
@@ -163,6 +167,20 @@ class Batch:
         _chk(self.L.dsvg_dev_upload(self.ctx, p, a.ctypes.data, a.nbytes), "dsvg_dev_upload")
         self._dev.append(p)
         return p
+
+    def pinned(self, shape):
+        """uint8 numpy array in pinned host memory (dsvg_host_alloc): uploads from it are asynchronous"""
+        n = int(_np.prod(shape))
+        p = _C.c_void_p(None)
+        _chk(self.L.dsvg_host_alloc(self.ctx, _C.byref(p), n), "dsvg_host_alloc")
+        self._pin.append(p)
+        return _np.ctypeslib.as_array(_C.cast(p, _C.POINTER(_C.c_uint8)), shape=(n,)).reshape(shape)
+
+    def stage(self, yuv):
+        """queue the upload of the host clip of a coming submit() (up to two; submit() must get the same memory)"""
+        assert yuv.dtype == _np.uint8 and yuv.flags["C_CONTIGUOUS"]
+        self._keep_staged = (getattr(self, "_keep_staged", []) + [yuv])[-3:]
+        _chk(self.L.dsv1_batch_stage(self.h, yuv.ctypes.data), "dsv1_batch_stage")
 
     def encode(self, yuv, on_device=False, eos=False):
         """yuv: numpy [nstreams][F][frame_bytes] (host) or a device pointer from upload();
@@ -229,6 +247,10 @@ class Batch:
             for p in self._dev:
                 self.L.dsvg_dev_free(self.ctx, p)
             self._dev = []
+            self.L.dsvg_ctx_sync(self.ctx)
+            for p in self._pin:
+                self.L.dsvg_host_free(self.ctx, p)
+            self._pin = []
             self.L.dsv1_batch_close(self.h)
             self.h = None
 

@@ -59,6 +59,14 @@ struct dsvg_ctx {
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
     int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
+    // host-resident input: two device ingest buffers filled on a copy stream of their own, so the upload of the
+    // next batch runs under the analysis and coding of the current one
+    hipStream_t st_h = nullptr;
+    uint8_t *ingest[2] = {nullptr, nullptr};
+    size_t ingest_bytes[2] = {0, 0};
+    hipEvent_t ev_up[2] = {nullptr, nullptr}, ev_used[2] = {nullptr, nullptr};
+    bool up_pending[2] = {false, false}, used_valid[2] = {false, false};
+    int ingest_next = 0;
     unsigned long long *gtab_d = nullptr, *gtab_h = nullptr;   // gather table (3 words per plane payload)
     uint8_t *gath_d = nullptr, *gath_h = nullptr;              // compacted payloads (device / pinned host)
     size_t gath_cap = 0;
@@ -72,7 +80,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ingest[0], c->ingest[1]};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -80,6 +88,11 @@ static void ctx_free(dsvg_ctx *c)
     if (c->st_a) (void)hipStreamDestroy(c->st_a);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->st_c) (void)hipStreamDestroy(c->st_c);
+    if (c->st_h) (void)hipStreamDestroy(c->st_h);
+    for (int i = 0; i < 2; i++) {
+        if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
+        if (c->ev_used[i]) (void)hipEventDestroy(c->ev_used[i]);
+    }
     for (hipEvent_t e : c->ev_coded) (void)hipEventDestroy(e);
     delete c;
 }
@@ -217,6 +230,7 @@ extern "C" int dsvg_ctx_sync(dsvg_ctx *c)
 {
     if (!c) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    if (c->st_h) HIPCHK(hipStreamSynchronize(c->st_h));
     HIPCHK(hipStreamSynchronize(c->st_a));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipStreamSynchronize(c->st_c));
@@ -245,6 +259,76 @@ extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t 
     if (!c) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     HIPCHK(hipMemcpy(dptr, src, bytes, hipMemcpyHostToDevice));
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_host_alloc(dsvg_ctx *c, void **hptr, size_t bytes)
+{
+    if (!c || !hptr) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipHostMalloc(hptr, bytes + 64, hipHostMallocDefault));
+    return DSVG_OK;
+}
+extern "C" int dsvg_host_free(dsvg_ctx *c, void *hptr)
+{
+    if (!c) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipHostFree(hptr));
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_ingest_begin(dsvg_ctx *c, const void *yuv_host, size_t bytes, void **dptr)
+{
+    if (!c || !yuv_host || !dptr || !bytes) { dsvg_set_error("bad ingest arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->st_h) {
+        HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; i++) {
+            HIPCHK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_used[i], hipEventDisableTiming));
+        }
+    }
+    const int k = c->ingest_next;
+    c->ingest_next ^= 1;
+    if (c->ingest_bytes[k] < bytes) {
+        if (c->ingest[k]) {                      // the old buffer may still be read by load kernels / an earlier copy
+            HIPCHK(hipStreamSynchronize(c->st_h));
+            HIPCHK(hipStreamSynchronize(c->st_a));
+            (void)hipFree(c->ingest[k]);
+            c->ingest[k] = nullptr; c->ingest_bytes[k] = 0;
+        }
+        HIPCHK(hipMalloc((void **)&c->ingest[k], bytes + 256));
+        c->ingest_bytes[k] = bytes;
+        c->used_valid[k] = false;
+    }
+    if (c->used_valid[k]) HIPCHK(hipStreamWaitEvent(c->st_h, c->ev_used[k], 0));    // its last readers (analysis stream)
+    HIPCHK(hipMemcpyAsync(c->ingest[k], yuv_host, bytes, hipMemcpyHostToDevice, c->st_h));
+    HIPCHK(hipEventRecord(c->ev_up[k], c->st_h));
+    c->up_pending[k] = true;
+    *dptr = c->ingest[k];
+    return DSVG_OK;
+}
+
+// a frame source inside an ingest buffer: the analysis stream waits for the upload; returns the buffer index or -1
+static int ingest_acquire(dsvg_ctx *c, const void *dsrc)
+{
+    for (int k = 0; k < 2; k++) {
+        const uint8_t *b = c->ingest[k], *p = (const uint8_t *)dsrc;
+        if (b && p >= b && p < b + c->ingest_bytes[k]) {
+            if (c->up_pending[k]) {
+                if (hipStreamWaitEvent(c->st_a, c->ev_up[k], 0) != hipSuccess) return -2;
+                c->up_pending[k] = false;
+            }
+            return k;
+        }
+    }
+    return -1;
+}
+static int ingest_release(dsvg_ctx *c, int k)
+{
+    if (k < 0) return DSVG_OK;
+    HIPCHK(hipEventRecord(c->ev_used[k], c->st_a));
+    c->used_valid[k] = true;
     return DSVG_OK;
 }
 
@@ -302,7 +386,10 @@ extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const 
         if (slots[i] < 0 || slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
     if (!c->ltab_d) HIPCHK(hipMalloc((void **)&c->ltab_d, sizeof(int) * (size_t)c->n_src + 64));
     HIPCHK(hipMemcpyAsync(c->ltab_d, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_a));   // pageable: staged by the runtime
-    return load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d);
+    const int k = ingest_acquire(c, yuv_dev);
+    if (k == -2) { dsvg_set_error("hipStreamWaitEvent failed"); return DSVG_ERR_HIP; }
+    const int rc = load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d);
+    return rc ? rc : ingest_release(c, k);
 }
 
 extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *sums_out)

@@ -38,8 +38,9 @@ struct dsv1_batch {
     DSV_MV *mvpool;
     unsigned char *stabpool;
     uint8_t *prefixpool;
-    void *yuv_dev;
-    size_t yuv_dev_bytes;
+    const void *staged_host[2];      /* dsv1_batch_stage: FIFO of host clips whose upload is already queued */
+    void *staged_dev[2];
+    int nstaged;
     int *slots_cur, *slots_ref, *pair_pic, *out_slots;
     unsigned *luma;
     DSV_MV *mv_tmp;
@@ -128,7 +129,6 @@ void dsv1_batch_close(dsv1_batch *b)
 {
     hp_report();
     if (!b) return;
-    if (b->yuv_dev) dsvg_dev_free(b->ctx, b->yuv_dev);
     if (b->ctx) dsvg_ctx_destroy(b->ctx);
     if (b->own_enc && b->enc) {
         int s;
@@ -535,17 +535,17 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     if (b->pending[par]) { dsv1_log(1, "batch submitted twice without collect"); return DSVG_ERR_ARG; }
     pics = b->pics + (size_t)par * S * F;
     if (!yuv_on_device) {
-        const size_t total = fb * (size_t)S * F;
-        if (b->yuv_dev_bytes < total) {
-            if ((rc = dsvg_ctx_sync(b->ctx))) return rc;
-            if (b->yuv_dev) dsvg_dev_free(b->ctx, b->yuv_dev);
-            b->yuv_dev = NULL;
-            if ((rc = dsvg_dev_alloc(b->ctx, &b->yuv_dev, total))) return rc;
-            b->yuv_dev_bytes = total;
+        /* host frames go through the context's double-buffered ingest (copy stream of its own): nothing here waits
+         * for the device, and a clip announced with dsv1_batch_stage() is already on its way */
+        if (!b->nstaged) {
+            if ((rc = dsv1_batch_stage(b, yuv))) return rc;
+        } else if (b->staged_host[0] != yuv) {
+            dsv1_log(1, "a different clip was staged for this submit");
+            return DSVG_ERR_ARG;
         }
-        if ((rc = dsvg_ctx_sync(b->ctx))) return rc;          /* the staging copy below is reused */
-        if ((rc = dsvg_dev_upload(b->ctx, b->yuv_dev, yuv, total))) return rc;
-        dyuv = (const uint8_t *)b->yuv_dev;
+        dyuv = (const uint8_t *)b->staged_dev[0];
+        b->staged_host[0] = b->staged_host[1]; b->staged_dev[0] = b->staged_dev[1];
+        b->nstaged--;
     }
     /* 1. source-only preparation for every frame: bordered layout, pyramid, mean luma */
     for (s = 0; s < S; s++)
@@ -641,6 +641,16 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     hp_batches++;
     b->gcount += (unsigned)F;
     b->parity ^= 1;
+    return DSVG_OK;
+}
+
+int dsv1_batch_stage(dsv1_batch *b, const void *yuv_host)
+{
+    int rc;
+    if (!b || !yuv_host) return DSVG_ERR_ARG;
+    if (b->nstaged == 2) { dsv1_log(1, "two clips are staged already"); return DSVG_ERR_ARG; }
+    if ((rc = dsvg_ingest_begin(b->ctx, yuv_host, b->g.frame_bytes * (size_t)b->nstreams * b->F, &b->staged_dev[b->nstaged]))) return rc;
+    b->staged_host[b->nstaged++] = yuv_host;
     return DSVG_OK;
 }
 

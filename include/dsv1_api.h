@@ -158,6 +158,13 @@ int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BU
  * into out (each quantiser needs the previous packet size) and collect only releases the slot. */
 int  dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
 int  dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out);
+/* Host-resident input (the .yuv reader of dsv_main.c:394-421): announce the host clip of a coming submit.  Its
+ * upload is queued at once on a copy stream and runs under whatever the device is doing; up to two clips may be
+ * staged, and dsv1_batch_submit(b, yuv_host, 0, ...) consumes the oldest one (it must be given the same pointer; a
+ * submit with nothing staged starts the upload itself).  Asynchronous when yuv_host is pinned (dsvg_host_alloc): the
+ * clip must stay unchanged until the collect of that batch returned.  Steady state, uploads back to back:
+ *   stage(i+2); submit(i+1); collect(i). */
+int  dsv1_batch_stage(dsv1_batch *b, const void *yuv_host);
 /* append the end-of-stream packet of stream s */
 int  dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out);
 /* Concatenate per-GOP streams (each encoded independently with fnum seeded to its position) into one

@@ -114,6 +114,15 @@ void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the hipStream_t all pipeline wor
 int dsvg_dev_alloc(dsvg_ctx *ctx, void **dptr, size_t bytes);
 int dsvg_dev_free(dsvg_ctx *ctx, void *dptr);
 int dsvg_dev_upload(dsvg_ctx *ctx, void *dptr, const void *src, size_t bytes);
+/* Host-resident input (dsv_main.c:394-421 reads each frame from the .yuv into host memory).  dsvg_host_alloc gives
+ * pinned memory; dsvg_ingest_begin starts the upload of `bytes` of packed frames on a copy stream of its own into one
+ * of two device buffers owned by the context and returns that buffer: a following dsvg_load_frames_map on it waits for
+ * the copy on the device, not on the host.  Asynchronous for pinned memory (the caller keeps yuv_host unchanged until
+ * that load has run: after a dsvg_get_luma_sums / dsvg_analyse / dsvg_ctx_sync that follows it); pageable memory works
+ * and is staged by the runtime inside the call.  At most two ingests may be outstanding. */
+int dsvg_host_alloc(dsvg_ctx *ctx, void **hptr, size_t bytes);
+int dsvg_host_free(dsvg_ctx *ctx, void *hptr);
+int dsvg_ingest_begin(dsvg_ctx *ctx, const void *yuv_host, size_t bytes, void **dptr);
 
 /* Tightly packed planar frames -> resident source slots [first_slot, first_slot+n):
  * copy into the bordered reference layout, replicate borders (dsv_clone_frame/dsv_extend_frame),

@@ -121,6 +121,41 @@ def test_pipelined_submit_collect_equals_plain_encode(pkg, orc):
         assert got[s] == want[s], "stream %d: %s" % (s, explain(got[s], want[s]))
 
 
+@pytest.mark.parametrize("pinned", [True, False])
+def test_staged_host_ingest_equals_plain_encode(pkg, orc, pinned):
+    """host-resident clips through the double-buffered ingest (dsv1_batch_stage: the upload of batch i+1 is queued
+    before batch i is submitted and batch i-1 collected): every batch has different content, three host buffers rotate"""
+    w, h, fmt, gop, S, nb = 352, 288, A.SUBSAMP_420, 4, 3, 6
+    clips = [A.gen_clip(w, h, fmt, 0x7300 + s, gop * nb, style=s % 3) for s in range(S)]
+    cfg = pkg.make_encoder_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1)
+    want = [A.orc_encode(clips[s], A.orc_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1), eos=False)[0] for s in range(S)]
+    b = pkg.Batch(cfg, S, gop)
+    shape = (S, gop, clips[0].shape[1])
+    hostbuf = [b.pinned(shape) if pinned else np.empty(shape, np.uint8) for _ in range(3)]   # two staged + one being coded
+
+    def fill(i):
+        hb = hostbuf[i % 3]
+        for s in range(S):
+            hb[s] = clips[s][i * gop:(i + 1) * gop]
+        return hb
+
+    got = [b""] * S
+    b.stage(fill(0))
+    b.stage(fill(1))
+    b.submit(hostbuf[0])
+    for i in range(1, nb):
+        if i + 1 < nb:
+            b.stage(fill(i + 1))             # buffer of batch i-2: collected in the previous iteration
+        b.submit(hostbuf[i % 3])
+        part = b.collect()                   # batch i-1
+        got = [g + p for g, p in zip(got, part)]
+    part = b.collect()
+    got = [g + p for g, p in zip(got, part)]
+    b.close()
+    for s in range(S):
+        assert got[s] == want[s], "stream %d: %s" % (s, explain(got[s], want[s]))
+
+
 def test_drop_in_dsv_enc_api(pkg, orc):
     """frame-at-a-time dsv_enc_* API (dsv_encoder.h:112-121), as dsv_main.c drives it"""
     L = pkg.lib()
