@@ -64,9 +64,16 @@ def lib():
         L.dsvg_dev_free.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsvg_dev_upload.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
+        L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_host_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
         L.dsvg_host_free.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsv1_batch_stage.argtypes = [_C.c_void_p, _C.c_void_p]
+        L.dsv1_decbatch_open.argtypes = [_C.POINTER(_C.c_void_p), _C.c_int, _C.POINTER(Meta), _C.c_int]
+        L.dsv1_decbatch_decode.argtypes = [_C.c_void_p, _C.POINTER(Buf), _C.c_void_p, _C.c_size_t, _C.c_int,
+                                           _C.POINTER(_C.c_int), _C.POINTER(_C.c_uint32)]
+        L.dsv1_decbatch_close.argtypes = [_C.c_void_p]
+        L.dsv1_decbatch_ctx.restype = _C.c_void_p
+        L.dsv1_decbatch_ctx.argtypes = [_C.c_void_p]
         L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_ulonglong]
         L.dsvg_prof_reset.argtypes = [_C.c_void_p]
         L.dsvg_prof_get.argtypes = [_C.c_void_p, _C.c_int, _C.POINTER(_C.c_double), _C.POINTER(_C.c_long),
@@ -259,6 +266,76 @@ class Batch:
             self.close()
         except Exception:
             pass
+
+
+class DecBatch:
+    """nstreams independent streams of one geometry, one packet per stream per decode() call (dsv1_decbatch_*)"""
+
+    def __init__(self, w, h, fmt, nstreams, device=0):
+        self.L = lib()
+        self.h = _C.c_void_p(None)
+        self.nstreams = nstreams
+        m = Meta()
+        m.width, m.height, m.subsamp = w, h, fmt
+        _chk(self.L.dsv1_decbatch_open(_C.byref(self.h), device, _C.byref(m), nstreams), "dsv1_decbatch_open")
+        self.ctx = self.L.dsv1_decbatch_ctx(self.h)
+        self.frame_bytes = w * h + 2 * _chroma_size(w, h, fmt)
+        self._dev = None
+
+    def decode(self, packets, out=None, on_device=False):
+        """packets: one bytes object per stream.  Host output: returns (frames [nstreams][frame_bytes] uint8, status,
+        fnum); on_device=True leaves the frames in a device buffer owned by this object (returns its pointer)."""
+        S = self.nstreams
+        assert len(packets) == S
+        keep = [_np.frombuffer(bytes(p) + b"\0" * 16, dtype=_np.uint8).copy() for p in packets]
+        bufs = (Buf * S)()
+        for s in range(S):
+            bufs[s].data = keep[s].ctypes.data_as(_C.POINTER(_C.c_uint8))
+            bufs[s].len = len(packets[s])
+        status = (_C.c_int * S)()
+        fnum = (_C.c_uint32 * S)()
+        if on_device:
+            if self._dev is None:
+                self._dev = _C.c_void_p(None)
+                _chk(self.L.dsvg_dev_alloc(self.ctx, _C.byref(self._dev), self.frame_bytes * S), "dsvg_dev_alloc")
+            dst = self._dev
+        else:
+            if out is None:
+                out = _np.zeros((S, self.frame_bytes), dtype=_np.uint8)
+            dst = out.ctypes.data
+        _chk(self.L.dsv1_decbatch_decode(self.h, bufs, dst, self.frame_bytes, 1 if on_device else 0, status, fnum), "dsv1_decbatch_decode")
+        return (self._dev if on_device else out), list(status), list(fnum)
+
+    def sync(self):
+        _chk(self.L.dsvg_ctx_sync(self.ctx), "dsvg_ctx_sync")
+
+    def download(self):
+        """host copy of the device output buffer of the last decode(on_device=True)"""
+        self.sync()
+        out = _np.zeros((self.nstreams, self.frame_bytes), dtype=_np.uint8)
+        _chk(self.L.dsvg_dev_download(self.ctx, out.ctypes.data, self._dev, out.nbytes), "dsvg_dev_download")
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.dsvg_ctx_sync(self.ctx)
+            if self._dev is not None:
+                self.L.dsvg_dev_free(self.ctx, self._dev)
+                self._dev = None
+            self.L.dsv1_decbatch_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def _chroma_size(w, h, fmt):
+    """chroma plane samples for a DSV_SUBSAMP_* format code (dsv.h:62-75: bits 2-3 horizontal, 0-1 vertical shift)"""
+    hs, vs = (fmt >> 2) & 3, fmt & 3
+    return ((w + (1 << hs) - 1) >> hs) * ((h + (1 << vs) - 1) >> vs)
 
 
 def encode_clip(clip, w, h, fmt, device=0, eos=True, start_fnum=0, **cli):

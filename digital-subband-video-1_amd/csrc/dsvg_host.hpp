@@ -54,7 +54,7 @@ struct Slab {
 // One id per kernel SYMBOL, named exactly as rocprofv3 prints it (up to the parameter list), so a bench.py
 // roofline entry can be held against the committed --kernel-trace --stats summary line by line.
 #define DSVG_KERNEL_IDS(X) \
-    X(KID_UNPACK, "k_unpack") X(KID_EXTEND, "k_extend") X(KID_EXTEND16, "k_extend16") X(KID_DS2X, "k_ds2x") X(KID_LUMA_SUM, "k_luma_sum") \
+    X(KID_UNPACK, "k_unpack") X(KID_EXTEND, "k_extend") X(KID_EXTEND16, "k_extend16") X(KID_DS2X, "k_ds2x") X(KID_LUMA_SUM, "k_luma_sum") X(KID_PACK16, "void k_pack_n<true>") X(KID_PACK, "void k_pack_n<false>") \
     X(KID_HME_LEVEL, "void k_hme_level<false>") X(KID_HME_LEVEL0, "void k_hme_level<true>") X(KID_HME_DETAIL, "k_hme_detail") \
     X(KID_MC, "k_mc") \
     X(KID_FWD_HAAR_PIX, "void k_fwd_haar_pix<false>") X(KID_FWD_HAAR_PIX_Q, "void k_fwd_haar_pix<true>") \

@@ -59,6 +59,7 @@ struct dsvg_ctx {
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
     int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
+    int *ptab_d = nullptr;           // slot table of dsvg_pack_recons
     // host-resident input: two device ingest buffers filled on a copy stream of their own, so the upload of the
     // next batch runs under the analysis and coding of the current one
     hipStream_t st_h = nullptr;
@@ -80,7 +81,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ingest[0], c->ingest[1]};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1]};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -262,6 +263,13 @@ extern "C" int dsvg_dev_upload(dsvg_ctx *c, void *dptr, const void *src, size_t 
     return DSVG_OK;
 }
 
+extern "C" int dsvg_dev_download(dsvg_ctx *c, void *dst, const void *dptr, size_t bytes)
+{
+    if (!c || !dst || !dptr) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipMemcpy(dst, dptr, bytes, hipMemcpyDeviceToHost));
+    return DSVG_OK;
+}
 extern "C" int dsvg_host_alloc(dsvg_ctx *c, void **hptr, size_t bytes)
 {
     if (!c || !hptr) return DSVG_ERR_ARG;
@@ -659,6 +667,35 @@ extern "C" int dsvg_download_recon(dsvg_ctx *c, int recon_slot, uint8_t *yuv_out
     launch_pack(c->st, c->yuv_stage, c->recon.p + (size_t)recon_slot * c->L[0].pitch, c->L[0]);
     HIPCHK(hipMemcpyAsync(yuv_out, c->yuv_stage, fb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_pack_recons(dsvg_ctx *c, int n, const int *recon_slots, void *yuv_out, size_t out_pitch, int out_on_device)
+{
+    if (!c || !recon_slots || !yuv_out || n < 1 || n > c->n_recon) { dsvg_set_error("bad pack_recons arguments"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t fb = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
+    if (out_pitch < fb) { dsvg_set_error("output pitch smaller than a frame"); return DSVG_ERR_ARG; }
+    for (int i = 0; i < n; i++)
+        if (recon_slots[i] < 0 || recon_slots[i] >= c->n_recon) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
+    if (!c->ptab_d) HIPCHK(hipMalloc((void **)&c->ptab_d, sizeof(int) * (size_t)c->n_recon + 64));
+    HIPCHK(hipMemcpyAsync(c->ptab_d, recon_slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st));   // pageable: staged by the runtime
+    if (out_on_device) {
+        launch_pack_n(c->st, (uint8_t *)yuv_out, out_pitch, c->recon.p, c->L[0], c->ptab_d, n, &c->prof);
+        HIPCHK(hipGetLastError());
+        return DSVG_OK;
+    }
+    const size_t sp = (fb + 255) & ~(size_t)255;
+    if (c->yuv_stage_bytes < sp * n) {
+        if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipStreamSynchronize(c->st_a)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
+        HIPCHK(hipMalloc((void **)&c->yuv_stage, sp * n + 256));
+        c->yuv_stage_bytes = sp * n;
+    }
+    launch_pack_n(c->st, c->yuv_stage, sp, c->recon.p, c->L[0], c->ptab_d, n, &c->prof);
+    if (out_pitch == sp) HIPCHK(hipMemcpyAsync(yuv_out, c->yuv_stage, sp * (size_t)(n - 1) + fb, hipMemcpyDeviceToHost, c->st));
+    else HIPCHK(hipMemcpy2DAsync(yuv_out, out_pitch, c->yuv_stage, sp, fb, (size_t)n, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    HIPCHK(hipGetLastError());
     return DSVG_OK;
 }
 

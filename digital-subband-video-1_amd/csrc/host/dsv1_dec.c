@@ -1,7 +1,8 @@
 /* dsv1_dec.c -- decoder session layer in plain C (dsv_decoder.c:21-145,286-472 semantics).
- * The host parses packet headers and side information (a few hundred bytes), hands the three plane
- * payloads to the device (entropy parse on the host for now, scatter + dequantise + inverse
- * transform + motion compensation on the GPU), and copies the finished picture back.
+ * The host parses packet headers and side information (a few hundred bytes) and hands the three plane
+ * payloads to the device: entropy parse, scatter + dequantise, inverse transform and motion compensation
+ * run on the GPU.  dsv_dec() is the reference's one-picture-per-call entry (the frame is copied back into
+ * a host DSV_FRAME); dsv1_decbatch_* decodes one picture of each of many independent streams per call.
  * Debug overlays (draw_info) are accepted and ignored. */
 #include <stdio.h>
 #include "dsv1_host.h"
@@ -29,100 +30,67 @@ DSV_META *dsv_get_metadata(DSV_DECODER *d)
     return m;
 }
 
-int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
+/* packet header (dsv_decoder.c:300-318): returns the packet type, leaves r after the two link words */
+static int parse_packet_header(bitw *r, uint8_t *data, int *type)
 {
-    bitw r;
-    DSV_META *m = &d->vidmeta;
-    dec_sess *ss;
-    dsvg_dec_job job;
-    DSV_MV *mvs = NULL;
-    unsigned char *stable = NULL;
-    uint8_t *packed = NULL;
-    DSV_FRAME *f;
-    int type, is_ref, has_ref, bw_, bh_, nbh, nbv, nblk, i, j, c, rc, ret = DSV_DEC_ERROR;
+    bw_init(r, data);
+    if (br_bits(r, 8) != 'D' || br_bits(r, 8) != 'S' || br_bits(r, 8) != 'V' || br_bits(r, 8) != '1') return -1;
+    (void)br_bits(r, 8);
+    *type = (int)br_bits(r, 8);
+    (void)br_bits(r, 32);
+    (void)br_bits(r, 32);
+    return 0;
+}
 
-    *fn = (DSV_FNUM)-1;
-    bw_init(&r, buffer->data);
-    if (br_bits(&r, 8) != 'D' || br_bits(&r, 8) != 'S' || br_bits(&r, 8) != 'V' || br_bits(&r, 8) != '1') {
-        dsv1_log(1, "bad 4cc");
-        dsv_buf_free(buffer);
-        return DSV_DEC_ERROR;
-    }
-    (void)br_bits(&r, 8);
-    type = (int)br_bits(&r, 8);
-    (void)br_bits(&r, 32);
-    (void)br_bits(&r, 32);
-    if (!(type & DSV_PT_PIC)) {
-        if (type == DSV_PT_META) {
-            m->width = (int)br_ueg(&r); m->height = (int)br_ueg(&r); m->subsamp = (int)br_ueg(&r);
-            m->fps_num = (int)br_ueg(&r); m->fps_den = (int)br_ueg(&r);
-            m->aspect_num = (int)br_ueg(&r); m->aspect_den = (int)br_ueg(&r);
-            d->got_metadata = 1;
-            ret = DSV_DEC_GOT_META;
-        } else if (type == DSV_PT_EOS) {
-            ret = DSV_DEC_EOS;
-        }
-        dsv_buf_free(buffer);
-        return ret;
-    }
-    if (!d->got_metadata) {
-        dsv1_log(2, "no metadata, skipping frame");
-        dsv_buf_free(buffer);
-        return DSV_DEC_OK;
-    }
-    has_ref = type & 1;
-    is_ref = (type & 0x6) == 0x6;
-    bw_align(&r);
-    *fn = br_bits(&r, 32);
-    bw_align(&r);
-    bw_ = (int)br_ueg(&r) << 2;
-    bh_ = (int)br_ueg(&r) << 2;
-    if (bw_ < 16 || bh_ < 16 || bw_ > 64 || bh_ > 64) { dsv_buf_free(buffer); return DSV_DEC_ERROR; }
+static void parse_meta(bitw *r, DSV_META *m)
+{
+    m->width = (int)br_ueg(r); m->height = (int)br_ueg(r); m->subsamp = (int)br_ueg(r);
+    m->fps_num = (int)br_ueg(r); m->fps_den = (int)br_ueg(r);
+    m->aspect_num = (int)br_ueg(r); m->aspect_den = (int)br_ueg(r);
+}
 
-    if (!d->ref) {
-        ss = (dec_sess *)calloc(1, sizeof(*ss));
-        if ((rc = dsvg_ctx_create(&ss->ctx, dsv1_device, m->width, m->height, m->subsamp, 1, 1, 2, 1, 1))) {
-            dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
-            free(ss);
-            dsv_buf_free(buffer);
-            return DSV_DEC_ERROR;
-        }
-        dsvg_ctx_geom(ss->ctx, &ss->g);
-        d->ref = ss;
-    }
-    ss = (dec_sess *)d->ref;
-    nbh = (m->width + bw_ - 1) / bw_;
-    nbv = (m->height + bh_ - 1) / bh_;
-    if (bw_ != ss->g.blk_w || bh_ != ss->g.blk_h) {
-        dsv1_log(1, "stream block size %dx%d differs from the encoder rule for this frame size", bw_, bh_);
-        dsv_buf_free(buffer);
-        return DSV_DEC_ERROR;
-    }
-    nblk = nbh * nbv;
-    stable = (unsigned char *)calloc((size_t)nblk, 1);
-    {   /* stability flags (decode_stability_blocks dsv_decoder.c:127-145) */
+/* picture packet after the header, first part (dsv_decoder.c:335-352): frame number and block size */
+static int parse_picture_head(bitw *r, DSV_FNUM *fn, int *bw_, int *bh_)
+{
+    bw_align(r);
+    *fn = br_bits(r, 32);
+    bw_align(r);
+    *bw_ = (int)br_ueg(r) << 2;
+    *bh_ = (int)br_ueg(r) << 2;
+    return (*bw_ < 16 || *bh_ < 16 || *bw_ > 64 || *bh_ > 64) ? -1 : 0;
+}
+
+/* rest of the picture packet: stability flags (decode_stability_blocks dsv_decoder.c:127-145), motion
+ * (decode_motion dsv_decoder.c:73-124), quantiser and the three plane payloads -> a device job.
+ * stable[nblk] and mvs[nblk] are caller storage (zeroed here). */
+static int parse_picture_body(bitw *r, uint8_t *data, const dsvg_geom *g, int has_ref, unsigned char *stable, DSV_MV *mvs, dsvg_dec_job *job)
+{
+    const int nbh = g->nblocks_h, nbv = g->nblocks_v, nblk = nbh * nbv;
+    int i, j, c;
+    memset(stable, 0, (size_t)nblk);
+    {
         zrle z;
         unsigned n;
-        bw_align(&r);
-        n = br_ueg(&r);
-        bw_align(&r);
-        zr_init(&z, buffer->data + bw_bytes(&r));
-        r.pos += n * 8;
+        bw_align(r);
+        n = br_ueg(r);
+        bw_align(r);
+        zr_init(&z, data + bw_bytes(r));
+        r->pos += n * 8;
         for (i = 0; i < nblk; i++) stable[i] = (unsigned char)zr_get(&z);
     }
-    if (has_ref) {   /* decode_motion dsv_decoder.c:73-124 */
+    if (has_ref) {
         bitw sub[4];
         zrle modes;
         DSV_PARAMS prm;
-        mvs = (DSV_MV *)calloc((size_t)nblk, sizeof(DSV_MV));
+        memset(mvs, 0, (size_t)nblk * sizeof(DSV_MV));
         memset(&prm, 0, sizeof(prm));
         prm.nblocks_h = nbh; prm.nblocks_v = nbv;
-        bw_align(&r);
+        bw_align(r);
         for (i = 0; i < 4; i++) {
-            const unsigned n = br_ueg(&r);
-            bw_align(&r);
-            bw_init(&sub[i], buffer->data + bw_bytes(&r));
-            r.pos += n * 8;
+            const unsigned n = br_ueg(r);
+            bw_align(r);
+            bw_init(&sub[i], data + bw_bytes(r));
+            r->pos += n * 8;
         }
         zr_init(&modes, sub[0].p);
         for (j = 0; j < nbv; j++)
@@ -140,24 +108,86 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
                 }
             }
     }
-    bw_align(&r);
-    memset(&job, 0, sizeof(job));
-    job.quant = (int)br_bits(&r, 11);
-    job.mvs = (const dsvg_mv *)mvs;
-    job.stable_blocks = stable;
+    bw_align(r);
+    memset(job, 0, sizeof(*job));
+    job->quant = (int)br_bits(r, 11);
+    job->mvs = (const dsvg_mv *)mvs;
+    job->stable_blocks = stable;
     for (c = 0; c < 3; c++) {
         int plen;
-        bw_align(&r);
-        plen = (int)br_bits(&r, 32);
-        bw_align(&r);
-        if (plen <= 0 || (size_t)plen > ss->g.plane_out_cap[c] * 4 + 64) {
+        bw_align(r);
+        plen = (int)br_bits(r, 32);
+        bw_align(r);
+        if (plen <= 0 || (size_t)plen > g->plane_out_cap[c] * 4 + 64) {
             dsv1_log(1, "plane length was strange: %d", plen);
-            goto done;
+            return -1;
         }
-        job.plane_data[c] = buffer->data + bw_bytes(&r);
-        job.plane_len[c] = (uint32_t)plen;
-        r.pos += (unsigned)plen * 8;
+        job->plane_data[c] = data + bw_bytes(r);
+        job->plane_len[c] = (uint32_t)plen;
+        r->pos += (unsigned)plen * 8;
     }
+    return 0;
+}
+
+int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
+{
+    bitw r;
+    DSV_META *m = &d->vidmeta;
+    dec_sess *ss;
+    dsvg_dec_job job;
+    DSV_MV *mvs = NULL;
+    unsigned char *stable = NULL;
+    uint8_t *packed = NULL;
+    DSV_FRAME *f;
+    int type, is_ref, has_ref, bw_, bh_, nblk, i, c, rc, ret = DSV_DEC_ERROR;
+
+    *fn = (DSV_FNUM)-1;
+    if (parse_packet_header(&r, buffer->data, &type)) {
+        dsv1_log(1, "bad 4cc");
+        dsv_buf_free(buffer);
+        return DSV_DEC_ERROR;
+    }
+    if (!(type & DSV_PT_PIC)) {
+        if (type == DSV_PT_META) {
+            parse_meta(&r, m);
+            d->got_metadata = 1;
+            ret = DSV_DEC_GOT_META;
+        } else if (type == DSV_PT_EOS) {
+            ret = DSV_DEC_EOS;
+        }
+        dsv_buf_free(buffer);
+        return ret;
+    }
+    if (!d->got_metadata) {
+        dsv1_log(2, "no metadata, skipping frame");
+        dsv_buf_free(buffer);
+        return DSV_DEC_OK;
+    }
+    has_ref = type & 1;
+    is_ref = (type & 0x6) == 0x6;
+    if (parse_picture_head(&r, fn, &bw_, &bh_)) { dsv_buf_free(buffer); return DSV_DEC_ERROR; }
+
+    if (!d->ref) {
+        ss = (dec_sess *)calloc(1, sizeof(*ss));
+        if ((rc = dsvg_ctx_create(&ss->ctx, dsv1_device, m->width, m->height, m->subsamp, 1, 1, 2, 1, 1))) {
+            dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
+            free(ss);
+            dsv_buf_free(buffer);
+            return DSV_DEC_ERROR;
+        }
+        dsvg_ctx_geom(ss->ctx, &ss->g);
+        d->ref = ss;
+    }
+    ss = (dec_sess *)d->ref;
+    if (bw_ != ss->g.blk_w || bh_ != ss->g.blk_h) {
+        dsv1_log(1, "stream block size %dx%d differs from the encoder rule for this frame size", bw_, bh_);
+        dsv_buf_free(buffer);
+        return DSV_DEC_ERROR;
+    }
+    nblk = ss->g.nblocks_h * ss->g.nblocks_v;
+    stable = (unsigned char *)calloc((size_t)nblk, 1);
+    mvs = (DSV_MV *)calloc((size_t)nblk, sizeof(DSV_MV));
+    if (parse_picture_body(&r, buffer->data, &ss->g, has_ref, stable, mvs, &job)) goto done;
     if (has_ref && !ss->have_ref) {
         dsv1_log(2, "reference frame not found");
         goto done;
@@ -190,3 +220,115 @@ done:
     dsv_buf_free(buffer);
     return ret;
 }
+
+/* ---- batched decoder: one picture of each of nstreams independent streams per call ---- */
+struct dsv1_decbatch {
+    dsvg_ctx *ctx;
+    dsvg_geom g;
+    DSV_META meta;
+    int nstreams, nblk;
+    unsigned char *have_ref;         /* [nstreams] */
+    unsigned char *stable;           /* [nstreams][nblk] */
+    DSV_MV *mvs;                     /* [nstreams][nblk] */
+    dsvg_dec_job *jobs;              /* compacted: the picture packets of this call */
+    int *slots;
+};
+
+void dsv1_decbatch_close(dsv1_decbatch *d)
+{
+    if (!d) return;
+    if (d->ctx) dsvg_ctx_destroy(d->ctx);
+    free(d->have_ref); free(d->stable); free(d->mvs); free(d->jobs); free(d->slots);
+    free(d);
+}
+
+int dsv1_decbatch_open(dsv1_decbatch **out, int device, const DSV_META *meta, int nstreams)
+{
+    dsv1_decbatch *d;
+    int rc;
+    if (!out || !meta || nstreams < 1) return DSVG_ERR_ARG;
+    *out = NULL;
+    d = (dsv1_decbatch *)calloc(1, sizeof(*d));
+    if (!d) return DSVG_ERR_ARG;
+    d->meta = *meta;
+    d->nstreams = nstreams;
+    /* stream s keeps its reference picture in reconstruction slot s; non-reference pictures go to slot nstreams + s */
+    if ((rc = dsvg_ctx_create(&d->ctx, device, meta->width, meta->height, meta->subsamp, 1, 1, 2 * nstreams, nstreams, nstreams))) {
+        free(d);
+        return rc;
+    }
+    dsvg_ctx_geom(d->ctx, &d->g);
+    d->nblk = d->g.nblocks_h * d->g.nblocks_v;
+    d->have_ref = (unsigned char *)calloc((size_t)nstreams, 1);
+    d->stable = (unsigned char *)calloc((size_t)nstreams * d->nblk, 1);
+    d->mvs = (DSV_MV *)calloc((size_t)nstreams * d->nblk, sizeof(DSV_MV));
+    d->jobs = (dsvg_dec_job *)calloc((size_t)nstreams, sizeof(dsvg_dec_job));
+    d->slots = (int *)calloc((size_t)nstreams, sizeof(int));
+    *out = d;
+    return DSVG_OK;
+}
+
+int dsv1_decbatch_decode(dsv1_decbatch *d, const DSV_BUF *packets, void *yuv_out, size_t out_pitch, int out_on_device, int *status, DSV_FNUM *fnum)
+{
+    int s, n = 0, rc;
+    if (!d || !packets || !yuv_out || !status || !fnum) return DSVG_ERR_ARG;
+    if (out_pitch == 0) out_pitch = d->g.frame_bytes;
+    /* host: headers + side information of every packet (a few hundred bytes each) */
+    for (s = 0; s < d->nstreams; s++) {
+        bitw r;
+        int type, bw_, bh_, has_ref, is_ref;
+        dsvg_dec_job *job = &d->jobs[n];
+        status[s] = DSV_DEC_ERROR;
+        fnum[s] = (DSV_FNUM)-1;
+        if (!packets[s].data || parse_packet_header(&r, packets[s].data, &type)) continue;
+        if (!(type & DSV_PT_PIC)) {
+            if (type == DSV_PT_META) {
+                DSV_META m;
+                parse_meta(&r, &m);
+                status[s] = (m.width == d->meta.width && m.height == d->meta.height && m.subsamp == d->meta.subsamp) ? DSV_DEC_GOT_META : DSV_DEC_ERROR;
+            } else if (type == DSV_PT_EOS) {
+                status[s] = DSV_DEC_EOS;
+            }
+            continue;
+        }
+        has_ref = type & 1;
+        is_ref = (type & 0x6) == 0x6;
+        if (parse_picture_head(&r, &fnum[s], &bw_, &bh_)) continue;
+        if (bw_ != d->g.blk_w || bh_ != d->g.blk_h) {
+            dsv1_log(1, "stream %d: block size %dx%d differs from the encoder rule for this frame size", s, bw_, bh_);
+            continue;
+        }
+        if (parse_picture_body(&r, packets[s].data, &d->g, has_ref, d->stable + (size_t)s * d->nblk, d->mvs + (size_t)s * d->nblk, job)) continue;
+        if (has_ref && !d->have_ref[s]) {
+            dsv1_log(2, "stream %d: reference frame not found", s);
+            continue;
+        }
+        job->ref_recon_slot = has_ref ? s : -1;
+        job->recon_slot = is_ref ? s : d->nstreams + s;
+        if (is_ref) d->have_ref[s] = 1;
+        d->slots[n] = s;                 /* remember whose job this is */
+        status[s] = DSV_DEC_OK;
+        n++;
+    }
+    if (!n) return DSVG_OK;
+    /* device: all pictures of the call as one batch, then one packing pass into the caller's layout */
+    if ((rc = dsvg_decode_pictures(d->ctx, n, d->jobs))) {
+        dsv1_log(1, "GPU decode failed: %s", dsvg_last_error());
+        for (s = 0; s < n; s++) status[d->slots[s]] = DSV_DEC_ERROR;
+        return rc;
+    }
+    if (n == d->nstreams) {
+        for (s = 0; s < n; s++) d->slots[s] = d->jobs[s].recon_slot;
+        rc = dsvg_pack_recons(d->ctx, n, d->slots, yuv_out, out_pitch, out_on_device);
+    } else {                             /* some streams had no picture this call: their output frames stay untouched */
+        rc = DSVG_OK;
+        for (s = 0; s < n && !rc; s++) {
+            const int st = d->slots[s], slot = d->jobs[s].recon_slot;
+            rc = dsvg_pack_recons(d->ctx, 1, &slot, (uint8_t *)yuv_out + (size_t)st * out_pitch, out_pitch, out_on_device);
+        }
+    }
+    if (rc) dsv1_log(1, "GPU pack failed: %s", dsvg_last_error());
+    return rc;
+}
+
+void *dsv1_decbatch_ctx(dsv1_decbatch *d) { return d ? (void *)d->ctx : NULL; }

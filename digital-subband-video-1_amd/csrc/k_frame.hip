@@ -72,6 +72,33 @@ __global__ __launch_bounds__(256) void k_pack(uint8_t *__restrict__ yuv, const u
     }
 }
 
+// batched form for the decoder: reconstruction slot slot_tab[z] -> packed planar frame z of the output (16 bytes per
+// lane when every plane row is 16-byte aligned on both sides)
+template <bool V16>
+__global__ __launch_bounds__(256) void k_pack_n(uint8_t *__restrict__ yuv, size_t out_pitch, const uint8_t *__restrict__ slab, FrameLayout L,
+                                                const int *__restrict__ slot_tab)
+{
+    const int c = blockIdx.y;
+    const int f = slot_tab[blockIdx.z];
+    const int w = L.w[c], h = L.h[c], s = L.stride[c];
+    size_t poff = 0;
+    for (int k = 0; k < c; k++) poff += (size_t)L.w[k] * L.h[k];
+    const uint8_t *src = slab + (size_t)f * L.pitch + L.off[c];
+    uint8_t *dst = yuv + (size_t)blockIdx.z * out_pitch + poff;
+    if (V16) {
+        const int wq = w >> 4, n = wq * h;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
+            const int y = i / wq, x = (i - y * wq) << 4;
+            *reinterpret_cast<uint4 *>(dst + (size_t)y * w + x) = *reinterpret_cast<const uint4 *>(src + (size_t)y * s + x);
+        }
+    } else {
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
+            const int y = i / w, x = i - y * w;
+            dst[(size_t)y * w + x] = src[(size_t)y * s + x];
+        }
+    }
+}
+
 // border replication of planes [0, nplanes) of frames: every border byte is the nearest interior pixel
 // (identical to the row memsets + row copies of frame.c:278-292).  One dword per thread-iteration:
 // the 64-byte left/right borders of all h+128 rows, then the top/bottom 64 rows over the interior.
@@ -229,6 +256,16 @@ void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)
 {
     hipLaunchKernelGGL(k_pack, dim3(nblk((long)L.w[0] * L.h[0], 1024), 3, 1), dim3(256), 0, st, yuv, frame, L);
+}
+void launch_pack_n(hipStream_t st, uint8_t *yuv, size_t out_pitch, const uint8_t *slab, const FrameLayout &L, const int *slot_tab, int n, Prof *pf)
+{
+    bool v16 = (L.pitch % 16) == 0 && (out_pitch % 16) == 0 && ((uintptr_t)yuv % 16) == 0 && ((uintptr_t)slab % 16) == 0;
+    for (int c = 0; c < 3; c++) v16 = v16 && (L.w[c] % 16) == 0 && (L.stride[c] % 16) == 0 && (L.off[c] % 16) == 0 && ((size_t)L.w[c] * L.h[c] % 16) == 0;
+    const double fb = (double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1];
+    if (pf) pf->begin(st, v16 ? KID_PACK16 : KID_PACK, 2.0 * fb * n);
+    if (v16) hipLaunchKernelGGL(k_pack_n<true>, dim3(nblk((long)L.w[0] * L.h[0] / 16, 256), 3, n), dim3(256), 0, st, yuv, out_pitch, slab, L, slot_tab);
+    else     hipLaunchKernelGGL(k_pack_n<false>, dim3(nblk((long)L.w[0] * L.h[0], 1024), 3, n), dim3(256), 0, st, yuv, out_pitch, slab, L, slot_tab);
+    if (pf) pf->end(st);
 }
 void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf)
 {

@@ -173,6 +173,20 @@ int  dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out);
 int  dsv1_concat_gops(const DSV_BUF *gops, int ngops, DSV_BUF *out);
 void *dsv1_batch_ctx(dsv1_batch *b);          /* the dsvg_ctx* (profiling hooks) */
 
+/* ---- extension: batched decoding (dsv_dec decodes one picture per call, dsv_decoder.c:286-472) ----
+ * nstreams independent streams of one geometry; every call takes ONE packet per stream (packets[s]: not freed, not
+ * modified) and decodes all picture packets among them as one device batch.  status[s] = DSV_DEC_OK (a frame was
+ * written), DSV_DEC_GOT_META, DSV_DEC_EOS or DSV_DEC_ERROR; fnum[s] = frame number (-1 if none).  The decoded frame
+ * of stream s is written tightly packed planar (Y, U, V) at yuv_out + s*out_pitch (out_pitch 0 = frame size), in
+ * device memory (asynchronous: dsvg_ctx_sync(dsv1_decbatch_ctx(d)) before reading) or host memory (synchronised).
+ * Reference pictures stay resident on the device.  Returns 0 or a DSVG_ERR_*. */
+typedef struct dsv1_decbatch dsv1_decbatch;
+int  dsv1_decbatch_open(dsv1_decbatch **out, int device, const DSV_META *meta, int nstreams);
+int  dsv1_decbatch_decode(dsv1_decbatch *d, const DSV_BUF *packets, void *yuv_out, size_t out_pitch, int out_on_device,
+                          int *status, DSV_FNUM *fnum);
+void dsv1_decbatch_close(dsv1_decbatch *d);
+void *dsv1_decbatch_ctx(dsv1_decbatch *d);
+
 #ifdef __cplusplus
 }
 #endif

@@ -114,6 +114,7 @@ void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the hipStream_t all pipeline wor
 int dsvg_dev_alloc(dsvg_ctx *ctx, void **dptr, size_t bytes);
 int dsvg_dev_free(dsvg_ctx *ctx, void *dptr);
 int dsvg_dev_upload(dsvg_ctx *ctx, void *dptr, const void *src, size_t bytes);
+int dsvg_dev_download(dsvg_ctx *ctx, void *dst, const void *dptr, size_t bytes);   /* synchronous */
 /* Host-resident input (dsv_main.c:394-421 reads each frame from the .yuv into host memory).  dsvg_host_alloc gives
  * pinned memory; dsvg_ingest_begin starts the upload of `bytes` of packed frames on a copy stream of its own into one
  * of two device buffers owned by the context and returns that buffer: a following dsvg_load_frames_map on it waits for
@@ -168,6 +169,9 @@ int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
 int dsvg_code_batch(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */
+/* n reconstruction slots -> tightly packed planar frames, frame i at yuv_out + i*out_pitch.  Device output: enqueued
+ * on the pipeline stream, no sync (dsvg_ctx_sync before reading it).  Host output: copied back and synchronised. */
+int dsvg_pack_recons(dsvg_ctx *ctx, int n, const int *recon_slots, void *yuv_out, size_t out_pitch, int out_on_device);
 
 /* Decoder side: coefficient (run,value) pairs parsed on the host are scattered + dequantised,
  * inverse transformed and motion compensated on the device (dsv_dec dsv_decoder.c:379-436). */

@@ -236,3 +236,50 @@ def _decode_and_compare(pkg, w, h, fmt, n, style, kw, seed, check_recon=True):
         if check_recon:     # holds unless HZCC scan regions overlap (a shared cell can re-quantise to 0 in the encoder's
             # second pass while the decoder keeps the first symbol: encoder/decoder drift of the reference itself)
             A.assert_same("decode == encoder recon %d" % t, got[t], recs[t])
+
+
+@pytest.mark.parametrize("geom", [(352, 288, A.SUBSAMP_420), (320, 240, A.SUBSAMP_444), (1920, 1080, A.SUBSAMP_420)])
+@pytest.mark.parametrize("on_device", [False, True])
+def test_batched_decoder_matches_oracle(pkg, orc, geom, on_device):
+    """dsv1_decbatch_*: one packet per stream per call, all picture packets of a call decoded as one device batch.
+    Streams differ in content, GOP length (so I and P pictures meet in one call) and length (EOS comes at different
+    calls); stream 3 is intra-only (non-reference pictures)."""
+    w, h, fmt = geom
+    big = w >= 1920
+    S = 4
+    gops = [3, 5, 4, 0]
+    nfr = [3, 4, 3, 2] if big else [7, 9, 6, 4]
+    streams, want = [], []
+    for s in range(S):
+        clip = A.gen_clip(w, h, fmt, 0xDEC0 + 16 * s + w, nfr[s], style=s % 3)
+        st, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=85 if s != 1 else 60, gop=gops[s], rc_mode_cli=1))
+        streams.append(A.split_packets(st))
+        want.append(A.orc_decode(st, w, h, fmt))
+        assert len(want[s]) == nfr[s]
+    d = pkg.DecBatch(w, h, fmt, S)
+    got = [[] for _ in range(S)]
+    fnums = [[] for _ in range(S)]
+    eos = bytes(streams[0][-1])
+    ncalls = max(len(p) for p in streams)
+    for k in range(ncalls):
+        pk = [streams[s][k] if k < len(streams[s]) else eos for s in range(S)]
+        if on_device:
+            _, status, fnum = d.decode(pk, on_device=True)
+            out = d.download()
+        else:
+            out, status, fnum = d.decode(pk)
+        for s in range(S):
+            if k >= len(streams[s]):
+                assert status[s] == 2          # DSV_DEC_EOS
+            elif streams[s][k][5] & 4:         # picture packet
+                assert status[s] == 0, "stream %d call %d: status %d" % (s, k, status[s])
+                got[s].append(out[s].copy())
+                fnums[s].append(fnum[s])
+            else:
+                assert status[s] in (2, 3)     # EOS / GOT_META
+    d.close()
+    for s in range(S):
+        assert len(got[s]) == nfr[s]
+        assert fnums[s] == list(range(nfr[s]))
+        for t in range(nfr[s]):
+            A.assert_same("stream %d frame %d" % (s, t), got[s][t], want[s][t])

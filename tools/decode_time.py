@@ -35,3 +35,37 @@ for rep in range(2):
     dt = time.perf_counter() - t0
     L.dsv_dec_free(C.byref(dec))
 print("%d frames 1920x1080 decoded in %.3f s: %.0f frames/s, %.2f Gpix/s (stream %d bytes)" % (n, dt, n / dt, n * W * H / dt / 1e9, len(stream)))
+
+# ---- batched decoder (dsv1_decbatch_*): S copies of the stream side by side, one packet per stream per call ----
+S = int(os.environ.get("DEC_STREAMS", "64"))
+for on_device in (1, 0):
+    d = pkg.DecBatch(W, H, FMT, S)
+    keep = [np.frombuffer(bytes(p) + b"\0" * 16, dtype=np.uint8).copy() for p in pk]
+    calls = []
+    for k, p in enumerate(pk):
+        bufs = (pkg.Buf * S)()
+        for s in range(S):
+            bufs[s].data = keep[k].ctypes.data_as(C.POINTER(C.c_uint8)); bufs[s].len = len(p)
+        calls.append(bufs)
+    status = (C.c_int * S)(); fnum = (C.c_uint32 * S)()
+    if on_device:
+        dst = C.c_void_p(None)
+        assert L.dsvg_dev_alloc(d.ctx, C.byref(dst), d.frame_bytes * S) == 0
+    else:
+        b = pkg.Batch(pkg.make_encoder_cfg(W, H, FMT), 1, 1)
+        host = b.pinned((S, d.frame_bytes))
+        dst = C.c_void_p(host.ctypes.data)
+    for rep in range(2):
+        d.sync()
+        t0 = time.perf_counter(); n = 0
+        for bufs in calls:
+            rc = L.dsv1_decbatch_decode(d.h, bufs, dst, d.frame_bytes, on_device, status, fnum)
+            assert rc == 0, L.dsvg_last_error()
+            n += sum(1 for s in range(S) if status[s] == 0 and fnum[s] != 0xFFFFFFFF)
+        d.sync()
+        dt = time.perf_counter() - t0
+    print("batched, %d streams, output %s: %d frames in %.3f s: %.0f frames/s, %.2f Gpix/s" %
+          (S, "left in HBM" if on_device else "copied to pinned host memory", n, dt, n / dt, n * W * H / dt / 1e9))
+    if on_device:
+        L.dsvg_dev_free(d.ctx, dst)
+    d.close()
