@@ -54,8 +54,10 @@ struct dsvg_ctx {
     int *aslots_h = nullptr;         // analysis-stream staging (pair tables)
     DMV *amv_h = nullptr;            // analysis-stream staging (motion fields)
     unsigned *luma_h = nullptr;
-    uint8_t *dec_h = nullptr;        // decoder: pinned staging of the plane payloads of one call
-    size_t dec_stage = 0;            //          bytes per staged plane
+    uint8_t *dec_h[2] = {nullptr, nullptr}, *dec_d[2] = {nullptr, nullptr};   // decoder: payload blob of one call (pinned / device), by call parity
+    size_t dec_cap[2] = {0, 0};
+    hipEvent_t ev_dec[2] = {nullptr, nullptr};   // uploads of the call that last used that parity
+    int dec_par = 0;
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
     int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
@@ -81,9 +83,9 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1]};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1]};
     for (void *p : d) if (p) (void)hipFree(p);
-    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
+    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (c->st_a) (void)hipStreamDestroy(c->st_a);
@@ -93,6 +95,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 2; i++) {
         if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
         if (c->ev_used[i]) (void)hipEventDestroy(c->ev_used[i]);
+        if (c->ev_dec[i]) (void)hipEventDestroy(c->ev_dec[i]);
     }
     for (hipEvent_t e : c->ev_coded) (void)hipEventDestroy(e);
     delete c;
@@ -720,32 +723,49 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) ord.push_back(i);
     const int nI = (int)ord.size();
     for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot >= 0) ord.push_back(i);
-    HIPCHK(hipStreamSynchronize(c->st));
-    c->calls_since_sync = 0;
-    if (!c->dec_h) {        // pinned staging for the plane payloads of one call
-        c->dec_stage = 0;
-        for (int p = 0; p < 3; p++) c->dec_stage = std::max(c->dec_stage, c->bits_cap[p]);
-        OPCHK(hmalloc(&c->dec_h, c->dec_stage * 3 * (size_t)c->max_jobs));
+    // Host staging (payload blob, job / flag / vector tables) is double-buffered by call parity: a call only waits for
+    // the uploads of the call before the previous one, so the caller's parsing of the next packets overlaps the device.
+    const int k = c->dec_par;
+    c->dec_par ^= 1;
+    if (!c->ev_dec[k]) HIPCHK(hipEventCreateWithFlags(&c->ev_dec[k], hipEventDisableTiming));
+    else HIPCHK(hipEventSynchronize(c->ev_dec[k]));
+    size_t blob = 0;
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++) {
+            const dsvg_dec_job &j = jobs[ord[t]];
+            if (!j.plane_data[p] || (size_t)j.plane_len[p] + 64 > c->bits_cap[p]) { dsvg_set_error("plane %d of decode job %d: bad length", p, ord[t]); return DSVG_ERR_ARG; }
+            blob += ((size_t)j.plane_len[p] + 64 + 15) & ~(size_t)15;
+        }
+    if (blob > c->dec_cap[k]) {
+        if (c->dec_h[k]) (void)hipHostFree(c->dec_h[k]);
+        if (c->dec_d[k]) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipFree(c->dec_d[k]); }
+        c->dec_h[k] = nullptr; c->dec_d[k] = nullptr; c->dec_cap[k] = 0;
+        const size_t cap = blob * 2 + (1u << 20);
+        HIPCHK(hipHostMalloc((void **)&c->dec_h[k], cap, hipHostMallocDefault));
+        HIPCHK(hipMalloc((void **)&c->dec_d[k], cap + 256));
+        c->dec_cap[k] = cap;
     }
-    int max_entries[3] = {0, 0, 0};
+    const size_t hb = (size_t)k * c->max_jobs;          // this parity's part of the pinned tables
+    int max_entries = 0;
     const CoefLayout &CL = c->CL;
+    size_t off = 0;
     for (int t = 0; t < njobs; t++) {
         const dsvg_dec_job &j = jobs[ord[t]];
         const int isP = j.ref_recon_slot >= 0;
         if (j.recon_slot < 0 || j.recon_slot >= c->n_recon || j.ref_recon_slot >= c->n_recon || !j.stable_blocks || (isP && !j.mvs)) {
             dsvg_set_error("bad decode job %d", ord[t]); return DSVG_ERR_ARG;
         }
-        JobDev &jb = c->jobs_h[t];
+        JobDev &jb = c->jobs_h[hb + t];
         fill_job(c, jb, t, isP, j.quant);
         jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
         jb.recon = c->recon.p + (size_t)j.recon_slot * c->L[0].pitch;
-        c->slots_h[t] = j.recon_slot;
-        memcpy(c->stable_h + (size_t)t * c->nblk, j.stable_blocks, (size_t)c->nblk);
-        if (isP) memcpy(c->mv_h + (size_t)t * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+        c->slots_h[hb + t] = j.recon_slot;
+        memcpy(c->stable_h + (hb + t) * c->nblk, j.stable_blocks, (size_t)c->nblk);
+        if (isP) memcpy(c->mv_h + (hb + t) * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+        jb.bits = c->dec_d[k];                          // the payloads of the call travel as one blob
         for (int p = 0; p < 3; p++) {
             // the host reads only the plane header (hzcc.c:479-483,307-311): SEG(DC), the 32-bit run count; the
             // code chain is parsed on the device (k_hz_parse) from the uploaded bytes
-            if (!j.plane_data[p] || (size_t)j.plane_len[p] + 64 > c->bits_cap[p]) { dsvg_set_error("plane %d of decode job %d: bad length", p, ord[t]); return DSVG_ERR_ARG; }
             Rd rd{j.plane_data[p], 0};
             jb.dec_dc[p] = rd.seg();
             rd.align();
@@ -754,22 +774,22 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
             jb.dec_bitpos[p] = (long long)rd.pos;
             jb.dec_len[p] = (int)j.plane_len[p];
             jb.dec_cnt[p] = 0;
-            max_entries[p] = std::max(max_entries[p], std::min(jb.dec_runs[p], jb.hz[p].nchunks * HZ_CHUNK - 1) + 1);
-            uint8_t *stage = c->dec_h + ((size_t)t * 3 + p) * c->dec_stage + 0;
+            max_entries = std::max(max_entries, std::min(jb.dec_runs[p], jb.hz[p].nchunks * HZ_CHUNK - 1) + 1);
+            jb.bits_off[p] = off;
+            uint8_t *stage = c->dec_h[k] + off;
             memcpy(stage, j.plane_data[p], j.plane_len[p]);
             memset(stage + j.plane_len[p], 0, 64);
+            off += ((size_t)j.plane_len[p] + 64 + 15) & ~(size_t)15;
         }
     }
-    for (int t = 0; t < njobs; t++)
-        for (int p = 0; p < 3; p++)
-            HIPCHK(hipMemcpyAsync(c->bits + (size_t)t * c->bits_per_job + c->bits_off[p], c->dec_h + ((size_t)t * 3 + p) * c->dec_stage,
-                                  (size_t)c->jobs_h[t].dec_len[p] + 64, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->stable, c->stable_h, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->dec_d[k], c->dec_h[k], off, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h + hb, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->stable, c->stable_h + hb * c->nblk, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h + hb * c->nblk, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h + hb, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
     HIPCHK(hipMemsetAsync(c->coef, 0, CL.total * (size_t)njobs * sizeof(int32_t), c->st));
-    for (int p = 0; p < 3; p++) launch_hz_parse_scatter(c->st, c->jobs_d, njobs, p, max_entries[p], &c->prof);
+    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, &c->prof);
     if (njobs > nI) {
         launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }

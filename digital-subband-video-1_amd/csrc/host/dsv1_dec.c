@@ -230,6 +230,7 @@ struct dsv1_decbatch {
     unsigned char *have_ref;         /* [nstreams] */
     unsigned char *stable;           /* [nstreams][nblk] */
     DSV_MV *mvs;                     /* [nstreams][nblk] */
+    dsvg_dec_job *pj;                /* [nstreams] parsed job of each stream's packet */
     dsvg_dec_job *jobs;              /* compacted: the picture packets of this call */
     int *slots;
 };
@@ -238,7 +239,7 @@ void dsv1_decbatch_close(dsv1_decbatch *d)
 {
     if (!d) return;
     if (d->ctx) dsvg_ctx_destroy(d->ctx);
-    free(d->have_ref); free(d->stable); free(d->mvs); free(d->jobs); free(d->slots);
+    free(d->have_ref); free(d->stable); free(d->mvs); free(d->jobs); free(d->pj); free(d->slots);
     free(d);
 }
 
@@ -263,53 +264,67 @@ int dsv1_decbatch_open(dsv1_decbatch **out, int device, const DSV_META *meta, in
     d->stable = (unsigned char *)calloc((size_t)nstreams * d->nblk, 1);
     d->mvs = (DSV_MV *)calloc((size_t)nstreams * d->nblk, sizeof(DSV_MV));
     d->jobs = (dsvg_dec_job *)calloc((size_t)nstreams, sizeof(dsvg_dec_job));
+    d->pj = (dsvg_dec_job *)calloc((size_t)nstreams, sizeof(dsvg_dec_job));
     d->slots = (int *)calloc((size_t)nstreams, sizeof(int));
     *out = d;
     return DSVG_OK;
 }
 
+/* host part of one stream's packet: header + side information (a few hundred bytes) -> pj[s], status[s], fnum[s] */
+typedef struct { dsv1_decbatch *d; const DSV_BUF *packets; int *status; DSV_FNUM *fnum; } parse_ctx;
+static void parse_stream(void *vp, int s, int tid)
+{
+    parse_ctx *pc = (parse_ctx *)vp;
+    dsv1_decbatch *d = pc->d;
+    bitw r;
+    int type, bw_, bh_, has_ref, is_ref;
+    dsvg_dec_job *job = &d->pj[s];
+    (void)tid;
+    pc->status[s] = DSV_DEC_ERROR;
+    pc->fnum[s] = (DSV_FNUM)-1;
+    if (!pc->packets[s].data || parse_packet_header(&r, pc->packets[s].data, &type)) return;
+    if (!(type & DSV_PT_PIC)) {
+        if (type == DSV_PT_META) {
+            DSV_META m;
+            parse_meta(&r, &m);
+            pc->status[s] = (m.width == d->meta.width && m.height == d->meta.height && m.subsamp == d->meta.subsamp) ? DSV_DEC_GOT_META : DSV_DEC_ERROR;
+        } else if (type == DSV_PT_EOS) {
+            pc->status[s] = DSV_DEC_EOS;
+        }
+        return;
+    }
+    has_ref = type & 1;
+    is_ref = (type & 0x6) == 0x6;
+    if (parse_picture_head(&r, &pc->fnum[s], &bw_, &bh_)) return;
+    if (bw_ != d->g.blk_w || bh_ != d->g.blk_h) {
+        dsv1_log(1, "stream %d: block size %dx%d differs from the encoder rule for this frame size", s, bw_, bh_);
+        return;
+    }
+    if (parse_picture_body(&r, pc->packets[s].data, &d->g, has_ref, d->stable + (size_t)s * d->nblk, d->mvs + (size_t)s * d->nblk, job)) return;
+    if (has_ref && !d->have_ref[s]) {
+        dsv1_log(2, "stream %d: reference frame not found", s);
+        return;
+    }
+    job->ref_recon_slot = has_ref ? s : -1;
+    job->recon_slot = is_ref ? s : d->nstreams + s;
+    if (is_ref) d->have_ref[s] = 1;
+    pc->status[s] = DSV_DEC_OK;
+}
+
 int dsv1_decbatch_decode(dsv1_decbatch *d, const DSV_BUF *packets, void *yuv_out, size_t out_pitch, int out_on_device, int *status, DSV_FNUM *fnum)
 {
     int s, n = 0, rc;
+    parse_ctx pc;
     if (!d || !packets || !yuv_out || !status || !fnum) return DSVG_ERR_ARG;
     if (out_pitch == 0) out_pitch = d->g.frame_bytes;
-    /* host: headers + side information of every packet (a few hundred bytes each) */
-    for (s = 0; s < d->nstreams; s++) {
-        bitw r;
-        int type, bw_, bh_, has_ref, is_ref;
-        dsvg_dec_job *job = &d->jobs[n];
-        status[s] = DSV_DEC_ERROR;
-        fnum[s] = (DSV_FNUM)-1;
-        if (!packets[s].data || parse_packet_header(&r, packets[s].data, &type)) continue;
-        if (!(type & DSV_PT_PIC)) {
-            if (type == DSV_PT_META) {
-                DSV_META m;
-                parse_meta(&r, &m);
-                status[s] = (m.width == d->meta.width && m.height == d->meta.height && m.subsamp == d->meta.subsamp) ? DSV_DEC_GOT_META : DSV_DEC_ERROR;
-            } else if (type == DSV_PT_EOS) {
-                status[s] = DSV_DEC_EOS;
-            }
-            continue;
+    pc.d = d; pc.packets = packets; pc.status = status; pc.fnum = fnum;
+    dsv1_par_for(d->nstreams, parse_stream, &pc);
+    for (s = 0; s < d->nstreams; s++)
+        if (status[s] == DSV_DEC_OK && fnum[s] != (DSV_FNUM)-1) {
+            d->jobs[n] = d->pj[s];
+            d->slots[n] = s;             /* whose job this is */
+            n++;
         }
-        has_ref = type & 1;
-        is_ref = (type & 0x6) == 0x6;
-        if (parse_picture_head(&r, &fnum[s], &bw_, &bh_)) continue;
-        if (bw_ != d->g.blk_w || bh_ != d->g.blk_h) {
-            dsv1_log(1, "stream %d: block size %dx%d differs from the encoder rule for this frame size", s, bw_, bh_);
-            continue;
-        }
-        if (parse_picture_body(&r, packets[s].data, &d->g, has_ref, d->stable + (size_t)s * d->nblk, d->mvs + (size_t)s * d->nblk, job)) continue;
-        if (has_ref && !d->have_ref[s]) {
-            dsv1_log(2, "stream %d: reference frame not found", s);
-            continue;
-        }
-        job->ref_recon_slot = has_ref ? s : -1;
-        job->recon_slot = is_ref ? s : d->nstreams + s;
-        if (is_ref) d->have_ref[s] = 1;
-        d->slots[n] = s;                 /* remember whose job this is */
-        status[s] = DSV_DEC_OK;
-        n++;
-    }
     if (!n) return DSVG_OK;
     /* device: all pictures of the call as one batch, then one packing pass into the caller's layout */
     if ((rc = dsvg_decode_pictures(d->ctx, n, d->jobs))) {

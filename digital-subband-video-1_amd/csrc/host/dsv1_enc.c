@@ -77,50 +77,6 @@ static void hp_report(void)
  * fork/join over them.  Threads: DSV1_HOST_THREADS, else min(6, cores / ranks on the node / 2); never more than streams. */
 #include <pthread.h>
 #include <unistd.h>
-typedef void (*par_fn)(void *ctx, int s, int tid);
-typedef struct { par_fn fn; void *ctx; int tid, nthr, S; } par_arg;
-static void *par_main(void *p)
-{
-    par_arg *a = (par_arg *)p;
-    int s;
-    for (s = a->tid; s < a->S; s += a->nthr) a->fn(a->ctx, s, a->tid);
-    return NULL;
-}
-static int par_threads(int S)
-{
-    static int n = 0;
-    if (!n) {
-        const char *e = getenv("DSV1_HOST_THREADS");
-        if (e) n = atoi(e);
-        else {
-            /* default: up to 6, but never more than half of this process's share of the host's cores (one process per
-             * GPU: LOCAL_WORLD_SIZE of the launcher tells how many share the node) */
-            const char *lw = getenv("LOCAL_WORLD_SIZE");
-            long cores = sysconf(_SC_NPROCESSORS_ONLN), ranks = lw ? atol(lw) : 1;
-            if (ranks < 1) ranks = 1;
-            if (cores < 1) cores = 1;
-            n = (int)(cores / ranks / 2);
-            if (n > 6) n = 6;
-        }
-        if (n < 1) n = 1;
-        if (n > 64) n = 64;
-    }
-    return n < S ? n : S;
-}
-static void par_for_streams(int S, par_fn fn, void *ctx)
-{
-    const int nthr = par_threads(S);
-    pthread_t th[64];
-    par_arg a[64];
-    int i, started = 0;
-    for (i = 0; i < nthr; i++) { a[i].fn = fn; a[i].ctx = ctx; a[i].tid = i; a[i].nthr = nthr; a[i].S = S; }
-    for (i = 1; i < nthr; i++, started++)
-        if (pthread_create(&th[i], NULL, par_main, &a[i]) != 0) break;
-    par_main(&a[0]);
-    for (i = started + 1; i < nthr; i++) { int s; for (s = i; s < S; s += nthr) fn(ctx, s, 0); }   /* threads that did not start */
-    for (i = 1; i <= started; i++) pthread_join(th[i], NULL);
-}
-
 static int slot_of(const dsv1_batch *b, int s, unsigned g) { return (int)(g % (unsigned)b->rows) * b->nstreams + s; }
 
 void *dsv1_batch_ctx(dsv1_batch *b) { return b ? (void *)b->ctx : NULL; }
@@ -606,7 +562,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     {
         side_ctx sc_;
         sc_.b = b; sc_.pics = pics;
-        par_for_streams(S, side_stream, &sc_);
+        dsv1_par_for(S, side_stream, &sc_);
     }
     HP_MARK(HP_SIDEINFO);
     /* 5. residual coding, frame step by frame step across all streams */
@@ -678,7 +634,7 @@ int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
         {
             asm_ctx ac;
             ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK;
-            par_for_streams(S, asm_stream, &ac);
+            dsv1_par_for(S, asm_stream, &ac);
             if (ac.rc) return ac.rc;
         }
         HP_MARK(HP_ASSEMBLE);

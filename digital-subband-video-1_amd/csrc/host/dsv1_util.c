@@ -4,6 +4,8 @@
  * motion-vector predictor (dsv.c:189-231) and the two CLI helpers of util.c.  None of this is hot. */
 #include <stdarg.h>
 #include <stdio.h>
+#include <pthread.h>
+#include <unistd.h>
 #include "dsv1_host.h"
 
 /* dsv.h:221 of the reference: the logging macros of callers compiled against the reference headers
@@ -270,3 +272,48 @@ void conv422to420(DSV_PLANE *s, DSV_PLANE *d)
                 (uint8_t)((s->data[(size_t)s->stride * y + x] + s->data[(size_t)s->stride * n + x] + 1) >> 1);
         }
 }
+
+/* ---- fork/join over independent streams (side information, packet assembly, packet parsing) ---- */
+typedef struct { dsv1_par_fn fn; void *ctx; int tid, nthr, S; } par_arg;
+static void *par_main(void *p)
+{
+    par_arg *a = (par_arg *)p;
+    int s;
+    for (s = a->tid; s < a->S; s += a->nthr) a->fn(a->ctx, s, a->tid);
+    return NULL;
+}
+static int par_threads(int S)
+{
+    static int n = 0;
+    if (!n) {
+        const char *e = getenv("DSV1_HOST_THREADS");
+        if (e) n = atoi(e);
+        else {
+            /* default: up to 6, but never more than half of this process's share of the host's cores (one process per
+             * GPU: LOCAL_WORLD_SIZE of the launcher tells how many share the node) */
+            const char *lw = getenv("LOCAL_WORLD_SIZE");
+            long cores = sysconf(_SC_NPROCESSORS_ONLN), ranks = lw ? atol(lw) : 1;
+            if (ranks < 1) ranks = 1;
+            if (cores < 1) cores = 1;
+            n = (int)(cores / ranks / 2);
+            if (n > 6) n = 6;
+        }
+        if (n < 1) n = 1;
+        if (n > 64) n = 64;
+    }
+    return n < S ? n : S;
+}
+void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx)
+{
+    const int nthr = par_threads(S);
+    pthread_t th[64];
+    par_arg a[64];
+    int i, started = 0;
+    for (i = 0; i < nthr; i++) { a[i].fn = fn; a[i].ctx = ctx; a[i].tid = i; a[i].nthr = nthr; a[i].S = S; }
+    for (i = 1; i < nthr; i++, started++)
+        if (pthread_create(&th[i], NULL, par_main, &a[i]) != 0) break;
+    par_main(&a[0]);
+    for (i = started + 1; i < nthr; i++) { int s; for (s = i; s < S; s += nthr) fn(ctx, s, 0); }   /* threads that did not start */
+    for (i = 1; i <= started; i++) pthread_join(th[i], NULL);
+}
+

@@ -670,8 +670,9 @@ static __device__ __forceinline__ int parse_step(int st, int b, bool &end)
     }
 }
 
-__global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__ jobs, int c)
+__global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__ jobs, int c0)
 {
+    const int c = c0 + (int)blockIdx.y;             // one workgroup per (picture, plane)
     __shared__ uint8_t s_tab[5][256];               // [state][byte] -> exit state | (code ends << 3)
     __shared__ unsigned s_wmap[16];                 // per-wave inclusive state maps (5 x 3 bits)
     __shared__ int s_wcnt[16], s_wlast[16];
@@ -846,8 +847,9 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__
 
 // scatter of one level group of the parsed entries (the groups go in order: a cell two scan regions share takes the
 // later region's value): phase 0 = LL + level 0, 1 = level 1, 2 = level 2
-__global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict__ jobs, int c, int phase)
+__global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict__ jobs, int c0, int phase)
 {
+    const int c = c0 + (int)blockIdx.z;
     const JobDev &jb = jobs[blockIdx.y];
     const HzPlane &hp = jb.hz[c];
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -914,15 +916,17 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
 
 // decoder: parse the uploaded plane payloads of `njobs` jobs (plane c) and scatter the entries; max_entries = largest
 // announced run count + 1 over the jobs (sizes the scatter grids)
-void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int max_entries, Prof *pf)
+// planes [c, c + nplanes) of every job: one parse launch (a workgroup per picture and plane), then the three ordered
+// scatter phases; max_entries = the largest entry count announced by any of those planes
+void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, Prof *pf)
 {
     PB(KID_HZ_PARSE, 0.0);
-    hipLaunchKernelGGL(k_hz_parse, dim3(njobs), dim3(PARSE_THREADS), 0, st, jobs, c);
+    hipLaunchKernelGGL(k_hz_parse, dim3(njobs, nplanes), dim3(PARSE_THREADS), 0, st, jobs, c);
     PE();
     if (max_entries <= 0) return;
     for (int ph = 0; ph < 3; ph++) {
         PB(KID_HZ_SCATTER, 0.0);
-        hipLaunchKernelGGL(k_hz_scatter_lv, dim3((max_entries + 255) / 256, njobs), dim3(256), 0, st, jobs, c, ph);
+        hipLaunchKernelGGL(k_hz_scatter_lv, dim3((max_entries + 255) / 256, njobs, nplanes), dim3(256), 0, st, jobs, c, ph);
         PE();
     }
 }
