@@ -83,6 +83,13 @@ struct HzPlaneSum {          // written by hz_scan per plane
     int last_chunk;          // last chunk holding a non-zero (-1 if the plane is empty)
 };
 
+// decoder: k_hz_parse -> k_hz_codes hand-over for one 128-bit chunk of a plane payload
+struct HzParseChunk {
+    unsigned long long m0, m1;   // bit 127-i of {m0,m1}: a code ends with chunk bit i
+    int cbase;                   // index (in the alternating chain) of the first code that ends in this chunk
+    int prev_end;                // payload bit after the code before that one
+};
+
 struct JobDev {              // everything a kernel needs to find one picture job's buffers
     const uint8_t *src;      // source frame (bordered, extended)
     const uint8_t *ref;      // reference reconstruction (bordered, extended) or nullptr
@@ -104,6 +111,9 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     int dec_cnt[3];          // decoder: number of (position,value) pairs per plane (written by k_hz_parse)
     int dec_runs[3], dec_len[3], dec_dc[3];   // decoder: run count / byte length / DC of the plane header (host)
     long long dec_bitpos[3]; // decoder: bit offset of the first code inside the uploaded payload
+    HzParseChunk *dec_meta[3];   // decoder: per 128-bit payload chunk, what k_hz_parse found (>= dec_len/16 + 2 entries)
+    long long dec_s0[3];         // decoder: first bit of the alternating code chain (k_hz_parse)
+    int dec_npass[3], dec_ncode[3], dec_first_bad[3];   // decoder: passes done / codes seen (k_hz_parse), first entry past the data (k_hz_codes)
     int16_t *sym;            // fused quantiser: quantised symbol of every detail scan cell, indexed nz_off[c] + scan position
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
     HzPlane hz[3];

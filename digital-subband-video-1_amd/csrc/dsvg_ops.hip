@@ -241,12 +241,13 @@ extern "C" int dsvg_op_decode_plane(uint8_t *in, unsigned len, dsvg_coefs *dst, 
     uint8_t *dpay; OPCHK(S.dev(&dpay, (size_t)len + 64, true));
     HIPCHK(hipMemcpyAsync(dpay, in, len, hipMemcpyHostToDevice, S.st));
     jb.bits = dpay; jb.bits_off[c] = 0;
+    OPCHK(S.dev(&jb.dec_meta[c], (size_t)len / 16 + 2, false));
     OPCHK(S.dev(&jb.nzpos, (size_t)hp.nchunks * HZ_CHUNK, false));
     OPCHK(S.dev(&jb.nzval, (size_t)hp.nchunks * HZ_CHUNK, false));
     JobDev *djb; OPCHK(S.dev(&djb, 1, false));
     HIPCHK(hipMemcpyAsync(djb, &jb, sizeof(jb), hipMemcpyHostToDevice, S.st));
     // parse, then three ordered scatter phases so that a later region's non-zero overwrites an earlier one
-    launch_hz_parse_scatter(S.st, djb, 1, c, 1, std::min(std::max(runs, 0), hp.nchunks * HZ_CHUNK - 1) + 1);
+    launch_hz_parse_scatter(S.st, djb, 1, c, 1, std::min(std::max(runs, 0), hp.nchunks * HZ_CHUNK - 1) + 1, (int)(len / 16 + 2));
     HIPCHK(hipMemcpyAsync(dst->data, dco, (size_t)dst->width * dst->height * 4, hipMemcpyDeviceToHost, S.st));
     OPCHK(S.sync());
     dst->data[0] = dc;

@@ -58,6 +58,8 @@ struct dsvg_ctx {
     size_t dec_cap[2] = {0, 0};
     hipEvent_t ev_dec[2] = {nullptr, nullptr};   // uploads of the call that last used that parity
     int dec_par = 0;
+    HzParseChunk *dec_meta = nullptr;            // decoder: k_hz_parse -> k_hz_codes records of one call
+    size_t dec_meta_cap = 0;
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
     size_t yuv_stage_bytes = 0;
     int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
@@ -83,7 +85,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1]};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -745,8 +747,19 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         HIPCHK(hipMalloc((void **)&c->dec_d[k], cap + 256));
         c->dec_cap[k] = cap;
     }
+    // per 128-bit payload chunk one hand-over record between the parse kernels (device only, consumed in stream order)
+    size_t nmeta = 0;
+    for (int t = 0; t < njobs; t++)
+        for (int p = 0; p < 3; p++) nmeta += (size_t)jobs[ord[t]].plane_len[p] / 16 + 2;
+    if (nmeta > c->dec_meta_cap) {
+        if (c->dec_meta) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipFree(c->dec_meta); c->dec_meta = nullptr; c->dec_meta_cap = 0; }
+        const size_t cap = nmeta * 2 + 4096;
+        HIPCHK(hipMalloc((void **)&c->dec_meta, cap * sizeof(HzParseChunk)));
+        c->dec_meta_cap = cap;
+    }
     const size_t hb = (size_t)k * c->max_jobs;          // this parity's part of the pinned tables
-    int max_entries = 0;
+    int max_entries = 0, max_chunks = 0;
+    size_t moff = 0;
     const CoefLayout &CL = c->CL;
     size_t off = 0;
     for (int t = 0; t < njobs; t++) {
@@ -775,6 +788,9 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
             jb.dec_len[p] = (int)j.plane_len[p];
             jb.dec_cnt[p] = 0;
             max_entries = std::max(max_entries, std::min(jb.dec_runs[p], jb.hz[p].nchunks * HZ_CHUNK - 1) + 1);
+            jb.dec_meta[p] = c->dec_meta + moff;
+            moff += (size_t)j.plane_len[p] / 16 + 2;
+            max_chunks = std::max(max_chunks, (int)(j.plane_len[p] / 16 + 2));
             jb.bits_off[p] = off;
             uint8_t *stage = c->dec_h[k] + off;
             memcpy(stage, j.plane_data[p], j.plane_len[p]);
@@ -789,7 +805,7 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h + hb, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
     HIPCHK(hipMemsetAsync(c->coef, 0, CL.total * (size_t)njobs * sizeof(int32_t), c->st));
-    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, &c->prof);
+    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof);
     if (njobs > nI) {
         launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }

@@ -631,13 +631,21 @@ __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs
 #define PARSE_THREADS 1024
 #define PARSE_BITS 128
 static __device__ __forceinline__ unsigned long long bits_at(const uint8_t *p, unsigned long long bitpos)
-{   // 64 bits of the MSB-first stream starting at bitpos (reads 9 bytes; the payload buffer has slack)
-    const uint8_t *q = p + (bitpos >> 3);
-    unsigned long long w = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) w = (w << 8) | q[i];
-    const unsigned sh = (unsigned)(bitpos & 7);
-    return sh ? (w << sh) | ((unsigned long long)q[8] >> (8 - sh)) : w;
+{   // 64 bits of the MSB-first stream starting at bitpos: two aligned 8-byte loads (p is 8-byte aligned and the payload
+    // buffer has 64 bytes of slack)
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p) + (bitpos >> 6);
+    const unsigned sh = (unsigned)(bitpos & 63);
+    const unsigned long long a = __builtin_bswap64(q[0]), b = __builtin_bswap64(q[1]);
+    return sh ? (a << sh) | (b >> (64 - sh)) : a;
+}
+// 128 bits from bitpos: three loads
+static __device__ __forceinline__ void bits128_at(const uint8_t *p, unsigned long long bitpos, unsigned long long &w0, unsigned long long &w1)
+{
+    const unsigned long long *q = reinterpret_cast<const unsigned long long *>(p) + (bitpos >> 6);
+    const unsigned sh = (unsigned)(bitpos & 63);
+    const unsigned long long a = __builtin_bswap64(q[0]), b = __builtin_bswap64(q[1]), c = __builtin_bswap64(q[2]);
+    w0 = sh ? (a << sh) | (b >> (64 - sh)) : a;
+    w1 = sh ? (b << sh) | (c >> (64 - sh)) : b;
 }
 static __device__ __forceinline__ unsigned compress_bits(unsigned long long x)      // bit 2i -> bit i (inverse of spread_bits)
 {
@@ -657,6 +665,18 @@ static __device__ __forceinline__ unsigned ueg_value(unsigned long long w, int l
     const unsigned long long body = w >> (64 - (len - 1));          // k pairs ('0', bit), the data bit is the low bit of each pair
     return ((1u << k) | compress_bits(body)) - 1u;
 }
+// the same for a code of at most 31 bits in the top bits of a 32-bit word
+static __device__ __forceinline__ unsigned ueg_value32(unsigned w, int len)
+{
+    const int k = (len - 1) >> 1;
+    if (k <= 0) return 0u;
+    unsigned x = (w >> (32 - (len - 1))) & 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0F0F0F0Fu;
+    x = (x | (x >> 4)) & 0x00FF00FFu;
+    x = (x | (x >> 8)) & 0x0000FFFFu;
+    return ((1u << k) | x) - 1u;
+}
 // one step of the machine: state x bit -> state; *end = a code ends with this bit
 static __device__ __forceinline__ int parse_step(int st, int b, bool &end)
 {
@@ -670,33 +690,48 @@ static __device__ __forceinline__ int parse_step(int st, int b, bool &end)
     }
 }
 
+// 128 payload bits from B with everything at or after endbits forced to zero
+static __device__ __forceinline__ void parse_chunk_bits(const uint8_t *pay, long long B, long long endbits, unsigned long long &w0, unsigned long long &w1)
+{
+    w0 = 0; w1 = 0;
+    if (B < endbits) bits128_at(pay, (unsigned long long)B, w0, w1);
+    if (B + 128 > endbits) {
+        const long long keep = endbits - B;                           // < 128
+        if (keep <= 0) { w0 = 0; w1 = 0; }
+        else if (keep < 64) { w0 &= ~0ull << (64 - keep); w1 = 0; }
+        else if (keep < 128) { w1 = keep == 64 ? 0ull : (w1 & (~0ull << (128 - keep))); }
+    }
+}
+
+// A. the serial part, one workgroup per (picture, plane): state maps, their scan, code-end masks; per 128-bit chunk it
+// leaves {end masks, index of the first code ending in it, end of the code before} for k_hz_codes.
 __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__ jobs, int c0)
 {
-    const int c = c0 + (int)blockIdx.y;             // one workgroup per (picture, plane)
-    __shared__ uint8_t s_tab[5][256];               // [state][byte] -> exit state | (code ends << 3)
+    const int c = c0 + (int)blockIdx.y;
+    __shared__ uint16_t s_tab[5][256];              // [state][byte] -> exit state | (code ends << 3) | (end mask << 8)
     __shared__ unsigned s_wmap[16];                 // per-wave inclusive state maps (5 x 3 bits)
     __shared__ int s_wcnt[16], s_wlast[16];
-    __shared__ int s_state, s_ncode, s_first_bad;
+    __shared__ int s_state, s_ncode;
     __shared__ long long s_lastend;
-    __shared__ unsigned long long s_q;
     JobDev &jb = jobs[blockIdx.x];
     const HzPlane &hp = jb.hz[c];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint8_t *pay = jb.bits + jb.bits_off[c];
     int32_t *R = jb.nzpos + jb.nz_off[c];           // [0] = DC position, [m] = run_m, then scan position of entry m
     int32_t *V = jb.nzval + jb.nz_off[c];
+    HzParseChunk *meta = jb.dec_meta[c];
     const long long endbits = 8ll * jb.dec_len[c];
     const int cap = hp.nchunks * HZ_CHUNK - 1;
     const int n = min(jb.dec_runs[c], cap);         // entries announced by the header
-    if (tid == 0) { R[0] = 0; V[0] = jb.dec_dc[c]; }
-    if (n <= 0) { if (tid == 0) jb.dec_cnt[c] = 1; return; }
+    if (tid == 0) { R[0] = 0; V[0] = jb.dec_dc[c]; jb.dec_first_bad[c] = 0x7fffffff; jb.dec_npass[c] = 0; jb.dec_ncode[c] = 0; }
+    if (n <= 0) return;
 
     for (int i = tid; i < 5 * 256; i += PARSE_THREADS) {
-        int st = i >> 8, cnt = 0;
+        int st = i >> 8, cnt = 0, mask = 0;
         const int byte = i & 255;
 #pragma unroll
-        for (int b = 7; b >= 0; b--) { bool e; st = parse_step(st, (byte >> b) & 1, e); cnt += e; }
-        s_tab[i >> 8][byte] = (uint8_t)(st | (cnt << 3));
+        for (int b = 7; b >= 0; b--) { bool e; st = parse_step(st, (byte >> b) & 1, e); cnt += e; if (e) mask |= 1 << b; }
+        s_tab[i >> 8][byte] = (uint16_t)(st | (cnt << 3) | (mask << 8));
     }
     const long long start0 = jb.dec_bitpos[c];
     if (tid == 0) {                                 // U(run_1), serially
@@ -704,24 +739,18 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__
         const int k = w ? __clzll((long long)(w & 0xAAAAAAAAAAAAAAAAull)) >> 1 : 31;   // first '1' at an even offset = the stop flag
         const int len = 2 * k + 1;
         R[1] = (int32_t)ueg_value(w, len);
-        s_state = 0; s_ncode = 0; s_first_bad = 0x7fffffff;
+        s_state = 0; s_ncode = 0;
         s_lastend = start0 + len;
     }
     __syncthreads();
     const int ncodes = 2 * n - 1;
     const long long S0 = s_lastend;                 // first bit of the alternating chain
+    int npass = 0;
 
-    for (long long pbase = S0; pbase < endbits && s_ncode < ncodes; pbase += (long long)PARSE_THREADS * PARSE_BITS) {
+    for (long long pbase = S0; pbase < endbits && s_ncode < ncodes; pbase += (long long)PARSE_THREADS * PARSE_BITS, npass++) {
         const long long B = pbase + (long long)tid * PARSE_BITS;
-        unsigned long long w0 = 0, w1 = 0;
-        if (B < endbits) { w0 = bits_at(pay, (unsigned long long)B); w1 = bits_at(pay, (unsigned long long)B + 64); }
-        // bits past the end of the plane data read as zero
-        if (B + 128 > endbits) {
-            const long long keep = endbits - B;                       // < 128
-            if (keep <= 0) { w0 = 0; w1 = 0; }
-            else if (keep < 64) { w0 &= ~0ull << (64 - keep); w1 = 0; }
-            else if (keep < 128) { w1 = keep == 64 ? 0ull : (w1 & (~0ull << (128 - keep))); }
-        }
+        unsigned long long w0, w1;
+        parse_chunk_bits(pay, B, endbits, w0, w1);
         // 1. state map of the chunk: exit state for each of the 5 entry states
         unsigned map = 0;
 #pragma unroll
@@ -754,13 +783,20 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__
             const unsigned excl = (unsigned)__shfl_up((int)inc, 1);
             if (lane > 0) st_in = (int)((excl >> (3 * st_in)) & 7);
         }
-        // 2. the chunk again from its real entry state: code-end mask (bit 127-i of {m0,m1} = a code ends with chunk bit i)
+        // 2. the chunk again from its real entry state: code-end mask (bit 127-i of {m0,m1} = a code ends with chunk bit i;
+        // the table gives the ends inside a byte: bit 7-j of the mask byte = a code ends with the byte's j-th bit)
         unsigned long long m0 = 0, m1 = 0;
         int st = st_in;
-#pragma unroll 4
-        for (int i = 0; i < 64; i++) { bool e; st = parse_step(st, (int)((w0 >> (63 - i)) & 1), e); if (e) m0 |= 1ull << (63 - i); }
-#pragma unroll 4
-        for (int i = 0; i < 64; i++) { bool e; st = parse_step(st, (int)((w1 >> (63 - i)) & 1), e); if (e) m1 |= 1ull << (63 - i); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned e = s_tab[st][(unsigned)(w0 >> (56 - 8 * k)) & 0xff];
+            st = (int)(e & 7); m0 |= (unsigned long long)(e >> 8) << (56 - 8 * k);
+        }
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const unsigned e = s_tab[st][(unsigned)(w1 >> (56 - 8 * k)) & 0xff];
+            st = (int)(e & 7); m1 |= (unsigned long long)(e >> 8) << (56 - 8 * k);
+        }
         const int cnt = __popcll(m0) + __popcll(m1);
         const int lastoff = m1 ? 127 - (__ffsll((long long)m1) - 1) : (m0 ? 63 - (__ffsll((long long)m0) - 1) : -1);   // chunk bit of the last end
         // exclusive prefix sum of counts, exclusive max-scan of last ends
@@ -778,34 +814,11 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__
             const int a = __shfl_up(csum, 1), b = __shfl_up(lmax, 1);
             if (lane > 0) { cbase += a; lbefore = max(lbefore, b); }
         }
-        long long prev_end = lbefore >= 0 ? pbase + lbefore + 1 : s_lastend;    // bit after the previous code
-        // 3. decode the codes that end in this chunk
-        int j = cbase;
-        for (int half = 0; half < 2 && j < ncodes; half++) {
-            unsigned long long m = half ? m1 : m0;
-            while (m && j < ncodes) {
-                const int hb = 63 - __clzll((long long)m);               // highest set bit = earliest end
-                m &= ~(1ull << hb);
-                const long long endp = B + half * 64 + (63 - hb) + 1;     // bit after the code
-                const int len = (int)min(endp - prev_end, 63ll);
-                const unsigned long long w = bits_at(pay, (unsigned long long)prev_end);
-                if (j == ncodes - 1) {                                    // the final N: U part here, sign = the next bit
-                    const unsigned mag = ueg_value(w, len) + 1u;
-                    const int sign = (int)((bits_at(pay, (unsigned long long)endp) >> 63) & 1);
-                    V[n] = sign ? -(int)mag : (int)mag;
-                    if (((endp + 1) >> 3) >= jb.dec_len[c]) atomicMin(&s_first_bad, n);
-                } else if ((j & 1) == 0) {
-                    R[j / 2 + 2] = (int32_t)ueg_value(w, len);            // U(run_{j/2+2})
-                } else {
-                    const unsigned mag = ueg_value(w, len - 1) + 1u;      // N(v_{(j+1)/2}): U part + sign
-                    const int sign = (int)((w >> (64 - len)) & 1);
-                    const int mi = (j + 1) / 2;
-                    V[mi] = sign ? -(int)mag : (int)mag;
-                    if ((endp >> 3) >= jb.dec_len[c]) atomicMin(&s_first_bad, mi);   // hzcc.c:337-339
-                }
-                prev_end = endp;
-                j++;
-            }
+        const long long prev_end = lbefore >= 0 ? pbase + lbefore + 1 : s_lastend;    // bit after the previous code
+        if (B < endbits) {
+            HzParseChunk mc;
+            mc.m0 = m0; mc.m1 = m1; mc.cbase = cbase; mc.prev_end = (int)prev_end;
+            meta[(size_t)npass * PARSE_THREADS + tid] = mc;
         }
         __syncthreads();
         if (tid == PARSE_THREADS - 1) {                                   // carry to the next pass
@@ -816,30 +829,141 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__
         }
         __syncthreads();
     }
+    if (tid == 0) { jb.dec_npass[c] = npass; jb.dec_ncode[c] = s_ncode; jb.dec_s0[c] = S0; }
+}
+
+// B. every chunk on its own: the codes that END in it go straight into the run / value arrays.  A code is at most
+// 63 bits, so it starts no earlier than the second word of the chunk before: three words of payload per thread.
+__global__ __launch_bounds__(256) void k_hz_codes(JobDev *__restrict__ jobs, int c0)
+{
+    const int c = c0 + (int)blockIdx.z;
+    JobDev &jb = jobs[blockIdx.y];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= jb.dec_npass[c] * PARSE_THREADS) return;
+    const int dlen = jb.dec_len[c];
+    const long long endbits = 8ll * dlen;
+    const long long B = jb.dec_s0[c] + (long long)i * PARSE_BITS;
+    if (B >= endbits) return;
+    const HzPlane &hp = jb.hz[c];
+    const int n = min(jb.dec_runs[c], hp.nchunks * HZ_CHUNK - 1);
+    const int ncodes = 2 * n - 1;
+    const uint8_t *pay = jb.bits + jb.bits_off[c];
+    int32_t *R = jb.nzpos + jb.nz_off[c];
+    int32_t *V = jb.nzval + jb.nz_off[c];
+    const HzParseChunk mc = jb.dec_meta[c][i];
+    int j = mc.cbase;
+    if (j >= ncodes || !(mc.m0 | mc.m1)) return;
+    unsigned long long w0, w1;
+    parse_chunk_bits(pay, B, endbits, w0, w1);
+    const unsigned long long wp = B >= 64 ? bits_at(pay, (unsigned long long)(B - 64)) : 0ull;
+    long long prev_end = mc.prev_end;
+    int first_bad = 0x7fffffff;
+    for (int half = 0; half < 2 && j < ncodes; half++) {
+        unsigned long long m = half ? mc.m1 : mc.m0;
+        while (m && j < ncodes) {
+            const int hb = 63 - __clzll((long long)m);                   // highest set bit = earliest end
+            m &= ~(1ull << hb);
+            const long long endp = B + half * 64 + (63 - hb) + 1;         // bit after the code
+            const int len = (int)min(endp - prev_end, 63ll);
+            const int rel = (int)(prev_end - (B - 64));
+            unsigned long long w;
+            if (rel >= 0) {
+                const int idx = rel >> 6, sh = rel & 63;
+                const unsigned long long wa = idx == 0 ? wp : (idx == 1 ? w0 : w1);
+                const unsigned long long wb = idx == 0 ? w0 : (idx == 1 ? w1 : 0ull);
+                w = sh ? (wa << sh) | (wb >> (64 - sh)) : wa;
+            } else {
+                w = bits_at(pay, (unsigned long long)prev_end);           // over-long code of a damaged stream
+            }
+            // one body for both code kinds: U(run) is all magnitude; N(value) is magnitude + sign bit, except the final N
+            // of the plane, which arrives where a U was due (its U part ends here, the sign is the next bit)
+            const bool last = j == ncodes - 1, isN = (j & 1) != 0;
+            const int ulen = isN ? len - 1 : len;                         // bits of the U part
+            const unsigned mag = ulen <= 31 ? ueg_value32((unsigned)(w >> 32), ulen) : ueg_value(w, ulen);
+            int sign = (int)((w >> (64 - len)) & 1);
+            if (last) sign = (int)((bits_at(pay, (unsigned long long)endp) >> 63) & 1);
+            const int mi = last ? n : (j + 1) >> 1;
+            const bool val = isN || last;
+            int32_t *dst = val ? V + mi : R + (j >> 1) + 2;
+            const int v1 = (int)mag + 1;
+            *dst = val ? (sign ? -v1 : v1) : (int)mag;
+            if (val && ((endp + (last ? 1 : 0)) >> 3) >= dlen) first_bad = min(first_bad, mi);   // hzcc.c:337-339
+            prev_end = endp;
+            j++;
+        }
+    }
+    if (first_bad != 0x7fffffff) atomicMin(&jb.dec_first_bad[c], first_bad);
+}
+
+// C. runs -> scan positions: q_1 = run_1, q_m = q_{m-1} + 1 + run_m, one workgroup per (picture, plane).  Eight
+// consecutive entries per thread and pass (two 16-byte loads; entry 0, the DC, adds nothing), wave scan of the thread
+// totals, waves chained through LDS.
+__global__ __launch_bounds__(PARSE_THREADS) void k_hz_positions(JobDev *__restrict__ jobs, int c0)
+{
+    const int c = c0 + (int)blockIdx.y;
+    __shared__ unsigned long long s_q, s_w64[16];
+    __shared__ int s_cnt[16];
+    JobDev &jb = jobs[blockIdx.x];
+    const HzPlane &hp = jb.hz[c];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    int32_t *R = jb.nzpos + jb.nz_off[c];
+    const int nscan = hp.nscan;
+    const int n = min(jb.dec_runs[c], hp.nchunks * HZ_CHUNK - 1);
+    if (n <= 0) { if (tid == 0) jb.dec_cnt[c] = 1; return; }
+    const int ncodes = 2 * n - 1, ncode = jb.dec_ncode[c], first_bad = jb.dec_first_bad[c];
     // entries actually usable: announced, fully inside the data, and (below) inside the scan
-    const int nent = s_ncode >= ncodes ? min(n, s_first_bad - 1) : min(s_ncode / 2, s_first_bad - 1);   // truncated data: whole pairs only
-    // runs -> scan positions: q_1 = run_1, q_m = q_{m-1} + 1 + run_m
+    const int nent = ncode >= ncodes ? min(n, first_bad - 1) : min(ncode / 2, first_bad - 1);   // truncated data: whole pairs only
     if (tid == 0) s_q = 0ull;
     __syncthreads();
     int count = 0;
-    for (int base = 1; base <= nent; base += PARSE_THREADS) {
-        const int m = base + tid;
-        unsigned long long v = m <= nent ? (unsigned long long)(unsigned)R[m] + (m > 1 ? 1ull : 0ull) : 0ull;
-        unsigned long long inc = v;
+    for (int base = 0; base <= nent; base += PARSE_THREADS * 8) {
+        const int mb = base + tid * 8;
+        int4 ra = make_int4(0, 0, 0, 0), rb = make_int4(0, 0, 0, 0);
+        if (mb <= nent) ra = *reinterpret_cast<const int4 *>(R + mb);
+        if (mb + 4 <= nent) rb = *reinterpret_cast<const int4 *>(R + mb + 4);
+        const int rv[8] = {ra.x, ra.y, ra.z, ra.w, rb.x, rb.y, rb.z, rb.w};
+        unsigned long long pre[8], tot = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = mb + i;
+            tot += (m >= 1 && m <= nent) ? (unsigned long long)(unsigned)rv[i] + (m > 1 ? 1ull : 0ull) : 0ull;
+            pre[i] = tot;
+        }
+        unsigned long long inc = tot;
 #pragma unroll
         for (int o = 1; o < 64; o <<= 1) {
             const unsigned long long a = __shfl_up(inc, o);
             if (lane >= o) inc += a;
         }
-        __shared__ unsigned long long s_w64[16];
         if (lane == 63) s_w64[wv] = inc;
         __syncthreads();
-        unsigned long long q = s_q + inc;
-        for (int w = 0; w < wv; w++) q += s_w64[w];
-        const bool ok = m <= nent && q < (unsigned long long)hp.nscan;
-        if (ok) R[m] = (int32_t)q;
-        count += __syncthreads_count(ok);
-        if (tid == PARSE_THREADS - 1) s_q = q;
+        unsigned long long q0 = s_q + (inc - tot);                        // positions before this thread's entries
+        for (int w = 0; w < wv; w++) q0 += s_w64[w];
+        int out[8], nok = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int m = mb + i;
+            const unsigned long long q = q0 + pre[i];
+            const bool ok = m >= 1 && m <= nent && q < (unsigned long long)nscan;
+            out[i] = ok ? (int)q : rv[i];
+            nok += ok;
+        }
+        if (mb + 7 <= nent) {
+            *reinterpret_cast<int4 *>(R + mb) = make_int4(mb == 0 ? 0 : out[0], out[1], out[2], out[3]);
+            *reinterpret_cast<int4 *>(R + mb + 4) = make_int4(out[4], out[5], out[6], out[7]);
+        } else {                                                          // tail: never write past entry nent
+#pragma unroll
+            for (int i = 0; i < 8; i++)
+                if (mb + i >= 1 && mb + i <= nent) R[mb + i] = out[i];
+        }
+        // positions are increasing, so the valid entries form a prefix: counting them is enough
+        int c64 = nok;
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) c64 += __shfl_xor(c64, o);
+        if (lane == 0) s_cnt[wv] = c64;
+        __syncthreads();
+        for (int w = 0; w < 16; w++) count += s_cnt[w];
+        if (tid == PARSE_THREADS - 1) s_q = q0 + tot;
         __syncthreads();
     }
     if (tid == 0) jb.dec_cnt[c] = 1 + count;      // positions are increasing: the valid entries are a prefix
@@ -916,12 +1040,21 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
 
 // decoder: parse the uploaded plane payloads of `njobs` jobs (plane c) and scatter the entries; max_entries = largest
 // announced run count + 1 over the jobs (sizes the scatter grids)
-// planes [c, c + nplanes) of every job: one parse launch (a workgroup per picture and plane), then the three ordered
+// planes [c, c + nplanes) of every job: the serial scan (a workgroup per picture and plane), the code decode spread over
+// the chip (max_chunks = most 128-bit chunks any of the payloads has), the run -> position pass, then the three ordered
 // scatter phases; max_entries = the largest entry count announced by any of those planes
-void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, Prof *pf)
+void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf)
 {
     PB(KID_HZ_PARSE, 0.0);
     hipLaunchKernelGGL(k_hz_parse, dim3(njobs, nplanes), dim3(PARSE_THREADS), 0, st, jobs, c);
+    PE();
+    if (max_chunks > 0) {
+        PB(KID_HZ_CODES, 0.0);
+        hipLaunchKernelGGL(k_hz_codes, dim3((max_chunks + 255) / 256, njobs, nplanes), dim3(256), 0, st, jobs, c);
+        PE();
+    }
+    PB(KID_HZ_POSITIONS, 0.0);
+    hipLaunchKernelGGL(k_hz_positions, dim3(njobs, nplanes), dim3(PARSE_THREADS), 0, st, jobs, c);
     PE();
     if (max_entries <= 0) return;
     for (int ph = 0; ph < 3; ph++) {
