@@ -58,6 +58,16 @@ def test_no_device_fails_loudly_not_silently(lib):
     rc = lib.dsvg_op_fwd_sbt(C.byref(pl), C.byref(A.Coefs(A.i32p(co), w, h)), 1)
     assert rc != 0 and lib.dsvg_last_error()
     assert not co.any()
+    # the session-level entry points refuse as well: batch encoder and batched decoder
+    import importlib
+    pkg = importlib.import_module("digital-subband-video-1_amd")
+    pkg.lib()
+    cfg = pkg.make_encoder_cfg(64, 64, A.SUBSAMP_420)
+    h = C.c_void_p(None)
+    assert lib.dsv1_batch_open(C.byref(h), C.byref(cfg), 0, 1, 1) != 0 and not h.value
+    m = pkg.Meta()
+    m.width, m.height, m.subsamp = 64, 64, A.SUBSAMP_420
+    assert lib.dsv1_decbatch_open(C.byref(h), 0, C.byref(m), 2) != 0 and not h.value
 
 
 def test_host_only_helpers_work_without_gpu(lib):
