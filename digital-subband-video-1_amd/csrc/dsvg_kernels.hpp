@@ -27,7 +27,9 @@ struct HmeArgs {
 // k_sbt.hip
 int  sbt_tail_supported(const SbtGeo &g);
 void sbt_set_func_attributes();
-void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr, int with_tail = 1, int fused = 0);
+void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr, int with_tail = 1, int fused = 0,
+                    const struct McGeo *mc = nullptr, const DMV *mvs0 = nullptr);   // mc: motion compensation fused into the P forward transform
+bool mc_fusable(const struct McGeo &MG);
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1,
                     int insym = 0);
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
@@ -41,7 +43,8 @@ int  hz_scan_items_max();
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);
 // k_bmc.hip
 // mvs0: the jobs' vector arrays when they are contiguous (job j at mvs0 + j * nblocks), else null (JobDev.mvs is used)
-void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr, const DMV *mvs0 = nullptr);
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr, const DMV *mvs0 = nullptr,
+               const int *list = nullptr, int nlist = 0);   // list: only these blocks (job * nblocks + block)
 // k_frame.hip
 int  unpack_fuses_level1(const FrameLayout &L);
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr,

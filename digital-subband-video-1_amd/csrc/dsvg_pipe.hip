@@ -26,6 +26,7 @@ struct dsvg_ctx {
     CoefLayout CL;
     SbtGeo3 G;
     McGeo MG;
+    bool mc_fused = false;           // P pictures: motion compensation inside the forward transform (k_fwd_mc_pix)
     int n_src = 0, n_recon = 0, max_jobs = 0, out_slots = 0, nwin = 0, win = 0, calls_since_sync = 0;
     Slab src[6], recon, xf, pred;
     int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *s5 = nullptr, *nzpos = nullptr, *nzval = nullptr;
@@ -64,6 +65,7 @@ struct dsvg_ctx {
     size_t yuv_stage_bytes = 0;
     int *ltab_d = nullptr;           // slot table of dsvg_load_frames_map
     int *ptab_d = nullptr;           // slot table of dsvg_pack_recons
+    int *ilist_h = nullptr, *ilist_d = nullptr;   // intra blocks of the P pictures of a batch (pinned / device), indexed like jobs_h
     // host-resident input: two device ingest buffers filled on a copy stream of their own, so the upload of the
     // next batch runs under the analysis and coding of the current one
     hipStream_t st_h = nullptr;
@@ -85,9 +87,9 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d};
     for (void *p : d) if (p) (void)hipFree(p);
-    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
+    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (c->st_a) (void)hipStreamDestroy(c->st_a);
@@ -156,6 +158,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         MG.w[p] = c->L[0].w[p]; MG.h[p] = c->L[0].h[p]; MG.stride[p] = c->L[0].stride[p]; MG.off[p] = c->L[0].off[p];
         MG.cw_extra[p] = CL.w[p] > c->L[0].w[p];
     }
+    c->mc_fused = mc_fusable(MG) && !getenv("DSV1_NO_MC_FUSION");
     // per-plane scan bookkeeping
     size_t nzo = 0, bo = 0; int cho = 0;
     for (int p = 0; p < 3; p++) {
@@ -213,6 +216,10 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = hmalloc(&c->luma_h, (size_t)n_src_slots))) return fail(rc);
     if ((rc = hmalloc(&c->aslots_h, 2 * O))) return fail(rc);
     if ((rc = hmalloc(&c->amv_h, (size_t)c->nblk * O))) return fail(rc);
+    if (c->mc_fused) {
+        if ((rc = hmalloc(&c->ilist_h, (size_t)c->nblk * std::max(S, O)))) return fail(rc);
+        if ((rc = dmalloc(&c->ilist_d, (size_t)c->nblk * std::max(S, O), false))) return fail(rc);
+    }
     (void)J;
     *out = c;
     return DSVG_OK;
@@ -524,8 +531,11 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         const int e = c->slot_ev[base + i];
         if (e >= 0) { HIPCHK(hipEventSynchronize(c->ev_coded[e])); break; }
     }
-    std::vector<int> nIs(nsteps);
+    std::vector<int> nIs(nsteps), ioff(nsteps, 0), icnt(nsteps, 0);
+    int *il = c->ilist_h + (size_t)base * c->nblk;         // intra blocks of each step's P pictures (mc_fused)
+    int iln = 0;
     for (int t = 0; t < nsteps; t++) {
+        ioff[t] = iln;
         const dsvg_pic_job *js = jobs + (size_t)t * njobs;
         // device order inside a step: intra jobs first, then inter jobs (kernels are specialised per type)
         std::vector<int> order;
@@ -551,8 +561,15 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             c->slots_h[d] = j.recon_slot;
             memcpy(c->stable_h + (size_t)d * c->nblk, j.stable_blocks, (size_t)c->nblk);
             if (isP) memcpy(c->mv_h + (size_t)d * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+            if (isP && c->mc_fused && !j.no_intra_blocks) {
+                const DMV *mv = reinterpret_cast<const DMV *>(j.mvs);
+                for (int b = 0; b < c->nblk; b++)
+                    if (mv[b].mode != 0) il[iln++] = (k - nIs[t]) * c->nblk + b;      // index relative to the step's first P job
+            }
         }
+        icnt[t] = iln - ioff[t];
     }
+    if (iln) HIPCHK(hipMemcpyAsync(c->ilist_d + (size_t)base * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs + (size_t)base * c->nblk, c->mv_h + (size_t)base * c->nblk, (size_t)c->nblk * total * sizeof(DMV), hipMemcpyHostToDevice, c->st));
@@ -566,9 +583,17 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         }
         if (njobs > nI) {
             const int nP = njobs - nI;
-            launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof, c->mvs + (size_t)(d0 + nI) * c->nblk);
-            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
-            launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
+            const DMV *mv0 = c->mvs + (size_t)(d0 + nI) * c->nblk;
+            if (c->mc_fused) {
+                // inter blocks are predicted inside the forward transform; k_mc only serves the intra blocks (block means)
+                if (icnt[t]) launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof, mv0, c->ilist_d + (size_t)base * c->nblk + ioff[t], icnt[t]);
+                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
+                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
+            } else {
+                launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof, mv0);
+                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
+                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
+            }
         }
         launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
         launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,

@@ -16,7 +16,7 @@
 
 typedef struct {
     DSV_FNUM fnum;
-    int gop_start, is_ref, has_ref, forced_intra, isP, quant;
+    int gop_start, is_ref, has_ref, forced_intra, isP, quant, n_intra;
     int cur_slot, ref_slot, out_slot;
     DSV_MV *mvs;
     unsigned char *stable;
@@ -419,6 +419,7 @@ static void side_stream(void *ctx, int s, int tid)
         if (pc->has_ref) {
             int nintra = 0, i;
             for (i = 0; i < nblk; i++) nintra += pc->mvs[i].mode != 0;
+            pc->n_intra = nintra;
             pc->forced_intra = 0;
             if (nintra * 100 / nblk > e->intra_pct_thresh) { pc->has_ref = 0; pc->forced_intra = 1; }
         }
@@ -581,6 +582,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                 j->mvs = (const dsvg_mv *)pc->mvs;
                 j->stable_blocks = pc->stable;
                 j->out_slot = pc->out_slot;
+                j->no_intra_blocks = pc->isP && pc->n_intra == 0;
             }
             if (serial) {
                 if ((rc = dsvg_code_pictures(b->ctx, S, b->jobs))) return rc;

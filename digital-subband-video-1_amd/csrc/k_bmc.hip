@@ -45,15 +45,23 @@ static __device__ __forceinline__ void mc_store4(uint8_t *pp, uint8_t *xp, const
     }
 }
 
-__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub, int njobs, const DMV *__restrict__ mvs0)
+__global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, McGeo G, int do_sub, int njobs, const DMV *__restrict__ mvs0,
+                                              const int *__restrict__ list, int nlist)
 {
     __shared__ __align__(16) uint8_t win[WROWS * WPITCH];
     __shared__ int s_sum[5];
     // logical order: job, plane, block -- one XCD's L2 sees whole neighbouring block rows of one plane
     const int nblk = G.nbh * G.nbv;
-    const int item = d_xcd_remap(blockIdx.x, nblk * 3 * njobs);
-    if (item >= nblk * 3 * njobs) return;
-    const int job = item / (3 * nblk), c = (item - job * 3 * nblk) / nblk, blk = item - (job * 3 + c) * nblk;
+    int job, c, blk;
+    if (list) {                                 // only the listed blocks (job * nblk + blk), three planes each
+        if ((int)blockIdx.x >= 3 * nlist) return;
+        const int fi = list[blockIdx.x / 3];
+        c = blockIdx.x % 3; job = fi / nblk; blk = fi - job * nblk;
+    } else {
+        const int item = d_xcd_remap(blockIdx.x, nblk * 3 * njobs);
+        if (item >= nblk * 3 * njobs) return;
+        job = item / (3 * nblk); c = (item - job * 3 * nblk) / nblk; blk = item - (job * 3 + c) * nblk;
+    }
     const JobDev &jb = jobs[job];
     const int tid = threadIdx.x;
     const int sh = c ? G.hs : 0, sv = c ? G.vs : 0;
@@ -294,11 +302,18 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     }
 }
 
-void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf, const DMV *mvs0)
+void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf, const DMV *mvs0, const int *list, int nlist)
 {
     double smp = 0;
     for (int c = 0; c < 3; c++) smp += (double)G.w[c] * G.h[c];
+    if (list) {                              // the blocks of a list only (intra blocks beside k_fwd_mc_pix): a few waves
+        if (nlist <= 0) return;
+        if (pf) pf->begin(st, KID_MC, 0.0);
+        hipLaunchKernelGGL(k_mc, dim3(3 * nlist), dim3(MC_NT), 0, st, jobs, G, do_sub, njobs, mvs0, list, nlist);
+        if (pf) pf->end(st);
+        return;
+    }
     if (pf) pf->begin(st, KID_MC, smp * njobs * (do_sub ? 4.0 : 2.0));   // ref + src in, pred + residual out
-    hipLaunchKernelGGL(k_mc, dim3(xcd_grid(G.nbh * G.nbv * 3 * njobs)), dim3(MC_NT), 0, st, jobs, G, do_sub, njobs, mvs0);
+    hipLaunchKernelGGL(k_mc, dim3(xcd_grid(G.nbh * G.nbv * 3 * njobs)), dim3(MC_NT), 0, st, jobs, G, do_sub, njobs, mvs0, nullptr, 0);
     if (pf) pf->end(st);
 }

@@ -306,6 +306,183 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
 }
 
 // --------------------------------------------------------------------------------------------
+// forward, P pictures of the encoder, with the motion compensation done in place of the residual load:
+// dsv_sub_pred (compensate bmc.c:204-302 + subf bmc.c:43-55) fused into levels 1..3 + quantiser.
+// Every thread predicts its own 8x8 patch (it lies inside one block when the block sizes of the plane are multiples
+// of 8 -- the launcher checks), subtracts it from the source, keeps the residual in registers and writes only the
+// prediction (the inverse transform adds it back): the residual frame never exists, and k_mc's dependent round trips
+// (vector -> reference -> source -> two stores) ride along with the transform arithmetic of the other waves.
+// One code path for all four half-pel phases, so blocks with different vectors in one wave do not diverge:
+//   luma   H = xh ? 9(b+c)-(a+d) : 16 b on 11 rows, V = yh ? 9(H1+H2)-(H0+H3) : 16 H1, sat8((V + 128) >> 8)
+//          == hpelL bmc.c:124-174 in every phase: (16 t + 128) >> 8 == (t + 8) >> 4 and (256 p + 128) >> 8 == p;
+//   chroma (a + B + C + D + 2) >> 2 with B/C/D falling back to a / b / c when a phase is off == hpel bmc.c:58-110.
+// Intra blocks (mode != 0: block means, bmc.c:176-189,262-299) keep the two-kernel route: k_mc runs for them alone
+// beforehand and their patches read its residual as k_fwd_haar_pix does.
+// --------------------------------------------------------------------------------------------
+struct __attribute__((aligned(4))) U4A4 { unsigned x, y, z, w; };     // 16 bytes at a dword-aligned address
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_fwd_mc_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
+                                                    const DMV *__restrict__ mvs0)
+{
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    if (I >= g.w3 || J >= g.h3) return;
+    const JobDev &jb = jobs[job];
+    const int sh = CH ? MG.hs : 0, sv = CH ? MG.vs : 0;
+    const int bw = MG.blk_w >> sh, bh = MG.blk_h >> sv;
+    const int pw = MG.w[c], ph = g.ph, stride = g.pstride;
+    const int x0 = 8 * I, y0 = 8 * J;
+    // block of the patch: block sizes are multiples of 8, so (I + 0.5) / (bw / 8) is never near an integer
+    const int bi = (int)(((float)I + 0.5f) * __builtin_amdgcn_rcpf((float)(bw >> 3)));
+    const int bj = (int)(((float)J + 0.5f) * __builtin_amdgcn_rcpf((float)(bh >> 3)));
+    const int nblk = MG.nbh * MG.nbv, blk = bj * MG.nbh + bi;
+    const DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
+    const uint8_t *sp = jb.src + g.poff;
+    int32_t *coef = jb.coef + g.coff;
+
+    int a[8][8];
+    if (mv.mode != 0) {
+        const uint8_t *px = jb.xf + g.poff;
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = y0 + r;
+            uint2 v = make_uint2(0x80808080u, 0x80808080u);
+            if (y < ph) v = *reinterpret_cast<const uint2 *>(px + (size_t)y * stride + x0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                a[r][i] = (int)((v.x >> (8 * i)) & 0xff) - 128;
+                a[r][i + 4] = (int)((v.y >> (8 * i)) & 0xff) - 128;
+            }
+        }
+    } else {
+        const int dx = mv.x >> sh, dy = mv.y >> sv;
+        const int xb = bi * bw, yb = bj * bh;
+        const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
+        const int wy = d_clamp(yb + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1) + (y0 - yb);
+        const bool xh = dx & 1, yh = dy & 1;
+        const uint8_t *gr = jb.ref + g.poff + (long)(wy - 1) * stride + (wx - 1);      // reference (wx-1, wy-1)
+        const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
+        const uint8_t *ga = gr - shb;
+        uint8_t *pp = jb.pred + g.poff;
+        const bool full8 = x0 + 8 <= pw;
+        // all loads first: 11 (luma) / 9 (chroma) reference rows of 16 bytes, 8 source rows of 8
+        constexpr int R0 = CH ? 1 : 0, NR = CH ? 9 : 11;
+        U4A4 rw[NR];
+        uint2 sw[8];
+#pragma unroll
+        for (int k = 0; k < NR; k++) rw[k] = *reinterpret_cast<const U4A4 *>(ga + (long)(R0 + k) * stride);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const int y = min(y0 + r, ph - 1);
+            sw[r] = *reinterpret_cast<const uint2 *>(sp + (size_t)y * stride + x0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#define RB12(k, m) ((int)(((m) < 4 ? lo##k : ((m) < 8 ? mi##k : hi##k)) >> (8 * ((m) & 3))) & 0xff)
+        if (CH == 0) {
+            int Hq[4][8];                                 // rolling window of horizontally filtered rows (x16 scale)
+#pragma unroll
+            for (int k = 0; k < 11; k++) {
+                const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), mi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
+                               hi = __builtin_amdgcn_alignbyte(rw[k].w, rw[k].z, shb);
+                int b[11];
+#pragma unroll
+                for (int m = 0; m < 11; m++) b[m] = (int)(((m < 4 ? lo : (m < 8 ? mi : hi)) >> (8 * (m & 3))) & 0xff);
+#pragma unroll
+                for (int i = 0; i < 8; i++) Hq[k & 3][i] = xh ? 9 * (b[i + 1] + b[i + 2]) - (b[i] + b[i + 3]) : 16 * b[i + 1];
+                if (k >= 3) {
+                    const int r = k - 3, y = y0 + r;
+                    int pv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int h0 = Hq[r & 3][i], h1 = Hq[(r + 1) & 3][i], h2 = Hq[(r + 2) & 3][i], h3 = Hq[(r + 3) & 3][i];
+                        const int v = yh ? 9 * (h1 + h2) - (h0 + h3) : 16 * h1;
+                        pv[i] = d_sat8((v + 128) >> 8);
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int s = (int)(((i < 4 ? sw[r].x : sw[r].y) >> (8 * (i & 3))) & 0xff);
+                        a[r][i] = y < ph ? d_sat8(s - pv[i] + 128) - 128 : 0;
+                    }
+                    if (y < ph) {
+                        if (full8) {
+                            *reinterpret_cast<uint2 *>(pp + (size_t)y * stride + x0) =
+                                make_uint2((unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24),
+                                           (unsigned)pv[4] | ((unsigned)pv[5] << 8) | ((unsigned)pv[6] << 16) | ((unsigned)pv[7] << 24));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; i++) {
+                                if (x0 + i < pw) pp[(size_t)y * stride + x0 + i] = (uint8_t)pv[i];
+                                else {              // beyond the picture: the residual frame holds the replicated source edge there
+                                    const int e = (int)(((i - 1 < 4 ? sw[r].x : sw[r].y) >> (8 * ((i - 1) & 3))) & 0xff);
+                                    a[r][i] = (x0 + i == pw && MG.cw_extra[c] && i > 0) ? e - 128 : 0;
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+        } else {
+            unsigned plo = 0, pmi = 0, phi = 0;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), mi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
+                               hi = __builtin_amdgcn_alignbyte(rw[k].w, rw[k].z, shb);
+                if (k >= 1) {
+                    const int r = k - 1, y = y0 + r;
+                    int pv[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+#define BY(l_, m_, h_, m) ((int)((((m) < 4 ? (l_) : ((m) < 8 ? (m_) : (h_))) >> (8 * ((m) & 3))) & 0xff))
+                        const int pa = BY(plo, pmi, phi, i + 1), pb = BY(plo, pmi, phi, i + 2), pc = BY(lo, mi, hi, i + 1), pd = BY(lo, mi, hi, i + 2);
+                        const int B = xh ? pb : pa, C = yh ? pc : pa, D = xh ? (yh ? pd : pb) : (yh ? pc : pa);
+                        pv[i] = (pa + B + C + D + 2) >> 2;
+                    }
+#pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const int s = (int)(((i < 4 ? sw[r].x : sw[r].y) >> (8 * (i & 3))) & 0xff);
+                        a[r][i] = y < ph ? d_sat8(s - pv[i] + 128) - 128 : 0;
+                    }
+                    if (y < ph) {
+                        if (full8) {
+                            *reinterpret_cast<uint2 *>(pp + (size_t)y * stride + x0) =
+                                make_uint2((unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24),
+                                           (unsigned)pv[4] | ((unsigned)pv[5] << 8) | ((unsigned)pv[6] << 16) | ((unsigned)pv[7] << 24));
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 8; i++) {
+                                if (x0 + i < pw) pp[(size_t)y * stride + x0 + i] = (uint8_t)pv[i];
+                                else {
+                                    const int e = (int)(((i - 1 < 4 ? sw[r].x : sw[r].y) >> (8 * ((i - 1) & 3))) & 0xff);
+                                    a[r][i] = (x0 + i == pw && MG.cw_extra[c] && i > 0) ? e - 128 : 0;
+                                }
+                            }
+                        }
+                    }
+                }
+                plo = lo; pmi = mi; phi = hi;
+            }
+        }
+#undef BY
+#undef RB12
+    }
+    const int W = g.W, H = g.H;
+    const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
+    int l1[4][4], l2[2][2], l3[1][1];
+    QCtx q;
+    const HzPlane &hp = jb.hz[c];
+    q.hp = &hp; q.stable = jb.stable;
+    q.sym = jb.sym + jb.nz_off[c];
+    q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+               (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+    haar_fwd_patch_q<8, 2>(a, l1, 4 * I, 4 * J, W, H, W, wo1, ho1, coef, false, q);
+    haar_fwd_patch_q<4, 1>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true, q);
+    haar_fwd_patch_q<2, 0>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true, q);
+    jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
+}
+
+// --------------------------------------------------------------------------------------------
 // forward, I pictures: level 1 = biorthogonal 4-tap, rows then columns (fwd_b4t_2d sbt.c:240-251)
 // --------------------------------------------------------------------------------------------
 template <bool Q>
@@ -1191,13 +1368,24 @@ int sbt_tail_supported(const SbtGeo &g)
 #define PB(kid, bytes) do { if (pf) pf->begin(st, kid, bytes); } while (0)
 #define PE() do { if (pf) pf->end(st); } while (0)
 
+bool mc_fusable(const McGeo &MG)
+{
+    return (MG.blk_w >> MG.hs) % 8 == 0 && (MG.blk_h >> MG.vs) % 8 == 0 && MG.blk_w % 8 == 0 && MG.blk_h % 8 == 0;
+}
+
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
-                    int from_src, Prof *pf, int with_tail, int fused)
+                    int from_src, Prof *pf, int with_tail, int fused, const McGeo *mc, const DMV *mvs0)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
-    if (isP) {
+    if (isP && fused && mc) {
+        // motion compensation inside the transform: reference + source in, prediction + symbols out
+        PB(c0 == 0 ? KID_FWD_MC_PIX_Y : KID_FWD_MC_PIX_C, smp * 5.0);
+        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_pix<0>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
+        else         hipLaunchKernelGGL((k_fwd_mc_pix<1>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
+        PE();
+    } else if (isP) {
         PB(fused ? KID_FWD_HAAR_PIX_Q : KID_FWD_HAAR_PIX, smp * (fused ? 3.0 : 5.0));   // 1 B/sample in, 4 B/sample out (details + LL3); fused: 2 B symbols
         if (fused) hipLaunchKernelGGL((k_fwd_haar_pix<true>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         else       hipLaunchKernelGGL((k_fwd_haar_pix<false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);

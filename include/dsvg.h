@@ -149,6 +149,7 @@ typedef struct {
     const dsvg_mv *mvs;      /* host, nblocks entries (P pictures) */
     const unsigned char *stable_blocks; /* host, nblocks entries (encode_stable_blocks output) */
     int out_slot;            /* where the packed planes wait for dsvg_fetch_pictures */
+    int no_intra_blocks;     /* P pictures: 1 = the caller knows that no block of mvs has mode != 0 (saves a scan) */
 } dsvg_pic_job;
 
 typedef struct {
