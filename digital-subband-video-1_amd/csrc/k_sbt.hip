@@ -194,36 +194,66 @@ static __device__ __forceinline__ void haar_fwd_patch(const int (&in)[N][N], int
     }
 }
 
-// the same level with the quantiser of scan level HZL applied to the three detail bands
+// the same level with the quantiser of scan level HZL applied to the three detail bands.  Split into the per-patch
+// set-up (HaarQ) and the work on one pair of input rows, so that a producer can hand rows over as they appear.
 template <int N, int HZL>
-static __device__ __forceinline__ void haar_fwd_patch_q(const int (&in)[N][N], int (&out)[N / 2][N / 2],
-                                                        int cx0, int cy0, int ws, int hs, int W,
-                                                        int wo, int ho, int32_t *__restrict__ coef, bool scaled,
-                                                        const QCtx &q)
-{
-    constexpr int M = N / 2;
-    const int nR = min(M, max(0, (ws >> 1) - cx0));
-    const int nC = min(M, max(0, wo - cx0));
-    const HzPlane &hp = *q.hp;
-    const QLevel L = q_level<HZL>(hp);
-    int cls[M][M];
-    q_flags<HZL, M>(q, L, cx0, cy0, wo, ho, cls);
-    const bool chx = HZL >= 1 && q.any_ov && cx0 == 0, chy = HZL >= 1 && q.any_ov && cy0 == 0;
+struct HaarQ {
+    static constexpr int M = N / 2;
+    QLevel L;
+    int nR, nC, cx0, cy0, ws, hs, wo, ho, bx0, bx1;
+    int frow[M];
+    bool chx, chy;
+    __device__ __forceinline__ void init(const QCtx &q, int cx0_, int cy0_, int ws_, int hs_, int wo_, int ho_)
+    {
+        cx0 = cx0_; cy0 = cy0_; ws = ws_; hs = hs_; wo = wo_; ho = ho_;
+        nR = min(M, max(0, (ws >> 1) - cx0));
+        nC = min(M, max(0, wo - cx0));
+        L = q_level<HZL>(*q.hp);
+        bx0 = (cx0 * L.dbx) >> 14; bx1 = ((cx0 + M - 1) * L.dbx) >> 14;
+        // the usual case, all cells of a row in one block: that row's flag byte is requested now, with the producer's
+        // own loads, not in the middle of its arithmetic
+        if (bx0 == bx1) {
+            const int nbh = q.hp->nbh;
 #pragma unroll
-    for (int j = 0; j < M; j++) {
+            for (int j = 0; j < M; j++) frow[j] = cy0 + j < ho ? q.stable[(((cy0 + j) * L.dby) >> 14) * nbh + bx0] : 0;
+        }
+        chx = HZL >= 1 && q.any_ov && cx0 == 0; chy = HZL >= 1 && q.any_ov && cy0 == 0;
+    }
+    // input rows 2j and 2j+1 of the patch -> LL row j (out) + the quantised detail symbols of cell row cy0 + j
+    __device__ __forceinline__ void rows(const QCtx &q, int j, const int (&r0)[N], const int (&r1)[N], int (&out)[M], bool scaled) const
+    {
         const int cy = cy0 + j;
         const bool hasB = 2 * cy + 1 < hs;
         const bool rowok = 2 * cy < hs;
-        int lh[M], hl[M], hh[M], slh[M], shl[M], shh[M];
+        int slh[M], shl[M], shh[M];
+        // flag class of the cells of this row (one byte load when they sit in one block, the usual case); looked up per
+        // row so that no table of the whole patch stays alive across the producer of the rows
+        int cls[M];
+        {
+            const int nbh = q.hp->nbh, by = (cy * L.dby) >> 14;
+            if (bx0 == bx1) {
+                const int f = frow[j];
+                const int k = HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0));
+#pragma unroll
+                for (int i = 0; i < M; i++) cls[i] = k;
+            } else {
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    int f = 0;
+                    if (cx0 + i < wo && cy < ho) f = q.stable[by * nbh + (((cx0 + i) * L.dbx) >> 14)];
+                    cls[i] = HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0));
+                }
+            }
+        }
 #pragma unroll
         for (int i = 0; i < M; i++) {
             const bool hasR = 2 * (cx0 + i) + 1 < ws;
-            const int a = in[2 * j][2 * i];
-            const int b = hasR ? in[2 * j][2 * i + 1] : a;
-            const int c = hasB ? in[2 * j + 1][2 * i] : a;
-            const int d = hasB ? (hasR ? in[2 * j + 1][2 * i + 1] : c) : b;
+            const int a = r0[2 * i];
+            const int b = hasR ? r0[2 * i + 1] : a;
+            const int c = hasB ? r1[2 * i] : a;
+            const int d = hasB ? (hasR ? r1[2 * i + 1] : c) : b;
             const int ll = a + b + c + d;
-            out[j][i] = scaled ? d_ll_down(ll) : ll;
+            out[i] = scaled ? d_ll_down(ll) : ll;
             int vlh = a - b + c - d, vhl = a + b - c - d, vhh = a - b - c + d;
             if (HZL >= 1) {                             // shared cells sit on the first column / row of the bands
                 if (i == 0 && chx && rowok && nR > 0) {
@@ -235,15 +265,14 @@ static __device__ __forceinline__ void haar_fwd_patch_q(const int (&in)[N][N], i
                     if (i < nR && !(i == 0 && chx)) vhh = q_chain(q, HZL, wo + cx0 + i, ho, vhh);
                 }
             }
-            const int k = cls[j][i];
+            const int k = cls[i];
             const int qq = HZL == 2 ? (k ? L.sh1 : L.sh0) : max(L.qp >> k, HZ_MINQ);
             const float rc = HZL == 2 ? 0.f : __builtin_amdgcn_rcpf((float)(qq << 1));
-            lh[i] = q_coef<HZL>(qq, rc, vlh, slh[i]);
-            hl[i] = q_coef<HZL>(qq, rc, vhl, shl[i]);
-            hh[i] = q_coef<HZL>(qq, rc, vhh, shh[i]);
+            (void)q_coef<HZL>(qq, rc, vlh, slh[i]);
+            (void)q_coef<HZL>(qq, rc, vhl, shl[i]);
+            (void)q_coef<HZL>(qq, rc, vhh, shh[i]);
         }
         // only the symbols leave the chip: the inverse transform (k_inv_haar_tile<.,0,SYM>) dequantises them again
-        (void)lh; (void)hl; (void)hh; (void)coef; (void)W;
         if (rowok) {
             store_sym_row<M>(q.sym + L.base0 + cy * L.sw + cx0, slh, nR);     // scan position = base + cy * sw + cx
             if (hasB) {
@@ -252,6 +281,18 @@ static __device__ __forceinline__ void haar_fwd_patch_q(const int (&in)[N][N], i
             }
         }
     }
+};
+template <int N, int HZL>
+static __device__ __forceinline__ void haar_fwd_patch_q(const int (&in)[N][N], int (&out)[N / 2][N / 2],
+                                                        int cx0, int cy0, int ws, int hs, int W,
+                                                        int wo, int ho, int32_t *__restrict__ coef, bool scaled,
+                                                        const QCtx &q)
+{
+    (void)W; (void)coef;
+    HaarQ<N, HZL> hq;
+    hq.init(q, cx0, cy0, ws, hs, wo, ho);
+#pragma unroll
+    for (int j = 0; j < N / 2; j++) hq.rows(q, j, in[2 * j], in[2 * j + 1], out[j], scaled);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -321,8 +362,126 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
 // --------------------------------------------------------------------------------------------
 struct __attribute__((aligned(4))) U4A4 { unsigned x, y, z, w; };     // 16 bytes at a dword-aligned address
 
+#define MCB(lo, mi, hi, m) ((int)((((m) < 4 ? (lo) : ((m) < 8 ? (mi) : (hi))) >> (8 * ((m) & 3))) & 0xff))
+static __device__ __forceinline__ void mc_pack8(const int (&pv)[8], unsigned &plo, unsigned &phi)
+{
+    plo = (unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24);
+    phi = (unsigned)pv[4] | ((unsigned)pv[5] << 8) | ((unsigned)pv[6] << 16) | ((unsigned)pv[7] << 24);
+}
+// Luma prediction of one 8x8 patch, gr = &reference(wx-1, wy-1).  AX / AY: some lane of the wave has a horizontal /
+// vertical half-pel phase (wave-uniform, so whole stages drop out for waves that do not need them); xh / yh: this lane's.
+template <bool AX, bool AY, typename EMIT>
+static __device__ __forceinline__ void mc_luma_patch(const uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
+{
+    const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
+    const uint8_t *ga = gr - shb;
+    if (!AY) {
+        // rows wy .. wy+7 only: copy, or the horizontal filter rounded on its own ((t + 8) >> 4)
+        U4A4 rw[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) rw[r] = *reinterpret_cast<const U4A4 *>(ga + (long)(r + 1) * stride);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const unsigned lo = __builtin_amdgcn_alignbyte(rw[r].y, rw[r].x, shb), mi = __builtin_amdgcn_alignbyte(rw[r].z, rw[r].y, shb),
+                           hi = __builtin_amdgcn_alignbyte(rw[r].w, rw[r].z, shb);
+            if (!AX) {
+                emit(r, __builtin_amdgcn_alignbyte(mi, lo, 1u), __builtin_amdgcn_alignbyte(hi, mi, 1u));              // bytes 1..8
+            } else {
+                int bq[11], pv[8];
+#pragma unroll
+                for (int m = 0; m < 11; m++) bq[m] = MCB(lo, mi, hi, m);
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int t = (9 * (bq[i + 1] + bq[i + 2]) - (bq[i] + bq[i + 3]) + 8) >> 4;
+                    pv[i] = xh ? d_sat8(t) : bq[i + 1];
+                }
+                unsigned pl, ph_;
+                mc_pack8(pv, pl, ph_);
+                emit(r, pl, ph_);
+            }
+        }
+    } else {
+        // all phases in one body: H = xh ? 9(b+c)-(a+d) : 16 b on rows wy-1 .. wy+9, V = yh ? 9(H1+H2)-(H0+H3) : 16 H1
+        U4A4 rw[11];
+#pragma unroll
+        for (int k = 0; k < 11; k++) rw[k] = *reinterpret_cast<const U4A4 *>(ga + (long)k * stride);
+        __builtin_amdgcn_sched_barrier(0);
+        int Hq[4][8];
+#pragma unroll
+        for (int k = 0; k < 11; k++) {
+            const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), mi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
+                           hi = __builtin_amdgcn_alignbyte(rw[k].w, rw[k].z, shb);
+            int bq[11];
+#pragma unroll
+            for (int m = 0; m < 11; m++) bq[m] = MCB(lo, mi, hi, m);
+#pragma unroll
+            for (int i = 0; i < 8; i++) Hq[k & 3][i] = (AX && xh) ? 9 * (bq[i + 1] + bq[i + 2]) - (bq[i] + bq[i + 3]) : 16 * bq[i + 1];
+            if (k >= 3) {
+                const int r = k - 3;
+                int pv[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const int h0 = Hq[r & 3][i], h1 = Hq[(r + 1) & 3][i], h2 = Hq[(r + 2) & 3][i], h3 = Hq[(r + 3) & 3][i];
+                    const int v = yh ? 9 * (h1 + h2) - (h0 + h3) : 16 * h1;
+                    pv[i] = d_sat8((v + 128) >> 8);
+                }
+                unsigned pl, ph_;
+                mc_pack8(pv, pl, ph_);
+                emit(r, pl, ph_);
+            }
+        }
+    }
+}
+// Chroma prediction of one 8x8 patch, gr = &reference(wx-1, wy-1).  ANY: some lane of the wave has a half-pel phase.
+// Bytes wx .. wx+8 of a row: 9 + misalignment <= 12, three dwords.
+struct __attribute__((aligned(4))) U3A4 { unsigned x, y, z; };
+template <bool ANY, typename EMIT>
+static __device__ __forceinline__ void mc_chroma_patch(const uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
+{
+    const uint8_t *g1 = gr + 1;                                           // reference (wx, wy-1)
+    const unsigned shb = (unsigned)(((uintptr_t)g1) & 3);
+    const uint8_t *ga = g1 - shb;
+    constexpr int NR = ANY ? 9 : 8;
+    U3A4 rw[NR];
+#pragma unroll
+    for (int k = 0; k < NR; k++) rw[k] = *reinterpret_cast<const U3A4 *>(ga + (long)(k + 1) * stride);
+    __builtin_amdgcn_sched_barrier(0);
+    unsigned qlo = 0, qhi = 0, qx = 0;
+#pragma unroll
+    for (int k = 0; k < NR; k++) {
+        // lo / hi = bytes wx .. wx+7, x = byte wx+8 (in its low byte)
+        const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), hi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
+                       x8 = rw[k].z >> (8 * shb);
+        if (!ANY) {
+            emit(k, lo, hi);
+        } else if (k >= 1) {
+            int pv[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const int pa = MCB(qlo, qhi, qx, i), pb = MCB(qlo, qhi, qx, i + 1), pc = MCB(lo, hi, x8, i), pd = MCB(lo, hi, x8, i + 1);
+                const int B = xh ? pb : pa, C = yh ? pc : pa, D = xh ? (yh ? pd : pb) : (yh ? pc : pa);
+                pv[i] = (pa + B + C + D + 2) >> 2;
+            }
+            unsigned pl, ph_;
+            mc_pack8(pv, pl, ph_);
+            emit(k - 1, pl, ph_);
+        }
+        qlo = lo; qhi = hi; qx = x8;
+    }
+}
+
+// four waves per SIMD (128 VGPRs, a few dwords spilled) measured against three without spills: luma the same, chroma 4 % faster
+#ifndef MC_WPE
+#define MC_WPE 4
+#endif
+#if MC_WPE > 0
+#define MC_WPE_ATTR __attribute__((amdgpu_waves_per_eu(MC_WPE)))
+#else
+#define MC_WPE_ATTR
+#endif
 template <int CH>
-__global__ __launch_bounds__(256) void k_fwd_mc_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
+__global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
                                                     const DMV *__restrict__ mvs0)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
@@ -339,10 +498,20 @@ __global__ __launch_bounds__(256) void k_fwd_mc_pix(const JobDev *__restrict__ j
     const int bj = (int)(((float)J + 0.5f) * __builtin_amdgcn_rcpf((float)(bh >> 3)));
     const int nblk = MG.nbh * MG.nbv, blk = bj * MG.nbh + bi;
     const DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
-    const uint8_t *sp = jb.src + g.poff;
     int32_t *coef = jb.coef + g.coff;
+    const int W = g.W, H = g.H;
+    const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
+    QCtx q;
+    const HzPlane &hp = jb.hz[c];
+    q.hp = &hp; q.stable = jb.stable;
+    q.sym = jb.sym + jb.nz_off[c];
+    q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+               (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+    // transform level 1 consumes the residual rows in pairs as they appear: only two of them are alive at a time
+    HaarQ<8, 2> hq1;
+    hq1.init(q, 4 * I, 4 * J, W, H, wo1, ho1);
+    int l1[4][4], ra[2][8];
 
-    int a[8][8];
     if (mv.mode != 0) {
         const uint8_t *px = jb.xf + g.poff;
 #pragma unroll
@@ -352,131 +521,64 @@ __global__ __launch_bounds__(256) void k_fwd_mc_pix(const JobDev *__restrict__ j
             if (y < ph) v = *reinterpret_cast<const uint2 *>(px + (size_t)y * stride + x0);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                a[r][i] = (int)((v.x >> (8 * i)) & 0xff) - 128;
-                a[r][i + 4] = (int)((v.y >> (8 * i)) & 0xff) - 128;
+                ra[r & 1][i] = (int)((v.x >> (8 * i)) & 0xff) - 128;
+                ra[r & 1][i + 4] = (int)((v.y >> (8 * i)) & 0xff) - 128;
             }
+            if (r & 1) hq1.rows(q, r >> 1, ra[0], ra[1], l1[r >> 1], false);
         }
     } else {
+        // the source rows depend on nothing: requested first
+        const uint8_t *sp = jb.src + g.poff;
+        uint2 sw[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) sw[r] = *reinterpret_cast<const uint2 *>(sp + (size_t)min(y0 + r, ph - 1) * stride + x0);
         const int dx = mv.x >> sh, dy = mv.y >> sv;
         const int xb = bi * bw, yb = bj * bh;
         const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
         const int wy = d_clamp(yb + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1) + (y0 - yb);
         const bool xh = dx & 1, yh = dy & 1;
         const uint8_t *gr = jb.ref + g.poff + (long)(wy - 1) * stride + (wx - 1);      // reference (wx-1, wy-1)
-        const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
-        const uint8_t *ga = gr - shb;
+        const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;        // over the lanes that predict
         uint8_t *pp = jb.pred + g.poff;
-        const bool full8 = x0 + 8 <= pw;
-        // all loads first: 11 (luma) / 9 (chroma) reference rows of 16 bytes, 8 source rows of 8
-        constexpr int R0 = CH ? 1 : 0, NR = CH ? 9 : 11;
-        U4A4 rw[NR];
-        uint2 sw[8];
+        const bool inside = x0 + 8 <= pw && y0 + 8 <= ph;
+        // per prediction row: residual clamp(src - pred + 128) - 128 == clamp(src - pred, -128, 127) (subf bmc.c:43-55 +
+        // p2sbc sbt.c:576) into the row registers, the prediction itself to its frame
+        auto emit = [&](int r, unsigned plo, unsigned phi) {
+            int (&row)[8] = ra[r & 1];
 #pragma unroll
-        for (int k = 0; k < NR; k++) rw[k] = *reinterpret_cast<const U4A4 *>(ga + (long)(R0 + k) * stride);
+            for (int i = 0; i < 8; i++) {
+                const int sv_ = (int)(((i < 4 ? sw[r].x : sw[r].y) >> (8 * (i & 3))) & 0xff);
+                const int pv_ = (int)(((i < 4 ? plo : phi) >> (8 * (i & 3))) & 0xff);
+                row[i] = d_clamp(sv_ - pv_, -128, 127);
+            }
+            if (inside) {
+                *reinterpret_cast<uint2 *>(pp + (size_t)(y0 + r) * stride + x0) = make_uint2(plo, phi);
+            } else {
+                // patches on the right / bottom edge: rows past the picture are zero (p2sbc skips them); the column
+                // right after an odd-width picture holds the replicated source edge in the reference's residual frame
+                const int y = y0 + r;
 #pragma unroll
-        for (int r = 0; r < 8; r++) {
-            const int y = min(y0 + r, ph - 1);
-            sw[r] = *reinterpret_cast<const uint2 *>(sp + (size_t)y * stride + x0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-#define RB12(k, m) ((int)(((m) < 4 ? lo##k : ((m) < 8 ? mi##k : hi##k)) >> (8 * ((m) & 3))) & 0xff)
+                for (int i = 0; i < 8; i++) {
+                    if (y >= ph) row[i] = 0;
+                    else if (x0 + i < pw) pp[(size_t)y * stride + x0 + i] = (uint8_t)((i < 4 ? plo : phi) >> (8 * (i & 3)));
+                    else {
+                        const int e = (int)(((i - 1 < 4 ? sw[r].x : sw[r].y) >> (8 * ((i - 1) & 3))) & 0xff);
+                        row[i] = (x0 + i == pw && MG.cw_extra[c] && i > 0) ? e - 128 : 0;
+                    }
+                }
+            }
+            if (r & 1) hq1.rows(q, r >> 1, ra[0], ra[1], l1[r >> 1], false);
+        };
         if (CH == 0) {
-            int Hq[4][8];                                 // rolling window of horizontally filtered rows (x16 scale)
-#pragma unroll
-            for (int k = 0; k < 11; k++) {
-                const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), mi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
-                               hi = __builtin_amdgcn_alignbyte(rw[k].w, rw[k].z, shb);
-                int b[11];
-#pragma unroll
-                for (int m = 0; m < 11; m++) b[m] = (int)(((m < 4 ? lo : (m < 8 ? mi : hi)) >> (8 * (m & 3))) & 0xff);
-#pragma unroll
-                for (int i = 0; i < 8; i++) Hq[k & 3][i] = xh ? 9 * (b[i + 1] + b[i + 2]) - (b[i] + b[i + 3]) : 16 * b[i + 1];
-                if (k >= 3) {
-                    const int r = k - 3, y = y0 + r;
-                    int pv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int h0 = Hq[r & 3][i], h1 = Hq[(r + 1) & 3][i], h2 = Hq[(r + 2) & 3][i], h3 = Hq[(r + 3) & 3][i];
-                        const int v = yh ? 9 * (h1 + h2) - (h0 + h3) : 16 * h1;
-                        pv[i] = d_sat8((v + 128) >> 8);
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int s = (int)(((i < 4 ? sw[r].x : sw[r].y) >> (8 * (i & 3))) & 0xff);
-                        a[r][i] = y < ph ? d_sat8(s - pv[i] + 128) - 128 : 0;
-                    }
-                    if (y < ph) {
-                        if (full8) {
-                            *reinterpret_cast<uint2 *>(pp + (size_t)y * stride + x0) =
-                                make_uint2((unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24),
-                                           (unsigned)pv[4] | ((unsigned)pv[5] << 8) | ((unsigned)pv[6] << 16) | ((unsigned)pv[7] << 24));
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 8; i++) {
-                                if (x0 + i < pw) pp[(size_t)y * stride + x0 + i] = (uint8_t)pv[i];
-                                else {              // beyond the picture: the residual frame holds the replicated source edge there
-                                    const int e = (int)(((i - 1 < 4 ? sw[r].x : sw[r].y) >> (8 * ((i - 1) & 3))) & 0xff);
-                                    a[r][i] = (x0 + i == pw && MG.cw_extra[c] && i > 0) ? e - 128 : 0;
-                                }
-                            }
-                        }
-                    }
-                }
-            }
+            if (any_y) mc_luma_patch<true, true>(gr, stride, xh, yh, emit);
+            else if (any_x) mc_luma_patch<true, false>(gr, stride, xh, yh, emit);
+            else mc_luma_patch<false, false>(gr, stride, xh, yh, emit);
         } else {
-            unsigned plo = 0, pmi = 0, phi = 0;
-#pragma unroll
-            for (int k = 0; k < 9; k++) {
-                const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), mi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
-                               hi = __builtin_amdgcn_alignbyte(rw[k].w, rw[k].z, shb);
-                if (k >= 1) {
-                    const int r = k - 1, y = y0 + r;
-                    int pv[8];
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-#define BY(l_, m_, h_, m) ((int)((((m) < 4 ? (l_) : ((m) < 8 ? (m_) : (h_))) >> (8 * ((m) & 3))) & 0xff))
-                        const int pa = BY(plo, pmi, phi, i + 1), pb = BY(plo, pmi, phi, i + 2), pc = BY(lo, mi, hi, i + 1), pd = BY(lo, mi, hi, i + 2);
-                        const int B = xh ? pb : pa, C = yh ? pc : pa, D = xh ? (yh ? pd : pb) : (yh ? pc : pa);
-                        pv[i] = (pa + B + C + D + 2) >> 2;
-                    }
-#pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const int s = (int)(((i < 4 ? sw[r].x : sw[r].y) >> (8 * (i & 3))) & 0xff);
-                        a[r][i] = y < ph ? d_sat8(s - pv[i] + 128) - 128 : 0;
-                    }
-                    if (y < ph) {
-                        if (full8) {
-                            *reinterpret_cast<uint2 *>(pp + (size_t)y * stride + x0) =
-                                make_uint2((unsigned)pv[0] | ((unsigned)pv[1] << 8) | ((unsigned)pv[2] << 16) | ((unsigned)pv[3] << 24),
-                                           (unsigned)pv[4] | ((unsigned)pv[5] << 8) | ((unsigned)pv[6] << 16) | ((unsigned)pv[7] << 24));
-                        } else {
-#pragma unroll
-                            for (int i = 0; i < 8; i++) {
-                                if (x0 + i < pw) pp[(size_t)y * stride + x0 + i] = (uint8_t)pv[i];
-                                else {
-                                    const int e = (int)(((i - 1 < 4 ? sw[r].x : sw[r].y) >> (8 * ((i - 1) & 3))) & 0xff);
-                                    a[r][i] = (x0 + i == pw && MG.cw_extra[c] && i > 0) ? e - 128 : 0;
-                                }
-                            }
-                        }
-                    }
-                }
-                plo = lo; pmi = mi; phi = hi;
-            }
+            if (any_x || any_y) mc_chroma_patch<true>(gr, stride, xh, yh, emit);
+            else mc_chroma_patch<false>(gr, stride, xh, yh, emit);
         }
-#undef BY
-#undef RB12
     }
-    const int W = g.W, H = g.H;
-    const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
-    int l1[4][4], l2[2][2], l3[1][1];
-    QCtx q;
-    const HzPlane &hp = jb.hz[c];
-    q.hp = &hp; q.stable = jb.stable;
-    q.sym = jb.sym + jb.nz_off[c];
-    q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
-               (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
-    haar_fwd_patch_q<8, 2>(a, l1, 4 * I, 4 * J, W, H, W, wo1, ho1, coef, false, q);
+    int l2[2][2], l3[1][1];
     haar_fwd_patch_q<4, 1>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true, q);
     haar_fwd_patch_q<2, 0>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true, q);
     jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
