@@ -64,6 +64,7 @@ def lib():
         L.dsvg_dev_free.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsvg_dev_upload.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
+        L.dsvg_ctx_code_streams.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_host_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
         L.dsvg_host_free.argtypes = [_C.c_void_p, _C.c_void_p]
@@ -229,6 +230,10 @@ class Batch:
 
     def sync(self):
         _chk(self.L.dsvg_ctx_sync(self.ctx), "dsvg_ctx_sync")
+
+    def code_streams(self, n=0):
+        """set (n >= 1) / query (n = 0) the number of coding streams; returns the previous value"""
+        return self.L.dsvg_ctx_code_streams(self.ctx, n)
 
     def kernel_names(self):
         return [self.L.dsvg_prof_kernel_name(i).decode() for i in range(self.L.dsvg_prof_kernels())]

@@ -12,6 +12,7 @@
 
 #define OPCHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
+#define DSVG_MAX_CODE_STREAMS 4
 struct dsvg_ctx {
     int device = 0;
     hipStream_t st = nullptr;        // residual-coding stream
@@ -20,6 +21,9 @@ struct dsvg_ctx {
     std::vector<hipEvent_t> ev_coded;  // ring: completion of each dsvg_code_pictures call
     std::vector<int> slot_ev;          // out slot -> index into ev_coded of the call that produces it
     long ncalls = 0;
+    hipStream_t stx[DSVG_MAX_CODE_STREAMS] = {};   // further coding streams (a share of the pictures of every frame step each), created on first use
+    hipEvent_t ev_fork = nullptr, ev_join[DSVG_MAX_CODE_STREAMS] = {};
+    int code_streams = 1;
     hipStream_t st_a = nullptr;      // analysis stream (frame load, pyramid, HME): overlaps coding of the previous batch
     int w = 0, h = 0, fmt = 0, bw = 0, bh = 0, nbh = 0, nbv = 0, nblk = 0, levels = 0;
     FrameLayout L[6];
@@ -93,6 +97,11 @@ static void ctx_free(dsvg_ctx *c)
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (c->st_a) (void)hipStreamDestroy(c->st_a);
+    for (int g = 0; g < DSVG_MAX_CODE_STREAMS; g++) {
+        if (c->stx[g]) (void)hipStreamDestroy(c->stx[g]);
+        if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->st_c) (void)hipStreamDestroy(c->st_c);
     if (c->st_h) (void)hipStreamDestroy(c->st_h);
@@ -159,6 +168,9 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         MG.cw_extra[p] = CL.w[p] > c->L[0].w[p];
     }
     c->mc_fused = mc_fusable(MG) && !getenv("DSV1_NO_MC_FUSION");
+    // two coding streams by default: with the analysis and fetch streams that is four, the number of hardware queues
+    // the runtime maps streams onto (three coding streams measured 18.5 ms per step against 14.3 with two and 15.4 with one)
+    { const char *e = getenv("DSV1_CODE_STREAMS"); c->code_streams = e ? atoi(e) : 2; }
     // per-plane scan bookkeeping
     size_t nzo = 0, bo = 0; int cho = 0;
     for (int p = 0; p < 3; p++) {
@@ -244,12 +256,20 @@ extern "C" int dsvg_ctx_sync(dsvg_ctx *c)
     if (!c) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     if (c->st_h) HIPCHK(hipStreamSynchronize(c->st_h));
+    for (int g = 1; g < DSVG_MAX_CODE_STREAMS; g++) if (c->stx[g]) HIPCHK(hipStreamSynchronize(c->stx[g]));
     HIPCHK(hipStreamSynchronize(c->st_a));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipStreamSynchronize(c->st_c));
     c->calls_since_sync = 0;
     HIPCHK(hipGetLastError());
     return DSVG_OK;
+}
+extern "C" int dsvg_ctx_code_streams(dsvg_ctx *c, int n)
+{
+    if (!c) return DSVG_ERR_ARG;
+    const int old = c->code_streams;
+    if (n >= 1) c->code_streams = std::min(n, DSVG_MAX_CODE_STREAMS);
+    return old;
 }
 extern "C" void *dsvg_ctx_stream(dsvg_ctx *c) { return c ? (void *)c->st : nullptr; }
 
@@ -491,19 +511,20 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
 
 // enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
-static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0)
+static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, hipStream_t st = nullptr)
 {
+    if (!st) st = c->st;
     const JobDev *jd = c->jobs_d + d0;
-    launch_sbt_tail(c->st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
+    launch_sbt_tail(st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
     if (nI > 0) {
-        launch_inv_sbt(c->st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym);
-        launch_inv_sbt(c->st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym);
+        launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym);
+        launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym);
     }
     if (n > nI) {
-        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, insym);
-        launch_inv_sbt(c->st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, insym);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, insym);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, insym);
     }
-    launch_extend(c->st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
+    launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
     return DSVG_OK;
 }
 
@@ -531,21 +552,41 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         const int e = c->slot_ev[base + i];
         if (e >= 0) { HIPCHK(hipEventSynchronize(c->ev_coded[e])); break; }
     }
-    std::vector<int> nIs(nsteps), ioff(nsteps, 0), icnt(nsteps, 0);
-    int *il = c->ilist_h + (size_t)base * c->nblk;         // intra blocks of each step's P pictures (mc_fused)
+    // Two coding streams, each with half of the pictures of every frame step: the chain of a step has a dozen small,
+    // latency-bound kernels (levels >= 4, LL quantiser, scan) during which one half leaves the chip to the other
+    // half's large kernels.  Needs steps of one picture type (the device order is I jobs, then P jobs) and enough jobs.
+    std::vector<int> nIs(nsteps);
+    for (int t = 0; t < nsteps; t++) {
+        int nI = 0;
+        for (int i = 0; i < njobs; i++) nI += jobs[(size_t)t * njobs + i].ref_recon_slot < 0;
+        nIs[t] = nI;
+    }
+    int NG = std::min(std::min(c->code_streams, DSVG_MAX_CODE_STREAMS), njobs / 8);
+    if (NG < 1) NG = 1;
+    bool anyP = false;
+    for (int t = 0; t < nsteps; t++) {
+        if (nIs[t] != 0 && nIs[t] != njobs) NG = 1;
+        anyP = anyP || nIs[t] == 0;
+    }
+    if (!anyP) NG = 1;               // I pictures only: their kernels are large and gain nothing (intra-only measured 3 % slower split)
+    int gk[DSVG_MAX_CODE_STREAMS + 1];                        // device jobs [gk[g], gk[g+1]) of every step -> stream g
+    for (int g = 0; g <= NG; g++) gk[g] = (int)((long)njobs * g / NG);
+    std::vector<int> ioff((size_t)NG * nsteps, 0), icnt((size_t)NG * nsteps, 0);
+    int *il = c->ilist_h + (size_t)base * c->nblk;         // intra blocks of each (step, group)'s P pictures (mc_fused)
     int iln = 0;
     for (int t = 0; t < nsteps; t++) {
-        ioff[t] = iln;
         const dsvg_pic_job *js = jobs + (size_t)t * njobs;
         // device order inside a step: intra jobs first, then inter jobs (kernels are specialised per type)
         std::vector<int> order;
         for (int i = 0; i < njobs; i++) if (js[i].ref_recon_slot < 0) order.push_back(i);
-        nIs[t] = (int)order.size();
         for (int i = 0; i < njobs; i++) if (js[i].ref_recon_slot >= 0) order.push_back(i);
         for (int k = 0; k < njobs; k++) {
             const dsvg_pic_job &j = js[order[k]];
             const int isP = j.ref_recon_slot >= 0;
             const int d = base + t * njobs + k;
+            int g = 0;
+            while (k >= gk[g + 1]) g++;
+            if (k == gk[g]) ioff[NG * t + g] = iln;
             if (j.src_slot < 0 || j.src_slot >= c->n_src || j.ref_recon_slot >= c->n_recon || j.recon_slot >= c->n_recon ||
                 j.out_slot < base || j.out_slot >= base + total || !j.stable_blocks || (isP && !j.mvs)) {
                 dsvg_set_error("bad picture job (step %d job %d)", t, order[k]); return DSVG_ERR_ARG;
@@ -562,43 +603,65 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             memcpy(c->stable_h + (size_t)d * c->nblk, j.stable_blocks, (size_t)c->nblk);
             if (isP) memcpy(c->mv_h + (size_t)d * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
             if (isP && c->mc_fused && !j.no_intra_blocks) {
+                // index relative to the first P job of the group's launch
+                const int k0 = std::max(gk[g], nIs[t]);
                 const DMV *mv = reinterpret_cast<const DMV *>(j.mvs);
                 for (int b = 0; b < c->nblk; b++)
-                    if (mv[b].mode != 0) il[iln++] = (k - nIs[t]) * c->nblk + b;      // index relative to the step's first P job
+                    if (mv[b].mode != 0) il[iln++] = (k - k0) * c->nblk + b;
             }
+            icnt[NG * t + g] = iln - ioff[NG * t + g];
         }
-        icnt[t] = iln - ioff[t];
     }
     if (iln) HIPCHK(hipMemcpyAsync(c->ilist_d + (size_t)base * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs + (size_t)base * c->nblk, c->mv_h + (size_t)base * c->nblk, (size_t)c->nblk * total * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots + base, c->slots_h + base, sizeof(int) * total, hipMemcpyHostToDevice, c->st));
-    for (int t = 0; t < nsteps; t++) {
-        const int d0 = base + t * njobs, nI = nIs[t];
-        const JobDev *jd = c->jobs_d + d0;
-        if (nI > 0) {
-            launch_fwd_sbt(c->st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0, 1);
-            launch_fwd_sbt(c->st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0, 1);
-        }
-        if (njobs > nI) {
-            const int nP = njobs - nI;
-            const DMV *mv0 = c->mvs + (size_t)(d0 + nI) * c->nblk;
-            if (c->mc_fused) {
-                // inter blocks are predicted inside the forward transform; k_mc only serves the intra blocks (block means)
-                if (icnt[t]) launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof, mv0, c->ilist_d + (size_t)base * c->nblk + ioff[t], icnt[t]);
-                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
-                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
-            } else {
-                launch_mc(c->st, jd + nI, nP, c->MG, 1, &c->prof, mv0);
-                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
-                launch_fwd_sbt(c->st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
+    if (NG > 1) {
+        if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+        HIPCHK(hipEventRecord(c->ev_fork, c->st));            // tables uploaded, source frames ready (st waited for ev_a)
+        for (int g = 1; g < NG; g++) {
+            if (!c->stx[g]) {
+                HIPCHK(hipStreamCreate(&c->stx[g]));
+                HIPCHK(hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
             }
+            HIPCHK(hipStreamWaitEvent(c->stx[g], c->ev_fork, 0));
         }
-        launch_sbt_tail(c->st, jd, njobs, c->G, 0, 3, 0, &c->prof);
-        launch_hz_encode(c->st, jd, njobs, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
-                         (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
-        OPCHK(enqueue_recon(c, nI, njobs, d0, 1));      // P pictures: straight from the symbol planes
+    }
+    for (int t = 0; t < nsteps; t++) {
+        for (int g = 0; g < NG; g++) {
+            hipStream_t st = g ? c->stx[g] : c->st;
+            const int k0 = gk[g], n = gk[g + 1] - gk[g];                                // device jobs [k0, k0 + n) of the step
+            const int d0 = base + t * njobs + k0;
+            const int nI = std::min(std::max(nIs[t] - k0, 0), n);                       // I jobs among them come first
+            const JobDev *jd = c->jobs_d + d0;
+            if (nI > 0) {
+                launch_fwd_sbt(st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0, 1);
+                launch_fwd_sbt(st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0, 1);
+            }
+            if (n > nI) {
+                const int nP = n - nI;
+                const DMV *mv0 = c->mvs + (size_t)(d0 + nI) * c->nblk;
+                if (c->mc_fused) {
+                    // inter blocks are predicted inside the forward transform; k_mc only serves the intra blocks (block means)
+                    if (icnt[NG * t + g]) launch_mc(st, jd + nI, nP, c->MG, 1, &c->prof, mv0, c->ilist_d + (size_t)base * c->nblk + ioff[NG * t + g], icnt[NG * t + g]);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
+                } else {
+                    launch_mc(st, jd + nI, nP, c->MG, 1, &c->prof, mv0);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
+                }
+            }
+            launch_sbt_tail(st, jd, n, c->G, 0, 3, 0, &c->prof);
+            launch_hz_encode(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
+                             (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
+            OPCHK(enqueue_recon(c, nI, n, d0, 1, st));      // P pictures: straight from the symbol planes
+        }
+    }
+    for (int g = 1; g < NG; g++) {
+        HIPCHK(hipEventRecord(c->ev_join[g], c->stx[g]));
+        HIPCHK(hipStreamWaitEvent(c->st, c->ev_join[g], 0));
     }
     {   // completion marker of this call; fetch waits on it from its own stream
         const int e = (int)(call % (long)c->ev_coded.size());

@@ -108,6 +108,10 @@ int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsa
 void dsvg_ctx_destroy(dsvg_ctx *ctx);
 int dsvg_ctx_geom(const dsvg_ctx *ctx, dsvg_geom *g);
 int dsvg_ctx_sync(dsvg_ctx *ctx);
+/* Coding streams: dsvg_code_batch shares the pictures of every frame step out over n HIP streams (default 2, or
+ * DSV1_CODE_STREAMS), so one group's small latency-bound kernels run under another group's large ones.  n >= 1 sets
+ * it (takes effect at the next batch), n = 0 only queries; returns the previous value. */
+int dsvg_ctx_code_streams(dsvg_ctx *ctx, int n);
 void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the hipStream_t all pipeline work is enqueued on */
 
 /* device memory helpers for callers that keep the raw clip in HBM (bench.py) */

@@ -283,3 +283,20 @@ def test_batched_decoder_matches_oracle(pkg, orc, geom, on_device):
         assert fnums[s] == list(range(nfr[s]))
         for t in range(nfr[s]):
             A.assert_same("stream %d frame %d" % (s, t), got[s][t], want[s][t])
+
+
+@pytest.mark.parametrize("nstreams_code", [1, 2, 3])
+def test_several_coding_streams_bit_exact(pkg, orc, nstreams_code, monkeypatch):
+    """DSV1_CODE_STREAMS: the pictures of every frame step are shared out over several HIP streams (each group runs
+    the whole chain on its own).  24 GOP streams with different content -- flat objects force intra blocks, so every
+    group has its own intra-block list; style 0 streams have none -- must give the bytes of the one-stream path."""
+    monkeypatch.setenv("DSV1_CODE_STREAMS", str(nstreams_code))
+    w, h, fmt, gop, S = 352, 288, A.SUBSAMP_420, 5, 24
+    clips = np.stack([A.gen_clip(w, h, fmt, 0x5C00 + s, gop, style=(s % 3)) for s in range(S)])
+    cfg = pkg.make_encoder_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1)
+    b = pkg.Batch(cfg, S, gop)          # the context reads the variable when it is created
+    got = b.encode(clips)
+    b.close()
+    for s in range(S):
+        want, _ = A.orc_encode(clips[s], A.orc_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1), eos=False)
+        assert got[s] == want, "stream %d: %s" % (s, explain(got[s], want))
