@@ -558,6 +558,38 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
 #pragma unroll
         for (int k = 0; k < 8; k++) cs[k] = 0;
         const int ndw = (cbw + 3) >> 2;
+        const uint8_t *fbs = A.slab[0] + (size_t)cur * L0.pitch, *fbr = A.slab[0] + (size_t)rf * L0.pitch;
+        const bool aligned = (((unsigned)L0.off[1] | (unsigned)L0.off[2] | (unsigned)L0.stride[1] | (unsigned)L0.stride[2] | (unsigned)cbx |
+                               (unsigned)(uintptr_t)fbs | (unsigned)(uintptr_t)fbr) & 3u) == 0;
+        if (aligned && ndw * cbh <= 4 * NT) {
+            // the usual case (block origins are multiples of 4 in the chroma planes): one aligned dword per item and
+            // plane, all of a lane's loads in flight together -- one memory round trip for the whole test
+            unsigned cw4[4][4], cm[4];
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+                const int q = tid + it * NT;
+                const bool ok = q < ndw * cbh;
+                const int y = ok ? q / ndw : 0, xd = ok ? 4 * (q - y * ndw) : 0;
+                const int nb = min(4, cbw - xd);
+                cm[it] = !ok ? 0u : (nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u));
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint8_t *fb = (k & 2) ? fbr : fbs;
+                    const int pl = 1 + (k & 1);
+                    cw4[it][k] = *reinterpret_cast<const unsigned *>(fb + L0.off[pl] + (long)(cby + y) * L0.stride[pl] + cbx + xd);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int it = 0; it < 4; it++)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned w = cw4[it][k] & cm[it];
+                    const int o = (k >> 1) * 4 + (k & 1) * 2;
+                    cs[o] = __builtin_amdgcn_sad_u8(w, 0u, cs[o]);
+                    cs[o + 1] = __builtin_amdgcn_udot4(w, w, cs[o + 1], false);
+                }
+        } else
         for (int q = tid; q < ndw * cbh; q += NT) {
             const int y = q / ndw, xd = 4 * (q - y * ndw);
             const int nb = min(4, cbw - xd);
