@@ -181,6 +181,13 @@ def main():
                  "alg_bytes_per_launch": round(by / max(nl, 1)),
                  "coding_streams": nstreams,
                  "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]}}
+        # the other large kernels, each alone on the chip (same untimed step): algorithmic bytes / HIP-event time
+        oth = []
+        for k, (m_, n_, b_) in sorted(table.items(), key=lambda kv: -kv[1][0]):
+            if k != prof_kernel and n_ and m_ > 0 and b_ > 0 and len(oth) < 6:
+                a_ = b_ / (m_ * 1e-3) / 1e9
+                oth.append({"kernel": k, "achieved": round(a_, 1), "frac": round(a_ / HBM_PEAK_GBS, 4), "avg_launch_us": round(1000.0 * m_ / n_, 2)})
+        kinfo["others_exclusive"] = oth
         if prof_kernel in table and table[prof_kernel][0] > 0:
             xm, xn, xb = table[prof_kernel]         # the same kernel alone on the chip (one coding stream, untimed step)
             xa = xb / (xm * 1e-3) / 1e9
