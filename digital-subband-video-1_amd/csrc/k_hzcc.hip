@@ -261,6 +261,9 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
     for (int k = 0; k < 4; k++) {
         const int p0 = cbase + k * 512 + 8 * lane;
         const uint4 rw = raw[k];
+        // most rounds of a P picture hold no symbol at all: one OR and a ballot decide that before anything is unpacked
+        // (cells past the end of the scan sit in the zero padding of the plane or are masked below)
+        if (__ballot((rw.x | rw.y | rw.z | rw.w) != 0u) == 0ull) continue;
         int v[8];
         v[0] = (int16_t)(rw.x & 0xffff); v[1] = (int)rw.x >> 16; v[2] = (int16_t)(rw.y & 0xffff); v[3] = (int)rw.y >> 16;
         v[4] = (int16_t)(rw.z & 0xffff); v[5] = (int)rw.z >> 16; v[6] = (int16_t)(rw.w & 0xffff); v[7] = (int)rw.w >> 16;
