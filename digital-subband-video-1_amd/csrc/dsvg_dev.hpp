@@ -111,6 +111,7 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     int dec_cnt[3];          // decoder: number of (position,value) pairs per plane (written by k_hz_parse)
     int dec_runs[3], dec_len[3], dec_dc[3];   // decoder: run count / byte length / DC of the plane header (host)
     long long dec_bitpos[3]; // decoder: bit offset of the first code inside the uploaded payload
+    uint8_t *nzf;            // encoder P pictures: flag byte per 4 scan positions (set by the forward transform where a symbol is non-zero, cleared by k_hz_collect); null = none
     HzParseChunk *dec_meta[3];   // decoder: per 128-bit payload chunk, what k_hz_parse found (>= dec_len/16 + 2 entries)
     long long dec_s0[3];         // decoder: first bit of the alternating code chain (k_hz_parse)
     int dec_npass[3], dec_ncode[3], dec_first_bad[3];   // decoder: passes done / codes seen (k_hz_parse), first entry past the data (k_hz_codes)

@@ -35,6 +35,7 @@ struct dsvg_ctx {
     Slab src[6], recon, xf, pred;
     int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *s5 = nullptr, *nzpos = nullptr, *nzval = nullptr;
     HzChunkSum *chunks = nullptr;
+    uint8_t *nzf = nullptr;          // per work job: flag byte per 4 scan positions (non-zero symbols of P pictures)
     int16_t *sym = nullptr;          // fused quantiser: per work job, scan-order symbol planes (same indexing as nzpos)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
@@ -91,7 +92,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -208,6 +209,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->sym, c->nz_total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->nzf, (c->nz_total >> 2) * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
@@ -594,6 +596,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             JobDev &jb = c->jobs_h[d];
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
+            jb.nzf = isP ? c->nzf + (size_t)k * (c->nz_total >> 2) : nullptr;   // P: non-zero flags for k_hz_collect
             jb.psum = c->psum + (size_t)j.out_slot * 3;
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;

@@ -247,11 +247,33 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
     const unsigned long long ltmask = (1ull << lane) - 1ull;
 
     uint4 raw[4];
+    if (jb.nzf) {
+        // P pictures: the forward transform flagged every group of four cells that holds a non-zero symbol -- two flag
+        // bytes per lane and round instead of sixteen symbol bytes; symbols are fetched only where a flag is up, and
+        // the flags are taken down again for the next picture
+        uint8_t *nzf = jb.nzf + (jb.nz_off[c] >> 2);
+        unsigned short fl[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p0 = cbase + k * 512 + 8 * lane;
+            fl[k] = p0 < nscan ? *reinterpret_cast<const unsigned short *>(nzf + (p0 >> 2)) : (unsigned short)0;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p0 = cbase + k * 512 + 8 * lane;
+            raw[k] = make_uint4(0, 0, 0, 0);
+            if (fl[k]) {
+                raw[k] = *reinterpret_cast<const uint4 *>(sym + p0);
+                *reinterpret_cast<unsigned short *>(nzf + (p0 >> 2)) = 0;
+            }
+        }
+    } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int p0 = cbase + k * 512 + 8 * lane;
         raw[k] = make_uint4(0, 0, 0, 0);
         if (p0 < nscan) raw[k] = *reinterpret_cast<const uint4 *>(sym + p0);   // the planes are padded to whole chunks
+    }
     }
     int run = 0;                    // entries written so far
     int cpos = -1, cval = 0;        // last entry so far (wave-uniform)

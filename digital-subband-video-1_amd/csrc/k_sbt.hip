@@ -57,7 +57,23 @@ struct QCtx {
     const uint8_t *stable;
     int16_t *sym;
     bool any_ov;
+    // P pictures of the encoder: one flag byte per four scan positions, set wherever a non-zero symbol is written, so
+    // that k_hz_collect reads 1/8 of the bytes to find the few non-zeros of a P picture (null: no flags kept)
+    uint8_t *nzf = nullptr;
 };
+// flag the non-zero cells of one stored symbol row (plain conditional byte stores: rare, and nothing waits for them)
+template <int M>
+static __device__ __forceinline__ void nz_flag_row(const QCtx &q, int pos0, const int (&v)[M], int n)
+{
+    int any = 0;
+#pragma unroll
+    for (int i = 0; i < M; i++) any |= i < n ? v[i] : 0;
+    if (any) {
+#pragma unroll
+        for (int i = 0; i < M; i++)
+            if (i < n && v[i] != 0) q.nzf[(pos0 + i) >> 2] = 1;
+    }
+}
 // wave-uniform constants of one scan level: its LH/HL/HH regions differ only in origin and scan base
 struct QLevel {
     int qp;                // levels 0,1: quantiser max(qp >> class, 16), class {none, stable, flag&2} (tmq4pos hzcc.c:64-74)
@@ -131,6 +147,7 @@ static __device__ int q_chain(const QCtx &q, int l, int gx, int gy, int val)
     const int etq = hz_cell_tq(e, q.stable, hp.nbh, ex, ey);
     const int ev = hz_quant_any(e, val, etq);
     q.sym[e.base + ey * e.sw + ex] = (int16_t)ev;
+    if (q.nzf && ev) q.nzf[(e.base + ey * e.sw + ex) >> 2] = 1;
     return ev ? hz_dequant_any(e, ev, etq) : 0;
 }
 template <int M>
@@ -279,6 +296,20 @@ struct HaarQ {
                 store_sym_row<M>(q.sym + L.base1 + cy * L.sw + cx0, shl, nC);
                 store_sym_row<M>(q.sym + L.base2 + cy * L.sw + cx0, shh, nR);
             }
+            if (q.nzf) {
+                int any = 0;                    // one test for the three bands (cells that are not stored only cost a look)
+#pragma unroll
+                for (int i = 0; i < M; i++) any |= slh[i] | shl[i] | shh[i];
+                if (any) {
+                    const int pr = cy * L.sw + cx0;
+#pragma unroll
+                    for (int i = 0; i < M; i++) {
+                        if (i < nR && slh[i] != 0) q.nzf[(L.base0 + pr + i) >> 2] = 1;
+                        if (hasB && i < nC && shl[i] != 0) q.nzf[(L.base1 + pr + i) >> 2] = 1;
+                        if (hasB && i < nR && shh[i] != 0) q.nzf[(L.base2 + pr + i) >> 2] = 1;
+                    }
+                }
+            }
         }
     }
 };
@@ -332,6 +363,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
         q.sym = jb.sym + jb.nz_off[c];
         q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                    (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+        q.nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
     }
     // transform level 1,2,3 <-> scan level 2,1,0
     if (Q) {
@@ -507,6 +539,7 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
     q.sym = jb.sym + jb.nz_off[c];
     q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+    q.nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
     // transform level 1 consumes the residual rows in pairs as they appear: only two of them are alive at a time
     HaarQ<8, 2> hq1;
     hq1.init(q, 4 * I, 4 * J, W, H, wo1, ho1);
