@@ -228,15 +228,17 @@ def main():
     if rank == 0:
         ncpu = min(args.cpu_gops, nd)
         if ncpu > 0:
-            # fresh GPU streams for the same GOP clips with the same frame numbers as the CPU run
-            chk = pkg.Batch(cfg, ncpu, GOP, device=dev)
-            for s in range(ncpu):
-                chk.set_fnum(s, s * GOP)
-            gpu_streams = chk.encode(distinct[:ncpu])
+            # fresh GPU streams for the same GOP clips with the same frame numbers as the CPU run -- 16 of them (every
+            # clip several times) so that the check goes through the same two-coding-stream path as the timed region
+            nchk = max(16, ncpu)
+            chk = pkg.Batch(cfg, nchk, GOP, device=dev)
+            for s in range(nchk):
+                chk.set_fnum(s, (s % ncpu) * GOP)
+            gpu_streams = chk.encode(np.stack([distinct[s % ncpu] for s in range(nchk)]))
             chk.close()
             # the timed CPU sample is reported at N=1 only; at N>1 one pass still serves as the parity spot check
             cpu, cpu_streams = cpu_baseline(distinct[:ncpu], pkg, A, reps=max(1, args.cpu_gops // ncpu) if world == 1 else 1)
-            bit_exact = all(a == c for a, c in zip(gpu_streams, cpu_streams))
+            bit_exact = all(gpu_streams[s] == cpu_streams[s % ncpu] for s in range(nchk))
             if world > 1:
                 cpu = None
         out_bytes = sum(len(o) for o in outs)
