@@ -300,3 +300,18 @@ def test_several_coding_streams_bit_exact(pkg, orc, nstreams_code, monkeypatch):
     for s in range(S):
         want, _ = A.orc_encode(clips[s], A.orc_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1), eos=False)
         assert got[s] == want, "stream %d: %s" % (s, explain(got[s], want))
+
+
+def test_1080p_two_coding_streams_bit_exact(pkg, orc):
+    """the default two coding streams at the bench shape: 16 streams (two clips, eight times each) of 1080p, one I and
+    three P pictures: both halves must give the oracle's bytes"""
+    w, h, fmt, gop, S = 1920, 1080, A.SUBSAMP_420, 4, 16
+    two = [A.gen_clip(w, h, fmt, 0x10800003 + 31 * k, gop, style=k) for k in range(2)]
+    want = [A.orc_encode(two[k], A.orc_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1), eos=False)[0] for k in range(2)]
+    cfg = pkg.make_encoder_cfg(w, h, fmt, qp=85, gop=gop, rc_mode_cli=1)
+    b = pkg.Batch(cfg, S, gop)
+    assert b.code_streams(0) == 2
+    got = b.encode(np.stack([two[s & 1] for s in range(S)]))
+    b.close()
+    for s in range(S):
+        assert got[s] == want[s & 1], "stream %d: %s" % (s, explain(got[s], want[s & 1]))
