@@ -710,7 +710,9 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
     for (int level = A.levels; level >= 0; level--) {
         const int step = 1 << level;
         const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
-        const double px = 2.0 * npairs * (double)A.L[level].w[0] * A.L[level].h[0];     // src + ref luma once
+        double px = 2.0 * npairs * (double)A.L[level].w[0] * A.L[level].h[0];           // src + ref luma once
+        if (level == 0)             // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681)
+            px += 2.0 * npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]);
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
         if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(xcd_grid(nvx * nvy * npairs)), dim3(NT), 0, st, A, level, npairs);
         else           hipLaunchKernelGGL((k_hme_level<true>), dim3(xcd_grid(nvx * nvy * npairs)), dim3(NT), 0, st, A, level, npairs);
