@@ -78,7 +78,7 @@ def main():
     ap.add_argument("--gops", type=int, default=96, help="closed GOPs per GPU per step (64: 106, 96: 114, 128: 115 Gpix/s on one box)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
-    ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events")
+    ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events (auto = the largest; none = no brackets, no roofline: counter passes)")
     ap.add_argument("--input", choices=["hbm", "host", "pinned"], default="hbm",
                     help="where the raw frames are when a step starts: hbm (the metric), or host memory (pageable / pinned) "
                          "uploaded over PCIe inside the timed region (diagnostic, DESIGN.md section 7)")
@@ -147,7 +147,7 @@ def main():
     table = {}
     prof_kernel = args.prof_kernel
     nstreams = b.code_streams(0)
-    if rank == 0:
+    if rank == 0 and prof_kernel != "none":     # "none": no event brackets at all (the counter passes of tools/collect_profiles.sh)
         b.code_streams(1)
         b.prof_enable(names)
         b.encode(src, on_device=ondev)
@@ -171,7 +171,7 @@ def main():
     dt = time.perf_counter() - t0
     b.collect(copy=False)                           # drain
     kinfo = None
-    if rank == 0:
+    if rank == 0 and prof_kernel != "none":
         ms, nl, by = b.prof_get(prof_kernel)
         b.prof_enable([])
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
