@@ -213,6 +213,11 @@ def main():
                 vi = e["valu_insts_per_launch"] * args.gops / T["gops"]
                 kinfo["valu_issue"] = {"wave_instr_per_launch": round(vi), "busy_frac": round(vi * 4.0 / (1024 * 2.4e9 * (ms * 1e-3 / max(nl, 1))), 3),
                                        "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json"}
+                if prof_kernel in table and table[prof_kernel][0] > 0:
+                    # the same instructions against the time the kernel needs alone on the chip (one step of the untimed
+                    # selection pass): what bounds the kernel itself, without the other coding stream's share
+                    per_step = vi * nl / (args.steps + 1)          # the brackets also cover the batch that fills the pipeline
+                    kinfo["valu_issue"]["busy_frac_exclusive"] = round(per_step * 4.0 / (1024 * 2.4e9 * table[prof_kernel][0] * 1e-3), 3)
 
     tmax = dt
     if world > 1:
