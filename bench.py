@@ -264,7 +264,8 @@ def main():
                        % (args.gops, {"hbm": "raw frames resident in HBM", "host": "raw frames uploaded from pageable host memory each step (PCIe inclusive, diagnostic)",
                                       "pinned": "raw frames uploaded from pinned host memory each step (PCIe inclusive, diagnostic)"}[args.input]),
                        "gops_per_gpu": args.gops, "frames_per_step": args.gops * GOP * world,
-                       "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world},
+                       "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world,
+                       "streams_on_own_hw_queue": L.dsvg_ctx_streams_apart(b.ctx)},
             "bit_exact_vs_cpu": bit_exact,
             "roofline": kinfo,
             "cpu_baseline": cpu,

@@ -65,6 +65,7 @@ def lib():
         L.dsvg_dev_upload.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
         L.dsvg_ctx_code_streams.argtypes = [_C.c_void_p, _C.c_int]
+        L.dsvg_ctx_streams_apart.argtypes = [_C.c_void_p]
         L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_host_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
         L.dsvg_host_free.argtypes = [_C.c_void_p, _C.c_void_p]

@@ -13,6 +13,60 @@
 #define OPCHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
 #define DSVG_MAX_CODE_STREAMS 4
+
+// ---- stream placement ------------------------------------------------------------------------------------------
+// The runtime maps HIP streams onto a handful of hardware queues (4 by default), least-loaded first, counting every
+// stream the process has -- the framework's, the communication library's.  Two of OUR busy streams on one queue run
+// one after the other (measured: -15 % with one unrelated extra stream in the process, none with two).  So the streams
+// are not taken as they come: candidates are created and probed pairwise with a 100 us spin kernel each -- both done
+// after ~100 us means different queues -- and a set of mutually concurrent ones is kept.
+__global__ void k_spin(long long ticks)
+{
+    const long long t0 = wall_clock64();                   // constant 100 MHz counter
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t e0, hipEvent_t ea, hipEvent_t eb)
+{
+    const long long T = 10000;                             // 100 us
+    if (hipEventRecord(e0, a) != hipSuccess || hipStreamWaitEvent(b, e0, 0) != hipSuccess) return true;
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, a, T);
+    hipLaunchKernelGGL(k_spin, dim3(1), dim3(64), 0, b, T);
+    (void)hipEventRecord(ea, a); (void)hipEventRecord(eb, b);
+    (void)hipEventSynchronize(ea); (void)hipEventSynchronize(eb);
+    float ta = 0, tb = 0;
+    if (hipEventElapsedTime(&ta, e0, ea) != hipSuccess || hipEventElapsedTime(&tb, e0, eb) != hipSuccess) return true;
+    return std::max(ta, tb) < 0.165f;                      // serialised: the later one ends after >= 200 us
+}
+// `want` streams that run concurrently with each other (as many as can be found among 12 candidates; the rest in
+// creation order); returns the number of mutually concurrent ones at the front of out[]
+static int pick_streams(hipStream_t *out, int want)
+{
+    const int NC = 12;
+    hipStream_t cand[NC] = {};
+    int nc = 0;
+    for (; nc < NC; nc++) if (hipStreamCreate(&cand[nc]) != hipSuccess) break;
+    if (nc < want) { for (int i = 0; i < nc; i++) (void)hipStreamDestroy(cand[i]); return -1; }
+    hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
+    bool probe = !getenv("DSV1_NO_STREAM_PROBE") && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
+    bool used[NC] = {};
+    int n = 0;
+    if (probe) {
+        (void)streams_concurrent(cand[0], cand[1], e0, ea, eb);          // first launch of the kernel: code load, not timed
+        for (int i = 0; i < nc && n < want; i++) {
+            bool ok = true;
+            for (int k = 0; k < n && ok; k++) ok = streams_concurrent(out[k], cand[i], e0, ea, eb);
+            if (ok) { out[n++] = cand[i]; used[i] = true; }
+        }
+    }
+    const int good = n;
+    for (int i = 0; i < nc && n < want; i++) if (!used[i]) { out[n++] = cand[i]; used[i] = true; }
+    for (int i = 0; i < nc; i++) if (!used[i]) (void)hipStreamDestroy(cand[i]);
+    if (e0) (void)hipEventDestroy(e0);
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    return good;
+}
+
 struct dsvg_ctx {
     int device = 0;
     hipStream_t st = nullptr;        // residual-coding stream
@@ -24,6 +78,7 @@ struct dsvg_ctx {
     hipStream_t stx[DSVG_MAX_CODE_STREAMS] = {};   // further coding streams (a share of the pictures of every frame step each), created on first use
     hipEvent_t ev_fork = nullptr, ev_join[DSVG_MAX_CODE_STREAMS] = {};
     int code_streams = 1;
+    int streams_apart = 0;           // how many of {coding, analysis, second coding, fetch} were found on hardware queues of their own
     hipStream_t st_a = nullptr;      // analysis stream (frame load, pyramid, HME): overlaps coding of the previous batch
     int w = 0, h = 0, fmt = 0, bw = 0, bh = 0, nbh = 0, nbv = 0, nblk = 0, levels = 0;
     FrameLayout L[6];
@@ -187,9 +242,25 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
 
     int rc = DSVG_OK;
     auto fail = [&](int r) { ctx_free(c); return r; };
-    if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st_a) != hipSuccess) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
+    if (max_jobs >= 16) {
+        // throughput contexts (several coding streams will run): coding, analysis, further coding streams on hardware
+        // queues of their own; the fetch stream (idle most of the time) takes what is left.  The probe costs ~30 ms.
+        const int ncs = std::max(1, std::min(c->code_streams, DSVG_MAX_CODE_STREAMS));
+        hipStream_t ps[3 + DSVG_MAX_CODE_STREAMS] = {};
+        const int want = 2 + std::max(ncs, 2);
+        const int good = pick_streams(ps, want);
+        if (good < 0) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
+        c->st = ps[0]; c->st_a = ps[1];
+        for (int g = 1; g < std::max(ncs, 2); g++) {
+            c->stx[g] = ps[1 + g];
+            if (hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
+        }
+        c->st_c = ps[want - 1];
+        c->streams_apart = good;
+    } else if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st_a) != hipSuccess || hipStreamCreate(&c->st_c) != hipSuccess) {
+        dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP);      // one picture (or a few) at a time: streams as they come
+    }
     if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
-    if (hipStreamCreate(&c->st_c) != hipSuccess) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
     c->ev_coded.resize((size_t)2 * c->nwin + 2);
     for (auto &e : c->ev_coded)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
@@ -273,6 +344,7 @@ extern "C" int dsvg_ctx_code_streams(dsvg_ctx *c, int n)
     if (n >= 1) c->code_streams = std::min(n, DSVG_MAX_CODE_STREAMS);
     return old;
 }
+extern "C" int dsvg_ctx_streams_apart(const dsvg_ctx *c) { return c ? c->streams_apart : 0; }
 extern "C" void *dsvg_ctx_stream(dsvg_ctx *c) { return c ? (void *)c->st : nullptr; }
 
 extern "C" int dsvg_dev_alloc(dsvg_ctx *c, void **dptr, size_t bytes)

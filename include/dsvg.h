@@ -112,6 +112,9 @@ int dsvg_ctx_sync(dsvg_ctx *ctx);
  * DSV1_CODE_STREAMS), so one group's small latency-bound kernels run under another group's large ones.  n >= 1 sets
  * it (takes effect at the next batch), n = 0 only queries; returns the previous value. */
 int dsvg_ctx_code_streams(dsvg_ctx *ctx, int n);
+/* how many of the context's four streams (coding, analysis, second coding, fetch) were placed on hardware queues of
+ * their own by the probe at creation (4 = all apart; 0 = probe switched off with DSV1_NO_STREAM_PROBE) */
+int dsvg_ctx_streams_apart(const dsvg_ctx *ctx);
 void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the hipStream_t all pipeline work is enqueued on */
 
 /* device memory helpers for callers that keep the raw clip in HBM (bench.py) */
