@@ -758,13 +758,14 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < n; i++)
         if (out_slots[i] < 0 || out_slots[i] >= c->out_slots) { dsvg_set_error("out slot out of range"); return DSVG_ERR_ARG; }
-    // wait (on the fetch stream only) for the coding calls that produce these slots -- later batches
-    // already enqueued on the coding stream keep running
+    // wait for the coding calls that produce these slots ON THE HOST (this call blocks for its results anyway) -- later
+    // batches already enqueued on the coding streams keep running, and the fetch stream never holds a pending wait: its
+    // hardware queue may be shared with a busy stream, which a queued wait would stall for the rest of the batch
     {
         std::vector<char> seen(c->ev_coded.size(), 0);
         for (int i = 0; i < n; i++) {
             const int e = c->slot_ev[out_slots[i]];
-            if (e >= 0 && !seen[e]) { seen[e] = 1; HIPCHK(hipStreamWaitEvent(c->st_c, c->ev_coded[e], 0)); }
+            if (e >= 0 && !seen[e]) { seen[e] = 1; HIPCHK(hipEventSynchronize(c->ev_coded[e])); }
         }
     }
     static const bool fprof = getenv("DSV1_HOST_PROF") != nullptr;
