@@ -145,14 +145,25 @@ def main():
     # launch covers half of the pictures and shares the chip with the other half's kernels); take the largest total
     names = b.kernel_names()
     table = {}
+    tiles = None
     prof_kernel = args.prof_kernel
     nstreams = b.code_streams(0)
     if rank == 0 and prof_kernel != "none":     # "none": no event brackets at all (the counter passes of tools/collect_profiles.sh)
         b.code_streams(1)
         b.prof_enable(names)
+        b.tile_stats()
         b.encode(src, on_device=ondev)
         b.sync()
+        tiles = b.tile_stats()
         table = {k: b.prof_get(k) for k in names}
+        # the sparse inverse transform moves data only for tiles that carry a residual: price it at what it really moved
+        # (general tile: 128x64 samples x 4 B = symbols 2 + prediction 1 + reconstruction 1; every tile: its 20x12 LL3
+        # values and patch flags, 5 B each)
+        for kname, tg, tz in (("void k_inv_haar_tile<true, 0, true>", tiles["general_luma"], tiles["zero_luma"]),
+                              ("void k_inv_haar_tile<false, 0, true>", tiles["general_chroma"], tiles["zero_chroma"])):
+            if kname in table and table[kname][1]:
+                m_, n_, _ = table[kname]
+                table[kname] = (m_, n_, tg * 128.0 * 64.0 * 4.0 + (tg + tz) * 240.0 * 5.0)
         if prof_kernel == "auto":
             prof_kernel = max(table, key=lambda k: table[k][0])
         b.code_streams(nstreams)
@@ -180,7 +191,8 @@ def main():
                  "avg_launch_us": round(1000.0 * ms / max(nl, 1), 2),
                  "alg_bytes_per_launch": round(by / max(nl, 1)),
                  "coding_streams": nstreams,
-                 "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]}}
+                 "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]},
+                 "sparse_inverse_tiles_one_step": tiles}
         # the other large kernels, each alone on the chip (same untimed step): algorithmic bytes / HIP-event time
         oth = []
         for k, (m_, n_, b_) in sorted(table.items(), key=lambda kv: -kv[1][0]):

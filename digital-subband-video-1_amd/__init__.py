@@ -66,6 +66,7 @@ def lib():
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
         L.dsvg_ctx_code_streams.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_ctx_streams_apart.argtypes = [_C.c_void_p]
+        L.dsvg_ctx_tile_stats.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
         L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_host_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
         L.dsvg_host_free.argtypes = [_C.c_void_p, _C.c_void_p]
@@ -235,6 +236,13 @@ class Batch:
     def code_streams(self, n=0):
         """set (n >= 1) / query (n = 0) the number of coding streams; returns the previous value"""
         return self.L.dsvg_ctx_code_streams(self.ctx, n)
+
+    def tile_stats(self, reset=True):
+        """inverse-transform tiles of P pictures since the last reset: dict general_luma / general_chroma (computed) and
+        zero_luma / zero_chroma (found empty: reconstruction = prediction).  Syncs."""
+        v = (_C.c_ulonglong * 4)()
+        _chk(self.L.dsvg_ctx_tile_stats(self.ctx, v, 1 if reset else 0), "dsvg_ctx_tile_stats")
+        return {"general_luma": v[0], "general_chroma": v[1], "zero_luma": v[2], "zero_chroma": v[3]}
 
     def kernel_names(self):
         return [self.L.dsvg_prof_kernel_name(i).decode() for i in range(self.L.dsvg_prof_kernels())]

@@ -116,6 +116,13 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     long long dec_s0[3];         // decoder: first bit of the alternating code chain (k_hz_parse)
     int dec_npass[3], dec_ncode[3], dec_first_bad[3];   // decoder: passes done / codes seen (k_hz_parse), first entry past the data (k_hz_codes)
     int16_t *sym;            // fused quantiser: quantised symbol of every detail scan cell, indexed nz_off[c] + scan position
+    // Sparse P pictures of the encoder (nzf != null): the symbol planes are ZERO between pictures.  The forward transform
+    // stores only non-zero symbols (+ nzf, cflag, pflag), the inverse transform skips tiles whose patches carry no flag and
+    // whose LL3 values are zero (reconstruction == prediction), and k_hz_collect -- the last reader -- takes symbols and
+    // flags down again.
+    uint8_t *pflag;          // per plane (offset s3off[c]) and 8x8-pixel patch: 1 = the patch has a non-zero detail symbol (levels 1-3); written for every patch of every picture
+    uint8_t *cflag;          // per scan chunk (chunk_off[c] + chunk): 1 = the chunk holds a non-zero detail symbol; cleared by k_hz_collect
+    unsigned *stat;          // [4] diagnostic counters: inverse tiles on the general path {luma, chroma}, on the zero path {luma, chroma}
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
     HzPlane hz[3];
     int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level

@@ -86,12 +86,17 @@ struct dsvg_ctx {
     SbtGeo3 G;
     McGeo MG;
     bool mc_fused = false;           // P pictures: motion compensation inside the forward transform (k_fwd_mc_pix)
+    bool no_inplace_pred = false;    // DSV1_NO_INPLACE_PRED: always keep the prediction in its own frame (A/B switch)
     int n_src = 0, n_recon = 0, max_jobs = 0, out_slots = 0, nwin = 0, win = 0, calls_since_sync = 0;
     Slab src[6], recon, xf, pred;
     int32_t *coef = nullptr, *s3 = nullptr, *s1 = nullptr, *s5 = nullptr, *nzpos = nullptr, *nzval = nullptr;
     HzChunkSum *chunks = nullptr;
     uint8_t *nzf = nullptr;          // per work job: flag byte per 4 scan positions (non-zero symbols of P pictures)
     int16_t *sym = nullptr;          // fused quantiser: per work job, scan-order symbol planes (same indexing as nzpos)
+    int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
+    uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
+    uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
+    unsigned *stat = nullptr;        // [4] inverse-transform tile counters (general luma / chroma, zero luma / chroma)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
     DMV *mvs = nullptr;
@@ -147,7 +152,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -224,6 +229,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         MG.cw_extra[p] = CL.w[p] > c->L[0].w[p];
     }
     c->mc_fused = mc_fusable(MG) && !getenv("DSV1_NO_MC_FUSION");
+    c->no_inplace_pred = getenv("DSV1_NO_INPLACE_PRED") != nullptr;
     // two coding streams by default: with the analysis and fetch streams that is four, the number of hardware queues
     // the runtime maps streams onto (three coding streams measured 18.5 ms per step against 14.3 with two and 15.4 with one)
     { const char *e = getenv("DSV1_CODE_STREAMS"); c->code_streams = e ? atoi(e) : 2; }
@@ -281,6 +287,10 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->sym, c->nz_total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->nzf, (c->nz_total >> 2) * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->symP, c->nz_total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->pflag, CL.s3total * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->cflag, (size_t)c->chunks_per_job * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->stat, 4, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
@@ -345,6 +355,17 @@ extern "C" int dsvg_ctx_code_streams(dsvg_ctx *c, int n)
     return old;
 }
 extern "C" int dsvg_ctx_streams_apart(const dsvg_ctx *c) { return c ? c->streams_apart : 0; }
+extern "C" int dsvg_ctx_tile_stats(dsvg_ctx *c, unsigned long long out[4], int reset)
+{
+    if (!c || !out) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    OPCHK(dsvg_ctx_sync(c));
+    unsigned v[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(v, c->stat, sizeof(v), hipMemcpyDeviceToHost));
+    for (int i = 0; i < 4; i++) out[i] = v[i];
+    if (reset) HIPCHK(hipMemset(c->stat, 0, sizeof(v)));
+    return DSVG_OK;
+}
 extern "C" void *dsvg_ctx_stream(dsvg_ctx *c) { return c ? (void *)c->st : nullptr; }
 
 extern "C" int dsvg_dev_alloc(dsvg_ctx *c, void **dptr, size_t bytes)
@@ -572,6 +593,9 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
     jb.nzval = c->nzval + (size_t)t * c->nz_total;
     jb.chunks = c->chunks + (size_t)t * c->chunks_per_job;
     jb.sym = c->sym + (size_t)t * c->nz_total;
+    jb.pflag = c->pflag + (size_t)t * CL.s3total;
+    jb.cflag = c->cflag + (size_t)t * c->chunks_per_job;
+    jb.stat = c->stat;
     jb.psum = c->psum + (size_t)t * 3;
     jb.bits = c->bits + (size_t)t * c->bits_per_job;
     for (int p = 0; p < 3; p++) {
@@ -668,12 +692,17 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             JobDev &jb = c->jobs_h[d];
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
-            jb.nzf = isP ? c->nzf + (size_t)k * (c->nz_total >> 2) : nullptr;   // P: non-zero flags for k_hz_collect
+            // P pictures run sparse: zero-kept symbol planes + non-zero flags (k_hz_collect takes both down again)
+            jb.nzf = isP ? c->nzf + (size_t)k * (c->nz_total >> 2) : nullptr;
+            if (isP) jb.sym = c->symP + (size_t)k * c->nz_total;
             jb.psum = c->psum + (size_t)j.out_slot * 3;
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
             jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
             jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;
+            // the reconstruction goes to another slot than the reference: the prediction is written straight into it and the
+            // inverse transform only touches the tiles that carry a residual (ping-pong slots, see dsv1_enc.c)
+            if (isP && jb.recon && j.recon_slot != j.ref_recon_slot && !c->no_inplace_pred) jb.pred = jb.recon;
             c->slots_h[d] = j.recon_slot;
             memcpy(c->stable_h + (size_t)d * c->nblk, j.stable_blocks, (size_t)c->nblk);
             if (isP) memcpy(c->mv_h + (size_t)d * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
@@ -729,9 +758,12 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                 }
             }
             launch_sbt_tail(st, jd, n, c->G, 0, 3, 0, &c->prof);
-            launch_hz_encode(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
-                             (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
-            OPCHK(enqueue_recon(c, nI, n, d0, 1, st));      // P pictures: straight from the symbol planes
+            // LL quantiser, then the reconstruction (P pictures: straight from the symbol planes), then the entropy stage:
+            // k_hz_collect is the LAST reader of the sparse symbol planes and clears what it reads
+            launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
+                            (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
+            OPCHK(enqueue_recon(c, nI, n, d0, 1, st));
+            launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0);
         }
     }
     for (int g = 1; g < NG; g++) {
@@ -836,6 +868,15 @@ extern "C" int dsvg_download_recon(dsvg_ctx *c, int recon_slot, uint8_t *yuv_out
     launch_pack(c->st, c->yuv_stage, c->recon.p + (size_t)recon_slot * c->L[0].pitch, c->L[0]);
     HIPCHK(hipMemcpyAsync(yuv_out, c->yuv_stage, fb, hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipStreamSynchronize(c->st));
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_download_recon_raw(dsvg_ctx *c, int recon_slot, uint8_t *raw_out, size_t bytes)
+{
+    if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    OPCHK(dsvg_ctx_sync(c));
+    HIPCHK(hipMemcpy(raw_out, c->recon.p + (size_t)recon_slot * c->L[0].pitch, bytes, hipMemcpyDeviceToHost));
     return DSVG_OK;
 }
 

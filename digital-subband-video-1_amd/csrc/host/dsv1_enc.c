@@ -42,6 +42,8 @@ struct dsv1_batch {
     void *staged_dev[2];
     int nstaged;
     int *slots_cur, *slots_ref, *pair_pic, *out_slots;
+    unsigned char *rpar;             /* per stream: which of its two reconstruction slots holds the current reference */
+    unsigned char *has_recon;        /* per stream: a reference picture has been coded */
     unsigned *luma;
     DSV_MV *mv_tmp;
     dsvg_pic_job *jobs;
@@ -80,6 +82,11 @@ static void hp_report(void)
 static int slot_of(const dsv1_batch *b, int s, unsigned g) { return (int)(g % (unsigned)b->rows) * b->nstreams + s; }
 
 void *dsv1_batch_ctx(dsv1_batch *b) { return b ? (void *)b->ctx : NULL; }
+int dsv1_batch_recon_slot(const dsv1_batch *b, int stream)
+{
+    if (!b || stream < 0 || stream >= b->nstreams || !b->has_recon[stream]) return -1;
+    return stream + b->nstreams * b->rpar[stream];
+}
 
 void dsv1_batch_close(dsv1_batch *b)
 {
@@ -96,7 +103,7 @@ void dsv1_batch_close(dsv1_batch *b)
     }
     free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
-    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt);
+    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon);
     free(b);
 }
 
@@ -111,7 +118,7 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     np = nstreams * F;
     b->rows = 2 * F + 1;
     rc = dsvg_ctx_create(&b->ctx, device, m->width, m->height, m->subsamp, encs[0].pyramid_levels,
-                         b->rows * nstreams, nstreams, nstreams, 2 * np);
+                         b->rows * nstreams, 2 * nstreams, nstreams, 2 * np);
     if (rc) { b->enc = NULL; dsv1_batch_close(b); return rc; }       /* the caller still owns encs */
     dsvg_ctx_geom(b->ctx, &b->g);
     b->nblk = b->g.nblocks_h * b->g.nblocks_v;
@@ -126,6 +133,8 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b->slots_ref = (int *)calloc((size_t)np, sizeof(int));
     b->pair_pic = (int *)calloc((size_t)np, sizeof(int));
     b->out_slots = (int *)calloc((size_t)np, sizeof(int));
+    b->rpar = (unsigned char *)calloc((size_t)nstreams, 1);
+    b->has_recon = (unsigned char *)calloc((size_t)nstreams, 1);
     b->luma = (unsigned *)calloc((size_t)b->rows * nstreams, sizeof(unsigned));
     b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
     b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
@@ -576,8 +585,15 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                 dsvg_pic_job *j = &b->jobs[(serial ? 0 : t * S) + s];
                 pc->quant = pick_quant(&b->enc[s], pc->isP, pc->forced_intra);
                 j->src_slot = pc->cur_slot;
-                j->ref_recon_slot = pc->isP ? s : -1;
-                j->recon_slot = pc->is_ref ? s : -1;
+                /* two reconstruction slots per stream, used alternately: a P picture's prediction is written straight
+                 * into the slot its reconstruction will live in (the reference sits in the other one), so the inverse
+                 * transform only touches the tiles that carry a residual (dsvg_code_batch) */
+                j->ref_recon_slot = pc->isP ? s + S * b->rpar[s] : -1;
+                if (pc->is_ref) {
+                    b->rpar[s] ^= 1;
+                    b->has_recon[s] = 1;
+                    j->recon_slot = s + S * b->rpar[s];
+                } else j->recon_slot = -1;
                 j->quant = pc->quant;
                 j->mvs = (const dsvg_mv *)pc->mvs;
                 j->stable_blocks = pc->stable;

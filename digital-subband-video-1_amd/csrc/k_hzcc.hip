@@ -243,14 +243,39 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
     int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
     int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
     const int cbase = chunk * HZ_CHUNK;
-    if (cbase < ll_end) return;     // chunks that reach into the LL region belong to k_hz_quant<true>
+    int16_t *symw = jb.sym + jb.nz_off[c];
+    uint8_t *cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] + chunk : nullptr;
+    if (cbase < ll_end) {
+        // chunks that reach into the LL region were compacted by k_hz_quant<true>; in sparse mode the detail symbols of
+        // the chunk that straddles the end of the LL region still have to be taken down (this kernel is their last reader)
+        if (cfl && cbase + HZ_CHUNK > ll_end && *cfl) {
+            uint8_t *nzf = jb.nzf + (jb.nz_off[c] >> 2);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int p0 = cbase + k * 512 + 8 * lane;
+                if (p0 < nscan && *reinterpret_cast<const unsigned short *>(nzf + (p0 >> 2))) {
+                    *reinterpret_cast<uint4 *>(symw + p0) = make_uint4(0, 0, 0, 0);
+                    *reinterpret_cast<unsigned short *>(nzf + (p0 >> 2)) = 0;
+                }
+            }
+            if (lane == 0) *cfl = 0;
+        }
+        return;
+    }
+    if (cfl && *cfl == 0) {             // sparse mode: nothing was stored into this chunk
+        if (lane == 0) {
+            HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
+            cs.nnz = 0; cs.bits_inner = 0; cs.first_pos = -1; cs.last_pos = -1; cs.last_val = 0;
+        }
+        return;
+    }
     const unsigned long long ltmask = (1ull << lane) - 1ull;
 
     uint4 raw[4];
     if (jb.nzf) {
         // P pictures: the forward transform flagged every group of four cells that holds a non-zero symbol -- two flag
         // bytes per lane and round instead of sixteen symbol bytes; symbols are fetched only where a flag is up, and
-        // the flags are taken down again for the next picture
+        // symbols, flags and the chunk flag are taken down again for the next picture (the plane stays zero)
         uint8_t *nzf = jb.nzf + (jb.nz_off[c] >> 2);
         unsigned short fl[4];
 #pragma unroll
@@ -264,9 +289,11 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
             raw[k] = make_uint4(0, 0, 0, 0);
             if (fl[k]) {
                 raw[k] = *reinterpret_cast<const uint4 *>(sym + p0);
+                *reinterpret_cast<uint4 *>(symw + p0) = make_uint4(0, 0, 0, 0);
                 *reinterpret_cast<unsigned short *>(nzf + (p0 >> 2)) = 0;
             }
         }
+        if (lane == 0) *cfl = 0;
     } else {
 #pragma unroll
     for (int k = 0; k < 4; k++) {

@@ -57,23 +57,20 @@ struct QCtx {
     const uint8_t *stable;
     int16_t *sym;
     bool any_ov;
-    // P pictures of the encoder: one flag byte per four scan positions, set wherever a non-zero symbol is written, so
-    // that k_hz_collect reads 1/8 of the bytes to find the few non-zeros of a P picture (null: no flags kept)
-    uint8_t *nzf = nullptr;
-};
-// flag the non-zero cells of one stored symbol row (plain conditional byte stores: rare, and nothing waits for them)
-template <int M>
-static __device__ __forceinline__ void nz_flag_row(const QCtx &q, int pos0, const int (&v)[M], int n)
-{
-    int any = 0;
-#pragma unroll
-    for (int i = 0; i < M; i++) any |= i < n ? v[i] : 0;
-    if (any) {
-#pragma unroll
-        for (int i = 0; i < M; i++)
-            if (i < n && v[i] != 0) q.nzf[(pos0 + i) >> 2] = 1;
+    // P pictures of the encoder (SPARSE mode, nzf != null): the symbol plane is zero between pictures and only non-zero
+    // symbols are stored, each with one flag byte per four scan positions (nzf) and one per 2048-cell scan chunk (cfl), so
+    // that k_hz_collect touches only what holds data; nz_any gathers "this thread stored something" for the patch flag
+    // the inverse transform keys its zero-tile path on.  null: every symbol is stored (I pictures).
+    uint8_t *nzf = nullptr, *cfl = nullptr;
+    mutable int nz_any = 0;
+    __device__ __forceinline__ void put_sparse(int pos, int v) const
+    {
+        sym[pos] = (int16_t)v;
+        nzf[pos >> 2] = 1;
+        cfl[pos >> 11] = 1;                 // HZ_CHUNK = 2048
     }
-}
+};
+static_assert(HZ_CHUNK == 2048, "cfl index");
 // wave-uniform constants of one scan level: its LH/HL/HH regions differ only in origin and scan base
 struct QLevel {
     int qp;                // levels 0,1: quantiser max(qp >> class, 16), class {none, stable, flag&2} (tmq4pos hzcc.c:64-74)
@@ -146,8 +143,8 @@ static __device__ int q_chain(const QCtx &q, int l, int gx, int gy, int val)
     const int ex = gx - e.x0, ey = gy - e.y0;
     const int etq = hz_cell_tq(e, q.stable, hp.nbh, ex, ey);
     const int ev = hz_quant_any(e, val, etq);
-    q.sym[e.base + ey * e.sw + ex] = (int16_t)ev;
-    if (q.nzf && ev) q.nzf[(e.base + ey * e.sw + ex) >> 2] = 1;
+    if (q.nzf) { if (ev) q.put_sparse(e.base + ey * e.sw + ex, ev); }      // (not read by the inverse: no patch flag)
+    else q.sym[e.base + ey * e.sw + ex] = (int16_t)ev;
     return ev ? hz_dequant_any(e, ev, etq) : 0;
 }
 template <int M>
@@ -291,23 +288,27 @@ struct HaarQ {
         }
         // only the symbols leave the chip: the inverse transform (k_inv_haar_tile<.,0,SYM>) dequantises them again
         if (rowok) {
-            store_sym_row<M>(q.sym + L.base0 + cy * L.sw + cx0, slh, nR);     // scan position = base + cy * sw + cx
-            if (hasB) {
-                store_sym_row<M>(q.sym + L.base1 + cy * L.sw + cx0, shl, nC);
-                store_sym_row<M>(q.sym + L.base2 + cy * L.sw + cx0, shh, nR);
-            }
+            const int pr = cy * L.sw + cx0;                               // scan position = base + cy * sw + cx
             if (q.nzf) {
-                int any = 0;                    // one test for the three bands (cells that are not stored only cost a look)
+                // sparse: a P picture has a few thousand non-zeros among millions of cells -- one test per row, then
+                // single stores (rare, and nothing waits for them)
+                int any = 0;
 #pragma unroll
-                for (int i = 0; i < M; i++) any |= slh[i] | shl[i] | shh[i];
+                for (int i = 0; i < M; i++) any |= (i < nR ? slh[i] : 0) | ((hasB && i < nC) ? shl[i] : 0) | ((hasB && i < nR) ? shh[i] : 0);
                 if (any) {
-                    const int pr = cy * L.sw + cx0;
+                    q.nz_any = 1;
 #pragma unroll
                     for (int i = 0; i < M; i++) {
-                        if (i < nR && slh[i] != 0) q.nzf[(L.base0 + pr + i) >> 2] = 1;
-                        if (hasB && i < nC && shl[i] != 0) q.nzf[(L.base1 + pr + i) >> 2] = 1;
-                        if (hasB && i < nR && shh[i] != 0) q.nzf[(L.base2 + pr + i) >> 2] = 1;
+                        if (i < nR && slh[i] != 0) q.put_sparse(L.base0 + pr + i, slh[i]);
+                        if (hasB && i < nC && shl[i] != 0) q.put_sparse(L.base1 + pr + i, shl[i]);
+                        if (hasB && i < nR && shh[i] != 0) q.put_sparse(L.base2 + pr + i, shh[i]);
                     }
+                }
+            } else {
+                store_sym_row<M>(q.sym + L.base0 + pr, slh, nR);
+                if (hasB) {
+                    store_sym_row<M>(q.sym + L.base1 + pr, shl, nC);
+                    store_sym_row<M>(q.sym + L.base2 + pr, shh, nR);
                 }
             }
         }
@@ -364,6 +365,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
         q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                    (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
         q.nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
+        q.cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] : nullptr;
     }
     // transform level 1,2,3 <-> scan level 2,1,0
     if (Q) {
@@ -376,6 +378,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
         haar_fwd_patch<2>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true);
     }
     jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
+    if (Q && jb.nzf) jb.pflag[g.s3off + (size_t)J * g.w3 + I] = (uint8_t)q.nz_any;     // every patch, every picture: never stale
 }
 
 // --------------------------------------------------------------------------------------------
@@ -540,6 +543,7 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
     q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
     q.nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
+    q.cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] : nullptr;
     // transform level 1 consumes the residual rows in pairs as they appear: only two of them are alive at a time
     HaarQ<8, 2> hq1;
     hq1.init(q, 4 * I, 4 * J, W, H, wo1, ho1);
@@ -615,6 +619,7 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
     haar_fwd_patch_q<4, 1>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true, q);
     haar_fwd_patch_q<2, 0>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true, q);
     jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
+    if (jb.nzf) jb.pflag[g.s3off + (size_t)J * g.w3 + I] = (uint8_t)q.nz_any;          // every patch, every picture: never stale
 }
 
 // --------------------------------------------------------------------------------------------
@@ -1234,6 +1239,45 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         const int ly = tid / A3W, lx = tid - ly * A3W;
         const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
         if (cx >= 0 && cy >= 0 && cx < inw && cy < inh) a3v = s3[(size_t)cy * inw + cx];
+    }
+    if constexpr (MODE == 0 && SYM) {
+        // Sparse P pictures: when no patch of the tile (halo included) carries a detail symbol and every LL3 value in
+        // reach is zero, every level's output is zero (no nudge fires on a flat band: mx == mn == 0) and the
+        // reconstruction is the prediction (sbc2int gives 128, addf adds pred - 128).  The "next LL" of a region's last
+        // complete cell is a detail of column / row 0 (sbt.c:463-527), so tiles that reach the last column / row also
+        // look at those patches.  One barrier; nothing else has been loaded yet.
+        if (jb.nzf != nullptr) {
+            const uint8_t *pfl = jb.pflag + g.s3off;
+            int nzv = a3v;
+            if (tid < A3H * A3W) {
+                const int ly = tid / A3W, lx = tid - ly * A3W;
+                const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
+                if (cx >= 0 && cy >= 0 && cx < inw && cy < inh) nzv |= pfl[(size_t)cy * inw + cx];
+                if (lx == 0 && I0 + IT_TX + 2 >= inw && cy >= 0 && cy < inh) nzv |= pfl[(size_t)cy * inw];
+                if (ly == 0 && J0 + IT_TY + 2 >= inh && cx >= 0 && cx < inw) nzv |= pfl[cx];
+            }
+            if (!__syncthreads_or(nzv != 0)) {
+                const uint8_t *predz = jb.ref != nullptr ? jb.pred + g.poff : nullptr;
+                uint8_t *outz = (jb.recon ? jb.recon : jb.xf) + g.poff;
+                if (tid == 0 && jb.stat) atomicAdd(jb.stat + 2 + (c != 0), 1u);
+                if (predz == outz) return;                           // the prediction was written in place (ping-pong slots)
+                const int px0t = 8 * I0, py0t = 8 * J0;               // tile origin in pixels
+                for (int u = tid; u < (8 * IT_TY) * (8 * IT_TX / 16); u += 256) {
+                    const int ry = u / (8 * IT_TX / 16), ux = u - ry * (8 * IT_TX / 16);
+                    const int y = py0t + ry, x = px0t + 16 * ux;
+                    if (y >= g.ph || x >= g.pw) continue;
+                    uint8_t *d = outz + (size_t)y * g.pstride + x;
+                    const uint8_t *sp = predz ? predz + (size_t)y * g.pstride + x : nullptr;
+                    if (x + 16 <= g.pw && ((((uintptr_t)d) | (uintptr_t)sp) & 15) == 0) {
+                        *reinterpret_cast<uint4 *>(d) = sp ? *reinterpret_cast<const uint4 *>(sp) : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+                    } else {
+                        for (int i = 0; i < 16 && x + i < g.pw; i++) d[i] = sp ? sp[i] : (uint8_t)128;
+                    }
+                }
+                return;
+            }
+            if (tid == 0 && jb.stat) atomicAdd(jb.stat + (c != 0), 1u);
+        }
     }
     const LvlGeo L3 = mk_lvl(W, H, TOP, jb.hqp[TOP], true);
     const auto D3 = mk_det<SYM, 0>(jb, c, coef, W, L3);

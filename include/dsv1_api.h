@@ -172,6 +172,9 @@ int  dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out);
  * (set_link_offsets dsv_encoder.c:171-192) and appends an EOS.  Returns dsv_alloc'd buffer. */
 int  dsv1_concat_gops(const DSV_BUF *gops, int ngops, DSV_BUF *out);
 void *dsv1_batch_ctx(dsv1_batch *b);          /* the dsvg_ctx* (profiling hooks) */
+/* reconstruction slot that holds `stream`'s current reference picture (the encoder's recon_frame, dsv_encoder.c:663-674),
+ * for dsvg_download_recon / dsvg_download_recon_raw; -1 if the stream has none yet */
+int   dsv1_batch_recon_slot(const dsv1_batch *b, int stream);
 
 /* ---- extension: batched decoding (dsv_dec decodes one picture per call, dsv_decoder.c:286-472) ----
  * nstreams independent streams of one geometry; every call takes ONE packet per stream (packets[s]: not freed, not

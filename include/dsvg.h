@@ -115,7 +115,12 @@ int dsvg_ctx_code_streams(dsvg_ctx *ctx, int n);
 /* how many of the context's four streams (coding, analysis, second coding, fetch) were placed on hardware queues of
  * their own by the probe at creation (4 = all apart; 0 = probe switched off with DSV1_NO_STREAM_PROBE) */
 int dsvg_ctx_streams_apart(const dsvg_ctx *ctx);
-void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the hipStream_t all pipeline work is enqueued on */
+void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the first coding hipStream_t (operator-style callers: dsvg_download_recon, dsvg_pack_recons run on it) */
+/* Sparse P pictures: tiles of the fused inverse transform (128x64 pixels) counted since the last reset --
+ * out[0], out[1] = tiles that took the general path (luma, chroma), out[2], out[3] = tiles found empty (no detail symbol,
+ * LL3 zero: reconstruction = prediction, nothing computed).  Syncs the context.  Used by bench.py to price the kernel at
+ * the bytes it really moved. */
+int dsvg_ctx_tile_stats(dsvg_ctx *ctx, unsigned long long out[4], int reset);
 
 /* device memory helpers for callers that keep the raw clip in HBM (bench.py) */
 int dsvg_dev_alloc(dsvg_ctx *ctx, void **dptr, size_t bytes);
@@ -151,7 +156,9 @@ int dsvg_analyse(dsvg_ctx *ctx, int npairs, const int *cur_slots, const int *ref
 typedef struct {
     int src_slot;            /* source frame to code */
     int ref_recon_slot;      /* reconstruction used for prediction, -1 for an I picture */
-    int recon_slot;          /* where to keep this picture's reconstruction, -1 = do not keep */
+    int recon_slot;          /* where to keep this picture's reconstruction, -1 = do not keep.  May equal ref_recon_slot
+                              * (updated in place through a separate prediction frame); a DIFFERENT slot is faster: the
+                              * prediction is then written straight into it and only tiles with a residual are touched again */
     int quant;               /* frame quantiser (quality2quant dsv_encoder.c:165) */
     const dsvg_mv *mvs;      /* host, nblocks entries (P pictures) */
     const unsigned char *stable_blocks; /* host, nblocks entries (encode_stable_blocks output) */
@@ -177,6 +184,9 @@ int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
 int dsvg_code_batch(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */
+/* the first `bytes` bytes of the slot's whole frame allocation in the reference layout (dsv_mk_frame frame.c:63-120:
+ * Y,U,V back to back, 64-px replicated borders): what the next picture's motion compensation reads.  Syncs. */
+int dsvg_download_recon_raw(dsvg_ctx *ctx, int recon_slot, uint8_t *raw_out, size_t bytes);
 /* n reconstruction slots -> tightly packed planar frames, frame i at yuv_out + i*out_pitch.  Device output: enqueued
  * on the pipeline stream, no sync (dsvg_ctx_sync before reading it).  Host output: copied back and synchronised. */
 int dsvg_pack_recons(dsvg_ctx *ctx, int n, const int *recon_slots, void *yuv_out, size_t out_pitch, int out_on_device);
