@@ -154,7 +154,7 @@ def main():
         b.tile_stats()
         b.encode(src, on_device=ondev)
         b.sync()
-        tiles = b.tile_stats()
+        tiles = b.tile_stats(enable=False)
         table = {k: b.prof_get(k) for k in names}
         # the sparse inverse transform moves data only for tiles that carry a residual: price it at what it really moved
         # (general tile: 128x64 samples x 4 B = symbols 2 + prediction 1 + reconstruction 1; every tile: its 20x12 LL3

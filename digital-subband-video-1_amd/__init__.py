@@ -237,11 +237,12 @@ class Batch:
         """set (n >= 1) / query (n = 0) the number of coding streams; returns the previous value"""
         return self.L.dsvg_ctx_code_streams(self.ctx, n)
 
-    def tile_stats(self, reset=True):
-        """inverse-transform tiles of P pictures since the last reset: dict general_luma / general_chroma (computed) and
-        zero_luma / zero_chroma (found empty: reconstruction = prediction).  Syncs."""
+    def tile_stats(self, enable=True):
+        """inverse-transform tiles of P pictures since the previous call: dict general_luma / general_chroma (computed)
+        and zero_luma / zero_chroma (found empty: reconstruction = prediction); counting continues only if `enable`.
+        Syncs and clears the counters."""
         v = (_C.c_ulonglong * 4)()
-        _chk(self.L.dsvg_ctx_tile_stats(self.ctx, v, 1 if reset else 0), "dsvg_ctx_tile_stats")
+        _chk(self.L.dsvg_ctx_tile_stats(self.ctx, v, 1 if enable else 0), "dsvg_ctx_tile_stats")
         return {"general_luma": v[0], "general_chroma": v[1], "zero_luma": v[2], "zero_chroma": v[3]}
 
     def kernel_names(self):

@@ -96,7 +96,8 @@ struct dsvg_ctx {
     int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
     uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
-    unsigned *stat = nullptr;        // [4] inverse-transform tile counters (general luma / chroma, zero luma / chroma)
+    unsigned *stat = nullptr;        // [4][64] inverse-transform tile counters (general luma / chroma, zero luma / chroma), sharded
+    bool stats_on = false;           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
     DMV *mvs = nullptr;
@@ -290,7 +291,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->symP, c->nz_total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->pflag, CL.s3total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->cflag, (size_t)c->chunks_per_job * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->stat, 4, true))) return fail(rc);
+    if ((rc = dmalloc(&c->stat, 4 * 64, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
@@ -355,15 +356,19 @@ extern "C" int dsvg_ctx_code_streams(dsvg_ctx *c, int n)
     return old;
 }
 extern "C" int dsvg_ctx_streams_apart(const dsvg_ctx *c) { return c ? c->streams_apart : 0; }
-extern "C" int dsvg_ctx_tile_stats(dsvg_ctx *c, unsigned long long out[4], int reset)
+extern "C" int dsvg_ctx_tile_stats(dsvg_ctx *c, unsigned long long out[4], int enable)
 {
     if (!c || !out) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     OPCHK(dsvg_ctx_sync(c));
-    unsigned v[4] = {0, 0, 0, 0};
+    unsigned v[4 * 64];
     HIPCHK(hipMemcpy(v, c->stat, sizeof(v), hipMemcpyDeviceToHost));
-    for (int i = 0; i < 4; i++) out[i] = v[i];
-    if (reset) HIPCHK(hipMemset(c->stat, 0, sizeof(v)));
+    for (int i = 0; i < 4; i++) {
+        out[i] = 0;
+        for (int k = 0; k < 64; k++) out[i] += v[64 * i + k];
+    }
+    HIPCHK(hipMemset(c->stat, 0, sizeof(v)));
+    c->stats_on = enable != 0;
     return DSVG_OK;
 }
 extern "C" void *dsvg_ctx_stream(dsvg_ctx *c) { return c ? (void *)c->st : nullptr; }
@@ -595,7 +600,7 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
     jb.sym = c->sym + (size_t)t * c->nz_total;
     jb.pflag = c->pflag + (size_t)t * CL.s3total;
     jb.cflag = c->cflag + (size_t)t * c->chunks_per_job;
-    jb.stat = c->stat;
+    jb.stat = c->stats_on ? c->stat : nullptr;
     jb.psum = c->psum + (size_t)t * 3;
     jb.bits = c->bits + (size_t)t * c->bits_per_job;
     for (int p = 0; p < 3; p++) {

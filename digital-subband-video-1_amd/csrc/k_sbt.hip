@@ -1240,15 +1240,17 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
         if (cx >= 0 && cy >= 0 && cx < inw && cy < inh) a3v = s3[(size_t)cy * inw + cx];
     }
+    // Sparse P pictures (MODE 0, SYM, jb.nzf set): when no patch of the tile (halo included) carries a detail symbol and
+    // every LL3 value in reach is zero, every level's output is zero (no nudge fires on a flat band: mx == mn == 0) and
+    // the reconstruction is the prediction (sbc2int gives 128, addf adds pred - 128).  The "next LL" of a region's last
+    // complete cell is a detail of column / row 0 (sbt.c:463-527), so tiles that reach the last column / row also look
+    // at those patches.  The flags are requested here with everything else; the decision rides on the first barrier.
+    int nzv = 0;
     if constexpr (MODE == 0 && SYM) {
-        // Sparse P pictures: when no patch of the tile (halo included) carries a detail symbol and every LL3 value in
-        // reach is zero, every level's output is zero (no nudge fires on a flat band: mx == mn == 0) and the
-        // reconstruction is the prediction (sbc2int gives 128, addf adds pred - 128).  The "next LL" of a region's last
-        // complete cell is a detail of column / row 0 (sbt.c:463-527), so tiles that reach the last column / row also
-        // look at those patches.  One barrier; nothing else has been loaded yet.
+        nzv = 1;
         if (jb.nzf != nullptr) {
             const uint8_t *pfl = jb.pflag + g.s3off;
-            int nzv = a3v;
+            nzv = a3v;
             if (tid < A3H * A3W) {
                 const int ly = tid / A3W, lx = tid - ly * A3W;
                 const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
@@ -1256,27 +1258,6 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
                 if (lx == 0 && I0 + IT_TX + 2 >= inw && cy >= 0 && cy < inh) nzv |= pfl[(size_t)cy * inw];
                 if (ly == 0 && J0 + IT_TY + 2 >= inh && cx >= 0 && cx < inw) nzv |= pfl[cx];
             }
-            if (!__syncthreads_or(nzv != 0)) {
-                const uint8_t *predz = jb.ref != nullptr ? jb.pred + g.poff : nullptr;
-                uint8_t *outz = (jb.recon ? jb.recon : jb.xf) + g.poff;
-                if (tid == 0 && jb.stat) atomicAdd(jb.stat + 2 + (c != 0), 1u);
-                if (predz == outz) return;                           // the prediction was written in place (ping-pong slots)
-                const int px0t = 8 * I0, py0t = 8 * J0;               // tile origin in pixels
-                for (int u = tid; u < (8 * IT_TY) * (8 * IT_TX / 16); u += 256) {
-                    const int ry = u / (8 * IT_TX / 16), ux = u - ry * (8 * IT_TX / 16);
-                    const int y = py0t + ry, x = px0t + 16 * ux;
-                    if (y >= g.ph || x >= g.pw) continue;
-                    uint8_t *d = outz + (size_t)y * g.pstride + x;
-                    const uint8_t *sp = predz ? predz + (size_t)y * g.pstride + x : nullptr;
-                    if (x + 16 <= g.pw && ((((uintptr_t)d) | (uintptr_t)sp) & 15) == 0) {
-                        *reinterpret_cast<uint4 *>(d) = sp ? *reinterpret_cast<const uint4 *>(sp) : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
-                    } else {
-                        for (int i = 0; i < 16 && x + i < g.pw; i++) d[i] = sp ? sp[i] : (uint8_t)128;
-                    }
-                }
-                return;
-            }
-            if (tid == 0 && jb.stat) atomicAdd(jb.stat + (c != 0), 1u);
         }
     }
     const LvlGeo L3 = mk_lvl(W, H, TOP, jb.hqp[TOP], true);
@@ -1328,7 +1309,29 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     __builtin_amdgcn_sched_barrier(0);
 
     if (tid < A3H * A3W) A3[tid] = a3v;
-    __syncthreads();
+    if constexpr (MODE == 0 && SYM) {
+        if (!__syncthreads_or(nzv != 0)) {
+            const uint8_t *predz = jb.ref != nullptr ? jb.pred + g.poff : nullptr;
+            uint8_t *outz = (jb.recon ? jb.recon : jb.xf) + g.poff;
+            if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+            if (predz == outz) return;                           // the prediction was written in place (ping-pong slots)
+            const int px0t = 8 * I0, py0t = 8 * J0;               // tile origin in pixels
+            for (int u = tid; u < (8 * IT_TY) * (8 * IT_TX / 16); u += 256) {
+                const int ry = u / (8 * IT_TX / 16), ux = u - ry * (8 * IT_TX / 16);
+                const int y = py0t + ry, x = px0t + 16 * ux;
+                if (y >= g.ph || x >= g.pw) continue;
+                uint8_t *d = outz + (size_t)y * g.pstride + x;
+                const uint8_t *sp = predz ? predz + (size_t)y * g.pstride + x : nullptr;
+                if (x + 16 <= g.pw && ((((uintptr_t)d) | (uintptr_t)sp) & 15) == 0) {
+                    *reinterpret_cast<uint4 *>(d) = sp ? *reinterpret_cast<const uint4 *>(sp) : make_uint4(0x80808080u, 0x80808080u, 0x80808080u, 0x80808080u);
+                } else {
+                    for (int i = 0; i < 16 && x + i < g.pw; i++) d[i] = sp ? sp[i] : (uint8_t)128;
+                }
+            }
+            return;
+        }
+        if (tid == 0 && jb.stat && jb.nzf) atomicAdd(jb.stat + 64 * (c != 0) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+    } else __syncthreads();
     if (ok3) {      // level TOP: cells I0-1 .. I0+TX (halo 1)
         const int ly = tid / (IT_TX + 2), lx = tid - ly * (IT_TX + 2);
         int o[4];

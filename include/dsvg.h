@@ -116,11 +116,12 @@ int dsvg_ctx_code_streams(dsvg_ctx *ctx, int n);
  * their own by the probe at creation (4 = all apart; 0 = probe switched off with DSV1_NO_STREAM_PROBE) */
 int dsvg_ctx_streams_apart(const dsvg_ctx *ctx);
 void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the first coding hipStream_t (operator-style callers: dsvg_download_recon, dsvg_pack_recons run on it) */
-/* Sparse P pictures: tiles of the fused inverse transform (128x64 pixels) counted since the last reset --
+/* Sparse P pictures: tiles of the fused inverse transform (128x64 pixels) counted since the previous call --
  * out[0], out[1] = tiles that took the general path (luma, chroma), out[2], out[3] = tiles found empty (no detail symbol,
- * LL3 zero: reconstruction = prediction, nothing computed).  Syncs the context.  Used by bench.py to price the kernel at
- * the bytes it really moved. */
-int dsvg_ctx_tile_stats(dsvg_ctx *ctx, unsigned long long out[4], int reset);
+ * LL3 zero: reconstruction = prediction, nothing computed).  Counting is off until a call with enable != 0 and stops
+ * again with enable = 0 (one atomic per tile).  Syncs the context and clears the counters.  bench.py uses it to price
+ * the kernel at the bytes it really moved. */
+int dsvg_ctx_tile_stats(dsvg_ctx *ctx, unsigned long long out[4], int enable);
 
 /* device memory helpers for callers that keep the raw clip in HBM (bench.py) */
 int dsvg_dev_alloc(dsvg_ctx *ctx, void **dptr, size_t bytes);

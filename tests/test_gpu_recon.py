@@ -38,6 +38,21 @@ def expected_raw(w, h, fmt, planar):
     return bf.raw().copy()
 
 
+def make_clip(w, h, fmt, seed, n, style):
+    """styles 0-2: the generator's; 10: a static scene (every P tile empty: reconstruction = prediction); 11: a static
+    scene with a small square moving over it (empty tiles next to tiles with a residual)"""
+    if style < 10:
+        return A.gen_clip(w, h, fmt, seed, n, style=style)
+    base = A.gen_clip(w, h, fmt, seed, 1, style=0)[0]
+    clip = np.repeat(base[None, :], n, axis=0).copy()
+    if style == 11:
+        for t in range(n):
+            y = clip[t, :w * h].reshape(h, w)
+            x0, y0 = (40 + 23 * t) % (w - 48), (24 + 9 * t) % (h - 48)
+            y[y0:y0 + 40, x0:x0 + 40] = (37 * t + np.arange(40)[None, :] * 5 + np.arange(40)[:, None] * 3) % 256
+    return clip
+
+
 CASES = [
     # w, h, fmt, frames, style, cli
     (352, 288, A.SUBSAMP_420, 5, 2, dict(qp=85, gop=12, rc_mode_cli=1)),          # flat objects: intra blocks, residual tiles
@@ -47,13 +62,17 @@ CASES = [
     (704, 480, A.SUBSAMP_422, 3, 2, dict(qp=95, gop=12, rc_mode_cli=1)),
     (1920, 1080, A.SUBSAMP_420, 3, 0, dict(qp=85, gop=12, rc_mode_cli=1)),        # 960x540 chroma: overlapping scan regions
     (1920, 1080, A.SUBSAMP_420, 3, 2, dict(qp=85, gop=12, rc_mode_cli=1)),
+    (352, 288, A.SUBSAMP_420, 4, 10, dict(qp=85, gop=12, rc_mode_cli=1)),         # static: the zero-tile path everywhere
+    (704, 480, A.SUBSAMP_420, 5, 11, dict(qp=85, gop=12, rc_mode_cli=1)),         # static + moving square: both paths
+    (1920, 1080, A.SUBSAMP_420, 3, 11, dict(qp=85, gop=12, rc_mode_cli=1)),
+    (250, 130, A.SUBSAMP_444, 4, 11, dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
 ]
 
 
 @pytest.mark.parametrize("case", range(len(CASES)))
 def test_recon_frames_equal_oracle(pkg, case):
     w, h, fmt, n, style, cli = CASES[case]
-    clip = A.gen_clip(w, h, fmt, 0x7EC0 + case, n, style=style)
+    clip = make_clip(w, h, fmt, 0x7EC0 + case, n, style)
     want_stream, want_rec = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli), want_recon=True, eos=False)
     L = pkg.lib()
     L.dsv1_batch_recon_slot.argtypes = [C.c_void_p, C.c_int]
@@ -76,20 +95,21 @@ def test_recon_frames_equal_oracle(pkg, case):
 
 
 def test_zero_and_general_tiles_both_taken(pkg):
-    """the sparse inverse must have exercised both of its paths in the cases above: an almost static clip takes the zero
-    path nearly everywhere, a clip with moving flat objects takes the general path where they are"""
+    """the sparse inverse must have exercised both of its paths in the cases above: a static clip takes the zero path
+    everywhere, a clip with a moving object takes the general path where the object is"""
     w, h, fmt = 704, 480, A.SUBSAMP_420
-    for style, want_general in ((0, False), (2, True)):
-        clip = A.gen_clip(w, h, fmt, 0x51AB + style, 4, style=style)
+    for style, want_general in ((10, False), (11, True)):
+        clip = make_clip(w, h, fmt, 0x51AB + style, 4, style)
         b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1), 1, 4)
         try:
             b.tile_stats()
             b.encode(clip.reshape(1, 4, -1))
-            st = b.tile_stats()
+            st = b.tile_stats(enable=False)
         finally:
             b.close()
-        assert st["zero_luma"] + st["general_luma"] > 0
+        assert st["zero_luma"] > 0 and st["zero_chroma"] > 0, st
         if want_general:
-            assert st["general_luma"] > 0
+            assert st["general_luma"] > 0, st
         else:
-            assert st["zero_luma"] > 0
+            # the I picture's quantisation error leaves a residual here and there
+            assert st["zero_luma"] > st["general_luma"] and st["zero_chroma"] > st["general_chroma"], st
