@@ -31,43 +31,158 @@ QP = 85
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
 
 
-def cpu_baseline(clips, pkg, A, reps=1):
-    """time the reference encoder (1 thread) on `clips` [g][GOP][bytes], `reps` passes over them (pass r encodes
-    GOP numbers r*len(clips)..); returns dict + the streams of the first pass"""
-    kind = "reference" if A.have_ref() else "port"
-    streams = []
-    nd = clips.shape[0]
-    clips = np.concatenate([clips] * reps, axis=0) if reps > 1 else clips
-    t0 = time.perf_counter()
-    if kind == "reference":
+def cpu_info():
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return model, os.cpu_count()
+
+
+def ref_encode(pkg, A, clip, w, h, fmt, start_fnum=0, **cli):
+    """one stream through the CPU checker: the REAL reference encoder (oracle/_ref, one thread) where it was built,
+    else our scalar port in oracle/.  clip [frames][bytes]; returns (.dsv bytes without EOS, kind)"""
+    if A.have_ref():
         L = C.CDLL(A.REF_SO)
         L.dsv_load_planar_frame.restype = C.c_void_p
         L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
-        L.estimate_bitrate.restype = C.c_uint
-        for g in range(clips.shape[0]):
-            enc = pkg.make_encoder_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1)     # same struct layout
-            enc.next_fnum = g * GOP
-            L.dsv_enc_start(C.byref(enc))
-            out = b""
-            bufs = (pkg.Buf * 4)()
-            for t in range(GOP):
-                fr = L.dsv_load_planar_frame(FMT, clips[g, t].ctypes.data, W, H)
-                nb = L.dsv_enc(C.byref(enc), fr, bufs) & 3
-                for i in range(nb):
-                    out += C.string_at(bufs[i].data, bufs[i].len)
-                    L.dsv_buf_free(C.byref(bufs[i]))
-            L.dsv_enc_free(C.byref(enc))
-            streams.append(out)
-    else:
-        for g in range(clips.shape[0]):
-            s, _ = A.orc_encode(clips[g], A.orc_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1), start_fnum=g * GOP, eos=False)
-            streams.append(s)
+        enc = pkg.make_encoder_cfg(w, h, fmt, **cli)     # same struct layout
+        enc.next_fnum = start_fnum
+        L.dsv_enc_start(C.byref(enc))
+        out = b""
+        bufs = (pkg.Buf * 4)()
+        for t in range(clip.shape[0]):
+            fr = L.dsv_load_planar_frame(fmt, clip[t].ctypes.data, w, h)
+            nb = L.dsv_enc(C.byref(enc), fr, bufs) & 3
+            for i in range(nb):
+                out += C.string_at(bufs[i].data, bufs[i].len)
+                L.dsv_buf_free(C.byref(bufs[i]))
+        L.dsv_enc_free(C.byref(enc))
+        return out, "reference"
+    s, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli), start_fnum=start_fnum, eos=False)
+    return s, "port"
+
+
+def cpu_baseline(clips, pkg, A, reps=1):
+    """time the reference encoder (1 thread) on `clips` [g][GOP][bytes], `reps` passes over them (pass r encodes
+    GOP numbers r*len(clips)..); returns dict + the streams of the first pass"""
+    streams = []
+    nd = clips.shape[0]
+    clips = np.concatenate([clips] * reps, axis=0) if reps > 1 else clips
+    kind = "port"
+    t0 = time.perf_counter()
+    for g in range(clips.shape[0]):
+        s_, kind = ref_encode(pkg, A, clips[g], W, H, FMT, start_fnum=g * GOP, qp=QP, gop=GOP, rc_mode_cli=1)
+        streams.append(s_)
     dt = time.perf_counter() - t0
     mpix = clips.shape[0] * GOP * W * H / 1e6
-    return {"value": round(mpix / dt, 2), "unit": "Mpix/s", "cores": 1, "kind": kind,
+    model, ncpu = cpu_info()
+    return {"value": round(mpix / dt, 2), "unit": "Mpix/s", "cores": 1, "kind": kind, "cpu_model": model, "nproc": ncpu,
             "sample": "%d GOPs x %d frames 1920x1080 4:2:0 -gop12 -qp85 -rc_mode1 (%d distinct synthetic clips), %.1f s"
                       % (clips.shape[0], GOP, nd, dt)}, streams[:nd]
+
+
+def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, **cli):
+    """the same pipelined loop on another shape of BASELINE.json (dsv_main.c:463-489 flag mapping in make_encoder_cfg):
+    `streams` x `frames` pictures per step, raw frames resident in HBM; CRF runs submit/collect, ABR (serial per frame)
+    plain encode calls.  One stream is compared bit for bit with the CPU checker on its first `check_frames` frames."""
+    fb = A.frame_bytes(w, h, fmt)
+    clip = A.gen_clip(w, h, fmt, seed, frames, style=0)
+    batch_in = np.empty((streams, frames, fb), dtype=np.uint8)
+    batch_in[:] = clip
+    cfg = pkg.make_encoder_cfg(w, h, fmt, **cli)
+    b = pkg.Batch(cfg, streams, frames, device=dev)
+    try:
+        d = b.upload(batch_in)
+        first = b.encode(d, on_device=True)
+        crf = cli.get("rc_mode_cli", 1) == 1
+        if crf:
+            b.submit(d, on_device=True)                  # fill the pipeline (as the headline loop does)
+        b.sync()
+        t0 = time.perf_counter()
+        if crf:
+            for _ in range(steps):
+                b.submit(d, on_device=True)
+                outs = b.collect(copy=False)
+            b.sync()
+            dt = time.perf_counter() - t0
+            b.collect(copy=False)
+            n = steps
+        else:
+            for _ in range(steps):
+                outs = b.encode(d, on_device=True)
+            b.sync()
+            dt = time.perf_counter() - t0
+            n = steps
+    finally:
+        b.close()
+    res = {"ms_per_step": round(1e3 * dt / n, 3), "Mpix_s": round(n * streams * frames * w * h / dt / 1e6, 1),
+           "frames_per_s": round(n * streams * frames / dt, 1), "pictures_per_step": streams * frames,
+           "dsv_bytes_per_step": int(sum(len(o) for o in outs))}
+    if check_frames:
+        # a fresh single-stream GPU encode of the first check_frames frames against the CPU checker
+        got = pkg.encode_clip(clip[:check_frames], w, h, fmt, device=dev, eos=False, **cli)
+        want, kind = ref_encode(pkg, A, clip[:check_frames], w, h, fmt, **cli)
+        res["bit_exact_vs_cpu"] = bool(got == want)
+        res["checked"] = "%d frames, 1 stream, vs %s" % (check_frames, kind)
+        # ... and the batch's own first stream starts with the same packets (CRF: streams are independent of the batch)
+        if crf and check_frames >= frames:
+            res["bit_exact_vs_cpu"] = res["bit_exact_vs_cpu"] and bytes(first[0]) == want
+    return res
+
+
+def decode_bench(pkg, A, dev, streams, reps):
+    """batched decoder (dsv1_decbatch_*): `streams` copies of a 1080p GOP=12 stream side by side, one packet of each per
+    call, decoded frames left in HBM; every frame of stream 0 compared with the oracle decoder's"""
+    clip = A.gen_clip(W, H, FMT, 0x10800003, GOP, style=0)
+    stream = pkg.encode_clip(clip, W, H, FMT, device=dev, qp=QP, gop=GOP, rc_mode_cli=1)
+    pk = A.split_packets(stream)
+    want = A.orc_decode(stream, W, H, FMT)
+    d = pkg.DecBatch(W, H, FMT, streams, device=dev)
+    try:
+        ok = True
+        k = 0
+        for p in pk:                                     # checked pass (host output of stream 0)
+            _, status, fnum = d.decode([p] * streams, on_device=True)
+            if status[0] == 0 and (p[5] & 4):
+                got = d.download()
+                ok = ok and k < len(want) and bool((got[0] == want[k]).all()) and bool((got[streams - 1] == want[k]).all())
+                k += 1
+        ok = ok and k == len(want)
+        # timed passes: the packet tables are built once (the C entry point is called directly, as a C caller would)
+        L = pkg.lib()
+        keep = [np.frombuffer(bytes(p) + b"\0" * 16, dtype=np.uint8).copy() for p in pk]
+        calls = []
+        for kk, p in enumerate(pk):
+            bufs = (pkg.Buf * streams)()
+            for s_ in range(streams):
+                bufs[s_].data = keep[kk].ctypes.data_as(C.POINTER(C.c_uint8))
+                bufs[s_].len = len(p)
+            calls.append(bufs)
+        status = (C.c_int * streams)()
+        fnum = (C.c_uint32 * streams)()
+        npic = sum(1 for p in pk if p[5] & 4)
+        d.sync()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            for bufs in calls:
+                rc = L.dsv1_decbatch_decode(d.h, bufs, d._dev, d.frame_bytes, 1, status, fnum)
+                if rc != 0:
+                    raise RuntimeError("dsv1_decbatch_decode rc=%d: %s" % (rc, L.dsvg_last_error().decode()))
+        d.sync()
+        dt = time.perf_counter() - t0
+        n = reps * npic * streams
+    finally:
+        d.close()
+    return {"Mpix_s": round(n * W * H / dt / 1e6, 1), "frames_per_s": round(n / dt, 1), "streams": streams,
+            "ms_per_call": round(1e3 * dt / (reps * len(pk)), 3), "bit_exact_vs_cpu": ok,
+            "checked": "%d frames of streams 0 and %d vs the oracle decoder" % (len(want), streams - 1),
+            "output": "decoded frames left in HBM (packed planar)"}
 
 
 def main():
@@ -79,6 +194,7 @@ def main():
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events (auto = the largest; none = no brackets, no roofline: counter passes)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive figure and the other shapes (configs 2, 4, 5, batched decode) reported after the headline")
     ap.add_argument("--input", choices=["hbm", "host", "pinned"], default="hbm",
                     help="where the raw frames are when a step starts: hbm (the metric), or host memory (pageable / pinned) "
                          "uploaded over PCIe inside the timed region (diagnostic, DESIGN.md section 7)")
@@ -230,6 +346,40 @@ def main():
                     # selection pass): what bounds the kernel itself, without the other coding stream's share
                     per_step = vi * nl / (args.steps + 1)          # the brackets also cover the batch that fills the pipeline
                     kinfo["valu_issue"]["busy_frac_exclusive"] = round(per_step * 4.0 / (1024 * 2.4e9 * table[prof_kernel][0] * 1e-3), 3)
+                # which roof is the kernel under?  Integer kernels that read each byte once and do a lot with it (the
+                # motion search: 15 candidate SADs, the half-pel lattice and the block statistics per block) sit under the
+                # VALU issue roof, not the HBM one: report against the closer roof and keep the other view beside it
+                vfrac = kinfo["valu_issue"]["busy_frac"]
+                if vfrac > kinfo["frac"]:
+                    peak_gi = 1024 * 2.4 / 4.0                     # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
+                    kinfo["hbm_view"] = {"achieved": kinfo["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": kinfo["frac"]}
+                    kinfo.update({"bound": "valu", "achieved": round(vfrac * peak_gi, 1), "peak": peak_gi, "unit": "G wave-instr/s", "frac": vfrac})
+
+    # ---- after the headline, outside its timed region: the same loop fed from pinned HOST memory ("frames
+    # pre-loaded in host RAM"; the upload of each batch over PCIe rides inside the step), never `value`
+    extras = rank == 0 and world == 1 and not args.no_extras and args.input == "hbm"
+    host_pinned = None
+    if extras:
+        ps = 3
+        host = b.pinned(batch_in.shape)
+        host[...] = batch_in
+        b.stage(host)
+        b.submit(host)
+        b.sync()
+        t1 = time.perf_counter()
+        b.stage(host)
+        for i in range(ps):
+            if i + 1 < ps:
+                b.stage(host)
+            b.submit(host)
+            b.collect(copy=False)
+        b.sync()
+        dth = time.perf_counter() - t1
+        b.collect(copy=False)
+        host_pinned = {"value": round(args.gops * GOP * W * H * ps / dth / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(1e3 * dth / ps, 3),
+                       "steps": ps, "note": "same workload, raw frames in pinned host memory, one %.2f GB upload per step inside the step (double-buffered ingest)"
+                                            % (batch_in.nbytes / 1e9)}
+        del host
 
     tmax = dt
     if world > 1:
@@ -282,6 +432,24 @@ def main():
             "roofline": kinfo,
             "cpu_baseline": cpu,
         }
+        if extras:
+            # the other shapes of BASELINE.json and the batched decoder, each with its own bit-exact check (measured
+            # after the headline; the headline's context is closed first so that every shape has the GPU to itself)
+            b.close()
+            res["value_host_pinned"] = host_pinned
+            shapes = {}
+            try:
+                shapes["cfg2_1080p_intra"] = dict(shape_bench(pkg, A, dev, 1920, 1080, 0x5, 64, 12, 4, 0x10800001, 12, qp=85, gop=0, rc_mode_cli=1),
+                                                  config="1920x1080 4:2:0 -gop0 -qp85 -rc_mode1, 64 streams x 12 frames per step")
+                shapes["cfg4_4k_gop12"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 16, 12, 4, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
+                                               config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 16 closed GOPs x 12 frames per step")
+                shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 2, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
+                                                 config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: serial per frame), 2 streams x 30 frames per step")
+                shapes["decode_1080p_batched"] = dict(decode_bench(pkg, A, dev, 64, 2),
+                                                      config="1920x1080 4:2:0 GOP=12 stream, dsv1_decbatch_*: 64 streams side by side, one picture of each per call")
+            except Exception as e:                       # the headline stands on its own
+                shapes["error"] = repr(e)
+            res["shapes"] = shapes
         print(json.dumps(res))
     b.close()
     if world > 1:
