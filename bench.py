@@ -203,6 +203,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    # one process per GPU: before anything touches the GPU, take this rank's share of the host cores (the session
+    # layer's worker threads, the runtime's helper threads and the first touch of the pinned buffers stay on it)
+    shard = importlib.import_module("digital-subband-video-1_amd.shard")
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    my_cores = shard.pin_rank_to_cores(local_rank, local_world)
     import torch
     import torch.distributed as dist
     # debugging aid for boxes with fewer GPUs than ranks (never set by the driver): all ranks share device 0 and the
@@ -427,6 +432,7 @@ def main():
                                       "pinned": "raw frames uploaded from pinned host memory each step (PCIe inclusive, diagnostic)"}[args.input]),
                        "gops_per_gpu": args.gops, "frames_per_step": args.gops * GOP * world,
                        "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world,
+                       "host_cores_rank0": len(my_cores),
                        "streams_on_own_hw_queue": L.dsvg_ctx_streams_apart(b.ctx)},
             "bit_exact_vs_cpu": bit_exact,
             "roofline": kinfo,

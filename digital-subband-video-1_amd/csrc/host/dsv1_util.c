@@ -1,3 +1,5 @@
+#define _GNU_SOURCE
+#include <sched.h>
 /* dsv1_util.c -- host glue the drop-in API needs around the GPU hot path: counting allocator
  * (dsv.c:41-96: zeroed, 16-byte header), log level (dsv.c:19-39), DSV_BUF (dsv.c:172-187), host frame
  * containers in the reference layout (frame.c:63-197), planar YUV file access (dsv.c:98-170), the
@@ -289,13 +291,21 @@ static int par_threads(int S)
         const char *e = getenv("DSV1_HOST_THREADS");
         if (e) n = atoi(e);
         else {
-            /* default: up to 6, but never more than half of this process's share of the host's cores (one process per
-             * GPU: LOCAL_WORLD_SIZE of the launcher tells how many share the node) */
+            /* default: up to 6, but never more than half of this process's share of the host's cores.  The share is
+             * the affinity mask when the launcher (bench.py: shard.pin_rank_to_cores) narrowed it, else the online cores
+             * divided by the ranks of the node (one process per GPU: LOCAL_WORLD_SIZE of the launcher) */
             const char *lw = getenv("LOCAL_WORLD_SIZE");
-            long cores = sysconf(_SC_NPROCESSORS_ONLN), ranks = lw ? atol(lw) : 1;
+            long online = sysconf(_SC_NPROCESSORS_ONLN), ranks = lw ? atol(lw) : 1, cores;
+            cpu_set_t set;
             if (ranks < 1) ranks = 1;
+            if (online < 1) online = 1;
+            cores = online / ranks;
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) {
+                const long allowed = CPU_COUNT(&set);
+                if (allowed > 0 && allowed < online) cores = allowed;     /* pinned: the mask is the share */
+            }
             if (cores < 1) cores = 1;
-            n = (int)(cores / ranks / 2);
+            n = (int)(cores / 2);
             if (n > 6) n = 6;
         }
         if (n < 1) n = 1;

@@ -26,3 +26,18 @@ def gather_streams(local_streams, dist=None, dst=0):
         return None
     allp = [p for part in gathered for p in part]
     return [b for _, b in sorted(allp)]
+
+
+def pin_rank_to_cores(local_rank, local_world):
+    """Give this rank a contiguous share of the cores the process may run on (os.sched_setaffinity) -- call it BEFORE
+    anything touches the GPU, so that the runtime's helper threads, the pinned staging buffers (first touch) and the
+    session layer's worker threads (dsv1_par_for sizes itself from the affinity mask) all stay on that share.
+    Returns the list of cores taken (all allowed cores when there is nothing to split)."""
+    import os
+    cores = sorted(os.sched_getaffinity(0))
+    if local_world <= 1 or len(cores) < local_world:
+        return cores
+    per = len(cores) // local_world
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    os.sched_setaffinity(0, mine)
+    return mine

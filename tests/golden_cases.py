@@ -25,8 +25,8 @@ STREAM_CASES = {
     "cfg3_1080p_gop12": (1920, 1080, A.SUBSAMP_420, 13, 0, 0x10800003, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
     "cfg3_1080p_gop12_style2": (1920, 1080, A.SUBSAMP_420, 4, 2, 0x10800004, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
     # BASELINE config 4 / 5 shapes (3840x2160), short
-    "cfg4_4k_gop12": (3840, 2160, A.SUBSAMP_420, 3, 0, 0x21600004, ["-gop12", "-qp85", "-rc_mode1", "-scd0"], dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
-    "cfg5_4k_444_abr": (3840, 2160, A.SUBSAMP_444, 3, 0, 0x21600005, ["-gop30", "-qp85", "-kbps20000"], dict(qp=85, gop=30, rc_mode_cli=0, kbps=20000)),
+    "cfg4_4k_gop12": (3840, 2160, A.SUBSAMP_420, 7, 0, 0x21600004, ["-gop12", "-qp85", "-rc_mode1", "-scd0"], dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
+    "cfg5_4k_444_abr": (3840, 2160, A.SUBSAMP_444, 7, 0, 0x21600005, ["-gop30", "-qp85", "-kbps20000"], dict(qp=85, gop=30, rc_mode_cli=0, kbps=20000)),
 }
 
 # operator-level known answers: name -> dict describing a seeded input
@@ -44,7 +44,66 @@ OP_CASES = {
     "bmc_360x200_422_far": dict(op="bmc", w=360, h=200, fmt=A.SUBSAMP_422, span=400, seed=32),
     "hme_352x288_style2": dict(op="hme", w=352, h=288, style=2, levels=3, seed=0xC1F041),
     "hme_704x480_style1": dict(op="hme", w=704, h=480, style=1, levels=3, seed=0xC1F042),
+    # 3840x2160: 64x64 blocks (the widest rows-per-lane path of the search, 32x32 chroma blocks)
+    "bmc_3840x2160_420": dict(op="bmc", w=3840, h=2160, fmt=A.SUBSAMP_420, span=90, seed=33),
+    "hme_3840x2160_style2": dict(op="hme", w=3840, h=2160, style=2, levels=5, seed=0xC1F043),
 }
+
+
+# ---- the seeded geometry / parameter sweep of tests/test_gpu_fuzz.py (defined here so that tools/make_goldens.py can
+# probe, in the build container, which of its inputs the REFERENCE itself cannot encode) --------------------------------
+def fuzz_cases():
+    rng = np.random.default_rng(0xD5F1)
+    fmts = [A.SUBSAMP_420, A.SUBSAMP_420, A.SUBSAMP_444, A.SUBSAMP_422, A.SUBSAMP_411]
+    out = []
+    for i in range(72):
+        big = i % 6 == 5                               # a few frames beyond every block-size threshold (352/704/1024/1280)
+        w = int(rng.integers(16, 700 if big else 215)) * 2
+        h = int(rng.integers(16, 400 if big else 150)) * 2
+        fmt = fmts[int(rng.integers(0, len(fmts)))]
+        if fmt == A.SUBSAMP_411:
+            w = (w + 3) & ~3
+        kw = dict(qp=int(rng.integers(15, 100)), gop=[0, 3, 12, 12][int(rng.integers(0, 4))], rc_mode_cli=int(rng.integers(0, 4) != 0))
+        if rng.integers(0, 3) == 0:
+            kw["scd"] = 0
+        out.append((w, h, fmt, 3 if big else int(rng.integers(3, 6)), int(rng.integers(0, 3)), kw, 0xF00D00 + i))
+    return out + [
+        # the smallest frames the reference accepts: chroma planes with only 3 / 4 / 5 transform levels
+        (32, 32, A.SUBSAMP_420, 4, 2, dict(qp=80, gop=12, rc_mode_cli=1), 0xF00E01),
+        (32, 32, A.SUBSAMP_411, 4, 1, dict(qp=90, gop=0, rc_mode_cli=1), 0xF00E02),
+        (40, 32, A.SUBSAMP_411, 4, 0, dict(qp=70, gop=3, rc_mode_cli=1), 0xF00E03),
+        (32, 64, A.SUBSAMP_420, 4, 2, dict(qp=85, gop=12, rc_mode_cli=0), 0xF00E04),
+    ]
+
+
+def fuzz_id(c):
+    return "%dx%d_f%x_%s" % (c[0], c[1], c[2], "_".join("%s%s" % kv for kv in sorted(c[5].items())))
+
+
+EXTREME_KINDS = ["noise01", "checker_flip", "stripes"]
+EXTREME_QPS = [99, 85, 60]
+EXTREME_GEOM = (352, 288, A.SUBSAMP_420, 5)
+EXTREME_KW = lambda qp: dict(qp=qp, gop=12, rc_mode_cli=1, scd=0, ipct=101)       # keep every inter candidate a P picture
+
+
+def extreme_clip(kind, qp):
+    """residuals at the edge of the 8-bit range: binary noise, flipping checkerboards, moving stripes"""
+    w, h, fmt, n = EXTREME_GEOM
+    rng = np.random.default_rng(7 + qp)
+    fb = A.frame_bytes(w, h, fmt)
+    clip = np.empty((n, fb), dtype=np.uint8)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for t in range(n):
+        if kind == "noise01":
+            y = (rng.integers(0, 2, size=(h, w)) * 255).astype(np.uint8)
+        elif kind == "checker_flip":
+            y = ((((xx >> (t % 3)) + (yy >> (t % 2)) + t) & 1) * 255).astype(np.uint8)
+        else:
+            y = ((((xx + 3 * t) // (1 + t)) & 1) * 255).astype(np.uint8)
+        c = (rng.integers(0, 2, size=(fb - w * h)) * 255).astype(np.uint8)
+        clip[t, : w * h] = y.reshape(-1)
+        clip[t, w * h:] = c
+    return clip
 
 
 def _sha(a):

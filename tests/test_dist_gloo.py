@@ -78,3 +78,13 @@ def test_two_rank_gop_sharding_equals_serial_stream():
         assert p.exitcode == 0
     assert len(sizes) == NGOPS
     assert ok, "sharded %d bytes vs serial %d bytes" % (n_joined, n_serial)
+
+
+def test_rank_core_pinning_splits_the_allowed_cores():
+    import subprocess
+    code = ("import os,sys,importlib; sys.path.insert(0, %r); sh = importlib.import_module('digital-subband-video-1_amd.shard'); "
+            "a = sorted(os.sched_getaffinity(0)); m = sh.pin_rank_to_cores(1, 2); "
+            "print(len(a), len(m), sorted(os.sched_getaffinity(0)) == m)" % A.ROOT)
+    r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, text=True, check=True)
+    n, mine, ok = r.stdout.split()
+    assert ok == "True" and (int(n) < 2 or int(mine) == int(n) // 2)

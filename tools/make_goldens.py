@@ -33,6 +33,29 @@ def sha(b):
     return hashlib.sha256(bytes(b)).hexdigest()
 
 
+def ref_encode_clip(clip, w, h, fmt, kw):
+    """one stream through the real reference LIBRARY (oracle/_ref/libdsv1ref.so), parameters mapped like the CLI does"""
+    import importlib
+    sys.path.insert(0, ROOT)
+    pkg = importlib.import_module("digital-subband-video-1_amd")       # only for the DSV_ENCODER struct + CLI flag mapping (host C, no GPU)
+    L = C.CDLL(A.REF_SO)
+    L.dsv_load_planar_frame.restype = C.c_void_p
+    L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    enc = pkg.make_encoder_cfg(w, h, fmt, **kw)
+    L.dsv_enc_start(C.byref(enc))
+    out = b""
+    bufs = (pkg.Buf * 4)()
+    for t in range(clip.shape[0]):
+        fr = L.dsv_load_planar_frame(fmt, clip[t].ctypes.data, w, h)
+        nb = L.dsv_enc(C.byref(enc), fr, bufs) & 3
+        for i in range(nb):
+            out += C.string_at(bufs[i].data, bufs[i].len)
+            L.dsv_buf_free(C.byref(bufs[i]))
+    L.dsv_enc_free(C.byref(enc))
+    return out
+
+
 def main():
     assert A.have_ref(), "build oracle/_ref first (make -C oracle ref)"
     os.makedirs(OUT, exist_ok=True)
@@ -61,6 +84,33 @@ def main():
         print(name, {k: v[:12] for k, v in ops[name].items()})
     with open(os.path.join(OUT, "ops.json"), "w") as f:
         json.dump(ops, f, indent=1, sort_keys=True)
+
+    # Inputs of the GPU sweep (tests/test_gpu_fuzz.py) on which the REFERENCE itself dies: each case is encoded by the
+    # reference library in a child process; what ends on a signal is listed, and the GPU tests skip it (there is no answer
+    # to be bit-exact with).  Probed here, once, instead of forking inside a process that holds the GPU.
+    skips = {}
+
+    def probe(case_id, clip, w, h, fmt, kw):
+        pid = os.fork()
+        if pid == 0:
+            try:
+                ref_encode_clip(clip, w, h, fmt, kw)
+            finally:
+                os._exit(0)
+        _, status = os.waitpid(pid, 0)
+        if os.WIFSIGNALED(status):
+            skips[case_id] = "signal %d" % os.WTERMSIG(status)
+            print("reference dies on", case_id, skips[case_id])
+
+    for c in G.fuzz_cases():
+        w, h, fmt, n, style, kw, seed = c
+        probe("fuzz:" + G.fuzz_id(c), A.gen_clip(w, h, fmt, seed, n, style=style), w, h, fmt, kw)
+    for kind in G.EXTREME_KINDS:
+        for qp in G.EXTREME_QPS:
+            w, h, fmt, n = G.EXTREME_GEOM
+            probe("extreme:%s:%d" % (kind, qp), G.extreme_clip(kind, qp), w, h, fmt, G.EXTREME_KW(qp))
+    with open(os.path.join(OUT, "ref_crash_skips.json"), "w") as f:
+        json.dump(skips, f, indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
