@@ -213,6 +213,7 @@ int Slab::alloc(size_t n, bool zero)
     if (e != hipSuccess) { dsvg_set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e)); return DSVG_ERR_HIP; }
     if (zero) {
         e = hipMemset(raw, 0, n + 2 * GUARD_BYTES);
+        if (e == hipSuccess) e = hipDeviceSynchronize();      // the users' streams are non-blocking: no implicit order against this NULL-stream fill
         if (e != hipSuccess) { dsvg_set_error("hipMemset failed: %s", hipGetErrorString(e)); return DSVG_ERR_HIP; }
     }
     p = raw + GUARD_BYTES;

@@ -44,7 +44,7 @@ static int pick_streams(hipStream_t *out, int want)
     const int NC = 12;
     hipStream_t cand[NC] = {};
     int nc = 0;
-    for (; nc < NC; nc++) if (hipStreamCreate(&cand[nc]) != hipSuccess) break;
+    for (; nc < NC; nc++) if (hipStreamCreateWithFlags(&cand[nc], hipStreamNonBlocking) != hipSuccess) break;
     if (nc < want) { for (int i = 0; i < nc; i++) (void)hipStreamDestroy(cand[i]); return -1; }
     hipEvent_t e0 = nullptr, ea = nullptr, eb = nullptr;
     bool probe = !getenv("DSV1_NO_STREAM_PROBE") && hipEventCreate(&e0) == hipSuccess && hipEventCreate(&ea) == hipSuccess && hipEventCreate(&eb) == hipSuccess;
@@ -258,13 +258,13 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         const int good = pick_streams(ps, want);
         if (good < 0) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
         c->st = ps[0]; c->st_a = ps[1];
-        for (int g = 1; g < std::max(ncs, 2); g++) {
-            c->stx[g] = ps[1 + g];
-            if (hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
-        }
+        for (int g = 1; g < std::max(ncs, 2); g++) c->stx[g] = ps[1 + g];      // every stream is owned by the ctx before anything can fail
         c->st_c = ps[want - 1];
+        for (int g = 1; g < std::max(ncs, 2); g++)
+            if (hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
         c->streams_apart = good;
-    } else if (hipStreamCreate(&c->st) != hipSuccess || hipStreamCreate(&c->st_a) != hipSuccess || hipStreamCreate(&c->st_c) != hipSuccess) {
+    } else if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->st_a, hipStreamNonBlocking) != hipSuccess ||
+               hipStreamCreateWithFlags(&c->st_c, hipStreamNonBlocking) != hipSuccess) {
         dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP);      // one picture (or a few) at a time: streams as they come
     }
     if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
@@ -317,6 +317,8 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         if ((rc = dmalloc(&c->ilist_d, (size_t)c->nblk * std::max(S, O), false))) return fail(rc);
     }
     (void)J;
+    // the pipeline streams are non-blocking (no implicit ordering against the NULL stream the memsets above ran on)
+    if (hipDeviceSynchronize() != hipSuccess) { dsvg_set_error("hipDeviceSynchronize failed"); return fail(DSVG_ERR_HIP); }
     *out = c;
     return DSVG_OK;
 }
@@ -362,12 +364,13 @@ extern "C" int dsvg_ctx_tile_stats(dsvg_ctx *c, unsigned long long out[4], int e
     HIPCHK(hipSetDevice(c->device));
     OPCHK(dsvg_ctx_sync(c));
     unsigned v[4 * 64];
-    HIPCHK(hipMemcpy(v, c->stat, sizeof(v), hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(v, c->stat, sizeof(v), hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipMemsetAsync(c->stat, 0, sizeof(v), c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
     for (int i = 0; i < 4; i++) {
         out[i] = 0;
         for (int k = 0; k < 64; k++) out[i] += v[64 * i + k];
     }
-    HIPCHK(hipMemset(c->stat, 0, sizeof(v)));
     c->stats_on = enable != 0;
     return DSVG_OK;
 }
@@ -651,9 +654,12 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     // the staging block [base, base+total) was last used when these out slots were coded before; that
     // call completed long ago if its results were fetched -- make sure anyway
     const long call = c->ncalls++;
-    for (int i = 0; i < total; i++) {
-        const int e = c->slot_ev[base + i];
-        if (e >= 0) { HIPCHK(hipEventSynchronize(c->ev_coded[e])); break; }
+    {
+        std::vector<char> seen(c->ev_coded.size(), 0);           // the block may have been coded last by several calls
+        for (int i = 0; i < total; i++) {
+            const int e = c->slot_ev[base + i];
+            if (e >= 0 && !seen[e]) { seen[e] = 1; HIPCHK(hipEventSynchronize(c->ev_coded[e])); }
+        }
     }
     // Two coding streams, each with half of the pictures of every frame step: the chain of a step has a dozen small,
     // latency-bound kernels (levels >= 4, LL quantiser, scan) during which one half leaves the chip to the other
@@ -672,6 +678,32 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         anyP = anyP || nIs[t] == 0;
     }
     if (!anyP) NG = 1;               // I pictures only: their kernels are large and gain nothing (intra-only measured 3 % slower split)
+    if (NG > 1) {
+        // The groups run on different streams and are only joined at the end of the call: a reconstruction written by
+        // group g in step k may be read as a reference in step k+1 only by group g (same stream = ordered), and no two
+        // groups may write one slot.  Callers that keep stream s at position s of every step satisfy this; any other
+        // job order takes the single-stream path instead of racing.
+        std::vector<int> writer((size_t)c->n_recon, -1);
+        for (int t = 0; t < nsteps && NG > 1; t++) {
+            const dsvg_pic_job *js = jobs + (size_t)t * njobs;
+            std::vector<int> ord;
+            for (int i = 0; i < njobs; i++) if (js[i].ref_recon_slot < 0) ord.push_back(i);
+            for (int i = 0; i < njobs; i++) if (js[i].ref_recon_slot >= 0) ord.push_back(i);
+            std::vector<int> now((size_t)c->n_recon, -1);
+            for (int k = 0; k < njobs; k++) {
+                const dsvg_pic_job &j = js[ord[k]];
+                int gg = 0;                                          // group of device position k (the gk[] split below)
+                while (gg + 1 < NG && k >= (int)((long)njobs * (gg + 1) / NG)) gg++;
+                if (j.ref_recon_slot >= 0 && j.ref_recon_slot < c->n_recon && writer[j.ref_recon_slot] >= 0 && writer[j.ref_recon_slot] != gg) NG = 1;
+                if (j.recon_slot >= 0 && j.recon_slot < c->n_recon) {
+                    if (now[j.recon_slot] >= 0 && now[j.recon_slot] != gg) NG = 1;
+                    if (writer[j.recon_slot] >= 0 && writer[j.recon_slot] != gg) NG = 1;     // overwriting what another group may still read
+                    now[j.recon_slot] = gg;
+                }
+            }
+            for (int r = 0; r < c->n_recon; r++) if (now[r] >= 0) writer[r] = now[r];
+        }
+    }
     int gk[DSVG_MAX_CODE_STREAMS + 1];                        // device jobs [gk[g], gk[g+1]) of every step -> stream g
     for (int g = 0; g <= NG; g++) gk[g] = (int)((long)njobs * g / NG);
     std::vector<int> ioff((size_t)NG * nsteps, 0), icnt((size_t)NG * nsteps, 0);
@@ -731,7 +763,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         HIPCHK(hipEventRecord(c->ev_fork, c->st));            // tables uploaded, source frames ready (st waited for ev_a)
         for (int g = 1; g < NG; g++) {
             if (!c->stx[g]) {
-                HIPCHK(hipStreamCreate(&c->stx[g]));
+                HIPCHK(hipStreamCreateWithFlags(&c->stx[g], hipStreamNonBlocking));
                 HIPCHK(hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming));
             }
             HIPCHK(hipStreamWaitEvent(c->stx[g], c->ev_fork, 0));
@@ -916,11 +948,11 @@ extern "C" int dsvg_pack_recons(dsvg_ctx *c, int n, const int *recon_slots, void
 
 // ------------------------------------------------------------------------------------------------
 namespace {
-struct Rd {                          // MSB-first reader (bs.c:111-125,148-157,209-219)
-    const uint8_t *p; unsigned pos;
-    unsigned bit() { unsigned b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u; pos++; return b; }
+struct Rd {                          // MSB-first reader (bs.c:111-125,148-157,209-219), bounded: past `end` bits read as 1
+    const uint8_t *p; unsigned pos, end;
+    unsigned bit() { if (pos >= end) return 1u; unsigned b = (p[pos >> 3] >> (7 - (pos & 7))) & 1u; pos++; return b; }
     unsigned bits(int n) { unsigned v = 0; while (n--) v = (v << 1) | bit(); return v; }
-    unsigned ueg() { unsigned m = 1; while (!bit()) m = (m << 1) | bit(); return m - 1; }
+    unsigned ueg() { unsigned m = 1; int k = 0; while (!bit() && k++ < 32) m = (m << 1) | bit(); return m - 1; }
     int seg() { int v = (int)ueg(); return (v && bit()) ? -v : v; }
     int neg() { int v = (int)ueg() + 1; return bit() ? -v : v; }
     void align() { pos = (pos + 7u) & ~7u; }
@@ -989,7 +1021,7 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         for (int p = 0; p < 3; p++) {
             // the host reads only the plane header (hzcc.c:479-483,307-311): SEG(DC), the 32-bit run count; the
             // code chain is parsed on the device (k_hz_parse) from the uploaded bytes
-            Rd rd{j.plane_data[p], 0};
+            Rd rd{j.plane_data[p], 0, (unsigned)j.plane_len[p] * 8u};
             jb.dec_dc[p] = rd.seg();
             rd.align();
             jb.dec_runs[p] = (int)rd.bits(32);

@@ -31,9 +31,10 @@ DSV_META *dsv_get_metadata(DSV_DECODER *d)
 }
 
 /* packet header (dsv_decoder.c:300-318): returns the packet type, leaves r after the two link words */
-static int parse_packet_header(bitw *r, uint8_t *data, int *type)
+static int parse_packet_header(bitw *r, uint8_t *data, unsigned len, int *type)
 {
-    bw_init(r, data);
+    if (len < DSV_PACKET_HDR_SIZE) return -1;
+    br_init(r, data, len);
     if (br_bits(r, 8) != 'D' || br_bits(r, 8) != 'S' || br_bits(r, 8) != 'V' || br_bits(r, 8) != '1') return -1;
     (void)br_bits(r, 8);
     *type = (int)br_bits(r, 8);
@@ -62,8 +63,11 @@ static int parse_picture_head(bitw *r, DSV_FNUM *fn, int *bw_, int *bh_)
 
 /* rest of the picture packet: stability flags (decode_stability_blocks dsv_decoder.c:127-145), motion
  * (decode_motion dsv_decoder.c:73-124), quantiser and the three plane payloads -> a device job.
- * stable[nblk] and mvs[nblk] are caller storage (zeroed here). */
-static int parse_picture_body(bitw *r, uint8_t *data, const dsvg_geom *g, int has_ref, unsigned char *stable, DSV_MV *mvs, dsvg_dec_job *job)
+ * stable[nblk] and mvs[nblk] are caller storage (zeroed here).  Unlike the reference (which only checks
+ * plen <= framesz * 2) every length the packet announces is held against the packet's own length `len`: a truncated or
+ * hostile packet is refused, never read past. */
+static int sub_fits(const bitw *r, unsigned n, unsigned len) { return !r->over && n <= len && bw_bytes(r) <= len - n; }
+static int parse_picture_body(bitw *r, uint8_t *data, unsigned len, const dsvg_geom *g, int has_ref, unsigned char *stable, DSV_MV *mvs, dsvg_dec_job *job)
 {
     const int nbh = g->nblocks_h, nbv = g->nblocks_v, nblk = nbh * nbv;
     int i, j, c;
@@ -74,7 +78,8 @@ static int parse_picture_body(bitw *r, uint8_t *data, const dsvg_geom *g, int ha
         bw_align(r);
         n = br_ueg(r);
         bw_align(r);
-        zr_init(&z, data + bw_bytes(r));
+        if (!sub_fits(r, n, len)) { dsv1_log(1, "stability block runs past the packet"); return -1; }
+        zr_init_rd(&z, data + bw_bytes(r), n);
         r->pos += n * 8;
         for (i = 0; i < nblk; i++) stable[i] = (unsigned char)zr_get(&z);
     }
@@ -89,10 +94,11 @@ static int parse_picture_body(bitw *r, uint8_t *data, const dsvg_geom *g, int ha
         for (i = 0; i < 4; i++) {
             const unsigned n = br_ueg(r);
             bw_align(r);
-            bw_init(&sub[i], data + bw_bytes(r));
+            if (!sub_fits(r, n, len)) { dsv1_log(1, "motion data run past the packet"); return -1; }
+            br_init(&sub[i], data + bw_bytes(r), n);
             r->pos += n * 8;
         }
-        zr_init(&modes, sub[0].p);
+        zr_init_rd(&modes, sub[0].p, sub[0].end >> 3);
         for (j = 0; j < nbv; j++)
             for (i = 0; i < nbh; i++) {
                 DSV_MV *mv = &mvs[i + j * nbh];
@@ -118,7 +124,8 @@ static int parse_picture_body(bitw *r, uint8_t *data, const dsvg_geom *g, int ha
         bw_align(r);
         plen = (int)br_bits(r, 32);
         bw_align(r);
-        if (plen <= 0 || (size_t)plen > g->plane_out_cap[c] * 4 + 64) {
+        /* one limit with the device side (dsvg_decode_pictures stages plane_len + 64 bytes per plane) */
+        if (plen <= 0 || (size_t)plen + 64 > g->plane_out_cap[c] || !sub_fits(r, (unsigned)plen, len)) {
             dsv1_log(1, "plane length was strange: %d", plen);
             return -1;
         }
@@ -142,7 +149,7 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
     int type, is_ref, has_ref, bw_, bh_, nblk, i, c, rc, ret = DSV_DEC_ERROR;
 
     *fn = (DSV_FNUM)-1;
-    if (parse_packet_header(&r, buffer->data, &type)) {
+    if (parse_packet_header(&r, buffer->data, buffer->len, &type)) {
         dsv1_log(1, "bad 4cc");
         dsv_buf_free(buffer);
         return DSV_DEC_ERROR;
@@ -187,7 +194,7 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
     nblk = ss->g.nblocks_h * ss->g.nblocks_v;
     stable = (unsigned char *)calloc((size_t)nblk, 1);
     mvs = (DSV_MV *)calloc((size_t)nblk, sizeof(DSV_MV));
-    if (parse_picture_body(&r, buffer->data, &ss->g, has_ref, stable, mvs, &job)) goto done;
+    if (parse_picture_body(&r, buffer->data, buffer->len, &ss->g, has_ref, stable, mvs, &job)) goto done;
     if (has_ref && !ss->have_ref) {
         dsv1_log(2, "reference frame not found");
         goto done;
@@ -282,7 +289,7 @@ static void parse_stream(void *vp, int s, int tid)
     (void)tid;
     pc->status[s] = DSV_DEC_ERROR;
     pc->fnum[s] = (DSV_FNUM)-1;
-    if (!pc->packets[s].data || parse_packet_header(&r, pc->packets[s].data, &type)) return;
+    if (!pc->packets[s].data || parse_packet_header(&r, pc->packets[s].data, pc->packets[s].len, &type)) return;
     if (!(type & DSV_PT_PIC)) {
         if (type == DSV_PT_META) {
             DSV_META m;
@@ -300,7 +307,7 @@ static void parse_stream(void *vp, int s, int tid)
         dsv1_log(1, "stream %d: block size %dx%d differs from the encoder rule for this frame size", s, bw_, bh_);
         return;
     }
-    if (parse_picture_body(&r, pc->packets[s].data, &d->g, has_ref, d->stable + (size_t)s * d->nblk, d->mvs + (size_t)s * d->nblk, job)) return;
+    if (parse_picture_body(&r, pc->packets[s].data, pc->packets[s].len, &d->g, has_ref, d->stable + (size_t)s * d->nblk, d->mvs + (size_t)s * d->nblk, job)) return;
     if (has_ref && !d->have_ref[s]) {
         dsv1_log(2, "stream %d: reference frame not found", s);
         return;

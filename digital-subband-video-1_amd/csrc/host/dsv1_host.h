@@ -10,9 +10,12 @@
 #include <string.h>
 #include "../../../include/dsv1_api.h"
 
-typedef struct { uint8_t *p; unsigned pos; } bitw;
+/* `end` bounds the READER (bits): past it every bit reads as 1 -- which ends any exp-Golomb prefix -- and `over` is set,
+ * so a truncated or hostile packet can neither run the reader off its buffer nor loop; the writer ignores it */
+typedef struct { uint8_t *p; unsigned pos, end; int over; } bitw;
 
-static inline void bw_init(bitw *b, uint8_t *buf) { b->p = buf; b->pos = 0; }
+static inline void bw_init(bitw *b, uint8_t *buf) { b->p = buf; b->pos = 0; b->end = ~0u; b->over = 0; }
+static inline void br_init(bitw *b, uint8_t *buf, unsigned nbytes) { b->p = buf; b->pos = 0; b->end = nbytes > 0x1fffffffu ? ~0u : nbytes * 8u; b->over = 0; }
 static inline void bw_align(bitw *b) { b->pos = (b->pos + 7u) & ~7u; }
 static inline unsigned bw_bytes(const bitw *b) { return b->pos >> 3; }
 static inline void bw_bit(bitw *b, unsigned one)
@@ -40,14 +43,22 @@ static inline void bw_bytes_in(bitw *b, const uint8_t *src, unsigned n)
     b->pos += n * 8u;
 }
 
-static inline unsigned br_bit(bitw *b) { unsigned v = (b->p[b->pos >> 3] >> (7 - (b->pos & 7))) & 1u; b->pos++; return v; }
+static inline unsigned br_bit(bitw *b)
+{
+    unsigned v;
+    if (b->pos >= b->end) { b->over = 1; return 1u; }
+    v = (b->p[b->pos >> 3] >> (7 - (b->pos & 7))) & 1u;
+    b->pos++;
+    return v;
+}
 static inline unsigned br_bits(bitw *b, int n) { unsigned v = 0; while (n--) v = (v << 1) | br_bit(b); return v; }
-static inline unsigned br_ueg(bitw *b) { unsigned m = 1; while (!br_bit(b)) m = (m << 1) | br_bit(b); return m - 1; }
+static inline unsigned br_ueg(bitw *b) { unsigned m = 1; int k = 0; while (!br_bit(b) && k++ < 32) m = (m << 1) | br_bit(b); return m - 1; }
 static inline int br_seg(bitw *b) { int v = (int)br_ueg(b); return (v && br_bit(b)) ? -v : v; }
 
 /* zero-bit run-length coder (bs.c:222-267) */
 typedef struct { bitw b; int nz; } zrle;
 static inline void zr_init(zrle *z, uint8_t *buf) { bw_init(&z->b, buf); z->nz = 0; }
+static inline void zr_init_rd(zrle *z, uint8_t *buf, unsigned nbytes) { br_init(&z->b, buf, nbytes); z->nz = 0; }
 static inline void zr_put(zrle *z, int bit) { if (bit) { bw_ueg(&z->b, (unsigned)z->nz); z->nz = 0; } else z->nz++; }
 static inline int zr_end(zrle *z) { bw_ueg(&z->b, (unsigned)z->nz); z->nz = 0; bw_align(&z->b); return (int)bw_bytes(&z->b); }
 static inline int zr_get(zrle *z)

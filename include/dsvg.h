@@ -181,7 +181,9 @@ typedef struct {
 int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
 /* nsteps consecutive frame steps of njobs pictures each (jobs[step*njobs + j]) in one call: one upload of
  * all tables, kernel chains back to back; step k+1 may predict from the reconstructions of step k.  The out
- * slots of the call must form one contiguous block. */
+ * slots of the call must form one contiguous block.  With several coding streams (dsvg_ctx_code_streams) the jobs of a
+ * step are shared out by position; a call in which a reconstruction slot would be written and read (or written twice) by
+ * jobs of different shares is run on one stream instead -- always correct, fastest when stream s keeps position s. */
 int dsvg_code_batch(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
-                        "--gops", "8", "--cpu-gops", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                        "--gops", "8", "--cpu-gops", "2", "--no-extras"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, p.stdout[-2000:]
@@ -32,3 +32,18 @@ def test_bench_line_has_the_contract_fields():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0
+
+
+def test_bench_line_carries_the_other_shapes():
+    """after the headline: the PCIe-inclusive figure, configs 2 / 4 / 5 and the batched decoder, each bit-exact"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1",
+                        "--gops", "8", "--cpu-gops", "1"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    assert d["value_host_pinned"]["value"] > 0 and d["value_host_pinned"]["value"] < d["value"] * 1.5
+    sh = d["shapes"]
+    assert "error" not in sh, sh
+    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg5_4k_444_abr", "decode_1080p_batched"):
+        assert sh[k]["Mpix_s"] > 0 and sh[k]["bit_exact_vs_cpu"] is True, (k, sh[k])
+    c = d["cpu_baseline"]
+    assert c["nproc"] >= 1 and isinstance(c["cpu_model"], str)

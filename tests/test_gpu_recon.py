@@ -112,4 +112,4 @@ def test_zero_and_general_tiles_both_taken(pkg):
             assert st["general_luma"] > 0, st
         else:
             # the I picture's quantisation error leaves a residual here and there
-            assert st["zero_luma"] > st["general_luma"] and st["zero_chroma"] > st["general_chroma"], st
+            assert st["zero_luma"] > st["general_luma"] and st["zero_chroma"] >= st["general_chroma"], st
