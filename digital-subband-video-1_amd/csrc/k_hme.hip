@@ -195,42 +195,40 @@ static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, int 
     }
 }
 
-template <bool LEVEL0>
-__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs)
+// The work of one block.  NKB > 0: the block is FULL (bw == 64: all sixteen column groups, bh == 4 * NKB: every lane owns
+// exactly NKB rows) -- row counts, masks and "does this row exist" are compile-time facts, so the search loops carry no
+// per-row scalar state (the generic form keeps ~40 row offsets and row-exists masks in SGPRs, which the compiler spills
+// to VGPR lanes and reads back with two v_readlane per row).  NKB == 0: any block (edges, small frames).
+template <bool LEVEL0, int NKB>
+static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, int pair, int i, int j, HmeShared &S)
 {
-    __shared__ HmeShared S;
+    constexpr bool FAST = NKB > 0;
+    constexpr int NKR = FAST ? NKB : NK;                // rows a lane may own
     const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;             // column group (4 px) / row group
     const int step = 1 << level;
-    const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
-    const int item = d_xcd_remap(blockIdx.x, nvx * nvy * npairs);
-    if (item >= nvx * nvy * npairs) return;
-    const int pair = item / (nvx * nvy), vb = item - pair * (nvx * nvy);
-    const int vi = vb % nvx, vj = vb / nvx;
-    const int i = vi * step, j = vj * step;
     const FrameLayout &L = A.L[level];
     const int fw = L.w[0], fh = L.h[0], stride = L.stride[0];
     const int BW = A.blk_w, BH = A.blk_h;
     const int bx = (i * BW) >> level, by = (j * BH) >> level;
-    if (bx >= fw || by >= fh) return;                       // stays a zero inter vector (hme.c:441-444)
     const int cur = A.cur_slots[pair], rf = A.ref_slots[pair];
     const uint8_t *sp = A.slab[level] + (size_t)cur * L.pitch + L.off[0];
     const uint8_t *rp = A.slab[level] + (size_t)rf * L.pitch + L.off[0];
-    const int bw = min(max(fw - bx, 0), BW), bh = min(max(fh - by, 0), BH);
+    const int bw = FAST ? 64 : min(max(fw - bx, 0), BW), bh = FAST ? 4 * NKB : min(max(fh - by, 0), BH);
     DMV *mf = A.mvf + ((size_t)pair * (A.levels + 1) + level) * A.nblk;
     const DMV *parent = level < A.levels ? A.mvf + ((size_t)pair * (A.levels + 1) + level + 1) * A.nblk : nullptr;
 
     // this thread's pixels: columns 4cg..4cg+3 of the nkb ADJACENT rows rg*nkb .. rg*nkb+nkb-1 (adjacent rows let the
     // +-1 search reuse every reference row for three source rows)
-    const int nkb = (bh + NRG - 1) / NRG;
+    const int nkb = FAST ? NKB : (bh + NRG - 1) / NRG;
     const int r0 = rg * nkb;
-#define ROWOK(k) ((k) < nkb && r0 + (k) < bh)
-    const bool uni = (bh % NRG) == 0;                   // every lane owns exactly nkb rows
+#define ROWOK(k) (FAST || ((k) < nkb && r0 + (k) < bh))
+    const bool uni = FAST || (bh % NRG) == 0;           // every lane owns exactly nkb rows
     const int xcol = 4 * cg;
-    const unsigned cmask = xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u));
-    unsigned srcw[NK];
+    const unsigned cmask = FAST ? 0xffffffffu : (xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u)));
+    unsigned srcw[NKR];
 #pragma unroll
-    for (int k = 0; k < NK; k++) {
+    for (int k = 0; k < NKR; k++) {
         const int r = r0 + k;
         srcw[k] = 0;
         if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
@@ -280,6 +278,19 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
                 const int cdx = ((int)(int16_t)(all & 0xffff)) >> level, cdy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
                 if (src_ok && !frame_invalid(fw, fh, bx + cdx, by + cdy, bw, bh)) {
                     validmask |= 1u << k;
+                    if constexpr (FAST) {
+                        // every row exists in every lane: NKB 8-byte loads back to back off a running pointer, then the SADs
+                        const uint8_t *p0 = rp + (long)(by + cdy + r0) * stride + bx + cdx + xcol;
+                        const unsigned sh = (unsigned)(((uintptr_t)p0) & 3);
+                        const uint8_t *q = p0 - sh;
+                        uint2 w[NKB];
+#pragma unroll
+                        for (int u = 0; u < NKB; u++) { w[u] = *reinterpret_cast<const uint2 *>(q); q += stride; }
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int u = 0; u < NKB; u++) acc[k] = __builtin_amdgcn_sad_u8(srcw[u], __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh), acc[k]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else
                     if (cmask && r0 < bh) {
                         // the candidate's rows are fetched back to back, then scored
                         const uint8_t *p0 = rp + (long)(by + cdy + r0) * stride + bx + cdx + xcol;
@@ -341,6 +352,37 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
         unsigned acc[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) acc[k] = 0;
+        if constexpr (FAST) {
+            const uint8_t *g0 = rp + (long)(by + dy - 1 + r0) * stride + (bx + dx - 1 + xcol);
+            const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
+            const uint8_t *q = g0 - mis;
+            constexpr int NR = NKB + 2, HB = (NR + 2) / 3;     // reference rows, rows per batch (three batches: registers)
+            unsigned v[3][3];                                  // rolling: v[t % 3][ox] = reference row t, offset ox
+#pragma unroll
+            for (int b0 = 0; b0 < NR; b0 += HB) {
+                struct __attribute__((aligned(4))) U3 { unsigned x, y, z; } d[HB];
+#pragma unroll
+                for (int u = 0; u < HB; u++)
+                    if (b0 + u < NR) { d[u] = *reinterpret_cast<const U3 *>(q); q += stride; }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < HB; u++) {
+                    const int t = b0 + u;
+                    if (t >= NR) break;
+                    const unsigned lo = __builtin_amdgcn_alignbyte(d[u].y, d[u].x, mis);       // window bytes 0..3 of the row
+                    const unsigned hi = __builtin_amdgcn_alignbyte(d[u].z, d[u].y, mis);       //              4..7
+                    v[t % 3][0] = lo;
+                    v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u);
+                    v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u);
+                    const int k = t - 2;                           // source row whose three reference rows are now complete
+                    if (k >= 0) {
+#pragma unroll
+                        for (int c9 = 0; c9 < 9; c9++) acc[c9] = __builtin_amdgcn_sad_u8(srcw[k], v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
         if (cmask && r0 < bh) {
             const uint8_t *g0 = rp + (long)(by + dy - 1 + r0) * stride + (bx + dx - 1 + xcol);
             const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
@@ -480,12 +522,16 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     // the zero-motion reference block (variance test, veto, quadrant votes) is read straight from global memory:
     // bx + 4cg is dword aligned, every thread takes the rows it owns
     __syncthreads();                                    // rwin complete
-    unsigned zrow[NK];
-    {
+    unsigned zrow[NKR];
+    if constexpr (FAST) {
+        const uint8_t *zq = rp + (long)(by + r0) * stride + bx + xcol;
+#pragma unroll
+        for (int kk = 0; kk < NKR; kk++) { zrow[kk] = *reinterpret_cast<const unsigned *>(zq); zq += stride; }
+    } else {
         const unsigned *zp = reinterpret_cast<const unsigned *>(rp + (long)(by + r0) * stride + bx + xcol);
         const int sdw = stride >> 2;
 #pragma unroll
-        for (int kk = 0; kk < NK; kk++) zrow[kk] = (cmask && r0 < bh) ? zp[(long)min(kk, nkb - 1) * sdw] : 0u;
+        for (int kk = 0; kk < NKR; kk++) zrow[kk] = (cmask && r0 < bh) ? zp[(long)min(kk, nkb - 1) * sdw] : 0u;
     }
     // ---- statistics: one fused pass + one 8-value and one 10-value reduction
     unsigned st[8];                 // src block gh,gv,s1,s2 ; zref s1,s2 ; spare
@@ -495,10 +541,10 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
         // the row above this thread's first row belongs to the previous row group: lane - 16, its last row
         unsigned lastw = srcw[0];
 #pragma unroll
-        for (int k = 1; k < NK; k++) lastw = (k == nkb - 1) ? srcw[k] : lastw;
+        for (int k = 1; k < NKR; k++) lastw = (k == nkb - 1) ? srcw[k] : lastw;
         unsigned upw = (unsigned)__shfl_up((int)lastw, 16);
 #pragma unroll
-        for (int kk = 0; kk < NK; kk++) {
+        for (int kk = 0; kk < NKR; kk++) {
             const int r = r0 + kk;
             const unsigned curw = srcw[kk];
             // horizontal neighbours: bytes x+1..x+4 of the same row; the 4th comes from the next column group = lane + 1
@@ -676,6 +722,30 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
     }
 }
 
+// one wave per visited block and frame pair; NKBF = rows per lane of a FULL block of this geometry (0: none is special)
+template <bool LEVEL0, int NKBF>
+__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs)
+{
+    __shared__ HmeShared S;
+    const int step = 1 << level;
+    const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
+    const int item = d_xcd_remap(blockIdx.x, nvx * nvy * npairs);
+    if (item >= nvx * nvy * npairs) return;
+    const int pair = item / (nvx * nvy), vb = item - pair * (nvx * nvy);
+    const int vi = vb % nvx, vj = vb / nvx;
+    const int i = vi * step, j = vj * step;
+    const int fw = A.L[level].w[0], fh = A.L[level].h[0];
+    const int bx = (i * A.blk_w) >> level, by = (j * A.blk_h) >> level;
+    if (bx >= fw || by >= fh) return;                       // stays a zero inter vector (hme.c:441-444)
+    if constexpr (NKBF > 0) {
+        if (A.blk_w == 64 && fw - bx >= 64 && fh - by >= 4 * NKBF && A.blk_h == 4 * NKBF) {
+            hme_block<LEVEL0, NKBF>(A, level, pair, i, j, S);
+            return;
+        }
+    }
+    hme_block<LEVEL0, 0>(A, level, pair, i, j, S);
+}
+
 // second pass of level 0: high_detail from the causal neighbours' final flags (hme.c:621-648)
 __global__ __launch_bounds__(256) void k_hme_detail(HmeArgs A)
 {
@@ -714,8 +784,13 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         if (level == 0)             // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681)
             px += 2.0 * npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]);
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
-        if (level > 0) hipLaunchKernelGGL((k_hme_level<false>), dim3(xcd_grid(nvx * nvy * npairs)), dim3(NT), 0, st, A, level, npairs);
-        else           hipLaunchKernelGGL((k_hme_level<true>), dim3(xcd_grid(nvx * nvy * npairs)), dim3(NT), 0, st, A, level, npairs);
+        const dim3 grid(xcd_grid(nvx * nvy * npairs)), blk(NT);
+        // rows per lane of a full block (64 wide, blk_h = 4 * rows): those blocks take the specialised body
+        const int nkbf = (A.blk_w == 64 && A.blk_h % 4 == 0) ? A.blk_h / 4 : 0;
+#define HME_LAUNCH(L0, N) hipLaunchKernelGGL((k_hme_level<L0, N>), grid, blk, 0, st, A, level, npairs)
+#define HME_PICK(L0) do { switch (nkbf) { case 16: HME_LAUNCH(L0, 16); break; case 12: HME_LAUNCH(L0, 12); break; case 8: HME_LAUNCH(L0, 8); break; \
+                                          default: HME_LAUNCH(L0, 0); } } while (0)
+        if (level > 0) HME_PICK(false); else HME_PICK(true);
         if (pf) pf->end(st);
     }
     if (pf) pf->begin(st, KID_HME_DETAIL, 0.0);

@@ -1154,7 +1154,7 @@ static __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __buil
 static __device__ __forceinline__ s16x2 pk_rdiv2(s16x2 v) { return (v + (short)1 + (v >> 15)) >> 1; }
 static __device__ __forceinline__ s16x2 pk_rdiv4(s16x2 v) { return (v + (short)2 + (v >> 15)) >> 2; }
 static __device__ __forceinline__ s16x2 pk_div4(s16x2 v) { return (v + ((v >> 15) & (short)3)) >> 2; }
-static __device__ __forceinline__ s16x2 pk_nudge(s16x2 ll, s16x2 lp, s16x2 ln, s16x2 det, short hqp)      // d_nudge x 2
+static __device__ __forceinline__ s16x2 pk_nudge(s16x2 ll, s16x2 lp, s16x2 ln, s16x2 det, short hqp, s16x2 pm = s16x2{-1, -1})      // d_nudge x 2 (pm: lanes that take it)
 {
     const s16x2 a = ll - ln, b = lp - ll, z = {0, 0};
     const s16x2 mx = pk_min(pk_max(a, b), z), mn = pk_max(pk_min(a, b), z);
@@ -1162,7 +1162,7 @@ static __device__ __forceinline__ s16x2 pk_nudge(s16x2 ll, s16x2 lp, s16x2 ln, s
     const s16x2 n = pk_rdiv2(pk_min(pk_max(t, mx), mn) - (det << 1));
     const s16x2 h = {hqp, hqp}, nh = {(short)-hqp, (short)-hqp};
     const s16x2 dl = pk_min(pk_max(n, nh), h);
-    const s16x2 mask = (z - (mn - mx)) >> 15;               // all ones where mx != mn (mx <= 0 <= mn)
+    const s16x2 mask = ((z - (mn - mx)) >> 15) & pm;        // all ones where mx != mn (mx <= 0 <= mn)
     return det + (dl & mask);
 }
 // pixels of two cells: even/odd output columns e, o (int16 pairs) -> sbc2int (+ prediction), packed back to bytes
@@ -1187,6 +1187,211 @@ static __device__ __forceinline__ unsigned pk_pixels(s16x2 e, s16x2 o, bool has_
 #define A2H (2 * IT_TY + 4)
 #define A1W (4 * IT_TX + 4)
 #define A1H (4 * IT_TY + 4)
+
+// ---- the encoder's P pictures, tiles away from the right / bottom edge: the fast body of k_inv_haar_tile<FILT,0,true> ----
+// Same arithmetic as the general body below (sbt.c:352-574 + sbc2int + addf), arranged for the common case:
+//   * every cell of the tile and its halo is complete and has in-band neighbours on the right and below (the caller
+//     checks I0 + IT_TX + 1 < w3 and J0 + IT_TY + 1 < h3), so no edge predicate survives except "cell 0 takes no nudge";
+//   * the LL arrays in LDS hold values that are already scaled up (x * 5 / 4, C.3.1.1): each LL value is a neighbour of
+//     four cells and its own cell's centre, so scaling it once where it is produced replaces five scalings per cell;
+//   * level 1 (unscaled in a P picture) works on int16 pairs straight from LDS (range: see pk_* above) -- two adjacent
+//     cells per instruction, neighbours by v_alignbit;
+//   * the level-1 symbols (1.5 of the 2 symbol bytes per sample) are only fetched for patches whose flag is up -- a P
+//     picture has a few thousand non-zero symbols -- so an empty patch costs prediction in, reconstruction out.
+static __device__ __forceinline__ int dq_lo24(int v, int q)                // hzdq_lo (hzcc.c:121-128), |v| < 2^16, q < 2^11
+{
+    const int a = v < 0 ? -v : v;
+    const int m = (int)(__umul24((unsigned)a, (unsigned)(q << 1)) + (unsigned)q) >> 1;
+    const int sg = v >> 31;
+    return v ? (m ^ sg) - sg : 0;
+}
+static __device__ __forceinline__ unsigned pk_i16(int a, int b) { return ((unsigned)a & 0xffffu) | ((unsigned)b << 16); }
+
+template <bool FILT>
+static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo &g, int c, int I0, int J0, int tid,
+                                                  int *__restrict__ A3u, int *__restrict__ A2u, unsigned *__restrict__ A1p)
+{
+    constexpr int W3 = IT_TX + 4, W2 = 2 * IT_TX + 4, WP = 2 * IT_TX + 2;      // row pitches: LL3 values, LL2 values, LL1 pairs
+    const HzPlane &hp = jb.hz[c];
+    const int16_t *__restrict__ sym = jb.sym + jb.nz_off[c];
+    const uint8_t *__restrict__ stable = jb.stable;
+    const uint8_t *__restrict__ pfl = jb.pflag + g.s3off;
+    const int32_t *__restrict__ s3 = jb.s3 + g.s3off;
+    const int nbh = hp.nbh, w3 = g.w3, stride = g.pstride;
+    const QLevel Q3 = q_level<0>(hp), Q2 = q_level<1>(hp), Q1 = q_level<2>(hp);
+    const uint8_t *pred = jb.pred + g.poff;
+    uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
+
+    // ---- phase 0: every global load of the tile.  The flags of this thread's two level-1 items go first: their symbol
+    // loads depend on them and are issued as soon as they are back, under the rest of the loads.
+    int pf1[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
+        pf1[u] = pfl[(size_t)(J0 + (ly >> 2)) * w3 + I0 + gx];
+    }
+    int a3v = 0, nzv = 0;
+    if (tid < A3H * A3W) {
+        const int ly = tid / W3, lx = tid - ly * W3;
+        const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
+        if (cx >= 0 && cy >= 0) { a3v = s3[(size_t)cy * w3 + cx]; nzv = pfl[(size_t)cy * w3 + cx]; }
+    }
+    int s3lh = 0, s3hl = 0, s3hh = 0, k3 = 0, lx3 = 0, ly3 = 0;
+    bool ok3 = false;
+    if (tid < (IT_TY + 2) * (IT_TX + 2)) {
+        ly3 = tid / (IT_TX + 2); lx3 = tid - ly3 * (IT_TX + 2);
+        const int cx = I0 - 1 + lx3, cy = J0 - 1 + ly3;
+        ok3 = cx >= 0 && cy >= 0;
+        if (ok3) {
+            const int o = cy * Q3.sw + cx;
+            s3lh = sym[Q3.base0 + o]; s3hl = sym[Q3.base1 + o]; s3hh = sym[Q3.base2 + o];
+            const int f = stable[((cy * Q3.dby) >> 14) * nbh + ((cx * Q3.dbx) >> 14)];
+            k3 = (f & 2) ? 2 : (f != 0);
+        }
+    }
+    constexpr int N2 = ((2 * IT_TY + 2) * (2 * IT_TX + 2) + 255) / 256;
+    int s2lh[N2], s2hl[N2], s2hh[N2], k2[N2];
+    bool ok2[N2];
+#pragma unroll
+    for (int u = 0; u < N2; u++) {
+        const int i = tid + 256 * u;
+        const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
+        const int cx = 2 * I0 - 1 + lx, cy = 2 * J0 - 1 + ly;
+        ok2[u] = i < (2 * IT_TY + 2) * (2 * IT_TX + 2) && cx >= 0 && cy >= 0;
+        s2lh[u] = s2hl[u] = s2hh[u] = k2[u] = 0;
+        if (ok2[u]) {
+            const int o = cy * Q2.sw + cx;
+            s2lh[u] = sym[Q2.base0 + o]; s2hl[u] = sym[Q2.base1 + o]; s2hh[u] = sym[Q2.base2 + o];
+            const int f = stable[((cy * Q2.dby) >> 14) * nbh + ((cx * Q2.dbx) >> 14)];
+            k2[u] = (f & 2) ? 2 : (f != 0);
+        }
+    }
+    uint2 pv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
+        const uint8_t *pp = pred + (size_t)(2 * (4 * J0 + ly)) * stride + 8 * (I0 + gx);
+        pv[u][0] = *reinterpret_cast<const uint2 *>(pp);
+        pv[u][1] = *reinterpret_cast<const uint2 *>(pp + stride);
+    }
+    uint2 d1lh[2], d1hl[2], d1hh[2];
+    s16x2 shv[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        d1lh[u] = d1hl[u] = d1hh[u] = make_uint2(0u, 0u);
+        shv[u][0] = shv[u][1] = s16x2{0, 0};
+        if (pf1[u]) {
+            const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
+            const int cy = 4 * J0 + ly, cx0 = 4 * (I0 + gx);
+            const int o = cy * Q1.sw + cx0;
+            d1lh[u] = *reinterpret_cast<const uint2 *>(sym + Q1.base0 + o);
+            d1hl[u] = *reinterpret_cast<const uint2 *>(sym + Q1.base1 + o);
+            d1hh[u] = *reinterpret_cast<const uint2 *>(sym + Q1.base2 + o);
+            const int by = ((cy * Q1.dby) >> 14) * nbh;
+            const int bx0 = (cx0 * Q1.dbx) >> 14, bx3 = ((cx0 + 3) * Q1.dbx) >> 14;
+            const int f0 = stable[by + bx0];
+            int f1 = f0, f2 = f0, f3 = f0;
+            if (bx0 != bx3) {
+                f1 = stable[by + (((cx0 + 1) * Q1.dbx) >> 14)];
+                f2 = stable[by + (((cx0 + 2) * Q1.dbx) >> 14)];
+                f3 = stable[by + bx3];
+            }
+            shv[u][0] = s16x2{(short)(f0 ? Q1.sh1 : Q1.sh0), (short)(f1 ? Q1.sh1 : Q1.sh0)};
+            shv[u][1] = s16x2{(short)(f2 ? Q1.sh1 : Q1.sh0), (short)(f3 ? Q1.sh1 : Q1.sh0)};
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+
+    if (tid < A3H * A3W) A3u[tid] = d_ll_up_t<true>(a3v);
+    if (!__syncthreads_or((nzv | a3v) != 0)) {
+        // nothing in reach: every output is zero, the reconstruction is the prediction
+        if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+        if (pred == outp) return;                                // written in place by the forward transform (ping-pong slots)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
+            uint8_t *dst = outp + (size_t)(2 * (4 * J0 + ly)) * stride + 8 * (I0 + gx);
+            *reinterpret_cast<uint2 *>(dst) = pv[u][0];
+            *reinterpret_cast<uint2 *>(dst + stride) = pv[u][1];
+        }
+        return;
+    }
+    if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (c != 0) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+
+    // ---- level 3: cells I0-1 .. I0+TX (halo 1) -> LL2 values, scaled up, in A2u
+    if (ok3) {
+        const int *pA = A3u + (ly3 + 1) * W3 + lx3 + 1;
+        const int LL = pA[0];
+        const int q = max(Q3.qp >> k3, HZ_MINQ);
+        int LH = dq_lo24(s3lh, q), HL = dq_lo24(s3hl, q);
+        const int HH = dq_lo24(s3hh, q);
+        if (FILT) {
+            const int hq = jb.hqp[3];
+            if (I0 - 1 + lx3 > 0) LH = d_nudge(LL, pA[-1], pA[1], LH, hq);
+            if (J0 - 1 + ly3 > 0) HL = d_nudge(LL, pA[-W3], pA[W3], HL, hq);
+        }
+        const int sA = LL + HL, sB = LH + HH, sC = LL - HL, sD = LH - HH;
+        int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
+        d[0] = d_ll_up_t<true>(d_div4<true>(sA + sB)); d[1] = d_ll_up_t<true>(d_div4<true>(sA - sB));
+        d[W2] = d_ll_up_t<true>(d_div4<true>(sC + sD)); d[W2 + 1] = d_ll_up_t<true>(d_div4<true>(sC - sD));
+    }
+    __syncthreads();
+    // ---- level 2: cells 2*I0-1 .. 2*I0+2*TX (halo 1) -> LL1 values (level 1 of a P picture is unscaled) as int16 pairs
+#pragma unroll
+    for (int u = 0; u < N2; u++) {
+        if (!ok2[u]) continue;
+        const int i = tid + 256 * u;
+        const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
+        const int *pA = A2u + (ly + 1) * W2 + lx + 1;
+        const int LL = pA[0];
+        const int q = max(Q2.qp >> k2[u], HZ_MINQ);
+        int LH = dq_lo24(s2lh[u], q), HL = dq_lo24(s2hl[u], q);
+        const int HH = dq_lo24(s2hh[u], q);
+        if (FILT) {
+            const int hq = jb.hqp[2];
+            if (2 * I0 - 1 + lx > 0) LH = d_nudge(LL, pA[-1], pA[1], LH, hq);
+            if (2 * J0 - 1 + ly > 0) HL = d_nudge(LL, pA[-W2], pA[W2], HL, hq);
+        }
+        const int sA = LL + HL, sB = LH + HH, sC = LL - HL, sD = LH - HH;
+        unsigned *d = A1p + (2 * ly) * WP + lx;
+        d[0] = pk_i16(d_div4<true>(sA + sB), d_div4<true>(sA - sB));
+        d[WP] = pk_i16(d_div4<true>(sC + sD), d_div4<true>(sC - sD));
+    }
+    __syncthreads();
+    // ---- level 1 + sbc2int + prediction add: an item = four adjacent cells = 8 pixels x 2 rows, as two int16 pairs
+    const short hq1 = (short)jb.hqp[1];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
+        const unsigned *row = A1p + (ly + 2) * WP + 2 * gx;          // pairs 2gx .. 2gx+3 hold LL1 columns 4gx .. 4gx+7 (halo 2)
+        const unsigned q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+        unsigned row0[2], row1[2];
+#pragma unroll
+        for (int h2 = 0; h2 < 2; h2++) {
+            const unsigned cw = h2 ? q2 : q1, lw = h2 ? q1 : q0, rw = h2 ? q3 : q2;
+            const s16x2 C = __builtin_bit_cast(s16x2, cw);
+            const unsigned sl = h2 ? d1lh[u].y : d1lh[u].x, sh_ = h2 ? d1hl[u].y : d1hl[u].x, sd = h2 ? d1hh[u].y : d1hh[u].x;
+            s16x2 LH = __builtin_bit_cast(s16x2, sl) << shv[u][h2], HL = __builtin_bit_cast(s16x2, sh_) << shv[u][h2];
+            const s16x2 HH = __builtin_bit_cast(s16x2, sd) << shv[u][h2];
+            if (FILT) {
+                const s16x2 lp = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(cw, lw, 16u));
+                const s16x2 ln = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(rw, cw, 16u));
+                const s16x2 up = __builtin_bit_cast(s16x2, row[1 + h2 - WP]), dn = __builtin_bit_cast(s16x2, row[1 + h2 + WP]);
+                const s16x2 pmh = s16x2{(short)((h2 | gx | I0) ? -1 : 0), -1};          // cell 0 of the plane has no left neighbour
+                const short pv_ = (short)((ly | J0) ? -1 : 0);                         // row 0 of the plane has none above
+                LH = pk_nudge(C, lp, ln, LH, hq1, pmh);
+                HL = pk_nudge(C, up, dn, HL, hq1, s16x2{pv_, pv_});
+            }
+            const s16x2 sA = C + HL, sB = LH + HH, sC = C - HL, sD = LH - HH;
+            row0[h2] = pk_pixels(pk_div4(sA + sB), pk_div4(sA - sB), true, h2 ? pv[u][0].y : pv[u][0].x);
+            row1[h2] = pk_pixels(pk_div4(sC + sD), pk_div4(sC - sD), true, h2 ? pv[u][1].y : pv[u][1].x);
+        }
+        uint8_t *dst = outp + (size_t)(2 * (4 * J0 + ly)) * stride + 8 * (I0 + gx);
+        *reinterpret_cast<uint2 *>(dst) = make_uint2(row0[0], row0[1]);
+        *reinterpret_cast<uint2 *>(dst + stride) = make_uint2(row1[0], row1[1]);
+    }
+}
+
 
 // MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
 // whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
@@ -1228,6 +1433,18 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
             if (w3o > 1 && h3o > 1) s3o[w3o + 1] = o[3];
         } else s3o[0] = ll;
         return;
+    }
+    if constexpr (MODE == 0 && SYM) {
+        // sparse P pictures of the encoder, tiles away from the right / bottom edge (cells complete, neighbours in band)
+        const QLevel Lq1 = q_level<2>(jb.hz[c]);
+        if (jb.nzf != nullptr && jb.ref != nullptr && I0 + IT_TX + 1 < inw && J0 + IT_TY + 1 < inh &&
+            ((Lq1.sw | Lq1.base0 | Lq1.base1 | Lq1.base2) & 3) == 0) {
+            inv_p_fast<FILT>(jb, g, c, I0, J0, tid, A3, A2, reinterpret_cast<unsigned *>(A1));
+            return;
+        }
+#ifdef AB_FAST_ONLY
+        return;
+#endif
     }
     // ---- phase 0: EVERY global load of the tile is issued here, before the first barrier, so the three level
     // phases below only wait on LDS: one memory round trip per workgroup instead of one per phase and loop pass.
@@ -1335,7 +1552,11 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     if (ok3) {      // level TOP: cells I0-1 .. I0+TX (halo 1)
         const int ly = tid / (IT_TX + 2), lx = tid - ly * (IT_TX + 2);
         int o[4];
+#ifdef AB_NO_L23
+        o[0] = o[1] = o[2] = o[3] = A3[(ly + 1) * A3W + (lx + 1)] + q3.lh;
+#else
         inv_cell_raw<FILT, MODE != 2>(A3 + (ly + 1) * A3W + (lx + 1), A3W, I0 - 1 + lx, J0 - 1 + ly, L3, D3, q3, o);
+#endif
         int *d = A2 + (2 * ly) * A2W + 2 * lx;
         d[0] = o[0]; d[1] = o[1]; d[A2W] = o[2]; d[A2W + 1] = o[3];
     }
@@ -1346,7 +1567,11 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         const int i = tid + 256 * u;
         const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
         int o[4];
+#ifdef AB_NO_L23
+        o[0] = o[1] = o[2] = o[3] = A2[(ly + 1) * A2W + (lx + 1)] + q2[u].lh;
+#else
         inv_cell_raw<FILT, MODE != 2>(A2 + (ly + 1) * A2W + (lx + 1), A2W, 2 * I0 - 1 + lx, 2 * J0 - 1 + ly, L2, D2, q2[u], o);
+#endif
         int *d = A1 + (2 * ly) * A1W + 2 * lx;
         d[0] = o[0]; d[1] = o[1]; d[A1W] = o[2]; d[A1W + 1] = o[3];
     }
@@ -1394,8 +1619,10 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
                     const s16x2 C = pk2(rc[k], rc[k + 1]);
                     s16x2 LH = pk2(lhv[k], lhv[k + 1]), HL = pk2(hlv[k], hlv[k + 1]);
                     const s16x2 HH = pk2(hhv[k], hhv[k + 1]);
+#ifndef AB_NO_L1_NUDGE
                     LH = pk_nudge(C, pk2(rc[k - 1], rc[k]), pk2(rc[k + 1], rc[k + 2]), LH, hq);
                     if (vy) HL = pk_nudge(C, pk2(rc[k - A1W], rc[k + 1 - A1W]), pk2(rc[k + A1W], rc[k + 1 + A1W]), HL, hq);
+#endif
                     const s16x2 sA = C + HL, sB = LH + HH, sC = C - HL, sD = LH - HH;
                     row0[h2] = pk_pixels(pk_div4(sA + sB), pk_div4(sA - sB), pred != nullptr, h2 ? pv1[u][0].y : pv1[u][0].x);
                     row1[h2] = pk_pixels(pk_div4(sC + sD), pk_div4(sC - sD), pred != nullptr, h2 ? pv1[u][1].y : pv1[u][1].x);

@@ -2,7 +2,7 @@
 # A/B compile-time variants on the same GPU box: bench twice with the tree as built, then once per EXTRA flag set
 # (rebuilding csrc with make EXTRA=...).  usage: run_ab_flags.sh <kernel substring> "<flags A>" ["<flags B>" ...]
 K=$1; shift
-one() { python bench.py --cpu-gops 0 --steps 20 | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['roofline']['all_kernels_ms_one_step']; print('$1', d['value'], d['ms_per_step'], {k:v for k,v in t.items() if '$K' in k})"; }
+one() { python bench.py --cpu-gops 0 --steps 6 --no-extras | python -c "import sys,json; d=json.loads(sys.stdin.read()); t=d['roofline']['all_kernels_ms_one_step']; print('$1', d['value'], d['ms_per_step'], {k:v for k,v in t.items() if '$K' in k})"; }
 one base; one base
 for F in "$@"; do
   touch digital-subband-video-1_amd/csrc/*.hip
