@@ -97,7 +97,8 @@ struct dsvg_ctx {
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
     uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
     unsigned *stat = nullptr;        // [4][64] inverse-transform tile counters (general luma / chroma, zero luma / chroma), sharded
-    bool stats_on = false;           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
+    bool stats_on = false;
+    bool fetch_shared = false;       // DSV1_FETCH_ON_ANALYSIS: st_c is st_a           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
     DMV *mvs = nullptr;
@@ -165,7 +166,7 @@ static void ctx_free(dsvg_ctx *c)
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-    if (c->st_c) (void)hipStreamDestroy(c->st_c);
+    if (c->st_c && !c->fetch_shared) (void)hipStreamDestroy(c->st_c);
     if (c->st_h) (void)hipStreamDestroy(c->st_h);
     for (int i = 0; i < 2; i++) {
         if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
@@ -260,6 +261,11 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         c->st = ps[0]; c->st_a = ps[1];
         for (int g = 1; g < std::max(ncs, 2); g++) c->stx[g] = ps[1 + g];      // every stream is owned by the ctx before anything can fail
         c->st_c = ps[want - 1];
+        if (getenv("DSV1_FETCH_ON_ANALYSIS")) {                 // experiment: the fetch copies share the analysis stream (one busy stream fewer)
+            (void)hipStreamDestroy(c->st_c);
+            c->st_c = c->st_a;
+            c->fetch_shared = true;
+        }
         for (int g = 1; g < std::max(ncs, 2); g++)
             if (hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
         c->streams_apart = good;

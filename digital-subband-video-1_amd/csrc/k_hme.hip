@@ -449,10 +449,45 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         return;
     }
     // ------------------------------------------------------------------ level 0 only
+    // Full blocks: the rows of the zero-motion reference block and of the four chroma blocks (source / reference, U / V)
+    // depend on no decision -- requested now, consumed by the statistics and the chroma variance test further down, so
+    // their memory round trips run under the half-pel stage instead of at the tail of the wave.
+    unsigned zpre[NKR], cpre[4][4];
+    bool cpre_ok = false;
+    if constexpr (FAST) {
+        const uint8_t *zq = rp + (long)(by + r0) * stride + bx + xcol;
+#pragma unroll
+        for (int kk = 0; kk < NKR; kk++) { zpre[kk] = *reinterpret_cast<const unsigned *>(zq); zq += stride; }
+        const FrameLayout &L0 = A.L[0];
+        const int cbw = bw >> L0.hs, cbh = bh >> L0.vs, ndw = cbw >> 2, rpp = ndw ? NT / ndw : NT + 1;
+        const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
+        const uint8_t *fbs = A.slab[0] + (size_t)cur * L0.pitch, *fbr = A.slab[0] + (size_t)rf * L0.pitch;
+        cpre_ok = (((unsigned)L0.off[1] | (unsigned)L0.off[2] | (unsigned)L0.stride[1] | (unsigned)cbx | (unsigned)(uintptr_t)fbs | (unsigned)(uintptr_t)fbr | (unsigned)cbw) & 3u) == 0 &&
+                  ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4 && L0.stride[1] == L0.stride[2];
+        if (cpre_ok) {
+            // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
+            const int sh = 31 - __clz(ndw), npass = cbh / rpp;
+            const long o0 = (long)(cby + (tid >> sh)) * L0.stride[1] + cbx + 4 * (tid & (ndw - 1)), adv = (long)rpp * L0.stride[1];
+            const uint8_t *q0 = fbs + L0.off[1] + o0, *q1 = fbs + L0.off[2] + o0, *q2 = fbr + L0.off[1] + o0, *q3 = fbr + L0.off[2] + o0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool on = u < npass;                             // wave-uniform
+                cpre[u][0] = on ? *reinterpret_cast<const unsigned *>(q0) : 0u;
+                cpre[u][1] = on ? *reinterpret_cast<const unsigned *>(q1) : 0u;
+                cpre[u][2] = on ? *reinterpret_cast<const unsigned *>(q2) : 0u;
+                cpre[u][3] = on ? *reinterpret_cast<const unsigned *>(q3) : 0u;
+                q0 += adv; q1 += adv; q2 += adv; q3 += adv;
+            }
+        }
+    }
     const unsigned yarea = (unsigned)(bw * bh), yareasq = yarea * yarea;
     const double ryarea = 1.0 / (double)yarea;
     const int wx = bx + ((bw >> 1) - WIN / 2), wy = by + ((bh >> 1) - WIN / 2);
+#ifdef AB_HME_NO_HP
+    const bool do_hp = false;
+#else
     const bool do_hp = best > BW * BH;
+#endif
     // stage: source 14x14 window, and either the 19x20 patch for the lattice or the full-pel 14x14 window
     const int smis = load_win<8, WIN>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
     int pmis;
@@ -524,9 +559,8 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     __syncthreads();                                    // rwin complete
     unsigned zrow[NKR];
     if constexpr (FAST) {
-        const uint8_t *zq = rp + (long)(by + r0) * stride + bx + xcol;
 #pragma unroll
-        for (int kk = 0; kk < NKR; kk++) { zrow[kk] = *reinterpret_cast<const unsigned *>(zq); zq += stride; }
+        for (int kk = 0; kk < NKR; kk++) zrow[kk] = zpre[kk];
     } else {
         const unsigned *zp = reinterpret_cast<const unsigned *>(rp + (long)(by + r0) * stride + bx + xcol);
         const int sdw = stride >> 2;
@@ -595,7 +629,11 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     else if (src_tex == 0 && ref_tex != 0) want_intra = true;
     else if (abs(src_avg - ref_avg) > 8) want_intra = true;
     else if (luma_tex <= 10 && (unsigned)best > yareasq / 16) want_intra = true;
+#ifdef AB_HME_NO_CHROMA
+    else if (0) {
+#else
     else {
+#endif
         // chroma variance test (c_maxvar hme.c:269-300): the four chroma blocks straight from HBM, one reduction
         const FrameLayout &L0 = A.L[0];
         const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
@@ -607,7 +645,22 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         const uint8_t *fbs = A.slab[0] + (size_t)cur * L0.pitch, *fbr = A.slab[0] + (size_t)rf * L0.pitch;
         const bool aligned = (((unsigned)L0.off[1] | (unsigned)L0.off[2] | (unsigned)L0.stride[1] | (unsigned)L0.stride[2] | (unsigned)cbx |
                                (unsigned)(uintptr_t)fbs | (unsigned)(uintptr_t)fbr) & 3u) == 0;
-        if (aligned && ndw * cbh <= 4 * NT) {
+        bool done_c = false;
+        if constexpr (FAST) {
+            if (cpre_ok) {                                             // requested at the top of the level-0 section
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int o = (k >> 1) * 4 + (k & 1) * 2;
+                        cs[o] = __builtin_amdgcn_sad_u8(cpre[u][k], 0u, cs[o]);
+                        cs[o + 1] = __builtin_amdgcn_udot4(cpre[u][k], cpre[u][k], cs[o + 1], false);
+                    }
+                done_c = true;
+            }
+        }
+        if (done_c) {
+        } else if (aligned && ndw * cbh <= 4 * NT) {
             // the usual case (block origins are multiples of 4 in the chroma planes): one aligned dword per item and
             // plane, all of a lane's loads in flight together -- one memory round trip for the whole test
             unsigned cw4[4][4], cm[4];
@@ -654,7 +707,8 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         }
         block_sum_n<8>(cs, S.part, phase);
         const unsigned carea = (unsigned)(cbw * cbh);
-        const double rcarea = 1.0 / (double)carea;
+        // full block: the chroma area is the luma area over a power of two -- the reciprocal is an exact scaling of ryarea
+        const double rcarea = FAST ? ryarea * (double)(1 << (L0.hs + L0.vs)) : 1.0 / (double)carea;
         const unsigned vsu = cs[1] - udiv_rd(cs[0] * cs[0], rcarea), vsv = cs[3] - udiv_rd(cs[2] * cs[2], rcarea);
         const unsigned vru = cs[5] - udiv_rd(cs[4] * cs[4], rcarea), vrv = cs[7] - udiv_rd(cs[6] * cs[6], rcarea);
         const unsigned cvs = vsu > vsv ? vsu : vsv, cvr = vru > vrv ? vru : vrv;
@@ -743,7 +797,9 @@ __global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npai
             return;
         }
     }
+#ifndef AB_HME_FASTONLY
     hme_block<LEVEL0, 0>(A, level, pair, i, j, S);
+#endif
 }
 
 // second pass of level 0: high_detail from the causal neighbours' final flags (hme.c:621-648)
