@@ -32,6 +32,8 @@ struct dsv1_batch {
     int rows;                   /* source-slot ring: rows x nstreams slots, rows = 2F+1 */
     unsigned gcount;            /* frames submitted so far per stream (ring position) */
     int parity;                 /* which half of the double-buffered per-batch state the next submit uses */
+    int nf_cur;                 /* frames per stream of the batch being submitted (F, or fewer for a single stream's tail) */
+    int nf_pending[2];          /* the same for the batches in flight */
     int pending[2];             /* batch submitted (device work enqueued) but not yet collected */
     DSV_ENCODER *enc;
     pic_t *pics;                /* [2][nstreams*F] */
@@ -422,7 +424,7 @@ static void side_stream(void *ctx, int s, int tid)
     uint8_t *tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
     int t;
     (void)tid;
-    for (t = 0; t < F; t++) {
+    for (t = 0; t < b->nf_cur; t++) {
         pic_t *pc = &c->pics[s * F + t];
         bitw w;
         if (pc->has_ref) {
@@ -455,7 +457,7 @@ static void side_stream(void *ctx, int s, int tid)
 }
 
 /* packet assembly of one stream of a collected batch (its own staging buffer per thread) */
-typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc; } asm_ctx;
+typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc, nf; } asm_ctx;
 static void asm_stream(void *ctx, int s, int tid)
 {
     asm_ctx *c = (asm_ctx *)ctx;
@@ -465,13 +467,13 @@ static void asm_stream(void *ctx, int s, int tid)
     size_t need = 0;
     int t, p;
     (void)tid;
-    for (t = 0; t < F; t++) {
+    for (t = 0; t < c->nf; t++) {
         const dsvg_pic_out *po = &b->outs[s * F + t];
         need += (size_t)c->pics[s * F + t].prefix_len + 192;
         for (p = 0; p < 3; p++) need += po->nbytes[p] + 32;
     }
     if (dsv1_buf_reserve(&c->out[s], (unsigned)need)) { c->rc = DSVG_ERR_ARG; return; }
-    for (t = 0; t < F; t++) {
+    for (t = 0; t < c->nf; t++) {
         const int rc = assemble(b, s, &c->pics[s * F + t], &b->outs[s * F + t], &c->out[s], &sc);
         if (rc) { c->rc = rc; break; }
     }
@@ -483,7 +485,8 @@ static void asm_stream(void *ctx, int s, int tid)
  * without waiting for the coding work; dsv1_batch_collect() fetches and assembles the packets.  ABR
  * (each quantiser needs the previous packet size) runs frame step by frame step and leaves nothing
  * pending except the already assembled packets. */
-static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out)
+static int stage_n(dsv1_batch *b, const void *yuv_host, int nf);
+static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out, int nf)
 {
     int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0, par;
     size_t fb;
@@ -495,6 +498,9 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     if (hp_on < 0) hp_on = getenv("DSV1_HOST_PROF") != NULL;
     HP_BEGIN();
     S = b->nstreams; F = b->F; nblk = b->nblk; fb = b->g.frame_bytes;
+    if (nf <= 0) nf = F;
+    if (nf > F || (nf < F && S != 1)) { dsv1_log(1, "a short batch needs a single stream"); return DSVG_ERR_ARG; }
+    b->nf_cur = nf;
     e0 = &b->enc[0];
     with_pyr = e0->gop != DSV_GOP_INTRA;
     par = b->parity;
@@ -504,7 +510,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         /* host frames go through the context's double-buffered ingest (copy stream of its own): nothing here waits
          * for the device, and a clip announced with dsv1_batch_stage() is already on its way */
         if (!b->nstaged) {
-            if ((rc = dsv1_batch_stage(b, yuv))) return rc;
+            if ((rc = stage_n(b, yuv, nf))) return rc;
         } else if (b->staged_host[0] != yuv) {
             dsv1_log(1, "a different clip was staged for this submit");
             return DSVG_ERR_ARG;
@@ -515,8 +521,8 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     }
     /* 1. source-only preparation for every frame: bordered layout, pyramid, mean luma */
     for (s = 0; s < S; s++)
-        for (t = 0; t < F; t++) b->slots_cur[s * F + t] = slot_of(b, s, b->gcount + (unsigned)t);
-    if ((rc = dsvg_load_frames_map(b->ctx, S * F, b->slots_cur, dyuv, fb, with_pyr))) return rc;
+        for (t = 0; t < nf; t++) b->slots_cur[s * F + t] = slot_of(b, s, b->gcount + (unsigned)t);
+    if ((rc = dsvg_load_frames_map(b->ctx, S * nf, b->slots_cur, dyuv, fb, with_pyr))) return rc;     /* nf < F only with S == 1 */
     if (with_pyr && e0->do_scd)
         if ((rc = dsvg_get_luma_sums(b->ctx, 0, b->rows * S, b->luma))) return rc;
 
@@ -529,7 +535,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
             e->stable_blocks = (unsigned char *)dsv_alloc(nblk);
         }
         if (e->pyramid_levels == 0) e->pyramid_levels = b->g.pyramid_levels;
-        for (t = 0; t < F; t++) {
+        for (t = 0; t < nf; t++) {
             pic_t *pc = &pics[s * F + t];
             pc->fnum = e->next_fnum++;
             pc->cur_slot = slot_of(b, s, b->gcount + (unsigned)t);
@@ -579,7 +585,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     {
         const int serial = e0->rc_mode != DSV_RATE_CONTROL_CRF;
         if (serial && !abr_out) return DSVG_ERR_ARG;
-        for (t = 0; t < F; t++) {
+        for (t = 0; t < nf; t++) {
             for (s = 0; s < S; s++) {
                 pic_t *pc = &pics[s * F + t];
                 dsvg_pic_job *j = &b->jobs[(serial ? 0 : t * S) + s];
@@ -608,50 +614,54 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                     if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s], &b->sc0))) return rc;
             }
         }
-        if (!serial && (rc = dsvg_code_batch(b->ctx, F, S, b->jobs))) return rc;   /* whole batch, one upload */
+        if (!serial && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
+        b->nf_pending[par] = nf;
     }
     HP_MARK(HP_ENQUEUE);
     hp_batches++;
-    b->gcount += (unsigned)F;
+    b->gcount += (unsigned)nf;
     b->parity ^= 1;
     return DSVG_OK;
 }
 
-int dsv1_batch_stage(dsv1_batch *b, const void *yuv_host)
+static int stage_n(dsv1_batch *b, const void *yuv_host, int nf)
 {
     int rc;
     if (!b || !yuv_host) return DSVG_ERR_ARG;
     if (b->nstaged == 2) { dsv1_log(1, "two clips are staged already"); return DSVG_ERR_ARG; }
-    if ((rc = dsvg_ingest_begin(b->ctx, yuv_host, b->g.frame_bytes * (size_t)b->nstreams * b->F, &b->staged_dev[b->nstaged]))) return rc;
+    if ((rc = dsvg_ingest_begin(b->ctx, yuv_host, b->g.frame_bytes * (size_t)b->nstreams * (size_t)nf, &b->staged_dev[b->nstaged]))) return rc;
     b->staged_host[b->nstaged++] = yuv_host;
     return DSVG_OK;
 }
+int dsv1_batch_stage(dsv1_batch *b, const void *yuv_host) { return stage_n(b, yuv_host, b ? b->F : 0); }
 
 int dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
 {
-    return batch_submit_impl(b, yuv, yuv_on_device, out);
+    return batch_submit_impl(b, yuv, yuv_on_device, out, 0);
 }
 
 /* Collect the OLDEST submitted batch: one gathered device-to-host copy, then packet assembly in
  * stream order.  The packets of stream s are appended to out[s]. */
 int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
 {
-    int par, S, F, k, rc;
+    int par, S, F, k, rc, nf;
     pic_t *pics;
     if (!b || !out) return DSVG_ERR_ARG;
     S = b->nstreams; F = b->F;
     par = b->pending[b->parity] ? b->parity : (b->parity ^ 1);   /* oldest first */
     if (!b->pending[par]) { dsv1_log(1, "nothing to collect"); return DSVG_ERR_ARG; }
     pics = b->pics + (size_t)par * S * F;
+    nf = b->nf_pending[par];
     if (b->pending[par] == 1) {
         HP_BEGIN();
-        for (k = 0; k < S * F; k++) b->out_slots[k] = pics[k].out_slot;
-        if ((rc = dsvg_fetch_pictures(b->ctx, S * F, b->out_slots, b->outs))) return rc;
+        /* a short batch (nf < F) has a single stream: its pictures are the first nf entries */
+        for (k = 0; k < S * nf; k++) b->out_slots[k] = pics[k].out_slot;
+        if ((rc = dsvg_fetch_pictures(b->ctx, S * nf, b->out_slots, b->outs))) return rc;
         HP_MARK(HP_FETCH);
         {
             asm_ctx ac;
-            ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK;
+            ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK; ac.nf = nf;
             dsv1_par_for(S, asm_stream, &ac);
             if (ac.rc) return ac.rc;
         }
@@ -666,7 +676,7 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
     int rc;
     if (!b || !out) return DSVG_ERR_ARG;
     if (b->pending[0] || b->pending[1]) { dsv1_log(1, "dsv1_batch_encode with batches in flight"); return DSVG_ERR_ARG; }
-    if ((rc = batch_submit_impl(b, yuv, yuv_on_device, out))) return rc;
+    if ((rc = batch_submit_impl(b, yuv, yuv_on_device, out, 0))) return rc;
     return dsv1_batch_collect(b, out);
 }
 
@@ -754,65 +764,165 @@ void dsv_enc_start(DSV_ENCODER *enc)                       /* dsv_encoder.c:724-
 void dsv_enc_set_metadata(DSV_ENCODER *enc, DSV_META *md) { memcpy(&enc->vidmeta, md, sizeof(DSV_META)); }
 void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
 
+/* Session behind the frame-at-a-time API.  CRF streams are PIPELINED: dsv_enc copies the frame into a pinned host batch
+ * (the CLI reuses its picture buffer, dsv_main.c:506-520), and every F frames one batch goes to the device with
+ * dsv1_batch_submit while the batch before it is collected; the finished packets wait in a backlog that later calls hand
+ * out (at most two buffers per call, as the reference does: metadata + picture, dsv_encoder.c:804-810).  A caller may get
+ * 0 buffers for a while -- dsv_main.c:521-531 loops over whatever count comes back -- and dsv_enc_end_of_stream returns
+ * the rest of the backlog in front of the EOS packet, in one buffer: the bytes that reach the file are those of the
+ * frame-synchronous encoder.  ABR needs every packet's size before the next quantiser and keeps one frame per call
+ * (DSV1_ENC_PIPELINE=0 forces that for CRF too). */
+typedef struct {
+    dsv1_batch *b;
+    int pipelined, F, fill, cur, inflight;
+    uint8_t *pin[2];
+    size_t fb;
+    DSV_BUF backlog;            /* finished packets not handed out yet */
+    unsigned off;               /* first byte of the backlog not handed out */
+} enc_sess;
+
+static void sess_free(enc_sess *ss)
+{
+    int i;
+    if (!ss) return;
+    if (ss->b) {
+        if (ss->b->ctx) { dsvg_ctx_sync(ss->b->ctx); for (i = 0; i < 2; i++) if (ss->pin[i]) dsvg_host_free(ss->b->ctx, ss->pin[i]); }
+        ss->b->enc = NULL;                              /* the caller owns the DSV_ENCODER */
+        dsv1_batch_close(ss->b);
+    }
+    dsv_buf_free(&ss->backlog);
+    free(ss);
+}
+
 void dsv_enc_free(DSV_ENCODER *enc)
 {
-    if (enc->ref) {
-        dsv1_batch *b = (dsv1_batch *)enc->ref;
-        b->enc = NULL;                                  /* the caller owns the DSV_ENCODER */
-        dsv1_batch_close(b);
-        enc->ref = NULL;
-    }
+    if (enc->ref) { sess_free((enc_sess *)enc->ref); enc->ref = NULL; }
     if (enc->stability) { dsv_free(enc->stability); enc->stability = NULL; }
     if (enc->stable_blocks) { dsv_free(enc->stable_blocks); enc->stable_blocks = NULL; }
+}
+
+/* collect the oldest batch in flight into the backlog */
+static int sess_collect(enc_sess *ss)
+{
+    DSV_BUF tmp = {NULL, 0};
+    int rc = dsv1_batch_collect(ss->b, &tmp);
+    if (!rc && tmp.len) rc = dsv1_buf_append(&ss->backlog, tmp.data, tmp.len) ? DSVG_ERR_ARG : DSVG_OK;
+    dsv_buf_free(&tmp);
+    ss->inflight--;
+    return rc;
+}
+
+/* submit the frames gathered so far (a short batch at the end of the stream) */
+static int sess_submit(enc_sess *ss)
+{
+    int rc;
+    if ((rc = batch_submit_impl(ss->b, ss->pin[ss->cur], 0, NULL, ss->fill))) return rc;
+    ss->inflight++;
+    ss->cur ^= 1;
+    ss->fill = 0;
+    return DSVG_OK;
+}
+
+/* hand out up to `max` whole packets from the backlog */
+static int sess_pop(enc_sess *ss, DSV_BUF *bufs, int max)
+{
+    int n = 0;
+    while (n < max && ss->off + DSV_PACKET_HDR_SIZE <= ss->backlog.len) {
+        const unsigned len = get_be32(ss->backlog.data + ss->off + DSV_PACKET_NEXT_OFFSET);
+        if (!len || ss->off + len > ss->backlog.len) break;
+        /* a metadata packet travels with the picture that follows it (the reference returns both from one call) */
+        if (n == max - 1 && ss->backlog.data[ss->off + DSV_PACKET_TYPE_OFFSET] == DSV_PT_META) break;
+        dsv_mk_buf(&bufs[n], (int)len);
+        memcpy(bufs[n].data, ss->backlog.data + ss->off, len);
+        ss->off += len;
+        n++;
+    }
+    if (ss->off == ss->backlog.len && ss->backlog.len) { ss->backlog.len = 0; ss->off = 0; }   /* keep the allocation */
+    return n;
 }
 
 void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:766-778 */
 {
     bitw w;
-    dsv_mk_buf(&bufs[0], DSV_PACKET_HDR_SIZE);
-    bw_init(&w, bufs[0].data);
+    enc_sess *ss = (enc_sess *)enc->ref;
+    uint8_t eos[DSV_PACKET_HDR_SIZE];
+    unsigned rest = 0;
+    if (ss && ss->pipelined) {
+        /* flush: the frames still waiting for a full batch, then everything in flight, oldest first */
+        int rc = DSVG_OK;
+        if (ss->fill > 0) {
+            if (ss->inflight == 2) rc = sess_collect(ss);
+            if (!rc) rc = sess_submit(ss);
+        }
+        while (!rc && ss->inflight > 0) rc = sess_collect(ss);
+        if (rc) dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error());
+    }
+    if (ss) rest = ss->backlog.len - ss->off;
+    memset(eos, 0, sizeof(eos));
+    bw_init(&w, eos);
     write_pkt_hdr(&w, DSV_PT_EOS);
-    link_packet(enc, bufs[0].data, bufs[0].len, 1);
+    link_packet(enc, eos, sizeof(eos), 1);
+    dsv_mk_buf(&bufs[0], (int)(rest + sizeof(eos)));
+    if (rest) {
+        memcpy(bufs[0].data, ss->backlog.data + ss->off, rest);
+        ss->backlog.len = 0; ss->off = 0;
+    }
+    memcpy(bufs[0].data + rest, eos, sizeof(eos));
 }
 
 int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
 {
-    dsv1_batch *b;
-    DSV_BUF acc = {NULL, 0};
-    uint8_t *packed, *o;
-    int c, y, rc, nbuf = 0;
-    unsigned off = 0;
+    enc_sess *ss;
+    uint8_t *o;
+    int c, y, rc;
 
     if (!bufs) { dsv1_log(1, "null buffer list passed to encoder!"); return 0; }
     if (!enc->ref) {
-        if ((rc = batch_open_on(&b, enc, 0, dsv1_device, 1, 1))) {
+        const char *e = getenv("DSV1_ENC_PIPELINE");
+        ss = (enc_sess *)calloc(1, sizeof(*ss));
+        ss->pipelined = enc->rc_mode == DSV_RATE_CONTROL_CRF && !(e && atoi(e) == 0);
+        /* one GOP per batch (the motion search of a whole batch is one launch per pyramid level), within 8..32 frames */
+        ss->F = !ss->pipelined ? 1 : (enc->gop >= 8 && enc->gop <= 32 ? enc->gop : 16);
+        if ((rc = batch_open_on(&ss->b, enc, 0, dsv1_device, 1, ss->F))) {
             dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
+            free(ss);
             dsv_frame_ref_dec(frame);
             return 0;
         }
-        enc->ref = b;
+        ss->fb = ss->b->g.frame_bytes;
+        for (c = 0; c < (ss->pipelined ? 2 : 1); c++)
+            if (dsvg_host_alloc(ss->b->ctx, (void **)&ss->pin[c], ss->fb * (size_t)ss->F)) {
+                dsv1_log(1, "pinned frame buffer: %s", dsvg_last_error());
+                sess_free(ss);
+                dsv_frame_ref_dec(frame);
+                return 0;
+            }
+        enc->ref = ss;
     }
-    b = (dsv1_batch *)enc->ref;
-    packed = (uint8_t *)malloc(b->g.frame_bytes);
-    o = packed;
+    ss = (enc_sess *)enc->ref;
+    /* the frame is copied now: the caller may reuse its pixel memory as soon as this returns */
+    o = ss->pin[ss->cur] + (size_t)ss->fill * ss->fb;
     for (c = 0; c < 3; c++)
         for (y = 0; y < frame->planes[c].h; y++, o += frame->planes[c].w)
             memcpy(o, frame->planes[c].data + (size_t)y * frame->planes[c].stride, (size_t)frame->planes[c].w);
-    rc = dsv1_batch_encode(b, packed, 0, &acc);
-    free(packed);
     dsv_frame_ref_dec(frame);                           /* the encoder owns the frame (dsv_encoder.c:38-40) */
-    if (rc) {
-        dsv1_log(1, "GPU encode failed: %s", dsvg_last_error());
+    ss->fill++;
+    if (!ss->pipelined) {
+        DSV_BUF acc = {NULL, 0};
+        ss->fill = 0;
+        rc = dsv1_batch_encode(ss->b, ss->pin[0], 0, &acc);
+        if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
         dsv_buf_free(&acc);
-        return 0;
+        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); return 0; }
+        return sess_pop(ss, bufs, 2);
     }
-    while (off + DSV_PACKET_HDR_SIZE <= acc.len && nbuf < 2) {
-        const unsigned n = get_be32(acc.data + off + DSV_PACKET_NEXT_OFFSET);
-        dsv_mk_buf(&bufs[nbuf], (int)n);
-        memcpy(bufs[nbuf].data, acc.data + off, n);
-        nbuf++;
-        off += n;
+    if (ss->fill == ss->F) {
+        /* the pinned half about to be refilled next was used by the batch before last: it is collected first */
+        rc = DSVG_OK;
+        if (ss->inflight == 2) rc = sess_collect(ss);
+        if (!rc) rc = sess_submit(ss);
+        if (!rc && ss->inflight == 2) rc = sess_collect(ss);
+        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); return 0; }
     }
-    dsv_buf_free(&acc);
-    return nbuf;
+    return sess_pop(ss, bufs, 2);
 }

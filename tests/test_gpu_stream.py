@@ -156,31 +156,62 @@ def test_staged_host_ingest_equals_plain_encode(pkg, orc, pinned):
         assert got[s] == want[s], "stream %d: %s" % (s, explain(got[s], want[s]))
 
 
-def test_drop_in_dsv_enc_api(pkg, orc):
-    """frame-at-a-time dsv_enc_* API (dsv_encoder.h:112-121), as dsv_main.c drives it"""
+def _drive_dsv_enc(pkg, clip, w, h, fmt, **cli):
+    """the frame-at-a-time API driven the way dsv_main.c:506-537 does: whatever count comes back is written out"""
     L = pkg.lib()
-    w, h, fmt, n = 352, 288, A.SUBSAMP_420, 7
-    clip = A.gen_clip(w, h, fmt, 0xD209, n, style=2)
-    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1))
-    enc = pkg.make_encoder_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1)
+    enc = pkg.make_encoder_cfg(w, h, fmt, **cli)
     L.dsv_enc_start(C.byref(enc))
     L.dsv_load_planar_frame.restype = C.c_void_p
     L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
     L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     out = b""
+    counts = []
     bufs = (pkg.Buf * 4)()
-    for t in range(n):
-        frame = L.dsv_load_planar_frame(fmt, clip[t].ctypes.data, w, h)
+    scratch = np.empty_like(clip[0])
+    for t in range(clip.shape[0]):
+        scratch[...] = clip[t]                           # the caller reuses ONE picture buffer (dsv_main.c:506-520)
+        frame = L.dsv_load_planar_frame(fmt, scratch.ctypes.data, w, h)
         nb = L.dsv_enc(C.byref(enc), frame, bufs) & 3
-        assert nb >= 1, L.dsvg_last_error()
+        counts.append(nb)
         for i in range(nb):
             out += C.string_at(bufs[i].data, bufs[i].len)
             L.dsv_buf_free(C.byref(bufs[i]))
+        scratch[...] = 0xA5                              # ... and overwrites it right after the call
     L.dsv_enc_end_of_stream(C.byref(enc), bufs)
     out += C.string_at(bufs[0].data, bufs[0].len)
     L.dsv_buf_free(C.byref(bufs[0]))
     L.dsv_enc_free(C.byref(enc))
+    return out, counts
+
+
+@pytest.mark.parametrize("n,cli", [
+    (7, dict(qp=85, gop=12, rc_mode_cli=1)),                 # shorter than one batch: everything comes out at end of stream
+    (31, dict(qp=85, gop=12, rc_mode_cli=1)),                # two full batches + a tail of 7, a forced-intra style clip
+    (40, dict(qp=70, gop=9, rc_mode_cli=1, scd=0)),
+    (21, dict(qp=85, gop=0, rc_mode_cli=1)),                 # intra-only CRF: batches of 16
+    (9, dict(qp=60, gop=12, rc_mode_cli=0)),                 # ABR: one frame per call, packets come back at once
+])
+def test_drop_in_dsv_enc_api(pkg, orc, n, cli):
+    """frame-at-a-time dsv_enc_* API (dsv_encoder.h:112-121): CRF streams are pipelined in batches behind it (deferred
+    output, flushed by dsv_enc_end_of_stream), ABR is served frame by frame -- the bytes are the serial encoder's"""
+    w, h, fmt = 352, 288, A.SUBSAMP_420
+    clip = A.gen_clip(w, h, fmt, 0xD209 + n, n, style=2)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli))
+    out, counts = _drive_dsv_enc(pkg, clip, w, h, fmt, **cli)
     assert out == want, explain(out, want)
+    if cli["rc_mode_cli"] == 0:
+        assert all(c >= 1 for c in counts)
+    else:
+        assert counts[0] == 0 and max(counts) <= 2          # deferred, never more than the reference's two buffers
+
+
+def test_drop_in_dsv_enc_unpipelined_switch(pkg, orc, monkeypatch):
+    monkeypatch.setenv("DSV1_ENC_PIPELINE", "0")
+    w, h, fmt, n = 352, 288, A.SUBSAMP_420, 7
+    clip = A.gen_clip(w, h, fmt, 0xD209, n, style=2)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1))
+    out, counts = _drive_dsv_enc(pkg, clip, w, h, fmt, qp=85, gop=12, rc_mode_cli=1)
+    assert out == want and all(c >= 1 for c in counts)
 
 
 class Decoder(C.Structure):
