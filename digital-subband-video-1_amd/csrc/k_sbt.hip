@@ -239,6 +239,39 @@ struct HaarQ {
         const int cy = cy0 + j;
         const bool hasB = 2 * cy + 1 < hs;
         const bool rowok = 2 * cy < hs;
+        if constexpr (HZL == 2) {
+            // Sparse P pictures, level 1 (shift quantiser, hzcc.c:221-224): a detail is a signed sum of the cell's four
+            // samples, so |detail| <= 4 max|sample|, and it quantises to zero when that stays below 2^shift.  Most
+            // residual rows of a well predicted picture are that small: one min3/max3 pass over the two rows decides, and
+            // the row pair then only yields its LL values -- no details, no quantiser, nothing to store.  (The cells two
+            // scan regions share are quantised by the earlier region's rule too: those patches take the full path.)
+            if (q.nzf != nullptr && !(chx || chy)) {
+                int mx = r0[0], mn = r0[0];
+#pragma unroll
+                for (int i = 1; i < N; i += 2) {
+                    mx = max(mx, max(r0[i], i + 1 < N ? r0[i + 1] : r0[i]));
+                    mn = min(mn, min(r0[i], i + 1 < N ? r0[i + 1] : r0[i]));
+                }
+#pragma unroll
+                for (int i = 0; i < N; i += 2) {
+                    mx = max(mx, max(r1[i], r1[i + 1]));
+                    mn = min(mn, min(r1[i], r1[i + 1]));
+                }
+                if (4 * max(mx, -mn) < (1 << min(L.sh0, L.sh1))) {
+#pragma unroll
+                    for (int i = 0; i < M; i++) {
+                        const bool hasR = 2 * (cx0 + i) + 1 < ws;
+                        const int a = r0[2 * i];
+                        const int b = hasR ? r0[2 * i + 1] : a;
+                        const int c = hasB ? r1[2 * i] : a;
+                        const int d = hasB ? (hasR ? r1[2 * i + 1] : c) : b;
+                        const int ll = a + b + c + d;
+                        out[i] = scaled ? d_ll_down(ll) : ll;
+                    }
+                    return;
+                }
+            }
+        }
         int slh[M], shl[M], shh[M];
         // flag class of the cells of this row (one byte load when they sit in one block, the usual case); looked up per
         // row so that no table of the whole patch stays alive across the producer of the rows
