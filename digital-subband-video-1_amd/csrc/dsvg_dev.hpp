@@ -18,6 +18,26 @@
 
 #define DSVG_RSU(x, s) (((x) + (1 << (s)) - 1) >> (s))   // DSV_ROUND_SHIFT dsv.h:62
 
+// Pointers that a kernel reads out of a table in memory (JobDev) are GENERIC pointers to the compiler: it emits flat_load /
+// flat_store with a 64-bit address computed per access.  Cast to the global address space where it matters
+// (`auto p = dsvg_global(jb.sym)`): global_load / global_store then take the wave-uniform base in SGPRs and a 32-bit lane
+// offset (no per-access address arithmetic), and they do not occupy the LDS/flat queue.
+#define DSVG_GLOBAL __attribute__((address_space(1)))
+template <typename T> static __device__ __forceinline__ DSVG_GLOBAL T *dsvg_global(T *p) { return (DSVG_GLOBAL T *)p; }
+// element `idx` of a global array with the byte offset formed in 32 bits (idx * sizeof(T) < 4 GiB is the caller's fact): the
+// compiler can then keep the SGPR base + 32-bit lane offset form instead of widening the index
+template <typename T> static __device__ __forceinline__ T dsvg_at(const DSVG_GLOBAL T *base, unsigned idx)
+{
+    return *reinterpret_cast<const DSVG_GLOBAL T *>(reinterpret_cast<const DSVG_GLOBAL char *>(base) + idx * (unsigned)sizeof(T));
+}
+// 8- and 16-byte accesses through such pointers (the HIP vector classes cannot be copied out of an address space)
+typedef unsigned dsvg_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned dsvg_u32x4 __attribute__((ext_vector_type(4)));
+template <typename P> static __device__ __forceinline__ uint2 dsvg_ld2(P p) { const dsvg_u32x2 v = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x2 *>(p); return make_uint2(v.x, v.y); }
+template <typename P> static __device__ __forceinline__ void dsvg_st2(P p, uint2 v) { *reinterpret_cast<DSVG_GLOBAL dsvg_u32x2 *>(p) = dsvg_u32x2{v.x, v.y}; }
+template <typename P> static __device__ __forceinline__ uint4 dsvg_ld4(P p) { const dsvg_u32x4 v = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
+template <typename P> static __device__ __forceinline__ void dsvg_st4(P p, uint4 v) { *reinterpret_cast<DSVG_GLOBAL dsvg_u32x4 *>(p) = dsvg_u32x4{v.x, v.y, v.z, v.w}; }
+
 struct DMV {                 // == DSV_MV (dsv.h:137-150), 12 bytes
     int16_t x, y;
     uint8_t mode, submask, lo_var, lo_tex, high_detail, pad[3];

@@ -1212,6 +1212,22 @@ static __device__ __forceinline__ unsigned pk_pixels(s16x2 e, s16x2 o, bool has_
     return __builtin_bit_cast(unsigned, e) | (__builtin_bit_cast(unsigned, o) << 8);
 }
 
+// the same with the prediction, in 11 instructions instead of 19: sat8(sat8(v + 128) + p - 128) == sat8(clamp(v, -128, 127) + p);
+// v_sat_pk_u8_i16 clamps a pair to bytes, v_perm_b32 interleaves the even and odd columns and splits the prediction bytes
+static __device__ __forceinline__ unsigned pk_pixels_pred(s16x2 e, s16x2 o, unsigned predw)
+{
+    const s16x2 lo = {-128, -128}, hi = {127, 127};
+    const unsigned pe = predw & 0x00ff00ffu, po = __builtin_amdgcn_perm(0u, predw, 0x0c030c01u);
+    e = pk_min(pk_max(e, lo), hi) + __builtin_bit_cast(s16x2, pe);
+    o = pk_min(pk_max(o, lo), hi) + __builtin_bit_cast(s16x2, po);
+    unsigned eb, ob;
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(eb) : "v"(__builtin_bit_cast(unsigned, e)));
+    asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ob) : "v"(__builtin_bit_cast(unsigned, o)));
+    return __builtin_amdgcn_perm(ob, eb, 0x05010400u);      // bytes e0 o0 e1 o1
+}
+// truncating x / 4 on a pair: x + 3 for negative x = x - 3 * (x >> 15), one multiply-add
+static __device__ __forceinline__ s16x2 pk_div4m(s16x2 v) { return (v + (v >> 15) * (short)-3) >> 2; }
+
 #define IT_TX 16     // level-3 cells per tile in x  (=> 128 px)
 #define IT_TY 8      // level-3 cells per tile in y  (=>  64 px)
 #define A3W (IT_TX + 4)
@@ -1246,39 +1262,51 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 {
     constexpr int W3 = IT_TX + 4, W2 = 2 * IT_TX + 4, WP = 2 * IT_TX + 2;      // row pitches: LL3 values, LL2 values, LL1 pairs
     const HzPlane &hp = jb.hz[c];
-    const int16_t *__restrict__ sym = jb.sym + jb.nz_off[c];
-    const uint8_t *__restrict__ stable = jb.stable;
-    const uint8_t *__restrict__ pfl = jb.pflag + g.s3off;
-    const int32_t *__restrict__ s3 = jb.s3 + g.s3off;
+    const auto sym = dsvg_global(static_cast<const int16_t *>(jb.sym + jb.nz_off[c]));
+    const auto stable = dsvg_global(jb.stable);
+    const auto pfl = dsvg_global(static_cast<const uint8_t *>(jb.pflag + g.s3off));
+    const auto s3 = dsvg_global(static_cast<const int32_t *>(jb.s3 + g.s3off));
     const int nbh = hp.nbh, w3 = g.w3, stride = g.pstride;
     const QLevel Q3 = q_level<0>(hp), Q2 = q_level<1>(hp), Q1 = q_level<2>(hp);
-    const uint8_t *pred = jb.pred + g.poff;
-    uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
+    const auto pred = dsvg_global(static_cast<const uint8_t *>(jb.pred + g.poff));
+    const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
 
     // ---- phase 0: every global load of the tile.  The flags of this thread's two level-1 items go first: their symbol
-    // loads depend on them and are issued as soon as they are back, under the rest of the loads.
+    // loads depend on them and are issued as soon as they are back, under the rest of the loads.  Addresses are 32-bit
+    // byte offsets from wave-uniform bases (global_load with an SGPR base: no 64-bit address arithmetic per load), index
+    // products are 24-bit multiplies, and the divisions by the row lengths 20 / 18 / 34 are multiply-shifts (exact for
+    // the item counts of a tile).
+    static_assert(IT_TX == 16 && IT_TY == 8, "the multiply-shift constants below are for 20 / 18 / 34 cells per row");
+    const unsigned utid = (unsigned)tid;
+    auto ldu8 = [](auto base, unsigned off) { return (int)*(base + off); };
+    auto lds16 = [](auto base, unsigned idx) { return (int)dsvg_at(base, idx); };
+    auto flagidx = [&](const QLevel &Q, unsigned cx, unsigned cy) { return __umul24(__umul24(cy, (unsigned)Q.dby) >> 14, (unsigned)nbh) + (__umul24(cx, (unsigned)Q.dbx) >> 14); };
     int pf1[2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
-        pf1[u] = pfl[(size_t)(J0 + (ly >> 2)) * w3 + I0 + gx];
+        const unsigned it = utid + 256u * u, ly = it >> 4, gx = it & 15u;
+        pf1[u] = ldu8(pfl, __umul24((unsigned)J0 + (ly >> 2), (unsigned)w3) + (unsigned)I0 + gx);
     }
     int a3v = 0, nzv = 0;
     if (tid < A3H * A3W) {
-        const int ly = tid / W3, lx = tid - ly * W3;
-        const int cx = I0 - 2 + lx, cy = J0 - 2 + ly;
-        if (cx >= 0 && cy >= 0) { a3v = s3[(size_t)cy * w3 + cx]; nzv = pfl[(size_t)cy * w3 + cx]; }
+        const unsigned ly = (utid * 205u) >> 12, lx = utid - ly * W3;
+        const int cx = I0 - 2 + (int)lx, cy = J0 - 2 + (int)ly;
+        if (cx >= 0 && cy >= 0) {
+            const unsigned o = __umul24((unsigned)cy, (unsigned)w3) + (unsigned)cx;
+            a3v = dsvg_at(s3, o);
+            nzv = ldu8(pfl, o);
+        }
     }
     int s3lh = 0, s3hl = 0, s3hh = 0, k3 = 0, lx3 = 0, ly3 = 0;
     bool ok3 = false;
     if (tid < (IT_TY + 2) * (IT_TX + 2)) {
-        ly3 = tid / (IT_TX + 2); lx3 = tid - ly3 * (IT_TX + 2);
+        ly3 = (int)((utid * 57u) >> 10); lx3 = tid - ly3 * (IT_TX + 2);
         const int cx = I0 - 1 + lx3, cy = J0 - 1 + ly3;
         ok3 = cx >= 0 && cy >= 0;
         if (ok3) {
-            const int o = cy * Q3.sw + cx;
-            s3lh = sym[Q3.base0 + o]; s3hl = sym[Q3.base1 + o]; s3hh = sym[Q3.base2 + o];
-            const int f = stable[((cy * Q3.dby) >> 14) * nbh + ((cx * Q3.dbx) >> 14)];
+            const unsigned o = __umul24((unsigned)cy, (unsigned)Q3.sw) + (unsigned)cx;
+            s3lh = lds16(sym, (unsigned)Q3.base0 + o); s3hl = lds16(sym, (unsigned)Q3.base1 + o); s3hh = lds16(sym, (unsigned)Q3.base2 + o);
+            const int f = ldu8(stable, flagidx(Q3, (unsigned)cx, (unsigned)cy));
             k3 = (f & 2) ? 2 : (f != 0);
         }
     }
@@ -1287,25 +1315,26 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     bool ok2[N2];
 #pragma unroll
     for (int u = 0; u < N2; u++) {
-        const int i = tid + 256 * u;
-        const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
-        const int cx = 2 * I0 - 1 + lx, cy = 2 * J0 - 1 + ly;
+        const unsigned i = utid + 256u * u;
+        const unsigned ly = (i * 241u) >> 13, lx = i - ly * (2 * IT_TX + 2);
+        const int cx = 2 * I0 - 1 + (int)lx, cy = 2 * J0 - 1 + (int)ly;
         ok2[u] = i < (2 * IT_TY + 2) * (2 * IT_TX + 2) && cx >= 0 && cy >= 0;
         s2lh[u] = s2hl[u] = s2hh[u] = k2[u] = 0;
         if (ok2[u]) {
-            const int o = cy * Q2.sw + cx;
-            s2lh[u] = sym[Q2.base0 + o]; s2hl[u] = sym[Q2.base1 + o]; s2hh[u] = sym[Q2.base2 + o];
-            const int f = stable[((cy * Q2.dby) >> 14) * nbh + ((cx * Q2.dbx) >> 14)];
+            const unsigned o = __umul24((unsigned)cy, (unsigned)Q2.sw) + (unsigned)cx;
+            s2lh[u] = lds16(sym, (unsigned)Q2.base0 + o); s2hl[u] = lds16(sym, (unsigned)Q2.base1 + o); s2hh[u] = lds16(sym, (unsigned)Q2.base2 + o);
+            const int f = ldu8(stable, flagidx(Q2, (unsigned)cx, (unsigned)cy));
             k2[u] = (f & 2) ? 2 : (f != 0);
         }
     }
     uint2 pv[2][2];
+    unsigned poff[2];                                   // byte offset of each item's first pixel row in the plane
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
-        const uint8_t *pp = pred + (size_t)(2 * (4 * J0 + ly)) * stride + 8 * (I0 + gx);
-        pv[u][0] = *reinterpret_cast<const uint2 *>(pp);
-        pv[u][1] = *reinterpret_cast<const uint2 *>(pp + stride);
+        const unsigned it = utid + 256u * u, ly = it >> 4, gx = it & 15u;
+        poff[u] = __umul24(2u * (4u * (unsigned)J0 + ly), (unsigned)stride) + 8u * ((unsigned)I0 + gx);
+        pv[u][0] = dsvg_ld2(pred + poff[u]);
+        pv[u][1] = dsvg_ld2(pred + poff[u] + (unsigned)stride);
     }
     uint2 d1lh[2], d1hl[2], d1hh[2];
     s16x2 shv[2][2];
@@ -1314,20 +1343,21 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         d1lh[u] = d1hl[u] = d1hh[u] = make_uint2(0u, 0u);
         shv[u][0] = shv[u][1] = s16x2{0, 0};
         if (pf1[u]) {
-            const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
-            const int cy = 4 * J0 + ly, cx0 = 4 * (I0 + gx);
-            const int o = cy * Q1.sw + cx0;
-            d1lh[u] = *reinterpret_cast<const uint2 *>(sym + Q1.base0 + o);
-            d1hl[u] = *reinterpret_cast<const uint2 *>(sym + Q1.base1 + o);
-            d1hh[u] = *reinterpret_cast<const uint2 *>(sym + Q1.base2 + o);
-            const int by = ((cy * Q1.dby) >> 14) * nbh;
-            const int bx0 = (cx0 * Q1.dbx) >> 14, bx3 = ((cx0 + 3) * Q1.dbx) >> 14;
-            const int f0 = stable[by + bx0];
+            const unsigned it = utid + 256u * u, ly = it >> 4, gx = it & 15u;
+            const unsigned cy = 4u * (unsigned)J0 + ly, cx0 = 4u * ((unsigned)I0 + gx);
+            const unsigned o = __umul24(cy, (unsigned)Q1.sw) + cx0;
+            const auto sb = reinterpret_cast<const DSVG_GLOBAL char *>(sym);
+            d1lh[u] = dsvg_ld2(sb + 2u * ((unsigned)Q1.base0 + o));
+            d1hl[u] = dsvg_ld2(sb + 2u * ((unsigned)Q1.base1 + o));
+            d1hh[u] = dsvg_ld2(sb + 2u * ((unsigned)Q1.base2 + o));
+            const unsigned by = __umul24(__umul24(cy, (unsigned)Q1.dby) >> 14, (unsigned)nbh);
+            const unsigned bx0 = __umul24(cx0, (unsigned)Q1.dbx) >> 14, bx3 = __umul24(cx0 + 3u, (unsigned)Q1.dbx) >> 14;
+            const int f0 = ldu8(stable, by + bx0);
             int f1 = f0, f2 = f0, f3 = f0;
             if (bx0 != bx3) {
-                f1 = stable[by + (((cx0 + 1) * Q1.dbx) >> 14)];
-                f2 = stable[by + (((cx0 + 2) * Q1.dbx) >> 14)];
-                f3 = stable[by + bx3];
+                f1 = ldu8(stable, by + (__umul24(cx0 + 1u, (unsigned)Q1.dbx) >> 14));
+                f2 = ldu8(stable, by + (__umul24(cx0 + 2u, (unsigned)Q1.dbx) >> 14));
+                f3 = ldu8(stable, by + bx3);
             }
             shv[u][0] = s16x2{(short)(f0 ? Q1.sh1 : Q1.sh0), (short)(f1 ? Q1.sh1 : Q1.sh0)};
             shv[u][1] = s16x2{(short)(f2 ? Q1.sh1 : Q1.sh0), (short)(f3 ? Q1.sh1 : Q1.sh0)};
@@ -1339,13 +1369,12 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     if (!__syncthreads_or((nzv | a3v) != 0)) {
         // nothing in reach: every output is zero, the reconstruction is the prediction
         if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
-        if (pred == outp) return;                                // written in place by the forward transform (ping-pong slots)
+        if ((const DSVG_GLOBAL uint8_t *)outp == pred) return;     // written in place by the forward transform (ping-pong slots)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
-            uint8_t *dst = outp + (size_t)(2 * (4 * J0 + ly)) * stride + 8 * (I0 + gx);
-            *reinterpret_cast<uint2 *>(dst) = pv[u][0];
-            *reinterpret_cast<uint2 *>(dst + stride) = pv[u][1];
+            const auto dst = outp + poff[u];
+            dsvg_st2(dst, pv[u][0]);
+            dsvg_st2(dst + (unsigned)stride, pv[u][1]);
         }
         return;
     }
@@ -1373,8 +1402,8 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 #pragma unroll
     for (int u = 0; u < N2; u++) {
         if (!ok2[u]) continue;
-        const int i = tid + 256 * u;
-        const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
+        const unsigned i = (unsigned)tid + 256u * u;
+        const int ly = (int)((i * 241u) >> 13), lx = (int)i - ly * (2 * IT_TX + 2);
         const int *pA = A2u + (ly + 1) * W2 + lx + 1;
         const int LL = pA[0];
         const int q = max(Q2.qp >> k2[u], HZ_MINQ);
@@ -1416,12 +1445,12 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
                 HL = pk_nudge(C, up, dn, HL, hq1, s16x2{pv_, pv_});
             }
             const s16x2 sA = C + HL, sB = LH + HH, sC = C - HL, sD = LH - HH;
-            row0[h2] = pk_pixels(pk_div4(sA + sB), pk_div4(sA - sB), true, h2 ? pv[u][0].y : pv[u][0].x);
-            row1[h2] = pk_pixels(pk_div4(sC + sD), pk_div4(sC - sD), true, h2 ? pv[u][1].y : pv[u][1].x);
+            row0[h2] = pk_pixels_pred(pk_div4m(sA + sB), pk_div4m(sA - sB), h2 ? pv[u][0].y : pv[u][0].x);
+            row1[h2] = pk_pixels_pred(pk_div4m(sC + sD), pk_div4m(sC - sD), h2 ? pv[u][1].y : pv[u][1].x);
         }
-        uint8_t *dst = outp + (size_t)(2 * (4 * J0 + ly)) * stride + 8 * (I0 + gx);
-        *reinterpret_cast<uint2 *>(dst) = make_uint2(row0[0], row0[1]);
-        *reinterpret_cast<uint2 *>(dst + stride) = make_uint2(row1[0], row1[1]);
+        const auto dst = outp + poff[u];
+        dsvg_st2(dst, make_uint2(row0[0], row0[1]));
+        dsvg_st2(dst + (unsigned)stride, make_uint2(row1[0], row1[1]));
     }
 }
 
