@@ -35,6 +35,8 @@ typedef unsigned dsvg_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned dsvg_u32x4 __attribute__((ext_vector_type(4)));
 template <typename P> static __device__ __forceinline__ uint2 dsvg_ld2(P p) { const dsvg_u32x2 v = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x2 *>(p); return make_uint2(v.x, v.y); }
 template <typename P> static __device__ __forceinline__ void dsvg_st2(P p, uint2 v) { *reinterpret_cast<DSVG_GLOBAL dsvg_u32x2 *>(p) = dsvg_u32x2{v.x, v.y}; }
+typedef unsigned dsvg_u32x4a4 __attribute__((ext_vector_type(4), aligned(4)));      // 16 / 12 bytes at a dword-aligned address
+typedef unsigned dsvg_u32x3a4 __attribute__((ext_vector_type(3), aligned(4)));
 template <typename P> static __device__ __forceinline__ uint4 dsvg_ld4(P p) { const dsvg_u32x4 v = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4 *>(p); return make_uint4(v.x, v.y, v.z, v.w); }
 template <typename P> static __device__ __forceinline__ void dsvg_st4(P p, uint4 v) { *reinterpret_cast<DSVG_GLOBAL dsvg_u32x4 *>(p) = dsvg_u32x4{v.x, v.y, v.z, v.w}; }
 
@@ -206,7 +208,8 @@ static __device__ __forceinline__ int hzdq_lo(int v, int q)           // dequant
 static __device__ __forceinline__ int hzq_hi(int v, int sh) { return v < 0 ? -((-v) >> sh) : v >> sh; }
 static __device__ __forceinline__ int hzdq_hi(int v, int sh) { return (int)((unsigned)v << sh); }
 // quantiser for cell (x,y) of region r (tmq4pos hzcc.c:64-74, highest level hzcc.c:221-224)
-static __device__ __forceinline__ int hz_cell_tq(const HzRegion &r, const uint8_t *__restrict__ stable, int nbh, int x, int y)
+template <typename SP>
+static __device__ __forceinline__ int hz_cell_tq(const HzRegion &r, SP stable, int nbh, int x, int y)
 {
     if (r.level < 0) return r.qp;
     const int flag = stable[((y * r.dby) >> 14) * nbh + ((x * r.dbx) >> 14)];

@@ -54,14 +54,14 @@ static __device__ __forceinline__ void store_row(int32_t *p, const int (&v)[M], 
 // belongs to the later region's sub-band, so its producer writes both symbols.
 struct QCtx {
     const HzPlane *hp;
-    const uint8_t *stable;
-    int16_t *sym;
+    const DSVG_GLOBAL uint8_t *stable;      // global address space: see dsvg_global (dsvg_dev.hpp)
+    DSVG_GLOBAL int16_t *sym;
     bool any_ov;
     // P pictures of the encoder (SPARSE mode, nzf != null): the symbol plane is zero between pictures and only non-zero
     // symbols are stored, each with one flag byte per four scan positions (nzf) and one per 2048-cell scan chunk (cfl), so
     // that k_hz_collect touches only what holds data; nz_any gathers "this thread stored something" for the patch flag
     // the inverse transform keys its zero-tile path on.  null: every symbol is stored (I pictures).
-    uint8_t *nzf = nullptr, *cfl = nullptr;
+    DSVG_GLOBAL uint8_t *nzf = nullptr, *cfl = nullptr;
     mutable int nz_any = 0;
     __device__ __forceinline__ void put_sparse(int pos, int v) const
     {
@@ -148,16 +148,15 @@ static __device__ int q_chain(const QCtx &q, int l, int gx, int gy, int val)
     return ev ? hz_dequant_any(e, ev, etq) : 0;
 }
 template <int M>
-static __device__ __forceinline__ void store_sym_row(int16_t *p, const int (&v)[M], int n)
+static __device__ __forceinline__ void store_sym_row(DSVG_GLOBAL int16_t *p, const int (&v)[M], int n)
 {
     if (n >= M) {
         if (M == 4 && (((uintptr_t)p) & 7) == 0) {
-            *reinterpret_cast<uint2 *>(p) = make_uint2((v[0] & 0xffff) | ((unsigned)v[1 % M] << 16),
-                                                       (v[2 % M] & 0xffff) | ((unsigned)v[3 % M] << 16));
+            dsvg_st2(p, make_uint2((v[0] & 0xffff) | ((unsigned)v[1 % M] << 16), (v[2 % M] & 0xffff) | ((unsigned)v[3 % M] << 16)));
             return;
         }
         if (M == 2 && (((uintptr_t)p) & 3) == 0) {
-            *reinterpret_cast<unsigned *>(p) = (v[0] & 0xffff) | ((unsigned)v[1 % M] << 16);
+            *reinterpret_cast<DSVG_GLOBAL unsigned *>(p) = (v[0] & 0xffff) | ((unsigned)v[1 % M] << 16);
             return;
         }
 #pragma unroll
@@ -393,12 +392,12 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
     QCtx q;
     if (Q) {
         const HzPlane &hp = jb.hz[c];
-        q.hp = &hp; q.stable = jb.stable;
-        q.sym = jb.sym + jb.nz_off[c];
+        q.hp = &hp; q.stable = dsvg_global(jb.stable);
+        q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
         q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                    (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
-        q.nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
-        q.cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] : nullptr;
+        q.nzf = jb.nzf ? dsvg_global(jb.nzf + (jb.nz_off[c] >> 2)) : nullptr;
+        q.cfl = jb.nzf ? dsvg_global(jb.cflag + jb.chunk_off[c]) : nullptr;
     }
     // transform level 1,2,3 <-> scan level 2,1,0
     if (Q) {
@@ -439,15 +438,15 @@ static __device__ __forceinline__ void mc_pack8(const int (&pv)[8], unsigned &pl
 // Luma prediction of one 8x8 patch, gr = &reference(wx-1, wy-1).  AX / AY: some lane of the wave has a horizontal /
 // vertical half-pel phase (wave-uniform, so whole stages drop out for waves that do not need them); xh / yh: this lane's.
 template <bool AX, bool AY, typename EMIT>
-static __device__ __forceinline__ void mc_luma_patch(const uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
+static __device__ __forceinline__ void mc_luma_patch(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
 {
     const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
-    const uint8_t *ga = gr - shb;
+    const DSVG_GLOBAL uint8_t *ga = gr - shb;
     if (!AY) {
         // rows wy .. wy+7 only: copy, or the horizontal filter rounded on its own ((t + 8) >> 4)
         U4A4 rw[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) rw[r] = *reinterpret_cast<const U4A4 *>(ga + (long)(r + 1) * stride);
+        for (int r = 0; r < 8; r++) { const dsvg_u32x4a4 t = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(ga + (r + 1) * stride); rw[r] = U4A4{t.x, t.y, t.z, t.w}; }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
@@ -473,7 +472,7 @@ static __device__ __forceinline__ void mc_luma_patch(const uint8_t *gr, int stri
         // all phases in one body: H = xh ? 9(b+c)-(a+d) : 16 b on rows wy-1 .. wy+9, V = yh ? 9(H1+H2)-(H0+H3) : 16 H1
         U4A4 rw[11];
 #pragma unroll
-        for (int k = 0; k < 11; k++) rw[k] = *reinterpret_cast<const U4A4 *>(ga + (long)k * stride);
+        for (int k = 0; k < 11; k++) { const dsvg_u32x4a4 t = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(ga + k * stride); rw[k] = U4A4{t.x, t.y, t.z, t.w}; }
         __builtin_amdgcn_sched_barrier(0);
         int Hq[4][8];
 #pragma unroll
@@ -505,15 +504,15 @@ static __device__ __forceinline__ void mc_luma_patch(const uint8_t *gr, int stri
 // Bytes wx .. wx+8 of a row: 9 + misalignment <= 12, three dwords.
 struct __attribute__((aligned(4))) U3A4 { unsigned x, y, z; };
 template <bool ANY, typename EMIT>
-static __device__ __forceinline__ void mc_chroma_patch(const uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
+static __device__ __forceinline__ void mc_chroma_patch(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
 {
-    const uint8_t *g1 = gr + 1;                                           // reference (wx, wy-1)
+    const DSVG_GLOBAL uint8_t *g1 = gr + 1;                               // reference (wx, wy-1)
     const unsigned shb = (unsigned)(((uintptr_t)g1) & 3);
-    const uint8_t *ga = g1 - shb;
+    const DSVG_GLOBAL uint8_t *ga = g1 - shb;
     constexpr int NR = ANY ? 9 : 8;
     U3A4 rw[NR];
 #pragma unroll
-    for (int k = 0; k < NR; k++) rw[k] = *reinterpret_cast<const U3A4 *>(ga + (long)(k + 1) * stride);
+    for (int k = 0; k < NR; k++) { const dsvg_u32x3a4 t = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x3a4 *>(ga + (k + 1) * stride); rw[k] = U3A4{t.x, t.y, t.z}; }
     __builtin_amdgcn_sched_barrier(0);
     unsigned qlo = 0, qhi = 0, qx = 0;
 #pragma unroll
@@ -571,24 +570,24 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
     const int wo1 = DSVG_RSU(W, 1), ho1 = DSVG_RSU(H, 1), wo2 = DSVG_RSU(W, 2), ho2 = DSVG_RSU(H, 2);
     QCtx q;
     const HzPlane &hp = jb.hz[c];
-    q.hp = &hp; q.stable = jb.stable;
-    q.sym = jb.sym + jb.nz_off[c];
+    q.hp = &hp; q.stable = dsvg_global(jb.stable);
+    q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
     q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
-    q.nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
-    q.cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] : nullptr;
+    q.nzf = jb.nzf ? dsvg_global(jb.nzf + (jb.nz_off[c] >> 2)) : nullptr;
+    q.cfl = jb.nzf ? dsvg_global(jb.cflag + jb.chunk_off[c]) : nullptr;
     // transform level 1 consumes the residual rows in pairs as they appear: only two of them are alive at a time
     HaarQ<8, 2> hq1;
     hq1.init(q, 4 * I, 4 * J, W, H, wo1, ho1);
     int l1[4][4], ra[2][8];
 
     if (mv.mode != 0) {
-        const uint8_t *px = jb.xf + g.poff;
+        const auto px = dsvg_global(static_cast<const uint8_t *>(jb.xf + g.poff));
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             const int y = y0 + r;
             uint2 v = make_uint2(0x80808080u, 0x80808080u);
-            if (y < ph) v = *reinterpret_cast<const uint2 *>(px + (size_t)y * stride + x0);
+            if (y < ph) v = dsvg_ld2(px + (unsigned)(y * stride + x0));
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 ra[r & 1][i] = (int)((v.x >> (8 * i)) & 0xff) - 128;
@@ -598,18 +597,18 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
         }
     } else {
         // the source rows depend on nothing: requested first
-        const uint8_t *sp = jb.src + g.poff;
+        const auto sp = dsvg_global(static_cast<const uint8_t *>(jb.src + g.poff));
         uint2 sw[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) sw[r] = *reinterpret_cast<const uint2 *>(sp + (size_t)min(y0 + r, ph - 1) * stride + x0);
+        for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)(min(y0 + r, ph - 1) * stride + x0));
         const int dx = mv.x >> sh, dy = mv.y >> sv;
         const int xb = bi * bw, yb = bj * bh;
         const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
         const int wy = d_clamp(yb + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1) + (y0 - yb);
         const bool xh = dx & 1, yh = dy & 1;
-        const uint8_t *gr = jb.ref + g.poff + (long)(wy - 1) * stride + (wx - 1);      // reference (wx-1, wy-1)
+        const auto gr = dsvg_global(static_cast<const uint8_t *>(jb.ref + g.poff)) + ((wy - 1) * stride + (wx - 1));      // reference (wx-1, wy-1); may lie before the plane's origin (border)
         const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;        // over the lanes that predict
-        uint8_t *pp = jb.pred + g.poff;
+        const auto pp = dsvg_global(jb.pred + g.poff);
         const bool inside = x0 + 8 <= pw && y0 + 8 <= ph;
         // per prediction row: residual clamp(src - pred + 128) - 128 == clamp(src - pred, -128, 127) (subf bmc.c:43-55 +
         // p2sbc sbt.c:576) into the row registers, the prediction itself to its frame
@@ -622,7 +621,7 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
                 row[i] = d_clamp(sv_ - pv_, -128, 127);
             }
             if (inside) {
-                *reinterpret_cast<uint2 *>(pp + (size_t)(y0 + r) * stride + x0) = make_uint2(plo, phi);
+                dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi));
             } else {
                 // patches on the right / bottom edge: rows past the picture are zero (p2sbc skips them); the column
                 // right after an odd-width picture holds the replicated source edge in the reference's residual frame
@@ -651,8 +650,8 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
     int l2[2][2], l3[1][1];
     haar_fwd_patch_q<4, 1>(l1, l2, 2 * I, 2 * J, wo1, ho1, W, wo2, ho2, coef, true, q);
     haar_fwd_patch_q<2, 0>(l2, l3, I, J, wo2, ho2, W, g.w3, g.h3, coef, true, q);
-    jb.s3[g.s3off + (size_t)J * g.w3 + I] = l3[0][0];
-    if (jb.nzf) jb.pflag[g.s3off + (size_t)J * g.w3 + I] = (uint8_t)q.nz_any;          // every patch, every picture: never stale
+    dsvg_global(jb.s3 + g.s3off)[(unsigned)(J * g.w3 + I)] = l3[0][0];
+    if (jb.nzf) dsvg_global(jb.pflag + g.s3off)[(unsigned)(J * g.w3 + I)] = (uint8_t)q.nz_any;      // every patch, every picture: never stale
 }
 
 // --------------------------------------------------------------------------------------------
@@ -719,8 +718,8 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
     bool chx = false, chy = false;
     if (Q) {
         const HzPlane &hp = jb.hz[c];
-        q.hp = &hp; q.stable = jb.stable;
-        q.sym = jb.sym + jb.nz_off[c];
+        q.hp = &hp; q.stable = dsvg_global(jb.stable);
+        q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
         q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                    (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
         Lq = q_level<2>(hp);
@@ -807,8 +806,8 @@ __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__
         static_assert(LV == 2, "only transform levels 1..3 have per-level scan regions");
         const HzPlane &hp = jb.hz[c];
         QCtx q;
-        q.hp = &hp; q.stable = jb.stable;
-        q.sym = jb.sym + jb.nz_off[c];
+        q.hp = &hp; q.stable = dsvg_global(jb.stable);
+        q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
         q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
                    (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
         haar_fwd_patch_q<4, 1>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true, q);
