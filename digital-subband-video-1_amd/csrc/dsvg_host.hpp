@@ -58,6 +58,7 @@ struct Slab {
     X(KID_HME_LEVEL, "void k_hme_level<false>") X(KID_HME_LEVEL0, "void k_hme_level<true>") X(KID_HME_DETAIL, "k_hme_detail") \
     X(KID_MC, "k_mc") \
     X(KID_FWD_HAAR_PIX, "void k_fwd_haar_pix<false>") X(KID_FWD_HAAR_PIX_Q, "void k_fwd_haar_pix<true>") X(KID_FWD_MC_PIX_Y, "void k_fwd_mc_pix<0>") X(KID_FWD_MC_PIX_C, "void k_fwd_mc_pix<1>") \
+    X(KID_FWD_MC_FAST_Y, "void k_fwd_mc_fast<0>") X(KID_FWD_MC_FAST_C, "void k_fwd_mc_fast<1>") \
     X(KID_FWD_B4T, "void k_fwd_b4t<false>") X(KID_FWD_B4T_Q, "void k_fwd_b4t<true>") \
     X(KID_FWD_HAAR_MID2, "void k_fwd_haar_mid<2, false>") X(KID_FWD_HAAR_MID2_Q, "void k_fwd_haar_mid<2, true>") X(KID_FWD_HAAR_MID4, "void k_fwd_haar_mid<4, false>") \
     X(KID_FWD_TAIL, "k_fwd_tail") \

@@ -28,7 +28,8 @@ struct HmeArgs {
 int  sbt_tail_supported(const SbtGeo &g);
 void sbt_set_func_attributes();
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, int from_src, Prof *pf = nullptr, int with_tail = 1, int fused = 0,
-                    const struct McGeo *mc = nullptr, const DMV *mvs0 = nullptr);   // mc: motion compensation fused into the P forward transform
+                    const struct McGeo *mc = nullptr, const DMV *mvs0 = nullptr,    // mc: motion compensation fused into the P forward transform
+                    int general_whole = 1);   // mc: 0 = the caller knows that no block of these pictures is intra (the general kernel then only runs on the strips of the grid the geometry asks for)
 bool mc_fusable(const struct McGeo &MG);
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1,
                     int insym = 0);

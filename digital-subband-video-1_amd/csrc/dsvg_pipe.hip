@@ -713,6 +713,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     int gk[DSVG_MAX_CODE_STREAMS + 1];                        // device jobs [gk[g], gk[g+1]) of every step -> stream g
     for (int g = 0; g <= NG; g++) gk[g] = (int)((long)njobs * g / NG);
     std::vector<int> ioff((size_t)NG * nsteps, 0), icnt((size_t)NG * nsteps, 0);
+    std::vector<char> noint((size_t)NG * nsteps, 1);          // every P picture of the (step, group) was scanned for intra blocks (and icnt says how many)
     int *il = c->ilist_h + (size_t)base * c->nblk;         // intra blocks of each (step, group)'s P pictures (mc_fused)
     int iln = 0;
     for (int t = 0; t < nsteps; t++) {
@@ -749,6 +750,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             c->slots_h[d] = j.recon_slot;
             memcpy(c->stable_h + (size_t)d * c->nblk, j.stable_blocks, (size_t)c->nblk);
             if (isP) memcpy(c->mv_h + (size_t)d * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+            if (isP && !c->mc_fused) noint[NG * t + g] = 0;
             if (isP && c->mc_fused && !j.no_intra_blocks) {
                 // index relative to the first P job of the group's launch
                 const int k0 = std::max(gk[g], nIs[t]);
@@ -792,8 +794,9 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                 if (c->mc_fused) {
                     // inter blocks are predicted inside the forward transform; k_mc only serves the intra blocks (block means)
                     if (icnt[NG * t + g]) launch_mc(st, jd + nI, nP, c->MG, 1, &c->prof, mv0, c->ilist_d + (size_t)base * c->nblk + ioff[NG * t + g], icnt[NG * t + g]);
-                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
-                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1, &c->MG, mv0);
+                    const int gw = icnt[NG * t + g] || !noint[NG * t + g];      // intra blocks somewhere in these pictures (or not known)
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1, &c->MG, mv0, gw);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1, &c->MG, mv0, gw);
                 } else {
                     launch_mc(st, jd + nI, nP, c->MG, 1, &c->prof, mv0);
                     launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);

@@ -538,6 +538,195 @@ static __device__ __forceinline__ void mc_chroma_patch(const DSVG_GLOBAL uint8_t
     }
 }
 
+// ---- the common patch of a sparse P picture: inter block, whole 8x8 patch inside the picture, every cell of each level in
+// ONE block of the stability map, no cell shared between scan regions.  Same arithmetic as the general body of
+// k_fwd_mc_pix below (compensate + subf + fwd + hzcc quantiser), with every "does this sample / cell / band exist" fact a
+// constant: ~600 instructions per patch instead of ~1900.
+struct FwdFastQ {
+    int sh1[4];                 // level 1: shift of each cell row (hzcc.c:221-224)
+    int q2[2], q3;              // levels 2, 3: quantiser of each cell row (tmq4pos hzcc.c:64-74)
+    float rc2[2], rc3;
+};
+// trunc(v / 2^sh) == sign(v) * (|v| >> sh): the level-1 symbol
+static __device__ __forceinline__ int sym_shift(int v, int sh) { return (v + ((v >> 31) & ((1 << sh) - 1))) >> sh; }
+
+// level 1 of one pair of residual rows (cell row cy1 of the plane, cells cx1 .. cx1 + 3) -> LL row + sparse symbols
+static __device__ __forceinline__ void fwd_fast_rows1(const QCtx &q, const QLevel &L1, int sh1, int cx1, int cy1,
+                                                      const int (&r0)[8], const int (&r1)[8], int (&out)[4])
+{
+    int mx = max(r0[0], r0[1]), mn = min(r0[0], r0[1]);
+#pragma unroll
+    for (int i = 2; i < 8; i += 2) { mx = max(mx, max(r0[i], r0[i + 1])); mn = min(mn, min(r0[i], r0[i + 1])); }
+#pragma unroll
+    for (int i = 0; i < 8; i += 2) { mx = max(mx, max(r1[i], r1[i + 1])); mn = min(mn, min(r1[i], r1[i + 1])); }
+    if (4 * max(mx, -mn) < (1 << sh1)) {                // |detail| <= 4 max|sample| < 2^shift: every symbol is zero
+#pragma unroll
+        for (int i = 0; i < 4; i++) out[i] = (r0[2 * i] + r0[2 * i + 1]) + (r1[2 * i] + r1[2 * i + 1]);
+        return;
+    }
+    int slh[4], shl[4], shh[4], any = 0;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int s0 = r0[2 * i] + r0[2 * i + 1], s1 = r1[2 * i] + r1[2 * i + 1];
+        const int d0 = r0[2 * i] - r0[2 * i + 1], d1 = r1[2 * i] - r1[2 * i + 1];
+        out[i] = s0 + s1;                               // level 1 of a P picture is unscaled (LVL_TEST sbt.c:22)
+        slh[i] = sym_shift(d0 + d1, sh1); shl[i] = sym_shift(s0 - s1, sh1); shh[i] = sym_shift(d0 - d1, sh1);
+        any |= slh[i] | shl[i] | shh[i];
+    }
+    if (any) {
+        q.nz_any = 1;
+        const int pr = cy1 * L1.sw + cx1;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (slh[i]) q.put_sparse(L1.base0 + pr + i, slh[i]);
+            if (shl[i]) q.put_sparse(L1.base1 + pr + i, shl[i]);
+            if (shh[i]) q.put_sparse(L1.base2 + pr + i, shh[i]);
+        }
+    }
+}
+// one scaled level (transform levels 2, 3: scan levels 1, 0) on an NxN patch of LL values -> LL patch + sparse symbols
+template <int N, int HZL>
+static __device__ __forceinline__ void fwd_fast_level(const QCtx &q, const QLevel &L, const int (&qqv)[N / 2], const float (&rcv)[N / 2], int cx0, int cy0,
+                                                      const int (&in)[N][N], int (&out)[N / 2][N / 2])
+{
+#pragma unroll
+    for (int j = 0; j < N / 2; j++)
+#pragma unroll
+        for (int i = 0; i < N / 2; i++) {
+            const int qq = qqv[j];
+            const float rc = rcv[j];
+            const int a = in[2 * j][2 * i], b = in[2 * j][2 * i + 1], c = in[2 * j + 1][2 * i], d = in[2 * j + 1][2 * i + 1];
+            const int s0 = a + b, s1 = c + d, d0 = a - b, d1 = c - d;
+            out[j][i] = d_ll_down(s0 + s1);
+            int slh, shl, shh;
+            (void)q_coef<HZL>(qq, rc, d0 + d1, slh);
+            (void)q_coef<HZL>(qq, rc, s0 - s1, shl);
+            (void)q_coef<HZL>(qq, rc, d0 - d1, shh);
+            if (slh | shl | shh) {
+                q.nz_any = 1;
+                const int pr = (cy0 + j) * L.sw + cx0 + i;
+                if (slh) q.put_sparse(L.base0 + pr, slh);
+                if (shl) q.put_sparse(L.base1 + pr, shl);
+                if (shh) q.put_sparse(L.base2 + pr, shh);
+            }
+        }
+}
+
+// which patches take the lean kernel: sparse P picture, inter block, the whole 8x8 patch inside the picture, no cell shared
+// between scan regions (they sit in the first row / column of patches), and ONE stability flag per level -- the cells of
+// the patch lie in one block of the map except where the fixed-point block steps of hzcc.c:196-197 round across an edge
+struct FwdFastSel { bool ok; QLevel L1, L2, L3; int i1[4], i2[2], i3; };
+static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, const HzPlane &hp, bool any_ov, int mode, int I, int J,
+                                                          int x0, int y0, int pw, int ph)
+{
+    // The map's block rows are hp.nbv / region height apart in coefficient space, not blk_h: a picture whose height is not
+    // a multiple of the block height makes them drift against the real block grid, so a patch often spans two map rows.
+    // One flag per CELL ROW of each level covers that; only a patch that spans two map COLUMNS goes to the general kernel.
+    FwdFastSel S;
+    S.ok = false;
+    // cells shared between scan regions (hzcc.c:30-48 rounds the region sizes up at every level): column 0 of the LH / HH
+    // bands of a level whose width is odd, row 0 of its HL / HH bands when its height is odd -- first column / row of patches
+    const bool ovx = any_ov && ((2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_w[1] > hp.s_w[2]));
+    const bool ovy = any_ov && ((2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_h[1] > hp.s_h[2]));
+    if (jb.nzf != nullptr && mode == 0 && x0 + 8 <= pw && y0 + 8 <= ph && !(ovx && I == 0) && !(ovy && J == 0)) {
+        S.L1 = q_level<2>(hp); S.L2 = q_level<1>(hp); S.L3 = q_level<0>(hp);
+        const int nbh = hp.nbh;
+        const int b1x = (4 * I * S.L1.dbx) >> 14, b2x = (2 * I * S.L2.dbx) >> 14;
+        S.ok = b1x == ((4 * I + 3) * S.L1.dbx) >> 14 && b2x == ((2 * I + 1) * S.L2.dbx) >> 14;
+#pragma unroll
+        for (int j = 0; j < 4; j++) S.i1[j] = (((4 * J + j) * S.L1.dby) >> 14) * nbh + b1x;
+#pragma unroll
+        for (int j = 0; j < 2; j++) S.i2[j] = (((2 * J + j) * S.L2.dby) >> 14) * nbh + b2x;
+        S.i3 = ((J * S.L3.dby) >> 14) * nbh + ((I * S.L3.dbx) >> 14);
+    }
+    return S;
+}
+
+template <int CH>
+__global__ __launch_bounds__(256) void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
+                                                     const DMV *__restrict__ mvs0)
+{
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    if (I >= g.w3 || J >= g.h3) return;
+    const JobDev &jb = jobs[job];
+    const int sh = CH ? MG.hs : 0, sv = CH ? MG.vs : 0;
+    const int bw = MG.blk_w >> sh, bh = MG.blk_h >> sv;
+    const int pw = MG.w[c], ph = g.ph, stride = g.pstride;
+    const int x0 = 8 * I, y0 = 8 * J;
+    const int bi = (int)(((float)I + 0.5f) * __builtin_amdgcn_rcpf((float)(bw >> 3)));
+    const int bj = (int)(((float)J + 0.5f) * __builtin_amdgcn_rcpf((float)(bh >> 3)));
+    const int nblk = MG.nbh * MG.nbv, blk = bj * MG.nbh + bi;
+    const DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
+    const HzPlane &hp = jb.hz[c];
+    QCtx q;
+    q.hp = &hp; q.stable = dsvg_global(jb.stable);
+    q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
+    q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+               (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+    q.nzf = jb.nzf ? dsvg_global(jb.nzf + (jb.nz_off[c] >> 2)) : nullptr;
+    q.cfl = jb.nzf ? dsvg_global(jb.cflag + jb.chunk_off[c]) : nullptr;
+    const FwdFastSel S = fwd_fast_sel(jb, hp, q.any_ov, mv.mode, I, J, x0, y0, pw, ph);
+    if (!S.ok) return;                                   // k_fwd_mc_pix takes these
+    const QLevel &L1 = S.L1, &L2 = S.L2, &L3 = S.L3;
+    int f1[4], f2[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) f1[j] = q.stable[S.i1[j]];
+#pragma unroll
+    for (int j = 0; j < 2; j++) f2[j] = q.stable[S.i2[j]];
+    const int f3 = q.stable[S.i3];
+    const auto sp = dsvg_global(static_cast<const uint8_t *>(jb.src + g.poff));
+    uint2 sw[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)((y0 + r) * stride + x0));
+    FwdFastQ fq;
+#pragma unroll
+    for (int j = 0; j < 4; j++) fq.sh1[j] = f1[j] ? L1.sh1 : L1.sh0;
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        fq.q2[j] = max(L2.qp >> ((f2[j] & 2) ? 2 : (f2[j] != 0)), HZ_MINQ);
+        fq.rc2[j] = __builtin_amdgcn_rcpf((float)(fq.q2[j] << 1));
+    }
+    fq.q3 = max(L3.qp >> ((f3 & 2) ? 2 : (f3 != 0)), HZ_MINQ);
+    fq.rc3 = __builtin_amdgcn_rcpf((float)(fq.q3 << 1));
+    const int dx = mv.x >> sh, dy = mv.y >> sv;
+    const int xb = bi * bw, yb = bj * bh;
+    const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
+    const int wy = d_clamp(yb + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1) + (y0 - yb);
+    const bool xh = dx & 1, yh = dy & 1;
+    const auto gr = dsvg_global(static_cast<const uint8_t *>(jb.ref + g.poff)) + ((wy - 1) * stride + (wx - 1));
+    const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;     // over the lanes on this path
+    const auto pp = dsvg_global(jb.pred + g.poff);
+    int l1[4][4], ra[2][8];
+    auto emit = [&](int r, unsigned plo, unsigned phi) {
+        int (&row)[8] = ra[r & 1];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int sv_ = (int)(((i < 4 ? sw[r].x : sw[r].y) >> (8 * (i & 3))) & 0xff);
+            const int pv_ = (int)(((i < 4 ? plo : phi) >> (8 * (i & 3))) & 0xff);
+            row[i] = d_clamp(sv_ - pv_, -128, 127);       // subf bmc.c:43-55 + p2sbc sbt.c:576
+        }
+        dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi));
+        if (r & 1) fwd_fast_rows1(q, L1, fq.sh1[r >> 1], 4 * I, 4 * J + (r >> 1), ra[0], ra[1], l1[r >> 1]);
+    };
+    if (CH == 0) {
+        if (any_y) mc_luma_patch<true, true>(gr, stride, xh, yh, emit);
+        else if (any_x) mc_luma_patch<true, false>(gr, stride, xh, yh, emit);
+        else mc_luma_patch<false, false>(gr, stride, xh, yh, emit);
+    } else {
+        if (any_x || any_y) mc_chroma_patch<true>(gr, stride, xh, yh, emit);
+        else mc_chroma_patch<false>(gr, stride, xh, yh, emit);
+    }
+    int l2[2][2], l3[1][1];
+    fwd_fast_level<4, 1>(q, L2, fq.q2, fq.rc2, 2 * I, 2 * J, l1, l2);
+    const int q3v[1] = {fq.q3};
+    const float rc3v[1] = {fq.rc3};
+    fwd_fast_level<2, 0>(q, L3, q3v, rc3v, I, J, l2, l3);
+    dsvg_global(jb.s3 + g.s3off)[(unsigned)(J * g.w3 + I)] = l3[0][0];
+    dsvg_global(jb.pflag + g.s3off)[(unsigned)(J * g.w3 + I)] = (uint8_t)q.nz_any;
+}
+
 // four waves per SIMD (128 VGPRs, a few dwords spilled) measured against three without spills: luma the same, chroma 4 % faster
 #ifndef MC_WPE
 #define MC_WPE 4
@@ -549,11 +738,12 @@ static __device__ __forceinline__ void mc_chroma_patch(const DSVG_GLOBAL uint8_t
 #endif
 template <int CH>
 __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
-                                                    const DMV *__restrict__ mvs0)
+                                                    const DMV *__restrict__ mvs0, int skip_fast, int bxofs, int byofs, int bxstep, int bystep)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
     const SbtGeo g = G.g[c];
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    // (strips of the grid: block columns bxofs + k * bxstep, block rows byofs + k * bystep)
+    const int I = (bxofs + (int)blockIdx.x * bxstep) * 64 + threadIdx.x, J = (byofs + (int)blockIdx.y * bystep) * 4 + threadIdx.y;
     if (I >= g.w3 || J >= g.h3) return;
     const JobDev &jb = jobs[job];
     const int sh = CH ? MG.hs : 0, sv = CH ? MG.vs : 0;
@@ -576,6 +766,11 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
                (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
     q.nzf = jb.nzf ? dsvg_global(jb.nzf + (jb.nz_off[c] >> 2)) : nullptr;
     q.cfl = jb.nzf ? dsvg_global(jb.cflag + jb.chunk_off[c]) : nullptr;
+    // the common patches (inter block, inside the picture, one stability flag per level) were coded by k_fwd_mc_fast
+    if (skip_fast && fwd_fast_sel(jb, hp, q.any_ov, mv.mode, I, J, x0, y0, pw, ph).ok) return;
+#ifdef AB_COUNT_GENERAL
+    if (jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + (threadIdx.x & 63), 1u);
+#endif
     // transform level 1 consumes the residual rows in pairs as they appear: only two of them are alive at a time
     HaarQ<8, 2> hq1;
     hq1.init(q, 4 * I, 4 * J, W, H, wo1, ho1);
@@ -1844,17 +2039,57 @@ bool mc_fusable(const McGeo &MG)
 }
 
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
-                    int from_src, Prof *pf, int with_tail, int fused, const McGeo *mc, const DMV *mvs0)
+                    int from_src, Prof *pf, int with_tail, int fused, const McGeo *mc, const DMV *mvs0, int general_whole)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
     if (isP && fused && mc) {
         // motion compensation inside the transform: reference + source in, prediction + symbols out
-        PB(c0 == 0 ? KID_FWD_MC_PIX_Y : KID_FWD_MC_PIX_C, smp * 5.0);
-        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_pix<0>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
-        else         hipLaunchKernelGGL((k_fwd_mc_pix<1>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
+        // two launches over the same grid: the lean kernel codes the common patches (few registers, no edge logic: it runs
+        // at the HBM rate of its 3 B/sample: reference + source in, prediction out), the general kernel everything else
+        // (picture edges, intra blocks, cells shared between scan regions) and returns at once for the common ones
+        PB(c0 == 0 ? KID_FWD_MC_FAST_Y : KID_FWD_MC_FAST_C, smp * 3.0);
+        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_fast<0>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
+        else         hipLaunchKernelGGL((k_fwd_mc_fast<1>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
         PE();
+        // Where can a patch fail fwd_fast_sel?  Intra blocks (anywhere: the caller knows), otherwise only in the first /
+        // last row or column of patches (cells shared between scan regions, a ragged picture edge) -- unless a patch can
+        // span two columns of the stability map, which depends on the geometry alone.  The general kernel is launched
+        // over the whole grid, over the strips that can hold such patches, or not at all.
+        bool whole = general_whole != 0, top = false, bottom = false, left = false, right = false;
+        for (int c = c0; c < c0 + npl; c++) {
+            const SbtGeo &gc = G.g[c];
+            const int sw0 = DSVG_RSU(gc.W, 3), sw1 = DSVG_RSU(gc.W, 2), sw2 = DSVG_RSU(gc.W, 1);
+            const int sh0 = DSVG_RSU(gc.H, 3), sh1 = DSVG_RSU(gc.H, 2), sh2 = DSVG_RSU(gc.H, 1);
+            left = left || 2 * sw0 > sw1 || 2 * sw1 > sw2;
+            top = top || 2 * sh0 > sh1 || 2 * sh1 > sh2;
+            right = right || (mc->w[c] & 7);
+            bottom = bottom || (gc.ph & 7);
+            const int d1 = (mc->nbh << 14) / sw2, d2 = (mc->nbh << 14) / sw1;       // HzRegion.dbx of transform levels 1, 2
+            for (int I = 0; I < gc.w3 && !whole; I++)
+                whole = ((4 * I * d1) >> 14) != (((4 * I + 3) * d1) >> 14) || ((2 * I * d2) >> 14) != (((2 * I + 1) * d2) >> 14);
+        }
+        const dim3 full = grid3(g.w3, g.h3, nz);
+        auto general = [&](dim3 gr, int bxo, int byo, int bxs, int bys) {
+            PB(c0 == 0 ? KID_FWD_MC_PIX_Y : KID_FWD_MC_PIX_C, 0.0);
+            if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_pix<0>), gr, dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, 1, bxo, byo, bxs, bys);
+            else         hipLaunchKernelGGL((k_fwd_mc_pix<1>), gr, dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, 1, bxo, byo, bxs, bys);
+            PE();
+        };
+        if (whole) general(full, 0, 0, 1, 1);
+        else {
+            // the top and bottom strips in one launch (two block rows: 0 and the last), likewise left and right
+            const int fy = (int)full.y, fx = (int)full.x;
+            if ((top || bottom) && fy == 1) general(dim3(full.x, 1, nz), 0, 0, 1, 1);
+            else if (top && bottom) general(dim3(full.x, 2, nz), 0, 0, 1, fy - 1);
+            else if (top) general(dim3(full.x, 1, nz), 0, 0, 1, 1);
+            else if (bottom) general(dim3(full.x, 1, nz), 0, fy - 1, 1, 1);
+            if ((left || right) && fx == 1) general(dim3(1, full.y, nz), 0, 0, 1, 1);
+            else if (left && right) general(dim3(2, full.y, nz), 0, 0, fx - 1, 1);
+            else if (left) general(dim3(1, full.y, nz), 0, 0, 1, 1);
+            else if (right) general(dim3(1, full.y, nz), fx - 1, 0, 1, 1);
+        }
     } else if (isP) {
         PB(fused ? KID_FWD_HAAR_PIX_Q : KID_FWD_HAAR_PIX, smp * (fused ? 3.0 : 5.0));   // 1 B/sample in, 4 B/sample out (details + LL3); fused: 2 B symbols
         if (fused) hipLaunchKernelGGL((k_fwd_haar_pix<true>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
