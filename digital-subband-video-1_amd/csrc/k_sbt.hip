@@ -2152,8 +2152,9 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     }
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
     if (isP) {
-        // 4 B/sample coefficients (2 B/sample symbols when insym) + 1 B prediction in, 1 B out
-        PB(insym ? (filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM) : (filt ? KID_INV_TILE_PIX_F : KID_INV_TILE_PIX), smp * (insym ? 4.0 : 6.0));
+        // 4 B/sample coefficients + 1 B prediction in, 1 B out; from the symbol planes (insym): prediction 1 + reconstruction 1 +
+        // the level-2/3 symbols 0.47 + flags -- the level-1 symbols (1.5 B/sample) are only fetched for flagged patches
+        PB(insym ? (filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM) : (filt ? KID_INV_TILE_PIX_F : KID_INV_TILE_PIX), smp * (insym ? 2.5 : 6.0));
         if (insym) {
             if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
             else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);

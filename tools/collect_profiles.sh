@@ -20,7 +20,7 @@ python3 $REPO/tools/make_pmc_traffic.py "$OUT/pmc_hbm_per_kernel.csv" $GOPS "$OU
 cp "$OUT/pmc_traffic.json" $REPO/profiles/pmc_traffic.json
 cd $REPO && python3 bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
 cd /tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $REPO/bench.py --cpu-gops 0 > "$OUT/bench_under_rocprof.json" 2>/dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/kt -- python3 $REPO/bench.py --cpu-gops 0 --no-extras > "$OUT/bench_under_rocprof.json" 2>/dev/null
 f=$(ls /tmp/kt/*/*kernel_stats.csv | head -1); cp "$f" "$OUT/rocprofv3_kernel_stats.csv"
 t=$(ls /tmp/kt/*/*kernel_trace.csv | head -1); python3 $REPO/tools/trace_summary.py "$t" > "$OUT/kernel_trace_summary.txt"
 cat "$OUT/bench.json"

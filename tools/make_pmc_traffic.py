@@ -10,7 +10,15 @@ utilisation: one wave64 VALU instruction occupies its SIMD for 4 cycles).
 usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json> [pmc_sq_per_kernel.csv]"""
 import csv
 import json
+import re
 import sys
+
+
+def kid(name):
+    """rocprofv3 prints k_hme_level<true, 12> (second argument: rows per lane of a full block, picked per geometry by the
+    launcher); the profiling API of the library and bench.py name the kernel by its first argument only"""
+    return re.sub(r"k_hme_level<(true|false), \d+>", r"k_hme_level<\1>", name)
+
 
 rows = list(csv.DictReader(open(sys.argv[1])))
 out = {"gops": int(sys.argv[2]),
@@ -21,12 +29,12 @@ out = {"gops": int(sys.argv[2]),
 for r in rows:
     f = float(r.get("FETCH_SIZE_per_launch", 0) or 0)
     w = float(r.get("WRITE_SIZE_per_launch", 0) or 0)
-    out["kernels"][r["kernel"]] = {"launches": int(r["launches"]), "fetch_kib_per_launch": f, "write_kib_per_launch": w,
+    out["kernels"][kid(r["kernel"])] = {"launches": int(r["launches"]), "fetch_kib_per_launch": f, "write_kib_per_launch": w,
                                    "hbm_bytes_per_launch": round((2 * f + w) * 1024),
                                    "hbm_bytes_per_launch_raw": round((f + w) * 1024)}
 if len(sys.argv) > 4:
     for r in csv.DictReader(open(sys.argv[4])):
-        e = out["kernels"].setdefault(r["kernel"], {"launches": int(r["launches"])})
+        e = out["kernels"].setdefault(kid(r["kernel"]), {"launches": int(r["launches"])})
         e["valu_insts_per_launch"] = float(r.get("SQ_INSTS_VALU_per_launch", 0) or 0)
         e["salu_insts_per_launch"] = float(r.get("SQ_INSTS_SALU_per_launch", 0) or 0)
         e["waves_per_launch"] = float(r.get("SQ_WAVES_per_launch", 0) or 0)
