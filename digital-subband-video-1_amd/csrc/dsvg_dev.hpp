@@ -145,6 +145,9 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     uint8_t *pflag;          // per plane (offset s3off[c]) and 8x8-pixel patch: 1 = the patch has a non-zero detail symbol (levels 1-3); written for every patch of every picture
     uint8_t *cflag;          // per scan chunk (chunk_off[c] + chunk): 1 = the chunk holds a non-zero detail symbol; cleared by k_hz_collect
     unsigned *stat;          // null, or [4][64] diagnostic counters (64 shards each: one address takes ~90 atomics/us): inverse tiles on the general path {luma, chroma}, on the zero path {luma, chroma}
+    int dec_sym[3];          // decoder, P pictures: 1 = the plane's detail entries are scattered as int16 symbols into the (zero-kept) symbol plane and the
+                             // fused inverse dequantises them (planes without shared scan cells); 0 = dequantised int32 coefficients
+    int pf_off[3];           // offset of each plane in pflag (= CoefLayout.s3off)
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
     HzPlane hz[3];
     int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level

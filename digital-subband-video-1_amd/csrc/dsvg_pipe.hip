@@ -98,6 +98,8 @@ struct dsvg_ctx {
     uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
     unsigned *stat = nullptr;        // [4][64] inverse-transform tile counters (general luma / chroma, zero luma / chroma), sharded
     bool stats_on = false;
+    bool no_dec_sym = false;         // DSV1_NO_DEC_SYM: the decoder keeps int32 coefficients for P pictures too (A/B switch)
+    bool dec_sym_ok[2] = {false, false};   // luma / chroma planes have no cell shared between scan regions
     bool fetch_shared = false;       // DSV1_FETCH_ON_ANALYSIS: st_c is st_a           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
@@ -232,6 +234,13 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     }
     c->mc_fused = mc_fusable(MG) && !getenv("DSV1_NO_MC_FUSION");
     c->no_inplace_pred = getenv("DSV1_NO_INPLACE_PRED") != nullptr;
+    c->no_dec_sym = getenv("DSV1_NO_DEC_SYM") != nullptr;
+    for (int g2 = 0; g2 < 2; g2++) {
+        HzPlane hp; make_hz_plane(hp, CL.w[g2 ? 1 : 0], CL.h[g2 ? 1 : 0], 100, 1, g2, c->nbh, c->nbv);
+        const bool ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+        // (the fused inverse from symbol planes also wants the level-1 bands 4-aligned and the plane's LL5 path as usual)
+        c->dec_sym_ok[g2] = !ov && (CL.off[g2 ? 1 : 0] & 3) == 0 && (CL.off[2] & 3) == 0;
+    }
     // two coding streams by default: with the analysis and fetch streams that is four, the number of hardware queues
     // the runtime maps streams onto (three coding streams measured 18.5 ms per step against 14.3 with two and 15.4 with one)
     { const char *e = getenv("DSV1_CODE_STREAMS"); c->code_streams = e ? atoi(e) : 2; }
@@ -613,6 +622,7 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
     jb.psum = c->psum + (size_t)t * 3;
     jb.bits = c->bits + (size_t)t * c->bits_per_job;
     for (int p = 0; p < 3; p++) {
+        jb.pf_off[p] = (int)CL.s3off[p];
         jb.bits_off[p] = c->bits_off[p]; jb.bits_cap[p] = c->bits_cap[p];
         jb.nz_off[p] = c->nz_off[p]; jb.hz_coef_off[p] = CL.off[p]; jb.chunk_off[p] = c->chunk_off[p];
         make_hz_plane(jb.hz[p], CL.w[p], CL.h[p], quant, isP, p, c->nbh, c->nbv);
@@ -623,18 +633,19 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
 
 // enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
+// insym: details come from the symbol planes -- bit 0: I pictures, bit 1: luma of P pictures, bit 2: chroma of P pictures
 static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, hipStream_t st = nullptr)
 {
     if (!st) st = c->st;
     const JobDev *jd = c->jobs_d + d0;
     launch_sbt_tail(st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
     if (nI > 0) {
-        launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym);
-        launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym);
+        launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym & 1);
+        launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym & 1);
     }
     if (n > nI) {
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, insym);
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, insym);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, (insym >> 1) & 1);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, (insym >> 2) & 1);
     }
     launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
     return DSVG_OK;
@@ -808,7 +819,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             // k_hz_collect is the LAST reader of the sparse symbol planes and clears what it reads
             launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
                             (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
-            OPCHK(enqueue_recon(c, nI, n, d0, 1, st));
+            OPCHK(enqueue_recon(c, nI, n, d0, 7, st));
             launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0);
         }
     }
@@ -1023,6 +1034,16 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         fill_job(c, jb, t, isP, j.quant);
         jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
         jb.recon = c->recon.p + (size_t)j.recon_slot * c->L[0].pitch;
+        if (isP && !c->no_dec_sym) {
+            // sparse decode of P pictures: the detail entries go to the zero-kept int16 symbol planes and the fused inverse
+            // of the encoder reconstructs from them (no 12 MB of int32 coefficients to clear and to read per picture); a
+            // plane whose scan regions share cells keeps the coefficient path (an absent later symbol must leave the
+            // earlier region's VALUE in place there, hzcc.c:295-435)
+            jb.sym = c->symP + (size_t)t * c->nz_total;
+            jb.nzf = c->nzf + (size_t)t * (c->nz_total >> 2);          // (marks the job as sparse for the inverse; the flags themselves are the encoder's)
+            for (int p = 0; p < 3; p++) jb.dec_sym[p] = c->dec_sym_ok[p < 1 ? 0 : 1];
+            if (j.recon_slot != j.ref_recon_slot && !c->no_inplace_pred) jb.pred = jb.recon;     // prediction written in place (ping-pong slots)
+        }
         c->slots_h[hb + t] = j.recon_slot;
         memcpy(c->stable_h + (hb + t) * c->nblk, j.stable_blocks, (size_t)c->nblk);
         if (isP) memcpy(c->mv_h + (hb + t) * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
@@ -1055,12 +1076,14 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h + hb * c->nblk, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h + hb, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
-    HIPCHK(hipMemsetAsync(c->coef, 0, CL.total * (size_t)njobs * sizeof(int32_t), c->st));
+    launch_dec_clear(c->st, c->jobs_d, njobs);
     launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof);
     if (njobs > nI) {
         launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }
-    OPCHK(enqueue_recon(c, nI, njobs));
+    const int insym = c->no_dec_sym ? 0 : (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
+    OPCHK(enqueue_recon(c, nI, njobs, 0, insym));
+    if (insym && njobs > nI) launch_hz_unscatter(c->st, c->jobs_d + nI, njobs - nI, max_entries);
     HIPCHK(hipGetLastError());
     return DSVG_OK;
 }

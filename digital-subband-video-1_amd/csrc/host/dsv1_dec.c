@@ -10,7 +10,7 @@
 typedef struct {
     dsvg_ctx *ctx;
     dsvg_geom g;
-    int have_ref;
+    int have_ref, rpar;         /* rpar: which of the two reference slots holds the current reference picture */
 } dec_sess;
 
 void dsv_dec_free(DSV_DECODER *d)
@@ -176,7 +176,7 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
 
     if (!d->ref) {
         ss = (dec_sess *)calloc(1, sizeof(*ss));
-        if ((rc = dsvg_ctx_create(&ss->ctx, dsv1_device, m->width, m->height, m->subsamp, 1, 1, 2, 1, 1))) {
+        if ((rc = dsvg_ctx_create(&ss->ctx, dsv1_device, m->width, m->height, m->subsamp, 1, 1, 3, 1, 1))) {
             dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
             free(ss);
             dsv_buf_free(buffer);
@@ -199,8 +199,10 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
         dsv1_log(2, "reference frame not found");
         goto done;
     }
-    job.ref_recon_slot = has_ref ? 0 : -1;
-    job.recon_slot = is_ref ? 0 : 1;
+    /* reference pictures alternate between slots 0 and 1 (the prediction of a P picture is written straight into the
+     * slot its reconstruction will live in, dsvg_decode_pictures); other pictures go to slot 2 */
+    job.ref_recon_slot = has_ref ? ss->rpar : -1;
+    job.recon_slot = is_ref ? (ss->rpar ^ 1) : 2;
     if ((rc = dsvg_decode_pictures(ss->ctx, 1, &job))) {
         dsv1_log(1, "GPU decode failed: %s", dsvg_last_error());
         goto done;
@@ -210,7 +212,7 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
         dsv1_log(1, "GPU download failed: %s", dsvg_last_error());
         goto done;
     }
-    if (is_ref) ss->have_ref = 1;
+    if (is_ref) { ss->have_ref = 1; ss->rpar ^= 1; }
     f = dsv_mk_frame(m->subsamp, m->width, m->height, 1);
     {
         const uint8_t *o = packed;
@@ -235,6 +237,7 @@ struct dsv1_decbatch {
     DSV_META meta;
     int nstreams, nblk;
     unsigned char *have_ref;         /* [nstreams] */
+    unsigned char *rpar;             /* [nstreams] which of the stream's two reference slots holds its current reference */
     unsigned char *stable;           /* [nstreams][nblk] */
     DSV_MV *mvs;                     /* [nstreams][nblk] */
     dsvg_dec_job *pj;                /* [nstreams] parsed job of each stream's packet */
@@ -246,7 +249,7 @@ void dsv1_decbatch_close(dsv1_decbatch *d)
 {
     if (!d) return;
     if (d->ctx) dsvg_ctx_destroy(d->ctx);
-    free(d->have_ref); free(d->stable); free(d->mvs); free(d->jobs); free(d->pj); free(d->slots);
+    free(d->have_ref); free(d->rpar); free(d->stable); free(d->mvs); free(d->jobs); free(d->pj); free(d->slots);
     free(d);
 }
 
@@ -260,14 +263,16 @@ int dsv1_decbatch_open(dsv1_decbatch **out, int device, const DSV_META *meta, in
     if (!d) return DSVG_ERR_ARG;
     d->meta = *meta;
     d->nstreams = nstreams;
-    /* stream s keeps its reference picture in reconstruction slot s; non-reference pictures go to slot nstreams + s */
-    if ((rc = dsvg_ctx_create(&d->ctx, device, meta->width, meta->height, meta->subsamp, 1, 1, 2 * nstreams, nstreams, nstreams))) {
+    /* stream s keeps its reference pictures alternately in reconstruction slots s and nstreams + s (ping-pong: a P picture's
+     * prediction is written straight into its own slot); non-reference pictures go to slot 2 * nstreams + s */
+    if ((rc = dsvg_ctx_create(&d->ctx, device, meta->width, meta->height, meta->subsamp, 1, 1, 3 * nstreams, nstreams, nstreams))) {
         free(d);
         return rc;
     }
     dsvg_ctx_geom(d->ctx, &d->g);
     d->nblk = d->g.nblocks_h * d->g.nblocks_v;
     d->have_ref = (unsigned char *)calloc((size_t)nstreams, 1);
+    d->rpar = (unsigned char *)calloc((size_t)nstreams, 1);
     d->stable = (unsigned char *)calloc((size_t)nstreams * d->nblk, 1);
     d->mvs = (DSV_MV *)calloc((size_t)nstreams * d->nblk, sizeof(DSV_MV));
     d->jobs = (dsvg_dec_job *)calloc((size_t)nstreams, sizeof(dsvg_dec_job));
@@ -312,9 +317,9 @@ static void parse_stream(void *vp, int s, int tid)
         dsv1_log(2, "stream %d: reference frame not found", s);
         return;
     }
-    job->ref_recon_slot = has_ref ? s : -1;
-    job->recon_slot = is_ref ? s : d->nstreams + s;
-    if (is_ref) d->have_ref[s] = 1;
+    job->ref_recon_slot = has_ref ? s + d->nstreams * d->rpar[s] : -1;
+    job->recon_slot = is_ref ? s + d->nstreams * (d->rpar[s] ^ 1) : 2 * d->nstreams + s;
+    if (is_ref) { d->have_ref[s] = 1; d->rpar[s] ^= 1; }
     pc->status[s] = DSV_DEC_OK;
 }
 

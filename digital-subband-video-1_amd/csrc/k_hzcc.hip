@@ -1039,13 +1039,66 @@ __global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict_
     const HzRegion r = hp.r[find_region(hp, p)];
     const int local = p - r.base;
     const int y = local / r.sw, x = local - y * r.sw;
+    if (jb.dec_sym[c] && r.level >= 0) {
+        // sparse decode: the SYMBOL goes to its scan slot (the fused inverse dequantises it: levels 1-3 never exist as
+        // int32 coefficients), and the 8x8-pixel patch it belongs to is flagged for the inverse's symbol fetch
+        (jb.sym + jb.nz_off[c])[p] = (int16_t)(v < -32767 ? -32767 : (v > 32767 ? 32767 : v));    // (beyond int16: not a symbol of 8-bit video)
+        jb.pflag[jb.pf_off[c] + (y >> r.level) * hp.r[0].sw + (x >> r.level)] = 1;
+        return;
+    }
     const int tq = cell_tq(r, jb.stable, hp.nbh, x, y);
     (jb.coef + jb.hz_coef_off[c])[(size_t)(r.y0 + y) * hp.w + r.x0 + x] = dequant_any(r, v, tq);
+}
+
+// decoder, after the reconstruction: the symbols scattered by k_hz_scatter_lv are taken down again (the planes stay zero)
+__global__ __launch_bounds__(256) void k_hz_unscatter(const JobDev *__restrict__ jobs, int c0)
+{
+    const int c = c0 + (int)blockIdx.z;
+    const JobDev &jb = jobs[blockIdx.y];
+    if (!jb.dec_sym[c]) return;
+    const HzPlane &hp = jb.hz[c];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= jb.dec_cnt[c]) return;
+    const int p = jb.nzpos[jb.nz_off[c] + i];
+    if (p >= hp.r[1].base && p < hp.nscan) (jb.sym + jb.nz_off[c])[p] = 0;
+}
+// decoder, before the scatter: what the scatter does not overwrite must be zero (hzcc_dec writes non-zeros only, hzcc.c:295-435).
+// Sparse planes: the LL region of the coefficient plane (levels >= 4) and the patch flags; other planes: the whole plane.
+__global__ __launch_bounds__(256) void k_dec_clear(const JobDev *__restrict__ jobs)
+{
+    const int c = (int)blockIdx.z;
+    const JobDev &jb = jobs[blockIdx.y];
+    const HzPlane &hp = jb.hz[c];
+    int32_t *plane = jb.coef + jb.hz_coef_off[c];
+    const int tid = blockIdx.x * 256 + threadIdx.x, nth = gridDim.x * 256;
+    if (jb.dec_sym[c]) {
+        const int w3 = hp.r[0].sw, h3 = hp.r[0].sh, n = w3 * h3;
+        for (int i = tid; i < n; i += nth) {
+            const int y = i / w3, x = i - y * w3;
+            plane[(size_t)y * hp.w + x] = 0;
+            jb.pflag[jb.pf_off[c] + i] = 0;
+        }
+    } else {
+        const size_t n4 = ((((uintptr_t)plane) & 15) == 0) ? ((size_t)hp.w * hp.h) >> 2 : 0;    // 16-byte stores where the plane allows
+        int4 *p4 = reinterpret_cast<int4 *>(plane);
+        for (size_t i = tid; i < n4; i += nth) p4[i] = make_int4(0, 0, 0, 0);
+        for (size_t i = (n4 << 2) + tid; i < (size_t)hp.w * hp.h; i += nth) plane[i] = 0;
+    }
 }
 
 // -------------------------------------------------------------------------------------------------
 #define PB(kid, bytes) do { if (pf) pf->begin(st, kid, bytes); } while (0)
 #define PE() do { if (pf) pf->end(st); } while (0)
+
+void launch_dec_clear(hipStream_t st, const JobDev *jobs, int njobs)
+{
+    hipLaunchKernelGGL(k_dec_clear, dim3(64, njobs, 3), dim3(256), 0, st, jobs);
+}
+void launch_hz_unscatter(hipStream_t st, const JobDev *jobs, int njobs, int max_entries)
+{
+    if (max_entries <= 0) return;
+    hipLaunchKernelGGL(k_hz_unscatter, dim3((max_entries + 255) / 256, njobs, 3), dim3(256), 0, st, jobs, 0);
+}
 
 // The entropy stage in two halves, so a pipeline can put them on different streams.
 // launch_hz_quant: everything the RECONSTRUCTION depends on -- jobs [0, nplain) take the full quantiser
