@@ -70,7 +70,7 @@ struct Slab {
     X(KID_INV_TILE_PIX_F, "void k_inv_haar_tile<true, 0, false>") X(KID_INV_TILE_PIX, "void k_inv_haar_tile<false, 0, false>") \
     X(KID_INV_TILE_S1_F, "void k_inv_haar_tile<true, 1, false>") X(KID_INV_TILE_S1, "void k_inv_haar_tile<false, 1, false>") \
     X(KID_INV_TILE_S1_SYM_F, "void k_inv_haar_tile<true, 1, true>") X(KID_INV_TILE_S1_SYM, "void k_inv_haar_tile<false, 1, true>") \
-    X(KID_INV_B4T, "k_inv_b4t")
+    X(KID_INV_B4T, "void k_inv_b4t<false>") X(KID_INV_B4T_SYM, "void k_inv_b4t<true>")
 enum {
 #define X(id, name) id,
     DSVG_KERNEL_IDS(X)

@@ -961,9 +961,11 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
             store_sym_row<4>(q.sym + Lq.base2 + o, shh, nC);
         }
         store_row<4>(jb.s1 + g.s1off + (size_t)cy * g.w1 + 4 * I, ll, nC);
-        store_row<4>(coef + (size_t)cy * W + hw + 4 * I, lh, nC);
-        store_row<4>(coef + (size_t)(hh + cy) * W + 4 * I, hl, nC);
-        store_row<4>(coef + (size_t)(hh + cy) * W + hw + 4 * I, hhv, nC);
+        if (!Q) {               // Q: k_inv_b4t<true> dequantises the symbols itself: the int32 bands are not needed
+            store_row<4>(coef + (size_t)cy * W + hw + 4 * I, lh, nC);
+            store_row<4>(coef + (size_t)(hh + cy) * W + 4 * I, hl, nC);
+            store_row<4>(coef + (size_t)(hh + cy) * W + hw + 4 * I, hhv, nC);
+        }
     }
 }
 
@@ -1944,6 +1946,10 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
 #define BT_C 32                 // level-1 cells per tile edge -> 64x64 px
 #define BT_VW (BT_C + 2)        // columns k0-1 .. k0+BT_C of each half
 
+// SYM (the encoder's I pictures): the level-1 details come from the int16 symbol planes k_fwd_b4t<true> left behind and are
+// dequantised here (shift quantiser hzcc.c:221-224) -- the dequantised int32 bands are then neither written by the forward
+// transform nor read back (3 + 3 B/sample less)
+template <bool SYM>
 __global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     __shared__ int VL[2 * BT_C][BT_VW];     // column-pass output, low-horizontal half
@@ -1967,6 +1973,29 @@ __global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs
         const int k = d_clamp(k0 - 1 + kl, 0, hw - 1);
         const int mp = m > 0 ? m - 1 : 0, mn = m < hh - 1 ? m + 1 : hh - 1;
         int Xp, X0, Xn, Yp, Y0, Yn;
+        if constexpr (SYM) {
+            const HzPlane &hp = jb.hz[c];
+            const QLevel L1 = q_level<2>(hp);
+            const auto sym = dsvg_global(static_cast<const int16_t *>(jb.sym + jb.nz_off[c]));
+            const auto stb = dsvg_global(jb.stable);
+            // shift of the cell (k, row): one flag per row, one byte load when the three rows lie in one block row of the map
+            const unsigned bxk = __umul24((unsigned)k, (unsigned)L1.dbx) >> 14, nbh = (unsigned)hp.nbh;
+            const unsigned byp = __umul24((unsigned)mp, (unsigned)L1.dby) >> 14, by0 = __umul24((unsigned)m, (unsigned)L1.dby) >> 14,
+                           byn = __umul24((unsigned)mn, (unsigned)L1.dby) >> 14;
+            const int f0 = stb[__umul24(by0, nbh) + bxk];
+            const int fp = byp == by0 ? f0 : (int)stb[__umul24(byp, nbh) + bxk], fn = byn == by0 ? f0 : (int)stb[__umul24(byn, nbh) + bxk];
+            const int shp = fp ? L1.sh1 : L1.sh0, sh0 = f0 ? L1.sh1 : L1.sh0, shn = fn ? L1.sh1 : L1.sh0;
+            const unsigned op = __umul24((unsigned)mp, (unsigned)L1.sw) + (unsigned)k, o0 = __umul24((unsigned)m, (unsigned)L1.sw) + (unsigned)k,
+                           on = __umul24((unsigned)mn, (unsigned)L1.sw) + (unsigned)k;
+            auto dq = [](int v, int sh) { return (int)((unsigned)v << sh); };
+            if (half == 0) {      // low-horizontal columns: X = LL1 (s1), Y = HL1
+                Xp = s1[(size_t)mp * g.w1 + k]; X0 = s1[(size_t)m * g.w1 + k]; Xn = s1[(size_t)mn * g.w1 + k];
+                Yp = dq(dsvg_at(sym, (unsigned)L1.base1 + op), shp); Y0 = dq(dsvg_at(sym, (unsigned)L1.base1 + o0), sh0); Yn = dq(dsvg_at(sym, (unsigned)L1.base1 + on), shn);
+            } else {              // high-horizontal columns: X = LH1, Y = HH1
+                Xp = dq(dsvg_at(sym, (unsigned)L1.base0 + op), shp); X0 = dq(dsvg_at(sym, (unsigned)L1.base0 + o0), sh0); Xn = dq(dsvg_at(sym, (unsigned)L1.base0 + on), shn);
+                Yp = dq(dsvg_at(sym, (unsigned)L1.base2 + op), shp); Y0 = dq(dsvg_at(sym, (unsigned)L1.base2 + o0), sh0); Yn = dq(dsvg_at(sym, (unsigned)L1.base2 + on), shn);
+            }
+        } else
         if (half == 0) {      // low-horizontal columns: X = LL1 (s1), Y = HL1
             Xp = s1[(size_t)mp * g.w1 + k]; X0 = s1[(size_t)m * g.w1 + k]; Xn = s1[(size_t)mn * g.w1 + k];
             Yp = coef[(size_t)(hh + mp) * W + k]; Y0 = coef[(size_t)(hh + m) * W + k]; Yn = coef[(size_t)(hh + mn) * W + k];
@@ -2096,7 +2125,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         else       hipLaunchKernelGGL((k_fwd_haar_pix<false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
     } else {
-        PB(fused ? KID_FWD_B4T_Q : KID_FWD_B4T, smp * (fused ? 6.5 : 5.0));   // fused: + 2 B symbols on the 3/4 detail cells
+        PB(fused ? KID_FWD_B4T_Q : KID_FWD_B4T, smp * (fused ? 3.5 : 5.0));   // 1 in, LL1 1 + details 3 out; fused: LL1 1 + symbols 1.5 out
         if (fused) hipLaunchKernelGGL((k_fwd_b4t<true>), grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         else       hipLaunchKernelGGL((k_fwd_b4t<false>), grid3((g.W + 7) / 8, (g.H + 7) / 8, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, from_src);
         PE();
@@ -2174,8 +2203,9 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         }
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
-        PB(KID_INV_B4T, smp * 5.0);
-        hipLaunchKernelGGL(k_inv_b4t, bg, dim3(256), 0, st, jobs, G, c0, npl);
+        PB(insym ? KID_INV_B4T_SYM : KID_INV_B4T, smp * (insym ? 3.5 : 5.0));           // LL1 1 + details 3 (symbols: 1.5) in, 1 out
+        if (insym) hipLaunchKernelGGL((k_inv_b4t<true>), bg, dim3(256), 0, st, jobs, G, c0, npl);
+        else       hipLaunchKernelGGL((k_inv_b4t<false>), bg, dim3(256), 0, st, jobs, G, c0, npl);
         PE();
     }
 }
