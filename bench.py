@@ -281,8 +281,7 @@ def main():
         # the sparse inverse transform moves data only for tiles that carry a residual: price it at what it really moved
         # (general tile: 128x64 samples x 2.5 B = prediction 1 + reconstruction 1 + level-2/3 symbols 0.47 + flags; the level-1
         # symbols are only fetched for flagged patches; every tile: its 20x12 LL3 values and patch flags, 5 B each)
-        for kname, tg, tz in (("void k_inv_haar_tile<true, 0, true>", tiles["general_luma"], tiles["zero_luma"]),
-                              ("void k_inv_haar_tile<false, 0, true>", tiles["general_chroma"], tiles["zero_chroma"])):
+        for kname, tg, tz in (("void k_inv_haar_tile<true, 0, true>", tiles["general_luma"], tiles["zero_luma"]),):
             if kname in table and table[kname][1]:
                 m_, n_, _ = table[kname]
                 table[kname] = (m_, n_, tg * 128.0 * 64.0 * 2.5 + (tg + tz) * 240.0 * 5.0)

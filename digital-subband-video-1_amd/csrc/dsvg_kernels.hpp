@@ -32,7 +32,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
                     int general_whole = 1);   // mc: 0 = the caller knows that no block of these pictures is intra (the general kernel then only runs on the strips of the grid the geometry asks for)
 bool mc_fusable(const struct McGeo &MG);
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1,
-                    int insym = 0);
+                    int insym = 0, int patch_kernel = 0);   // patch_kernel: sparse P pictures (flags valid, prediction given): unfiltered planes take k_inv_patch_c
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
 // k_hzcc.hip
 void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf = nullptr, double samples = 0,

@@ -98,6 +98,7 @@ struct dsvg_ctx {
     uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
     unsigned *stat = nullptr;        // [4][64] inverse-transform tile counters (general luma / chroma, zero luma / chroma), sharded
     bool stats_on = false;
+    bool no_patch_kernel = false;    // DSV1_NO_PATCH_KERNEL: chroma of P pictures stays on the tile kernel (A/B switch)
     bool no_dec_sym = false;         // DSV1_NO_DEC_SYM: the decoder keeps int32 coefficients for P pictures too (A/B switch)
     bool dec_sym_ok[2] = {false, false};   // luma / chroma planes have no cell shared between scan regions
     bool fetch_shared = false;       // DSV1_FETCH_ON_ANALYSIS: st_c is st_a           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
@@ -235,6 +236,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     c->mc_fused = mc_fusable(MG) && !getenv("DSV1_NO_MC_FUSION");
     c->no_inplace_pred = getenv("DSV1_NO_INPLACE_PRED") != nullptr;
     c->no_dec_sym = getenv("DSV1_NO_DEC_SYM") != nullptr;
+    c->no_patch_kernel = getenv("DSV1_NO_PATCH_KERNEL") != nullptr;
     for (int g2 = 0; g2 < 2; g2++) {
         HzPlane hp; make_hz_plane(hp, CL.w[g2 ? 1 : 0], CL.h[g2 ? 1 : 0], 100, 1, g2, c->nbh, c->nbv);
         const bool ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
@@ -645,7 +647,7 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
     }
     if (n > nI) {
         launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, (insym >> 1) & 1);
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, (insym >> 2) & 1);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, (insym >> 2) & 1, ((insym >> 2) & 1) && !c->no_patch_kernel);
     }
     launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
     return DSVG_OK;

@@ -1655,7 +1655,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 // whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
 // other two modes).  The tile is IT_TX x IT_TY cells of the mode's top level.
 template <bool FILT, int MODE, bool SYM>
-__global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+__global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int bxofs, int byofs)
 {
     static_assert(!SYM || MODE != 2, "levels >= 4 live in the LL region: int32 coefficients");
     constexpr bool TO_PIX = (MODE == 0);
@@ -1670,7 +1670,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     const int32_t *coef = jb.coef + g.coff;
     const int inw = DSVG_RSU(W, TOP), inh = DSVG_RSU(H, TOP);
     const int32_t *s3 = (MODE == 2) ? jb.s5 + g.s5off : jb.s3 + g.s3off;       // LL band of level TOP
-    const int I0 = blockIdx.x * IT_TX, J0 = blockIdx.y * IT_TY;
+    const int I0 = ((int)blockIdx.x + bxofs) * IT_TX, J0 = ((int)blockIdx.y + byofs) * IT_TY;     // (offsets: a strip of the tile grid)
     const int tid = threadIdx.x;
     const bool isP = jb.isP != 0;
 
@@ -1941,6 +1941,115 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
 }
 
 // --------------------------------------------------------------------------------------------
+// inverse levels 3,2,1 of a sparse P picture WITHOUT the smoothing filter (chroma, sbt.c:352-435): a cell's outputs depend
+// on nothing but its own LL value and details, so an 8x8-pixel patch is a closed computation -- one thread per patch, no LDS,
+// no halo, no barrier (the tile kernel spent its time waiting on four barriers and a tile's worth of loads per workgroup:
+// 1.4 ms per step for 680 instructions per wave).  Most patches carry no detail symbol (flag off): every level's output is
+// then the scaled LL value, the whole patch gets ONE residual value v = ((LL3 * 5/4 / 4) * 5/4 / 4) / 4, and when that is zero
+// -- a small LL3 -- the reconstruction is the prediction that is already in place: nothing is loaded or stored.
+// Patches [0, imax) x [0, jmax): whole patches inside the picture; the tile kernel takes the strips beyond.
+// --------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax)
+{
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    const SbtGeo g = G.g[c];
+    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    if (I >= imax || J >= jmax) return;
+    const JobDev &jb = jobs[job];
+    const unsigned pidx = (unsigned)(J * g.w3 + I);
+    const int ll3 = dsvg_at(dsvg_global(static_cast<const int32_t *>(jb.s3 + g.s3off)), pidx);
+    const int pf = dsvg_global(static_cast<const uint8_t *>(jb.pflag + g.s3off))[pidx];
+    const auto pred = dsvg_global(static_cast<const uint8_t *>(jb.pred + g.poff));
+    const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
+    const bool inplace = (const DSVG_GLOBAL uint8_t *)outp == pred;
+    const unsigned stride = (unsigned)g.pstride, p0 = (unsigned)(8 * J) * stride + 8u * (unsigned)I;
+    int res[8][8];                                              // residual of the patch (before sbc2int)
+    if (!pf) {
+        const int v3 = d_div4<true>(d_ll_up_t<true>(ll3));
+        const int v2 = d_div4<true>(d_ll_up_t<true>(v3));
+        const int v1 = d_div4<true>(v2);                        // level 1 of a P picture is unscaled
+        const int cv = d_clamp(v1, -128, 127);
+        if (cv == 0) {                                          // reconstruction = prediction
+            if (inplace) return;
+#pragma unroll
+            for (int r = 0; r < 8; r++) dsvg_st2(outp + (p0 + r * stride), dsvg_ld2(pred + (p0 + r * stride)));
+            return;
+        }
+        const s16x2 cc = s16x2{(short)cv, (short)cv};
+        uint2 pv[8];
+#pragma unroll
+        for (int r = 0; r < 8; r++) pv[r] = dsvg_ld2(pred + (p0 + r * stride));
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            unsigned o[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const unsigned pw_ = h ? pv[r].y : pv[r].x;
+                const s16x2 e = cc + __builtin_bit_cast(s16x2, pw_ & 0x00ff00ffu), od = cc + __builtin_bit_cast(s16x2, __builtin_amdgcn_perm(0u, pw_, 0x0c030c01u));
+                unsigned eb, ob;
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(eb) : "v"(__builtin_bit_cast(unsigned, e)));
+                asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ob) : "v"(__builtin_bit_cast(unsigned, od)));
+                o[h] = __builtin_amdgcn_perm(ob, eb, 0x05010400u);
+            }
+            dsvg_st2(outp + (p0 + r * stride), make_uint2(o[0], o[1]));
+        }
+        return;
+    }
+    // the patch has detail symbols: the three levels in registers, symbols dequantised on the way (rare)
+    const HzPlane &hp = jb.hz[c];
+    const auto sym = dsvg_global(static_cast<const int16_t *>(jb.sym + jb.nz_off[c]));
+    const auto stb = dsvg_global(jb.stable);
+    const QLevel Q3 = q_level<0>(hp), Q2 = q_level<1>(hp), Q1 = q_level<2>(hp);
+    const unsigned nbh = (unsigned)hp.nbh;
+    auto flag = [&](const QLevel &Q, int cx, int cy) { return (int)stb[__umul24(__umul24((unsigned)cy, (unsigned)Q.dby) >> 14, nbh) + (__umul24((unsigned)cx, (unsigned)Q.dbx) >> 14)]; };
+    int l2[2][2], l1[4][4];
+    {
+        const int f = flag(Q3, I, J), q = max(Q3.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ);
+        const unsigned o = (unsigned)(J * Q3.sw + I);
+        const int LL = d_ll_up_t<true>(ll3), LH = dq_lo24(dsvg_at(sym, (unsigned)Q3.base0 + o), q), HL = dq_lo24(dsvg_at(sym, (unsigned)Q3.base1 + o), q),
+                  HH = dq_lo24(dsvg_at(sym, (unsigned)Q3.base2 + o), q);
+        l2[0][0] = d_div4<true>(LL + LH + HL + HH); l2[0][1] = d_div4<true>(LL - LH + HL - HH);
+        l2[1][0] = d_div4<true>(LL + LH - HL - HH); l2[1][1] = d_div4<true>(LL - LH - HL + HH);
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int cx = 2 * I + i, cy = 2 * J + j;
+            const int f = flag(Q2, cx, cy), q = max(Q2.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ);
+            const unsigned o = (unsigned)(cy * Q2.sw + cx);
+            const int LL = d_ll_up_t<true>(l2[j][i]), LH = dq_lo24(dsvg_at(sym, (unsigned)Q2.base0 + o), q), HL = dq_lo24(dsvg_at(sym, (unsigned)Q2.base1 + o), q),
+                      HH = dq_lo24(dsvg_at(sym, (unsigned)Q2.base2 + o), q);
+            l1[2 * j][2 * i] = d_div4<true>(LL + LH + HL + HH); l1[2 * j][2 * i + 1] = d_div4<true>(LL - LH + HL - HH);
+            l1[2 * j + 1][2 * i] = d_div4<true>(LL + LH - HL - HH); l1[2 * j + 1][2 * i + 1] = d_div4<true>(LL - LH - HL + HH);
+        }
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int cx = 4 * I + i, cy = 4 * J + j;
+            const int sh = flag(Q1, cx, cy) ? Q1.sh1 : Q1.sh0;
+            const unsigned o = (unsigned)(cy * Q1.sw + cx);
+            const int LL = l1[j][i], LH = (int)((unsigned)(int)dsvg_at(sym, (unsigned)Q1.base0 + o) << sh), HL = (int)((unsigned)(int)dsvg_at(sym, (unsigned)Q1.base1 + o) << sh),
+                      HH = (int)((unsigned)(int)dsvg_at(sym, (unsigned)Q1.base2 + o) << sh);
+            res[2 * j][2 * i] = d_div4<true>(LL + LH + HL + HH); res[2 * j][2 * i + 1] = d_div4<true>(LL - LH + HL - HH);
+            res[2 * j + 1][2 * i] = d_div4<true>(LL + LH - HL - HH); res[2 * j + 1][2 * i + 1] = d_div4<true>(LL - LH - HL + HH);
+        }
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const uint2 pv = dsvg_ld2(pred + (p0 + r * stride));
+        unsigned lo = 0, hi = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const int p = (int)(((i < 4 ? pv.x : pv.y) >> (8 * (i & 3))) & 0xff);
+            const int sv = d_sat8(d_sat8(res[r][i] + 128) + p - 128);      // sbc2int, then dsv_frame_add / addf bmc.c:29-41
+            if (i < 4) lo |= (unsigned)sv << (8 * i); else hi |= (unsigned)sv << (8 * (i - 4));
+        }
+        dsvg_st2(outp + (p0 + r * stride), make_uint2(lo, hi));
+    }
+}
+
+// --------------------------------------------------------------------------------------------
 // inverse, I pictures: level 1 biorthogonal, columns then rows (inv_b4t_2d sbt.c:253-265) + sbc2int
 // --------------------------------------------------------------------------------------------
 #define BT_C 32                 // level-1 cells per tile edge -> 64x64 px
@@ -2161,7 +2270,7 @@ void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
 }
 
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail,
-                    int insym)
+                    int insym, int patch_kernel)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
@@ -2175,31 +2284,50 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     {   // levels 5..4 (LL5 -> LL3) for every picture type
         const dim3 mg((g.w5 + IT_TX - 1) / IT_TX, (g.h5 + IT_TY - 1) / IT_TY, nz);
         PB(filt ? KID_INV_TILE_54_F : KID_INV_TILE_54, s3 * 8.0);
-        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl);
-        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+        else      hipLaunchKernelGGL((k_inv_haar_tile<false, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
         PE();
     }
     const dim3 tg((g.w3 + IT_TX - 1) / IT_TX, (g.h3 + IT_TY - 1) / IT_TY, nz);
     if (isP) {
         // 4 B/sample coefficients + 1 B prediction in, 1 B out; from the symbol planes (insym): prediction 1 + reconstruction 1 +
         // the level-2/3 symbols 0.47 + flags -- the level-1 symbols (1.5 B/sample) are only fetched for flagged patches
-        PB(insym ? (filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM) : (filt ? KID_INV_TILE_PIX_F : KID_INV_TILE_PIX), smp * (insym ? 2.5 : 6.0));
-        if (insym) {
-            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (insym && !filt && patch_kernel) {
+            // no smoothing filter: patches are closed computations -- the lean kernel takes every whole patch that does not lie
+            // in a tile of the last tile row / column with a ragged edge, the tile kernel those strips
+            const int fullc = G.g[c0].pw / 8, fullr = G.g[c0].ph / 8;
+            const int tcx = fullc >= g.w3 ? (int)tg.x : fullc / IT_TX, tcy = fullr >= g.h3 ? (int)tg.y : fullr / IT_TY;   // first tile column / row of the strips
+            const int imax = tcx >= (int)tg.x ? g.w3 : tcx * IT_TX, jmax = tcy >= (int)tg.y ? g.h3 : tcy * IT_TY;
+            if (imax > 0 && jmax > 0) {
+                PB(KID_INV_PATCH_C, 64.0 * imax * jmax * nz * 2.0);          // prediction in, reconstruction out (+ 5 B per patch: LL3, flag)
+                hipLaunchKernelGGL(k_inv_patch_c, dim3((imax + 63) / 64, (jmax + 3) / 4, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax);
+                PE();
+            }
+            if (tcx < (int)tg.x || tcy < (int)tg.y) {
+                PB(KID_INV_TILE_PIX_SYM, (smp - 64.0 * imax * jmax * nz) * 2.5);
+                if (tcx < (int)tg.x) hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(tg.x - tcx, tg.y, nz), dim3(256), 0, st, jobs, G, c0, npl, tcx, 0);
+                if (tcy < (int)tg.y && tcx > 0) hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(tcx, tg.y - tcy, nz), dim3(256), 0, st, jobs, G, c0, npl, 0, tcy);
+                PE();
+            }
+        } else if (insym) {
+            PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, smp * 2.5);
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+            PE();
         } else {
-            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            PB(filt ? KID_INV_TILE_PIX_F : KID_INV_TILE_PIX, smp * 6.0);
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, false>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, false>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+            PE();
         }
-        PE();
     } else {
         PB(insym ? (filt ? KID_INV_TILE_S1_SYM_F : KID_INV_TILE_S1_SYM) : (filt ? KID_INV_TILE_S1_F : KID_INV_TILE_S1), smp * (insym ? 1.4 : 2.0));
         if (insym) {
-            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, true>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, true>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, true>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
         } else {
-            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
-            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl);
+            if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
+            else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
         }
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);

@@ -107,9 +107,10 @@ def test_zero_and_general_tiles_both_taken(pkg):
             st = b.tile_stats(enable=False)
         finally:
             b.close()
-        assert st["zero_luma"] > 0 and st["zero_chroma"] > 0, st
+        # (the chroma planes of P pictures go through the thread-per-patch kernel, which is not counted in tiles)
+        assert st["zero_luma"] > 0, st
         if want_general:
             assert st["general_luma"] > 0, st
         else:
             # the I picture's quantisation error leaves a residual here and there
-            assert st["zero_luma"] > st["general_luma"] and st["zero_chroma"] >= st["general_chroma"], st
+            assert st["zero_luma"] > st["general_luma"], st
