@@ -1963,7 +1963,6 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
     const bool inplace = (const DSVG_GLOBAL uint8_t *)outp == pred;
     const unsigned stride = (unsigned)g.pstride, p0 = (unsigned)(8 * J) * stride + 8u * (unsigned)I;
-    int res[8][8];                                              // residual of the patch (before sbc2int)
     if (!pf) {
         const int v3 = d_div4<true>(d_ll_up_t<true>(ll3));
         const int v2 = d_div4<true>(d_ll_up_t<true>(v3));
@@ -2023,8 +2022,10 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
             l1[2 * j][2 * i] = d_div4<true>(LL + LH + HL + HH); l1[2 * j][2 * i + 1] = d_div4<true>(LL - LH + HL - HH);
             l1[2 * j + 1][2 * i] = d_div4<true>(LL + LH - HL - HH); l1[2 * j + 1][2 * i + 1] = d_div4<true>(LL - LH - HL + HH);
         }
+    // level 1 + pixels one cell row (two pixel rows) at a time: few values alive (this path sets the kernel's registers)
 #pragma unroll
-    for (int j = 0; j < 4; j++)
+    for (int j = 0; j < 4; j++) {
+        int r0[8], r1[8];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const int cx = 4 * I + i, cy = 4 * J + j;
@@ -2032,20 +2033,22 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
             const unsigned o = (unsigned)(cy * Q1.sw + cx);
             const int LL = l1[j][i], LH = (int)((unsigned)(int)dsvg_at(sym, (unsigned)Q1.base0 + o) << sh), HL = (int)((unsigned)(int)dsvg_at(sym, (unsigned)Q1.base1 + o) << sh),
                       HH = (int)((unsigned)(int)dsvg_at(sym, (unsigned)Q1.base2 + o) << sh);
-            res[2 * j][2 * i] = d_div4<true>(LL + LH + HL + HH); res[2 * j][2 * i + 1] = d_div4<true>(LL - LH + HL - HH);
-            res[2 * j + 1][2 * i] = d_div4<true>(LL + LH - HL - HH); res[2 * j + 1][2 * i + 1] = d_div4<true>(LL - LH - HL + HH);
+            r0[2 * i] = d_div4<true>(LL + LH + HL + HH); r0[2 * i + 1] = d_div4<true>(LL - LH + HL - HH);
+            r1[2 * i] = d_div4<true>(LL + LH - HL - HH); r1[2 * i + 1] = d_div4<true>(LL - LH - HL + HH);
         }
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const uint2 pv = dsvg_ld2(pred + (p0 + r * stride));
-        unsigned lo = 0, hi = 0;
+        for (int rr = 0; rr < 2; rr++) {
+            const int r = 2 * j + rr;
+            const uint2 pv = dsvg_ld2(pred + (p0 + r * stride));
+            unsigned lo = 0, hi = 0;
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int p = (int)(((i < 4 ? pv.x : pv.y) >> (8 * (i & 3))) & 0xff);
-            const int sv = d_sat8(d_sat8(res[r][i] + 128) + p - 128);      // sbc2int, then dsv_frame_add / addf bmc.c:29-41
-            if (i < 4) lo |= (unsigned)sv << (8 * i); else hi |= (unsigned)sv << (8 * (i - 4));
+            for (int i = 0; i < 8; i++) {
+                const int p = (int)(((i < 4 ? pv.x : pv.y) >> (8 * (i & 3))) & 0xff);
+                const int sv = d_sat8(d_sat8((rr ? r1[i] : r0[i]) + 128) + p - 128);      // sbc2int, then dsv_frame_add / addf bmc.c:29-41
+                if (i < 4) lo |= (unsigned)sv << (8 * i); else hi |= (unsigned)sv << (8 * (i - 4));
+            }
+            dsvg_st2(outp + (p0 + r * stride), make_uint2(lo, hi));
         }
-        dsvg_st2(outp + (p0 + r * stride), make_uint2(lo, hi));
     }
 }
 
