@@ -430,90 +430,104 @@ static __device__ void hz_fix_overlaps(const JobDev &jb, const HzPlane &hp, int 
     }
 }
 
-#define SCAN_THREADS 1024
-#define SCAN_ITEMS 8            // chunks per thread (<= 8192 chunks = 16.7 M scan cells per plane)
+// 256 threads, not 1024: beside another stream's saturating kernel a 16-wave workgroup waits for a whole CU's worth of
+// wave slots to come free at once -- measured 118 us per launch in the two-stream timed region against 19 us alone on the
+// chip, on the critical path of every frame step.  Planes with more than 2048 chunks are walked in tiles with carries.
+#define SCAN_THREADS 256
+#define SCAN_ITEMS 8            // chunks per thread and tile
+#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
 __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restrict__ jobs)
 {
     __shared__ unsigned long long s_u64[16];
     __shared__ int s_i[16];
+    __shared__ int s_incl_ne[SCAN_THREADS];
+    __shared__ int s_c_ne, s_c_nnz;                            // carries into the next tile: last non-empty chunk, entries so far,
+    __shared__ unsigned long long s_c_bits;                    // bits so far
     const int job = blockIdx.y, c = blockIdx.x;
     const JobDev &jb = jobs[job];
     const HzPlane &hp = jb.hz[c];
     HzChunkSum *cs = jb.chunks + jb.chunk_off[c];
     const int n = hp.nchunks;
     if (n > 0 && !jb.fused) hz_fix_overlaps(jb, hp, c, SCAN_THREADS);   // the fused path stores final values itself
-    const int per = (n + SCAN_THREADS - 1) / SCAN_THREADS;     // host guarantees per <= SCAN_ITEMS
-    const int first = threadIdx.x * per;
-
-    // pass 1: index of the last non-empty chunk at or before each chunk (max-scan), nnz prefix
-    int lastne = -1, nnzsum = 0;
-    for (int i = 0; i < per; i++) {
-        const int ch = first + i;
-        if (ch < n) {
-            const int z = cs[ch].nnz;
-            if (z > 0) lastne = ch;
-            nnzsum += z;
-        }
-    }
-    const int incl_ne = block_scan_incl<int>(lastne, -1, OpMaxI(), s_i);
-    // exclusive: last non-empty chunk strictly before this thread's first chunk
-    int carry_ne = __shfl_up(incl_ne, 1);
-    if ((threadIdx.x & 63) == 0) carry_ne = -1;                // fixed below through shared memory
+    if (threadIdx.x == 0) { s_c_ne = -1; s_c_nnz = 0; s_c_bits = 0ull; }
     __syncthreads();
-    __shared__ int s_incl_ne[SCAN_THREADS];
-    s_incl_ne[threadIdx.x] = incl_ne;
-    __syncthreads();
-    carry_ne = threadIdx.x ? s_incl_ne[threadIdx.x - 1] : -1;
+    for (int t0 = 0; t0 < n; t0 += SCAN_TILE) {
+        const int limit = min(n, t0 + SCAN_TILE);
+        const int per = (limit - t0 + SCAN_THREADS - 1) / SCAN_THREADS;     // <= SCAN_ITEMS
+        const int first = t0 + threadIdx.x * per;
+        const int c_ne = s_c_ne, c_nnz = s_c_nnz;
+        const unsigned long long c_bits = s_c_bits;
 
-    const int incl_nnz = block_scan_incl<int>(nnzsum, 0, OpAddI(), s_i);
-    int nzbase = incl_nnz - nnzsum;
-
-    // pass 2: per chunk first-symbol length, chunk bit totals
-    unsigned long long mybits = 0;
-    int prev_ne = carry_ne;
-    unsigned long long cb[SCAN_ITEMS];
-    int pp[SCAN_ITEMS], pvv[SCAN_ITEMS];
-#pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        cb[i] = 0; pp[i] = -1; pvv[i] = 0;
-        const int ch = first + i;
-        if (i < per && ch < n) {
-            const HzChunkSum s = cs[ch];
-            int ppos = -1, pval = 0;
-            if (prev_ne >= 0) { ppos = cs[prev_ne].last_pos; pval = cs[prev_ne].last_val; }
-            pp[i] = ppos; pvv[i] = pval;
-            if (s.nnz > 0) {
-                unsigned b = (unsigned)len_ueg((unsigned)(s.first_pos - ppos - 1));
-                if (prev_ne >= 0) b += (unsigned)len_neg(pval);
-                cb[i] = (unsigned long long)b + s.bits_inner;
-                prev_ne = ch;
+        // pass 1: index of the last non-empty chunk at or before each chunk (max-scan), nnz prefix
+        int lastne = -1, nnzsum = 0;
+        for (int i = 0; i < per; i++) {
+            const int ch = first + i;
+            if (ch < limit) {
+                const int z = cs[ch].nnz;
+                if (z > 0) lastne = ch;
+                nnzsum += z;
             }
-            mybits += cb[i];
         }
-    }
-    const unsigned long long incl_bits = block_scan_incl<unsigned long long>(mybits, 0ull, OpAddU64(), s_u64);
-    unsigned long long off = incl_bits - mybits;
+        const int incl_ne = max(block_scan_incl<int>(lastne, -1, OpMaxI(), s_i), c_ne);
+        __syncthreads();
+        s_incl_ne[threadIdx.x] = incl_ne;
+        __syncthreads();
+        // exclusive: last non-empty chunk strictly before this thread's first chunk
+        const int carry_ne = threadIdx.x ? s_incl_ne[threadIdx.x - 1] : c_ne;
+
+        const int incl_nnz = block_scan_incl<int>(nnzsum, 0, OpAddI(), s_i);
+        int nzbase = c_nnz + incl_nnz - nnzsum;
+
+        // pass 2: per chunk first-symbol length, chunk bit totals
+        unsigned long long mybits = 0;
+        int prev_ne = carry_ne;
+        unsigned long long cb[SCAN_ITEMS];
+        int pp[SCAN_ITEMS], pvv[SCAN_ITEMS];
 #pragma unroll
-    for (int i = 0; i < SCAN_ITEMS; i++) {
-        const int ch = first + i;
-        if (i < per && ch < n) {
-            cs[ch].bit_off = off;
-            cs[ch].prev_pos = pp[i];
-            cs[ch].prev_val = pvv[i];
-            cs[ch].nz_base = nzbase;
-            off += cb[i];
-            nzbase += cs[ch].nnz;
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            cb[i] = 0; pp[i] = -1; pvv[i] = 0;
+            const int ch = first + i;
+            if (i < per && ch < limit) {
+                const HzChunkSum s = cs[ch];
+                int ppos = -1, pval = 0;
+                if (prev_ne >= 0) { ppos = cs[prev_ne].last_pos; pval = cs[prev_ne].last_val; }
+                pp[i] = ppos; pvv[i] = pval;
+                if (s.nnz > 0) {
+                    unsigned b = (unsigned)len_ueg((unsigned)(s.first_pos - ppos - 1));
+                    if (prev_ne >= 0) b += (unsigned)len_neg(pval);
+                    cb[i] = (unsigned long long)b + s.bits_inner;
+                    prev_ne = ch;
+                }
+                mybits += cb[i];
+            }
         }
+        const unsigned long long incl_bits = block_scan_incl<unsigned long long>(mybits, 0ull, OpAddU64(), s_u64);
+        unsigned long long off = c_bits + incl_bits - mybits;
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            const int ch = first + i;
+            if (i < per && ch < limit) {
+                cs[ch].bit_off = off;
+                cs[ch].prev_pos = pp[i];
+                cs[ch].prev_val = pvv[i];
+                cs[ch].nz_base = nzbase;
+                off += cb[i];
+                nzbase += cs[ch].nnz;
+            }
+        }
+        __syncthreads();                                       // every thread has read the carries of this tile
+        if (threadIdx.x == SCAN_THREADS - 1) { s_c_ne = incl_ne; s_c_nnz = c_nnz + incl_nnz; s_c_bits = c_bits + incl_bits; }
+        __syncthreads();
     }
     __shared__ unsigned long long s_total;
-    if (threadIdx.x == SCAN_THREADS - 1) {
+    if (threadIdx.x == 0) {
         HzPlaneSum &ps = jb.psum[c];
-        const int lne = incl_ne;                               // last non-empty chunk of the plane
-        unsigned long long tb = incl_bits;
+        const int lne = s_c_ne;                                // last non-empty chunk of the plane
+        unsigned long long tb = s_c_bits;
         if (lne >= 0) tb += (unsigned long long)len_neg(cs[lne].last_val);   // trailing NEG (hzcc.c:283-285)
         ps.total_bits = tb;
-        ps.nruns = (unsigned)incl_nnz;
+        ps.nruns = (unsigned)s_c_nnz;
         ps.last_chunk = lne;
         ps.overflow = ((tb + 7) >> 3) > jb.bits_cap[c] ? 1 : 0;
         s_total = ps.overflow ? 0ull : tb;
@@ -1175,4 +1189,4 @@ void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long
     hipLaunchKernelGGL(k_gather_bits, dim3(8, nitems), dim3(256), 0, st, bits, (size_t)0, tab, dst);
 }
 
-int hz_scan_items_max() { return SCAN_ITEMS * SCAN_THREADS; }
+int hz_scan_items_max() { return 1 << 22; }     // the scan walks a plane in tiles: no practical limit on its chunks

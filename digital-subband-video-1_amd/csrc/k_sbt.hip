@@ -1021,8 +1021,10 @@ __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__
 // --------------------------------------------------------------------------------------------
 // LDS tails: levels >= 4 of one plane inside one workgroup
 // --------------------------------------------------------------------------------------------
-#define TAIL_THREADS 1024
-#define TAIL_MAXC 4             // cells per thread at the first tail level (host checks)
+// 256 threads, not 1024: beside another stream's saturating kernel a 16-wave workgroup waits for a whole CU's worth of wave
+// slots to come free at once (33 / 26 us per launch in the two-stream timed region against 11 alone on the chip)
+#define TAIL_THREADS 256
+#define TAIL_MAXC 16            // cells per thread at the first tail level (host checks)
 #define TAIL_LV 6               // first level handled inside LDS
 
 __global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
