@@ -38,7 +38,7 @@ void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
 void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf = nullptr, double samples = 0,
                       int nplain = -1, int ll_chunks = 1);
 void launch_hz_quant(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ll_chunks);
-void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain);
+void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ndense = -1);
 void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf = nullptr);
 void launch_dec_clear(hipStream_t st, const JobDev *jobs, int njobs);                       // decoder: zero what the scatter leaves untouched
 void launch_hz_unscatter(hipStream_t st, const JobDev *jobs, int njobs, int max_entries);   // decoder: take the scattered symbols down again

@@ -93,6 +93,7 @@ struct dsvg_ctx {
     HzChunkSum *chunks = nullptr;
     uint8_t *nzf = nullptr;          // per work job: flag byte per 4 scan positions (non-zero symbols of P pictures)
     int16_t *sym = nullptr;          // fused quantiser: per work job, scan-order symbol planes (same indexing as nzpos)
+    bool no_list_pack = false;       // DSV1_NO_LIST_PACK=1: a wave per chunk for sparse pictures too (A/B)
     int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
     uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
@@ -237,6 +238,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     c->no_inplace_pred = getenv("DSV1_NO_INPLACE_PRED") != nullptr;
     c->no_dec_sym = getenv("DSV1_NO_DEC_SYM") != nullptr;
     c->no_patch_kernel = getenv("DSV1_NO_PATCH_KERNEL") != nullptr;
+    c->no_list_pack = getenv("DSV1_NO_LIST_PACK") != nullptr;
     for (int g2 = 0; g2 < 2; g2++) {
         HzPlane hp; make_hz_plane(hp, CL.w[g2 ? 1 : 0], CL.h[g2 ? 1 : 0], 100, 1, g2, c->nbh, c->nbv);
         const bool ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
@@ -822,7 +824,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
                             (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
             OPCHK(enqueue_recon(c, nI, n, d0, 7, st));
-            launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0);
+            launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
         }
     }
     for (int g = 1; g < NG; g++) {

@@ -144,7 +144,11 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
     }
 }
 
-// same, 16 bytes per thread-iteration, for planes whose width is a multiple of 16 (every store aligned)
+// same for planes whose width is a multiple of 16 (every store a 16-byte one).  A thread has one load round trip and then
+// several stores behind it (one store per thread left the kernel waiting on 94 k wave launches of one round trip each):
+// side borders: 4 rows of one 16-byte column of the 128 border bytes of a row; top / bottom: 8 rows of a 16-byte column
+#define EXT16_SIDE_ROWS 4
+#define EXT16_TB_ROWS 8
 __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, FrameLayout L, int first, int nplanes,
                                                   const int *__restrict__ slot_tab)
 {
@@ -155,23 +159,35 @@ __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, Fr
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
     const int B = DSVG_BORDER;
-    const int n1 = (h + 2 * B) * 8;                   // side borders: 4 + 4 x 16 bytes per row
+    const int rg = (h + 2 * B + EXT16_SIDE_ROWS - 1) / EXT16_SIDE_ROWS;
+    const int n1 = rg * 8;
     const int wq = w >> 4;
-    const int n2 = 2 * B * wq;                        // top + bottom rows over the interior
+    const int n2 = (2 * B / EXT16_TB_ROWS) * wq;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += gridDim.x * 256) {
         if (i < n1) {
-            const int r = i >> 3, k = i & 7;
-            const int y = r - B;
-            const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
-            const unsigned v = p[(long)sy * s + (k < 4 ? 0 : w - 1)] * 0x01010101u;
-            uint8_t *d = p + (long)y * s + (k < 4 ? -B + 16 * k : w + 16 * (k - 4));
-            *reinterpret_cast<uint4 *>(d) = make_uint4(v, v, v, v);
+            const int k = i & 7, r0 = (i >> 3) * EXT16_SIDE_ROWS;
+            const int sx = k < 4 ? 0 : w - 1, dx = k < 4 ? -B + 16 * k : w + 16 * (k - 4);
+            unsigned v[EXT16_SIDE_ROWS];
+#pragma unroll
+            for (int j = 0; j < EXT16_SIDE_ROWS; j++) {
+                const int y = r0 + j - B;
+                const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
+                v[j] = p[(long)sy * s + sx] * 0x01010101u;
+            }
+#pragma unroll
+            for (int j = 0; j < EXT16_SIDE_ROWS; j++) {
+                const int y = r0 + j - B;
+                if (y < h + B) *reinterpret_cast<uint4 *>(p + (long)y * s + dx) = make_uint4(v[j], v[j], v[j], v[j]);
+            }
         } else {
             const int j = i - n1;
-            const int r = j / wq, x = 16 * (j - r * wq);
-            const int y = r < B ? r - B : h + (r - B);
-            *reinterpret_cast<uint4 *>(p + (long)y * s + x) =
-                *reinterpret_cast<const uint4 *>(p + (long)(r < B ? 0 : h - 1) * s + x);
+            const int g = j / wq, x = 16 * (j - g * wq);
+            const int r0 = g * EXT16_TB_ROWS;                        // 0 .. 2B-1: top rows first, then the bottom ones
+            const bool top = r0 < B;
+            const uint4 v = *reinterpret_cast<const uint4 *>(p + (long)(top ? 0 : h - 1) * s + x);
+            uint8_t *d = p + (long)(top ? r0 - B : h + (r0 - B)) * s + x;
+#pragma unroll
+            for (int q = 0; q < EXT16_TB_ROWS; q++) *reinterpret_cast<uint4 *>(d + (long)q * s) = v;
         }
     }
 }
@@ -273,7 +289,8 @@ void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int firs
     bool v16 = (L.pitch % 16) == 0;
     for (int c = 0; c < nplanes; c++) v16 = v16 && (L.w[c] % 16) == 0 && (L.stride[c] % 16) == 0 && (L.off[c] % 16) == 0;
     if (pf) pf->begin(st, v16 ? KID_EXTEND16 : KID_EXTEND, 8.0 * items * n);
-    if (v16) hipLaunchKernelGGL(k_extend16, dim3(nblk(items / 4, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
+    const long it16 = ((L.h[0] + 128 + EXT16_SIDE_ROWS - 1) / EXT16_SIDE_ROWS) * 8L + (128 / EXT16_TB_ROWS) * (long)(L.w[0] >> 4);
+    if (v16) hipLaunchKernelGGL(k_extend16, dim3(nblk(it16, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
     else     hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
     if (pf) pf->end(st);
 }

@@ -31,6 +31,17 @@
 #define quant_any hz_quant_any
 #define dequant_any hz_dequant_any
 
+// inclusive prefix sum over the wave in six DPP adds (row_shr 1, 2, 4, 8 inside the rows of 16; row_bcast 15 / 31 across them)
+static __device__ __forceinline__ unsigned wave_scan_incl(unsigned x)
+{
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);
+    x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);
+    return x;
+}
 static __device__ __forceinline__ int len_ueg(unsigned v) { return 2 * (31 - __clz((int)(v + 1))) + 1; }
 static __device__ __forceinline__ int len_neg(int v) { return len_ueg((unsigned)(v < 0 ? -v : v) - 1u) + 1; }
 
@@ -231,12 +242,8 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
 // workgroup, no LDS and no barrier: the chunk is read as 4 rounds of 16 bytes (8 symbols) per lane, all four
 // loads issued up front, and the non-zeros go straight to the chunk's ordered list.  The few chunks that
 // reach into the LL region (scan cells below r[1].base) are left to k_hz_quant<true>.
-__global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ jobs)
+static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, int chunk, int lane)
 {
-    const JobDev &jb = jobs[blockIdx.y];
-    const int lane = threadIdx.x & 63;
-    int c, chunk;
-    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
     const HzPlane &hp = jb.hz[c];
     const int ll_end = hp.r[1].base, nscan = hp.nscan;
     const int16_t *sym = jb.sym + jb.nz_off[c];
@@ -373,6 +380,52 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
         cs.first_pos = run ? first_pos : -1;
         cs.last_pos = run ? cpos : -1;
         cs.last_val = run ? cval : 0;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ jobs)
+{
+    const JobDev &jb = jobs[blockIdx.y];
+    int c, chunk;
+    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
+    collect_chunk(jb, c, chunk, threadIdx.x & 63);
+}
+
+// Sparse pictures: 93 % of a P picture's chunks hold nothing, and a launch of one wave per chunk is bound by the rate at
+// which waves can be started (121 k waves that read one flag byte each).  Here a workgroup owns HZ_LIST_CPW chunks, spread
+// over the picture (chunk = workgroup + k * workgroups: flagged chunks cluster where something moves); every wave reads
+// the same HZ_LIST_CPW chunk flags, one per lane, and takes every fourth flagged chunk -- no LDS, no barrier, and on
+// average well under one chunk per wave, so nothing is serialised.  Chunks without a flag get their empty summary from
+// wave 0.  (A dense job in such a launch -- a scene change inside a step -- is handled too: every chunk counts as flagged.)
+#define HZ_LIST_CPW 32
+__global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restrict__ jobs)
+{
+    const JobDev &jb = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int c = 0, chunk = 0;
+    const bool have = lane < HZ_LIST_CPW && flat_chunk(jb, (int)blockIdx.x + lane * (int)gridDim.x, c, chunk);
+    bool work = false;
+    if (have) {
+        const int ll_end = jb.hz[c].r[1].base, cbase = chunk * HZ_CHUNK;
+        const bool fl = jb.nzf ? jb.cflag[jb.chunk_off[c] + chunk] != 0 : true;
+        if (cbase < ll_end) work = jb.nzf && cbase + HZ_CHUNK > ll_end && fl;      // only the straddling chunk's cleanup
+        else {
+            work = fl;
+            if (!fl && wv == 0) {
+                HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
+                cs.nnz = 0; cs.bits_inner = 0; cs.first_pos = -1; cs.last_pos = -1; cs.last_val = 0;
+            }
+        }
+    }
+    unsigned long long m = __ballot(work);
+    // collect_chunk takes the chunk flags down: every wave must have its view of them before any wave starts (a late wave
+    // would count fewer flagged chunks, take the wrong ones, and overwrite a finished summary with an empty one)
+    __syncthreads();
+    for (int k = 0; m; k++) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if ((k & 3) != wv) continue;
+        collect_chunk(jb, __shfl(c, l), __shfl(chunk, l), lane);
     }
 }
 
@@ -613,69 +666,232 @@ static __device__ __forceinline__ void or_bits_lds(unsigned *w32, unsigned pos, 
 // Each round of 64 symbols is assembled in the wave's LDS window with LDS atomics and flushed with plain
 // coalesced stores; only the first and last word of a round can be shared (with the neighbouring round or
 // chunk) and go out as global atomicOr -- an I picture would otherwise issue ~2.5 global atomics per symbol.
+// the fences order the wave's LDS traffic only: a fence over all address spaces would also wait for the round's global
+// stores to be acknowledged -- a round trip per round of 64 symbols on the serial path of a dense chunk
+#ifdef EMIT_FULL_FENCE
+#define EMIT_FENCE(o) __builtin_amdgcn_fence(o, "wavefront")
+#else
+#define EMIT_FENCE(o) __builtin_amdgcn_fence(o, "wavefront", "local")
+#endif
 #define EMIT_STAGE_WORDS 200            // 64 symbols x (<= 47 + 49 bits) = 6144 bits = 192 words, + straddle
-__global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs)
+#ifdef EMIT_STATS
+// diagnostic build (tools/ab/emit_stats.py): lifetimes of the emit waves, by chunk density
+__device__ unsigned long long g_emit_stat[8][64];
+extern "C" int dsvg_debug_emit_stats(unsigned long long *out)
 {
-    __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
-    const int job = blockIdx.y;
-    const JobDev &jb = jobs[job];
-    const int lane = threadIdx.x & 63;
-    unsigned *stg = s_stage[threadIdx.x >> 6];
-    int c, chunk;
-    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
+    unsigned long long h[8][64];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_emit_stat), sizeof h) != hipSuccess) return -1;
+    for (int k = 0; k < 8; k++) {
+        out[k] = 0;
+        for (int i = 0; i < 64; i++) out[k] = (k == 6) ? (h[k][i] > out[k] ? h[k][i] : out[k]) : out[k] + h[k][i];
+    }
+    memset(h, 0, sizeof h);
+    return hipMemcpyToSymbol(HIP_SYMBOL(g_emit_stat), h, sizeof h) == hipSuccess ? 0 : -1;
+}
+#endif
+// lanes that have no word to store in a round store here instead: every round then issues the same vector-memory
+// operations, which lets the compiler wait for the prefetched entries alone (s_waitcnt vmcnt(1)) instead of for everything
+__device__ unsigned g_emit_dump[128];
+
+// One chunk by one wave.  A round takes 64 entries (one per lane), builds their codes, assembles the round's bits in the
+// wave's LDS window and stores the COMPLETE words it filled with plain stores; the incomplete last word is carried into
+// the next round's first word.  Only the chunk's first and last word can be shared with a neighbouring chunk: those two
+// go out as global atomicOr after the loop.  Nothing in a round waits for a store: the serial path of a dense chunk
+// (32 rounds) is arithmetic + LDS only.
+static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
+{
+#ifdef EMIT_STATS
+    const unsigned long long t_in = wall_clock64();
+#endif
     const HzPlaneSum ps = jb.psum[c];
     if (ps.overflow) return;
     const HzChunkSum cs = jb.chunks[jb.chunk_off[c] + chunk];
-    unsigned *out32 = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
-    const int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
-    const int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
-
-    unsigned long long at0 = cs.bit_off;
-    for (int base = 0; base < cs.nnz; base += 64) {
-        const int j = base + lane;
-        int l1 = 0, l2 = 0;
-        unsigned long long p1 = 0, p2 = 0;
-        if (j < cs.nnz) {
-            const int pos = gpos[j];
-            const int ppos = j ? gpos[j - 1] : cs.prev_pos;
-            const int pval = j ? gval[j - 1] : cs.prev_val;
-            p1 = pat_ueg((unsigned)(pos - ppos - 1), l1);
-            if (j > 0 || cs.prev_pos >= 0) p2 = pat_neg(pval, l2);
+    DSVG_GLOBAL unsigned *out32 = dsvg_global(reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]));
+    const DSVG_GLOBAL int32_t *gpos = dsvg_global(jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK);
+    const DSVG_GLOBAL int32_t *gval = dsvg_global(jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK);
+    const int nnz = cs.nnz;
+    if (nnz > 0) {
+        unsigned at0 = (unsigned)(cs.bit_off & 31);      // bit position relative to the chunk's first word
+        const unsigned wbase = (unsigned)(cs.bit_off >> 5);
+        unsigned carry = 0, firstv = 0;
+        bool first_pending = true;                       // the chunk's first word has not been taken out of the stage yet
+        // a lane reads its own entry only -- the predecessor comes from the lane below (the last lane's of the round before
+        // is carried) -- and the next round's entries are requested before this round is assembled
+        int npos = dsvg_at(gpos, (unsigned)min(lane, nnz - 1)), nval = dsvg_at(gval, (unsigned)min(lane, nnz - 1));
+        int cpos = cs.prev_pos, cval = cs.prev_val;
+        // (the same two stores behind the first loads as behind every round's: the loop head then waits for exactly "all
+        // but the two youngest operations")
+        ((DSVG_GLOBAL unsigned *)g_emit_dump)[lane] = 0;
+        ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;
+        for (int base = 0; base < nnz; base += 64) {
+            const int j = base + lane;
+            const int pos = npos, val = nval;
+            npos = dsvg_at(gpos, (unsigned)min(j + 64, nnz - 1)); nval = dsvg_at(gval, (unsigned)min(j + 64, nnz - 1));
+            int ppos = __builtin_amdgcn_update_dpp(0, pos, 0x138, 0xf, 0xf, true);      // wave_shr:1
+            int pval = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, true);
+            if (lane == 0) { ppos = cpos; pval = cval; }
+            cpos = __builtin_amdgcn_readlane(pos, 63); cval = __builtin_amdgcn_readlane(val, 63);
+            const bool valid = j < nnz, hasn = valid && (j > 0 || cs.prev_pos >= 0);
+            const unsigned m = valid ? (unsigned)(pos - ppos - 1) + 1u : 1u;              // UEG codes run + 1
+            const unsigned mag = hasn ? (unsigned)(pval < 0 ? -pval : pval) : 1u;         // NEG codes UEG(|v| - 1), then the sign
+            const unsigned o0 = at0 & 31, w0 = at0 >> 5;
+            unsigned tot;
+            if (__ballot(m >= 256u || mag >= 256u) == 0ull) {
+                // the common round: runs and values below 256, i.e. at most 15 + 16 bits per lane -- both codes in one 32-bit
+                // pattern (both bit spreads in one go), a round of at most 63 words, two LDS atomics per lane
+                const int k1 = 31 - __clz((int)m), k2 = 31 - __clz((int)mag);
+                unsigned x = ((m & ((1u << k1) - 1u)) << 16) | (mag & ((1u << k2) - 1u));
+                x = (x | (x << 4)) & 0x0F0F0F0Fu;
+                x = (x | (x << 2)) & 0x33333333u;
+                x = (x | (x << 1)) & 0x55555555u;
+                unsigned pat = ((x >> 16) << 1) | 1u;
+                unsigned len = valid ? 2u * k1 + 1u : 0u;
+                if (hasn) {
+                    pat = (pat << (2 * k2 + 2)) | ((((x & 0xffffu) << 1) | 1u) << 1) | (pval < 0 ? 1u : 0u);
+                    len += 2u * k2 + 2u;
+                }
+                const unsigned incl = wave_scan_incl(len);
+                tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                stg[lane] = lane ? 0u : carry;
+                if (lane < 2) stg[64 + lane] = 0;
+                EMIT_FENCE(__ATOMIC_RELEASE);
+                __builtin_amdgcn_wave_barrier();
+                if (len) {
+                    const unsigned rel = o0 + (incl - len);
+                    const unsigned long long hi = (unsigned long long)pat << (64 - (rel & 31) - len);
+                    const unsigned h0 = (unsigned)(hi >> 32), h1 = (unsigned)hi;
+                    if (h0) atomicOr(stg + (rel >> 5), h0);
+                    if (h1) atomicOr(stg + (rel >> 5) + 1, h1);
+                }
+                EMIT_FENCE(__ATOMIC_ACQ_REL);
+                __builtin_amdgcn_wave_barrier();
+                const int nfull = (int)((o0 + tot) >> 5);                     // complete words of the round, <= 63
+                const unsigned v = stg[lane];
+                carry = (unsigned)__builtin_amdgcn_readlane((int)v, nfull & 63);
+                if (nfull == 64) carry = 0;                                   // (cannot happen: 31 + 64 * 31 bits)
+                const bool mine = lane < nfull && !(first_pending && lane == 0);
+                DSVG_GLOBAL unsigned *d = mine ? out32 + (wbase + w0 + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + lane;
+                *d = __builtin_bswap32(v);
+                ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;         // (every path of the round: two stores per lane)
+                if (first_pending && nfull > 0) { firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)v); first_pending = false; }
+            } else if (__ballot(m >= 32768u || mag >= 32768u) == 0ull) {
+                // runs and values below 2^15 (the LL region of a picture): codes of at most 29 + 30 bits in one 64-bit pattern,
+                // a round of at most 120 words, two words per lane
+                const int k1 = 31 - __clz((int)m), k2 = 31 - __clz((int)mag);
+                unsigned x1 = m & ((1u << k1) - 1u), x2 = mag & ((1u << k2) - 1u);
+                x1 = (x1 | (x1 << 8)) & 0x00FF00FFu; x2 = (x2 | (x2 << 8)) & 0x00FF00FFu;
+                x1 = (x1 | (x1 << 4)) & 0x0F0F0F0Fu; x2 = (x2 | (x2 << 4)) & 0x0F0F0F0Fu;
+                x1 = (x1 | (x1 << 2)) & 0x33333333u; x2 = (x2 | (x2 << 2)) & 0x33333333u;
+                x1 = (x1 | (x1 << 1)) & 0x55555555u; x2 = (x2 | (x2 << 1)) & 0x55555555u;
+                unsigned long long pat = ((unsigned long long)x1 << 1) | 1ull;
+                unsigned len = valid ? 2u * k1 + 1u : 0u;
+                if (hasn) {
+                    pat = (pat << (2 * k2 + 2)) | ((((unsigned long long)x2 << 1) | 1ull) << 1) | (pval < 0 ? 1ull : 0ull);
+                    len += 2u * k2 + 2u;
+                }
+                const unsigned incl = wave_scan_incl(len);
+                tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                stg[lane] = lane ? 0u : carry;
+                stg[64 + lane] = 0;
+                EMIT_FENCE(__ATOMIC_RELEASE);
+                __builtin_amdgcn_wave_barrier();
+                if (len) or_bits_lds(stg, o0 + (incl - len), pat, (int)len);
+                EMIT_FENCE(__ATOMIC_ACQ_REL);
+                __builtin_amdgcn_wave_barrier();
+                const int nfull = (int)((o0 + tot) >> 5);                     // <= 118
+                const unsigned v0 = stg[lane], v1 = stg[64 + lane];
+                carry = stg[nfull];
+                const bool mine0 = lane < nfull && !(first_pending && lane == 0), mine1 = 64 + lane < nfull;
+                DSVG_GLOBAL unsigned *d0 = mine0 ? out32 + (wbase + w0 + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + lane;
+                DSVG_GLOBAL unsigned *d1 = mine1 ? out32 + (wbase + w0 + 64u + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + 64 + lane;
+                *d0 = __builtin_bswap32(v0);
+                *d1 = __builtin_bswap32(v1);
+                if (first_pending && nfull > 0) { firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)v0); first_pending = false; }
+            } else {
+                int l1 = 0, l2 = 0;
+                unsigned long long p1 = 0, p2 = 0;
+                if (valid) {
+                    p1 = pat_ueg(m - 1u, l1);
+                    if (hasn) p2 = pat_neg(pval, l2);
+                }
+                const unsigned len = (unsigned)(l1 + l2);
+                const unsigned incl = wave_scan_incl(len);
+                tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                const int nw = (int)((o0 + tot + 31) >> 5);                   // words touched, <= 193
+                for (int i = lane; i < nw + 2; i += 64) stg[i] = i ? 0u : carry;
+                EMIT_FENCE(__ATOMIC_RELEASE);
+                __builtin_amdgcn_wave_barrier();
+                const unsigned rel = o0 + (incl - len);
+                if (l1) or_bits_lds(stg, rel, p1, l1);
+                if (l2) or_bits_lds(stg, rel + l1, p2, l2);
+                EMIT_FENCE(__ATOMIC_ACQ_REL);
+                __builtin_amdgcn_wave_barrier();
+                const int nfull = (int)((o0 + tot) >> 5);
+                for (int i = lane; i < nfull; i += 64)
+                    if (!(first_pending && i == 0)) out32[wbase + w0 + (unsigned)i] = __builtin_bswap32(stg[i]);
+                carry = stg[nfull];
+                if (first_pending && nfull > 0) { firstv = stg[0]; first_pending = false; }
+                ((DSVG_GLOBAL unsigned *)g_emit_dump)[lane] = 0;              // (two stores at the end of every path: see above)
+                ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;
+            }
+            EMIT_FENCE(__ATOMIC_ACQ_REL);
+            __builtin_amdgcn_wave_barrier();
+            at0 += tot;
         }
-        const unsigned len = (unsigned)(l1 + l2);
-        unsigned incl = len;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const unsigned n = __shfl_up(incl, o);
-            if (lane >= o) incl += n;
-        }
-        const unsigned tot = __shfl(incl, 63);
-        const unsigned long long w0 = at0 >> 5;                       // first word of this round
-        const unsigned o0 = (unsigned)(at0 & 31);
-        const int nw = (int)((o0 + tot + 31) >> 5);                   // words touched, <= 193
-        for (int i = lane; i < nw + 2; i += 64) stg[i] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        const unsigned rel = o0 + (incl - len);
-        if (l1) or_bits_lds(stg, rel, p1, l1);
-        if (l2) or_bits_lds(stg, rel + l1, p2, l2);
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < nw; i += 64) {
-            const unsigned v = stg[i];
-            if (v) {
-                if (i == 0 || i == nw - 1) atomicOr(out32 + w0 + i, __builtin_bswap32(v));
-                else out32[w0 + i] = __builtin_bswap32(v);
+        if (lane == 0) {
+            // the first and the last word of the chunk, possibly shared with the neighbouring chunks (or with each other)
+            unsigned *og = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
+            if (first_pending) { if (carry) atomicOr(og + wbase, __builtin_bswap32(carry)); }
+            else {
+                if (firstv) atomicOr(og + wbase, __builtin_bswap32(firstv));
+                if (carry) atomicOr(og + (wbase + (at0 >> 5)), __builtin_bswap32(carry));
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        at0 += tot;
     }
     if (lane == 0 && chunk == ps.last_chunk) {       // trailing value of the plane
         int l;
         const unsigned long long p = pat_neg(cs.last_val, l);
-        or_bits(out32, ps.total_bits - (unsigned long long)l, p, l);
+        or_bits(reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]), ps.total_bits - (unsigned long long)l, p, l);
+    }
+#ifdef EMIT_STATS
+    if (lane == 0 && cs.nnz > 0) {
+        const unsigned long long dt = wall_clock64() - t_in;
+        const int rounds = (cs.nnz + 63) >> 6, sh = (chunk * 7 + c) & 63, k = rounds >= 8 ? 3 : 0;
+        atomicAdd(&g_emit_stat[k][sh], 1ull);
+        atomicAdd(&g_emit_stat[k + 1][sh], (unsigned long long)rounds);
+        atomicAdd(&g_emit_stat[k + 2][sh], dt);
+        atomicMax(&g_emit_stat[6][sh], dt);
+        atomicAdd(&g_emit_stat[7][sh], (unsigned long long)cs.nnz);
+    }
+#endif
+}
+
+__global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs)
+{
+    __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
+    const JobDev &jb = jobs[blockIdx.y];
+    int c, chunk;
+    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
+    emit_chunk(jb, c, chunk, threadIdx.x & 63, s_stage[threadIdx.x >> 6]);
+}
+
+// the same for sparse pictures, organised like k_hz_collect_list: a lane per chunk reads the entry count of its summary,
+// the waves share out the chunks that have entries
+__global__ __launch_bounds__(256) void k_hz_emit_list(const JobDev *__restrict__ jobs)
+{
+    __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
+    const JobDev &jb = jobs[blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    int c = 0, chunk = 0;
+    const bool have = lane < HZ_LIST_CPW && flat_chunk(jb, (int)blockIdx.x + lane * (int)gridDim.x, c, chunk);
+    const bool work = have && jb.chunks[jb.chunk_off[c] + chunk].nnz > 0;
+    unsigned long long m = __ballot(work);
+    for (int k = 0; m; k++) {
+        const int l = __ffsll((long long)m) - 1;
+        m &= m - 1;
+        if ((k & 3) != wv) continue;
+        emit_chunk(jb, __shfl(c, l), __shfl(chunk, l), lane, s_stage[wv]);
     }
 }
 
@@ -1135,20 +1351,37 @@ void launch_hz_quant(hipStream_t st, const JobDev *jobs, int njobs, int job_chun
         PE();
     }
 }
-void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain)
+void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ndense)
 {
     if (nplain < 0 || nplain > njobs) nplain = njobs;
-    if (njobs > nplain) {
-        PB(KID_HZ_COLLECT, samples * (njobs - nplain) * 2.0);   // 2 B/sample of symbols in
-        hipLaunchKernelGGL(k_hz_collect, dim3((job_chunks + 3) / 4, njobs - nplain), dim3(256), 0, st, jobs + nplain);
+    // fused jobs [nplain, nplain + ndense) are dense (I pictures: every chunk has entries: a wave per chunk); the rest are
+    // sparse (P pictures: most chunks empty: k_hz_*_list)
+    if (ndense < 0 || ndense > njobs - nplain) ndense = njobs - nplain;
+    const int nsparse = njobs - nplain - ndense;
+    const int list_wgs = (job_chunks + HZ_LIST_CPW - 1) / HZ_LIST_CPW;
+    if (ndense > 0) {
+        PB(KID_HZ_COLLECT, samples * ndense * 2.0);             // 2 B/sample of symbols in
+        hipLaunchKernelGGL(k_hz_collect, dim3((job_chunks + 3) / 4, ndense), dim3(256), 0, st, jobs + nplain);
+        PE();
+    }
+    if (nsparse > 0) {
+        PB(KID_HZ_COLLECT_LIST, 0.0);
+        hipLaunchKernelGGL(k_hz_collect_list, dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
         PE();
     }
     PB(KID_HZ_SCAN, 0.0);
     hipLaunchKernelGGL(k_hz_scan, dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
     PE();
-    PB(KID_HZ_EMIT, 0.0);
-    hipLaunchKernelGGL(k_hz_emit, dim3((job_chunks + 3) / 4, njobs), dim3(256), 0, st, jobs);
-    PE();
+    if (nplain + ndense > 0) {
+        PB(KID_HZ_EMIT, 0.0);
+        hipLaunchKernelGGL(k_hz_emit, dim3((job_chunks + 3) / 4, nplain + ndense), dim3(256), 0, st, jobs);
+        PE();
+    }
+    if (nsparse > 0) {
+        PB(KID_HZ_EMIT_LIST, 0.0);
+        hipLaunchKernelGGL(k_hz_emit_list, dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
+        PE();
+    }
 }
 void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain,
                       int ll_chunks)

@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""lifetimes of the k_hz_emit waves per frame step (needs a library built with EXTRA=-DEMIT_STATS):
+light chunks (< 8 rounds of 64 symbols) and dense ones; ticks of the 100 MHz wall clock"""
+import ctypes as C, importlib, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
+import numpy as np
+import _cabi as A
+pkg = importlib.import_module("digital-subband-video-1_amd")
+L = pkg.lib()
+W, H, FMT, S, N = 1920, 1080, A.SUBSAMP_420, int(sys.argv[1]) if len(sys.argv) > 1 else 32, 4
+clips = [A.gen_clip(W, H, FMT, 0x10800003 + g, N, style=0) for g in range(4)]
+b = pkg.Batch(pkg.make_encoder_cfg(W, H, FMT, qp=85, gop=12, rc_mode_cli=1), S, 1)
+out = (C.c_ulonglong * 8)()
+try:
+    L.dsvg_debug_emit_stats.argtypes = [C.c_void_p]
+except AttributeError:
+    pass
+for t in range(N):
+    fr = np.stack([clips[s % 4][t] for s in range(S)]).reshape(S, 1, -1)
+    pk = b.encode(fr)
+    bad = [s for s in range(S) if pk[s] != pk[s % 4]]
+    if bad: print("  NONDETERMINISTIC: streams", bad[:16], "differ from their twins", [len(pk[s]) - len(pk[s % 4]) for s in bad[:16]])
+    if hasattr(L, "dsvg_debug_emit_stats"): L.dsvg_debug_emit_stats(out)
+    v = list(out)
+    print("frame %d (%s): %d B/picture; light: %d waves, %.1f rounds/wave, %.2f us/wave, %.2f us/round; dense: %d waves, %.1f rounds/wave, %.2f us/wave, %.2f us/round; "
+          "max %.1f us; %d entries/picture" % (t, "I" if t == 0 else "P", sum(len(x) for x in pk) // S,
+          v[0], v[1] / max(v[0], 1), 0.01 * v[2] / max(v[0], 1), 0.01 * v[2] / max(v[1], 1),
+          v[3], v[4] / max(v[3], 1), 0.01 * v[5] / max(v[3], 1), 0.01 * v[5] / max(v[4], 1), 0.01 * v[6], v[7] // S))
+b.close()
