@@ -149,6 +149,7 @@ struct JobDev {              // everything a kernel needs to find one picture jo
                              // fused inverse dequantises them (planes without shared scan cells); 0 = dequantised int32 coefficients
     int pf_off[3];           // offset of each plane in pflag (= CoefLayout.s3off)
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
+    short ext[8];            // border of the reconstruction that will be read: pixels left, right, rows above, below -- luma [0..3], chroma [4..7] (k_extend16)
     HzPlane hz[3];
     int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level
     int isP;

@@ -93,6 +93,8 @@ struct dsvg_ctx {
     HzChunkSum *chunks = nullptr;
     uint8_t *nzf = nullptr;          // per work job: flag byte per 4 scan positions (non-zero symbols of P pictures)
     int16_t *sym = nullptr;          // fused quantiser: per work job, scan-order symbol planes (same indexing as nzpos)
+    std::vector<short> slot_ext;     // per reconstruction slot: the border extents its last encoder job wrote (dsvg_recon_border)
+    bool no_lazy_border = false;     // DSV1_NO_LAZY_BORDER=1: every reconstruction gets its whole border (A/B)
     bool no_list_pack = false;       // DSV1_NO_LIST_PACK=1: a wave per chunk for sparse pictures too (A/B)
     int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
@@ -239,6 +241,7 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     c->no_dec_sym = getenv("DSV1_NO_DEC_SYM") != nullptr;
     c->no_patch_kernel = getenv("DSV1_NO_PATCH_KERNEL") != nullptr;
     c->no_list_pack = getenv("DSV1_NO_LIST_PACK") != nullptr;
+    c->no_lazy_border = getenv("DSV1_NO_LAZY_BORDER") != nullptr;
     for (int g2 = 0; g2 < 2; g2++) {
         HzPlane hp; make_hz_plane(hp, CL.w[g2 ? 1 : 0], CL.h[g2 ? 1 : 0], 100, 1, g2, c->nbh, c->nbv);
         const bool ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
@@ -272,6 +275,16 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
         const int good = pick_streams(ps, want);
         if (good < 0) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
         c->st = ps[0]; c->st_a = ps[1];
+        if (const char *pr = getenv("DSV1_ANALYSIS_PRIO")) {    // experiment: the analysis stream at another priority (-1 high, 1 low)
+            int lo = 0, hi = 0;
+            hipStream_t hs = nullptr;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
+                hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, atoi(pr) < 0 ? hi : lo) == hipSuccess) {
+                (void)hipStreamDestroy(c->st_a);
+                c->st_a = hs;
+                fprintf(stderr, "[dsvg] analysis stream priority %d (range %d..%d)\n", atoi(pr) < 0 ? hi : lo, lo, hi);
+            }
+        }
         for (int g = 1; g < std::max(ncs, 2); g++) c->stx[g] = ps[1 + g];      // every stream is owned by the ctx before anything can fail
         c->st_c = ps[want - 1];
         if (getenv("DSV1_FETCH_ON_ANALYSIS")) {                 // experiment: the fetch copies share the analysis stream (one busy stream fewer)
@@ -499,8 +512,9 @@ static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, si
 {
     // the first pyramid level comes out of the unpack kernel when the luma plane allows it (one read of the frame less)
     const bool fuse1 = with_pyramid && c->levels >= 1 && unpack_fuses_level1(c->L[0]);
-    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr);
-    launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof);
+    const bool sides = unpack_writes_sides(dsrc, pitch, c->src[0].p, c->L[0]) && !getenv("DSV1_NO_UNPACK_SIDES");
+    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides);
+    launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
             if (!(l == 1 && fuse1))
@@ -633,12 +647,56 @@ static void fill_job(dsvg_ctx *c, JobDev &jb, int t, int isP, int quant, int d =
     }
     make_hqp(jb.hqp, quant, isP);
     jb.isP = isP; jb.quant = quant;
+    for (int i = 0; i < 8; i++) jb.ext[i] = DSVG_BORDER;
+}
+
+// How far a picture with motion field `mv` reads beyond the edges of its reference: the window of an inter block starts at
+// the clamped position k_mc / k_fwd_mc_* use (bmc.c:248-255) and is read with a margin of up to 2 pixels before and 3
+// after (4-tap luma filter, staging); accumulated (max) into ext[0..3] luma / ext[4..7] chroma of the reference's job.
+static void border_reach(const dsvg_ctx *c, const DMV *mv, const short *reach, short *ext)
+{
+    const McGeo &G = c->MG;
+    int need[8] = {16, 16, 8, 8, 16, 16, 8, 8};           // referenced at all: intra blocks and staging touch the first pixels
+    if (reach) {
+        // the caller's summary of the vectors: as if the block with the longest vector sat at the edge it points to
+        for (int pl = 0; pl < 2; pl++) {
+            const int sh = pl ? G.hs : 0, sv = pl ? G.vs : 0;
+            int *n = need + 4 * pl;
+            n[0] = std::max(n[0], 2 - (reach[0] >> sh));
+            n[1] = std::max(n[1], (reach[1] >> sh) + 4);
+            n[2] = std::max(n[2], 2 - (reach[2] >> sv));
+            n[3] = std::max(n[3], (reach[3] >> sv) + 4);
+        }
+    } else
+    for (int b = 0; b < c->nblk; b++) {
+        if (mv[b].mode != 0) continue;
+        const int bi = b % G.nbh, bj = b / G.nbh;
+        for (int pl = 0; pl < 2; pl++) {
+            const int sh = pl ? G.hs : 0, sv = pl ? G.vs : 0;
+            const int bw = G.blk_w >> sh, bh = G.blk_h >> sv, pw = G.w[pl], ph = G.h[pl];
+            const int x = bi * bw, y = bj * bh;
+            if (x >= pw || y >= ph) continue;
+            const int cw = std::min(bw, pw - x), ch = std::min(bh, ph - y);
+            const int dx = mv[b].x >> sh, dy = mv[b].y >> sv;
+            const int wx = std::min(std::max(x + (dx >> 1), -DSVG_BORDER), pw - bw + DSVG_BORDER - 1);
+            const int wy = std::min(std::max(y + (dy >> 1), -DSVG_BORDER), ph - bh + DSVG_BORDER - 1);
+            int *n = need + 4 * pl;
+            n[0] = std::max(n[0], 2 - wx);
+            n[1] = std::max(n[1], wx + cw + 3 - (pw - 1));
+            n[2] = std::max(n[2], 2 - wy);
+            n[3] = std::max(n[3], wy + ch + 3 - (ph - 1));
+        }
+    }
+    bool whole = false;
+    for (int i = 0; i < 8; i++) whole = whole || need[i] > DSVG_BORDER - 4;       // reaches the border's last pixels (or the byte
+    for (int i = 0; i < 8; i++)                                                  // after them = the next row's first): everything
+        ext[i] = (short)std::max((int)ext[i], whole ? DSVG_BORDER : need[i]);
 }
 
 // enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
 // insym: details come from the symbol planes -- bit 0: I pictures, bit 1: luma of P pictures, bit 2: chroma of P pictures
-static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, hipStream_t st = nullptr)
+static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, hipStream_t st = nullptr, bool lazy_border = false)
 {
     if (!st) st = c->st;
     const JobDev *jd = c->jobs_d + d0;
@@ -651,7 +709,7 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
         launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, (insym >> 1) & 1);
         launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, (insym >> 2) & 1, ((insym >> 2) & 1) && !c->no_patch_kernel);
     }
-    launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof);
+    launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof, lazy_border ? jd : nullptr);
     return DSVG_OK;
 }
 
@@ -731,6 +789,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     std::vector<char> noint((size_t)NG * nsteps, 1);          // every P picture of the (step, group) was scanned for intra blocks (and icnt says how many)
     int *il = c->ilist_h + (size_t)base * c->nblk;         // intra blocks of each (step, group)'s P pictures (mc_fused)
     int iln = 0;
+    std::vector<const dsvg_pic_job *> dj((size_t)total);   // the caller's job behind every device job
     for (int t = 0; t < nsteps; t++) {
         const dsvg_pic_job *js = jobs + (size_t)t * njobs;
         // device order inside a step: intra jobs first, then inter jobs (kernels are specialised per type)
@@ -749,6 +808,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                 dsvg_set_error("bad picture job (step %d job %d)", t, order[k]); return DSVG_ERR_ARG;
             }
             JobDev &jb = c->jobs_h[d];
+            dj[(size_t)t * njobs + k] = &j;
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
             // P pictures run sparse: zero-kept symbol planes + non-zero flags (k_hz_collect takes both down again)
@@ -776,6 +836,38 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             icnt[NG * t + g] = iln - ioff[NG * t + g];
         }
     }
+    if (!c->no_lazy_border) {
+        // Borders of the reconstructions: a reconstruction is read beyond its edges only by the pictures that predict from it,
+        // and only as far as their motion vectors point -- which is known here (the vectors of every picture of the call are).
+        // A slot rewritten within the call gets the reach of the pictures in between; a slot that outlives the call gets the
+        // whole border unless the caller vouches that no later call predicts from it (border_hint).
+        std::vector<int> writer((size_t)c->n_recon, -1);
+        for (int t = 0; t < nsteps; t++) {
+            for (int k = 0; k < njobs; k++) {
+                const dsvg_pic_job *j = dj[(size_t)t * njobs + k];
+                const int w = j->ref_recon_slot >= 0 ? writer[j->ref_recon_slot] : -1;
+                if (w >= 0) border_reach(c, reinterpret_cast<const DMV *>(j->mvs), j->has_reach ? j->mv_reach : nullptr, c->jobs_h[base + w].ext);
+            }
+            for (int k = 0; k < njobs; k++) {
+                const dsvg_pic_job *j = dj[(size_t)t * njobs + k];
+                if (j->recon_slot < 0) continue;
+                for (int i = 0; i < 8; i++) c->jobs_h[base + t * njobs + k].ext[i] = 0;
+                writer[j->recon_slot] = t * njobs + k;
+            }
+        }
+        for (int r = 0; r < c->n_recon; r++)
+            if (writer[r] >= 0 && !dj[writer[r]]->border_hint)
+                for (int i = 0; i < 8; i++) c->jobs_h[base + writer[r]].ext[i] = DSVG_BORDER;
+    }
+    if (getenv("DSV1_BORDER_DEBUG"))
+        for (int t = 0; t < nsteps; t++) {
+            const short *e = c->jobs_h[base + t * njobs].ext;
+            fprintf(stderr, "[dsvg border] step %d job 0: luma %d %d %d %d chroma %d %d %d %d; reach %d %d %d %d\n", t, e[0], e[1], e[2], e[3], e[4], e[5], e[6], e[7],
+                    dj[(size_t)t * njobs]->mv_reach[0], dj[(size_t)t * njobs]->mv_reach[1], dj[(size_t)t * njobs]->mv_reach[2], dj[(size_t)t * njobs]->mv_reach[3]);
+        }
+    if (c->slot_ext.size() != (size_t)c->n_recon * 8) c->slot_ext.assign((size_t)c->n_recon * 8, (short)DSVG_BORDER);
+    for (int i = 0; i < total; i++)                             // (what dsvg_recon_border reports)
+        if (dj[i]->recon_slot >= 0) memcpy(&c->slot_ext[(size_t)dj[i]->recon_slot * 8], c->jobs_h[base + i].ext, sizeof(short) * 8);
     if (iln) HIPCHK(hipMemcpyAsync(c->ilist_d + (size_t)base * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
@@ -823,7 +915,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             // k_hz_collect is the LAST reader of the sparse symbol planes and clears what it reads
             launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
                             (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
-            OPCHK(enqueue_recon(c, nI, n, d0, 7, st));
+            OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true));
             launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
         }
     }
@@ -932,10 +1024,37 @@ extern "C" int dsvg_download_recon(dsvg_ctx *c, int recon_slot, uint8_t *yuv_out
     return DSVG_OK;
 }
 
+extern "C" int dsvg_extend_recon(dsvg_ctx *c, int recon_slot)
+{
+    if (!c || recon_slot < 0 || recon_slot >= c->n_recon) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    launch_extend(c->st, c->recon.p, c->L[0], recon_slot, 1, 3, nullptr, nullptr, nullptr);
+    HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_recon_border(dsvg_ctx *c, int recon_slot, short *ext_out)
+{
+    if (!c || !ext_out || recon_slot < 0 || recon_slot >= c->n_recon) return DSVG_ERR_ARG;
+    for (int i = 0; i < 8; i++) ext_out[i] = c->slot_ext.size() == (size_t)c->n_recon * 8 ? c->slot_ext[(size_t)recon_slot * 8 + i] : (short)DSVG_BORDER;
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_download_recon_asis(dsvg_ctx *c, int recon_slot, uint8_t *raw_out, size_t bytes)
+{
+    if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    OPCHK(dsvg_ctx_sync(c));
+    HIPCHK(hipMemcpy(raw_out, c->recon.p + (size_t)recon_slot * c->L[0].pitch, bytes, hipMemcpyDeviceToHost));
+    return DSVG_OK;
+}
+
 extern "C" int dsvg_download_recon_raw(dsvg_ctx *c, int recon_slot, uint8_t *raw_out, size_t bytes)
 {
     if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    OPCHK(dsvg_ctx_sync(c));
+    OPCHK(dsvg_extend_recon(c, recon_slot));            // the encoder writes only the part of the border that is read
     OPCHK(dsvg_ctx_sync(c));
     HIPCHK(hipMemcpy(raw_out, c->recon.p + (size_t)recon_slot * c->L[0].pitch, bytes, hipMemcpyDeviceToHost));
     return DSVG_OK;

@@ -17,6 +17,7 @@
 typedef struct {
     DSV_FNUM fnum;
     int gop_start, is_ref, has_ref, forced_intra, isP, quant, n_intra;
+    short reach[4];                  /* min / max of the inter blocks' mv.x >> 1, mv.y >> 1 */
     int cur_slot, ref_slot, out_slot;
     DSV_MV *mvs;
     unsigned char *stable;
@@ -46,6 +47,7 @@ struct dsv1_batch {
     int *slots_cur, *slots_ref, *pair_pic, *out_slots;
     unsigned char *rpar;             /* per stream: which of its two reconstruction slots holds the current reference */
     unsigned char *has_recon;        /* per stream: a reference picture has been coded */
+    unsigned char *border_skipped;   /* per stream: the last reconstruction was coded with border_hint (next picture: a GOP start) */
     unsigned *luma;
     DSV_MV *mv_tmp;
     dsvg_pic_job *jobs;
@@ -105,7 +107,7 @@ void dsv1_batch_close(dsv1_batch *b)
     }
     free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
-    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon);
+    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped);
     free(b);
 }
 
@@ -137,6 +139,7 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b->out_slots = (int *)calloc((size_t)np, sizeof(int));
     b->rpar = (unsigned char *)calloc((size_t)nstreams, 1);
     b->has_recon = (unsigned char *)calloc((size_t)nstreams, 1);
+    b->border_skipped = (unsigned char *)calloc((size_t)nstreams, 1);
     b->luma = (unsigned *)calloc((size_t)b->rows * nstreams, sizeof(unsigned));
     b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
     b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
@@ -429,8 +432,20 @@ static void side_stream(void *ctx, int s, int tid)
         bitw w;
         if (pc->has_ref) {
             int nintra = 0, i;
-            for (i = 0; i < nblk; i++) nintra += pc->mvs[i].mode != 0;
+            int x0 = 0, x1 = 0, y0 = 0, y1 = 0;           /* full-pel reach of the inter blocks' vectors */
+            for (i = 0; i < nblk; i++) {
+                const DSV_MV *m = &pc->mvs[i];
+                if (m->mode != 0) { nintra++; continue; }
+                {
+                    const int dx = m->u.mv.x >> 1, dy = m->u.mv.y >> 1;
+                    if (dx < x0) x0 = dx;
+                    if (dx > x1) x1 = dx;
+                    if (dy < y0) y0 = dy;
+                    if (dy > y1) y1 = dy;
+                }
+            }
             pc->n_intra = nintra;
+            pc->reach[0] = (short)x0; pc->reach[1] = (short)x1; pc->reach[2] = (short)y0; pc->reach[3] = (short)y1;
             pc->forced_intra = 0;
             if (nintra * 100 / nblk > e->intra_pct_thresh) { pc->has_ref = 0; pc->forced_intra = 1; }
         }
@@ -558,6 +573,12 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                     e->prev_avg_luma = al;
                 }
             }
+            if (pc->has_ref && t == 0 && b->border_skipped[s]) {
+                /* the batch before promised a GOP start here (border_hint) and the caller changed the frame numbering
+                 * in between (dsv1_batch_set_fnum): give the reference its whole border after all */
+                if ((rc = dsvg_extend_recon(b->ctx, s + S * b->rpar[s]))) return rc;
+            }
+            if (t == 0) b->border_skipped[s] = 0;
             if (pc->has_ref) {
                 b->slots_cur[npairs] = pc->cur_slot;
                 b->slots_ref[npairs] = pc->ref_slot;
@@ -605,6 +626,13 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                 j->stable_blocks = pc->stable;
                 j->out_slot = pc->out_slot;
                 j->no_intra_blocks = pc->isP && pc->n_intra == 0;
+                j->has_reach = pc->isP;
+                memcpy(j->mv_reach, pc->reach, sizeof pc->reach);
+                /* who predicts from this reconstruction: the next picture of the stream -- in this call, or (last frame of
+                 * the batch) the first of the next one, which is known not to when it starts a GOP (dsv_encoder.c:702-708) */
+                j->border_hint = !serial && (t + 1 < nf || b->enc[s].force_metadata ||
+                                             (DSV_FNUM)(b->enc[s].prev_gop + (DSV_FNUM)b->enc[s].gop) <= b->enc[s].next_fnum);
+                if (t + 1 == nf) b->border_skipped[s] = (unsigned char)(j->border_hint && j->recon_slot >= 0);
             }
             if (serial) {
                 if ((rc = dsvg_code_pictures(b->ctx, S, b->jobs))) return rc;

@@ -10,8 +10,11 @@
 // tightly packed planar frames -> interiors of bordered frames (grid.y = plane, grid.z = frame)
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv, size_t yuv_pitch,
                                                 uint8_t *__restrict__ slab, FrameLayout L, int first_slot,
-                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1)
+                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1, int sides)
 {
+    // sides: the 64-byte left / right borders of every row are written here too (launch_unpack checked that every plane
+    // takes a 16-byte path): they complete the 128-byte lines the row's first and last pixels lie in, where a separate
+    // border kernel writes half lines; the rows above and below the picture are left to k_extend16
     const int c = blockIdx.y, f = blockIdx.z;
     const int slot = slot_tab ? slot_tab[f] : first_slot + f;
     const int w = L.w[c], h = L.h[c];
@@ -31,6 +34,20 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
             const uint4 r1 = reinterpret_cast<const uint4 *>(src + (size_t)(2 * y2 + 1) * w)[x];
             reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2) * L.stride[0])[x] = r0;
             reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2 + 1) * L.stride[0])[x] = r1;
+            if (sides && (x == 0 || x == nv - 1)) {
+                const unsigned v0 = (x == 0 ? (r0.x & 0xff) : (r0.w >> 24)) * 0x01010101u, v1 = (x == 0 ? (r1.x & 0xff) : (r1.w >> 24)) * 0x01010101u;
+                uint4 *b0 = reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2) * L.stride[0] + (x == 0 ? -DSVG_BORDER : w));
+                uint4 *b1 = reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2 + 1) * L.stride[0] + (x == 0 ? -DSVG_BORDER : w));
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) { b0[k] = make_uint4(v0, v0, v0, v0); b1[k] = make_uint4(v1, v1, v1, v1); }
+            }
+            if (sides && nv == 1) {                              // (a 16-pixel-wide plane: the one column is first and last)
+                const unsigned v0 = (r0.w >> 24) * 0x01010101u, v1 = (r1.w >> 24) * 0x01010101u;
+                uint4 *b0 = reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2) * L.stride[0] + w);
+                uint4 *b1 = reinterpret_cast<uint4 *>(dst + (size_t)(2 * y2 + 1) * L.stride[0] + w);
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) { b0[k] = make_uint4(v0, v0, v0, v0); b1[k] = make_uint4(v1, v1, v1, v1); }
+            }
             const unsigned a[4] = {r0.x, r0.y, r0.z, r0.w}, b[4] = {r1.x, r1.y, r1.z, r1.w};
             unsigned o[2] = {0u, 0u};
 #pragma unroll
@@ -48,8 +65,20 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
         const int nv = w >> 4;
         for (int i = blockIdx.x * 256 + threadIdx.x; i < nv * h; i += gridDim.x * 256) {
             const int y = i / nv, x = i - y * nv;
-            reinterpret_cast<uint4 *>(dst + (size_t)y * L.stride[c])[x] =
-                reinterpret_cast<const uint4 *>(src + (size_t)y * w)[x];
+            const uint4 r = reinterpret_cast<const uint4 *>(src + (size_t)y * w)[x];
+            reinterpret_cast<uint4 *>(dst + (size_t)y * L.stride[c])[x] = r;
+            if (sides && x == 0) {
+                const unsigned v = (r.x & 0xff) * 0x01010101u;
+                uint4 *b = reinterpret_cast<uint4 *>(dst + (size_t)y * L.stride[c] - DSVG_BORDER);
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) b[k] = make_uint4(v, v, v, v);
+            }
+            if (sides && x == nv - 1) {
+                const unsigned v = (r.w >> 24) * 0x01010101u;
+                uint4 *b = reinterpret_cast<uint4 *>(dst + (size_t)y * L.stride[c] + w);
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) b[k] = make_uint4(v, v, v, v);
+            }
         }
     } else {
         for (int i = blockIdx.x * 256 + threadIdx.x; i < w * h; i += gridDim.x * 256) {
@@ -149,9 +178,14 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
 // side borders: 4 rows of one 16-byte column of the 128 border bytes of a row; top / bottom: 8 rows of a 16-byte column
 #define EXT16_SIDE_ROWS 4
 #define EXT16_TB_ROWS 8
+// `jobs` (encoder): frame z is the reconstruction of jobs[z], whose ext[] says how far the pictures that predict from it
+// reach into the border (dsvg_code_batch works that out from their motion vectors) -- only that much is written: columns
+// in units of 16, rows in units of EXT16_TB_ROWS.  null: the whole border.
 __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, FrameLayout L, int first, int nplanes,
-                                                  const int *__restrict__ slot_tab)
+                                                  const int *__restrict__ slot_tab, const JobDev *__restrict__ jobs, int tb_only)
 {
+    // tb_only: the side borders of the picture rows exist already (k_unpack): only the rows above and below, over the whole
+    // width of the allocation (corners included), as copies of the bordered first / last row
     const int c = blockIdx.y;
     if (c >= nplanes) return;
     const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
@@ -159,33 +193,40 @@ __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, Fr
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
     const int B = DSVG_BORDER;
-    const int rg = (h + 2 * B + EXT16_SIDE_ROWS - 1) / EXT16_SIDE_ROWS;
-    const int n1 = rg * 8;
-    const int wq = w >> 4;
-    const int n2 = (2 * B / EXT16_TB_ROWS) * wq;
+    int el = B, er = B, et = B, eb = B;
+    if (jobs) {
+        const short *e = jobs[blockIdx.z].ext + (c ? 4 : 0);
+        el = min(B, (e[0] + 15) & ~15); er = min(B, (e[1] + 15) & ~15);
+        et = min(B, (e[2] + EXT16_TB_ROWS - 1) & ~(EXT16_TB_ROWS - 1)); eb = min(B, (e[3] + EXT16_TB_ROWS - 1) & ~(EXT16_TB_ROWS - 1));
+    }
+    const int nc = tb_only ? 0 : (el + er) >> 4, ncl = el >> 4;      // 16-byte columns of the side borders of a row
+    const int rg = (h + et + eb + EXT16_SIDE_ROWS - 1) / EXT16_SIDE_ROWS;
+    const int n1 = rg * nc;
+    const int wq = (w + (tb_only ? 2 * B : 0)) >> 4, xo = tb_only ? -B : 0;
+    const int n2 = ((et + eb) / EXT16_TB_ROWS) * wq;
     for (int i = blockIdx.x * 256 + threadIdx.x; i < n1 + n2; i += gridDim.x * 256) {
         if (i < n1) {
-            const int k = i & 7, r0 = (i >> 3) * EXT16_SIDE_ROWS;
-            const int sx = k < 4 ? 0 : w - 1, dx = k < 4 ? -B + 16 * k : w + 16 * (k - 4);
+            const int g = i / nc, k = i - g * nc, r0 = g * EXT16_SIDE_ROWS - et;      // first of this item's rows
+            const int sx = k < ncl ? 0 : w - 1, dx = k < ncl ? -el + 16 * k : w + 16 * (k - ncl);
             unsigned v[EXT16_SIDE_ROWS];
 #pragma unroll
             for (int j = 0; j < EXT16_SIDE_ROWS; j++) {
-                const int y = r0 + j - B;
+                const int y = r0 + j;
                 const int sy = y < 0 ? 0 : (y > h - 1 ? h - 1 : y);
                 v[j] = p[(long)sy * s + sx] * 0x01010101u;
             }
 #pragma unroll
             for (int j = 0; j < EXT16_SIDE_ROWS; j++) {
-                const int y = r0 + j - B;
-                if (y < h + B) *reinterpret_cast<uint4 *>(p + (long)y * s + dx) = make_uint4(v[j], v[j], v[j], v[j]);
+                const int y = r0 + j;
+                if (y < h + eb) *reinterpret_cast<uint4 *>(p + (long)y * s + dx) = make_uint4(v[j], v[j], v[j], v[j]);
             }
         } else {
             const int j = i - n1;
-            const int g = j / wq, x = 16 * (j - g * wq);
-            const int r0 = g * EXT16_TB_ROWS;                        // 0 .. 2B-1: top rows first, then the bottom ones
-            const bool top = r0 < B;
+            const int g = j / wq, x = xo + 16 * (j - g * wq);
+            const int r0 = g * EXT16_TB_ROWS;                        // 0 .. et+eb-1: the rows above first, then the rows below
+            const bool top = r0 < et;
             const uint4 v = *reinterpret_cast<const uint4 *>(p + (long)(top ? 0 : h - 1) * s + x);
-            uint8_t *d = p + (long)(top ? r0 - B : h + (r0 - B)) * s + x;
+            uint8_t *d = p + (long)(top ? r0 - et : h + (r0 - et)) * s + x;
 #pragma unroll
             for (int q = 0; q < EXT16_TB_ROWS; q++) *reinterpret_cast<uint4 *>(d + (long)q * s) = v;
         }
@@ -260,13 +301,22 @@ static inline int nblk(long items, int cap) { long b = (items + 255) / 256; retu
 // slab1 / L1: when given (and the luma plane qualifies, see unpack_fuses_level1) the first pyramid level is produced
 // by the same kernel
 int unpack_fuses_level1(const FrameLayout &L) { return (L.w[0] & 15) == 0 && (L.h[0] & 1) == 0; }
+// can k_unpack write the side borders (and launch_extend be told tb_only)?  every plane on a 16-byte path of k_unpack and
+// of k_extend16
+bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *slab, const FrameLayout &L)
+{
+    bool ok = ((uintptr_t)yuv % 16) == 0 && (yuv_pitch % 16) == 0 && ((uintptr_t)slab % 16) == 0 && (L.pitch % 16) == 0 &&
+              ((size_t)L.w[0] * L.h[0] % 16) == 0 && ((size_t)L.w[1] * L.h[1] % 16) == 0;
+    for (int c = 0; c < 3; c++) ok = ok && (L.w[c] % 16) == 0 && (L.stride[c] % 16) == 0 && (L.off[c] % 16) == 0;
+    return ok;
+}
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
-                   uint8_t *slab1, const FrameLayout *L1)
+                   uint8_t *slab1, const FrameLayout *L1, bool sides)
 {
     FrameLayout dummy = L;
     if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0));
     hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
-                       slab1, L1 ? *L1 : dummy);
+                       slab1, L1 ? *L1 : dummy, sides ? 1 : 0);
     if (pf) pf->end(st);
 }
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)
@@ -283,14 +333,14 @@ void launch_pack_n(hipStream_t st, uint8_t *yuv, size_t out_pitch, const uint8_t
     else     hipLaunchKernelGGL(k_pack_n<false>, dim3(nblk((long)L.w[0] * L.h[0], 1024), 3, n), dim3(256), 0, st, yuv, out_pitch, slab, L, slot_tab);
     if (pf) pf->end(st);
 }
-void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf)
+void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf, const JobDev *jobs, bool tb_only)
 {
     const long items = (long)(L.h[0] + 128) * 32 + 32L * L.w[0];        // dwords of the luma border
     bool v16 = (L.pitch % 16) == 0;
     for (int c = 0; c < nplanes; c++) v16 = v16 && (L.w[c] % 16) == 0 && (L.stride[c] % 16) == 0 && (L.off[c] % 16) == 0;
     if (pf) pf->begin(st, v16 ? KID_EXTEND16 : KID_EXTEND, 8.0 * items * n);
     const long it16 = ((L.h[0] + 128 + EXT16_SIDE_ROWS - 1) / EXT16_SIDE_ROWS) * 8L + (128 / EXT16_TB_ROWS) * (long)(L.w[0] >> 4);
-    if (v16) hipLaunchKernelGGL(k_extend16, dim3(nblk(it16, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
+    if (v16) hipLaunchKernelGGL(k_extend16, dim3(nblk(it16, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab, jobs, tb_only ? 1 : 0);
     else     hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
     if (pf) pf->end(st);
 }

@@ -165,6 +165,14 @@ typedef struct {
     const unsigned char *stable_blocks; /* host, nblocks entries (encode_stable_blocks output) */
     int out_slot;            /* where the packed planes wait for dsvg_fetch_pictures */
     int no_intra_blocks;     /* P pictures: 1 = the caller knows that no block of mvs has mode != 0 (saves a scan) */
+    int has_reach;           /* P pictures: 1 = mv_reach holds min(mv.x >> 1), max(mv.x >> 1), min(mv.y >> 1), max(mv.y >> 1) over the
+                              * inter blocks of mvs, each taken with 0 (saves a pass over the vectors: see border_hint) */
+    short mv_reach[4];
+    int border_hint;         /* 1 = no picture coded by a LATER call predicts from this reconstruction (the caller knows the
+                              * next picture of the stream: it is in this call, or it starts a GOP).  The replicated border
+                              * (dsv_extend_frame) is then written only as far as the motion vectors of the pictures of this
+                              * call that predict from it reach -- possibly not at all.  0 = unknown: if the slot is not
+                              * rewritten within the call, the whole 64-pixel border is written */
 } dsvg_pic_job;
 
 typedef struct {
@@ -190,6 +198,14 @@ int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);       
 /* the first `bytes` bytes of the slot's whole frame allocation in the reference layout (dsv_mk_frame frame.c:63-120:
  * Y,U,V back to back, 64-px replicated borders): what the next picture's motion compensation reads.  Syncs. */
 int dsvg_download_recon_raw(dsvg_ctx *ctx, int recon_slot, uint8_t *raw_out, size_t bytes);
+/* The encoder writes a reconstruction's border only as far as the pictures that predict from it read it (dsv_pic_job.border_hint,
+ * dsvg_code_batch).  dsvg_recon_border: the extents the slot's last encoder job wrote -- pixels left, right, rows above, below
+ * the picture, luma [0..3] and chroma [4..7] (columns are written in units of 16, rows in units of 8, at most 64).
+ * dsvg_download_recon_asis: the allocation as it is (dsvg_download_recon_raw completes the border first).
+ * dsvg_extend_recon: complete the border of a slot now (asynchronous, coding stream). */
+int dsvg_recon_border(dsvg_ctx *ctx, int recon_slot, short ext_out[8]);
+int dsvg_download_recon_asis(dsvg_ctx *ctx, int recon_slot, uint8_t *raw_out, size_t bytes);
+int dsvg_extend_recon(dsvg_ctx *ctx, int recon_slot);
 /* n reconstruction slots -> tightly packed planar frames, frame i at yuv_out + i*out_pitch.  Device output: enqueued
  * on the pipeline stream, no sync (dsvg_ctx_sync before reading it).  Host output: copied back and synchronised. */
 int dsvg_pack_recons(dsvg_ctx *ctx, int n, const int *recon_slots, void *yuv_out, size_t out_pitch, int out_on_device);

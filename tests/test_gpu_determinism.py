@@ -34,7 +34,7 @@ def test_twin_streams_and_repeats(w, h, streams, frames, per_batch, reps):
             b.close()
         if first is None:
             first = got[:4]
-            want = A.orc_encode(clips[0], A.orc_cfg(w, h, fmt, **cli), eos=False)
+            want = A.orc_encode(clips[0], A.orc_cfg(w, h, fmt, **cli), eos=False)[0]
             assert got[0] == want, "stream 0 differs from the oracle"
         else:
             assert got[:4] == first, "repetition %d differs from the first run" % r

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 
 class PicJob(C.Structure):
     _fields_ = [("src_slot", C.c_int), ("ref_recon_slot", C.c_int), ("recon_slot", C.c_int), ("quant", C.c_int),
-                ("mvs", C.c_void_p), ("stable_blocks", C.c_void_p), ("out_slot", C.c_int), ("no_intra_blocks", C.c_int)]
+                ("mvs", C.c_void_p), ("stable_blocks", C.c_void_p), ("out_slot", C.c_int), ("no_intra_blocks", C.c_int), ("has_reach", C.c_int), ("mv_reach", C.c_short * 4), ("border_hint", C.c_int)]
 
 
 class PicOut(C.Structure):

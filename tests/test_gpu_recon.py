@@ -1,6 +1,9 @@
 """GPU parity of the fused encoder's RECONSTRUCTION frames (dsv_encoder.c:523-525,663-674): after every
-picture the frame the next P picture will predict from -- picture area AND the 64-pixel replicated border the motion
+picture the frame the next P picture will predict from -- picture area AND the replicated border the motion
 compensation reads (dsv_extend_frame frame.c:263-295) -- must equal the oracle encoder's recon_frame byte for byte.
+The encoder writes the border only as far as the next picture's motion vectors reach (dsvg_recon_border); that part is
+compared as the encoder left it (dsvg_download_recon_asis), and the whole 64-pixel border after dsvg_download_recon_raw
+has completed it.
 The stream tests only see this indirectly (through the next picture's bytes); the last picture of a stream, the border
 and the sparse zero-tile path of k_inv_haar_tile (reconstruction = prediction, written in place by k_fwd_mc_pix) are
 observed here directly."""
@@ -36,6 +39,22 @@ def expected_raw(w, h, fmt, planar):
         view = np.lib.stride_tricks.as_strided(bf.buf[start:], shape=(ph + 2 * A.BORDER, pw + 2 * A.BORDER), strides=(s, 1))
         view[:, :] = ext
     return bf.raw().copy()
+
+
+def border_mask(w, h, fmt, ext):
+    """bytes of the frame allocation the encoder vouches for: the picture areas and the border within `ext`"""
+    bf = A.BorderedFrame(w, h, fmt)
+    m = np.zeros(bf.raw().size, dtype=bool)
+    for i in range(3):
+        pw, ph = bf.dims[i]
+        el, er, et, eb = [int(v) for v in ext[(4 if i else 0):(4 if i else 0) + 4]]
+        el, er = min(64, (el + 15) & ~15), min(64, (er + 15) & ~15)
+        et, eb = min(64, (et + 7) & ~7), min(64, (eb + 7) & ~7)
+        s_ = bf.strides[i]
+        start = bf.offs[i] - bf.GUARD - (s_ * A.BORDER + A.BORDER)
+        view = np.lib.stride_tricks.as_strided(m[start:], shape=(ph + 2 * A.BORDER, pw + 2 * A.BORDER), strides=(s_, 1))
+        view[A.BORDER - et:A.BORDER + ph + eb, A.BORDER - el:A.BORDER + pw + er] = True
+    return m
 
 
 def make_clip(w, h, fmt, seed, n, style):
@@ -77,21 +96,32 @@ def test_recon_frames_equal_oracle(pkg, case):
     L = pkg.lib()
     L.dsv1_batch_recon_slot.argtypes = [C.c_void_p, C.c_int]
     L.dsvg_download_recon_raw.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
-    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), 1, 1)
-    try:
-        got_stream = b""
-        for t in range(n):
-            got_stream += b.encode(clip[t].reshape(1, 1, -1))[0]
-            slot = L.dsv1_batch_recon_slot(b.h, 0)
-            assert slot >= 0
-            want = expected_raw(w, h, fmt, want_rec[t])
-            got = np.zeros_like(want)
-            assert L.dsvg_download_recon_raw(b.ctx, slot, got.ctypes.data, got.size) == 0, L.dsvg_last_error()
-            bad = np.nonzero(got != want)[0]
-            assert bad.size == 0, "frame %d: %d reconstruction bytes differ, first at raw offset %d" % (t, bad.size, int(bad[0]))
-        assert got_stream == want_stream
-    finally:
-        b.close()
+    L.dsvg_download_recon_asis.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.dsvg_recon_border.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    # frame by frame (every reconstruction outlives its call: whole borders), then the clip as one batch (borders as far as
+    # the next picture's vectors reach; intermediate reconstructions are gone, the last one is looked at)
+    for per_call in (1, n):
+        b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), 1, per_call)
+        try:
+            got_stream = b""
+            for t in range(0, n, per_call):
+                got_stream += b.encode(clip[t:t + per_call].reshape(1, per_call, -1))[0]
+                slot = L.dsv1_batch_recon_slot(b.h, 0)
+                assert slot >= 0
+                want = expected_raw(w, h, fmt, want_rec[t + per_call - 1])
+                got = np.zeros_like(want)
+                ext = (C.c_short * 8)()
+                assert L.dsvg_recon_border(b.ctx, slot, ext) == 0
+                assert L.dsvg_download_recon_asis(b.ctx, slot, got.ctypes.data, got.size) == 0, L.dsvg_last_error()
+                m = border_mask(w, h, fmt, list(ext))
+                bad = np.nonzero((got != want) & m)[0]
+                assert bad.size == 0, "frame %d: %d reconstruction bytes differ (border %s), first at raw offset %d" % (t, bad.size, list(ext), int(bad[0]))
+                assert L.dsvg_download_recon_raw(b.ctx, slot, got.ctypes.data, got.size) == 0, L.dsvg_last_error()
+                bad = np.nonzero(got != want)[0]
+                assert bad.size == 0, "frame %d: %d bytes differ after the border was completed, first at raw offset %d" % (t, bad.size, int(bad[0]))
+            assert got_stream == want_stream
+        finally:
+            b.close()
 
 
 def test_zero_and_general_tiles_both_taken(pkg):
