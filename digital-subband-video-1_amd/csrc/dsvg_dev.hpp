@@ -149,6 +149,9 @@ struct JobDev {              // everything a kernel needs to find one picture jo
                              // fused inverse dequantises them (planes without shared scan cells); 0 = dequantised int32 coefficients
     int pf_off[3];           // offset of each plane in pflag (= CoefLayout.s3off)
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
+    int32_t *llsym;          // encoder, llq: quantised symbols of the LL region (scan cells below hz[c].r[1].base), int32, plane c at ll_off[c] + scan position;
+    int ll_off[3];           //   written by k_fwd_haar_mid<4,.,true> (levels 4, 5) and k_tail_q (levels >= 6), read by k_hz_collect*
+    int llq;                 // 1: the LL region is quantised where it is produced (no k_hz_quant<true>): k_hz_collect* compacts its chunks too
     short ext[8];            // border of the reconstruction that will be read: pixels left, right, rows above, below -- luma [0..3], chroma [4..7] (k_extend16)
     HzPlane hz[3];
     int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level

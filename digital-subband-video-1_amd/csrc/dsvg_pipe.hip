@@ -96,6 +96,10 @@ struct dsvg_ctx {
     std::vector<short> slot_ext;     // per reconstruction slot: the border extents its last encoder job wrote (dsvg_recon_border)
     bool no_lazy_border = false;     // DSV1_NO_LAZY_BORDER=1: every reconstruction gets its whole border (A/B)
     bool no_list_pack = false;       // DSV1_NO_LIST_PACK=1: a wave per chunk for sparse pictures too (A/B)
+    int32_t *llsym = nullptr;        // per work job: LL-region symbols of the encoder (JobDev.llsym)
+    int ll_off[3] = {0, 0, 0};
+    size_t ll_total = 0;
+    bool llq = true;                 // the LL quantiser runs inside k_fwd_haar_mid<4> / k_tail_q (DSV1_NO_LLQ=1: k_hz_quant<true>, A/B)
     int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
     uint8_t *cflag = nullptr;        // per work job: flag byte per scan chunk (indexed like chunks)
@@ -160,7 +164,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat, c->llsym};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -323,6 +327,13 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     if ((rc = dmalloc(&c->symP, c->nz_total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->pflag, CL.s3total * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->cflag, (size_t)c->chunks_per_job * J, true))) return fail(rc);
+    {   // LL symbol planes (int32, scan order), each plane's share padded to 8 entries (16-byte reads in k_hz_collect*)
+        size_t o = 0;
+        for (int p = 0; p < 3; p++) { c->ll_off[p] = (int)o; o += ((size_t)CL.w3[p] * CL.h3[p] + 7) & ~(size_t)7; }
+        c->ll_total = o;
+        if ((rc = dmalloc(&c->llsym, c->ll_total * J, true))) return fail(rc);
+    }
+    c->llq = !getenv("DSV1_NO_LLQ");
     if ((rc = dmalloc(&c->stat, 4 * 64, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
@@ -696,11 +707,12 @@ static void border_reach(const dsvg_ctx *c, const DMV *mv, const short *reach, s
 // enqueue the reconstruction half shared by encoder and decoder: inverse transform (+prediction) and
 // border extension of kept reconstructions, for device jobs [0,nI) intra and [nI,n) inter
 // insym: details come from the symbol planes -- bit 0: I pictures, bit 1: luma of P pictures, bit 2: chroma of P pictures
-static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, hipStream_t st = nullptr, bool lazy_border = false)
+static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, hipStream_t st = nullptr, bool lazy_border = false,
+                         bool tail_done = false)
 {
     if (!st) st = c->st;
     const JobDev *jd = c->jobs_d + d0;
-    launch_sbt_tail(st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike
+    if (!tail_done) launch_sbt_tail(st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike (encoder with llq: k_tail_q did it)
     if (nI > 0) {
         launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym & 1);
         launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym & 1);
@@ -811,6 +823,9 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             dj[(size_t)t * njobs + k] = &j;
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
+            jb.llq = c->llq ? 1 : 0;           // ... and the LL region's into the kernels that produce it
+            jb.llsym = c->llsym + (size_t)k * c->ll_total;
+            for (int p = 0; p < 3; p++) jb.ll_off[p] = c->ll_off[p];
             // P pictures run sparse: zero-kept symbol planes + non-zero flags (k_hz_collect takes both down again)
             jb.nzf = isP ? c->nzf + (size_t)k * (c->nz_total >> 2) : nullptr;
             if (isP) jb.sym = c->symP + (size_t)k * c->nz_total;
@@ -891,9 +906,10 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             const int d0 = base + t * njobs + k0;
             const int nI = std::min(std::max(nIs[t] - k0, 0), n);                       // I jobs among them come first
             const JobDev *jd = c->jobs_d + d0;
+            const int fz = c->llq ? 2 : 1;                                              // fused quantiser (2: the LL region's too)
             if (nI > 0) {
-                launch_fwd_sbt(st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0, 1);
-                launch_fwd_sbt(st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0, 1);
+                launch_fwd_sbt(st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0, fz);
+                launch_fwd_sbt(st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0, fz);
             }
             if (n > nI) {
                 const int nP = n - nI;
@@ -902,20 +918,24 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                     // inter blocks are predicted inside the forward transform; k_mc only serves the intra blocks (block means)
                     if (icnt[NG * t + g]) launch_mc(st, jd + nI, nP, c->MG, 1, &c->prof, mv0, c->ilist_d + (size_t)base * c->nblk + ioff[NG * t + g], icnt[NG * t + g]);
                     const int gw = icnt[NG * t + g] || !noint[NG * t + g];      // intra blocks somewhere in these pictures (or not known)
-                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1, &c->MG, mv0, gw);
-                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1, &c->MG, mv0, gw);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, fz, &c->MG, mv0, gw);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, fz, &c->MG, mv0, gw);
                 } else {
                     launch_mc(st, jd + nI, nP, c->MG, 1, &c->prof, mv0);
-                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, 1);
-                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, 1);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 0, 1, 1, 0, &c->prof, 0, fz);
+                    launch_fwd_sbt(st, jd + nI, nP, c->G, 1, 2, 1, 0, &c->prof, 0, fz);
                 }
             }
-            launch_sbt_tail(st, jd, n, c->G, 0, 3, 0, &c->prof);
-            // LL quantiser, then the reconstruction (P pictures: straight from the symbol planes), then the entropy stage:
-            // k_hz_collect is the LAST reader of the sparse symbol planes and clears what it reads
-            launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
-                            (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
-            OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true));
+            // levels >= 6 in LDS; the LL quantiser (inside the tail kernel and k_fwd_haar_mid<4> when llq, else k_hz_quant<true>);
+            // then the reconstruction (P pictures: straight from the symbol planes), then the entropy stage:
+            // k_hz_collect* is the LAST reader of the sparse symbol planes and clears what it reads
+            if (c->llq) launch_tail_q(st, jd, n, c->G, 0, 3, &c->prof);
+            else {
+                launch_sbt_tail(st, jd, n, c->G, 0, 3, 0, &c->prof);
+                launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
+                                (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
+            }
+            OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true, c->llq));
             launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
         }
     }

@@ -242,6 +242,128 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
 // workgroup, no LDS and no barrier: the chunk is read as 4 rounds of 16 bytes (8 symbols) per lane, all four
 // loads issued up front, and the non-zeros go straight to the chunk's ordered list.  The few chunks that
 // reach into the LL region (scan cells below r[1].base) are left to k_hz_quant<true>.
+// compaction state of one chunk and one round of it: 8 consecutive cells per lane (v[j] = symbol of scan cell p0 + j), the
+// non-zeros appended to the chunk's ordered list, in-chunk code lengths summed
+struct CollectState {
+    int run = 0;                    // entries written so far
+    int cpos = -1, cval = 0;        // last entry so far (wave-uniform)
+    int first_pos = -1;
+    unsigned bits = 0;              // per-lane partial of bits_inner
+};
+static __device__ __forceinline__ void collect_round(CollectState &st, const int (&v)[8], int p0, int lane, int32_t *gpos, int32_t *gval)
+{
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) cnt += (v[j] != 0);
+    const unsigned long long have = __ballot(cnt != 0);
+    if (have == 0ull) return;                                 // wave-uniform: a round of zeros costs nothing more
+    int incl = cnt;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int nb = __shfl_up(incl, o);
+        if (lane >= o) incl += nb;
+    }
+    // this lane's last entry, for the lanes after it
+    int lpos = -1, lval = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++)
+        if (v[j] != 0) { lpos = p0 + j; lval = v[j]; }
+    // predecessor of this lane's first entry: the nearest earlier lane with entries, else the carry
+    const unsigned long long before = have & ltmask;
+    const int src = before ? 63 - __clzll(before) : 0;
+    int ppos = __shfl(lpos, src), pval = __shfl(lval, src);
+    if (!before) { ppos = st.cpos; pval = st.cval; }
+    int at = st.run + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (v[j] != 0) {
+            gpos[at] = p0 + j;
+            gval[at] = v[j];
+            if (at > 0) st.bits += (unsigned)(len_ueg((unsigned)(p0 + j - ppos - 1)) + len_neg(pval));
+            ppos = p0 + j; pval = v[j];
+            at++;
+        }
+    }
+    const int lastl = 63 - __clzll(have), firstl = __ffsll((long long)have) - 1;
+    if (st.first_pos < 0) {                                   // first entry of the chunk = first entry of lane firstl
+        int fp = -1;
+#pragma unroll
+        for (int j = 7; j >= 0; j--)
+            if (v[j] != 0) fp = p0 + j;
+        st.first_pos = __shfl(fp, firstl);
+    }
+    st.cpos = __shfl(lpos, lastl); st.cval = __shfl(lval, lastl);
+    st.run += __shfl(incl, 63);
+}
+static __device__ __forceinline__ void collect_finish(const JobDev &jb, int c, int chunk, int lane, CollectState &st)
+{
+    unsigned bits = st.bits;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o);
+    if (lane == 0) {
+        HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
+        cs.nnz = st.run;
+        cs.bits_inner = bits;
+        cs.first_pos = st.run ? st.first_pos : -1;
+        cs.last_pos = st.run ? st.cpos : -1;
+        cs.last_val = st.run ? st.cval : 0;
+    }
+}
+
+// a chunk that reaches into the LL region of a job whose LL symbols were written by the transform (jb.llq): cells below
+// ll_end come from the int32 LL symbol plane, the detail cells of the chunk that straddles ll_end from the int16 plane
+// (sparse jobs: taken down again, as in collect_chunk)
+static __device__ __forceinline__ void collect_chunk_ll(const JobDev &jb, int c, int chunk, int lane)
+{
+    const HzPlane &hp = jb.hz[c];
+    const int ll_end = hp.r[1].base, nscan = hp.nscan, cbase = chunk * HZ_CHUNK;
+    const int32_t *ls = jb.llsym + jb.ll_off[c];
+    int16_t *sym = jb.sym + jb.nz_off[c];
+    uint8_t *nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
+    int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    CollectState st;
+    int v[4][8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int p0 = cbase + k * 512 + 8 * lane;
+#pragma unroll
+        for (int j = 0; j < 8; j++) v[k][j] = 0;
+        if (p0 + 8 <= ll_end) {
+            const int4 a = *reinterpret_cast<const int4 *>(ls + p0), b = *reinterpret_cast<const int4 *>(ls + p0 + 4);
+            v[k][0] = a.x; v[k][1] = a.y; v[k][2] = a.z; v[k][3] = a.w; v[k][4] = b.x; v[k][5] = b.y; v[k][6] = b.z; v[k][7] = b.w;
+        } else if (p0 < nscan) {
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int p = p0 + j;
+                if (p < ll_end) v[k][j] = ls[p];
+                else if (p < nscan && (!nzf || nzf[p >> 2])) {
+                    v[k][j] = sym[p];
+                    if (nzf) sym[p] = 0;
+                }
+            }
+        }
+    }
+    if (nzf && cbase + HZ_CHUNK > ll_end) {
+        // the flags of the detail cells read above (a flag byte covers 4 cells: cleared after every lane has read its cells)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int p0 = cbase + k * 512 + 8 * lane;
+            if (p0 + 8 > ll_end && p0 < nscan) {
+                if (p0 + 3 >= ll_end) nzf[p0 >> 2] = 0;
+                if (p0 + 7 >= ll_end) nzf[(p0 >> 2) + 1] = 0;
+            }
+        }
+        if (lane == 0) jb.cflag[jb.chunk_off[c] + chunk] = 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) collect_round(st, v[k], cbase + k * 512 + 8 * lane, lane, gpos, gval);
+    collect_finish(jb, c, chunk, lane, st);
+}
+
 static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, int chunk, int lane)
 {
     const HzPlane &hp = jb.hz[c];
@@ -252,6 +374,7 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
     const int cbase = chunk * HZ_CHUNK;
     int16_t *symw = jb.sym + jb.nz_off[c];
     uint8_t *cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] + chunk : nullptr;
+    if (cbase < ll_end && jb.llq) { collect_chunk_ll(jb, c, chunk, lane); return; }
     if (cbase < ll_end) {
         // chunks that reach into the LL region were compacted by k_hz_quant<true>; in sparse mode the detail symbols of
         // the chunk that straddles the end of the LL region still have to be taken down (this kernel is their last reader)
@@ -309,10 +432,7 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
         if (p0 < nscan) raw[k] = *reinterpret_cast<const uint4 *>(sym + p0);   // the planes are padded to whole chunks
     }
     }
-    int run = 0;                    // entries written so far
-    int cpos = -1, cval = 0;        // last entry so far (wave-uniform)
-    int first_pos = -1;
-    unsigned bits = 0;              // per-lane partial of bits_inner
+    CollectState st;
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int p0 = cbase + k * 512 + 8 * lane;
@@ -328,59 +448,9 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
             for (int j = 0; j < 8; j++)
                 if (p0 + j >= nscan) v[j] = 0;
         }
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) cnt += (v[j] != 0);
-        const unsigned long long have = __ballot(cnt != 0);
-        if (have == 0ull) continue;                               // wave-uniform: a round of zeros costs nothing more
-        int incl = cnt;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            const int nb = __shfl_up(incl, o);
-            if (lane >= o) incl += nb;
-        }
-        // this lane's last entry, for the lanes after it
-        int lpos = -1, lval = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-            if (v[j] != 0) { lpos = p0 + j; lval = v[j]; }
-        // predecessor of this lane's first entry: the nearest earlier lane with entries, else the carry
-        const unsigned long long before = have & ltmask;
-        const int src = before ? 63 - __clzll(before) : 0;
-        int ppos = __shfl(lpos, src), pval = __shfl(lval, src);
-        if (!before) { ppos = cpos; pval = cval; }
-        int at = run + incl - cnt;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (v[j] != 0) {
-                gpos[at] = p0 + j;
-                gval[at] = v[j];
-                if (at > 0) bits += (unsigned)(len_ueg((unsigned)(p0 + j - ppos - 1)) + len_neg(pval));
-                ppos = p0 + j; pval = v[j];
-                at++;
-            }
-        }
-        const int lastl = 63 - __clzll(have), firstl = __ffsll((long long)have) - 1;
-        if (first_pos < 0) {                                      // first entry of the chunk = first entry of lane firstl
-            int fp = -1;
-#pragma unroll
-            for (int j = 7; j >= 0; j--)
-                if (v[j] != 0) fp = p0 + j;
-            first_pos = __shfl(fp, firstl);
-        }
-        cpos = __shfl(lpos, lastl); cval = __shfl(lval, lastl);
-        run += __shfl(incl, 63);
+        collect_round(st, v, p0, lane, gpos, gval);
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) bits += __shfl_down(bits, o);
-    if (lane == 0) {
-        HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
-        cs.nnz = run;
-        cs.bits_inner = bits;
-        cs.first_pos = run ? first_pos : -1;
-        cs.last_pos = run ? cpos : -1;
-        cs.last_val = run ? cval : 0;
-    }
+    collect_finish(jb, c, chunk, lane, st);
 }
 
 __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ jobs)
@@ -408,7 +478,7 @@ __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restric
     if (have) {
         const int ll_end = jb.hz[c].r[1].base, cbase = chunk * HZ_CHUNK;
         const bool fl = jb.nzf ? jb.cflag[jb.chunk_off[c] + chunk] != 0 : true;
-        if (cbase < ll_end) work = jb.nzf && cbase + HZ_CHUNK > ll_end && fl;      // only the straddling chunk's cleanup
+        if (cbase < ll_end) work = jb.llq || (jb.nzf && cbase + HZ_CHUNK > ll_end && fl);   // llq: the LL chunks are compacted here; else only the straddling chunk's cleanup
         else {
             work = fl;
             if (!fl && wv == 0) {

@@ -171,10 +171,23 @@ static __device__ __forceinline__ void store_sym_row(DSVG_GLOBAL int16_t *p, con
 // One forward Haar level on an NxN register patch whose top-left input sample is cell
 // (2*cx0, 2*cy0) of the level's ws x hs input region.  Missing right/bottom samples are mirrored
 // (equivalent to the edge formulas sbt.c:309-346); sub-bands that do not exist are not stored.
-template <int N>
+// LL region of the entropy coder (every band of levels >= 4, hzcc.c:161-186): one quantiser for all of it.  LLQ variants of
+// the producers quantise each detail where it appears: the dequantised value goes where the coefficient would have gone
+// (the inverse reads it), the symbol into the job's LL symbol plane at its scan position y * sw + x.
+struct LLQ {
+    int qp, sw;
+    int32_t *sym;
+    __device__ __forceinline__ int put(int x, int y, int v) const
+    {
+        const int s = hzq_lo(v, qp);
+        sym[y * sw + x] = s;
+        return s ? hzdq_lo(s, qp) : 0;
+    }
+};
+template <int N, bool Q = false>
 static __device__ __forceinline__ void haar_fwd_patch(const int (&in)[N][N], int (&out)[N / 2][N / 2],
                                                       int cx0, int cy0, int ws, int hs, int W,
-                                                      int wo, int ho, int32_t *__restrict__ coef, bool scaled)
+                                                      int wo, int ho, int32_t *__restrict__ coef, bool scaled, const LLQ *lq = nullptr)
 {
     constexpr int M = N / 2;
     const int nR = min(M, max(0, (ws >> 1) - cx0));   // cells of this row that have a right sample
@@ -198,6 +211,14 @@ static __device__ __forceinline__ void haar_fwd_patch(const int (&in)[N][N], int
             hh[i] = a - b - c + d;
         }
         if (2 * cy < hs) {
+            if (Q) {
+#pragma unroll
+                for (int i = 0; i < M; i++) {
+                    if (i < nR) lh[i] = lq->put(wo + cx0 + i, cy, lh[i]);
+                    if (hasB && i < nC) hl[i] = lq->put(cx0 + i, ho + cy, hl[i]);
+                    if (hasB && i < nR) hh[i] = lq->put(wo + cx0 + i, ho + cy, hh[i]);
+                }
+            }
             store_row<M>(coef + (size_t)cy * W + wo + cx0, lh, nR);
             if (hasB) {
                 store_row<M>(coef + (size_t)(ho + cy) * W + cx0, hl, nC);
@@ -971,7 +992,7 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
 
 // forward: two Haar levels (LV, LV+1) from a compact LL band.  LV = 2: intra pictures, LL1 (s1) -> levels
 // 2..3, LL3 -> s3.  LV = 4: every picture, LL3 (s3) -> levels 4..5, LL5 -> s5 (the band the LDS tail takes).
-template <int LV, bool Q>
+template <int LV, bool Q, bool LQ = false>
 __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
@@ -1012,9 +1033,11 @@ __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__
         out[(size_t)J * ow + I] = l3[0][0];
         return;
     }
-    haar_fwd_patch<4>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true);     // levels >= 2 are always scaled
+    LLQ lq;
+    if (LQ) { lq.qp = jb.hz[c].r[0].qp; lq.sw = jb.hz[c].r[0].sw; lq.sym = jb.llsym + jb.ll_off[c]; }
+    haar_fwd_patch<4, LQ>(a, l2, 2 * I, 2 * J, iw, ih, W, wo1, ho1, coef, true, &lq);     // levels >= 2 are always scaled
     if (LV + 1 > g.lvls) { out[0] = l2[0][0]; return; }
-    haar_fwd_patch<2>(l2, l3, I, J, wo1, ho1, W, ow, oh, coef, true);
+    haar_fwd_patch<2, LQ>(l2, l3, I, J, wo1, ho1, W, ow, oh, coef, true, &lq);
     out[(size_t)J * ow + I] = l3[0][0];
 }
 
@@ -1161,6 +1184,120 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restr
         __syncthreads();
     }
     int32_t *s5 = jb.s5 + g.s5off;
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) s5[i] = T[i];
+}
+
+// encoder: forward tail, the LL quantiser on its band, inverse tail -- one kernel, the band never leaves LDS in between
+// (k_fwd_tail + k_hz_quant<true>'s share + k_inv_tail).  Cell 0 is the DC, which travels unquantised (hzcc.c:161,457-460).
+__global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    extern __shared__ int T[];
+    const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
+    const SbtGeo g = G.g[c];
+    const JobDev &jb = jobs[job];
+    const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
+    int32_t *s5 = jb.s5 + g.s5off;
+    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) T[i] = s5[i];
+    __syncthreads();
+    for (int lvl = TAIL_LV; lvl <= g.lvls; lvl++) {
+        const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
+        const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
+        const int ncell = wo * ho;
+        int ll[TAIL_MAXC], lh[TAIL_MAXC], hl[TAIL_MAXC], hh[TAIL_MAXC];
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const bool hasR = 2 * cx + 1 < ws, hasB = 2 * cy + 1 < hs;
+                const int *p = T + 2 * cy * w3 + 2 * cx;
+                const int a = p[0];
+                const int b = hasR ? p[1] : a;
+                const int cc = hasB ? p[w3] : a;
+                const int d = hasB ? (hasR ? p[w3 + 1] : cc) : b;
+                ll[k] = d_ll_down(a + b + cc + d);
+                lh[k] = a - b + cc - d;
+                hl[k] = a + b - cc - d;
+                hh[k] = a - b - cc + d;
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const bool hasR = 2 * cx + 1 < ws, hasB = 2 * cy + 1 < hs;
+                T[cy * w3 + cx] = ll[k];
+                if (hasR) T[cy * w3 + wo + cx] = lh[k];
+                if (hasB) T[(ho + cy) * w3 + cx] = hl[k];
+                if (hasR && hasB) T[(ho + cy) * w3 + wo + cx] = hh[k];
+            }
+        }
+        __syncthreads();
+    }
+    {   // the quantiser: symbols out, dequantised values stay in LDS
+        const HzRegion &r0 = jb.hz[c].r[0];
+        const int qp = r0.qp, sw = r0.sw;
+        int32_t *ls = jb.llsym + jb.ll_off[c];
+        for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) {
+            const int y = i / w3, x = i - y * w3;
+            if (i == 0) { jb.psum[c].dc = T[0]; ls[0] = 0; continue; }
+            const int v = hzq_lo(T[i], qp);
+            ls[y * sw + x] = v;
+            T[i] = v ? hzdq_lo(v, qp) : 0;
+        }
+    }
+    __syncthreads();
+    const bool filt = (c == 0);
+    for (int lvl = g.lvls; lvl >= TAIL_LV; lvl--) {
+        const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
+        const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
+        const int wfull = ws & ~1, hfull = hs & ~1;
+        const int ncell = wo * ho;
+        const int hqp = jb.hqp[lvl];
+        int o0[TAIL_MAXC], o1[TAIL_MAXC], o2[TAIL_MAXC], o3[TAIL_MAXC];
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const int x = 2 * cx, y = 2 * cy;
+                const bool hasR = x + 1 < ws, hasB = y + 1 < hs;
+                const int *pLL = T + cy * w3 + cx;
+                const int LL = d_ll_up(pLL[0]);
+                int LH = hasR ? pLL[wo] : 0;
+                int HL = hasB ? pLL[ho * w3] : 0;
+                const int HH = (hasR && hasB) ? pLL[ho * w3 + wo] : 0;
+                if (filt && hasR && hasB) {
+                    if (x > 0 && x < wfull - 1) LH = d_nudge(LL, d_ll_up(pLL[-1]), d_ll_up(pLL[1]), LH, hqp);
+                    if (y > 0 && y < hfull - 1) HL = d_nudge(LL, d_ll_up(pLL[-w3]), d_ll_up(pLL[w3]), HL, hqp);
+                }
+                o0[k] = d_div4<false>(LL + LH + HL + HH);
+                o1[k] = d_div4<false>(LL - LH + HL - HH);
+                o2[k] = d_div4<false>(LL + LH - HL - HH);
+                o3[k] = d_div4<false>(LL - LH - HL + HH);
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TAIL_MAXC; k++) {
+            const int cell = threadIdx.x + k * TAIL_THREADS;
+            if (cell < ncell) {
+                const int cy = cell / wo, cx = cell - cy * wo;
+                const int x = 2 * cx, y = 2 * cy;
+                const bool hasR = x + 1 < ws, hasB = y + 1 < hs;
+                int *o = T + y * w3 + x;
+                o[0] = o0[k];
+                if (hasR) o[1] = o1[k];
+                if (hasB) {
+                    o[w3] = o2[k];
+                    if (hasR) o[w3 + 1] = o3[k];
+                }
+            }
+        }
+        __syncthreads();
+    }
     for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) s5[i] = T[i];
 }
 
@@ -2187,6 +2324,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
+    const bool llq = fused >= 2;                     // the LL quantiser in k_fwd_haar_mid<4> (JobDev.llq set by the caller)
     if (isP && fused && mc) {
         // motion compensation inside the transform: reference + source in, prediction + symbols out
         // two launches over the same grid: the lean kernel codes the common patches (few registers, no edge logic: it runs
@@ -2250,7 +2388,8 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     }
     // levels 4..5 (LL3 -> LL5) for every picture type
     PB(KID_FWD_HAAR_MID4, s3 * 8.0);
-    hipLaunchKernelGGL((k_fwd_haar_mid<4, false>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    if (llq) hipLaunchKernelGGL((k_fwd_haar_mid<4, false, true>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    else     hipLaunchKernelGGL((k_fwd_haar_mid<4, false>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
     PE();
     if (with_tail) {
         PB(KID_FWD_TAIL, (double)g.w5 * g.h5 * nz * 8.0);
@@ -2271,6 +2410,20 @@ void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
     PB(inverse ? KID_INV_TAIL : KID_FWD_TAIL, s3 * 8.0);
     if (inverse) hipLaunchKernelGGL(k_inv_tail, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
     else         hipLaunchKernelGGL(k_fwd_tail, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
+    PE();
+}
+
+// encoder: forward tail + LL quantiser + inverse tail of planes [c0, c0+npl) of all jobs in one launch
+void launch_tail_q(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, Prof *pf)
+{
+    size_t lds = 0;
+    double s3 = 0;
+    for (int c = c0; c < c0 + npl; c++) {
+        lds = std::max(lds, (size_t)G.g[c].w5 * G.g[c].h5 * 4);
+        s3 += (double)G.g[c].w5 * G.g[c].h5 * njobs;
+    }
+    PB(KID_TAIL_Q, s3 * 8.0);
+    hipLaunchKernelGGL(k_tail_q, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
     PE();
 }
 
@@ -2347,4 +2500,5 @@ void sbt_set_func_attributes()
 {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_inv_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
