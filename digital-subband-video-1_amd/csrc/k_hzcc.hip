@@ -242,6 +242,34 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
 // workgroup, no LDS and no barrier: the chunk is read as 4 rounds of 16 bytes (8 symbols) per lane, all four
 // loads issued up front, and the non-zeros go straight to the chunk's ordered list.  The few chunks that
 // reach into the LL region (scan cells below r[1].base) are left to k_hz_quant<true>.
+#ifdef EMIT_STATS
+// diagnostic build (tools/ab/emit_stats.py): lifetimes of the emit waves, by chunk density
+__device__ unsigned long long g_emit_stat[8][64];
+__device__ unsigned long long g_coll_stat[8][64];
+static int debug_stats(const void *sym, unsigned long long *out);
+extern "C" int dsvg_debug_coll_stats(unsigned long long *out) { return debug_stats(HIP_SYMBOL(g_coll_stat), out); }
+extern "C" int dsvg_debug_emit_stats(unsigned long long *out) { return debug_stats(HIP_SYMBOL(g_emit_stat), out); }
+static int debug_stats(const void *sym, unsigned long long *out)
+{
+    unsigned long long h[8][64];
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(h, sym, sizeof h) != hipSuccess) return -1;
+    for (int k = 0; k < 8; k++) {
+        out[k] = 0;
+        for (int i = 0; i < 64; i++) out[k] = (k == 6) ? (h[k][i] > out[k] ? h[k][i] : out[k]) : out[k] + h[k][i];
+    }
+    memset(h, 0, sizeof h);
+    return hipMemcpyToSymbol(sym, h, sizeof h) == hipSuccess ? 0 : -1;
+}
+#endif
+#ifdef EMIT_STATS
+#define COLL_T0 const unsigned long long t_in = wall_clock64();
+#define COLL_T1(nnz_, ll_) do { if (lane == 0) { const unsigned long long dt = wall_clock64() - t_in; const int sh = (chunk * 7 + c) & 63, k = (ll_) ? 3 : 0; \
+    atomicAdd(&g_coll_stat[k][sh], 1ull); atomicAdd(&g_coll_stat[k + 1][sh], (unsigned long long)(nnz_)); atomicAdd(&g_coll_stat[k + 2][sh], dt); atomicMax(&g_coll_stat[6][sh], dt); } } while (0)
+#else
+#define COLL_T0
+#define COLL_T1(nnz_, ll_)
+#endif
 // compaction state of one chunk and one round of it: 8 consecutive cells per lane (v[j] = symbol of scan cell p0 + j), the
 // non-zeros appended to the chunk's ordered list, in-chunk code lengths summed
 struct CollectState {
@@ -323,6 +351,7 @@ static __device__ __forceinline__ void collect_chunk_ll(const JobDev &jb, int c,
     uint8_t *nzf = jb.nzf ? jb.nzf + (jb.nz_off[c] >> 2) : nullptr;
     int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
     int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
+    COLL_T0
     CollectState st;
     int v[4][8];
 #pragma unroll
@@ -362,6 +391,7 @@ static __device__ __forceinline__ void collect_chunk_ll(const JobDev &jb, int c,
 #pragma unroll
     for (int k = 0; k < 4; k++) collect_round(st, v[k], cbase + k * 512 + 8 * lane, lane, gpos, gval);
     collect_finish(jb, c, chunk, lane, st);
+    COLL_T1(st.run, 1);
 }
 
 static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, int chunk, int lane)
@@ -399,8 +429,7 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
         }
         return;
     }
-    const unsigned long long ltmask = (1ull << lane) - 1ull;
-
+    COLL_T0
     uint4 raw[4];
     if (jb.nzf) {
         // P pictures: the forward transform flagged every group of four cells that holds a non-zero symbol -- two flag
@@ -451,13 +480,14 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
         collect_round(st, v, p0, lane, gpos, gval);
     }
     collect_finish(jb, c, chunk, lane, st);
+    COLL_T1(st.run, 0);
 }
 
 __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ jobs)
 {
     const JobDev &jb = jobs[blockIdx.y];
     int c, chunk;
-    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
+    if (!flat_chunk(jb, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c, chunk)) return;
     collect_chunk(jb, c, chunk, threadIdx.x & 63);
 }
 
@@ -467,7 +497,9 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
 // the same HZ_LIST_CPW chunk flags, one per lane, and takes every fourth flagged chunk -- no LDS, no barrier, and on
 // average well under one chunk per wave, so nothing is serialised.  Chunks without a flag get their empty summary from
 // wave 0.  (A dense job in such a launch -- a scene change inside a step -- is handled too: every chunk counts as flagged.)
-#define HZ_LIST_CPW 32
+#ifndef HZ_LIST_CPW
+#define HZ_LIST_CPW 64
+#endif
 __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restrict__ jobs)
 {
     const JobDev &jb = jobs[blockIdx.y];
@@ -481,10 +513,7 @@ __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restric
         if (cbase < ll_end) work = jb.llq || (jb.nzf && cbase + HZ_CHUNK > ll_end && fl);   // llq: the LL chunks are compacted here; else only the straddling chunk's cleanup
         else {
             work = fl;
-            if (!fl && wv == 0) {
-                HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
-                cs.nnz = 0; cs.bits_inner = 0; cs.first_pos = -1; cs.last_pos = -1; cs.last_val = 0;
-            }
+            if (!fl && wv == 0) jb.chunks[jb.chunk_off[c] + chunk].nnz = 0;     // (of an empty chunk's summary only the count is ever read)
         }
     }
     unsigned long long m = __ballot(work);
@@ -495,7 +524,7 @@ __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restric
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
         if ((k & 3) != wv) continue;
-        collect_chunk(jb, __shfl(c, l), __shfl(chunk, l), lane);
+        collect_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane);      // (scalars: the job table is then read with scalar loads)
     }
 }
 
@@ -744,22 +773,6 @@ static __device__ __forceinline__ void or_bits_lds(unsigned *w32, unsigned pos, 
 #define EMIT_FENCE(o) __builtin_amdgcn_fence(o, "wavefront", "local")
 #endif
 #define EMIT_STAGE_WORDS 200            // 64 symbols x (<= 47 + 49 bits) = 6144 bits = 192 words, + straddle
-#ifdef EMIT_STATS
-// diagnostic build (tools/ab/emit_stats.py): lifetimes of the emit waves, by chunk density
-__device__ unsigned long long g_emit_stat[8][64];
-extern "C" int dsvg_debug_emit_stats(unsigned long long *out)
-{
-    unsigned long long h[8][64];
-    if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(g_emit_stat), sizeof h) != hipSuccess) return -1;
-    for (int k = 0; k < 8; k++) {
-        out[k] = 0;
-        for (int i = 0; i < 64; i++) out[k] = (k == 6) ? (h[k][i] > out[k] ? h[k][i] : out[k]) : out[k] + h[k][i];
-    }
-    memset(h, 0, sizeof h);
-    return hipMemcpyToSymbol(HIP_SYMBOL(g_emit_stat), h, sizeof h) == hipSuccess ? 0 : -1;
-}
-#endif
 // lanes that have no word to store in a round store here instead: every round then issues the same vector-memory
 // operations, which lets the compiler wait for the prefetched entries alone (s_waitcnt vmcnt(1)) instead of for everything
 __device__ unsigned g_emit_dump[128];
@@ -942,7 +955,7 @@ __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs
     __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     int c, chunk;
-    if (!flat_chunk(jb, blockIdx.x * 4 + (threadIdx.x >> 6), c, chunk)) return;
+    if (!flat_chunk(jb, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c, chunk)) return;
     emit_chunk(jb, c, chunk, threadIdx.x & 63, s_stage[threadIdx.x >> 6]);
 }
 
@@ -961,7 +974,7 @@ __global__ __launch_bounds__(256) void k_hz_emit_list(const JobDev *__restrict__
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
         if ((k & 3) != wv) continue;
-        emit_chunk(jb, __shfl(c, l), __shfl(chunk, l), lane, s_stage[wv]);
+        emit_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane, s_stage[wv]);
     }
 }
 

@@ -13,6 +13,7 @@ clips = [A.gen_clip(W, H, FMT, 0x10800003 + g, N, style=0) for g in range(4)]
 b = pkg.Batch(pkg.make_encoder_cfg(W, H, FMT, qp=85, gop=12, rc_mode_cli=1), S, 1)
 out = (C.c_ulonglong * 8)()
 try:
+    L.dsvg_debug_coll_stats.argtypes = [C.c_void_p]
     L.dsvg_debug_emit_stats.argtypes = [C.c_void_p]
 except AttributeError:
     pass
@@ -27,4 +28,9 @@ for t in range(N):
           "max %.1f us; %d entries/picture" % (t, "I" if t == 0 else "P", sum(len(x) for x in pk) // S,
           v[0], v[1] / max(v[0], 1), 0.01 * v[2] / max(v[0], 1), 0.01 * v[2] / max(v[1], 1),
           v[3], v[4] / max(v[3], 1), 0.01 * v[5] / max(v[3], 1), 0.01 * v[5] / max(v[4], 1), 0.01 * v[6], v[7] // S))
+    if hasattr(L, "dsvg_debug_coll_stats"):
+        L.dsvg_debug_coll_stats(out)
+        v = list(out)
+        print("   collect: detail chunks %d waves, %.0f entries/wave, %.2f us/wave; LL chunks %d waves, %.0f entries/wave, %.2f us/wave; max %.1f us" % (
+              v[0], v[1] / max(v[0], 1), 0.01 * v[2] / max(v[0], 1), v[3], v[4] / max(v[3], 1), 0.01 * v[5] / max(v[3], 1), 0.01 * v[6]))
 b.close()
