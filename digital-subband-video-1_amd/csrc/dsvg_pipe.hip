@@ -93,6 +93,7 @@ struct dsvg_ctx {
     HzChunkSum *chunks = nullptr;
     uint8_t *nzf = nullptr;          // per work job: flag byte per 4 scan positions (non-zero symbols of P pictures)
     int16_t *sym = nullptr;          // fused quantiser: per work job, scan-order symbol planes (same indexing as nzpos)
+    std::vector<hipEvent_t> ev_fetch;   // one per piece of a chunked fetch (dsvg_fetch_pictures_cb)
     std::vector<short> slot_ext;     // per reconstruction slot: the border extents its last encoder job wrote (dsvg_recon_border)
     bool no_lazy_border = false;     // DSV1_NO_LAZY_BORDER=1: every reconstruction gets its whole border (A/B)
     bool no_list_pack = false;       // DSV1_NO_LIST_PACK=1: a wave per chunk for sparse pictures too (A/B)
@@ -935,7 +936,10 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                 launch_hz_quant(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0,
                                 (c->CL.w3[0] * c->CL.h3[0] + HZ_CHUNK - 1) / HZ_CHUNK);
             }
-            OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true, c->llq));
+            // (pictures nobody predicts from -- intra-only streams -- have no reconstruction to make (dsv_encoder.c:665); a group without a single kept reconstruction skips the inverse transform altogether)
+            bool keeps = false;
+            for (int k = k0; k < k0 + n && !keeps; k++) keeps = dj[(size_t)t * njobs + k]->recon_slot >= 0;
+            if (keeps) OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true, c->llq));
             launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
         }
     }
@@ -957,8 +961,9 @@ extern "C" int dsvg_code_pictures(dsvg_ctx *c, int njobs, const dsvg_pic_job *jo
     return dsvg_code_batch(c, 1, njobs, jobs);
 }
 
-extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsvg_pic_out *outs)
+extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, dsvg_pic_out *outs, int nchunks, int align, dsvg_fetch_cb cb, void *arg)
 {
+    if (nchunks < 1 || align < 1) { dsvg_set_error("bad fetch_pictures arguments"); return DSVG_ERR_ARG; }
     if (!c || !outs || !out_slots || n < 1 || n > c->out_slots) { dsvg_set_error("bad fetch_pictures arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < n; i++)
@@ -1011,10 +1016,6 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
     launch_gather_bits(c->st_c, c->bits, c->gtab_d, 3 * n, c->gath_d);
     if (fprof) HIPCHK(hipStreamSynchronize(c->st_c));
     const double tf2 = fprof ? tnow() : 0.0;
-    if (total) HIPCHK(hipMemcpyAsync(c->gath_h, c->gath_d, total, hipMemcpyDeviceToHost, c->st_c));
-    HIPCHK(hipStreamSynchronize(c->st_c));
-    if (fprof) fprintf(stderr, "[dsvg fetch] wait for coding + sizes %.2f ms, gather %.2f ms, D2H of %.1f MB %.2f ms\n", tf1 - tf0, tf2 - tf1, total / 1e6, tnow() - tf2);
-    HIPCHK(hipGetLastError());
     for (int i = 0; i < n; i++) {
         const int o = out_slots[i];
         dsvg_pic_out &po = outs[i];
@@ -1025,8 +1026,40 @@ extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsv
             po.payload[p] = c->gath_h + c->gtab_h[3 * (3 * (size_t)i + p) + 1];
         }
     }
+    // 3. the copy, in nchunks pieces that end on multiples of `align` pictures: the caller's work on a piece (packet
+    //    assembly) runs while the later pieces are still on the link
+    if (!cb) nchunks = 1;
+    nchunks = std::max(1, std::min(nchunks, n / align));
+    while ((int)c->ev_fetch.size() < nchunks) {
+        hipEvent_t e;
+        HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        c->ev_fetch.push_back(e);
+    }
+    std::vector<int> cend((size_t)nchunks);
+    for (int j = 0; j < nchunks; j++) {
+        cend[j] = j + 1 == nchunks ? n : (int)((long)(n / align) * (j + 1) / nchunks) * align;
+        const int first = j ? cend[j - 1] : 0;
+        const size_t o0 = first < n ? (size_t)c->gtab_h[3 * (3 * (size_t)first) + 1] : total;
+        const size_t o1 = cend[j] < n ? (size_t)c->gtab_h[3 * (3 * (size_t)cend[j]) + 1] : total;
+        if (o1 > o0) HIPCHK(hipMemcpyAsync(c->gath_h + o0, c->gath_d + o0, o1 - o0, hipMemcpyDeviceToHost, c->st_c));
+        HIPCHK(hipEventRecord(c->ev_fetch[j], c->st_c));
+    }
+    for (int j = 0; j < nchunks; j++) {
+        HIPCHK(hipEventSynchronize(c->ev_fetch[j]));
+        const int first = j ? cend[j - 1] : 0;
+        if (cb && cend[j] > first) cb(arg, first, cend[j] - first);
+    }
+    if (fprof) fprintf(stderr, "[dsvg fetch] wait for coding + sizes %.2f ms, gather %.2f ms, D2H of %.1f MB (+ the caller's work on %d pieces) %.2f ms\n", tf1 - tf0, tf2 - tf1, total / 1e6, nchunks, tnow() - tf2);
+    HIPCHK(hipGetLastError());
     return DSVG_OK;
 }
+
+extern "C" int dsvg_fetch_pictures(dsvg_ctx *c, int n, const int *out_slots, dsvg_pic_out *outs)
+{
+    return dsvg_fetch_pictures_cb(c, n, out_slots, outs, 1, 1, nullptr, nullptr);
+}
+
+
 
 extern "C" int dsvg_download_recon(dsvg_ctx *c, int recon_slot, uint8_t *yuv_out)
 {

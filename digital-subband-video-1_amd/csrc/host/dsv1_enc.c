@@ -472,11 +472,12 @@ static void side_stream(void *ctx, int s, int tid)
 }
 
 /* packet assembly of one stream of a collected batch (its own staging buffer per thread) */
-typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc, nf; } asm_ctx;
+typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc, nf, s0; } asm_ctx;
 static void asm_stream(void *ctx, int s, int tid)
 {
     asm_ctx *c = (asm_ctx *)ctx;
     dsv1_batch *b = c->b;
+    s += c->s0;                                  /* (a piece of the batch: streams s0 ..) */
     const int F = b->F;
     pkt_scratch sc = {NULL, 0};
     size_t need = 0;
@@ -493,6 +494,13 @@ static void asm_stream(void *ctx, int s, int tid)
         if (rc) { c->rc = rc; break; }
     }
     free(sc.pkt);
+}
+/* dsvg_fetch_pictures_cb: pictures [first, first + count) have arrived (whole streams: the pieces end on multiples of nf) */
+static void asm_piece(void *ctx, int first, int count)
+{
+    asm_ctx *c = (asm_ctx *)ctx;
+    c->s0 = first / c->nf;
+    dsv1_par_for(count / c->nf, asm_stream, c);
 }
 
 /* Submit one batch: all source-only analysis now (analysis stream), per-stream decisions and side info
@@ -685,15 +693,14 @@ int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
         HP_BEGIN();
         /* a short batch (nf < F) has a single stream: its pictures are the first nf entries */
         for (k = 0; k < S * nf; k++) b->out_slots[k] = pics[k].out_slot;
-        if ((rc = dsvg_fetch_pictures(b->ctx, S * nf, b->out_slots, b->outs))) return rc;
-        HP_MARK(HP_FETCH);
         {
+            /* the copy comes in pieces of whole streams; the packets of a piece are assembled while the next is on the link */
             asm_ctx ac;
-            ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK; ac.nf = nf;
-            dsv1_par_for(S, asm_stream, &ac);
+            ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK; ac.nf = nf; ac.s0 = 0;
+            if ((rc = dsvg_fetch_pictures_cb(b->ctx, S * nf, b->out_slots, b->outs, S >= 16 ? 4 : 1, nf, asm_piece, &ac))) return rc;
             if (ac.rc) return ac.rc;
         }
-        HP_MARK(HP_ASSEMBLE);
+        HP_MARK(HP_FETCH);
     }
     b->pending[par] = 0;
     return DSVG_OK;

@@ -194,6 +194,11 @@ int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
  * jobs of different shares is run on one stream instead -- always correct, fastest when stream s keeps position s. */
 int dsvg_code_batch(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
+/* The same with the device-to-host copy cut into `nchunks` pieces that end on multiples of `align` pictures: as soon as a
+ * piece has arrived, cb(arg, first, count) is called for its pictures (outs[first .. first+count) are valid then) while the
+ * later pieces are still being copied -- the caller's packet assembly overlaps the link. */
+typedef void (*dsvg_fetch_cb)(void *arg, int first, int count);
+int dsvg_fetch_pictures_cb(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs, int nchunks, int align, dsvg_fetch_cb cb, void *arg);
 int dsvg_download_recon(dsvg_ctx *ctx, int recon_slot, uint8_t *yuv_out);            /* syncs */
 /* the first `bytes` bytes of the slot's whole frame allocation in the reference layout (dsv_mk_frame frame.c:63-120:
  * Y,U,V back to back, 64-px replicated borders): what the next picture's motion compensation reads.  Syncs. */
