@@ -281,7 +281,15 @@ def main():
         # the sparse inverse transform moves data only for tiles that carry a residual: price it at what it really moved
         # (general tile: 128x64 samples x 2.5 B = prediction 1 + reconstruction 1 + level-2/3 symbols 0.47 + flags; the level-1
         # symbols are only fetched for flagged patches; every tile: its 20x12 LL3 values and patch flags, 5 B each)
-        for kname, tg, tz in (("void k_inv_haar_tile<true, 0, true>", tiles["general_luma"], tiles["zero_luma"]),):
+        # The tiles away from the right / bottom edge run in k_inv_p_tile<true>, the strips in k_inv_haar_tile<true, 0, true>
+        # (launch_inv_sbt): the counted tiles are shared out by the grid's geometry.
+        w3, h3 = (W + 7) >> 3, (H + 7) >> 3
+        ntx, nty = (w3 + 15) // 16, (h3 + 7) // 8
+        fx = (w3 - 18) // 16 + 1 if w3 >= 18 else 0
+        fy = (h3 - 10) // 8 + 1 if h3 >= 10 else 0
+        ffast = (fx * fy) / float(ntx * nty)
+        for kname, share in (("void k_inv_p_tile<true>", ffast), ("void k_inv_haar_tile<true, 0, true>", 1.0 - ffast)):
+            tg, tz = tiles["general_luma"] * share, tiles["zero_luma"] * share
             if kname in table and table[kname][1]:
                 m_, n_, _ = table[kname]
                 table[kname] = (m_, n_, tg * 128.0 * 64.0 * 2.5 + (tg + tz) * 240.0 * 5.0)

@@ -167,6 +167,7 @@ struct SbtGeo {              // per-plane constants for the transform kernels
     int lvls;                // total levels
     int w3, h3, w1, h1, w5, h5;
     int pw;                  // pixel plane width (recon store guard)
+    int l1a;                 // 1: the level-1 scan regions start and advance in multiples of 4 cells (8-byte symbol loads of the fast inverse body)
 };
 
 // round-half-away-from-zero divisions (sbt.c:63-88: v < 0 ? -((h - v) >> k) : (v + h) >> k), branch-free:

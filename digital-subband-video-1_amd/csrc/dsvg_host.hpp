@@ -62,7 +62,7 @@ struct Slab {
     X(KID_FWD_B4T, "void k_fwd_b4t<false>") X(KID_FWD_B4T_Q, "void k_fwd_b4t<true>") \
     X(KID_FWD_HAAR_MID2, "void k_fwd_haar_mid<2, false>") X(KID_FWD_HAAR_MID2_Q, "void k_fwd_haar_mid<2, true>") X(KID_FWD_HAAR_MID4, "void k_fwd_haar_mid<4, false>") \
     X(KID_FWD_TAIL, "k_fwd_tail") \
-    X(KID_HZ_QUANT, "void k_hz_quant<false>") X(KID_HZ_QUANT_LL, "void k_hz_quant<true>") X(KID_HZ_COLLECT, "k_hz_collect") X(KID_TAIL_Q, "k_tail_q") X(KID_HZ_COLLECT_LIST, "k_hz_collect_list") X(KID_HZ_EMIT_LIST, "k_hz_emit_list") X(KID_HZ_SCAN, "k_hz_scan") \
+    X(KID_HZ_QUANT, "void k_hz_quant<false>") X(KID_HZ_QUANT_LL, "void k_hz_quant<true>") X(KID_HZ_COLLECT, "k_hz_collect") X(KID_TAIL_Q, "k_tail_q") X(KID_INV_P_TILE_F, "void k_inv_p_tile<true>") X(KID_INV_P_TILE, "void k_inv_p_tile<false>") X(KID_HZ_COLLECT_LIST, "k_hz_collect_list") X(KID_HZ_EMIT_LIST, "k_hz_emit_list") X(KID_HZ_SCAN, "k_hz_scan") \
     X(KID_HZ_EMIT, "k_hz_emit") X(KID_HZ_PARSE, "k_hz_parse") X(KID_HZ_CODES, "k_hz_codes") X(KID_HZ_POSITIONS, "k_hz_positions") X(KID_HZ_SCATTER, "k_hz_scatter_lv") \
     X(KID_INV_TAIL, "k_inv_tail") X(KID_INV_PATCH_C, "k_inv_patch_c") \
     X(KID_INV_TILE_54_F, "void k_inv_haar_tile<true, 2, false>") X(KID_INV_TILE_54, "void k_inv_haar_tile<false, 2, false>") \

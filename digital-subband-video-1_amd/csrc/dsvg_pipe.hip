@@ -228,6 +228,11 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     for (int p = 0; p < 3; p++) {
         make_sbt_geo(c->G.g[p], CL.w[p], CL.h[p], c->L[0].w[p], c->L[0].h[p], c->L[0].stride[p], c->L[0].off[p],
                      CL.off[p], CL.s3off[p], CL.s1off[p], CL.s5off[p]);
+        {
+            HzPlane hp0;
+            make_hz_plane(hp0, CL.w[p], CL.h[p], 100, 1, p, c->nbh, c->nbv);
+            c->G.g[p].l1a = ((hp0.r[7].sw | hp0.r[7].base | hp0.r[8].base | hp0.r[9].base) & 3) == 0;
+        }
         if (!sbt_tail_supported(c->G.g[p])) {
             dsvg_set_error("plane %dx%d: LL5 band does not fit the LDS tail kernel", CL.w[p], CL.h[p]);
             delete c; return DSVG_ERR_UNSUPPORTED;
@@ -719,7 +724,7 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
         launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym & 1);
     }
     if (n > nI) {
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, (insym >> 1) & 1);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, (insym >> 1) & 1, ((insym >> 1) & 1) && !c->no_patch_kernel);
         launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, (insym >> 2) & 1, ((insym >> 2) & 1) && !c->no_patch_kernel);
     }
     launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof, lazy_border ? jd : nullptr);

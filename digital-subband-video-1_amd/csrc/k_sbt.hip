@@ -1591,6 +1591,53 @@ static __device__ __forceinline__ int dq_lo24(int v, int q)                // hz
 }
 static __device__ __forceinline__ unsigned pk_i16(int a, int b) { return ((unsigned)a & 0xffffu) | ((unsigned)b << 16); }
 
+// pk_nudge for a detail that is zero: the nudge itself
+static __device__ __forceinline__ s16x2 pk_nudge0(s16x2 ll, s16x2 lp, s16x2 ln, short hqp, s16x2 pm)
+{
+    const s16x2 a = ll - ln, b = lp - ll, z = {0, 0};
+    const s16x2 mx = pk_min(pk_max(a, b), z), mn = pk_max(pk_min(a, b), z);
+    const s16x2 n = pk_rdiv2(pk_min(pk_max(pk_rdiv4(lp - ln), mx), mn));
+    const s16x2 h = {hqp, hqp}, nh = {(short)-hqp, (short)-hqp};
+    return pk_min(pk_max(n, nh), h) & ((mx - mn) >> 15) & pm;          // mx <= 0 <= mn, mn - mx <= 28000
+}
+// level 1 of one item of inv_p_fast: four adjacent cells (two int16 pairs) of one cell row -> 8 pixels x 2 rows.
+// row: the item's first LL1 pair in LDS (one pair of halo on each side, rows above / below at -WP / +WP); ZERO: no detail
+// symbol in the item (LH = HL = HH = 0 before the nudge); colnz / rownz: 0 for the plane's first cell column / row
+template <bool FILT, bool ZERO>
+static __device__ __forceinline__ void inv_l1_item(const unsigned *row, int WP, uint2 dlh, uint2 dhl, uint2 dhh, const s16x2 (&shv)[2], const uint2 (&pv)[2],
+                                                   short hq1, int colnz, int rownz, unsigned (&row0)[2], unsigned (&row1)[2])
+{
+    const unsigned q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
+    const short pv_ = (short)(rownz ? -1 : 0);                             // row 0 of the plane has none above
+#pragma unroll
+    for (int h2 = 0; h2 < 2; h2++) {
+        const unsigned cw = h2 ? q2 : q1, lw = h2 ? q1 : q0, rw = h2 ? q3 : q2;
+        const s16x2 C = __builtin_bit_cast(s16x2, cw);
+        s16x2 LH = {0, 0}, HL = {0, 0}, HH = {0, 0};
+        if (!ZERO) {
+            const unsigned sl = h2 ? dlh.y : dlh.x, sh_ = h2 ? dhl.y : dhl.x, sd = h2 ? dhh.y : dhh.x;
+            LH = __builtin_bit_cast(s16x2, sl) << shv[h2]; HL = __builtin_bit_cast(s16x2, sh_) << shv[h2];
+            HH = __builtin_bit_cast(s16x2, sd) << shv[h2];
+        }
+        if (FILT) {
+            const s16x2 lp = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(cw, lw, 16u));
+            const s16x2 ln = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(rw, cw, 16u));
+            const s16x2 up = __builtin_bit_cast(s16x2, row[1 + h2 - WP]), dn = __builtin_bit_cast(s16x2, row[1 + h2 + WP]);
+            const s16x2 pmh = s16x2{(short)((h2 | colnz) ? -1 : 0), -1};    // cell 0 of the plane has no left neighbour
+            if (ZERO) {
+                LH = pk_nudge0(C, lp, ln, hq1, pmh);
+                HL = pk_nudge0(C, up, dn, hq1, s16x2{pv_, pv_});
+            } else {
+                LH = pk_nudge(C, lp, ln, LH, hq1, pmh);
+                HL = pk_nudge(C, up, dn, HL, hq1, s16x2{pv_, pv_});
+            }
+        }
+        const s16x2 sA = C + HL, sB = ZERO ? LH : LH + HH, sC = C - HL, sD = ZERO ? LH : LH - HH;
+        row0[h2] = pk_pixels_pred(pk_div4m(sA + sB), pk_div4m(sA - sB), h2 ? pv[0].y : pv[0].x);
+        row1[h2] = pk_pixels_pred(pk_div4m(sC + sD), pk_div4m(sC - sD), h2 ? pv[1].y : pv[1].x);
+    }
+}
+
 template <bool FILT>
 static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo &g, int c, int I0, int J0, int tid,
                                                   int *__restrict__ A3u, int *__restrict__ A2u, unsigned *__restrict__ A1p)
@@ -1638,6 +1685,8 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         ly3 = (int)((utid * 57u) >> 10); lx3 = tid - ly3 * (IT_TX + 2);
         const int cx = I0 - 1 + lx3, cy = J0 - 1 + ly3;
         ok3 = cx >= 0 && cy >= 0;
+        // (fetching these symbols only for flagged patches, as level 1 does, was slower: 4.45 -> 4.70 ms per step -- the flag
+        // load puts a second round trip in front of the first barrier, and these are 0.47 B/sample, not 1.5)
         if (ok3) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)Q3.sw) + (unsigned)cx;
             s3lh = lds16(sym, (unsigned)Q3.base0 + o); s3hl = lds16(sym, (unsigned)Q3.base1 + o); s3hh = lds16(sym, (unsigned)Q3.base2 + o);
@@ -1719,9 +1768,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     if (ok3) {
         const int *pA = A3u + (ly3 + 1) * W3 + lx3 + 1;
         const int LL = pA[0];
-        const int q = max(Q3.qp >> k3, HZ_MINQ);
-        int LH = dq_lo24(s3lh, q), HL = dq_lo24(s3hl, q);
-        const int HH = dq_lo24(s3hh, q);
+        int LH = 0, HL = 0, HH = 0;
+        if (__ballot((s3lh | s3hl | s3hh) != 0)) {           // (a wave without a level-3 symbol: no dequantiser)
+            const int q = max(Q3.qp >> k3, HZ_MINQ);
+            LH = dq_lo24(s3lh, q); HL = dq_lo24(s3hl, q); HH = dq_lo24(s3hh, q);
+        }
         if (FILT) {
             const int hq = jb.hqp[3];
             if (I0 - 1 + lx3 > 0) LH = d_nudge(LL, pA[-1], pA[1], LH, hq);
@@ -1741,9 +1792,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const int ly = (int)((i * 241u) >> 13), lx = (int)i - ly * (2 * IT_TX + 2);
         const int *pA = A2u + (ly + 1) * W2 + lx + 1;
         const int LL = pA[0];
-        const int q = max(Q2.qp >> k2[u], HZ_MINQ);
-        int LH = dq_lo24(s2lh[u], q), HL = dq_lo24(s2hl[u], q);
-        const int HH = dq_lo24(s2hh[u], q);
+        int LH = 0, HL = 0, HH = 0;
+        if (__ballot((s2lh[u] | s2hl[u] | s2hh[u]) != 0)) {
+            const int q = max(Q2.qp >> k2[u], HZ_MINQ);
+            LH = dq_lo24(s2lh[u], q); HL = dq_lo24(s2hl[u], q); HH = dq_lo24(s2hh[u], q);
+        }
         if (FILT) {
             const int hq = jb.hqp[2];
             if (2 * I0 - 1 + lx > 0) LH = d_nudge(LL, pA[-1], pA[1], LH, hq);
@@ -1755,40 +1808,36 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         d[WP] = pk_i16(d_div4<true>(sC + sD), d_div4<true>(sC - sD));
     }
     __syncthreads();
-    // ---- level 1 + sbc2int + prediction add: an item = four adjacent cells = 8 pixels x 2 rows, as two int16 pairs
+    // ---- level 1 + sbc2int + prediction add: an item = four adjacent cells = 8 pixels x 2 rows, as two int16 pairs.
+    // An item none of whose lanes has a flagged patch (the usual one in a sparse picture) takes the body without details.
     const short hq1 = (short)jb.hqp[1];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
         const unsigned *row = A1p + (ly + 2) * WP + 2 * gx;          // pairs 2gx .. 2gx+3 hold LL1 columns 4gx .. 4gx+7 (halo 2)
-        const unsigned q0 = row[0], q1 = row[1], q2 = row[2], q3 = row[3];
         unsigned row0[2], row1[2];
-#pragma unroll
-        for (int h2 = 0; h2 < 2; h2++) {
-            const unsigned cw = h2 ? q2 : q1, lw = h2 ? q1 : q0, rw = h2 ? q3 : q2;
-            const s16x2 C = __builtin_bit_cast(s16x2, cw);
-            const unsigned sl = h2 ? d1lh[u].y : d1lh[u].x, sh_ = h2 ? d1hl[u].y : d1hl[u].x, sd = h2 ? d1hh[u].y : d1hh[u].x;
-            s16x2 LH = __builtin_bit_cast(s16x2, sl) << shv[u][h2], HL = __builtin_bit_cast(s16x2, sh_) << shv[u][h2];
-            const s16x2 HH = __builtin_bit_cast(s16x2, sd) << shv[u][h2];
-            if (FILT) {
-                const s16x2 lp = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(cw, lw, 16u));
-                const s16x2 ln = __builtin_bit_cast(s16x2, __builtin_amdgcn_alignbit(rw, cw, 16u));
-                const s16x2 up = __builtin_bit_cast(s16x2, row[1 + h2 - WP]), dn = __builtin_bit_cast(s16x2, row[1 + h2 + WP]);
-                const s16x2 pmh = s16x2{(short)((h2 | gx | I0) ? -1 : 0), -1};          // cell 0 of the plane has no left neighbour
-                const short pv_ = (short)((ly | J0) ? -1 : 0);                         // row 0 of the plane has none above
-                LH = pk_nudge(C, lp, ln, LH, hq1, pmh);
-                HL = pk_nudge(C, up, dn, HL, hq1, s16x2{pv_, pv_});
-            }
-            const s16x2 sA = C + HL, sB = LH + HH, sC = C - HL, sD = LH - HH;
-            row0[h2] = pk_pixels_pred(pk_div4m(sA + sB), pk_div4m(sA - sB), h2 ? pv[u][0].y : pv[u][0].x);
-            row1[h2] = pk_pixels_pred(pk_div4m(sC + sD), pk_div4m(sC - sD), h2 ? pv[u][1].y : pv[u][1].x);
-        }
+        const bool zero1 = __ballot(pf1[u] != 0) == 0ull;
+        if (zero1) inv_l1_item<FILT, true>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
+        else inv_l1_item<FILT, false>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
         const auto dst = outp + poff[u];
         dsvg_st2(dst, make_uint2(row0[0], row0[1]));
         dsvg_st2(dst + (unsigned)stride, make_uint2(row1[0], row1[1]));
     }
 }
 
+
+// The fast body as a kernel of its own, for the tiles that take it (launch_inv_sbt: the interior of the tile grid of sparse
+// P pictures; k_inv_haar_tile gets the right / bottom strips): register allocation and LDS are then the fast body's, not
+// the maximum over the general body as well.
+template <bool FILT>
+__global__ __launch_bounds__(256) void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+{
+    __shared__ int A3[A3H * A3W];
+    __shared__ int A2[A2H * A2W];
+    __shared__ unsigned A1p[(4 * IT_TY + 4) * (2 * IT_TX + 2)];
+    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    inv_p_fast<FILT>(jobs[job], G.g[c], c, (int)blockIdx.x * IT_TX, (int)blockIdx.y * IT_TY, threadIdx.x, A3, A2, A1p);
+}
 
 // MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
 // whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
@@ -1809,7 +1858,17 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     const int32_t *coef = jb.coef + g.coff;
     const int inw = DSVG_RSU(W, TOP), inh = DSVG_RSU(H, TOP);
     const int32_t *s3 = (MODE == 2) ? jb.s5 + g.s5off : jb.s3 + g.s3off;       // LL band of level TOP
-    const int I0 = ((int)blockIdx.x + bxofs) * IT_TX, J0 = ((int)blockIdx.y + byofs) * IT_TY;     // (offsets: a strip of the tile grid)
+    // (offsets: a strip of the tile grid.  byofs < 0: the L-shaped rest of the grid beside the bxofs x (-byofs - 1) tiles that
+    // k_inv_p_tile takes, blockIdx.x running through the right strip (all rows), then the bottom strip)
+    int bx = (int)blockIdx.x + bxofs, by = (int)blockIdx.y + byofs;
+    if (byofs < 0) {
+        const int fx = bxofs, fy = -byofs - 1, ntx = (inw + IT_TX - 1) / IT_TX, nty = (inh + IT_TY - 1) / IT_TY;
+        const int nr = (ntx - fx) * nty;
+        int b = (int)blockIdx.x;
+        if (b < nr) { by = b / (ntx - fx); bx = fx + b - by * (ntx - fx); }
+        else { b -= nr; by = b / fx; bx = b - by * fx; by += fy; }
+    }
+    const int I0 = bx * IT_TX, J0 = by * IT_TY;
     const int tid = threadIdx.x;
     const bool isP = jb.isP != 0;
 
@@ -2463,11 +2522,32 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             }
             if (tcx < (int)tg.x || tcy < (int)tg.y) {
                 PB(KID_INV_TILE_PIX_SYM, (smp - 64.0 * imax * jmax * nz) * 2.5);
-                if (tcx < (int)tg.x) hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(tg.x - tcx, tg.y, nz), dim3(256), 0, st, jobs, G, c0, npl, tcx, 0);
-                if (tcy < (int)tg.y && tcx > 0) hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(tcx, tg.y - tcy, nz), dim3(256), 0, st, jobs, G, c0, npl, 0, tcy);
+                // (right strip and bottom strip in one L-shaped launch)
+                const int nrest = ((int)tg.x - tcx) * (int)tg.y + tcx * ((int)tg.y - tcy);
+                hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, tcx, -tcy - 1);
                 PE();
             }
         } else if (insym) {
+            // sparse pictures (patch_kernel: every job has flags and a reference) on a geometry with aligned level-1 rows: the
+            // tiles whose cells and halo are complete (not in the last tile column / row, nor within a cell of the band's end)
+            // take the fast body as a kernel of its own, the general kernel the right and bottom strips
+            const int fx = (patch_kernel && g.l1a && g.w3 >= IT_TX + 2) ? (g.w3 - IT_TX - 2) / IT_TX + 1 : 0;
+            const int fy = (patch_kernel && g.l1a && g.h3 >= IT_TY + 2) ? (g.h3 - IT_TY - 2) / IT_TY + 1 : 0;
+            if (fx > 0 && fy > 0) {
+                const double fsmp = 64.0 * fx * IT_TX * fy * IT_TY * nz;            // samples of the fast tiles
+                PB(filt ? KID_INV_P_TILE_F : KID_INV_P_TILE, fsmp * 2.5);
+                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), dim3(fx, fy, nz), dim3(256), 0, st, jobs, G, c0, npl);
+                else      hipLaunchKernelGGL((k_inv_p_tile<false>), dim3(fx, fy, nz), dim3(256), 0, st, jobs, G, c0, npl);
+                PE();
+                PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, (smp - fsmp) * 2.5);
+                const int nrest = ((int)tg.x - fx) * (int)tg.y + fx * ((int)tg.y - fy);      // right strip + bottom strip, one launch
+                if (nrest > 0) {
+                    if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fx, -fy - 1);
+                    else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fx, -fy - 1);
+                }
+                PE();
+                return;
+            }
             PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, smp * 2.5);
             if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
             else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
