@@ -777,29 +777,37 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 }
 
 // one wave per visited block and frame pair; NKBF = rows per lane of a FULL block of this geometry (0: none is special)
-template <bool LEVEL0, int NKBF>
-__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs)
+// PART 1: the full blocks only (64 wide, 4 * NKBF rows: the specialised body), grid = fullx x fully blocks per pair;
+// PART 2: the rest of the block grid (right column / bottom row of partial blocks), the generic body -- as kernels of their
+// own: in one kernel the register allocation is the generic body's (106 SGPRs + 246 spilled to VGPR lanes, 79 VGPRs; the
+// specialised body alone: 64 SGPRs, no spills).  PART 0: every block, generic body (geometries without full blocks).
+// PART 3: every block, either body (the small upper levels of the pyramid: a second launch costs more than it saves).
+template <bool LEVEL0, int NKBF, int PART>
+__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
 {
     __shared__ HmeShared S;
     const int step = 1 << level;
     const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
-    const int item = d_xcd_remap(blockIdx.x, nvx * nvy * npairs);
-    if (item >= nvx * nvy * npairs) return;
-    const int pair = item / (nvx * nvy), vb = item - pair * (nvx * nvy);
-    const int vi = vb % nvx, vj = vb / nvx;
+    const int per = PART == 1 ? fullx * fully : (PART == 2 ? nvx * nvy - fullx * fully : nvx * nvy);      // blocks of a pair in this launch
+    const int item = d_xcd_remap(blockIdx.x, per * npairs);
+    if (item >= per * npairs) return;
+    const int pair = item / per;
+    int vb = item - pair * per, vi, vj;
+    if (PART == 1) { vj = vb / fullx; vi = vb - vj * fullx; }
+    else if (PART == 2) {
+        const int nr = (nvx - fullx) * nvy;                 // right strip (all rows), then the bottom strip under the full blocks
+        if (vb < nr) { vj = vb / (nvx - fullx); vi = fullx + vb - vj * (nvx - fullx); }
+        else { vb -= nr; vj = vb / fullx; vi = vb - vj * fullx; vj += fully; }
+    } else { vi = vb % nvx; vj = vb / nvx; }
     const int i = vi * step, j = vj * step;
     const int fw = A.L[level].w[0], fh = A.L[level].h[0];
     const int bx = (i * A.blk_w) >> level, by = (j * A.blk_h) >> level;
     if (bx >= fw || by >= fh) return;                       // stays a zero inter vector (hme.c:441-444)
-    if constexpr (NKBF > 0) {
-        if (A.blk_w == 64 && fw - bx >= 64 && fh - by >= 4 * NKBF && A.blk_h == 4 * NKBF) {
-            hme_block<LEVEL0, NKBF>(A, level, pair, i, j, S);
-            return;
-        }
+    if constexpr (PART == 3) {                              // every block in one launch, each with the body that fits it
+        if (fw - bx >= 64 && fh - by >= 4 * NKBF) { hme_block<LEVEL0, NKBF>(A, level, pair, i, j, S); return; }
     }
-#ifndef AB_HME_FASTONLY
-    hme_block<LEVEL0, 0>(A, level, pair, i, j, S);
-#endif
+    if constexpr (PART == 1) hme_block<LEVEL0, NKBF>(A, level, pair, i, j, S);
+    else hme_block<LEVEL0, 0>(A, level, pair, i, j, S);
 }
 
 // second pass of level 0: high_detail from the causal neighbours' final flags (hme.c:621-648)
@@ -840,13 +848,25 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         if (level == 0)             // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681)
             px += 2.0 * npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]);
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
-        const dim3 grid(xcd_grid(nvx * nvy * npairs)), blk(NT);
-        // rows per lane of a full block (64 wide, blk_h = 4 * rows): those blocks take the specialised body
-        const int nkbf = (A.blk_w == 64 && A.blk_h % 4 == 0) ? A.blk_h / 4 : 0;
-#define HME_LAUNCH(L0, N) hipLaunchKernelGGL((k_hme_level<L0, N>), grid, blk, 0, st, A, level, npairs)
-#define HME_PICK(L0) do { switch (nkbf) { case 16: HME_LAUNCH(L0, 16); break; case 12: HME_LAUNCH(L0, 12); break; case 8: HME_LAUNCH(L0, 8); break; \
-                                          default: HME_LAUNCH(L0, 0); } } while (0)
-        if (level > 0) HME_PICK(false); else HME_PICK(true);
+        const dim3 blk(NT);
+        // rows per lane of a full block (64 wide, blk_h = 4 * rows): those blocks take the specialised body, in a launch of
+        // their own; the partial blocks at the right / bottom edge of the level's frame the generic one
+        const int nkbf = (A.blk_w == 64 && (A.blk_h == 64 || A.blk_h == 48 || A.blk_h == 32)) ? A.blk_h / 4 : 0;
+        const int fw = A.L[level].w[0], fh = A.L[level].h[0];
+        const int fullx = nkbf ? std::min(nvx, fw / 64) : 0, fully = nkbf ? std::min(nvy, fh / A.blk_h) : 0;
+        const int nfull = fullx * fully, nrest = nvx * nvy - nfull;
+#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid((cnt) * npairs)), blk, 0, st, A, level, npairs, fullx, fully)
+#define HME_FULL(L0) do { switch (nkbf) { case 16: HME_LAUNCH(L0, 16, 1, nfull); break; case 12: HME_LAUNCH(L0, 12, 1, nfull); break; \
+                                          default: HME_LAUNCH(L0, 8, 1, nfull); } } while (0)
+        (void)nrest;
+        if (nfull > 0 && level > 0) {
+            switch (nkbf) { case 16: HME_LAUNCH(false, 16, 3, nvx * nvy); break; case 12: HME_LAUNCH(false, 12, 3, nvx * nvy); break;
+                            default: HME_LAUNCH(false, 8, 3, nvx * nvy); }
+        } else if (nfull > 0) {
+            HME_FULL(true);
+            if (nrest > 0) HME_LAUNCH(true, 0, 2, nrest);
+        } else if (level > 0) HME_LAUNCH(false, 0, 0, nvx * nvy);
+        else HME_LAUNCH(true, 0, 0, nvx * nvy);
         if (pf) pf->end(st);
     }
     if (pf) pf->begin(st, KID_HME_DETAIL, 0.0);

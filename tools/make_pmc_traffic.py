@@ -15,9 +15,11 @@ import sys
 
 
 def kid(name):
-    """rocprofv3 prints k_hme_level<true, 12> (second argument: rows per lane of a full block, picked per geometry by the
-    launcher); the profiling API of the library and bench.py name the kernel by its first argument only"""
-    return re.sub(r"k_hme_level<(true|false), \d+>", r"k_hme_level<\1>", name)
+    """rocprofv3 prints k_hme_level<true, 12, 1> (second argument: rows per lane of a full block, picked per geometry by the
+    launcher; third: 1 = the launch over the full blocks, 2 = the partial blocks at the frame's edge); the profiling API of
+    the library and bench.py name the kernel by its first argument only"""
+    name = re.sub(r"k_hme_level<(true|false), \d+, [013]>", r"k_hme_level<\1>", name)          # the full blocks (or every block)
+    return re.sub(r"k_hme_level<(true|false), \d+, 2>", r"k_hme_level<\1> (partial blocks)", name)
 
 
 rows = list(csv.DictReader(open(sys.argv[1])))
