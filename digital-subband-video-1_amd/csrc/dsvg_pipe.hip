@@ -9,6 +9,7 @@
 #include <algorithm>
 #include "dsvg_host.hpp"
 #include <ctime>
+extern "C" void dsv1_par_for(int S, void (*fn)(void *ctx, int s, int tid), void *ctx);     // host/dsv1_util.c: the worker pool
 
 #define OPCHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -741,6 +742,9 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         dsvg_set_error("bad code_batch arguments"); return DSVG_ERR_ARG;
     }
     HIPCHK(hipSetDevice(c->device));
+    static const bool cprof = getenv("DSV1_HOST_PROF") != nullptr;
+    const auto cnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
+    const double tc0 = cprof ? cnow() : 0.0;
     const int total = nsteps * njobs;
     int base = jobs[0].out_slot;
     for (int i = 1; i < total; i++) base = std::min(base, jobs[i].out_slot);
@@ -825,8 +829,28 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                 j.out_slot < base || j.out_slot >= base + total || !j.stable_blocks || (isP && !j.mvs)) {
                 dsvg_set_error("bad picture job (step %d job %d)", t, order[k]); return DSVG_ERR_ARG;
             }
-            JobDev &jb = c->jobs_h[d];
             dj[(size_t)t * njobs + k] = &j;
+            if (isP && !c->mc_fused) noint[NG * t + g] = 0;
+            if (isP && c->mc_fused && !j.no_intra_blocks) {
+                // index relative to the first P job of the group's launch
+                const int k0 = std::max(gk[g], nIs[t]);
+                const DMV *mv = reinterpret_cast<const DMV *>(j.mvs);
+                for (int b = 0; b < c->nblk; b++)
+                    if (mv[b].mode != 0) il[iln++] = (k - k0) * c->nblk + b;
+            }
+            icnt[NG * t + g] = iln - ioff[NG * t + g];
+        }
+    }
+    {   // the job records themselves (quantiser tables of three planes, pointers, copies of the block tables): independent per
+        // job, built on the session layer's worker pool (1 920 jobs: 1.5 ms on one thread)
+        struct BuildCtx { dsvg_ctx *c; const std::vector<const dsvg_pic_job *> *dj; int base, njobs; } bc = {c, &dj, base, njobs};
+        dsv1_par_for(total, [](void *vp, int idx, int) {
+            BuildCtx &B = *static_cast<BuildCtx *>(vp);
+            dsvg_ctx *c = B.c;
+            const dsvg_pic_job &j = *(*B.dj)[(size_t)idx];
+            const int k = idx % B.njobs, d = B.base + idx;
+            const int isP = j.ref_recon_slot >= 0;
+            JobDev &jb = c->jobs_h[d];
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
             jb.llq = c->llq ? 1 : 0;           // ... and the LL region's into the kernels that produce it
@@ -846,16 +870,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             c->slots_h[d] = j.recon_slot;
             memcpy(c->stable_h + (size_t)d * c->nblk, j.stable_blocks, (size_t)c->nblk);
             if (isP) memcpy(c->mv_h + (size_t)d * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
-            if (isP && !c->mc_fused) noint[NG * t + g] = 0;
-            if (isP && c->mc_fused && !j.no_intra_blocks) {
-                // index relative to the first P job of the group's launch
-                const int k0 = std::max(gk[g], nIs[t]);
-                const DMV *mv = reinterpret_cast<const DMV *>(j.mvs);
-                for (int b = 0; b < c->nblk; b++)
-                    if (mv[b].mode != 0) il[iln++] = (k - k0) * c->nblk + b;
-            }
-            icnt[NG * t + g] = iln - ioff[NG * t + g];
-        }
+        }, &bc);
     }
     if (!c->no_lazy_border) {
         // Borders of the reconstructions: a reconstruction is read beyond its edges only by the pictures that predict from it,
@@ -889,6 +904,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     if (c->slot_ext.size() != (size_t)c->n_recon * 8) c->slot_ext.assign((size_t)c->n_recon * 8, (short)DSVG_BORDER);
     for (int i = 0; i < total; i++)                             // (what dsvg_recon_border reports)
         if (dj[i]->recon_slot >= 0) memcpy(&c->slot_ext[(size_t)dj[i]->recon_slot * 8], c->jobs_h[base + i].ext, sizeof(short) * 8);
+    const double tc1 = cprof ? cnow() : 0.0;
     if (iln) HIPCHK(hipMemcpyAsync(c->ilist_d + (size_t)base * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
@@ -952,6 +968,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         HIPCHK(hipEventRecord(c->ev_join[g], c->stx[g]));
         HIPCHK(hipStreamWaitEvent(c->st, c->ev_join[g], 0));
     }
+    if (cprof) fprintf(stderr, "[dsvg code_batch] %d jobs: tables %.2f ms, uploads + %d frame steps of launches %.2f ms\n", total, tc1 - tc0, nsteps, cnow() - tc1);
     {   // completion marker of this call; fetch waits on it from its own stream
         const int e = (int)(call % (long)c->ev_coded.size());
         HIPCHK(hipEventRecord(c->ev_coded[e], c->st));

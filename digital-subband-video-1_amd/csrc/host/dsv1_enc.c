@@ -58,7 +58,7 @@ struct dsv1_batch {
 /* source slot of frame number g (per-stream counter) of stream s */
 /* host-side phase timing (DSV1_HOST_PROF=1): where a batch's wall time goes inside submit / collect */
 #include <time.h>
-enum { HP_LOAD, HP_DECIDE, HP_ANALYSE, HP_SIDEINFO, HP_ENQUEUE, HP_FETCH, HP_ASSEMBLE, HP_N };
+enum { HP_LOAD, HP_DECIDE, HP_ANALYSE, HP_SIDEINFO, HP_ENQUEUE, HP_PREFIX, HP_FETCH, HP_ASSEMBLE, HP_N };
 static double hp_acc[HP_N];
 static long hp_batches;
 static int hp_on = -1;
@@ -73,7 +73,7 @@ static double hp_now(void)
 static void hp_report(void)
 {
     static const char *nm[HP_N] = {"load+pyramid (enqueue, luma sums wait)", "GOP / scene-change decisions", "motion search (enqueue + GPU wait + D2H)",
-                                   "stability + motion side info", "job tables + coding enqueue", "fetch (GPU wait + gather + D2H)", "packet assembly"};
+                                   "intra decisions + stability flags", "job tables + coding enqueue", "packet prefixes (stability / motion bits)", "fetch (GPU wait + gather + D2H)", "packet assembly"};
     int k;
     if (hp_on <= 0 || !hp_batches) return;
     for (k = 0; k < HP_N; k++) fprintf(stderr, "[dsv1 host] %-44s %8.3f ms / batch\n", nm[k], hp_acc[k] / (double)hp_batches);
@@ -256,13 +256,10 @@ static void write_pkt_hdr(bitw *w, int type)
 }
 
 /* stability flags of one picture: updates the per-stream accumulators in coding order
- * (encode_stable_blocks dsv_encoder.c:330-408) and appends the ZBRLE block to the packet prefix */
-static void stability_pass(DSV_ENCODER *e, pic_t *pc, int nblk, bitw *w, uint8_t *tmp)
+ * (encode_stable_blocks dsv_encoder.c:330-408); the flags go to pc->stable (the coding kernels need them) */
+static void stability_update(DSV_ENCODER *e, pic_t *pc, int nblk)
 {
-    zrle z;
-    int i, div, bytes;
-    memset(tmp, 0, (size_t)nblk * 4 + 16);
-    zr_init(&z, tmp);
+    int i, div;
     if (e->refresh_ctr >= e->stable_refresh) {
         e->refresh_ctr = 0;
         memset(e->stability, 0, sizeof(*e->stability) * (size_t)nblk);
@@ -271,13 +268,16 @@ static void stability_pass(DSV_ENCODER *e, pic_t *pc, int nblk, bitw *w, uint8_t
     if (div <= 0) div = 1;
     for (i = 0; i < nblk; i++) {
         int stable = 0, intra = 0;
+        /* (acc / div == 0 with C's truncating division and div >= 1 is -div < acc < div -- the accumulators are signed 16-bit
+         * fields and may wrap: no division per block) */
+#define NEAR0(a) ((a) < div && (a) > -div)
         if (pc->isP) {
             const DSV_MV *mv = &pc->mvs[i];
             if (mv->mode == 0) {
                 e->stability[i].x += abs(mv->u.mv.x) >> 2;
                 e->stability[i].y += abs(mv->u.mv.y) >> 2;
                 stable = mv->high_detail;
-                stable |= (e->stability[i].x / div == 0 && e->stability[i].y / div == 0 && !mv->lo_tex && !mv->lo_var);
+                stable |= (NEAR0(e->stability[i].x) && NEAR0(e->stability[i].y) && !mv->lo_tex && !mv->lo_var);
             } else {
                 intra = 1;
             }
@@ -286,12 +286,21 @@ static void stability_pass(DSV_ENCODER *e, pic_t *pc, int nblk, bitw *w, uint8_t
                 e->stability[i].y = 0x3fff;
             }
         } else {
-            stable = (e->stability[i].x / div == 0 && e->stability[i].y / div == 0);
+            stable = (NEAR0(e->stability[i].x) && NEAR0(e->stability[i].y));
         }
+#undef NEAR0
         e->stable_blocks[i] = (unsigned char)(stable | (intra << 1));
-        zr_put(&z, e->stable_blocks[i] & 1);
     }
     memcpy(pc->stable, e->stable_blocks, (size_t)nblk);
+}
+/* ... and their ZBRLE block in the packet prefix (from pc->stable: may run after the coding work was enqueued) */
+static void stability_write(const pic_t *pc, int nblk, bitw *w, uint8_t *tmp)
+{
+    zrle z;
+    int i, bytes;
+    memset(tmp, 0, (size_t)nblk * 4 + 16);
+    zr_init(&z, tmp);
+    for (i = 0; i < nblk; i++) zr_put(&z, pc->stable[i] & 1);
     bw_align(w);
     bytes = zr_end(&z);
     bw_ueg(w, (unsigned)bytes);
@@ -418,18 +427,19 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
 }
 
 typedef struct { dsv1_batch *b; pic_t *pics; } side_ctx;
+/* what the coding work needs of the side information, per stream in coding order: intra decisions, the stability flags
+ * (accumulators), the vectors' reach.  The bits of the packet prefix are written by prefix_stream AFTER the coding work
+ * has been enqueued: the GPU has nothing else to do while this runs. */
 static void side_stream(void *ctx, int s, int tid)
 {
     side_ctx *c = (side_ctx *)ctx;
     dsv1_batch *b = c->b;
     const int F = b->F, nblk = b->nblk;
     DSV_ENCODER *e = &b->enc[s];
-    uint8_t *tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
     int t;
     (void)tid;
     for (t = 0; t < b->nf_cur; t++) {
         pic_t *pc = &c->pics[s * F + t];
-        bitw w;
         if (pc->has_ref) {
             int nintra = 0, i;
             int x0 = 0, x1 = 0, y0 = 0, y1 = 0;           /* full-pel reach of the inter blocks' vectors */
@@ -450,6 +460,21 @@ static void side_stream(void *ctx, int s, int tid)
             if (nintra * 100 / nblk > e->intra_pct_thresh) { pc->has_ref = 0; pc->forced_intra = 1; }
         }
         pc->isP = pc->has_ref;
+        stability_update(e, pc, nblk);
+        if (pc->isP) e->refresh_ctr++;               /* dsv_enc dsv_encoder.c:812-814 */
+    }
+}
+static void prefix_stream(void *ctx, int s, int tid)
+{
+    side_ctx *c = (side_ctx *)ctx;
+    dsv1_batch *b = c->b;
+    const int F = b->F, nblk = b->nblk;
+    uint8_t *tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
+    int t;
+    (void)tid;
+    for (t = 0; t < b->nf_cur; t++) {
+        pic_t *pc = &c->pics[s * F + t];
+        bitw w;
         memset(pc->prefix, 0, (size_t)b->prefix_cap);
         bw_init(&w, pc->prefix);
         write_pkt_hdr(&w, DSV_PT_PIC | (pc->is_ref << 1) | pc->has_ref);
@@ -459,8 +484,7 @@ static void side_stream(void *ctx, int s, int tid)
         bw_ueg(&w, (unsigned)b->g.blk_w >> 2);
         bw_ueg(&w, (unsigned)b->g.blk_h >> 2);
         bw_align(&w);
-        stability_pass(e, pc, nblk, &w, tmp);
-        if (pc->isP) e->refresh_ctr++;               /* dsv_enc dsv_encoder.c:812-814 */
+        stability_write(pc, nblk, &w, tmp);
         if (pc->has_ref) {
             bw_align(&w);
             motion_pass(b, pc, &w, tmp);
@@ -618,7 +642,10 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     /* 5. residual coding, frame step by frame step across all streams */
     {
         const int serial = e0->rc_mode != DSV_RATE_CONTROL_CRF;
+        side_ctx sc_;
+        sc_.b = b; sc_.pics = pics;
         if (serial && !abr_out) return DSVG_ERR_ARG;
+        if (serial) dsv1_par_for(S, prefix_stream, &sc_);      /* ABR assembles every picture as soon as it is coded */
         for (t = 0; t < nf; t++) {
             for (s = 0; s < S; s++) {
                 pic_t *pc = &pics[s * F + t];
@@ -656,10 +683,13 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
             }
         }
         if (!serial && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
+        HP_MARK(HP_ENQUEUE);
+        /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
+        if (!serial) dsv1_par_for(S, prefix_stream, &sc_);
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
         b->nf_pending[par] = nf;
     }
-    HP_MARK(HP_ENQUEUE);
+    HP_MARK(HP_PREFIX);
     hp_batches++;
     b->gcount += (unsigned)nf;
     b->parity ^= 1;
