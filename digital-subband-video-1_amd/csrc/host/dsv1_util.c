@@ -348,7 +348,7 @@ void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx)
 {
     const int nthr = par_threads(S);
     int i;
-    if (nthr <= 1 || S <= 1) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }
+    if (nthr <= 1 || S < 4) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }     /* (a wake-up costs ~30 us: ABR codes one picture of a stream or two per call) */
     pthread_mutex_lock(&g_pool.call);
     pthread_mutex_lock(&g_pool.mu);
     while (g_pool.started < nthr - 1) {                 /* workers are created on first need and never leave */
