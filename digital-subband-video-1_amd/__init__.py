@@ -293,9 +293,13 @@ class DecBatch:
         m = Meta()
         m.width, m.height, m.subsamp = w, h, fmt
         _chk(self.L.dsv1_decbatch_open(_C.byref(self.h), device, _C.byref(m), nstreams), "dsv1_decbatch_open")
-        self.ctx = self.L.dsv1_decbatch_ctx(self.h)
         self.frame_bytes = w * h + 2 * _chroma_size(w, h, fmt)
         self._dev = None
+
+    @property
+    def ctx(self):
+        """the device context (not cached: the batch builds a new one when its streams announce another block size)"""
+        return self.L.dsv1_decbatch_ctx(self.h)
 
     def decode(self, packets, out=None, on_device=False):
         """packets: one bytes object per stream.  Host output: returns (frames [nstreams][frame_bytes] uint8, status,

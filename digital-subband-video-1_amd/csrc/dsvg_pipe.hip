@@ -202,9 +202,20 @@ template <typename T> static int hmalloc(T **p, size_t n)
     return DSVG_OK;
 }
 
+extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int height, int subsamp,
+                                   int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots, int blk_w, int blk_h);
 extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsamp,
                                int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots)
 {
+    return dsvg_ctx_create_blk(out, device, width, height, subsamp, pyramid_levels, n_src_slots, n_recon_slots, max_jobs, out_slots, 0, 0);
+}
+extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int height, int subsamp,
+                                   int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots, int blk_w, int blk_h)
+{
+    if ((blk_w || blk_h) && (blk_w < 16 || blk_w > 64 || blk_h < 16 || blk_h > 64 || (blk_w & 3) || (blk_h & 3))) {
+        dsvg_set_error("block size %dx%d: multiples of 4 in 16..64 (dsv_decoder.c:351-356)", blk_w, blk_h);
+        return DSVG_ERR_ARG;
+    }
     if (out_slots < max_jobs) out_slots = max_jobs;
     if (!out || width < 32 || height < 32 || n_src_slots < 1 || n_recon_slots < 1 || max_jobs < 1) {
         dsvg_set_error("bad ctx_create arguments");
@@ -220,6 +231,10 @@ extern "C" int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height
     c->n_src = n_src_slots; c->n_recon = n_recon_slots; c->max_jobs = max_jobs; c->out_slots = out_slots;
     c->nwin = (out_slots + max_jobs - 1) / max_jobs + 1;
     block_geometry(width, height, &c->bw, &c->bh, &c->nbh, &c->nbv);
+    if (blk_w) {                                            // a decoder: the block size its stream announces
+        c->bw = blk_w; c->bh = blk_h;
+        c->nbh = (width + blk_w - 1) / blk_w; c->nbv = (height + blk_h - 1) / blk_h;
+    }
     c->nblk = c->nbh * c->nbv;
     c->levels = pyramid_levels > 0 ? std::min(pyramid_levels, DSVG_MAX_PYRAMID) : auto_pyramid_levels(width, height, c->nbh, c->nbv);
     make_frame_layout(c->L[0], subsamp, width, height);
@@ -384,6 +399,7 @@ extern "C" int dsvg_ctx_geom(const dsvg_ctx *c, dsvg_geom *g)
     g->pyramid_levels = c->levels;
     g->frame_bytes = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
     for (int p = 0; p < 3; p++) g->plane_out_cap[p] = c->bits_cap[p];
+    g->frame_alloc_bytes = c->L[0].bytes;
     return DSVG_OK;
 }
 
@@ -1121,6 +1137,15 @@ extern "C" int dsvg_download_recon_asis(dsvg_ctx *c, int recon_slot, uint8_t *ra
     HIPCHK(hipSetDevice(c->device));
     OPCHK(dsvg_ctx_sync(c));
     HIPCHK(hipMemcpy(raw_out, c->recon.p + (size_t)recon_slot * c->L[0].pitch, bytes, hipMemcpyDeviceToHost));
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_upload_recon_raw(dsvg_ctx *c, int recon_slot, const uint8_t *raw, size_t bytes)
+{
+    if (!c || !raw || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    OPCHK(dsvg_ctx_sync(c));
+    HIPCHK(hipMemcpy(c->recon.p + (size_t)recon_slot * c->L[0].pitch, raw, bytes, hipMemcpyHostToDevice));
     return DSVG_OK;
 }
 

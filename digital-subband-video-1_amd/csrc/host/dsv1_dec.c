@@ -6,6 +6,8 @@
  * Debug overlays (draw_info) are accepted and ignored. */
 #include <stdio.h>
 #include "dsv1_host.h"
+#define DSV_MIN_BLOCK_SIZE 16          /* dsv.h:50-51 */
+#define DSV_MAX_BLOCK_SIZE 64
 
 typedef struct {
     dsvg_ctx *ctx;
@@ -174,22 +176,40 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
     is_ref = (type & 0x6) == 0x6;
     if (parse_picture_head(&r, fn, &bw_, &bh_)) { dsv_buf_free(buffer); return DSV_DEC_ERROR; }
 
-    if (!d->ref) {
-        ss = (dec_sess *)calloc(1, sizeof(*ss));
-        if ((rc = dsvg_ctx_create(&ss->ctx, dsv1_device, m->width, m->height, m->subsamp, 1, 1, 3, 1, 1))) {
+    if (bw_ < DSV_MIN_BLOCK_SIZE || bh_ < DSV_MIN_BLOCK_SIZE || bw_ > DSV_MAX_BLOCK_SIZE || bh_ > DSV_MAX_BLOCK_SIZE) {
+        dsv1_log(1, "bad block sizes %dx%d", bw_, bh_);       /* dsv_decoder.c:354-358 */
+        dsv_buf_free(buffer);
+        return DSV_DEC_ERROR;
+    }
+    ss = (dec_sess *)d->ref;
+    if (!ss || bw_ != ss->g.blk_w || bh_ != ss->g.blk_h) {
+        /* the block size is the stream's to choose, per picture (dsv_decoder.c:335-360): a context for this one; the
+         * reference picture, if this picture needs one, moves over in the frame layout both contexts share */
+        dec_sess *ns = (dec_sess *)calloc(1, sizeof(*ns));
+        if (!ns || (rc = dsvg_ctx_create_blk(&ns->ctx, dsv1_device, m->width, m->height, m->subsamp, 1, 1, 3, 1, 1, bw_, bh_))) {
             dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
-            free(ss);
+            free(ns);
             dsv_buf_free(buffer);
             return DSV_DEC_ERROR;
         }
-        dsvg_ctx_geom(ss->ctx, &ss->g);
-        d->ref = ss;
-    }
-    ss = (dec_sess *)d->ref;
-    if (bw_ != ss->g.blk_w || bh_ != ss->g.blk_h) {
-        dsv1_log(1, "stream block size %dx%d differs from the encoder rule for this frame size", bw_, bh_);
-        dsv_buf_free(buffer);
-        return DSV_DEC_ERROR;
+        dsvg_ctx_geom(ns->ctx, &ns->g);
+        if (ss) {
+            if (ss->have_ref) {
+                const size_t nb = ss->g.frame_alloc_bytes;
+                uint8_t *raw = (uint8_t *)malloc(nb);
+                if (!raw || dsvg_download_recon_raw(ss->ctx, ss->rpar, raw, nb) || dsvg_upload_recon_raw(ns->ctx, 0, raw, nb)) {
+                    dsv1_log(1, "reference picture could not be carried over: %s", dsvg_last_error());
+                    free(raw); dsvg_ctx_destroy(ns->ctx); free(ns);
+                    dsv_buf_free(buffer);
+                    return DSV_DEC_ERROR;
+                }
+                free(raw);
+                ns->have_ref = 1; ns->rpar = 0;
+            }
+            dsvg_ctx_destroy(ss->ctx);
+            free(ss);
+        }
+        d->ref = ss = ns;
     }
     nblk = ss->g.nblocks_h * ss->g.nblocks_v;
     stable = (unsigned char *)calloc((size_t)nblk, 1);
@@ -235,7 +255,7 @@ struct dsv1_decbatch {
     dsvg_ctx *ctx;
     dsvg_geom g;
     DSV_META meta;
-    int nstreams, nblk;
+    int nstreams, nblk, device;
     unsigned char *have_ref;         /* [nstreams] */
     unsigned char *rpar;             /* [nstreams] which of the stream's two reference slots holds its current reference */
     unsigned char *stable;           /* [nstreams][nblk] */
@@ -263,6 +283,7 @@ int dsv1_decbatch_open(dsv1_decbatch **out, int device, const DSV_META *meta, in
     if (!d) return DSVG_ERR_ARG;
     d->meta = *meta;
     d->nstreams = nstreams;
+    d->device = device;
     /* stream s keeps its reference pictures alternately in reconstruction slots s and nstreams + s (ping-pong: a P picture's
      * prediction is written straight into its own slot); non-reference pictures go to slot 2 * nstreams + s */
     if ((rc = dsvg_ctx_create(&d->ctx, device, meta->width, meta->height, meta->subsamp, 1, 1, 3 * nstreams, nstreams, nstreams))) {
@@ -309,7 +330,8 @@ static void parse_stream(void *vp, int s, int tid)
     is_ref = (type & 0x6) == 0x6;
     if (parse_picture_head(&r, &pc->fnum[s], &bw_, &bh_)) return;
     if (bw_ != d->g.blk_w || bh_ != d->g.blk_h) {
-        dsv1_log(1, "stream %d: block size %dx%d differs from the encoder rule for this frame size", s, bw_, bh_);
+        /* (the batch has ONE geometry: dsv1_decbatch_decode follows the streams' block size while no stream holds a reference) */
+        dsv1_log(1, "stream %d: block size %dx%d, the batch decodes %dx%d", s, bw_, bh_, d->g.blk_w, d->g.blk_h);
         return;
     }
     if (parse_picture_body(&r, pc->packets[s].data, pc->packets[s].len, &d->g, has_ref, d->stable + (size_t)s * d->nblk, d->mvs + (size_t)s * d->nblk, job)) return;
@@ -329,6 +351,33 @@ int dsv1_decbatch_decode(dsv1_decbatch *d, const DSV_BUF *packets, void *yuv_out
     parse_ctx pc;
     if (!d || !packets || !yuv_out || !status || !fnum) return DSVG_ERR_ARG;
     if (out_pitch == 0) out_pitch = d->g.frame_bytes;
+    {   /* The block size is the streams' to choose (dsv_decoder.c:335-360); the batch shares one context, so it follows the
+         * first picture packet of a call as long as no stream holds a reference picture (i.e. at the streams' start or where
+         * every stream restarts with an I picture); a change in mid-GOP is an error of that stream (parse_stream). */
+        int any_ref = 0;
+        for (s = 0; s < d->nstreams; s++) any_ref |= d->have_ref[s];
+        for (s = 0; s < d->nstreams && !any_ref; s++) {
+            bitw r;
+            int type, bw_, bh_;
+            DSV_FNUM f_;
+            if (!packets[s].data || parse_packet_header(&r, packets[s].data, packets[s].len, &type) || !(type & DSV_PT_PIC)) continue;
+            if (parse_picture_head(&r, &f_, &bw_, &bh_)) continue;
+            if ((bw_ != d->g.blk_w || bh_ != d->g.blk_h) && bw_ >= DSV_MIN_BLOCK_SIZE && bh_ >= DSV_MIN_BLOCK_SIZE &&
+                bw_ <= DSV_MAX_BLOCK_SIZE && bh_ <= DSV_MAX_BLOCK_SIZE) {
+                dsvg_ctx *nc = NULL;
+                if ((rc = dsvg_ctx_create_blk(&nc, d->device, d->meta.width, d->meta.height, d->meta.subsamp, 1, 1, 3 * d->nstreams, d->nstreams,
+                                              d->nstreams, bw_, bh_))) return rc;
+                dsvg_ctx_destroy(d->ctx);
+                d->ctx = nc;
+                dsvg_ctx_geom(d->ctx, &d->g);
+                d->nblk = d->g.nblocks_h * d->g.nblocks_v;
+                free(d->stable); free(d->mvs);
+                d->stable = (unsigned char *)calloc((size_t)d->nstreams * d->nblk, 1);
+                d->mvs = (DSV_MV *)calloc((size_t)d->nstreams * d->nblk, sizeof(DSV_MV));
+            }
+            break;
+        }
+    }
     pc.d = d; pc.packets = packets; pc.status = status; pc.fnum = fnum;
     dsv1_par_for(d->nstreams, parse_stream, &pc);
     for (s = 0; s < d->nstreams; s++)

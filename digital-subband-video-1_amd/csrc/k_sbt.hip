@@ -1826,11 +1826,16 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 }
 
 
+#ifdef INV_P_TILE_W8
+#define INV_P_TILE_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#else
+#define INV_P_TILE_ATTR
+#endif
 // The fast body as a kernel of its own, for the tiles that take it (launch_inv_sbt: the interior of the tile grid of sparse
 // P pictures; k_inv_haar_tile gets the right / bottom strips): register allocation and LDS are then the fast body's, not
 // the maximum over the general body as well.
 template <bool FILT>
-__global__ __launch_bounds__(256) void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     __shared__ int A3[A3H * A3W];
     __shared__ int A2[A2H * A2W];

@@ -188,7 +188,8 @@ int  dsv1_decbatch_open(dsv1_decbatch **out, int device, const DSV_META *meta, i
 int  dsv1_decbatch_decode(dsv1_decbatch *d, const DSV_BUF *packets, void *yuv_out, size_t out_pitch, int out_on_device,
                           int *status, DSV_FNUM *fnum);
 void dsv1_decbatch_close(dsv1_decbatch *d);
-void *dsv1_decbatch_ctx(dsv1_decbatch *d);
+void *dsv1_decbatch_ctx(dsv1_decbatch *d);      /* (ask again after every decode call: the batch builds a new context when its streams
+                                                  * announce another block size while none of them holds a reference picture) */
 
 #ifdef __cplusplus
 }

@@ -96,6 +96,7 @@ typedef struct {
     int pyramid_levels;                       /* dsv_encoder.c:602-613 (after auto) */
     size_t frame_bytes;                       /* tightly packed planar input frame */
     size_t plane_out_cap[3];                  /* capacity of one packed plane payload */
+    size_t frame_alloc_bytes;                 /* one frame in the reference layout, borders included (dsvg_download_recon_raw) */
 } dsvg_geom;
 
 /* n_src_slots source frames (padded + pyramid) and n_recon_slots reconstructions stay resident;
@@ -105,6 +106,10 @@ typedef struct {
  * largest number of frame pairs one dsvg_analyse call may carry. */
 int dsvg_ctx_create(dsvg_ctx **out, int device, int width, int height, int subsamp,
                     int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots);
+/* the same with the block size given (0, 0 = the encoder's rule for the frame size, dsv_encoder.c:557-592): decoders take it
+ * from their stream (dsv_decoder.c:335-360); multiples of 4 in 16..64 */
+int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int height, int subsamp,
+                        int pyramid_levels, int n_src_slots, int n_recon_slots, int max_jobs, int out_slots, int blk_w, int blk_h);
 void dsvg_ctx_destroy(dsvg_ctx *ctx);
 int dsvg_ctx_geom(const dsvg_ctx *ctx, dsvg_geom *g);
 int dsvg_ctx_sync(dsvg_ctx *ctx);
@@ -211,6 +216,9 @@ int dsvg_download_recon_raw(dsvg_ctx *ctx, int recon_slot, uint8_t *raw_out, siz
 int dsvg_recon_border(dsvg_ctx *ctx, int recon_slot, short ext_out[8]);
 int dsvg_download_recon_asis(dsvg_ctx *ctx, int recon_slot, uint8_t *raw_out, size_t bytes);
 int dsvg_extend_recon(dsvg_ctx *ctx, int recon_slot);
+/* a frame allocation in the reference layout (as dsvg_download_recon_raw returns it) into a reconstruction slot: how a decoder
+ * carries its reference picture over when the stream changes its block size and a new context is needed.  Syncs. */
+int dsvg_upload_recon_raw(dsvg_ctx *ctx, int recon_slot, const uint8_t *raw, size_t bytes);
 /* n reconstruction slots -> tightly packed planar frames, frame i at yuv_out + i*out_pitch.  Device output: enqueued
  * on the pipeline stream, no sync (dsvg_ctx_sync before reading it).  Host output: copied back and synchronised. */
 int dsvg_pack_recons(dsvg_ctx *ctx, int n, const int *recon_slots, void *yuv_out, size_t out_pitch, int out_on_device);

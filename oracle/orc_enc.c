@@ -17,6 +17,7 @@
  */
 #include <limits.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <string.h>
 #include "orc.h"
 
@@ -321,6 +322,14 @@ size_t orc_enc_frame(orc_encoder *e, const uint8_t *yuv, uint8_t **out, size_t *
     prm.vidmeta = &e->c.meta;
     prm.blk_w = block_dim(w);
     prm.blk_h = block_dim(h);
+    {   /* test vectors for decoders: streams whose block size is not the encoder's rule (the reference decoder takes it from
+         * the packet, dsv_decoder.c:335-360).  ORC_BLK_OVERRIDE="WxH", multiples of 4 in 16..64 */
+        const char *ov = getenv("ORC_BLK_OVERRIDE");
+        int ow = 0, oh = 0;
+        if (ov && sscanf(ov, "%dx%d", &ow, &oh) == 2 && ow >= 16 && ow <= 64 && oh >= 16 && oh <= 64 && !(ow & 3) && !(oh & 3)) {
+            prm.blk_w = ow; prm.blk_h = oh;
+        }
+    }
     prm.nblocks_h = (w + prm.blk_w - 1) / prm.blk_w;
     prm.nblocks_v = (h + prm.blk_h - 1) / prm.blk_h;
     e->nblk = prm.nblocks_h * prm.nblocks_v;

@@ -230,37 +230,45 @@ def test_gpu_decoder_1080p(pkg, orc, kw, n, style):
     _decode_and_compare(pkg, 1920, 1080, A.SUBSAMP_420, n, style, kw, 0xABD001 + n)
 
 
-def _decode_and_compare(pkg, w, h, fmt, n, style, kw, seed, check_recon=True):
+def product_decode(pkg, stream):
+    """the drop-in dsv_dec, packet by packet: list of decoded frames (packed planar)"""
     L = pkg.lib()
-    clip = A.gen_clip(w, h, fmt, seed, n, style=style)
-    stream, recs = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw), want_recon=True)
-    want = A.orc_decode(stream, w, h, fmt)
     L.dsv_alloc.restype = C.c_void_p
     L.dsv_dec.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint32)]
     L.dsv_frame_ref_dec.argtypes = [C.c_void_p]
     dec = Decoder()
     got = []
-    for p in A.split_packets(stream):
-        buf = pkg.Buf()
-        mem = L.dsv_alloc(len(p))
-        C.memmove(mem, p, len(p))
-        buf.data = C.cast(mem, C.POINTER(C.c_uint8))
-        buf.len = len(p)
-        frame = C.c_void_p(None)
-        fn = C.c_uint32(0)
-        rc = L.dsv_dec(C.byref(dec), C.byref(buf), C.byref(frame), C.byref(fn))
-        if rc == 0 and frame.value:
-            f = C.cast(frame, C.POINTER(A.Frame)).contents
-            planes = []
-            for c in range(3):
-                pl = f.planes[c]
-                arr = np.ctypeslib.as_array(pl.data, shape=(pl.h * pl.stride,))
-                planes.append(np.lib.stride_tricks.as_strided(arr, shape=(pl.h, pl.w), strides=(pl.stride, 1)).copy().reshape(-1))
-            got.append(np.concatenate(planes))
-            L.dsv_frame_ref_dec(frame)
-        elif rc == 1:
-            raise AssertionError("dsv_dec error: %s" % L.dsvg_last_error())
-    L.dsv_dec_free(C.byref(dec))
+    try:
+        for p in A.split_packets(stream):
+            buf = pkg.Buf()
+            mem = L.dsv_alloc(len(p))
+            C.memmove(mem, p, len(p))
+            buf.data = C.cast(mem, C.POINTER(C.c_uint8))
+            buf.len = len(p)
+            frame = C.c_void_p(None)
+            fn = C.c_uint32(0)
+            rc = L.dsv_dec(C.byref(dec), C.byref(buf), C.byref(frame), C.byref(fn))
+            if rc == 0 and frame.value:
+                f = C.cast(frame, C.POINTER(A.Frame)).contents
+                planes = []
+                for c in range(3):
+                    pl = f.planes[c]
+                    arr = np.ctypeslib.as_array(pl.data, shape=(pl.h * pl.stride,))
+                    planes.append(np.lib.stride_tricks.as_strided(arr, shape=(pl.h, pl.w), strides=(pl.stride, 1)).copy().reshape(-1))
+                got.append(np.concatenate(planes))
+                L.dsv_frame_ref_dec(frame)
+            elif rc == 1:
+                raise AssertionError("dsv_dec error: %s" % L.dsvg_last_error())
+    finally:
+        L.dsv_dec_free(C.byref(dec))
+    return got
+
+
+def _decode_and_compare(pkg, w, h, fmt, n, style, kw, seed, check_recon=True):
+    clip = A.gen_clip(w, h, fmt, seed, n, style=style)
+    stream, recs = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw), want_recon=True)
+    want = A.orc_decode(stream, w, h, fmt)
+    got = product_decode(pkg, stream)
     assert len(got) == len(want) == n
     for t in range(n):
         A.assert_same("decoded frame %d" % t, got[t], want[t])
