@@ -177,6 +177,7 @@ static void ctx_free(dsvg_ctx *c)
         if (c->ev_join[g]) (void)hipEventDestroy(c->ev_join[g]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    for (hipEvent_t e : c->ev_fetch) (void)hipEventDestroy(e);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
     if (c->st_c && !c->fetch_shared) (void)hipStreamDestroy(c->st_c);
     if (c->st_h) (void)hipStreamDestroy(c->st_h);
