@@ -286,12 +286,7 @@ static __device__ __forceinline__ void collect_round(CollectState &st, const int
     for (int j = 0; j < 8; j++) cnt += (v[j] != 0);
     const unsigned long long have = __ballot(cnt != 0);
     if (have == 0ull) return;                                 // wave-uniform: a round of zeros costs nothing more
-    int incl = cnt;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int nb = __shfl_up(incl, o);
-        if (lane >= o) incl += nb;
-    }
+    const int incl = (int)wave_scan_incl((unsigned)cnt);
     // this lane's last entry, for the lanes after it
     int lpos = -1, lval = 0;
 #pragma unroll
@@ -319,10 +314,10 @@ static __device__ __forceinline__ void collect_round(CollectState &st, const int
 #pragma unroll
         for (int j = 7; j >= 0; j--)
             if (v[j] != 0) fp = p0 + j;
-        st.first_pos = __shfl(fp, firstl);
+        st.first_pos = __builtin_amdgcn_readlane(fp, firstl);
     }
-    st.cpos = __shfl(lpos, lastl); st.cval = __shfl(lval, lastl);
-    st.run += __shfl(incl, 63);
+    st.cpos = __builtin_amdgcn_readlane(lpos, lastl); st.cval = __builtin_amdgcn_readlane(lval, lastl);
+    st.run += __builtin_amdgcn_readlane(incl, 63);
 }
 static __device__ __forceinline__ void collect_finish(const JobDev &jb, int c, int chunk, int lane, CollectState &st)
 {
