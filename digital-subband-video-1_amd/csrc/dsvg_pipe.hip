@@ -945,7 +945,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             const int d0 = base + t * njobs + k0;
             const int nI = std::min(std::max(nIs[t] - k0, 0), n);                       // I jobs among them come first
             const JobDev *jd = c->jobs_d + d0;
-            const int fz = c->llq ? 2 : 1;                                              // fused quantiser (2: the LL region's too)
+            const int fz = c->llq ? 4 : 3;                                              // fused quantiser (4: the LL region's too); levels 4..5 launched once below
             if (nI > 0) {
                 launch_fwd_sbt(st, jd, nI, c->G, 0, 1, 0, 1, &c->prof, 0, fz);
                 launch_fwd_sbt(st, jd, nI, c->G, 1, 2, 0, 1, &c->prof, 0, fz);
@@ -968,6 +968,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             // levels >= 6 in LDS; the LL quantiser (inside the tail kernel and k_fwd_haar_mid<4> when llq, else k_hz_quant<true>);
             // then the reconstruction (P pictures: straight from the symbol planes), then the entropy stage:
             // k_hz_collect* is the LAST reader of the sparse symbol planes and clears what it reads
+            launch_fwd_mid4(st, jd, n, c->G, 0, 3, c->llq, &c->prof);                  // levels 4..5 of all planes, I and P jobs alike
             if (c->llq) launch_tail_q(st, jd, n, c->G, 0, 3, &c->prof);
             else {
                 launch_sbt_tail(st, jd, n, c->G, 0, 3, 0, &c->prof);

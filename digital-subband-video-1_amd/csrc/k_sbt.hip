@@ -2382,13 +2382,29 @@ bool mc_fusable(const McGeo &MG)
     return (MG.blk_w >> MG.hs) % 8 == 0 && (MG.blk_h >> MG.vs) % 8 == 0 && MG.blk_w % 8 == 0 && MG.blk_h % 8 == 0;
 }
 
+// levels 4..5 (LL3 -> LL5) of planes [c0, c0+npl) of njobs jobs in one launch (the grid is sized for the largest plane; the
+// threads of a smaller plane beyond its band leave at once); llq: with the LL quantiser
+void launch_fwd_mid4(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, bool llq, Prof *pf)
+{
+    int w5 = 1, h5 = 1;
+    double s3 = 0;
+    for (int c = c0; c < c0 + npl; c++) {
+        w5 = std::max(w5, G.g[c].w5); h5 = std::max(h5, G.g[c].h5);
+        s3 += (double)G.g[c].w3 * G.g[c].h3 * njobs;
+    }
+    PB(KID_FWD_HAAR_MID4, s3 * 8.0);
+    if (llq) hipLaunchKernelGGL((k_fwd_haar_mid<4, false, true>), grid3(w5, h5, njobs * npl), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    else     hipLaunchKernelGGL((k_fwd_haar_mid<4, false>), grid3(w5, h5, njobs * npl), dim3(64, 4), 0, st, jobs, G, c0, npl);
+    PE();
+}
+
 void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP,
                     int from_src, Prof *pf, int with_tail, int fused, const McGeo *mc, const DMV *mvs0, int general_whole)
 {
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
-    const bool llq = fused >= 2;                     // the LL quantiser in k_fwd_haar_mid<4> (JobDev.llq set by the caller)
+    const bool llq = fused == 2 || fused == 4;       // the LL quantiser in k_fwd_haar_mid<4> (JobDev.llq set by the caller)
     if (isP && fused && mc) {
         // motion compensation inside the transform: reference + source in, prediction + symbols out
         // two launches over the same grid: the lean kernel codes the common patches (few registers, no edge logic: it runs
@@ -2450,11 +2466,9 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         else       hipLaunchKernelGGL((k_fwd_haar_mid<2, false>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
         PE();
     }
-    // levels 4..5 (LL3 -> LL5) for every picture type
-    PB(KID_FWD_HAAR_MID4, s3 * 8.0);
-    if (llq) hipLaunchKernelGGL((k_fwd_haar_mid<4, false, true>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
-    else     hipLaunchKernelGGL((k_fwd_haar_mid<4, false>), grid3(g.w5, g.h5, nz), dim3(64, 4), 0, st, jobs, G, c0, npl);
-    PE();
+    // levels 4..5 (LL3 -> LL5) for every picture type (fused >= 3: the caller launches them once for all planes and jobs
+    // of the frame step, launch_fwd_mid4)
+    if (fused < 3) launch_fwd_mid4(st, jobs, njobs, G, c0, npl, llq, pf);
     if (with_tail) {
         PB(KID_FWD_TAIL, (double)g.w5 * g.h5 * nz * 8.0);
         hipLaunchKernelGGL(k_fwd_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w5 * g.h5 * 4, st, jobs, G, c0, npl);
