@@ -320,6 +320,13 @@ static struct {
     int active;                     /* workers still inside the current job */
 } g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, NULL, NULL, 0, 0, 0};
 
+/* a forked child has none of the workers: it starts its own on first need */
+static void pool_after_fork_child(void)
+{
+    pthread_mutex_init(&g_pool.mu, NULL); pthread_mutex_init(&g_pool.call, NULL);
+    pthread_cond_init(&g_pool.go, NULL); pthread_cond_init(&g_pool.done, NULL);
+    g_pool.started = 0; g_pool.nworkers = 0; g_pool.active = 0; g_pool.gen = 0;
+}
 static void pool_run_items(int tid)
 {
     for (;;) {
@@ -351,6 +358,10 @@ void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx)
     if (nthr <= 1 || S < 4) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }     /* (a wake-up costs ~30 us: ABR codes one picture of a stream or two per call) */
     pthread_mutex_lock(&g_pool.call);
     pthread_mutex_lock(&g_pool.mu);
+    {
+        static int atfork_set = 0;
+        if (!atfork_set) { atfork_set = 1; pthread_atfork(NULL, NULL, pool_after_fork_child); }
+    }
     while (g_pool.started < nthr - 1) {                 /* workers are created on first need and never leave */
         pthread_t th;
         pthread_attr_t at;
