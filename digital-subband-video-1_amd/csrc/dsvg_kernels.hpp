@@ -53,12 +53,13 @@ void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, in
 // k_frame.hip
 int  unpack_fuses_level1(const FrameLayout &L);
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr,
-                   uint8_t *slab1 = nullptr, const FrameLayout *L1 = nullptr, bool sides = false);
+                   uint8_t *slab1 = nullptr, const FrameLayout *L1 = nullptr, bool sides = false, bool sides1 = false);
 bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *slab, const FrameLayout &L);
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);
 void launch_pack_n(hipStream_t st, uint8_t *yuv, size_t out_pitch, const uint8_t *slab, const FrameLayout &L, const int *slot_tab, int n, Prof *pf = nullptr);
 void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int first, int n, int nplanes, const int *slot_tab, Prof *pf = nullptr, const JobDev *jobs = nullptr, bool tb_only = false);
-void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr);
+void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr, bool sides = false);
+bool level_sides_ok(const uint8_t *slab, const FrameLayout &L);
 void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums, Prof *pf = nullptr, const int *slot_tab = nullptr);
 void launch_frame_add(hipStream_t st, uint8_t *dst, const FrameLayout &DL, const uint8_t *src, const FrameLayout &SL);
 // k_hme.hip

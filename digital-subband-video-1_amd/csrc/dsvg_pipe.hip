@@ -548,13 +548,19 @@ static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, si
     // the first pyramid level comes out of the unpack kernel when the luma plane allows it (one read of the frame less)
     const bool fuse1 = with_pyramid && c->levels >= 1 && unpack_fuses_level1(c->L[0]);
     const bool sides = unpack_writes_sides(dsrc, pitch, c->src[0].p, c->L[0]) && !getenv("DSV1_NO_UNPACK_SIDES");
-    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides);
+    // the pyramid levels whose width allows it get their side borders from the kernel that writes their rows as well
+    static const bool no_lsides = getenv("DSV1_NO_LEVEL_SIDES") != nullptr;
+    const bool sides1 = fuse1 && sides && !no_lsides && level_sides_ok(c->src[1].p, c->L[1]);
+    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1);
     launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
-            if (!(l == 1 && fuse1))
-                launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d);
-            launch_extend(c->st_a, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof);
+            bool ls = (l == 1 && fuse1) ? sides1 : false;
+            if (!(l == 1 && fuse1)) {
+                ls = !no_lsides && level_sides_ok(c->src[l].p, c->L[l]);
+                launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d, ls);
+            }
+            launch_extend(c->st_a, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof, nullptr, ls);
         }
         if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st_a));
         else       HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st_a));

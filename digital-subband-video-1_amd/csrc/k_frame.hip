@@ -58,6 +58,12 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
                 o[k >> 2] |= ((sum + 2) >> 2) << (8 * (k & 3));
             }
             *reinterpret_cast<uint2 *>(dst1 + (size_t)y2 * L1.stride[0] + 8 * x) = make_uint2(o[0], o[1]);
+            if (sides > 1 && (x == 0 || x == nv - 1)) {          // (sides & 2: the first pyramid level's rows get theirs too)
+                const unsigned v = (x == 0 ? (o[0] & 0xff) : (o[1] >> 24)) * 0x01010101u;
+                uint4 *b = reinterpret_cast<uint4 *>(dst1 + (size_t)y2 * L1.stride[0] + (x == 0 ? -DSVG_BORDER : L1.w[0]));
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) b[k] = make_uint4(v, v, v, v);
+            }
         }
         return;
     }
@@ -236,8 +242,10 @@ __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, Fr
 // 2x2 box downsample of the luma plane: (p1+p2+p3+p4+2)>>2 (frame.c:240-261)
 __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab, FrameLayout SL,
                                               uint8_t *__restrict__ dslab, FrameLayout DL, int first,
-                                              const int *__restrict__ slot_tab)
+                                              const int *__restrict__ slot_tab, int sides)
 {
+    // sides: the level's width is a multiple of 16: the threads of a row's first and last pixels also write its 64-byte side
+    // borders (whole 128-byte lines; k_extend16 then adds the rows above and below only)
     const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
     const uint8_t *sp = sslab + (size_t)f * SL.pitch + SL.off[0];
     uint8_t *dp = dslab + (size_t)f * DL.pitch + DL.off[0];
@@ -262,6 +270,18 @@ __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab,
         else
             for (int k = 0; k < 4; k++)
                 if (x4 + k < dw) d[k] = (uint8_t)(out >> (8 * k));
+        if (sides && (x4 == 0 || x4 + 4 == dw)) {
+            const unsigned v = (x4 == 0 ? (out & 0xff) : (out >> 24)) * 0x01010101u;
+            uint4 *b = reinterpret_cast<uint4 *>(dp + (size_t)y * DL.stride[0] + (x4 == 0 ? -DSVG_BORDER : dw));
+#pragma unroll
+            for (int k = 0; k < DSVG_BORDER / 16; k++) b[k] = make_uint4(v, v, v, v);
+            if (dw == 4) {                                           // (one thread holds both ends)
+                const unsigned v2 = (out >> 24) * 0x01010101u;
+                uint4 *b2 = reinterpret_cast<uint4 *>(dp + (size_t)y * DL.stride[0] + dw);
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) b2[k] = make_uint4(v2, v2, v2, v2);
+            }
+        }
     }
 }
 
@@ -311,12 +331,12 @@ bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *sl
     return ok;
 }
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
-                   uint8_t *slab1, const FrameLayout *L1, bool sides)
+                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1)
 {
     FrameLayout dummy = L;
     if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0));
     hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
-                       slab1, L1 ? *L1 : dummy, sides ? 1 : 0);
+                       slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0));
     if (pf) pf->end(st);
 }
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)
@@ -344,10 +364,15 @@ void launch_extend(hipStream_t st, uint8_t *slab, const FrameLayout &L, int firs
     else     hipLaunchKernelGGL(k_extend, dim3(nblk(items, 256), nplanes, n), dim3(256), 0, st, slab, L, first, nplanes, slot_tab);
     if (pf) pf->end(st);
 }
-void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf, const int *slot_tab)
+// can the kernel that writes a level's luma rows (k_ds2x, or k_unpack for the first level) write their side borders too?
+bool level_sides_ok(const uint8_t *slab, const FrameLayout &L)
+{
+    return (L.w[0] % 16) == 0 && (L.stride[0] % 16) == 0 && (L.off[0] % 16) == 0 && (L.pitch % 16) == 0 && ((uintptr_t)slab % 16) == 0;
+}
+void launch_ds2x(hipStream_t st, const uint8_t *sslab, const FrameLayout &SL, uint8_t *dslab, const FrameLayout &DL, int first, int n, Prof *pf, const int *slot_tab, bool sides)
 {
     if (pf) pf->begin(st, KID_DS2X, 5.0 * n * (double)DL.w[0] * DL.h[0]);
-    hipLaunchKernelGGL(k_ds2x, dim3(nblk((long)DL.w[0] * DL.h[0] / 4, 512), 1, n), dim3(256), 0, st, sslab, SL, dslab, DL, first, slot_tab);
+    hipLaunchKernelGGL(k_ds2x, dim3(nblk((long)DL.w[0] * DL.h[0] / 4, 512), 1, n), dim3(256), 0, st, sslab, SL, dslab, DL, first, slot_tab, sides ? 1 : 0);
     if (pf) pf->end(st);
 }
 void launch_luma_sum(hipStream_t st, const uint8_t *slab, const FrameLayout &L, int first, int n, unsigned *sums, Prof *pf, const int *slot_tab)
