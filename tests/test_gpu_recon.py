@@ -144,3 +144,36 @@ def test_zero_and_general_tiles_both_taken(pkg):
         else:
             # the I picture's quantisation error leaves a residual here and there
             assert st["zero_luma"] > st["general_luma"], st
+
+
+def test_renumbered_stream_gets_its_reference_border_back(pkg):
+    """The last reconstruction of a batch is coded without a border when the next frame number starts a GOP (border_hint).
+    If the caller renumbers the stream in between (dsv1_batch_set_fnum) so that the next picture is a P picture after all,
+    the session completes the border first (dsvg_extend_recon).  The oracle encoder, renumbered the same way, is the
+    reference; the pan clip's vectors point out of the picture."""
+    w, h, fmt, gop = 352, 288, A.SUBSAMP_420, 6
+    cli = dict(qp=85, gop=gop, rc_mode_cli=1, scd=0)
+    clip = A.gen_clip(w, h, fmt, 0x5E7F, 2 * gop, style=0)
+    # oracle: frames 0..5 numbered 0..5, then the numbering jumps back to 3: no GOP start at the seventh frame
+    Lo = A.load_orc()
+    cfg = A.orc_cfg(w, h, fmt, **cli)
+    e = Lo.orc_enc_open(C.byref(cfg))
+    out, n_, cap = C.c_void_p(None), C.c_size_t(0), C.c_size_t(0)
+    Lo.orc_enc_set_next_fnum(e, 0)
+    for t in range(2 * gop):
+        if t == gop:
+            Lo.orc_enc_set_next_fnum(e, 3)
+        Lo.orc_enc_frame(e, clip[t].ctypes.data, C.byref(out), C.byref(n_), C.byref(cap), None)
+    want = C.string_at(out.value, n_.value)
+    C.CDLL(None).free(out)
+    Lo.orc_enc_close(e)
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), 1, gop)
+    try:
+        got = b.encode(clip[:gop].reshape(1, gop, -1))[0]
+        b.set_fnum(0, 3)
+        got += b.encode(clip[gop:].reshape(1, gop, -1))[0]
+    finally:
+        b.close()
+    pk = A.split_packets(want)
+    assert sum(1 for p in pk if (p[5] & 4) and not (p[5] & 1)) == 2, "the test wants a P picture right after the renumbering"
+    assert got == want
