@@ -177,3 +177,39 @@ def test_renumbered_stream_gets_its_reference_border_back(pkg):
     pk = A.split_packets(want)
     assert sum(1 for p in pk if (p[5] & 4) and not (p[5] & 1)) == 2, "the test wants a P picture right after the renumbering"
     assert got == want
+
+
+@pytest.mark.parametrize("w,h,style", [(352, 288, 0), (704, 480, 2), (1920, 1080, 0)])
+def test_lazy_border_of_the_reference_inside_a_batch(pkg, w, h, style):
+    """Batches of two frames: the first reconstruction of a pair is read only by the second picture, so its border is written
+    as far as that picture's vectors reach (dsvg_recon_border) -- observed directly here in the slot the pair's first picture
+    was kept in: picture area and the vouched-for part of the border equal the oracle's recon_frame, and the extents are
+    smaller than the whole border somewhere (the mechanism is active)."""
+    fmt, n = A.SUBSAMP_420, 6
+    cli = dict(qp=85, gop=12, rc_mode_cli=1, scd=0)
+    clip = make_clip(w, h, fmt, 0x1A2B + w, n, style)
+    want_stream, want_rec = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli), want_recon=True, eos=False)
+    L = pkg.lib()
+    L.dsv1_batch_recon_slot.argtypes = [C.c_void_p, C.c_int]
+    L.dsvg_download_recon_asis.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_size_t]
+    L.dsvg_recon_border.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), 1, 2)
+    lazy = 0
+    try:
+        got_stream = b""
+        for t in range(0, n, 2):
+            got_stream += b.encode(clip[t:t + 2].reshape(1, 2, -1))[0]
+            last = L.dsv1_batch_recon_slot(b.h, 0)              # one stream, two slots: the pair's first picture sits in the other
+            first = 1 - last
+            want = expected_raw(w, h, fmt, want_rec[t])
+            got = np.zeros_like(want)
+            ext = (C.c_short * 8)()
+            assert L.dsvg_recon_border(b.ctx, first, ext) == 0
+            assert L.dsvg_download_recon_asis(b.ctx, first, got.ctypes.data, got.size) == 0, L.dsvg_last_error()
+            bad = np.nonzero((got != want) & border_mask(w, h, fmt, list(ext)))[0]
+            assert bad.size == 0, "frame %d: %d bytes differ inside the border %s, first at raw offset %d" % (t, bad.size, list(ext), int(bad[0]))
+            lazy += min(ext) < 64
+        assert got_stream == want_stream
+        assert lazy > 0, "no reconstruction had a partial border"
+    finally:
+        b.close()
