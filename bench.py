@@ -188,7 +188,7 @@ def decode_bench(pkg, A, dev, streams, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gops", type=int, default=160, help="closed GOPs per GPU per step (same box, round 2: 96: 131.9, 128: 135.3, 160: 139.0, 192: 142.2 Gpix/s -- "
                                                           "the per-step latency-bound kernels and host round trips amortise; 160 GOPs keep ~50 GB of HBM and 6 GB of host memory)")
