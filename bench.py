@@ -286,6 +286,8 @@ def main():
         w3, h3 = (W + 7) >> 3, (H + 7) >> 3
         ntx, nty = (w3 + 15) // 16, (h3 + 7) // 8
         fx = (w3 - 18) // 16 + 1 if w3 >= 18 else 0
+        if fx == ntx - 1 and w3 == 16 * ntx and W % 8 == 0:
+            fx += 1                                 # the last tile column ends with the band: the fast kernel's edge body takes it
         fy = (h3 - 10) // 8 + 1 if h3 >= 10 else 0
         ffast = (fx * fy) / float(ntx * nty)
         for kname, share in (("void k_inv_p_tile<true>", ffast), ("void k_inv_haar_tile<true, 0, true>", 1.0 - ffast)):

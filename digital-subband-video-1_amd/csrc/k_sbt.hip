@@ -1638,7 +1638,11 @@ static __device__ __forceinline__ void inv_l1_item(const unsigned *row, int WP, 
     }
 }
 
-template <bool FILT>
+// ER: the tile is the last of its tile row and ends exactly where the band ends (w3 a multiple of IT_TX, every cell of every
+// level complete: W a multiple of 8).  The cells right of it do not exist; what the reference reads as the "next LL" of the
+// last cell of a row is the first coefficient of the LH band of that row and level (sbt.c:463-527: the bands lie side by
+// side in its buffer) -- the threads that own the non-existent halo cells put exactly those values where the halo values go.
+template <bool FILT, bool ER = false>
 static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo &g, int c, int I0, int J0, int tid,
                                                   int *__restrict__ A3u, int *__restrict__ A2u, unsigned *__restrict__ A1p)
 {
@@ -1673,6 +1677,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     if (tid < A3H * A3W) {
         const unsigned ly = (utid * 205u) >> 12, lx = utid - ly * W3;
         const int cx = I0 - 2 + (int)lx, cy = J0 - 2 + (int)ly;
+        if (ER && cx >= w3) {
+            if (cx == w3 && cy >= 0) {                   // "next LL" of the row's last cell: LH3 of column 0, dequantised
+                const int f = ldu8(stable, flagidx(Q3, 0u, (unsigned)cy));
+                a3v = dq_lo24(lds16(sym, (unsigned)Q3.base0 + __umul24((unsigned)cy, (unsigned)Q3.sw)), max(Q3.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ));
+                nzv = ldu8(pfl, __umul24((unsigned)cy, (unsigned)w3));
+            }
+        } else
         if (cx >= 0 && cy >= 0) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)w3) + (unsigned)cx;
             a3v = dsvg_at(s3, o);
@@ -1687,6 +1698,14 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         ok3 = cx >= 0 && cy >= 0;
         // (fetching these symbols only for flagged patches, as level 1 does, was slower: 4.45 -> 4.70 ms per step -- the flag
         // load puts a second round trip in front of the first barrier, and these are 0.47 B/sample, not 1.5)
+        if (ER && ok3 && cx >= w3) {
+            // the non-existent cell right of the band: its two LL2 outputs are the LH2 values of column 0 of level-2 rows
+            // 2cy, 2cy+1 (s3lh / s3hl: the symbols, k3 / s3hh: their quantiser classes)
+            s3lh = lds16(sym, (unsigned)Q2.base0 + __umul24(2u * (unsigned)cy, (unsigned)Q2.sw));
+            s3hl = lds16(sym, (unsigned)Q2.base0 + __umul24(2u * (unsigned)cy + 1u, (unsigned)Q2.sw));
+            const int fa = ldu8(stable, flagidx(Q2, 0u, 2u * (unsigned)cy)), fb = ldu8(stable, flagidx(Q2, 0u, 2u * (unsigned)cy + 1u));
+            k3 = (fa & 2) ? 2 : (fa != 0); s3hh = (fb & 2) ? 2 : (fb != 0);
+        } else
         if (ok3) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)Q3.sw) + (unsigned)cx;
             s3lh = lds16(sym, (unsigned)Q3.base0 + o); s3hl = lds16(sym, (unsigned)Q3.base1 + o); s3hh = lds16(sym, (unsigned)Q3.base2 + o);
@@ -1704,6 +1723,15 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const int cx = 2 * I0 - 1 + (int)lx, cy = 2 * J0 - 1 + (int)ly;
         ok2[u] = i < (2 * IT_TY + 2) * (2 * IT_TX + 2) && cx >= 0 && cy >= 0;
         s2lh[u] = s2hl[u] = s2hh[u] = k2[u] = 0;
+        if (ER && ok2[u] && cx >= 2 * w3) {
+            // right of the band at level 2: the LL1 halo values are the LH1 values of column 0 of level-1 rows 2cy, 2cy+1
+            // (s2lh / s2hl: symbols, k2 / s2hh: their shifts)
+            s2lh[u] = lds16(sym, (unsigned)Q1.base0 + __umul24(2u * (unsigned)cy, (unsigned)Q1.sw));
+            s2hl[u] = lds16(sym, (unsigned)Q1.base0 + __umul24(2u * (unsigned)cy + 1u, (unsigned)Q1.sw));
+            const unsigned bya = __umul24(__umul24(2u * (unsigned)cy, (unsigned)Q1.dby) >> 14, (unsigned)nbh),
+                           byb = __umul24(__umul24(2u * (unsigned)cy + 1u, (unsigned)Q1.dby) >> 14, (unsigned)nbh);
+            k2[u] = ldu8(stable, bya) ? Q1.sh1 : Q1.sh0; s2hh[u] = ldu8(stable, byb) ? Q1.sh1 : Q1.sh0;
+        } else
         if (ok2[u]) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)Q2.sw) + (unsigned)cx;
             s2lh[u] = lds16(sym, (unsigned)Q2.base0 + o); s2hl[u] = lds16(sym, (unsigned)Q2.base1 + o); s2hh[u] = lds16(sym, (unsigned)Q2.base2 + o);
@@ -1765,6 +1793,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (c != 0) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
 
     // ---- level 3: cells I0-1 .. I0+TX (halo 1) -> LL2 values, scaled up, in A2u
+    if (ER && ok3 && I0 - 1 + lx3 >= w3) {
+        int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
+        d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> k3, HZ_MINQ))); d[1] = 0;
+        d[W2] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> s3hh, HZ_MINQ))); d[W2 + 1] = 0;
+    } else
     if (ok3) {
         const int *pA = A3u + (ly3 + 1) * W3 + lx3 + 1;
         const int LL = pA[0];
@@ -1790,6 +1823,12 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         if (!ok2[u]) continue;
         const unsigned i = (unsigned)tid + 256u * u;
         const int ly = (int)((i * 241u) >> 13), lx = (int)i - ly * (2 * IT_TX + 2);
+        if (ER && 2 * I0 - 1 + lx >= 2 * w3) {
+            unsigned *d = A1p + (2 * ly) * WP + lx;
+            d[0] = pk_i16((int)((unsigned)s2lh[u] << k2[u]), 0);
+            d[WP] = pk_i16((int)((unsigned)s2hl[u] << s2hh[u]), 0);
+            continue;
+        }
         const int *pA = A2u + (ly + 1) * W2 + lx + 1;
         const int LL = pA[0];
         int LH = 0, HL = 0, HH = 0;
@@ -1834,14 +1873,17 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 // The fast body as a kernel of its own, for the tiles that take it (launch_inv_sbt: the interior of the tile grid of sparse
 // P pictures; k_inv_haar_tile gets the right / bottom strips): register allocation and LDS are then the fast body's, not
 // the maximum over the general body as well.
+// er_col: the tile column that ends exactly where the band ends and takes the ER body (-1: none) -- in the same launch as the
+// interior tiles (as a launch of its own the column's 16 x 160 workgroups took as long as the general kernel's strip did)
 template <bool FILT>
-__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int er_col)
 {
     __shared__ int A3[A3H * A3W];
     __shared__ int A2[A2H * A2W];
     __shared__ unsigned A1p[(4 * IT_TY + 4) * (2 * IT_TX + 2)];
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
-    inv_p_fast<FILT>(jobs[job], G.g[c], c, (int)blockIdx.x * IT_TX, (int)blockIdx.y * IT_TY, threadIdx.x, A3, A2, A1p);
+    if ((int)blockIdx.x == er_col) inv_p_fast<FILT, true>(jobs[job], G.g[c], c, (int)blockIdx.x * IT_TX, (int)blockIdx.y * IT_TY, threadIdx.x, A3, A2, A1p);
+    else inv_p_fast<FILT, false>(jobs[job], G.g[c], c, (int)blockIdx.x * IT_TX, (int)blockIdx.y * IT_TY, threadIdx.x, A3, A2, A1p);
 }
 
 // MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
@@ -2552,17 +2594,21 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             // take the fast body as a kernel of its own, the general kernel the right and bottom strips
             const int fx = (patch_kernel && g.l1a && g.w3 >= IT_TX + 2) ? (g.w3 - IT_TX - 2) / IT_TX + 1 : 0;
             const int fy = (patch_kernel && g.l1a && g.h3 >= IT_TY + 2) ? (g.h3 - IT_TY - 2) / IT_TY + 1 : 0;
+            static const bool no_er = getenv("DSV1_NO_EDGE_TILES") != nullptr;
             if (fx > 0 && fy > 0) {
                 const double fsmp = 64.0 * fx * IT_TX * fy * IT_TY * nz;            // samples of the fast tiles
                 PB(filt ? KID_INV_P_TILE_F : KID_INV_P_TILE, fsmp * 2.5);
-                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), dim3(fx, fy, nz), dim3(256), 0, st, jobs, G, c0, npl);
-                else      hipLaunchKernelGGL((k_inv_p_tile<false>), dim3(fx, fy, nz), dim3(256), 0, st, jobs, G, c0, npl);
+                // the last tile column too, when it ends exactly where the band ends and every cell of every level is complete
+                const bool er = !no_er && fx == (int)tg.x - 1 && g.w3 == (int)tg.x * IT_TX && (g.W & 7) == 0;
+                const int fxg = er ? fx + 1 : fx;              // tile columns the fast kernel takes (rows [0, fy))
+                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), dim3(fxg, fy, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1);
+                else      hipLaunchKernelGGL((k_inv_p_tile<false>), dim3(fxg, fy, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1);
                 PE();
                 PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, (smp - fsmp) * 2.5);
-                const int nrest = ((int)tg.x - fx) * (int)tg.y + fx * ((int)tg.y - fy);      // right strip + bottom strip, one launch
+                const int nrest = ((int)tg.x - fxg) * (int)tg.y + fxg * ((int)tg.y - fy);      // right strip + bottom strip, one launch
                 if (nrest > 0) {
-                    if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fx, -fy - 1);
-                    else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fx, -fy - 1);
+                    if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fxg, -fy - 1);
+                    else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fxg, -fy - 1);
                 }
                 PE();
                 return;
