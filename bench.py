@@ -289,6 +289,8 @@ def main():
         if fx == ntx - 1 and w3 == 16 * ntx and W % 8 == 0:
             fx += 1                                 # the last tile column ends with the band: the fast kernel's edge body takes it
         fy = (h3 - 10) // 8 + 1 if h3 >= 10 else 0
+        if fy == nty - 1 and H % 8 == 0:
+            fy += 1                                 # ... and the last tile row
         ffast = (fx * fy) / float(ntx * nty)
         for kname, share in (("void k_inv_p_tile<true>", ffast), ("void k_inv_haar_tile<true, 0, true>", 1.0 - ffast)):
             tg, tz = tiles["general_luma"] * share, tiles["zero_luma"] * share

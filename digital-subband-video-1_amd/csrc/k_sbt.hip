@@ -1642,7 +1642,10 @@ static __device__ __forceinline__ void inv_l1_item(const unsigned *row, int WP, 
 // level complete: W a multiple of 8).  The cells right of it do not exist; what the reference reads as the "next LL" of the
 // last cell of a row is the first coefficient of the LH band of that row and level (sbt.c:463-527: the bands lie side by
 // side in its buffer) -- the threads that own the non-existent halo cells put exactly those values where the halo values go.
-template <bool FILT, bool ER = false>
+// EB: the tile lies in the last tile row, the band ends inside it or at its end (h3 - J0 <= IT_TY), every cell complete (H a
+// multiple of 8).  The same with rows: the "next LL" below a column's last cell is the first HL coefficient of that column
+// and level; the cell rows past the band's end are not loaded, computed or stored.
+template <bool FILT, bool ER = false, bool EB = false>
 static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo &g, int c, int I0, int J0, int tid,
                                                   int *__restrict__ A3u, int *__restrict__ A2u, unsigned *__restrict__ A1p)
 {
@@ -1652,7 +1655,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     const auto stable = dsvg_global(jb.stable);
     const auto pfl = dsvg_global(static_cast<const uint8_t *>(jb.pflag + g.s3off));
     const auto s3 = dsvg_global(static_cast<const int32_t *>(jb.s3 + g.s3off));
-    const int nbh = hp.nbh, w3 = g.w3, stride = g.pstride;
+    const int nbh = hp.nbh, w3 = g.w3, h3 = g.h3, stride = g.pstride;
     const QLevel Q3 = q_level<0>(hp), Q2 = q_level<1>(hp), Q1 = q_level<2>(hp);
     const auto pred = dsvg_global(static_cast<const uint8_t *>(jb.pred + g.poff));
     const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
@@ -1668,20 +1671,29 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     auto lds16 = [](auto base, unsigned idx) { return (int)dsvg_at(base, idx); };
     auto flagidx = [&](const QLevel &Q, unsigned cx, unsigned cy) { return __umul24(__umul24(cy, (unsigned)Q.dby) >> 14, (unsigned)nbh) + (__umul24(cx, (unsigned)Q.dbx) >> 14); };
     int pf1[2];
+    bool v1[2];                                         // the item's cell row exists (EB: the band may end inside the tile)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const unsigned it = utid + 256u * u, ly = it >> 4, gx = it & 15u;
-        pf1[u] = ldu8(pfl, __umul24((unsigned)J0 + (ly >> 2), (unsigned)w3) + (unsigned)I0 + gx);
+        v1[u] = !EB || J0 + (int)(ly >> 2) < h3;
+        pf1[u] = v1[u] ? ldu8(pfl, __umul24((unsigned)J0 + (ly >> 2), (unsigned)w3) + (unsigned)I0 + gx) : 0;
     }
     int a3v = 0, nzv = 0;
     if (tid < A3H * A3W) {
         const unsigned ly = (utid * 205u) >> 12, lx = utid - ly * W3;
         const int cx = I0 - 2 + (int)lx, cy = J0 - 2 + (int)ly;
         if (ER && cx >= w3) {
-            if (cx == w3 && cy >= 0) {                   // "next LL" of the row's last cell: LH3 of column 0, dequantised
+            if (cx == w3 && cy >= 0 && (!EB || cy < h3)) {      // "next LL" of the row's last cell: LH3 of column 0, dequantised
                 const int f = ldu8(stable, flagidx(Q3, 0u, (unsigned)cy));
                 a3v = dq_lo24(lds16(sym, (unsigned)Q3.base0 + __umul24((unsigned)cy, (unsigned)Q3.sw)), max(Q3.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ));
                 nzv = ldu8(pfl, __umul24((unsigned)cy, (unsigned)w3));
+            }
+        } else
+        if (EB && cy >= h3) {
+            if (cy == h3 && cx >= 0) {                   // below the column's last cell: HL3 of row 0, dequantised
+                const int f = ldu8(stable, flagidx(Q3, (unsigned)cx, 0u));
+                a3v = dq_lo24(lds16(sym, (unsigned)Q3.base1 + (unsigned)cx), max(Q3.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ));
+                nzv = ldu8(pfl, (unsigned)cx);
             }
         } else
         if (cx >= 0 && cy >= 0) {
@@ -1695,7 +1707,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     if (tid < (IT_TY + 2) * (IT_TX + 2)) {
         ly3 = (int)((utid * 57u) >> 10); lx3 = tid - ly3 * (IT_TX + 2);
         const int cx = I0 - 1 + lx3, cy = J0 - 1 + ly3;
-        ok3 = cx >= 0 && cy >= 0;
+        ok3 = cx >= 0 && cy >= 0 && (!EB || cy <= h3) && !(ER && EB && cx >= w3 && cy >= h3);
         // (fetching these symbols only for flagged patches, as level 1 does, was slower: 4.45 -> 4.70 ms per step -- the flag
         // load puts a second round trip in front of the first barrier, and these are 0.47 B/sample, not 1.5)
         if (ER && ok3 && cx >= w3) {
@@ -1704,6 +1716,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
             s3lh = lds16(sym, (unsigned)Q2.base0 + __umul24(2u * (unsigned)cy, (unsigned)Q2.sw));
             s3hl = lds16(sym, (unsigned)Q2.base0 + __umul24(2u * (unsigned)cy + 1u, (unsigned)Q2.sw));
             const int fa = ldu8(stable, flagidx(Q2, 0u, 2u * (unsigned)cy)), fb = ldu8(stable, flagidx(Q2, 0u, 2u * (unsigned)cy + 1u));
+            k3 = (fa & 2) ? 2 : (fa != 0); s3hh = (fb & 2) ? 2 : (fb != 0);
+        } else
+        if (EB && ok3 && cy >= h3) {
+            // the non-existent cell row below the band: its LL2 outputs are the HL2 values of row 0 of level-2 columns 2cx, 2cx+1
+            s3lh = lds16(sym, (unsigned)Q2.base1 + 2u * (unsigned)cx);
+            s3hl = lds16(sym, (unsigned)Q2.base1 + 2u * (unsigned)cx + 1u);
+            const int fa = ldu8(stable, flagidx(Q2, 2u * (unsigned)cx, 0u)), fb = ldu8(stable, flagidx(Q2, 2u * (unsigned)cx + 1u, 0u));
             k3 = (fa & 2) ? 2 : (fa != 0); s3hh = (fb & 2) ? 2 : (fb != 0);
         } else
         if (ok3) {
@@ -1721,7 +1740,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const unsigned i = utid + 256u * u;
         const unsigned ly = (i * 241u) >> 13, lx = i - ly * (2 * IT_TX + 2);
         const int cx = 2 * I0 - 1 + (int)lx, cy = 2 * J0 - 1 + (int)ly;
-        ok2[u] = i < (2 * IT_TY + 2) * (2 * IT_TX + 2) && cx >= 0 && cy >= 0;
+        ok2[u] = i < (2 * IT_TY + 2) * (2 * IT_TX + 2) && cx >= 0 && cy >= 0 && (!EB || cy <= 2 * h3) && !(ER && EB && cx >= 2 * w3 && cy >= 2 * h3);
         s2lh[u] = s2hl[u] = s2hh[u] = k2[u] = 0;
         if (ER && ok2[u] && cx >= 2 * w3) {
             // right of the band at level 2: the LL1 halo values are the LH1 values of column 0 of level-1 rows 2cy, 2cy+1
@@ -1731,6 +1750,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
             const unsigned bya = __umul24(__umul24(2u * (unsigned)cy, (unsigned)Q1.dby) >> 14, (unsigned)nbh),
                            byb = __umul24(__umul24(2u * (unsigned)cy + 1u, (unsigned)Q1.dby) >> 14, (unsigned)nbh);
             k2[u] = ldu8(stable, bya) ? Q1.sh1 : Q1.sh0; s2hh[u] = ldu8(stable, byb) ? Q1.sh1 : Q1.sh0;
+        } else
+        if (EB && ok2[u] && cy >= 2 * h3) {
+            // below the band at level 2: the LL1 halo values are the HL1 values of row 0 of level-1 columns 2cx, 2cx+1
+            s2lh[u] = lds16(sym, (unsigned)Q1.base1 + 2u * (unsigned)cx);
+            s2hl[u] = lds16(sym, (unsigned)Q1.base1 + 2u * (unsigned)cx + 1u);
+            k2[u] = ldu8(stable, __umul24(2u * (unsigned)cx, (unsigned)Q1.dbx) >> 14) ? Q1.sh1 : Q1.sh0;
+            s2hh[u] = ldu8(stable, __umul24(2u * (unsigned)cx + 1u, (unsigned)Q1.dbx) >> 14) ? Q1.sh1 : Q1.sh0;
         } else
         if (ok2[u]) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)Q2.sw) + (unsigned)cx;
@@ -1745,8 +1771,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     for (int u = 0; u < 2; u++) {
         const unsigned it = utid + 256u * u, ly = it >> 4, gx = it & 15u;
         poff[u] = __umul24(2u * (4u * (unsigned)J0 + ly), (unsigned)stride) + 8u * ((unsigned)I0 + gx);
-        pv[u][0] = dsvg_ld2(pred + poff[u]);
-        pv[u][1] = dsvg_ld2(pred + poff[u] + (unsigned)stride);
+        pv[u][0] = pv[u][1] = make_uint2(0u, 0u);
+        if (v1[u]) {
+            pv[u][0] = dsvg_ld2(pred + poff[u]);
+            pv[u][1] = dsvg_ld2(pred + poff[u] + (unsigned)stride);
+        }
     }
     uint2 d1lh[2], d1hl[2], d1hh[2];
     s16x2 shv[2][2];
@@ -1784,6 +1813,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         if ((const DSVG_GLOBAL uint8_t *)outp == pred) return;     // written in place by the forward transform (ping-pong slots)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
+            if (!v1[u]) continue;
             const auto dst = outp + poff[u];
             dsvg_st2(dst, pv[u][0]);
             dsvg_st2(dst + (unsigned)stride, pv[u][1]);
@@ -1797,6 +1827,12 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
         d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> k3, HZ_MINQ))); d[1] = 0;
         d[W2] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> s3hh, HZ_MINQ))); d[W2 + 1] = 0;
+    } else
+    if (EB && ok3 && J0 - 1 + ly3 >= h3) {
+        int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
+        d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> k3, HZ_MINQ)));
+        d[1] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> s3hh, HZ_MINQ)));
+        d[W2] = 0; d[W2 + 1] = 0;
     } else
     if (ok3) {
         const int *pA = A3u + (ly3 + 1) * W3 + lx3 + 1;
@@ -1829,6 +1865,12 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
             d[WP] = pk_i16((int)((unsigned)s2hl[u] << s2hh[u]), 0);
             continue;
         }
+        if (EB && 2 * J0 - 1 + ly >= 2 * h3) {
+            unsigned *d = A1p + (2 * ly) * WP + lx;
+            d[0] = pk_i16((int)((unsigned)s2lh[u] << k2[u]), (int)((unsigned)s2hl[u] << s2hh[u]));
+            d[WP] = 0;
+            continue;
+        }
         const int *pA = A2u + (ly + 1) * W2 + lx + 1;
         const int LL = pA[0];
         int LH = 0, HL = 0, HH = 0;
@@ -1855,6 +1897,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
         const unsigned *row = A1p + (ly + 2) * WP + 2 * gx;          // pairs 2gx .. 2gx+3 hold LL1 columns 4gx .. 4gx+7 (halo 2)
         unsigned row0[2], row1[2];
+        if (EB && !v1[u]) continue;
         const bool zero1 = __ballot(pf1[u] != 0) == 0ull;
         if (zero1) inv_l1_item<FILT, true>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
         else inv_l1_item<FILT, false>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
@@ -1876,14 +1919,18 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 // er_col: the tile column that ends exactly where the band ends and takes the ER body (-1: none) -- in the same launch as the
 // interior tiles (as a launch of its own the column's 16 x 160 workgroups took as long as the general kernel's strip did)
 template <bool FILT>
-__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int er_col)
+__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int er_col, int eb_row)
 {
     __shared__ int A3[A3H * A3W];
     __shared__ int A2[A2H * A2W];
     __shared__ unsigned A1p[(4 * IT_TY + 4) * (2 * IT_TX + 2)];
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
-    if ((int)blockIdx.x == er_col) inv_p_fast<FILT, true>(jobs[job], G.g[c], c, (int)blockIdx.x * IT_TX, (int)blockIdx.y * IT_TY, threadIdx.x, A3, A2, A1p);
-    else inv_p_fast<FILT, false>(jobs[job], G.g[c], c, (int)blockIdx.x * IT_TX, (int)blockIdx.y * IT_TY, threadIdx.x, A3, A2, A1p);
+    const int I0 = (int)blockIdx.x * IT_TX, J0 = (int)blockIdx.y * IT_TY;
+    const bool er = (int)blockIdx.x == er_col, eb = (int)blockIdx.y == eb_row;      // (eb_row: the last tile row, likewise)
+    if (er && eb) inv_p_fast<FILT, true, true>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
+    else if (er) inv_p_fast<FILT, true, false>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
+    else if (eb) inv_p_fast<FILT, false, true>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
+    else inv_p_fast<FILT, false, false>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
 }
 
 // MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
@@ -2596,21 +2643,23 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             const int fy = (patch_kernel && g.l1a && g.h3 >= IT_TY + 2) ? (g.h3 - IT_TY - 2) / IT_TY + 1 : 0;
             static const bool no_er = getenv("DSV1_NO_EDGE_TILES") != nullptr;
             if (fx > 0 && fy > 0) {
-                const double fsmp = 64.0 * fx * IT_TX * fy * IT_TY * nz;            // samples of the fast tiles
-                PB(filt ? KID_INV_P_TILE_F : KID_INV_P_TILE, fsmp * 2.5);
                 // the last tile column too, when it ends exactly where the band ends and every cell of every level is complete
                 const bool er = !no_er && fx == (int)tg.x - 1 && g.w3 == (int)tg.x * IT_TX && (g.W & 7) == 0;
-                const int fxg = er ? fx + 1 : fx;              // tile columns the fast kernel takes (rows [0, fy))
-                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), dim3(fxg, fy, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1);
-                else      hipLaunchKernelGGL((k_inv_p_tile<false>), dim3(fxg, fy, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1);
+                // ... and the last tile row, when it is the only one left and every cell row is complete
+                const bool eb = !no_er && fy == (int)tg.y - 1 && (g.H & 7) == 0;
+                const int fxg = er ? fx + 1 : fx, fyg = eb ? fy + 1 : fy;      // tile columns / rows the fast kernel takes
+                const double fsmp = 64.0 * std::min(fxg * IT_TX, g.w3) * std::min(fyg * IT_TY, g.h3) * nz;   // samples of the fast tiles
+                PB(filt ? KID_INV_P_TILE_F : KID_INV_P_TILE, fsmp * 2.5);
+                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), dim3(fxg, fyg, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1);
+                else      hipLaunchKernelGGL((k_inv_p_tile<false>), dim3(fxg, fyg, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1);
                 PE();
-                PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, (smp - fsmp) * 2.5);
-                const int nrest = ((int)tg.x - fxg) * (int)tg.y + fxg * ((int)tg.y - fy);      // right strip + bottom strip, one launch
+                const int nrest = ((int)tg.x - fxg) * (int)tg.y + fxg * ((int)tg.y - fyg);      // right strip + bottom strip, one launch
                 if (nrest > 0) {
-                    if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fxg, -fy - 1);
-                    else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fxg, -fy - 1);
+                    PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, (smp - fsmp) * 2.5);
+                    if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fxg, -fyg - 1);
+                    else      hipLaunchKernelGGL((k_inv_haar_tile<false, 0, true>), dim3(nrest, 1, nz), dim3(256), 0, st, jobs, G, c0, npl, fxg, -fyg - 1);
+                    PE();
                 }
-                PE();
                 return;
             }
             PB(filt ? KID_INV_TILE_PIX_SYM_F : KID_INV_TILE_PIX_SYM, smp * 2.5);
