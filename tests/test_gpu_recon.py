@@ -85,6 +85,11 @@ CASES = [
     (704, 480, A.SUBSAMP_420, 5, 11, dict(qp=85, gop=12, rc_mode_cli=1)),         # static + moving square: both paths
     (1920, 1080, A.SUBSAMP_420, 3, 11, dict(qp=85, gop=12, rc_mode_cli=1)),
     (250, 130, A.SUBSAMP_444, 4, 11, dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
+    # the fast inverse kernel's edge tiles: last tile column ends with the band, last tile row holds 2 / 5 / 8 cell rows
+    (1280, 720, A.SUBSAMP_420, 3, 0, dict(qp=85, gop=12, rc_mode_cli=1)),
+    (640, 360, A.SUBSAMP_420, 4, 2, dict(qp=70, gop=12, rc_mode_cli=1)),
+    (768, 576, A.SUBSAMP_444, 3, 1, dict(qp=85, gop=12, rc_mode_cli=1)),              # 4:4:4: the chroma planes take the luma-sized kernels
+    (1024, 768, A.SUBSAMP_422, 3, 0, dict(qp=60, gop=12, rc_mode_cli=1)),
 ]
 
 
