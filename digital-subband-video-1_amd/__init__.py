@@ -163,6 +163,8 @@ class Batch:
         self.nstreams, self.F = nstreams, frames_per_call
         _chk(self.L.dsv1_batch_open(_C.byref(self.h), _C.byref(cfg), device, nstreams, frames_per_call), "dsv1_batch_open")
         self.ctx = self.L.dsv1_batch_ctx(self.h)
+        m = cfg.vidmeta
+        self.frame_bytes = m.width * m.height + 2 * _chroma_size(m.width, m.height, m.subsamp)
         self._dev = []
         self._pin = []
 
@@ -200,6 +202,8 @@ class Batch:
             ptr = yuv
         else:
             a = _np.ascontiguousarray(yuv, dtype=_np.uint8)
+            if a.size != self.nstreams * self.F * self.frame_bytes:      # (the C entry point reads nstreams x F frames whatever it is given)
+                raise ValueError("a batch is %d streams x %d frames x %d bytes, got %d bytes" % (self.nstreams, self.F, self.frame_bytes, a.size))
             ptr = a.ctypes.data
         _chk(self.L.dsv1_batch_encode(self.h, ptr, 1 if on_device else 0, bufs), "dsv1_batch_encode")
         if eos:
@@ -214,6 +218,8 @@ class Batch:
             ptr = yuv
         else:
             self._keep = _np.ascontiguousarray(yuv, dtype=_np.uint8)
+            if self._keep.size != self.nstreams * self.F * self.frame_bytes:
+                raise ValueError("a batch is %d streams x %d frames x %d bytes, got %d bytes" % (self.nstreams, self.F, self.frame_bytes, self._keep.size))
             ptr = self._keep.ctypes.data
         if not hasattr(self, "_abr"):
             self._abr = []

@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Random stream-parity soak on the GPU box: geometries (with an emphasis on multiples of 8 / 16 / 128, where the edge
+tiles of the fast inverse kernel and the 16-byte border paths apply), formats, quantisers, GOP lengths, content styles and
+batch shapes (several streams side by side, frames per call) -- product stream against the oracle's, byte for byte.
+usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case)"""
+import importlib, os, random, sys, time
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
+sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+import numpy as np
+import _cabi as A
+pkg = importlib.import_module("digital-subband-video-1_amd")
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+WS = [128, 144, 160, 256, 320, 352, 384, 400, 512, 640, 704, 720, 768, 800, 960, 1024, 1280]
+HS = [64, 72, 96, 128, 144, 176, 240, 256, 288, 320, 360, 384, 400, 480, 512, 576, 600, 720]
+FMTS = [A.SUBSAMP_420, A.SUBSAMP_420, A.SUBSAMP_444, A.SUBSAMP_422, A.SUBSAMP_411]
+bad = 0
+t0 = time.time()
+for k in range(N):
+    w, h = rng.choice(WS), rng.choice(HS)
+    if rng.random() < 0.2:
+        w += rng.choice([2, 4, 6, 10, 14]); h += rng.choice([2, 4, 6])
+    fmt = rng.choice(FMTS)
+    # (the reference divides by zero when a chroma edge block is one pixel wide or high, bmc.c:176-189: the oracle follows it)
+    bw, bh = A.block_dims(w, h)[:2]
+    cw, ch = A.chroma_dims(w, h, fmt)
+    if cw % max(1, bw >> A.hshift(fmt)) == 1 or ch % max(1, bh >> A.vshift(fmt)) == 1 or w % bw == 1 or h % bh == 1:
+        continue
+    n = rng.choice([3, 4, 5, 7])
+    S = rng.choice([1, 1, 2, 5, 17])
+    F = rng.choice([f for f in (1, 2, 3, n) if n % f == 0])        # (the batch API takes whole batches)
+    style = rng.choice([0, 1, 2])
+    cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
+    seed = rng.randrange(1 << 30)
+    clips = [A.gen_clip(w, h, fmt, seed + s, n, style=style) for s in range(min(S, 3))]
+    try:
+        want = [A.orc_encode(c, A.orc_cfg(w, h, fmt, **cli), eos=False)[0] for c in clips]
+    except Exception as e:
+        print("case %d skipped (oracle: %s)" % (k, e)); continue
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), S, F)
+    try:
+        got = [b""] * S
+        t = 0
+        while t < n:
+            f = F
+            fr = np.stack([clips[s % len(clips)][t:t + f] for s in range(S)]).reshape(S, f, -1)
+            pk = b.encode(fr)
+            for s in range(S):
+                got[s] += pk[s]
+            t += f
+        for s in range(S):
+            if got[s] != want[s % len(clips)]:
+                bad += 1
+                print("MISMATCH case %d: %dx%d fmt %d n %d S %d F %d style %d %s seed %d stream %d" % (k, w, h, fmt, n, S, F, style, cli, seed, s))
+                break
+    finally:
+        b.close()
+print("soak: %d cases, %d mismatches, %.0f s" % (N, bad, time.time() - t0))
+sys.exit(1 if bad else 0)
