@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Random stream-parity soak on the GPU box: geometries (with an emphasis on multiples of 8 / 16 / 128, where the edge
+"""Random stream-parity soak on the GPU box (encoder; every third case the decoder too): geometries (with an emphasis on multiples of 8 / 16 / 128, where the edge
 tiles of the fast inverse kernel and the 16-byte border paths apply), formats, quantisers, GOP lengths, content styles and
 batch shapes (several streams side by side, frames per call) -- product stream against the oracle's, byte for byte.
 usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case)"""
@@ -9,6 +9,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
 import numpy as np
 import _cabi as A
 pkg = importlib.import_module("digital-subband-video-1_amd")
+from test_gpu_stream import product_decode
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 WS = [128, 144, 160, 256, 320, 352, 384, 400, 512, 640, 704, 720, 768, 800, 960, 1024, 1280]
@@ -55,5 +56,11 @@ for k in range(N):
                 break
     finally:
         b.close()
+    if k % 3 == 0:                                   # every third case also through the drop-in decoder
+        frames = product_decode(pkg, want[0])
+        ref = A.orc_decode(want[0], w, h, fmt)
+        if len(frames) != len(ref) or any((x != y).any() for x, y in zip(frames, ref)):
+            bad += 1
+            print("DECODE MISMATCH case %d: %dx%d fmt %d n %d style %d %s seed %d" % (k, w, h, fmt, n, style, cli, seed))
 print("soak: %d cases, %d mismatches, %.0f s" % (N, bad, time.time() - t0))
 sys.exit(1 if bad else 0)
