@@ -12,8 +12,8 @@ pkg = importlib.import_module("digital-subband-video-1_amd")
 from test_gpu_stream import product_decode
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-WS = [128, 144, 160, 256, 320, 352, 384, 400, 512, 640, 704, 720, 768, 800, 960, 1024, 1280]
-HS = [64, 72, 96, 128, 144, 176, 240, 256, 288, 320, 360, 384, 400, 480, 512, 576, 600, 720]
+WS = [1920, 128, 144, 160, 256, 320, 352, 384, 400, 512, 640, 704, 720, 768, 800, 960, 1024, 1280]
+HS = [1080, 64, 72, 96, 128, 144, 176, 240, 256, 288, 320, 360, 384, 400, 480, 512, 576, 600, 720]
 FMTS = [A.SUBSAMP_420, A.SUBSAMP_420, A.SUBSAMP_444, A.SUBSAMP_422, A.SUBSAMP_411]
 bad = 0
 t0 = time.time()
@@ -28,7 +28,7 @@ for k in range(N):
     if cw % max(1, bw >> A.hshift(fmt)) == 1 or ch % max(1, bh >> A.vshift(fmt)) == 1 or w % bw == 1 or h % bh == 1:
         continue
     n = rng.choice([3, 4, 5, 7])
-    S = rng.choice([1, 1, 2, 5, 17])
+    S = rng.choice([1, 1, 2, 5, 17, 33, 64])
     F = rng.choice([f for f in (1, 2, 3, n) if n % f == 0])        # (the batch API takes whole batches)
     style = rng.choice([0, 1, 2])
     cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
