@@ -887,7 +887,27 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
     int32_t *coef = jb.coef + g.coff;
     const int hw = W >> 1, hh = H >> 1;
 
-    int RL[10][4], RH[10][4];       // row-pass outputs of rows 8J-1 .. 8J+8 for cells 4I..4I+3
+    // Row pass and column pass interleaved: cell row m needs the row-pass outputs of rows 2m .. 2m+3 of the ten (8J-1 .. 8J+8),
+    // so a window of four rows is alive at a time instead of all ten (158 -> ~100 VGPRs: three waves per SIMD became five).
+    int RL[4][4], RH[4][4];         // row-pass outputs of the last four rows for cells 4I..4I+3 (row r in slot r & 3)
+    const int nC = min(4, max(0, hw - 4 * I));
+    // Q: the level-1 detail bands (scan level 2, shift quantiser) are quantised here; the DEQUANTISED values go to the
+    // coefficient plane (k_inv_b4t reads them) and the symbols to the symbol plane (k_hz_collect compacts them), so the
+    // separate quantiser pass over the plane (k_hz_quant<false>: 8 B per coefficient) disappears for I pictures too.
+    QCtx q;
+    QLevel Lq;
+    int cls[4][4];
+    bool chx = false, chy = false;
+    if (Q) {
+        const HzPlane &hp = jb.hz[c];
+        q.hp = &hp; q.stable = dsvg_global(jb.stable);
+        q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
+        q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
+                   (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
+        Lq = q_level<2>(hp);
+        q_flags<2, 4>(q, Lq, 4 * I, 4 * J, hw, hh, cls);
+        chx = q.any_ov && I == 0; chy = q.any_ov && J == 0;
+    }
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         int y = 8 * J - 1 + r;
@@ -920,72 +940,55 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int xm = v[2 * k], x0 = v[2 * k + 1], x1 = v[2 * k + 2], xp = v[2 * k + 3];
-            RL[r][k] = d_rdiv2(3 * x0 + 3 * x1 - xm - xp);
-            RH[r][k] = d_rdiv2(xm - 3 * x0 + 3 * x1 - xp);
+            RL[r & 3][k] = d_rdiv2(3 * x0 + 3 * x1 - xm - xp);
+            RH[r & 3][k] = d_rdiv2(xm - 3 * x0 + 3 * x1 - xp);
         }
-    }
-    const int nC = min(4, max(0, hw - 4 * I));
-    // Q: the level-1 detail bands (scan level 2, shift quantiser) are quantised here; the DEQUANTISED values go to the
-    // coefficient plane (k_inv_b4t reads them) and the symbols to the symbol plane (k_hz_collect compacts them), so the
-    // separate quantiser pass over the plane (k_hz_quant<false>: 8 B per coefficient) disappears for I pictures too.
-    QCtx q;
-    QLevel Lq;
-    int cls[4][4];
-    bool chx = false, chy = false;
-    if (Q) {
-        const HzPlane &hp = jb.hz[c];
-        q.hp = &hp; q.stable = dsvg_global(jb.stable);
-        q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
-        q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
-                   (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
-        Lq = q_level<2>(hp);
-        q_flags<2, 4>(q, Lq, 4 * I, 4 * J, hw, hh, cls);
-        chx = q.any_ov && I == 0; chy = q.any_ov && J == 0;
-    }
+        if (r >= 3 && ((r - 3) & 1) == 0) {
+            const int m = (r - 3) >> 1;
+            const int cy = 4 * J + m;
+            if (cy < hh) {
+                int ll[4], lh[4], hl[4], hhv[4];
+                int slh[4], shl[4], shh[4];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int cy = 4 * J + m;
-        if (cy >= hh) break;
-        int ll[4], lh[4], hl[4], hhv[4];
-        int slh[4], shl[4], shh[4];
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int am = RL[2 * m][k], a0 = RL[2 * m + 1][k], a1 = RL[2 * m + 2][k], ap = RL[2 * m + 3][k];
-            const int bm = RH[2 * m][k], b0 = RH[2 * m + 1][k], b1 = RH[2 * m + 2][k], bp = RH[2 * m + 3][k];
-            ll[k] = d_rdiv2(3 * a0 + 3 * a1 - am - ap);
-            hl[k] = d_rdiv2(am - 3 * a0 + 3 * a1 - ap);
-            lh[k] = d_rdiv2(3 * b0 + 3 * b1 - bm - bp);
-            hhv[k] = d_rdiv2(bm - 3 * b0 + 3 * b1 - bp);
-            if (Q) {
-                slh[k] = shl[k] = shh[k] = 0;
-                if (k < nC) {
-                    // cells two scan regions share sit on the first column / row of the bands (as in haar_fwd_patch_q)
-                    if (k == 0 && chx) {
-                        lh[k] = q_chain(q, 2, hw, cy, lh[k]);
-                        hhv[k] = q_chain(q, 2, hw, hh + cy, hhv[k]);
+                for (int k = 0; k < 4; k++) {
+                    const int am = RL[(r - 3) & 3][k], a0 = RL[(r - 2) & 3][k], a1 = RL[(r - 1) & 3][k], ap = RL[r & 3][k];
+                    const int bm = RH[(r - 3) & 3][k], b0 = RH[(r - 2) & 3][k], b1 = RH[(r - 1) & 3][k], bp = RH[r & 3][k];
+                    ll[k] = d_rdiv2(3 * a0 + 3 * a1 - am - ap);
+                    hl[k] = d_rdiv2(am - 3 * a0 + 3 * a1 - ap);
+                    lh[k] = d_rdiv2(3 * b0 + 3 * b1 - bm - bp);
+                    hhv[k] = d_rdiv2(bm - 3 * b0 + 3 * b1 - bp);
+                    if (Q) {
+                        slh[k] = shl[k] = shh[k] = 0;
+                        if (k < nC) {
+                            // cells two scan regions share sit on the first column / row of the bands (as in haar_fwd_patch_q)
+                            if (k == 0 && chx) {
+                                lh[k] = q_chain(q, 2, hw, cy, lh[k]);
+                                hhv[k] = q_chain(q, 2, hw, hh + cy, hhv[k]);
+                            }
+                            if (m == 0 && chy) {
+                                hl[k] = q_chain(q, 2, 4 * I + k, hh, hl[k]);
+                                if (!(k == 0 && chx)) hhv[k] = q_chain(q, 2, hw + 4 * I + k, hh, hhv[k]);
+                            }
+                            const int sh = cls[m][k] ? Lq.sh1 : Lq.sh0;
+                            lh[k] = q_coef<2>(sh, 0.f, lh[k], slh[k]);
+                            hl[k] = q_coef<2>(sh, 0.f, hl[k], shl[k]);
+                            hhv[k] = q_coef<2>(sh, 0.f, hhv[k], shh[k]);
+                        }
                     }
-                    if (m == 0 && chy) {
-                        hl[k] = q_chain(q, 2, 4 * I + k, hh, hl[k]);
-                        if (!(k == 0 && chx)) hhv[k] = q_chain(q, 2, hw + 4 * I + k, hh, hhv[k]);
-                    }
-                    const int sh = cls[m][k] ? Lq.sh1 : Lq.sh0;
-                    lh[k] = q_coef<2>(sh, 0.f, lh[k], slh[k]);
-                    hl[k] = q_coef<2>(sh, 0.f, hl[k], shl[k]);
-                    hhv[k] = q_coef<2>(sh, 0.f, hhv[k], shh[k]);
+                }
+                if (Q) {
+                    const int o = cy * Lq.sw + 4 * I;
+                    store_sym_row<4>(q.sym + Lq.base0 + o, slh, nC);
+                    store_sym_row<4>(q.sym + Lq.base1 + o, shl, nC);
+                    store_sym_row<4>(q.sym + Lq.base2 + o, shh, nC);
+                }
+                store_row<4>(jb.s1 + g.s1off + (size_t)cy * g.w1 + 4 * I, ll, nC);
+                if (!Q) {               // Q: k_inv_b4t<true> dequantises the symbols itself: the int32 bands are not needed
+                    store_row<4>(coef + (size_t)cy * W + hw + 4 * I, lh, nC);
+                    store_row<4>(coef + (size_t)(hh + cy) * W + 4 * I, hl, nC);
+                    store_row<4>(coef + (size_t)(hh + cy) * W + hw + 4 * I, hhv, nC);
                 }
             }
-        }
-        if (Q) {
-            const int o = cy * Lq.sw + 4 * I;
-            store_sym_row<4>(q.sym + Lq.base0 + o, slh, nC);
-            store_sym_row<4>(q.sym + Lq.base1 + o, shl, nC);
-            store_sym_row<4>(q.sym + Lq.base2 + o, shh, nC);
-        }
-        store_row<4>(jb.s1 + g.s1off + (size_t)cy * g.w1 + 4 * I, ll, nC);
-        if (!Q) {               // Q: k_inv_b4t<true> dequantises the symbols itself: the int32 bands are not needed
-            store_row<4>(coef + (size_t)cy * W + hw + 4 * I, lh, nC);
-            store_row<4>(coef + (size_t)(hh + cy) * W + 4 * I, hl, nC);
-            store_row<4>(coef + (size_t)(hh + cy) * W + hw + 4 * I, hhv, nC);
         }
     }
 }
