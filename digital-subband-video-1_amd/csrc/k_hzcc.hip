@@ -7,13 +7,18 @@
 // is parallelised as
 //   k_hz_quant<false>  one workgroup per 2048 scan cells: quantise, write the DEQUANTISED value back in place
 //               (hzcc.c:172-184), compact the non-zeros in scan order with wave ballots, and sum the bit
-//               lengths of every symbol whose predecessor lies in the same chunk (I pictures, operator calls)
-//   k_hz_quant<true> + k_hz_collect  the same for P pictures whose detail bands were already quantised by the
-//               forward transform (k_fwd_haar_pix<true>): LL chunks / wave-per-chunk compaction of the symbols
+//               lengths of every symbol whose predecessor lies in the same chunk (operator calls)
+//   k_hz_collect / k_hz_collect_list   the encoder's pictures are quantised where their coefficients appear (the detail
+//               bands in the forward transform, the LL region in k_fwd_haar_mid<4> / k_tail_q): what is left is the
+//               compaction.  Dense pictures (I): a wave per chunk.  Sparse pictures (P): a workgroup per 64 chunks spread over
+//               the picture, a lane per chunk flag, the waves share out the flagged chunks.  (k_hz_quant<true>: the LL region
+//               quantised by a kernel of its own, DSV1_NO_LLQ)
 //   k_hz_scan   one workgroup per plane: carries (position,value) of the last non-zero across
 //               chunks (max-scan), adds each chunk's first-symbol length, prefix-sums bit offsets
-//   k_hz_emit   one wave per chunk: builds each <=92-bit symbol (UEG spread via bit interleave), assembles
-//               rounds of 64 symbols in LDS and flushes them with plain stores (atomicOr only on shared words)
+//   k_hz_emit / k_hz_emit_list   a wave per chunk with entries: rounds of 64 entries, both codes of an entry in one
+//               pattern where they are short (the usual round), the round's bits assembled in LDS; complete words leave
+//               by plain stores, the partial word is carried into the next round, a chunk's first and last word (shared
+//               with its neighbours) by atomicOr after the loop -- no round waits for a store
 //   k_hz_parse  the decoder's entropy parse (state-machine scan) + k_hz_scatter_lv
 // Scan regions can overlap for some plane sizes (960x540: SURVEY.md Q7); a cell seen by two
 // regions is processed twice exactly like the sequential reference: the later region quantises
