@@ -4,15 +4,22 @@
 // and dsv_inv_sbt sbt.c:654-714 (inv :438, inv_simple :352, inv_b4t_* :129-265, sbc2int :595).
 //
 // Decomposition (per plane, batched over picture jobs in grid.z):
-//   forward  P : k_fwd_haar_pix   one thread = one 8x8 pixel patch = Haar levels 1..3 in registers
-//                                 (8-byte coalesced row loads, 16/8/4-byte coalesced sub-band stores)
+//   forward  P : k_fwd_mc_fast    (encoder) one thread = one 8x8 pixel patch: motion compensation (bmc.c) + Haar levels 1..3
+//                                 + the quantiser of their detail bands in registers, symbols stored sparsely; the common
+//                                 patch.  k_fwd_mc_pix: the general body (picture edges, intra blocks, shared scan cells),
+//                                 on the strips of the grid that can hold such patches.  k_fwd_haar_pix: from a residual
+//                                 frame (operator calls, block sizes that are not multiples of 8)
 //            I : k_fwd_b4t        level 1 biorthogonal (1,3,3,1): row pass + column pass per thread on a
 //                                 10x10 neighbourhood, LL1 -> s1;  k_fwd_haar_mid<2>: levels 2..3 from s1
-//            all: k_fwd_haar_mid<4> levels 4..5 (LL3 -> LL5);  k_fwd_tail: levels 6..top inside LDS by one workgroup
+//            all: k_fwd_haar_mid<4> levels 4..5 (LL3 -> LL5; encoder: with the LL quantiser);  k_fwd_tail: levels 6..top
+//                                 inside LDS by one workgroup;  k_tail_q (encoder): forward tail + LL quantiser + inverse tail
 //   inverse all: k_inv_tail       levels top..6 inside LDS, LL5 -> s5;  k_inv_haar_tile<.,2>: levels 5,4 -> s3
-//            P : k_inv_haar_tile  levels 3,2,1 on a 128x64 pixel tile through LDS (halo 2/1/0 cells),
-//                                 fused with sbc2int, the prediction add (dsv_frame_add bmc.c:304) and
-//                                 the store into the reconstruction frame
+//            P : k_inv_p_tile     (sparse pictures, luma) levels 3,2,1 on a 128x64 pixel tile through LDS from the symbol
+//                                 planes: the fast body, with edge variants for the last tile column / row;
+//                k_inv_patch_c    (sparse pictures, chroma: no smoothing filter) one thread = one 8x8 patch, no LDS;
+//                k_inv_haar_tile  the general tile body (halo 2/1/0 cells, any edge, coefficient or symbol input), fused
+//                                 with sbc2int, the prediction add (dsv_frame_add bmc.c:304) and the store into the
+//                                 reconstruction frame
 //            I : k_inv_haar_tile<..TO_S1> levels 3,2 -> s1, then k_inv_b4t (column pass through LDS,
 //                                 then row pass) fused with sbc2int
 // Every formula keeps the C semantics of the reference: truncating *4/5, *5/4 and /4, rounding
