@@ -80,7 +80,7 @@ static void hp_report(void)
 }
 
 /* The per-stream host phases (side info, packet assembly) are independent across streams: a plain pthread
- * fork/join over them.  Threads: DSV1_HOST_THREADS, else min(6, cores / ranks on the node / 2); never more than streams. */
+ * parallel loop over them on the worker pool (dsv1_par_for).  Workers: DSV1_HOST_THREADS, else min(12, cores / ranks on the node / 2); never more than streams. */
 #include <pthread.h>
 #include <unistd.h>
 static int slot_of(const dsv1_batch *b, int s, unsigned g) { return (int)(g % (unsigned)b->rows) * b->nstreams + s; }

@@ -81,7 +81,7 @@ int  dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n);
 int  dsv1_buf_reserve(DSV_BUF *b, unsigned n);
 void dsv1_log(int level, const char *fmt, ...);
 extern int dsv1_device;
-/* fork/join over S independent streams: fn(ctx, s, worker) for every s; DSV1_HOST_THREADS workers (default min(6,
+/* parallel loop over S independent items on a persistent worker pool: fn(ctx, s, worker) for every s; DSV1_HOST_THREADS workers (default min(12,
  * half of this process's share of the cores)) */
 typedef void (*dsv1_par_fn)(void *ctx, int s, int tid);
 void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx);

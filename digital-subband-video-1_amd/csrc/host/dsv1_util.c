@@ -275,7 +275,7 @@ void conv422to420(DSV_PLANE *s, DSV_PLANE *d)
         }
 }
 
-/* ---- fork/join over independent streams (side information, packet assembly, packet parsing) ---- */
+/* ---- parallel loop over independent items (side information, packet assembly, packet parsing, job records) ---- */
 static int par_threads(int S)
 {
     static int n = 0;
