@@ -79,7 +79,7 @@ static void hp_report(void)
     for (k = 0; k < HP_N; k++) fprintf(stderr, "[dsv1 host] %-44s %8.3f ms / batch\n", nm[k], hp_acc[k] / (double)hp_batches);
 }
 
-/* The per-stream host phases (side info, packet assembly) are independent across streams: a plain pthread
+/* The per-stream host phases (side info, packet assembly) are independent across streams: a
  * parallel loop over them on the worker pool (dsv1_par_for).  Workers: DSV1_HOST_THREADS, else min(12, cores / ranks on the node / 2); never more than streams. */
 #include <pthread.h>
 #include <unistd.h>
