@@ -6,7 +6,8 @@
 // Decomposition (per plane, batched over picture jobs in grid.z):
 //   forward  P : k_fwd_mc_fast    (encoder) one thread = one 8x8 pixel patch: motion compensation (bmc.c) + Haar levels 1..3
 //                                 + the quantiser of their detail bands in registers, symbols stored sparsely; the common
-//                                 patch.  k_fwd_mc_pix: the general body (picture edges, intra blocks, shared scan cells),
+//                                 patch (residual rows, level 1 and the half-pel filters that fit 16 bits on two samples
+//                                 per instruction, v_pk_*_i16).  k_fwd_mc_pix: the general body (picture edges, intra blocks, shared scan cells),
 //                                 on the strips of the grid that can hold such patches.  k_fwd_haar_pix: from a residual
 //                                 frame (operator calls, block sizes that are not multiples of 8)
 //            I : k_fwd_b4t        level 1 biorthogonal (1,3,3,1): row pass + column pass per thread on a
@@ -24,6 +25,7 @@
 //                                 then row pass) fused with sbc2int
 // Every formula keeps the C semantics of the reference: truncating *4/5, *5/4 and /4, rounding
 // helpers round half away from zero, mirrored left/top and clamped right/bottom B4T edges.
+#include <type_traits>
 #include "dsvg_dev.hpp"
 #include <algorithm>
 #include "dsvg_kernels.hpp"
@@ -457,6 +459,57 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
 // --------------------------------------------------------------------------------------------
 struct __attribute__((aligned(4))) U4A4 { unsigned x, y, z, w; };     // 16 bytes at a dword-aligned address
 
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ s16x2 pk2(int a, int b) { return s16x2{(short)a, (short)b}; }
+static __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+static __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+// Eight 8-bit samples of a row as four registers of two int16 (v_pk_*_i16 works on two samples per instruction):
+// e0 = (p0, p2), e1 = (p4, p6), o0 = (p1, p3), o1 = (p5, p7) -- a sample and its right neighbour sit in the same half of
+// an e / o pair, which is what the horizontal steps (half-pel filters, Haar level 1) combine.
+struct PkRow { s16x2 e0, e1, o0, o1; };
+static __device__ __forceinline__ s16x2 pk_u(unsigned v) { return __builtin_bit_cast(s16x2, v); }
+static __device__ __forceinline__ unsigned pk_b(s16x2 v) { return __builtin_bit_cast(unsigned, v); }
+#define PK_EVEN(hi_, lo_) pk_u((lo_) & 0x00ff00ffu)                               /* bytes (0, 2) of lo_ */
+#define PK_ODD(hi_, lo_) pk_u(__builtin_amdgcn_perm(0u, (lo_), 0x0c030c01u))      /* bytes (1, 3) of lo_ */
+#define PK_E2(hi_, lo_) pk_u(__builtin_amdgcn_perm((hi_), (lo_), 0x0c040c02u))    /* bytes (2, 4): 4 = byte 0 of hi_ */
+#define PK_O2(hi_, lo_) pk_u(__builtin_amdgcn_perm((hi_), (lo_), 0x0c050c03u))    /* bytes (3, 5) */
+static __device__ __forceinline__ PkRow pk_unpack8(unsigned lo, unsigned hi)
+{
+    return PkRow{PK_EVEN(0u, lo), PK_EVEN(0u, hi), PK_ODD(0u, lo), PK_ODD(0u, hi)};
+}
+static __device__ __forceinline__ void pk_bytes8(const PkRow &p, unsigned &lo, unsigned &hi)       // samples 0 .. 255
+{
+    lo = (pk_b(p.o0) << 8) | pk_b(p.e0);
+    hi = (pk_b(p.o1) << 8) | pk_b(p.e1);
+}
+// luma, waves with horizontal half-pel phases only (mc_luma_patch<true, false> on two samples per instruction):
+// t = (9 (b + c) - (a + d) + 8) >> 4 lies in -32 .. 287, the products in -510 .. 4598
+template <typename EMITPK>
+static __device__ __forceinline__ void mc_luma_patch_hpk(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, EMITPK emit_pk)
+{
+    const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
+    const DSVG_GLOBAL uint8_t *ga = gr - shb;
+    U4A4 rw[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) { const dsvg_u32x4a4 t = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(ga + (r + 1) * stride); rw[r] = U4A4{t.x, t.y, t.z, t.w}; }
+    __builtin_amdgcn_sched_barrier(0);
+    const s16x2 z = s16x2{0, 0}, m255 = s16x2{255, 255};
+    auto H = [&](s16x2 a, s16x2 b, s16x2 c, s16x2 d) {
+        const s16x2 t = ((b + c) * (short)9 + (short)8 - (a + d)) >> 4;
+        const s16x2 u = pk_min(pk_max(t, z), m255);
+        return xh ? u : b;
+    };
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const unsigned lo = __builtin_amdgcn_alignbyte(rw[r].y, rw[r].x, shb), mi = __builtin_amdgcn_alignbyte(rw[r].z, rw[r].y, shb),
+                       hi = __builtin_amdgcn_alignbyte(rw[r].w, rw[r].z, shb);
+        // A[m] = (byte m, byte m + 2) of the row's window; sample i reads bytes i .. i + 3
+        const s16x2 A0 = PK_EVEN(0u, lo), A1 = PK_ODD(0u, lo), A2 = PK_E2(mi, lo), A3 = PK_O2(mi, lo), A4 = PK_EVEN(0u, mi), A5 = PK_ODD(0u, mi),
+                    A6 = PK_E2(hi, mi), A7 = PK_O2(hi, mi), A8 = PK_EVEN(0u, hi);
+        emit_pk(r, PkRow{H(A0, A1, A2, A3), H(A4, A5, A6, A7), H(A1, A2, A3, A4), H(A5, A6, A7, A8)});
+    }
+}
+
 #define MCB(lo, mi, hi, m) ((int)((((m) < 4 ? (lo) : ((m) < 8 ? (mi) : (hi))) >> (8 * ((m) & 3))) & 0xff))
 static __device__ __forceinline__ void mc_pack8(const int (&pv)[8], unsigned &plo, unsigned &phi)
 {
@@ -465,9 +518,20 @@ static __device__ __forceinline__ void mc_pack8(const int (&pv)[8], unsigned &pl
 }
 // Luma prediction of one 8x8 patch, gr = &reference(wx-1, wy-1).  AX / AY: some lane of the wave has a horizontal /
 // vertical half-pel phase (wave-uniform, so whole stages drop out for waves that do not need them); xh / yh: this lane's.
-template <bool AX, bool AY, typename EMIT>
-static __device__ __forceinline__ void mc_luma_patch(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, bool yh, EMIT emit)
+struct NoEmitInts {};
+// emit_i (optional): takes the eight samples of a row as ints instead of packed bytes
+template <bool AX, bool AY, typename EMIT, typename EMITI = NoEmitInts>
+static __device__ __forceinline__ void mc_luma_patch(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, bool yh, EMIT emit, EMITI emit_i = EMITI{})
 {
+    auto out8 = [&](int r, const int (&pv)[8]) {
+        if constexpr (std::is_same_v<EMITI, NoEmitInts>) {
+            unsigned pl, ph_;
+            mc_pack8(pv, pl, ph_);
+            emit(r, pl, ph_);
+        } else {
+            emit_i(r, pv);
+        }
+    };
     const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
     const DSVG_GLOBAL uint8_t *ga = gr - shb;
     if (!AY) {
@@ -491,9 +555,7 @@ static __device__ __forceinline__ void mc_luma_patch(const DSVG_GLOBAL uint8_t *
                     const int t = (9 * (bq[i + 1] + bq[i + 2]) - (bq[i] + bq[i + 3]) + 8) >> 4;
                     pv[i] = xh ? d_sat8(t) : bq[i + 1];
                 }
-                unsigned pl, ph_;
-                mc_pack8(pv, pl, ph_);
-                emit(r, pl, ph_);
+                out8(r, pv);
             }
         }
     } else {
@@ -521,9 +583,7 @@ static __device__ __forceinline__ void mc_luma_patch(const DSVG_GLOBAL uint8_t *
                     const int v = yh ? 9 * (h1 + h2) - (h0 + h3) : 16 * h1;
                     pv[i] = d_sat8((v + 128) >> 8);
                 }
-                unsigned pl, ph_;
-                mc_pack8(pv, pl, ph_);
-                emit(r, pl, ph_);
+                out8(r, pv);
             }
         }
     }
@@ -563,6 +623,33 @@ static __device__ __forceinline__ void mc_chroma_patch(const DSVG_GLOBAL uint8_t
             emit(k - 1, pl, ph_);
         }
         qlo = lo; qhi = hi; qx = x8;
+    }
+}
+
+// chroma, waves with a half-pel phase, two samples per instruction: h = a + B per row (B = the right neighbour when the lane's
+// vector has a horizontal phase), prediction = (h_above + (vertical phase ? h_below : h_above) + 2) >> 2 == mc_chroma_patch<true>
+template <typename EMITPK>
+static __device__ __forceinline__ void mc_chroma_patch_pk(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, bool yh, EMITPK emit_pk)
+{
+    const DSVG_GLOBAL uint8_t *g1 = gr + 1;                               // reference (wx, wy-1)
+    const unsigned shb = (unsigned)(((uintptr_t)g1) & 3);
+    const DSVG_GLOBAL uint8_t *ga = g1 - shb;
+    U3A4 rw[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const dsvg_u32x3a4 t = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x3a4 *>(ga + (k + 1) * stride); rw[k] = U3A4{t.x, t.y, t.z}; }
+    __builtin_amdgcn_sched_barrier(0);
+    const s16x2 two = s16x2{2, 2};
+    PkRow hp;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), hi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
+                       x8 = rw[k].z >> (8 * shb);
+        const s16x2 A0 = PK_EVEN(0u, lo), A1 = PK_ODD(0u, lo), A2 = PK_E2(hi, lo), A4 = PK_EVEN(0u, hi), A5 = PK_ODD(0u, hi), A6 = PK_E2(x8, hi);
+        const PkRow h = PkRow{A0 + (xh ? A1 : A0), A4 + (xh ? A5 : A4), A1 + (xh ? A2 : A1), A5 + (xh ? A6 : A5)};
+        if (k >= 1)
+            emit_pk(k - 1, PkRow{(hp.e0 + (yh ? h.e0 : hp.e0) + two) >> 2, (hp.e1 + (yh ? h.e1 : hp.e1) + two) >> 2,
+                                 (hp.o0 + (yh ? h.o0 : hp.o0) + two) >> 2, (hp.o1 + (yh ? h.o1 : hp.o1) + two) >> 2});
+        hp = h;
     }
 }
 
@@ -610,6 +697,31 @@ static __device__ __forceinline__ void fwd_fast_rows1(const QCtx &q, const QLeve
             if (shl[i]) q.put_sparse(L1.base1 + pr + i, shl[i]);
             if (shh[i]) q.put_sparse(L1.base2 + pr + i, shh[i]);
         }
+    }
+}
+// the same on packed rows: 16 v_pk instructions for the four cells; the all-zero test is exact (a symbol is zero iff
+// |detail| < 2^shift; details are at most 1020)
+static __device__ __forceinline__ void fwd_fast_rows1_pk(const QCtx &q, const QLevel &L1, int sh1, int cx1, int cy1,
+                                                         const PkRow &r0, const PkRow &r1, int (&out)[4])
+{
+    const s16x2 s0a = r0.e0 + r0.o0, s0b = r0.e1 + r0.o1, d0a = r0.e0 - r0.o0, d0b = r0.e1 - r0.o1;
+    const s16x2 s1a = r1.e0 + r1.o0, s1b = r1.e1 + r1.o1, d1a = r1.e0 - r1.o0, d1b = r1.e1 - r1.o1;
+    const s16x2 lla = s0a + s1a, llb = s0b + s1b;              // cells (0, 1), (2, 3); level 1 of a P picture is unscaled (LVL_TEST sbt.c:22)
+    const s16x2 lha = d0a + d1a, lhb = d0b + d1b, hla = s0a - s1a, hlb = s0b - s1b, hha = d0a - d1a, hhb = d0b - d1b;
+    out[0] = lla.x; out[1] = lla.y; out[2] = llb.x; out[3] = llb.y;
+    const s16x2 mx = pk_max(pk_max(pk_max(lha, lhb), pk_max(hla, hlb)), pk_max(hha, hhb));
+    const s16x2 mn = pk_min(pk_min(pk_min(lha, lhb), pk_min(hla, hlb)), pk_min(hha, hhb));
+    const s16x2 am = pk_max(mx, s16x2{0, 0} - mn);
+    if ((pk_b(am) & ~(((1u << min(sh1, 15)) - 1u) * 0x00010001u)) == 0) return;
+    q.nz_any = 1;
+    const int lh[4] = {lha.x, lha.y, lhb.x, lhb.y}, hl[4] = {hla.x, hla.y, hlb.x, hlb.y}, hh[4] = {hha.x, hha.y, hhb.x, hhb.y};
+    const int pr = cy1 * L1.sw + cx1;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int slh = sym_shift(lh[i], sh1), shl = sym_shift(hl[i], sh1), shh = sym_shift(hh[i], sh1);
+        if (slh) q.put_sparse(L1.base0 + pr + i, slh);
+        if (shl) q.put_sparse(L1.base1 + pr + i, shl);
+        if (shh) q.put_sparse(L1.base2 + pr + i, shh);
     }
 }
 // one scaled level (transform levels 2, 3: scan levels 1, 0) on an NxN patch of LL values -> LL patch + sparse symbols
@@ -726,6 +838,39 @@ __global__ __launch_bounds__(256) void k_fwd_mc_fast(const JobDev *__restrict__ 
     const auto gr = dsvg_global(static_cast<const uint8_t *>(jb.ref + g.poff)) + ((wy - 1) * stride + (wx - 1));
     const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;     // over the lanes on this path
     const auto pp = dsvg_global(jb.pred + g.poff);
+#ifndef FWD_FAST_NO_PK
+    // residual rows and level 1 on two samples per instruction; the half-pel paths of the bench's kind (luma: horizontal
+    // phases; chroma: any) hand their prediction over in that form already
+    int l1[4][4];
+    PkRow rp[2];
+    const s16x2 cmin = s16x2{-128, -128}, cmax = s16x2{127, 127};
+    auto emit_core = [&](int r, const PkRow &P, unsigned plo, unsigned phi) {
+        const PkRow Sr = pk_unpack8(sw[r].x, sw[r].y);
+        PkRow &R = rp[r & 1];
+        R.e0 = pk_min(pk_max(Sr.e0 - P.e0, cmin), cmax); R.e1 = pk_min(pk_max(Sr.e1 - P.e1, cmin), cmax);       // subf bmc.c:43-55 + p2sbc sbt.c:576
+        R.o0 = pk_min(pk_max(Sr.o0 - P.o0, cmin), cmax); R.o1 = pk_min(pk_max(Sr.o1 - P.o1, cmin), cmax);
+        dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi));
+        if (r & 1) fwd_fast_rows1_pk(q, L1, fq.sh1[r >> 1], 4 * I, 4 * J + (r >> 1), rp[0], rp[1], l1[r >> 1]);
+    };
+    auto emit = [&](int r, unsigned plo, unsigned phi) { emit_core(r, pk_unpack8(plo, phi), plo, phi); };
+    auto emit_pk = [&](int r, const PkRow &P) {
+        unsigned plo, phi;
+        pk_bytes8(P, plo, phi);
+        emit_core(r, P, plo, phi);
+    };
+    // (the vertical filter's 17-bit sums stay in 32-bit lanes: its samples arrive as ints and are paired up here -- never
+    // through packed bytes: the compiler turns sat8(x >> 8) pairs followed by a byte merge into v_ashr_pk_u8_i32 and takes
+    // bits 31:16 of its result for zero, which gfx950 leaves as they were; see the ISA check in the Makefile)
+    auto emit_i = [&](int r, const int (&pv)[8]) { emit_pk(r, PkRow{pk2(pv[0], pv[2]), pk2(pv[4], pv[6]), pk2(pv[1], pv[3]), pk2(pv[5], pv[7])}); };
+    if (CH == 0) {
+        if (any_y) mc_luma_patch<true, true>(gr, stride, xh, yh, emit, emit_i);
+        else if (any_x) mc_luma_patch_hpk(gr, stride, xh, emit_pk);
+        else mc_luma_patch<false, false>(gr, stride, xh, yh, emit);
+    } else {
+        if (any_x || any_y) mc_chroma_patch_pk(gr, stride, xh, yh, emit_pk);
+        else mc_chroma_patch<false>(gr, stride, xh, yh, emit);
+    }
+#else
     int l1[4][4], ra[2][8];
     auto emit = [&](int r, unsigned plo, unsigned phi) {
         int (&row)[8] = ra[r & 1];
@@ -746,6 +891,7 @@ __global__ __launch_bounds__(256) void k_fwd_mc_fast(const JobDev *__restrict__ 
         if (any_x || any_y) mc_chroma_patch<true>(gr, stride, xh, yh, emit);
         else mc_chroma_patch<false>(gr, stride, xh, yh, emit);
     }
+#endif
     int l2[2][2], l3[1][1];
     fwd_fast_level<4, 1>(q, L2, fq.q2, fq.rc2, 2 * I, 2 * J, l1, l2);
     const int q3v[1] = {fq.q3};
@@ -1525,10 +1671,6 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
 // details <= 1020, reconstructed LL1 (the level-2 outputs in A1) <= ~7000, so lp - ln <= 14000, mn - mx <= 28000 and
 // the output sums <= 10100 -- all inside int16.  The decoder, which must follow the reference on arbitrary streams,
 // keeps the 32-bit cells.
-typedef short s16x2 __attribute__((ext_vector_type(2)));
-static __device__ __forceinline__ s16x2 pk2(int a, int b) { return s16x2{(short)a, (short)b}; }
-static __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
-static __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
 static __device__ __forceinline__ s16x2 pk_rdiv2(s16x2 v) { return (v + (short)1 + (v >> 15)) >> 1; }
 static __device__ __forceinline__ s16x2 pk_rdiv4(s16x2 v) { return (v + (short)2 + (v >> 15)) >> 2; }
 static __device__ __forceinline__ s16x2 pk_div4(s16x2 v) { return (v + ((v >> 15) & (short)3)) >> 2; }
@@ -2265,6 +2407,13 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
     const bool inplace = (const DSVG_GLOBAL uint8_t *)outp == pred;
     const unsigned stride = (unsigned)g.pstride, p0 = (unsigned)(8 * J) * stride + 8u * (unsigned)I;
+#ifndef PATCH_C_NO_HOIST
+    // the prediction rows are asked for together with the patch's LL value and flag: one round trip in front of the stores
+    // instead of two
+    uint2 pv[8];
+#pragma unroll
+    for (int r = 0; r < 8; r++) pv[r] = dsvg_ld2(pred + (p0 + r * stride));
+#endif
     if (!pf) {
         const int v3 = d_div4<true>(d_ll_up_t<true>(ll3));
         const int v2 = d_div4<true>(d_ll_up_t<true>(v3));
@@ -2273,13 +2422,19 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
         if (cv == 0) {                                          // reconstruction = prediction
             if (inplace) return;
 #pragma unroll
+#ifndef PATCH_C_NO_HOIST
+            for (int r = 0; r < 8; r++) dsvg_st2(outp + (p0 + r * stride), pv[r]);
+#else
             for (int r = 0; r < 8; r++) dsvg_st2(outp + (p0 + r * stride), dsvg_ld2(pred + (p0 + r * stride)));
+#endif
             return;
         }
         const s16x2 cc = s16x2{(short)cv, (short)cv};
+#ifdef PATCH_C_NO_HOIST
         uint2 pv[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) pv[r] = dsvg_ld2(pred + (p0 + r * stride));
+#endif
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             unsigned o[2];
@@ -2341,11 +2496,15 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
             const int r = 2 * j + rr;
-            const uint2 pv = dsvg_ld2(pred + (p0 + r * stride));
+#ifndef PATCH_C_NO_HOIST
+            const uint2 pw2 = pv[r];
+#else
+            const uint2 pw2 = dsvg_ld2(pred + (p0 + r * stride));
+#endif
             unsigned lo = 0, hi = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                const int p = (int)(((i < 4 ? pv.x : pv.y) >> (8 * (i & 3))) & 0xff);
+                const int p = (int)(((i < 4 ? pw2.x : pw2.y) >> (8 * (i & 3))) & 0xff);
                 const int sv = d_sat8(d_sat8((rr ? r1[i] : r0[i]) + 128) + p - 128);      // sbc2int, then dsv_frame_add / addf bmc.c:29-41
                 if (i < 4) lo |= (unsigned)sv << (8 * i); else hi |= (unsigned)sv << (8 * (i - 4));
             }
