@@ -588,6 +588,45 @@ static __device__ __forceinline__ void mc_luma_patch(const DSVG_GLOBAL uint8_t *
         }
     }
 }
+// luma, waves with a vertical half-pel phase (mc_luma_patch<AX, true>): the horizontal stage H = 9 (b + c) - (a + d) or 16 b
+// (-510 .. 4590) on two samples per instruction, four rows of it kept as int16 pairs; the vertical stage pairs up
+// u = h1 + h2, w = h0 + h3 (lanes without a vertical phase: u = w = 2 h1, 9 u - w = 16 h1) in 16 bits and finishes
+// 9 u - w in 32 (17-bit sums)
+template <bool AX, typename EMITPK>
+static __device__ __forceinline__ void mc_luma_patch_vpk(const DSVG_GLOBAL uint8_t *gr, int stride, bool xh, bool yh, EMITPK emit_pk)
+{
+    const unsigned shb = (unsigned)(((uintptr_t)gr) & 3);
+    const DSVG_GLOBAL uint8_t *ga = gr - shb;
+    U4A4 rw[11];
+#pragma unroll
+    for (int k = 0; k < 11; k++) { const dsvg_u32x4a4 t = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(ga + k * stride); rw[k] = U4A4{t.x, t.y, t.z, t.w}; }
+    __builtin_amdgcn_sched_barrier(0);
+    auto Hrow = [&](s16x2 a, s16x2 b, s16x2 c, s16x2 d) {
+        const s16x2 g = b << 4;
+        if (!AX) return g;
+        const s16x2 f = (b + c) * (short)9 - (a + d);
+        return xh ? f : g;
+    };
+    auto V = [&](s16x2 a0, s16x2 a1, s16x2 a2, s16x2 a3) {
+        const s16x2 u = a1 + (yh ? a2 : a1), w = (yh ? a0 : a1) + (yh ? a3 : a1);
+        const int vx = (9 * (int)u.x - (int)w.x + 128) >> 8, vy = (9 * (int)u.y - (int)w.y + 128) >> 8;
+        return pk2(d_sat8(vx), d_sat8(vy));
+    };
+    PkRow Hq[4];
+#pragma unroll
+    for (int k = 0; k < 11; k++) {
+        const unsigned lo = __builtin_amdgcn_alignbyte(rw[k].y, rw[k].x, shb), mi = __builtin_amdgcn_alignbyte(rw[k].z, rw[k].y, shb),
+                       hi = __builtin_amdgcn_alignbyte(rw[k].w, rw[k].z, shb);
+        const s16x2 A0 = PK_EVEN(0u, lo), A1 = PK_ODD(0u, lo), A2 = PK_E2(mi, lo), A3 = PK_O2(mi, lo), A4 = PK_EVEN(0u, mi), A5 = PK_ODD(0u, mi),
+                    A6 = PK_E2(hi, mi), A7 = PK_O2(hi, mi), A8 = PK_EVEN(0u, hi);
+        Hq[k & 3] = PkRow{Hrow(A0, A1, A2, A3), Hrow(A4, A5, A6, A7), Hrow(A1, A2, A3, A4), Hrow(A5, A6, A7, A8)};
+        if (k >= 3) {
+            const int r = k - 3;
+            const PkRow &h0 = Hq[r & 3], &h1 = Hq[(r + 1) & 3], &h2 = Hq[(r + 2) & 3], &h3 = Hq[(r + 3) & 3];
+            emit_pk(r, PkRow{V(h0.e0, h1.e0, h2.e0, h3.e0), V(h0.e1, h1.e1, h2.e1, h3.e1), V(h0.o0, h1.o0, h2.o0, h3.o0), V(h0.o1, h1.o1, h2.o1, h3.o1)});
+        }
+    }
+}
 // Chroma prediction of one 8x8 patch, gr = &reference(wx-1, wy-1).  ANY: some lane of the wave has a half-pel phase.
 // Bytes wx .. wx+8 of a row: 9 + misalignment <= 12, three dwords.
 struct __attribute__((aligned(4))) U3A4 { unsigned x, y, z; };
@@ -783,8 +822,8 @@ static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, cons
 }
 
 template <int CH>
-__global__ __launch_bounds__(256) void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
-                                                     const DMV *__restrict__ mvs0)
+static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict__ jobs, const SbtGeo3 &G, const McGeo &MG, int c0, int npl,
+                                                        const DMV *__restrict__ mvs0)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
     const SbtGeo g = G.g[c];
@@ -861,9 +900,16 @@ __global__ __launch_bounds__(256) void k_fwd_mc_fast(const JobDev *__restrict__ 
     // (the vertical filter's 17-bit sums stay in 32-bit lanes: its samples arrive as ints and are paired up here -- never
     // through packed bytes: the compiler turns sat8(x >> 8) pairs followed by a byte merge into v_ashr_pk_u8_i32 and takes
     // bits 31:16 of its result for zero, which gfx950 leaves as they were; see the ISA check in the Makefile)
+#ifdef FWD_FAST_NO_VPK
     auto emit_i = [&](int r, const int (&pv)[8]) { emit_pk(r, PkRow{pk2(pv[0], pv[2]), pk2(pv[4], pv[6]), pk2(pv[1], pv[3]), pk2(pv[5], pv[7])}); };
+#endif
     if (CH == 0) {
+#ifdef FWD_FAST_NO_VPK
         if (any_y) mc_luma_patch<true, true>(gr, stride, xh, yh, emit, emit_i);
+#else
+        if (any_y && any_x) mc_luma_patch_vpk<true>(gr, stride, xh, yh, emit_pk);
+        else if (any_y) mc_luma_patch_vpk<false>(gr, stride, xh, yh, emit_pk);
+#endif
         else if (any_x) mc_luma_patch_hpk(gr, stride, xh, emit_pk);
         else mc_luma_patch<false, false>(gr, stride, xh, yh, emit);
     } else {
@@ -899,6 +945,38 @@ __global__ __launch_bounds__(256) void k_fwd_mc_fast(const JobDev *__restrict__ 
     fwd_fast_level<2, 0>(q, L3, q3v, rc3v, I, J, l2, l3);
     dsvg_global(jb.s3 + g.s3off)[(unsigned)(J * g.w3 + I)] = l3[0][0];
     dsvg_global(jb.pflag + g.s3off)[(unsigned)(J * g.w3 + I)] = (uint8_t)q.nz_any;
+}
+// Occupancy per plane kind, measured (160-GOP step): luma 4 waves per SIMD 2.60 ms, 5 (what its 96 VGPRs would give) 2.65,
+// 3: 2.98; chroma at the 5 its registers give 1.31, 4: 1.31-1.39, 6 (spills): 1.72
+#ifndef FAST_WPE_L
+#define FAST_WPE_L 4
+#endif
+#ifndef FAST_WPE_C
+#define FAST_WPE_C 0
+#endif
+#if FAST_WPE_L > 0
+#define FAST_WPE_L_ATTR __attribute__((amdgpu_waves_per_eu(FAST_WPE_L, FAST_WPE_L)))
+#else
+#define FAST_WPE_L_ATTR
+#endif
+#if FAST_WPE_C > 0
+#define FAST_WPE_C_ATTR __attribute__((amdgpu_waves_per_eu(FAST_WPE_C, FAST_WPE_C)))
+#else
+#define FAST_WPE_C_ATTR
+#endif
+template <int CH>
+__global__ void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0);
+template <>
+__global__ __launch_bounds__(256) FAST_WPE_L_ATTR void k_fwd_mc_fast<0>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
+                                                                        const DMV *__restrict__ mvs0)
+{
+    fwd_mc_fast_body<0>(jobs, G, MG, c0, npl, mvs0);
+}
+template <>
+__global__ __launch_bounds__(256) FAST_WPE_C_ATTR void k_fwd_mc_fast<1>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
+                                                                        const DMV *__restrict__ mvs0)
+{
+    fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0);
 }
 
 // four waves per SIMD (128 VGPRs, a few dwords spilled) measured against three without spills: luma the same, chroma 4 % faster
@@ -2407,13 +2485,6 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
     const bool inplace = (const DSVG_GLOBAL uint8_t *)outp == pred;
     const unsigned stride = (unsigned)g.pstride, p0 = (unsigned)(8 * J) * stride + 8u * (unsigned)I;
-#ifndef PATCH_C_NO_HOIST
-    // the prediction rows are asked for together with the patch's LL value and flag: one round trip in front of the stores
-    // instead of two
-    uint2 pv[8];
-#pragma unroll
-    for (int r = 0; r < 8; r++) pv[r] = dsvg_ld2(pred + (p0 + r * stride));
-#endif
     if (!pf) {
         const int v3 = d_div4<true>(d_ll_up_t<true>(ll3));
         const int v2 = d_div4<true>(d_ll_up_t<true>(v3));
@@ -2422,19 +2493,13 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
         if (cv == 0) {                                          // reconstruction = prediction
             if (inplace) return;
 #pragma unroll
-#ifndef PATCH_C_NO_HOIST
-            for (int r = 0; r < 8; r++) dsvg_st2(outp + (p0 + r * stride), pv[r]);
-#else
             for (int r = 0; r < 8; r++) dsvg_st2(outp + (p0 + r * stride), dsvg_ld2(pred + (p0 + r * stride)));
-#endif
             return;
         }
         const s16x2 cc = s16x2{(short)cv, (short)cv};
-#ifdef PATCH_C_NO_HOIST
         uint2 pv[8];
 #pragma unroll
         for (int r = 0; r < 8; r++) pv[r] = dsvg_ld2(pred + (p0 + r * stride));
-#endif
 #pragma unroll
         for (int r = 0; r < 8; r++) {
             unsigned o[2];
@@ -2496,11 +2561,7 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
 #pragma unroll
         for (int rr = 0; rr < 2; rr++) {
             const int r = 2 * j + rr;
-#ifndef PATCH_C_NO_HOIST
-            const uint2 pw2 = pv[r];
-#else
             const uint2 pw2 = dsvg_ld2(pred + (p0 + r * stride));
-#endif
             unsigned lo = 0, hi = 0;
 #pragma unroll
             for (int i = 0; i < 8; i++) {
