@@ -777,10 +777,15 @@ static __device__ __forceinline__ void fwd_fast_level(const QCtx &q, const QLeve
             const int a = in[2 * j][2 * i], b = in[2 * j][2 * i + 1], c = in[2 * j + 1][2 * i], d = in[2 * j + 1][2 * i + 1];
             const int s0 = a + b, s1 = c + d, d0 = a - b, d1 = c - d;
             out[j][i] = d_ll_down(s0 + s1);
+            // a symbol is floor((2 |v| + 1) / 2q): zero iff |v| < q -- one test per cell in front of the three divisions
+            const int vlh = d0 + d1, vhl = s0 - s1, vhh = d0 - d1;
+#ifndef FWD_FAST_NO_QTEST
+            if (max(max(max(vlh, vhl), vhh), -min(min(vlh, vhl), vhh)) < qq) continue;
+#endif
             int slh, shl, shh;
-            (void)q_coef<HZL>(qq, rc, d0 + d1, slh);
-            (void)q_coef<HZL>(qq, rc, s0 - s1, shl);
-            (void)q_coef<HZL>(qq, rc, d0 - d1, shh);
+            (void)q_coef<HZL>(qq, rc, vlh, slh);
+            (void)q_coef<HZL>(qq, rc, vhl, shl);
+            (void)q_coef<HZL>(qq, rc, vhh, shh);
             if (slh | shl | shh) {
                 q.nz_any = 1;
                 const int pr = (cy0 + j) * L.sw + cx0 + i;
