@@ -23,6 +23,14 @@
 #include "dsvg_kernels.hpp"
 #include "dsvg_host.hpp"
 
+// which row-load sites of the full-block body take global_load's SGPR-base form (see lane_ro): 1 source block, 2 inherited
+// candidates, 4 the +-1 search, 8 zero-motion rows, 16 chroma blocks.  Measured per 160-GOP step: none 4.35 ms, 2+4: 4.30,
+// 2+4+8: 4.29, all: 4.35 (the source and chroma loads sit at the head of a dependency chain: scalar row steps in front of
+// each of them cost what the vector adds saved)
+#ifndef HME_SADDR_SITES
+#define HME_SADDR_SITES 14
+#endif
+#define HME_LRO_BARRIER(site, x) do { if ((HME_SADDR_SITES) & (site)) asm volatile("" : "+v"(x)); } while (0)
 #define NT 64              // threads per workgroup = ONE wave per block: 16 column groups x 4 row groups, no cross-wave exchange
 #define NRG (NT / 16)
 #define NK (64 / NRG)       // rows per thread
@@ -225,14 +233,28 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 #define ROWOK(k) (FAST || ((k) < nkb && r0 + (k) < bh))
     const bool uni = FAST || (bh % NRG) == 0;           // every lane owns exactly nkb rows
     const int xcol = 4 * cg;
+    // full blocks: a row load is (wave-uniform row base in SGPRs) + (this lane's constant offset: its first row and column) --
+    // global_load's SGPR-base form, the row step is two scalar adds instead of a 64-bit vector add per row and lane (the
+    // launcher takes this body only when the stride is a multiple of 4: the misalignment of a row is then wave-uniform too).
+    // The compiler picks that form only when it sees the offset's zero extension in the block of the load: each site
+    // takes its copy through an empty asm, or the hoisted 64-bit pair ends in a v_lshl_add_u64 per row again.
+    const unsigned lane_ro = (unsigned)(r0 * stride + xcol);
     const unsigned cmask = FAST ? 0xffffffffu : (xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u)));
     unsigned srcw[NKR];
+    if constexpr (FAST) {
+        auto sq = dsvg_global(sp + (long)by * stride + bx);
+        unsigned lro = lane_ro;
+        HME_LRO_BARRIER(1, lro);
 #pragma unroll
-    for (int k = 0; k < NKR; k++) {
-        const int r = r0 + k;
-        srcw[k] = 0;
-        if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
-        srcw[k] &= cmask;
+        for (int k = 0; k < NKR; k++) { srcw[k] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(sq + lro); sq += stride; }
+    } else {
+#pragma unroll
+        for (int k = 0; k < NKR; k++) {
+            const int r = r0 + k;
+            srcw[k] = 0;
+            if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
+            srcw[k] &= cmask;
+        }
     }
     // parents (hme.c:452-480): every lane reads the same five vectors (wave-uniform addresses -> SGPRs) and
     // de-duplicates them in registers in the reference's order -- no LDS hand-off, no barrier
@@ -280,12 +302,14 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                     validmask |= 1u << k;
                     if constexpr (FAST) {
                         // every row exists in every lane: NKB 8-byte loads back to back off a running pointer, then the SADs
-                        const uint8_t *p0 = rp + (long)(by + cdy + r0) * stride + bx + cdx + xcol;
-                        const unsigned sh = (unsigned)(((uintptr_t)p0) & 3);
-                        const uint8_t *q = p0 - sh;
+                        const uint8_t *ub = rp + (long)(by + cdy) * stride + (bx + cdx);
+                        const unsigned sh = (unsigned)(((uintptr_t)ub) & 3);
+                        auto q = dsvg_global(ub - sh);
+                        unsigned lro = lane_ro;
+                        HME_LRO_BARRIER(2, lro);              // (the zero extension stays next to the loads: see lane_ro)
                         uint2 w[NKB];
 #pragma unroll
-                        for (int u = 0; u < NKB; u++) { w[u] = *reinterpret_cast<const uint2 *>(q); q += stride; }
+                        for (int u = 0; u < NKB; u++) { w[u] = dsvg_ld2(q + lro); q += stride; }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < NKB; u++) acc[k] = __builtin_amdgcn_sad_u8(srcw[u], __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh), acc[k]);
@@ -353,9 +377,11 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 #pragma unroll
         for (int k = 0; k < 9; k++) acc[k] = 0;
         if constexpr (FAST) {
-            const uint8_t *g0 = rp + (long)(by + dy - 1 + r0) * stride + (bx + dx - 1 + xcol);
+            const uint8_t *g0 = rp + (long)(by + dy - 1) * stride + (bx + dx - 1);
             const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
-            const uint8_t *q = g0 - mis;
+            auto q = dsvg_global(g0 - mis);
+            unsigned lro = lane_ro;
+            HME_LRO_BARRIER(4, lro);
             constexpr int NR = NKB + 2, HB = (NR + 2) / 3;     // reference rows, rows per batch (three batches: registers)
             unsigned v[3][3];                                  // rolling: v[t % 3][ox] = reference row t, offset ox
 #pragma unroll
@@ -363,7 +389,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 struct __attribute__((aligned(4))) U3 { unsigned x, y, z; } d[HB];
 #pragma unroll
                 for (int u = 0; u < HB; u++)
-                    if (b0 + u < NR) { d[u] = *reinterpret_cast<const U3 *>(q); q += stride; }
+                    if (b0 + u < NR) { const dsvg_u32x3a4 t3 = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x3a4 *>(q + lro); d[u] = U3{t3.x, t3.y, t3.z}; q += stride; }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < HB; u++) {
@@ -455,9 +481,11 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     unsigned zpre[NKR], cpre[4][4];
     bool cpre_ok = false;
     if constexpr (FAST) {
-        const uint8_t *zq = rp + (long)(by + r0) * stride + bx + xcol;
+        auto zq = dsvg_global(rp + (long)by * stride + bx);
+        unsigned lro = lane_ro;
+        HME_LRO_BARRIER(8, lro);
 #pragma unroll
-        for (int kk = 0; kk < NKR; kk++) { zpre[kk] = *reinterpret_cast<const unsigned *>(zq); zq += stride; }
+        for (int kk = 0; kk < NKR; kk++) { zpre[kk] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }
         const FrameLayout &L0 = A.L[0];
         const int cbw = bw >> L0.hs, cbh = bh >> L0.vs, ndw = cbw >> 2, rpp = ndw ? NT / ndw : NT + 1;
         const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
@@ -467,15 +495,21 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         if (cpre_ok) {
             // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
             const int sh = 31 - __clz(ndw), npass = cbh / rpp;
-            const long o0 = (long)(cby + (tid >> sh)) * L0.stride[1] + cbx + 4 * (tid & (ndw - 1)), adv = (long)rpp * L0.stride[1];
-            const uint8_t *q0 = fbs + L0.off[1] + o0, *q1 = fbs + L0.off[2] + o0, *q2 = fbr + L0.off[1] + o0, *q3 = fbr + L0.off[2] + o0;
+            // (wave-uniform bases + one 32-bit lane offset, as the luma rows)
+            const long ob = (long)cby * L0.stride[1] + cbx, adv = (long)rpp * L0.stride[1];
+            const unsigned clo = (unsigned)((tid >> sh) * L0.stride[1] + 4 * (tid & (ndw - 1)));
+            auto q0 = dsvg_global(fbs + L0.off[1] + ob), q1 = dsvg_global(fbs + L0.off[2] + ob), q2 = dsvg_global(fbr + L0.off[1] + ob), q3 = dsvg_global(fbr + L0.off[2] + ob);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
-                const bool on = u < npass;                             // wave-uniform
-                cpre[u][0] = on ? *reinterpret_cast<const unsigned *>(q0) : 0u;
-                cpre[u][1] = on ? *reinterpret_cast<const unsigned *>(q1) : 0u;
-                cpre[u][2] = on ? *reinterpret_cast<const unsigned *>(q2) : 0u;
-                cpre[u][3] = on ? *reinterpret_cast<const unsigned *>(q3) : 0u;
+                cpre[u][0] = cpre[u][1] = cpre[u][2] = cpre[u][3] = 0u;
+                if (u < npass) {                                       // wave-uniform
+                    unsigned c2 = clo;
+                    HME_LRO_BARRIER(16, c2);                               // (per block of code: see lane_ro)
+                    cpre[u][0] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q0 + c2);
+                    cpre[u][1] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q1 + c2);
+                    cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c2);
+                    cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c2);
+                }
                 q0 += adv; q1 += adv; q2 += adv; q3 += adv;
             }
         }
@@ -851,7 +885,7 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         const dim3 blk(NT);
         // rows per lane of a full block (64 wide, blk_h = 4 * rows): those blocks take the specialised body, in a launch of
         // their own; the partial blocks at the right / bottom edge of the level's frame the generic one
-        const int nkbf = (A.blk_w == 64 && (A.blk_h == 64 || A.blk_h == 48 || A.blk_h == 32)) ? A.blk_h / 4 : 0;
+        const int nkbf = (A.blk_w == 64 && (A.blk_h == 64 || A.blk_h == 48 || A.blk_h == 32) && (A.L[level].stride[0] & 3) == 0) ? A.blk_h / 4 : 0;
         const int fw = A.L[level].w[0], fh = A.L[level].h[0];
         const int fullx = nkbf ? std::min(nvx, fw / 64) : 0, fully = nkbf ? std::min(nvy, fh / A.blk_h) : 0;
         const int nfull = fullx * fully, nrest = nvx * nvy - nfull;
