@@ -463,6 +463,9 @@ typedef short s16x2 __attribute__((ext_vector_type(2)));
 static __device__ __forceinline__ s16x2 pk2(int a, int b) { return s16x2{(short)a, (short)b}; }
 static __device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
 static __device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+static __device__ __forceinline__ s16x2 pk_rdiv2(s16x2 v) { return (v + (short)1 + (v >> 15)) >> 1; }
+static __device__ __forceinline__ s16x2 pk_rdiv4(s16x2 v) { return (v + (short)2 + (v >> 15)) >> 2; }
+static __device__ __forceinline__ s16x2 pk_div4(s16x2 v) { return (v + ((v >> 15) & (short)3)) >> 2; }
 // Eight 8-bit samples of a row as four registers of two int16 (v_pk_*_i16 works on two samples per instruction):
 // e0 = (p0, p2), e1 = (p4, p6), o0 = (p1, p3), o1 = (p5, p7) -- a sample and its right neighbour sit in the same half of
 // an e / o pair, which is what the horizontal steps (half-pel filters, Haar level 1) combine.
@@ -1144,6 +1147,104 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
         q_flags<2, 4>(q, Lq, 4 * I, 4 * J, hw, hh, cls);
         chx = q.any_ov && I == 0; chy = q.any_ov && J == 0;
     }
+#ifndef FWD_B4T_NO_PK
+    if constexpr (Q) {
+        // The encoder's body on int16 pairs (cells (0,1) and (2,3) of the patch side by side, v_pk_*_i16): samples are 8 bit,
+        // the row pass stays within +-1018 before its rounding, the column pass within +-4072.  Picture edges are byte fix-ups of
+        // the row's window (left mirror x[-1] = x[1], right clamp x[W] = x[W-1]; rows mirror / clamp by address); a patch whose
+        // eight samples do not all exist (width not a multiple of 8) takes the scalar body below.
+        if (W - 1 - 8 * I >= 7) {
+            const bool ledge = I == 0, redge = 8 * I + 8 > W - 1;
+            const auto pxg = dsvg_global(px);
+            s16x2 RL[4][2], RH[4][2];
+            s16x2 shv[4][2];
+#pragma unroll
+            for (int m = 0; m < 4; m++)
+#pragma unroll
+                for (int h = 0; h < 2; h++)      // 16-bit shifts take four bits: |value| < 2^12, so 15 stands for anything larger
+                    shv[m][h] = s16x2{(short)min(cls[m][2 * h] ? Lq.sh1 : Lq.sh0, 15), (short)min(cls[m][2 * h + 1] ? Lq.sh1 : Lq.sh0, 15)};
+            const s16x2 c512 = s16x2{512, 512};
+#pragma unroll
+            for (int r = 0; r < 10; r++) {
+                int y = 8 * J - 1 + r;
+                y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
+                unsigned lo = 0x80808080u, mi = 0x80808080u, hi = 0x80808080u;      // bytes x = 8I-1 .. 8I+2, +3 .. +6, +7 .. (sample 0 = byte 128)
+                if (y < g.ph) {
+                    const unsigned ro = (unsigned)(y * g.pstride + 8 * I);
+                    const uint2 mm = dsvg_ld2(pxg + ro);
+                    const unsigned lft = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro - 4u);
+                    const unsigned rgt = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro + 8u);
+                    lo = __builtin_amdgcn_alignbyte(mm.x, lft, 3u);
+                    mi = __builtin_amdgcn_alignbyte(mm.y, mm.x, 3u);
+                    hi = __builtin_amdgcn_alignbyte(rgt, mm.y, 3u);
+                    if (ledge) lo = __builtin_amdgcn_perm(0u, lo, 0x03020102u);       // x[-1] = x[1]
+                    if (redge) hi = __builtin_amdgcn_perm(0u, hi, 0x03020000u);       // x[W] = x[W-1]
+                }
+                // A[j] = (byte j, byte j + 2): cell k reads bytes 2k .. 2k+3 as xm, x0, x1, xp
+                const s16x2 A0 = PK_EVEN(0u, lo), A1 = PK_ODD(0u, lo), A2 = PK_E2(mi, lo), A3 = PK_O2(mi, lo), A4 = PK_EVEN(0u, mi), A5 = PK_ODD(0u, mi),
+                            A6 = PK_E2(hi, mi), A7 = PK_O2(hi, mi);
+                // (the -128 of every sample: -512 in the low-pass sum, nothing in the high-pass one)
+                RL[r & 3][0] = pk_rdiv2((A1 + A2) * (short)3 - (A0 + A3) - c512); RH[r & 3][0] = pk_rdiv2((A0 - A3) + (A2 - A1) * (short)3);
+                RL[r & 3][1] = pk_rdiv2((A5 + A6) * (short)3 - (A4 + A7) - c512); RH[r & 3][1] = pk_rdiv2((A4 - A7) + (A6 - A5) * (short)3);
+                if (r >= 3 && ((r - 3) & 1) == 0) {
+                    const int m = (r - 3) >> 1;
+                    const int cy = 4 * J + m;
+                    if (cy < hh) {
+                        int ll[4], slh[4], shl[4], shh[4];
+                        s16x2 plh[2], phl[2], phh[2];
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const s16x2 am = RL[(r - 3) & 3][h], a0 = RL[(r - 2) & 3][h], a1 = RL[(r - 1) & 3][h], ap = RL[r & 3][h];
+                            const s16x2 bm = RH[(r - 3) & 3][h], b0 = RH[(r - 2) & 3][h], b1 = RH[(r - 1) & 3][h], bp = RH[r & 3][h];
+                            const s16x2 pll = pk_rdiv2((a0 + a1) * (short)3 - (am + ap));
+                            phl[h] = pk_rdiv2((am - ap) + (a1 - a0) * (short)3);
+                            plh[h] = pk_rdiv2((b0 + b1) * (short)3 - (bm + bp));
+                            phh[h] = pk_rdiv2((bm - bp) + (b1 - b0) * (short)3);
+                            ll[2 * h] = pll.x; ll[2 * h + 1] = pll.y;
+                        }
+                        if (chx || (m == 0 && chy)) {
+                            // cells two scan regions share (first column / row of the bands): the scalar steps of the body below
+                            int lh[4] = {plh[0].x, plh[0].y, plh[1].x, plh[1].y}, hl[4] = {phl[0].x, phl[0].y, phl[1].x, phl[1].y},
+                                hhv[4] = {phh[0].x, phh[0].y, phh[1].x, phh[1].y};
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                slh[k] = shl[k] = shh[k] = 0;
+                                if (k < nC) {
+                                    if (k == 0 && chx) {
+                                        lh[k] = q_chain(q, 2, hw, cy, lh[k]);
+                                        hhv[k] = q_chain(q, 2, hw, hh + cy, hhv[k]);
+                                    }
+                                    if (m == 0 && chy) {
+                                        hl[k] = q_chain(q, 2, 4 * I + k, hh, hl[k]);
+                                        if (!(k == 0 && chx)) hhv[k] = q_chain(q, 2, hw + 4 * I + k, hh, hhv[k]);
+                                    }
+                                    const int sh = cls[m][k] ? Lq.sh1 : Lq.sh0;
+                                    (void)q_coef<2>(sh, 0.f, lh[k], slh[k]);
+                                    (void)q_coef<2>(sh, 0.f, hl[k], shl[k]);
+                                    (void)q_coef<2>(sh, 0.f, hhv[k], shh[k]);
+                                }
+                            }
+                        } else {
+                            // the shift quantiser (hzcc.c:115-130): symbol = sign(v) (|v| >> shift)
+                            auto qs = [](s16x2 v, s16x2 sh) { const s16x2 sg = v >> 15, a = (v ^ sg) - sg; return ((a >> sh) ^ sg) - sg; };
+#pragma unroll
+                            for (int h = 0; h < 2; h++) {
+                                const s16x2 a = qs(plh[h], shv[m][h]), b = qs(phl[h], shv[m][h]), d = qs(phh[h], shv[m][h]);
+                                slh[2 * h] = a.x; slh[2 * h + 1] = a.y; shl[2 * h] = b.x; shl[2 * h + 1] = b.y; shh[2 * h] = d.x; shh[2 * h + 1] = d.y;
+                            }
+                        }
+                        const int o = cy * Lq.sw + 4 * I;
+                        store_sym_row<4>(q.sym + Lq.base0 + o, slh, nC);
+                        store_sym_row<4>(q.sym + Lq.base1 + o, shl, nC);
+                        store_sym_row<4>(q.sym + Lq.base2 + o, shh, nC);
+                        store_row<4>(jb.s1 + g.s1off + (size_t)cy * g.w1 + 4 * I, ll, nC);
+                    }
+                }
+            }
+            return;
+        }
+    }
+#endif
 #pragma unroll
     for (int r = 0; r < 10; r++) {
         int y = 8 * J - 1 + r;
@@ -1754,9 +1855,6 @@ static __device__ __forceinline__ void inv_cell_vals(const int *pA, int astride,
 // details <= 1020, reconstructed LL1 (the level-2 outputs in A1) <= ~7000, so lp - ln <= 14000, mn - mx <= 28000 and
 // the output sums <= 10100 -- all inside int16.  The decoder, which must follow the reference on arbitrary streams,
 // keeps the 32-bit cells.
-static __device__ __forceinline__ s16x2 pk_rdiv2(s16x2 v) { return (v + (short)1 + (v >> 15)) >> 1; }
-static __device__ __forceinline__ s16x2 pk_rdiv4(s16x2 v) { return (v + (short)2 + (v >> 15)) >> 2; }
-static __device__ __forceinline__ s16x2 pk_div4(s16x2 v) { return (v + ((v >> 15) & (short)3)) >> 2; }
 static __device__ __forceinline__ s16x2 pk_nudge(s16x2 ll, s16x2 lp, s16x2 ln, s16x2 det, short hqp, s16x2 pm = s16x2{-1, -1})      // d_nudge x 2 (pm: lanes that take it)
 {
     const s16x2 a = ll - ln, b = lp - ll, z = {0, 0};
