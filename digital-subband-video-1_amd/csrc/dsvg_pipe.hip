@@ -546,17 +546,24 @@ static int ingest_release(dsvg_ctx *c, int k)
 static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d)
 {
     // the first pyramid level comes out of the unpack kernel when the luma plane allows it (one read of the frame less)
-    const bool fuse1 = with_pyramid && c->levels >= 1 && unpack_fuses_level1(c->L[0]);
+    // (the kernel's fused path needs 16-byte aligned frames: a caller's odd device pointer takes the separate passes)
+    const bool fuse1 = with_pyramid && c->levels >= 1 && unpack_fuses_level1(c->L[0]) && ((uintptr_t)dsrc & 15) == 0 && (pitch & 15) == 0;
     const bool sides = unpack_writes_sides(dsrc, pitch, c->src[0].p, c->L[0]) && !getenv("DSV1_NO_UNPACK_SIDES");
     // the pyramid levels whose width allows it get their side borders from the kernel that writes their rows as well
     static const bool no_lsides = getenv("DSV1_NO_LEVEL_SIDES") != nullptr;
     const bool sides1 = fuse1 && sides && !no_lsides && level_sides_ok(c->src[1].p, c->L[1]);
-    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1);
+    // ... and the second level with it (one pass over level 1 less) when both are exact halvings
+    static const bool no_fuse2 = getenv("DSV1_NO_FUSE_LEVEL2") != nullptr;
+    const bool fuse2 = fuse1 && !no_fuse2 && c->levels >= 2 && unpack_fuses_level2(c->L[0], c->L[1], c->L[2]);
+    const bool sides2 = fuse2 && sides && !no_lsides && level_sides_ok(c->src[2].p, c->L[2]);
+    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1,
+                  fuse2 ? c->src[2].p : nullptr, fuse2 ? &c->L[2] : nullptr, sides2);
     launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
-            bool ls = (l == 1 && fuse1) ? sides1 : false;
-            if (!(l == 1 && fuse1)) {
+            const bool fused = (l == 1 && fuse1) || (l == 2 && fuse2);
+            bool ls = fused ? (l == 1 ? sides1 : sides2) : false;
+            if (!fused) {
                 ls = !no_lsides && level_sides_ok(c->src[l].p, c->L[l]);
                 launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d, ls);
             }

@@ -11,7 +11,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // tightly packed planar frames -> interiors of bordered frames (grid.y = plane, grid.z = frame)
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv, size_t yuv_pitch,
                                                 uint8_t *__restrict__ slab, FrameLayout L, int first_slot,
-                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1, int sides)
+                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1, int sides,
+                                                uint8_t *__restrict__ slab2, FrameLayout L2)
 {
     // sides: the 64-byte left / right borders of every row are written here too (launch_unpack checked that every plane
     // takes a 16-byte path): they complete the 128-byte lines the row's first and last pixels lie in, where a separate
@@ -24,6 +25,77 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
     const uint8_t *src = yuv + (size_t)f * yuv_pitch + poff;
     uint8_t *dst = slab + (size_t)slot * L.pitch + L.off[c];
     const bool vec = ((w & 15) == 0) && ((((uintptr_t)src) & 15) == 0);
+    if (vec && c == 0 && slab1 && slab2 && (h & 3) == 0) {
+        // luma with the first TWO pyramid levels fused in: four rows x 16 pixels per thread -> two rows x 8 of level 1 and
+        // one row x 4 of level 2 (each level the rounded 2x2 mean of the one below, frame.c:240-261); sides & 4: level 2's
+        // side borders too
+        uint8_t *dst1 = slab1 + (size_t)slot * L1.pitch + L1.off[0];
+        uint8_t *dst2 = slab2 + (size_t)slot * L2.pitch + L2.off[0];
+        const int nv = w >> 4, hq = h >> 2;
+        for (int i = blockIdx.x * 256 + threadIdx.x; i < nv * hq; i += gridDim.x * 256) {
+            const int y4 = i / nv, x = i - y4 * nv;
+            u32x4 q[4];
+#pragma unroll
+            for (int r = 0; r < 4; r++) q[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + (size_t)(4 * y4 + r) * w) + x);
+#pragma unroll
+            for (int r = 0; r < 4; r++) __builtin_nontemporal_store(q[r], reinterpret_cast<u32x4 *>(dst + (size_t)(4 * y4 + r) * L.stride[0]) + x);
+            const bool edge = x == 0 || x == nv - 1;
+            if (sides && edge) {
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned v = (x == 0 ? (q[r].x & 0xff) : (q[r].w >> 24)) * 0x01010101u;
+                    uint4 *b = reinterpret_cast<uint4 *>(dst + (size_t)(4 * y4 + r) * L.stride[0] + (x == 0 ? -DSVG_BORDER : w));
+#pragma unroll
+                    for (int k = 0; k < DSVG_BORDER / 16; k++) b[k] = make_uint4(v, v, v, v);
+                }
+            }
+            if (sides && nv == 1) {                              // (a 16-pixel-wide plane: the one column is first and last)
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const unsigned v = (q[r].w >> 24) * 0x01010101u;
+                    uint4 *b = reinterpret_cast<uint4 *>(dst + (size_t)(4 * y4 + r) * L.stride[0] + w);
+#pragma unroll
+                    for (int k = 0; k < DSVG_BORDER / 16; k++) b[k] = make_uint4(v, v, v, v);
+                }
+            }
+            unsigned o1[2][2];
+#pragma unroll
+            for (int p = 0; p < 2; p++) {
+                const unsigned a[4] = {q[2 * p].x, q[2 * p].y, q[2 * p].z, q[2 * p].w}, b[4] = {q[2 * p + 1].x, q[2 * p + 1].y, q[2 * p + 1].z, q[2 * p + 1].w};
+                o1[p][0] = o1[p][1] = 0u;
+#pragma unroll
+                for (int k = 0; k < 8; k++) {
+                    const unsigned wa = a[k >> 1], wb = b[k >> 1];
+                    const int sh = 16 * (k & 1);
+                    const unsigned sum = ((wa >> sh) & 0xff) + ((wa >> (sh + 8)) & 0xff) + ((wb >> sh) & 0xff) + ((wb >> (sh + 8)) & 0xff);
+                    o1[p][k >> 2] |= ((sum + 2) >> 2) << (8 * (k & 3));
+                }
+                *reinterpret_cast<uint2 *>(dst1 + (size_t)(2 * y4 + p) * L1.stride[0] + 8 * x) = make_uint2(o1[p][0], o1[p][1]);
+                if (sides > 1 && (sides & 2) && edge) {
+                    const unsigned v = (x == 0 ? (o1[p][0] & 0xff) : (o1[p][1] >> 24)) * 0x01010101u;
+                    uint4 *bb = reinterpret_cast<uint4 *>(dst1 + (size_t)(2 * y4 + p) * L1.stride[0] + (x == 0 ? -DSVG_BORDER : L1.w[0]));
+#pragma unroll
+                    for (int k = 0; k < DSVG_BORDER / 16; k++) bb[k] = make_uint4(v, v, v, v);
+                }
+            }
+            unsigned o2 = 0u;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned wa = o1[0][k >> 1], wb = o1[1][k >> 1];
+                const int sh = 16 * (k & 1);
+                const unsigned sum = ((wa >> sh) & 0xff) + ((wa >> (sh + 8)) & 0xff) + ((wb >> sh) & 0xff) + ((wb >> (sh + 8)) & 0xff);
+                o2 |= ((sum + 2) >> 2) << (8 * k);
+            }
+            *reinterpret_cast<unsigned *>(dst2 + (size_t)y4 * L2.stride[0] + 4 * x) = o2;
+            if ((sides & 4) && edge) {
+                const unsigned v = (x == 0 ? (o2 & 0xff) : (o2 >> 24)) * 0x01010101u;
+                uint4 *bb = reinterpret_cast<uint4 *>(dst2 + (size_t)y4 * L2.stride[0] + (x == 0 ? -DSVG_BORDER : L2.w[0]));
+#pragma unroll
+                for (int k = 0; k < DSVG_BORDER / 16; k++) bb[k] = make_uint4(v, v, v, v);
+            }
+        }
+        return;
+    }
     if (vec && c == 0 && slab1 && (h & 1) == 0) {
         // luma with the first pyramid level fused in (dsv_ds2x_frame_luma frame.c:240-261: (p1+p2+p3+p4+2)>>2): two rows x 16
         // pixels per thread, so the bordered frame is not read again for the 2x2 means (even dims: no border pixel enters)
@@ -328,6 +400,12 @@ static inline int nblk(long items, int cap) { long b = (items + 255) / 256; retu
 // slab1 / L1: when given (and the luma plane qualifies, see unpack_fuses_level1) the first pyramid level is produced
 // by the same kernel
 int unpack_fuses_level1(const FrameLayout &L) { return (L.w[0] & 15) == 0 && (L.h[0] & 1) == 0; }
+// ... and the second one too: four source rows per thread, both levels exact halvings
+int unpack_fuses_level2(const FrameLayout &L, const FrameLayout &L1, const FrameLayout &L2)
+{
+    return unpack_fuses_level1(L) && (L.h[0] & 3) == 0 && L1.w[0] * 2 == L.w[0] && L1.h[0] * 2 == L.h[0] && L2.w[0] * 4 == L.w[0] && L2.h[0] * 4 == L.h[0] &&
+           (L2.stride[0] & 3) == 0 && (L2.off[0] & 3) == 0 && (L2.pitch & 3) == 0;
+}
 // can k_unpack write the side borders (and launch_extend be told tb_only)?  every plane on a 16-byte path of k_unpack and
 // of k_extend16
 bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *slab, const FrameLayout &L)
@@ -338,12 +416,12 @@ bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *sl
     return ok;
 }
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
-                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1)
+                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2)
 {
     FrameLayout dummy = L;
-    if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0));
+    if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0) + (slab2 ? 0.0625 * n * L.w[0] * L.h[0] : 0.0));
     hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
-                       slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0));
+                       slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0) | (sides && sides2 ? 4 : 0), slab2, L2 ? *L2 : dummy);
     if (pf) pf->end(st);
 }
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)

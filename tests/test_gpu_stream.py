@@ -354,3 +354,20 @@ def test_1080p_two_coding_streams_bit_exact(pkg, orc):
     b.close()
     for s in range(S):
         assert got[s] == want[s & 1], "stream %d: %s" % (s, explain(got[s], want[s & 1]))
+
+
+@pytest.mark.parametrize("shift", [4, 8, 1])
+def test_device_clip_at_an_odd_address(pkg, shift):
+    """A caller's device-resident clip need not be 16-byte aligned: the frame load then takes its scalar paths and the
+    pyramid its separate passes (k_unpack fuses the first two levels only for aligned frames) -- same stream."""
+    w, h, fmt, n = 352, 288, A.SUBSAMP_420, 5
+    cli = dict(qp=85, gop=12, rc_mode_cli=1)
+    clip = A.gen_clip(w, h, fmt, 0x0DD0 + shift, n, style=0)
+    want = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli), eos=False)[0]
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), 1, n)
+    try:
+        base = b.upload(np.concatenate([np.zeros(shift, np.uint8), clip.reshape(-1)]))
+        got = b.encode(C.c_void_p(base.value + shift), on_device=True)[0]
+    finally:
+        b.close()
+    assert got == want
