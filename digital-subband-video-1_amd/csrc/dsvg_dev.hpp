@@ -199,6 +199,18 @@ static __device__ __forceinline__ int d_xcd_remap(int lin, int total)
     return (lin & 7) * per + (lin >> 3);
 }
 static inline int xcd_grid(int total) { return 8 * ((total + 7) / 8); }
+// A logical gx x gy x gz grid launched as xcd_grid(gx * gy * gz) workgroups in one dimension: the workgroup's logical
+// (x, y, z), x fastest -- an XCD then walks whole rows of neighbouring tiles, whose shared cache lines (halo rows, lines
+// that straddle two tiles) are fetched into its L2 once instead of once per XCD.  false: a padding workgroup.
+struct Blk3 { int x, y, z; };
+static __device__ __forceinline__ bool d_xcd_blk3(int gx, int gy, int gz, Blk3 &b, bool plain = false)
+{
+    const int total = gx * gy * gz, item = plain ? (int)blockIdx.x : d_xcd_remap((int)blockIdx.x, total);   // plain: the hardware's round robin (A/B)
+    if (item >= total) return false;
+    const int r = item / gx;
+    b.x = item - r * gx; b.z = r / gy; b.y = r - b.z * gy;
+    return true;
+}
 
 // ---- HZCC quantiser arithmetic shared by the transform-fused path (k_sbt.hip) and k_hzcc.hip -----------
 #define HZ_MINQ 16

@@ -831,11 +831,15 @@ static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, cons
 
 template <int CH>
 static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict__ jobs, const SbtGeo3 &G, const McGeo &MG, int c0, int npl,
-                                                        const DMV *__restrict__ mvs0)
+                                                        const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
 {
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    // one-dimensional launch in XCD order (d_xcd_blk3): the reference rows above and below a workgroup's 32 pixel rows and the
+    // lines its rows share with the workgroup beside it are in the same L2 as the neighbour that reads them too
+    Blk3 B;
+    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
+    const int job = B.z / npl, c = c0 + B.z % npl;
     const SbtGeo g = G.g[c];
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if (I >= g.w3 || J >= g.h3) return;
     const JobDev &jb = jobs[job];
     const int sh = CH ? MG.hs : 0, sv = CH ? MG.vs : 0;
@@ -973,18 +977,18 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
 #define FAST_WPE_C_ATTR
 #endif
 template <int CH>
-__global__ void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0);
+__global__ void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain);
 template <>
 __global__ __launch_bounds__(256) FAST_WPE_L_ATTR void k_fwd_mc_fast<0>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
-                                                                        const DMV *__restrict__ mvs0)
+                                                                        const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
 {
-    fwd_mc_fast_body<0>(jobs, G, MG, c0, npl, mvs0);
+    fwd_mc_fast_body<0>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
 }
 template <>
 __global__ __launch_bounds__(256) FAST_WPE_C_ATTR void k_fwd_mc_fast<1>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
-                                                                        const DMV *__restrict__ mvs0)
+                                                                        const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
 {
-    fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0);
+    fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
 }
 
 // four waves per SIMD (128 VGPRs, a few dwords spilled) measured against three without spills: luma the same, chroma 4 % faster
@@ -2142,7 +2146,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     if (tid < A3H * A3W) A3u[tid] = d_ll_up_t<true>(a3v);
     if (!__syncthreads_or((nzv | a3v) != 0)) {
         // nothing in reach: every output is zero, the reconstruction is the prediction
-        if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+        if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + (((blockIdx.x >> 3) + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
         if ((const DSVG_GLOBAL uint8_t *)outp == pred) return;     // written in place by the forward transform (ping-pong slots)
 #pragma unroll
         for (int u = 0; u < 2; u++) {
@@ -2153,7 +2157,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         }
         return;
     }
-    if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (c != 0) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+    if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (c != 0) + (((blockIdx.x >> 3) + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
 
     // ---- level 3: cells I0-1 .. I0+TX (halo 1) -> LL2 values, scaled up, in A2u
     if (ER && ok3 && I0 - 1 + lx3 >= w3) {
@@ -2252,14 +2256,19 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 // er_col: the tile column that ends exactly where the band ends and takes the ER body (-1: none) -- in the same launch as the
 // interior tiles (as a launch of its own the column's 16 x 160 workgroups took as long as the general kernel's strip did)
 template <bool FILT>
-__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int er_col, int eb_row)
+__global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int er_col, int eb_row,
+                                                                    int gx, int gy, int gz, int plain)
 {
     __shared__ int A3[A3H * A3W];
     __shared__ int A2[A2H * A2W];
     __shared__ unsigned A1p[(4 * IT_TY + 4) * (2 * IT_TX + 2)];
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
-    const int I0 = (int)blockIdx.x * IT_TX, J0 = (int)blockIdx.y * IT_TY;
-    const bool er = (int)blockIdx.x == er_col, eb = (int)blockIdx.y == eb_row;      // (eb_row: the last tile row, likewise)
+    // one-dimensional launch, tiles dealt to the XCDs in contiguous runs (d_xcd_blk3): a tile shares the 128-byte lines its
+    // pixel rows straddle (the 64-pixel border shifts them by half a line) and its halo rows of symbols with its neighbours
+    Blk3 B;
+    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
+    const int job = B.z / npl, c = c0 + B.z % npl;
+    const int I0 = B.x * IT_TX, J0 = B.y * IT_TY;
+    const bool er = B.x == er_col, eb = B.y == eb_row;      // (eb_row: the last tile row, likewise)
     if (er && eb) inv_p_fast<FILT, true, true>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
     else if (er) inv_p_fast<FILT, true, false>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
     else if (eb) inv_p_fast<FILT, false, true>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
@@ -2413,7 +2422,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
         if (!__syncthreads_or(nzv != 0)) {
             const uint8_t *predz = jb.ref != nullptr ? jb.pred + g.poff : nullptr;
             uint8_t *outz = (jb.recon ? jb.recon : jb.xf) + g.poff;
-            if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+            if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (2 + (c != 0)) + (((blockIdx.x >> 3) + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
             if (predz == outz) return;                           // the prediction was written in place (ping-pong slots)
             const int px0t = 8 * I0, py0t = 8 * J0;               // tile origin in pixels
             for (int u = tid; u < (8 * IT_TY) * (8 * IT_TX / 16); u += 256) {
@@ -2430,7 +2439,7 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
             }
             return;
         }
-        if (tid == 0 && jb.stat && jb.nzf) atomicAdd(jb.stat + 64 * (c != 0) + ((blockIdx.x + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+        if (tid == 0 && jb.stat && jb.nzf) atomicAdd(jb.stat + 64 * (c != 0) + (((blockIdx.x >> 3) + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
     } else __syncthreads();
     if (ok3) {      // level TOP: cells I0-1 .. I0+TX (halo 1)
         const int ly = tid / (IT_TX + 2), lx = tid - ly * (IT_TX + 2);
@@ -2574,11 +2583,14 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
 // -- a small LL3 -- the reconstruction is the prediction that is already in place: nothing is loaded or stored.
 // Patches [0, imax) x [0, jmax): whole patches inside the picture; the tile kernel takes the strips beyond.
 // --------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax)
+__global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax,
+                                                     int gx, int gy, int gz, int plain)
 {
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    Blk3 B;                                                 // one-dimensional launch in XCD order (d_xcd_blk3)
+    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
+    const int job = B.z / npl, c = c0 + B.z % npl;
     const SbtGeo g = G.g[c];
-    const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
+    const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if (I >= imax || J >= jmax) return;
     const JobDev &jb = jobs[job];
     const unsigned pidx = (unsigned)(J * g.w3 + I);
@@ -2797,6 +2809,10 @@ __global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs
 // host launchers
 // --------------------------------------------------------------------------------------------
 static inline dim3 grid3(int w3, int h3, int nz) { return dim3((w3 + 63) / 64, (h3 + 3) / 4, nz); }
+// a logical gx x gy x gz grid for a kernel that decodes it with d_xcd_blk3 (DSV1_NO_XCD_ORDER: the A/B switch -- the
+// same kernels with the hardware's round-robin order, i.e. neighbouring tiles on different XCDs)
+static inline dim3 tile_grid(int gx, int gy, int gz) { return dim3(xcd_grid(gx * gy * gz)); }
+static inline int xcd_plain() { static const int v = getenv("DSV1_NO_XCD_ORDER") != nullptr; return v; }
 
 int sbt_tail_supported(const SbtGeo &g)
 {
@@ -2845,8 +2861,9 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         // at the HBM rate of its 3 B/sample: reference + source in, prediction out), the general kernel everything else
         // (picture edges, intra blocks, cells shared between scan regions) and returns at once for the common ones
         PB(c0 == 0 ? KID_FWD_MC_FAST_Y : KID_FWD_MC_FAST_C, smp * 3.0);
-        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_fast<0>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
-        else         hipLaunchKernelGGL((k_fwd_mc_fast<1>), grid3(g.w3, g.h3, nz), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0);
+        const dim3 fg = grid3(g.w3, g.h3, nz);
+        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_fast<0>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, xcd_plain());
+        else         hipLaunchKernelGGL((k_fwd_mc_fast<1>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, xcd_plain());
         PE();
         // Where can a patch fail fwd_fast_sel?  Intra blocks (anywhere: the caller knows), otherwise only in the first /
         // last row or column of patches (cells shared between scan regions, a ragged picture edge) -- unless a patch can
@@ -2970,7 +2987,8 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             const int imax = tcx >= (int)tg.x ? g.w3 : tcx * IT_TX, jmax = tcy >= (int)tg.y ? g.h3 : tcy * IT_TY;
             if (imax > 0 && jmax > 0) {
                 PB(KID_INV_PATCH_C, 64.0 * imax * jmax * nz * 2.0);          // prediction in, reconstruction out (+ 5 B per patch: LL3, flag)
-                hipLaunchKernelGGL(k_inv_patch_c, dim3((imax + 63) / 64, (jmax + 3) / 4, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax);
+                const int cgx = (imax + 63) / 64, cgy = (jmax + 3) / 4;
+                hipLaunchKernelGGL(k_inv_patch_c, tile_grid(cgx, cgy, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax, cgx, cgy, nz, xcd_plain());
                 PE();
             }
             if (tcx < (int)tg.x || tcy < (int)tg.y) {
@@ -2995,8 +3013,9 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
                 const int fxg = er ? fx + 1 : fx, fyg = eb ? fy + 1 : fy;      // tile columns / rows the fast kernel takes
                 const double fsmp = 64.0 * std::min(fxg * IT_TX, g.w3) * std::min(fyg * IT_TY, g.h3) * nz;   // samples of the fast tiles
                 PB(filt ? KID_INV_P_TILE_F : KID_INV_P_TILE, fsmp * 2.5);
-                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), dim3(fxg, fyg, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1);
-                else      hipLaunchKernelGGL((k_inv_p_tile<false>), dim3(fxg, fyg, nz), dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1);
+                const dim3 pg = tile_grid(fxg, fyg, nz);
+                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), pg, dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1, fxg, fyg, nz, xcd_plain());
+                else      hipLaunchKernelGGL((k_inv_p_tile<false>), pg, dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1, fxg, fyg, nz, xcd_plain());
                 PE();
                 const int nrest = ((int)tg.x - fxg) * (int)tg.y + fxg * ((int)tg.y - fyg);      // right strip + bottom strip, one launch
                 if (nrest > 0) {
