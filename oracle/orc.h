@@ -172,11 +172,7 @@ int  orc_dec_packet(orc_decoder *d, const uint8_t *pkt, size_t len, uint8_t *yuv
 void orc_dec_get_meta(const orc_decoder *d, orc_meta *m);
 void orc_dec_close(orc_decoder *d);
 
-/* ---- synthetic clip generator (integer only) ----------------------------- */
-/* writes one planar frame t of the clip identified by (w,h,subsamp,seed,style) into out.
- * style 0 = pan+texture (throughput clips), 1 = + flat moving objects (parity clips) */
-void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t, int style);
-size_t orc_frame_bytes(int w, int h, int subsamp);
+/* (the synthetic clip generator lives in tools/clipgen/clipgen.c: it is input data, not part of the checker) */
 
 #ifdef __cplusplus
 }

@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SO = os.path.join(ROOT, "oracle", "_ref", "libdsv1ref.so")
 REF_CLI = os.path.join(ROOT, "oracle", "_ref", "dsv1")
 ORC_SO = os.path.join(ROOT, "oracle", "liborc.so")
+CLIPGEN_SO = os.path.join(ROOT, "tools", "clipgen", "libclipgen.so")
 PKG_DIR = os.path.join(ROOT, "digital-subband-video-1_amd")
 PROD_SO = os.path.join(PKG_DIR, "libdsv1_mi355x.so")
 
@@ -246,8 +247,6 @@ def load_orc():
         L.orc_dec_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_uint)]
         L.orc_dec_close.argtypes = [C.c_void_p]
         L.orc_dec_get_meta.argtypes = [C.c_void_p, C.POINTER(Meta)]
-        L.orc_frame_bytes.restype = C.c_size_t
-        L.orc_gen_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int]
         L.orc_hme_run.restype = C.c_int
         L.orc_get_quant.restype = C.c_int
         _libs["orc"] = L
@@ -292,13 +291,25 @@ def assert_same(name, got, want, shape=None):
     raise AssertionError("\n".join(msg))
 
 
+def load_clipgen():
+    """the synthetic clip generator (tools/clipgen: neither product nor oracle)"""
+    if "clipgen" not in _libs:
+        if not os.path.exists(CLIPGEN_SO):
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-o", CLIPGEN_SO, os.path.join(ROOT, "tools", "clipgen", "clipgen.c")])
+        L = C.CDLL(CLIPGEN_SO)
+        L.clipgen_frame.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_uint32, C.c_int, C.c_int]
+        _libs["clipgen"] = L
+    return _libs["clipgen"]
+
+
 def gen_clip(w, h, fmt, seed, nframes, style=0, start=0):
-    """synthetic clip (nframes, frame_bytes) via the integer generator oracle/orc_gen.c"""
-    L = load_orc()
+    """synthetic clip (nframes, frame_bytes) via the integer generator tools/clipgen/clipgen.c
+    (style 0 pan + texture, 1 + flat moving objects, 2 static + textured square + luma step, 3 style 0 with scene cuts)"""
+    L = load_clipgen()
     fb = frame_bytes(w, h, fmt)
     out = np.empty((nframes, fb), dtype=np.uint8)
     for t in range(nframes):
-        L.orc_gen_frame(out[t].ctypes.data, w, h, fmt, seed, start + t, style)
+        L.clipgen_frame(out[t].ctypes.data, w, h, fmt, seed, start + t, style)
     return out
 
 

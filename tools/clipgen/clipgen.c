@@ -1,5 +1,7 @@
 /*
- * orc_gen.c -- TEST INFRASTRUCTURE: integer-only synthetic YUV clip generator.
+ * clipgen.c -- integer-only synthetic YUV clip generator: the input of bench.py, the tests and the golden
+ * fixtures.  Not part of the product library and not part of the oracle (it holds no arithmetic of the coded path);
+ * built into tools/clipgen/libclipgen.so by __graft_entry__.build().
  *
  * Stateless: frame t of clip (w,h,subsamp,seed,style) is a pure function of its arguments, so
  * the golden fixtures, the CPU baseline and the GPU bench all see identical bytes.
@@ -11,10 +13,17 @@
  *   style 2: static background (no pan), a fast TEXTURED bright square (blocks it half covers
  *   become intra with partial sub-block masks) and a global +14 luma step from frame 5 on
  *   (scene-change detection).
+ *   style 3: style 0 with SCENE CUTS: every 7 frames the texture is another one and the brightness steps by 12 (the mean
+ *   luma of the smallest pyramid level moves by more than the default scene_change_delta of 4: dsv_encoder.c:538-554).
  */
 #include <stdlib.h>
 #include <string.h>
-#include "orc.h"
+#include <stdint.h>
+#include <stddef.h>
+
+#define RSHIFT_UP(x, s) (((x) + (1 << (s)) - 1) >> (s))   /* DSV_ROUND_SHIFT dsv.h:62 */
+#define HSHIFT(fmt) (((fmt) >> 2) & 3)                /* dsv.h:83 */
+#define VSHIFT(fmt) ((fmt) & 3)                       /* dsv.h:84 */
 
 static inline uint32_t mix(uint32_t a)
 {
@@ -34,16 +43,23 @@ static inline int tri(int v, int period)          /* 0 .. period/2 */
 }
 static inline uint8_t sat8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v)); }
 
-size_t orc_frame_bytes(int w, int h, int subsamp)
+size_t clipgen_frame_bytes(int w, int h, int subsamp)
 {
-    size_t cw = (size_t)ORC_RSHIFT_UP(w, ORC_HSHIFT(subsamp)), ch = (size_t)ORC_RSHIFT_UP(h, ORC_VSHIFT(subsamp));
+    size_t cw = (size_t)RSHIFT_UP(w, HSHIFT(subsamp)), ch = (size_t)RSHIFT_UP(h, VSHIFT(subsamp));
     return (size_t)w * h + 2 * cw * ch;
 }
 
 #define MARGIN 192
 
-void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t, int style)
+void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t, int style)
 {
+    int lift = 0;                                   /* style 3: brightness step of the scene */
+    if (style == 3) {
+        const int scene = t / 7;
+        seed ^= mix(0x5CE9Eu + (uint32_t)scene);
+        lift = 12 * (scene % 3);
+        style = 0;
+    }
     const int TW = w + 2 * MARGIN, TH = h + 2 * MARGIN;
     uint8_t *noise = (uint8_t *)malloc((size_t)TW * TH);
     uint8_t *tex = (uint8_t *)malloc((size_t)TW * TH);
@@ -84,7 +100,7 @@ void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
             int tv = xfrac ? (tr[xi] + tr[xi + 1] + 1) >> 1 : tr[xi];
             int ramp = 64 + (tri(x, 74) * 128 / 37 + tri(y, 46) * 128 / 23) / 2;
             int d = (int)(hash3((uint32_t)x, (uint32_t)y, seed ^ (0xD17Du + (uint32_t)t * 977u)) & 3) - 1;
-            Y[(size_t)y * w + x] = sat8((3 * tv + 2 * ramp) / 5 + d);
+            Y[(size_t)y * w + x] = sat8((3 * tv + 2 * ramp) / 5 + d + lift);
         }
     }
     if (style == 1) {
@@ -110,7 +126,7 @@ void orc_gen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
             for (size_t i = 0; i < (size_t)w * h; i++) Y[i] = sat8(Y[i] + 14);
     }
 
-    const int cw = ORC_RSHIFT_UP(w, ORC_HSHIFT(subsamp)), ch = ORC_RSHIFT_UP(h, ORC_VSHIFT(subsamp));
+    const int cw = RSHIFT_UP(w, HSHIFT(subsamp)), ch = RSHIFT_UP(h, VSHIFT(subsamp));
     uint8_t *U = out + (size_t)w * h, *V = U + (size_t)cw * ch;
     for (int y = 0; y < ch; y++)
         for (int x = 0; x < cw; x++) {

@@ -4,7 +4,7 @@
 Run in the build container only (the reference does not exist on the GPU box):
     make -C oracle ref && python tools/make_goldens.py
 
-A fixture is data: inputs come from the committed integer generator (oracle/orc_gen.c, regenerated at
+A fixture is data: inputs come from the committed integer generator (tools/clipgen/clipgen.c, regenerated at
 test time from (w,h,fmt,seed,style)), expected outputs are produced here by the reference:
   * streams.json   -- for each stream case: CLI flags, sha256 + length of the whole .dsv, sha256 of every
                       packet, sha256 of every decoded frame (reference decoder)
