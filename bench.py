@@ -29,6 +29,14 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 W, H, FMT, GOP = 1920, 1080, 0x5, 12
 QP = 85
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+# VALU issue roof, MEASURED on this chip (tools/ubench/valu_rates.hip, kept in profiles/r03_valu_rates.txt; 8 waves per SIMD,
+# chip-wide G wave64-instructions/s): the integer / byte / packed-16 forms these kernels are made of (v_sad_u8 516, v_perm_b32
+# 526, v_alignbyte_b32 539, v_dot4_u32_u8 528, v_mul_lo_u32 536, v_pk_add_i16 534, v_pk_max_i16 530, v_med3_i32 534, v_bfe_u32 545,
+# v_lshl_add_u32 518, v_cndmask_b32_e64 529) issue once per ~4.6 cycles of SIMD time whatever the occupancy; only the plain
+# VOP2 adds / logic ops / moves (v_add_u32 820, v_and_b32 881, v_xor_b32 894, v_ashrrev_i32 883, v_mov_b32 980) share a
+# 2-cycle slot between waves.  The roof a kernel of the first kind is priced against:
+VALU_PEAK_GI = 530.0
+VALU_FAST_GI = 850.0
 
 
 def cpu_info():
@@ -87,12 +95,34 @@ def cpu_baseline(clips, pkg, A, reps=1):
                       % (clips.shape[0], GOP, nd, dt)}, streams[:nd]
 
 
-def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, **cli):
+def intra_block_pct(A, clip, w, h, fmt, **cli):
+    """share of intra blocks in the P pictures of `clip`, from the motion fields of the oracle encoder (checker role: it
+    describes the content of a shape, nothing timed goes through it)"""
+    L = A.load_orc()
+    cfg = A.orc_cfg(w, h, fmt, **cli)
+    e = L.orc_enc_open(C.byref(cfg))
+    out, n, cap = C.c_void_p(None), C.c_size_t(0), C.c_size_t(0)
+    intra = total = 0
+    for t in range(clip.shape[0]):
+        L.orc_enc_frame(e, clip[t].ctypes.data, C.byref(out), C.byref(n), C.byref(cap), None)
+        cnt = C.c_int(0)
+        p = L.orc_enc_last_mvs(e, C.byref(cnt))
+        if t == 0 or not p or cnt.value == 0:
+            continue
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(cnt.value * 12,)).reshape(cnt.value, 12)
+        intra += int((a[:, 4] != 0).sum())
+        total += cnt.value
+    C.CDLL(None).free(out)
+    L.orc_enc_close(e)
+    return round(100.0 * intra / max(total, 1), 1)
+
+
+def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, style=0, **cli):
     """the same pipelined loop on another shape of BASELINE.json (dsv_main.c:463-489 flag mapping in make_encoder_cfg):
     `streams` x `frames` pictures per step, raw frames resident in HBM; CRF runs submit/collect, ABR (serial per frame)
     plain encode calls.  One stream is compared bit for bit with the CPU checker on its first `check_frames` frames."""
     fb = A.frame_bytes(w, h, fmt)
-    clip = A.gen_clip(w, h, fmt, seed, frames, style=0)
+    clip = A.gen_clip(w, h, fmt, seed, frames, style=style)
     batch_in = np.empty((streams, frames, fb), dtype=np.uint8)
     batch_in[:] = clip
     cfg = pkg.make_encoder_cfg(w, h, fmt, **cli)
@@ -353,25 +383,33 @@ def main():
                     kinfo["traffic_raw"] = round(e["hbm_bytes_per_launch_raw"] * args.gops / T["gops"])
                 kinfo["traffic_source"] = T.get("source", "profiles/pmc_traffic.json")
             if e and e.get("valu_insts_per_launch") and ms > 0:
-                # integer/byte kernels can be bound by VALU issue rather than HBM: a wave64 VALU instruction holds
-                # one of the 1024 SIMDs for 4 cycles (2.4 GHz peak clock)
+                # integer/byte kernels can be bound by VALU issue rather than HBM: wave64 instructions of the kinds used here
+                # issue at VALU_PEAK_GI chip-wide (measured, see the constant)
                 vi = e["valu_insts_per_launch"] * args.gops / T["gops"]
-                kinfo["valu_issue"] = {"wave_instr_per_launch": round(vi), "busy_frac": round(vi * 4.0 / (1024 * 2.4e9 * (ms * 1e-3 / max(nl, 1))), 3),
-                                       "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json"}
+                kinfo["valu_issue"] = {"wave_instr_per_launch": round(vi), "busy_frac": round(vi / (VALU_PEAK_GI * 1e9 * (ms * 1e-3 / max(nl, 1))), 3),
+                                       "source": "SQ_INSTS_VALU, profiles/pmc_traffic.json; peak from profiles/r03_valu_rates.txt"}
+                if e.get("valu_busy_by_counters") is not None:
+                    # the same question answered by the counters alone (cycles with a VALU instruction in flight / SIMD cycles, the
+                    # kernel alone on the chip under the profiler)
+                    kinfo["valu_issue"]["busy_frac_by_counters"] = e["valu_busy_by_counters"]
+                    kinfo["valu_issue"]["salu_busy_frac_by_counters"] = e.get("salu_busy_by_counters")
                 if prof_kernel in table and table[prof_kernel][0] > 0:
                     # the same instructions against the time the kernel needs alone on the chip (one step of the untimed
                     # selection pass): what bounds the kernel itself, without the other coding stream's share
                     per_step = vi * nl / (args.steps + 1)          # the brackets also cover the batch that fills the pipeline
-                    kinfo["valu_issue"]["busy_frac_exclusive"] = round(per_step * 4.0 / (1024 * 2.4e9 * table[prof_kernel][0] * 1e-3), 3)
+                    kinfo["valu_issue"]["busy_frac_exclusive"] = round(per_step / (VALU_PEAK_GI * 1e9 * table[prof_kernel][0] * 1e-3), 3)
                 # which roof is the kernel under?  Integer kernels that read each byte once and do a lot with it (the
                 # motion search: 15 candidate SADs, the half-pel lattice and the block statistics per block) sit under the
-                # VALU issue roof, not the HBM one: the second entry prices the kernel against that roof, and
-                # `binding_roof` names the closer one (the fields above stay the HBM view the contract asks for)
+                # VALU issue roof, not the HBM one: the second entry prices the kernel against that roof, and `bound`
+                # names the closer one (achieved / peak / frac stay the HBM view the contract asks for)
                 vfrac = kinfo["valu_issue"]["busy_frac"]
-                peak_gi = 1024 * 2.4 / 4.0                         # 1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction
-                kinfo["valu_roof"] = {"bound": "valu", "achieved": round(vfrac * peak_gi, 1), "peak": peak_gi, "unit": "G wave-instr/s", "frac": vfrac,
-                                      "frac_exclusive": kinfo["valu_issue"].get("busy_frac_exclusive")}
+                kinfo["valu_roof"] = {"bound": "valu", "achieved": round(vfrac * VALU_PEAK_GI, 1), "peak": VALU_PEAK_GI, "unit": "G wave-instr/s", "frac": vfrac,
+                                      "frac_exclusive": kinfo["valu_issue"].get("busy_frac_exclusive"),
+                                      "peak_source": "measured: tools/ubench/valu_rates.hip -> profiles/r03_valu_rates.txt (integer / byte / packed-16 forms at 8 waves per SIMD; "
+                                                     "plain VOP2 add / logic / move forms reach %.0f)" % VALU_FAST_GI}
                 kinfo["binding_roof"] = "valu" if max(vfrac, kinfo["valu_roof"]["frac_exclusive"] or 0.0) > kinfo["frac"] else "hbm"
+                kinfo["bound"] = kinfo["binding_roof"]
+                kinfo["quoted_against"] = "hbm (achieved / peak / frac); valu_roof holds the other roof"
 
     # ---- after the headline, outside its timed region: the same loop fed from pinned HOST memory ("frames
     # pre-loaded in host RAM"; the upload of each batch over PCIe rides inside the step), never `value`
@@ -451,6 +489,21 @@ def main():
             "roofline": kinfo,
             "cpu_baseline": cpu,
         }
+        tp = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(tp):
+            # the whole step against the HBM roof: bytes every kernel of one frame-step batch moved by the counters (the committed
+            # rocprofv3 --pmc passes over this command, all kernels summed, scaled to this run's GOPs) / this run's step time
+            T = json.load(open(tp))
+            st_ = T.get("step")
+            if st_:
+                hb = st_["hbm_bytes"] * args.gops / T["gops"]
+                res["pipeline"] = {"bound": "hbm", "hbm_bytes_per_step": round(hb), "hbm_bytes_per_step_raw": round(st_["hbm_bytes_raw"] * args.gops / T["gops"]),
+                                   "achieved": round(hb / (1e-3 * res["ms_per_step"]) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                   "frac": round(hb / (1e-3 * res["ms_per_step"]) / 1e9 / HBM_PEAK_GBS, 4),
+                                   "algorithmic_bytes_per_step": round(41.2 * GOP * W * H * args.gops),
+                                   "note": "counter bytes = (2 x FETCH_SIZE + WRITE_SIZE) of every kernel of a step (profiles/pmc_traffic.json, "
+                                           "FETCH_SIZE tallies 128-byte requests at 64 bytes: profiles/r03_fetch_calib.txt); algorithmic = SURVEY 8(d)'s 41.2 B per luma pixel of the "
+                                           "unfused reference pipeline -- the fused kernels move less than that"}
         if extras:
             # the other shapes of BASELINE.json and the batched decoder, each with its own bit-exact check (measured
             # after the headline; the headline's context is closed first so that every shape has the GPU to itself)
@@ -464,6 +517,13 @@ def main():
                                                config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 16 closed GOPs x 12 frames per step")
                 shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 2, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
                                                  config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: serial per frame), 2 streams x 30 frames per step")
+                # the content that leaves the lean kernels: flat moving objects force a third of the blocks intra (whole-grid
+                # k_fwd_mc_pix, k_mc for the intra blocks, dense symbols) -- same shape and batch as the headline
+                wc = A.gen_clip(W, H, FMT, 0x10800003, 4, style=1)
+                shapes["cfg3_style1_worstcase"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 3, 0x10800003, 12, style=1, qp=QP, gop=GOP, rc_mode_cli=1),
+                                                       config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1, %d closed GOPs x 12 frames per step, clip style 1 "
+                                                              "(flat square + flat band changing every frame)" % args.gops,
+                                                       intra_blocks_pct_of_P_pictures=intra_block_pct(A, wc, W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1))
                 shapes["decode_1080p_batched"] = dict(decode_bench(pkg, A, dev, 64, 2),
                                                       config="1920x1080 4:2:0 GOP=12 stream, dsv1_decbatch_*: 64 streams side by side, one picture of each per call")
             except Exception as e:                       # the headline stands on its own

@@ -85,6 +85,8 @@ extern int dsv1_device;
  * half of this process's share of the cores)) */
 typedef void (*dsv1_par_fn)(void *ctx, int s, int tid);
 void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx);
+/* the default size of that pool as a function of the host (dsv1_util.c); exported so that the rule can be tested without the host it is for */
+int dsv1_host_threads_rule(long online, long allowed, long ranks, int pinned_by_launcher);
 
 #define CLAMPI(v, lo, hi) ((v) < (lo) ? (lo) : ((v) > (hi) ? (hi) : (v)))
 

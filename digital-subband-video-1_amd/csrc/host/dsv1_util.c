@@ -276,6 +276,24 @@ void conv422to420(DSV_PLANE *s, DSV_PLANE *d)
 }
 
 /* ---- parallel loop over independent items (side information, packet assembly, packet parsing, job records) ---- */
+/* Worker threads of a rank, from the host's cores: up to 12 (measured with the worker pool, 1080p GOP 12, 160 streams: 6 threads
+ * 24.6 ms per step, 8: 24.1, 12: 23.9, 16: 24.0), never more than half of this process's share of the cores.  The share:
+ * the affinity mask when the launcher made it this rank's own (shard.pin_rank_to_cores exports DSV1_CORES_PINNED=1); else the
+ * allowed cores -- the whole host, or a mask narrowed by taskset / a cgroup that ALL ranks of the node run under -- divided by
+ * the ranks of the node (one process per GPU: LOCAL_WORLD_SIZE of the launcher). */
+int dsv1_host_threads_rule(long online, long allowed, long ranks, int pinned_by_launcher)
+{
+    long cores, n;
+    if (ranks < 1) ranks = 1;
+    if (online < 1) online = 1;
+    if (allowed < 1 || allowed > online) allowed = online;
+    cores = pinned_by_launcher ? allowed : allowed / ranks;
+    if (cores < 1) cores = 1;
+    n = cores / 2;
+    if (n > 12) n = 12;
+    if (n < 1) n = 1;
+    return (int)n;
+}
 static int par_threads(int S)
 {
     static int n = 0;
@@ -283,23 +301,11 @@ static int par_threads(int S)
         const char *e = getenv("DSV1_HOST_THREADS");
         if (e) n = atoi(e);
         else {
-            /* default: up to 12 (measured with the worker pool, 1080p GOP 12, 160 streams: 6 threads 24.6 ms per step, 8: 24.1,
-             * 12: 23.9, 16: 24.0), but never more than half of this process's share of the host's cores.  The share is
-             * the affinity mask when the launcher (bench.py: shard.pin_rank_to_cores) narrowed it, else the online cores
-             * divided by the ranks of the node (one process per GPU: LOCAL_WORLD_SIZE of the launcher) */
-            const char *lw = getenv("LOCAL_WORLD_SIZE");
-            long online = sysconf(_SC_NPROCESSORS_ONLN), ranks = lw ? atol(lw) : 1, cores;
+            const char *lw = getenv("LOCAL_WORLD_SIZE"), *pin = getenv("DSV1_CORES_PINNED");
+            long online = sysconf(_SC_NPROCESSORS_ONLN), allowed = online;
             cpu_set_t set;
-            if (ranks < 1) ranks = 1;
-            if (online < 1) online = 1;
-            cores = online / ranks;
-            if (sched_getaffinity(0, sizeof(set), &set) == 0) {
-                const long allowed = CPU_COUNT(&set);
-                if (allowed > 0 && allowed < online) cores = allowed;     /* pinned: the mask is the share */
-            }
-            if (cores < 1) cores = 1;
-            n = (int)(cores / 2);
-            if (n > 12) n = 12;
+            if (sched_getaffinity(0, sizeof(set), &set) == 0) allowed = CPU_COUNT(&set);
+            n = dsv1_host_threads_rule(online, allowed, lw ? atol(lw) : 1, pin && atoi(pin) != 0);
         }
         if (n < 1) n = 1;
         if (n > 64) n = 64;

@@ -28,16 +28,80 @@ def gather_streams(local_streams, dist=None, dst=0):
     return [b for _, b in sorted(allp)]
 
 
+def _gpu_numa_nodes():
+    """NUMA node of every AMD GPU of the host in PCI bus order (the order HIP enumerates them in when no
+    *_VISIBLE_DEVICES variable reorders them), read from sysfs -- nothing here touches the GPU runtime.
+    [] when sysfs does not tell (containers without /sys/bus/pci, single-node hosts report -1)."""
+    import glob
+    import os
+    out = []
+    for dev in sorted(glob.glob("/sys/bus/pci/devices/*")):
+        try:
+            if open(os.path.join(dev, "vendor")).read().strip() != "0x1002":
+                continue
+            if not open(os.path.join(dev, "class")).read().strip().startswith(("0x0302", "0x0380", "0x1200")):
+                continue                                    # 3D / display controllers, processing accelerators
+            out.append(int(open(os.path.join(dev, "numa_node")).read().strip()))
+        except (OSError, ValueError):
+            continue
+    return out
+
+
+def _node_cpus(node):
+    """cores of a NUMA node (sysfs cpulist), [] if unknown"""
+    try:
+        txt = open("/sys/devices/system/node/node%d/cpulist" % node).read().strip()
+    except OSError:
+        return []
+    cpus = []
+    for part in txt.split(","):
+        if "-" in part:
+            a, b = part.split("-")
+            cpus.extend(range(int(a), int(b) + 1))
+        elif part:
+            cpus.append(int(part))
+    return cpus
+
+
+def split_cores(cores, local_rank, local_world, numa_of_rank=None, node_cpus=None):
+    """This rank's share of `cores` (sorted ids the process may run on).  With the GPUs' NUMA nodes known
+    (numa_of_rank[r] = node of rank r's GPU, node_cpus(node) = that node's cores) the ranks whose GPUs hang off the same
+    node split that node's allowed cores among themselves, so a rank's pinned staging buffers are first touched on the
+    socket its GPU is attached to; otherwise (or when some node would leave a rank without a core: then for ALL ranks) the
+    r-th contiguous slice."""
+    if local_world <= 1 or len(cores) < local_world:
+        return list(cores)
+    if numa_of_rank and node_cpus and len(numa_of_rank) >= local_world:
+        # all ranks or none (a mix of node shares and slices would overlap): every rank's node must be known and hold at
+        # least one allowed core per rank attached to it
+        nodes = numa_of_rank[:local_world]
+        share = {}
+        ok = all(n >= 0 for n in nodes)
+        for n in set(nodes) if ok else ():
+            share[n] = sorted(set(cores) & set(node_cpus(n)))
+            ok = ok and len(share[n]) >= nodes.count(n)
+        if ok:
+            node = nodes[local_rank]
+            peers = [r for r in range(local_world) if nodes[r] == node]
+            per = len(share[node]) // len(peers)
+            k = peers.index(local_rank)
+            return share[node][k * per:(k + 1) * per]
+    per = len(cores) // local_world
+    return list(cores[local_rank * per:(local_rank + 1) * per])
+
+
 def pin_rank_to_cores(local_rank, local_world):
-    """Give this rank a contiguous share of the cores the process may run on (os.sched_setaffinity) -- call it BEFORE
-    anything touches the GPU, so that the runtime's helper threads, the pinned staging buffers (first touch) and the
-    session layer's worker threads (dsv1_par_for sizes itself from the affinity mask) all stay on that share.
+    """Give this rank its share of the cores the process may run on (os.sched_setaffinity; split_cores: by the NUMA node of
+    the rank's GPU where sysfs tells, else a contiguous slice) -- call it BEFORE anything touches the GPU, so that the
+    runtime's helper threads, the pinned staging buffers (first touch) and the session layer's worker threads all stay on
+    that share.  Exports DSV1_CORES_PINNED=1: the worker pool (dsv1_util.c: par_threads) then takes the mask as this rank's
+    private share; a mask narrowed by anything else (taskset, a cgroup) is divided by LOCAL_WORLD_SIZE there.
     Returns the list of cores taken (all allowed cores when there is nothing to split)."""
     import os
     cores = sorted(os.sched_getaffinity(0))
     if local_world <= 1 or len(cores) < local_world:
         return cores
-    per = len(cores) // local_world
-    mine = cores[local_rank * per:(local_rank + 1) * per]
+    mine = split_cores(cores, local_rank, local_world, _gpu_numa_nodes(), _node_cpus)
     os.sched_setaffinity(0, mine)
+    os.environ["DSV1_CORES_PINNED"] = "1"
     return mine

@@ -32,28 +32,35 @@ def _free_port():
     return p
 
 
-@pytest.mark.timeout(900)
-def test_bench_two_ranks_on_one_gpu():
+@pytest.mark.timeout(1500)
+@pytest.mark.parametrize("ranks,gops", [(2, 8), (8, 4)])
+def test_bench_ranks_on_one_gpu(ranks, gops):
+    """2 ranks, and the 8 ranks of a full node (their core split, 8 stream-placement probes on one device, the barrier and
+    the MAX over 8 processes) -- the latter with 4 GOPs per rank so that eight contexts fit beside each other"""
     env = dict(os.environ)
     env["DSV1_BENCH_DEBUG_SHARED_GPU"] = "1"
     env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
-    gops, steps = 8, 2
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(_free_port()), os.path.join(A.ROOT, "bench.py"), "--gpus", "2", "--steps", str(steps), "--warmup", "1",
+    steps = 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(A.ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", "1",
            "--gops", str(gops), "--cpu-gops", "2"]
-    r = subprocess.run(cmd, cwd=A.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=800)
+    r = subprocess.run(cmd, cwd=A.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints ONE line, rank 1 none
+    assert len(lines) == 1, r.stdout[-2000:]            # rank 0 prints ONE line, the other ranks none
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == steps and d["scaling"] == "weak"
+    assert d["n_gpus"] == ranks and d["steps"] == steps and d["scaling"] == "weak"
     assert d["bit_exact_vs_cpu"] is True
     assert d["cpu_baseline"] is None                     # the timed CPU sample belongs to N=1
     assert "shapes" not in d
     pix = gops * 12 * 1920 * 1080
-    want = 2 * pix * steps / (d["ms_per_step"] * 1e-3 * steps) / 1e6      # whole job: both ranks' pixels over the MAX time
+    want = ranks * pix * steps / (d["ms_per_step"] * 1e-3 * steps) / 1e6      # whole job: all ranks' pixels over the MAX time
     assert abs(d["value"] - want) <= 0.01 * want
-    assert d["config"]["frames_per_step"] == 2 * gops * 12
+    assert d["config"]["frames_per_step"] == ranks * gops * 12
+    ncores = len(os.sched_getaffinity(0))
+    if ncores >= ranks:
+        assert d["config"]["host_cores_rank0"] == ncores // ranks          # shard.pin_rank_to_cores: this rank's share only
+    assert d["config"]["streams_on_own_hw_queue"] >= 1                     # the placement probe ran with 8 processes on the device
 
 
 def test_gop_sharding_over_two_encoder_contexts_equals_serial(pkg):

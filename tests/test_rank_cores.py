@@ -1,0 +1,75 @@
+"""8-rank readiness without an 8-GPU box: how a node's host cores are shared out over the ranks (shard.split_cores /
+pin_rank_to_cores) and how many session-layer workers a rank starts (dsv1_host_threads_rule, dsv1_util.c).  DESIGN.md
+section 5's bound: a rank needs >= 4 cores to keep its GPU the bottleneck."""
+import ctypes as C
+import importlib
+import os
+
+import pytest
+
+import _cabi as A
+
+shard = importlib.import_module("digital-subband-video-1_amd.shard")
+
+
+def test_split_64_cores_over_8_ranks_contiguous():
+    cores = list(range(64))
+    shares = [shard.split_cores(cores, r, 8) for r in range(8)]
+    assert all(len(s) == 8 for s in shares)
+    assert sorted(c for s in shares for c in s) == cores            # disjoint, nothing left over
+    assert shares[3] == list(range(24, 32))
+
+
+def test_split_by_numa_node_of_the_gpu():
+    # two sockets, SMT siblings numbered after the first 32 cores of each socket (0-31,64-95 | 32-63,96-127), four GPUs per socket
+    node_cpus = {0: list(range(0, 32)) + list(range(64, 96)), 1: list(range(32, 64)) + list(range(96, 128))}
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    cores = list(range(128))
+    shares = [shard.split_cores(cores, r, 8, numa, lambda n: node_cpus[n]) for r in range(8)]
+    assert all(len(s) == 16 for s in shares)
+    for r in range(8):
+        assert set(shares[r]) <= set(node_cpus[numa[r]]), "rank %d got cores of the remote socket" % r
+    assert sorted(c for s in shares for c in s) == cores
+    # a mask that leaves a node without cores for its ranks falls back to the plain slice
+    masked = list(range(0, 32))
+    shares = [shard.split_cores(masked, r, 8, numa, lambda n: node_cpus[n]) for r in range(8)]
+    assert all(len(s) == 4 for s in shares) and sorted(c for s in shares for c in s) == masked      # all ranks: disjoint slices
+    # unknown topology (-1 / nothing): the slice
+    assert shard.split_cores(cores, 2, 8, [-1] * 8, lambda n: []) == list(range(32, 48))
+    assert shard.split_cores(cores, 2, 8, [], None) == list(range(32, 48))
+
+
+def test_pin_rank_sets_mask_and_flag(monkeypatch):
+    allowed = sorted(os.sched_getaffinity(0))
+    if len(allowed) < 2:
+        pytest.skip("one core")
+    monkeypatch.delenv("DSV1_CORES_PINNED", raising=False)
+    try:
+        mine = shard.pin_rank_to_cores(1, 2)
+        assert sorted(os.sched_getaffinity(0)) == mine and 0 < len(mine) <= len(allowed) // 2 + 1
+        assert os.environ.get("DSV1_CORES_PINNED") == "1"
+    finally:
+        os.sched_setaffinity(0, allowed)
+        os.environ.pop("DSV1_CORES_PINNED", None)
+
+
+def test_worker_pool_rule_leaves_the_gpu_the_bottleneck():
+    if not os.path.exists(A.PROD_SO):
+        import __graft_entry__ as g
+        g.build()
+    L = C.CDLL(A.PROD_SO)
+    rule = L.dsv1_host_threads_rule
+    rule.restype = C.c_int
+    rule.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int]
+    # 64-core mask, 8 ranks, pinned by bench.py: each rank's mask is its own 8 cores -> 4 workers, on its own cores
+    assert rule(64, 8, 8, 1) == 4
+    # the same host without the launcher's pinning: the 64 cores are everybody's -> 64 / 8 / 2
+    assert rule(64, 64, 8, 0) == 4
+    # a cgroup / taskset mask of 32 cores shared by 8 unpinned ranks must not be taken as each rank's private share
+    assert rule(256, 32, 8, 0) == 2
+    # one rank on a big host: capped at 12; a tiny host: at least one
+    assert rule(256, 256, 1, 0) == 12 and rule(2, 2, 8, 0) == 1 and rule(1, 1, 1, 1) == 1
+    # every rank of a 64-core node keeps >= 4 cores and starts no more workers than cores / 2
+    for ranks in (1, 2, 4, 8):
+        share = 64 // ranks
+        assert share >= 4 and rule(64, share, ranks, 1) <= share // 2

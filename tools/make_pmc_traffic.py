@@ -2,12 +2,15 @@
 """profiles/pmc_traffic.json from the per-kernel PMC summary of tools/collect_profiles.sh.
 
 HBM bytes per launch = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: rocprofv3 reports both in KiB, and on gfx950
-FETCH_SIZE tallies the 128-byte requests of a wide coalesced read at 64 bytes (MI355X_MICROARCH.md, HBM), so
-the read side is doubled.  That calibration is for 16 B/lane streams; narrower accesses may be over-corrected,
-which the file says in `source`.
-If the SQ summary is given too, the VALU instruction count per launch is added (bench.py turns it into an issue
-utilisation: one wave64 VALU instruction occupies its SIMD for 4 cycles).
-usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json> [pmc_sq_per_kernel.csv]"""
+FETCH_SIZE tallies every 128-byte read request at 64 bytes (MI355X_MICROARCH.md, HBM), so the read side is
+doubled.  profiles/r03_fetch_calib.txt (tools/ubench/fetch_calib.hip) checked that on this chip for 4 / 8 / 16
+bytes per lane and for reads that use only half or a quarter of each line: every touched line is ONE 128-byte
+request whatever part of it is used, always tallied at 64 bytes; WRITE_SIZE is exact.
+`step`: all kernels of one frame step of the batch summed (launch counts divided by the steps the profile ran:
+k_unpack runs once per step) -- what bench.py's `pipeline` object prices against the step time.
+If the SQ summaries are given too, per-launch instruction counts and (second file: the pass with
+SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE) the VALU busy fraction by the counters are added.
+usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json> [pmc_sq_per_kernel.csv [pmc_roof_per_kernel.csv]]"""
 import csv
 import json
 import re
@@ -25,8 +28,8 @@ def kid(name):
 rows = list(csv.DictReader(open(sys.argv[1])))
 out = {"gops": int(sys.argv[2]),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --gops %s --steps 1`; "
-                 "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, read side doubled per the gfx950 correction "
-                 "(calibrated for 16 B/lane streams)" % sys.argv[2],
+                 "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, read side doubled: FETCH_SIZE tallies each 128-byte request at 64 bytes "
+                 "on gfx950 (checked for every access shape used here: profiles/r03_fetch_calib.txt)" % sys.argv[2],
        "kernels": {}}
 for r in rows:
     f = float(r.get("FETCH_SIZE_per_launch", 0) or 0)
@@ -40,5 +43,19 @@ if len(sys.argv) > 4:
         e["valu_insts_per_launch"] = float(r.get("SQ_INSTS_VALU_per_launch", 0) or 0)
         e["salu_insts_per_launch"] = float(r.get("SQ_INSTS_SALU_per_launch", 0) or 0)
         e["waves_per_launch"] = float(r.get("SQ_WAVES_per_launch", 0) or 0)
+if len(sys.argv) > 5:
+    # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs:
+    # busy fraction of the 1024 SIMDs = 4 * ACTIVE_INST_VALU / (128 * GUI_ACTIVE)
+    for r in csv.DictReader(open(sys.argv[5])):
+        e = out["kernels"].setdefault(kid(r["kernel"]), {"launches": int(r["launches"])})
+        g = float(r.get("GRBM_GUI_ACTIVE_per_launch", 0) or 0)
+        if g > 0:
+            e["valu_busy_by_counters"] = round(4.0 * float(r.get("SQ_ACTIVE_INST_VALU_per_launch", 0) or 0) / (128.0 * g), 4)
+            e["salu_busy_by_counters"] = round(4.0 * float(r.get("SQ_ACTIVE_INST_SCA_per_launch", 0) or 0) / (128.0 * g), 4)
+            e["gui_active_cycles_per_launch"] = g / 8.0
+steps = max(1, out["kernels"].get("k_unpack", {}).get("launches", 1))
+tot = sum(e.get("hbm_bytes_per_launch", 0) * e["launches"] for k, e in out["kernels"].items() if not k.startswith("__amd") and k != "k_spin")
+raw = sum(e.get("hbm_bytes_per_launch_raw", 0) * e["launches"] for k, e in out["kernels"].items() if not k.startswith("__amd") and k != "k_spin")
+out["step"] = {"steps_profiled": steps, "hbm_bytes": round(tot / steps), "hbm_bytes_raw": round(raw / steps)}
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out["kernels"]), "kernels")
