@@ -36,3 +36,28 @@ def test_makefile_refuses_ashr_pk(bad):
         for p in (src, obj):
             if os.path.exists(p):
                 os.remove(p)
+
+
+@pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+@pytest.mark.parametrize("how", ["no_objdump", "other_arch_name"])
+def test_makefile_isa_check_fails_closed(how):
+    """the check must not pass because it could not be made: a missing llvm-objdump, or a bundle entry that is not named
+    for the architecture asked for, refuses the object"""
+    name = "zz_guard_closed_%s" % how
+    src = os.path.join(CSRC, name + ".hip")
+    obj = os.path.join(CSRC, "build", name + ".o")
+    try:
+        with open(src, "w") as f:
+            f.write(PROBE % "")
+        if how == "no_objdump":
+            cmd = ["make", "-C", CSRC, obj, "OBJDUMP=/nonexistent/llvm-objdump"]
+        else:
+            # compile for gfx950 but make the rule look for another architecture's code object
+            cmd = ["make", "-C", CSRC, obj, "ARCH=gfx950", "HIPFLAGS=--offload-arch=gfx942 -O3 -std=c++17 -fPIC"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        assert r.returncode != 0 and "refused" in r.stdout, r.stdout[-800:]
+        assert not os.path.exists(obj)
+    finally:
+        for p in (src, obj):
+            if os.path.exists(p):
+                os.remove(p)
