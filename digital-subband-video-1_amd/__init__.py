@@ -157,11 +157,17 @@ class StreamBytes:
 class Batch:
     """nstreams independent encoder streams, frames_per_call frames each per encode() call"""
 
-    def __init__(self, cfg, nstreams, frames_per_call, device=0):
+    def __init__(self, cfg, nstreams, frames_per_call, device=0, chains=0):
+        """chains > 0: ONE stream in chain mode (dsv1_stream_open): frames_per_call consecutive frames per call, the chains of
+        pictures between I pictures coded side by side"""
         self.L = lib()
         self.h = _C.c_void_p(None)
         self.nstreams, self.F = nstreams, frames_per_call
-        _chk(self.L.dsv1_batch_open(_C.byref(self.h), _C.byref(cfg), device, nstreams, frames_per_call), "dsv1_batch_open")
+        if chains:
+            assert nstreams == 1
+            _chk(self.L.dsv1_stream_open(_C.byref(self.h), _C.byref(cfg), device, frames_per_call, chains), "dsv1_stream_open")
+        else:
+            _chk(self.L.dsv1_batch_open(_C.byref(self.h), _C.byref(cfg), device, nstreams, frames_per_call), "dsv1_batch_open")
         self.ctx = self.L.dsv1_batch_ctx(self.h)
         m = cfg.vidmeta
         self.frame_bytes = m.width * m.height + 2 * _chroma_size(m.width, m.height, m.subsamp)
@@ -372,6 +378,30 @@ def encode_clip(clip, w, h, fmt, device=0, eos=True, start_fnum=0, **cli):
         if start_fnum:
             b.set_fnum(0, start_fnum)
         return b.encode(clip.reshape(1, n, -1), eos=eos)[0]
+    finally:
+        b.close()
+
+
+def encode_stream(clip, w, h, fmt, frames_per_call, chains, device=0, eos=True, **cli):
+    """one stream through the GOP-parallel chain mode (dsv1_stream_open): the clip in calls of frames_per_call frames
+    (clip.shape[0] must be a multiple), two calls in flight -> .dsv bytes, byte for byte the serial encoder's"""
+    cfg = make_encoder_cfg(w, h, fmt, **cli)
+    n = clip.shape[0]
+    assert n % frames_per_call == 0
+    b = Batch(cfg, 1, frames_per_call, device, chains=chains)
+    try:
+        out = b""
+        calls = [clip[i:i + frames_per_call].reshape(1, frames_per_call, -1) for i in range(0, n, frames_per_call)]
+        b.submit(calls[0])
+        for k in range(1, len(calls)):
+            b.submit(calls[k])
+            out += bytes(b.collect()[0])
+        out += bytes(b.collect()[0])
+        if eos:
+            e = Buf()
+            _chk(b.L.dsv1_batch_eos(b.h, 0, _C.byref(e)), "dsv1_batch_eos")
+            out += _take(e)
+        return out
     finally:
         b.close()
 

@@ -53,6 +53,13 @@ struct dsv1_batch {
     dsvg_pic_job *jobs;
     dsvg_pic_out *outs;
     pkt_scratch sc0;                 /* packet staging of the serial (ABR / single-frame) path */
+    /* CHAIN MODE (dsv1_stream_open): ONE stream, the residual coding of a call's frames runs GOP-parallel.  A chain = an I
+     * picture and the P pictures that follow it; `chains` = how many are coded side by side (0: the mode is off).  Everything
+     * that decides what a chain is -- GOP starts, scene changes, forced-intra P pictures, the stability flags -- depends on
+     * source pixels only and is replayed serially on the host first (the always-exact two-pass scheme). */
+    int chains;
+    int *ch_start, *ch_len, *ch_pair, *ch_cur;   /* per chain of the call: first picture, length, reconstruction slot pair, slot of the pair that holds its newest reconstruction */
+    int carry_pair, carry_cur;       /* the pair / slot that holds the reconstruction of the call's last picture (the next call may predict from it) */
 };
 
 /* source slot of frame number g (per-stream counter) of stream s */
@@ -89,6 +96,7 @@ void *dsv1_batch_ctx(dsv1_batch *b) { return b ? (void *)b->ctx : NULL; }
 int dsv1_batch_recon_slot(const dsv1_batch *b, int stream)
 {
     if (!b || stream < 0 || stream >= b->nstreams || !b->has_recon[stream]) return -1;
+    if (b->chains) return b->carry_cur;
     return stream + b->nstreams * b->rpar[stream];
 }
 
@@ -108,21 +116,27 @@ void dsv1_batch_close(dsv1_batch *b)
     free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
     free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped);
+    free(b->ch_start); free(b->ch_len); free(b->ch_pair); free(b->ch_cur);
     free(b);
 }
 
-static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int device, int nstreams, int F)
+static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int device, int nstreams, int F, int chains)
 {
     dsv1_batch *b;
     const DSV_META *m = &encs[0].vidmeta;
     int rc, i, np;
-    if (!out || nstreams < 1 || F < 1) return DSVG_ERR_ARG;
+    if (!out || nstreams < 1 || F < 1 || chains < 0 || (chains && nstreams != 1)) return DSVG_ERR_ARG;
     b = (dsv1_batch *)calloc(1, sizeof(*b));
+    if (!b) return DSVG_ERR_ARG;
     b->nstreams = nstreams; b->F = F; b->enc = encs; b->own_enc = own;
+    if (chains > F) chains = F;
+    b->chains = chains; b->carry_pair = -1; b->carry_cur = -1;
     np = nstreams * F;
     b->rows = 2 * F + 1;
+    /* chain mode: `chains` pictures per frame step, a pair of reconstruction slots per chain + one pair for the chain the
+     * call before left open */
     rc = dsvg_ctx_create(&b->ctx, device, m->width, m->height, m->subsamp, encs[0].pyramid_levels,
-                         b->rows * nstreams, 2 * nstreams, nstreams, 2 * np);
+                         b->rows * nstreams, chains ? 2 * (chains + 1) : 2 * nstreams, chains ? chains : nstreams, 2 * np);
     if (rc) { b->enc = NULL; dsv1_batch_close(b); return rc; }       /* the caller still owns encs */
     dsvg_ctx_geom(b->ctx, &b->g);
     b->nblk = b->g.nblocks_h * b->g.nblocks_v;
@@ -144,6 +158,12 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
     b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
     b->outs = (dsvg_pic_out *)calloc((size_t)np, sizeof(dsvg_pic_out));
+    if (chains) {
+        b->ch_start = (int *)calloc((size_t)F + 1, sizeof(int));
+        b->ch_len = (int *)calloc((size_t)F + 1, sizeof(int));
+        b->ch_pair = (int *)calloc((size_t)F + 1, sizeof(int));
+        b->ch_cur = (int *)calloc((size_t)F + 1, sizeof(int));
+    }
     b->sc0.cap = (size_t)b->prefix_cap + b->g.plane_out_cap[0] + 2 * b->g.plane_out_cap[1] + 256;
     b->sc0.pkt = (uint8_t *)malloc(b->sc0.cap);
     for (i = 0; i < 2 * np; i++) {
@@ -166,8 +186,27 @@ int dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int ns
         encs[s].ref = NULL; encs[s].stability = NULL; encs[s].stable_blocks = NULL;
         dsv_enc_start(&encs[s]);
     }
-    rc = batch_open_on(out, encs, 1, device, nstreams, frames_per_call);
+    rc = batch_open_on(out, encs, 1, device, nstreams, frames_per_call, 0);
     if (rc) free(encs);
+    return rc;
+}
+
+/* ONE stream, frames_per_call consecutive frames per call, residual coding GOP-parallel (chain mode, see struct dsv1_batch):
+ * the same bytes as the frame-serial encoder for ANY CRF configuration -- scene changes, forced-intra P pictures, a
+ * stable_refresh that does not line up with the GOP length (GOP 30), metadata forced in mid-stream.  max_chains = chains coded
+ * side by side (more chains in a call simply take further rounds).  ABR streams are refused (serial by definition). */
+int dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int frames_per_call, int max_chains)
+{
+    DSV_ENCODER *enc;
+    int rc;
+    if (!cfg || frames_per_call < 1 || max_chains < 1 || cfg->rc_mode != DSV_RATE_CONTROL_CRF) return DSVG_ERR_ARG;
+    enc = (DSV_ENCODER *)calloc(1, sizeof(DSV_ENCODER));
+    if (!enc) return DSVG_ERR_ARG;
+    *enc = *cfg;
+    enc->ref = NULL; enc->stability = NULL; enc->stable_blocks = NULL;
+    dsv_enc_start(enc);
+    rc = batch_open_on(out, enc, 1, device, 1, frames_per_call, max_chains);
+    if (rc) free(enc);
     return rc;
 }
 
@@ -464,6 +503,7 @@ static void side_stream(void *ctx, int s, int tid)
         if (pc->isP) e->refresh_ctr++;               /* dsv_enc dsv_encoder.c:812-814 */
     }
 }
+static void prefix_one(const dsv1_batch *b, pic_t *pc, uint8_t *tmp);
 static void prefix_stream(void *ctx, int s, int tid)
 {
     side_ctx *c = (side_ctx *)ctx;
@@ -472,27 +512,121 @@ static void prefix_stream(void *ctx, int s, int tid)
     uint8_t *tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
     int t;
     (void)tid;
-    for (t = 0; t < b->nf_cur; t++) {
-        pic_t *pc = &c->pics[s * F + t];
-        bitw w;
-        memset(pc->prefix, 0, (size_t)b->prefix_cap);
-        bw_init(&w, pc->prefix);
-        write_pkt_hdr(&w, DSV_PT_PIC | (pc->is_ref << 1) | pc->has_ref);
-        bw_align(&w);
-        bw_bits(&w, 32, pc->fnum);
-        bw_align(&w);
-        bw_ueg(&w, (unsigned)b->g.blk_w >> 2);
-        bw_ueg(&w, (unsigned)b->g.blk_h >> 2);
-        bw_align(&w);
-        stability_write(pc, nblk, &w, tmp);
-        if (pc->has_ref) {
-            bw_align(&w);
-            motion_pass(b, pc, &w, tmp);
-        }
-        bw_align(&w);
-        pc->prefix_len = bw_bytes(&w);
-    }
+    for (t = 0; t < b->nf_cur; t++) prefix_one(b, &c->pics[s * F + t], tmp);
     free(tmp);
+}
+
+/* the packet prefix of ONE picture (chain mode: a single stream, its pictures are the parallel items) */
+static void prefix_one(const dsv1_batch *b, pic_t *pc, uint8_t *tmp)
+{
+    bitw w;
+    memset(pc->prefix, 0, (size_t)b->prefix_cap);
+    bw_init(&w, pc->prefix);
+    write_pkt_hdr(&w, DSV_PT_PIC | (pc->is_ref << 1) | pc->has_ref);
+    bw_align(&w);
+    bw_bits(&w, 32, pc->fnum);
+    bw_align(&w);
+    bw_ueg(&w, (unsigned)b->g.blk_w >> 2);
+    bw_ueg(&w, (unsigned)b->g.blk_h >> 2);
+    bw_align(&w);
+    stability_write(pc, b->nblk, &w, tmp);
+    if (pc->has_ref) {
+        bw_align(&w);
+        motion_pass(b, pc, &w, tmp);
+    }
+    bw_align(&w);
+    pc->prefix_len = bw_bytes(&w);
+}
+static void prefix_picture(void *ctx, int t, int tid)
+{
+    side_ctx *c = (side_ctx *)ctx;
+    uint8_t *tmp = (uint8_t *)malloc(((size_t)c->b->nblk * 8 + 64) * 4 + 64);
+    (void)tid;
+    if (!tmp) return;
+    prefix_one(c->b, &c->pics[t], tmp);
+    free(tmp);
+}
+
+/* Chain mode, step 5 of a submit: the call's pictures -- decisions, motion fields and stability flags all known -- fall into
+ * chains (a picture without a reference starts one; the call's first picture continues the chain the call before left open
+ * when it is a P picture).  Chains do not depend on each other, so frame step k codes the k-th picture of every chain of a
+ * round (at most `chains` side by side); consecutive steps with the same number of live chains go to the device as one
+ * dsvg_code_batch call.  Calls are ordered against each other on the coding streams, so a slot pair may be reused by a later
+ * round, and a chain may change its position from call to call. */
+static int code_chains(dsv1_batch *b, pic_t *pics, int nf, int par)
+{
+    const int C = b->chains;
+    DSV_ENCODER *e = &b->enc[0];
+    int nch = 0, t, g0, rc, os = par * b->F;
+    for (t = 0; t < nf; t++) {
+        if (t == 0 || !pics[t].isP) { b->ch_start[nch] = t; b->ch_len[nch] = 0; nch++; }
+        b->ch_len[nch - 1]++;
+        pics[t].quant = pick_quant(e, pics[t].isP, pics[t].forced_intra);
+    }
+    if (pics[0].isP && b->carry_cur < 0) { dsv1_log(1, "a P picture without a reference picture on the device"); return DSVG_ERR_ARG; }
+    for (g0 = 0; g0 < nch; g0 += C) {
+        const int gn = nch - g0 < C ? nch - g0 : C;
+        int c, L = 0, k = 0, nextpair = 0;
+        for (c = g0; c < g0 + gn; c++) {
+            if (b->ch_len[c] > L) L = b->ch_len[c];
+            if (c == 0 && pics[0].isP) { b->ch_pair[c] = b->carry_pair; b->ch_cur[c] = b->carry_cur; continue; }
+            /* C + 1 pairs: the one the open chain of the call before lives in is left alone while that chain goes on (round 0) */
+            if (g0 == 0 && pics[0].isP && nextpair == b->carry_pair) nextpair++;
+            b->ch_pair[c] = nextpair++;
+            b->ch_cur[c] = -1;
+        }
+        while (k < L) {
+            int nj = 0, k2, kk, idx = 0;
+            for (c = g0; c < g0 + gn; c++) nj += b->ch_len[c] > k;
+            for (k2 = k + 1; k2 < L; k2++) {
+                int n2 = 0;
+                for (c = g0; c < g0 + gn; c++) n2 += b->ch_len[c] > k2;
+                if (n2 != nj) break;
+            }
+            for (kk = k; kk < k2; kk++)
+                for (c = g0; c < g0 + gn; c++) {
+                    pic_t *pc;
+                    dsvg_pic_job *j;
+                    int tt, last_of_chain;
+                    if (b->ch_len[c] <= kk) continue;
+                    tt = b->ch_start[c] + kk;
+                    pc = &pics[tt];
+                    j = &b->jobs[idx++];
+                    memset(j, 0, sizeof(*j));
+                    j->src_slot = pc->cur_slot;
+                    j->ref_recon_slot = pc->isP ? b->ch_cur[c] : -1;
+                    if (pc->is_ref) {
+                        /* the pair's other slot: the prediction is written straight into it (dsvg_code_batch) */
+                        b->ch_cur[c] = 2 * b->ch_pair[c] + (b->ch_cur[c] == 2 * b->ch_pair[c] ? 1 : 0);
+                        j->recon_slot = b->ch_cur[c];
+                    } else j->recon_slot = -1;
+                    j->quant = pc->quant;
+                    j->mvs = (const dsvg_mv *)pc->mvs;
+                    j->stable_blocks = pc->stable;
+                    pc->out_slot = os++;
+                    j->out_slot = pc->out_slot;
+                    j->no_intra_blocks = pc->isP && pc->n_intra == 0;
+                    j->has_reach = pc->isP;
+                    memcpy(j->mv_reach, pc->reach, sizeof pc->reach);
+                    /* who predicts from this reconstruction?  The chain's next picture -- in this call (the device then writes
+                     * the border as far as that picture's vectors reach), or in a later one (0: the whole border).  The chain's
+                     * last picture: nobody, when the stream's next picture is known to be an I picture (it starts the next chain
+                     * of this submit, or it starts a GOP: dsv_encoder.c:702-708); else unknown */
+                    last_of_chain = kk + 1 == b->ch_len[c];
+                    if (!last_of_chain) j->border_hint = kk + 1 < k2;
+                    else if (tt + 1 < nf) j->border_hint = 1;
+                    else j->border_hint = e->force_metadata || (DSV_FNUM)(e->prev_gop + (DSV_FNUM)e->gop) <= e->next_fnum;
+                    if (tt + 1 == nf) b->border_skipped[0] = (unsigned char)(j->border_hint && j->recon_slot >= 0);
+                }
+            if ((rc = dsvg_code_batch(b->ctx, k2 - k, nj, b->jobs))) return rc;
+            k = k2;
+        }
+    }
+    if (pics[nf - 1].is_ref) {
+        b->carry_pair = b->ch_pair[nch - 1]; b->carry_cur = b->ch_cur[nch - 1];
+        b->has_recon[0] = 1;
+    }
+    return DSVG_OK;
 }
 
 /* packet assembly of one stream of a collected batch (its own staging buffer per thread) */
@@ -533,6 +667,8 @@ static void asm_piece(void *ctx, int first, int count)
  * (each quantiser needs the previous packet size) runs frame step by frame step and leaves nothing
  * pending except the already assembled packets. */
 static int stage_n(dsv1_batch *b, const void *yuv_host, int nf);
+static int code_chains(dsv1_batch *b, pic_t *pics, int nf, int par);
+static void prefix_picture(void *ctx, int t, int tid);
 static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out, int nf)
 {
     int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0, par;
@@ -608,7 +744,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
             if (pc->has_ref && t == 0 && b->border_skipped[s]) {
                 /* the batch before promised a GOP start here (border_hint) and the caller changed the frame numbering
                  * in between (dsv1_batch_set_fnum): give the reference its whole border after all */
-                if ((rc = dsvg_extend_recon(b->ctx, s + S * b->rpar[s]))) return rc;
+                if ((rc = dsvg_extend_recon(b->ctx, b->chains ? b->carry_cur : s + S * b->rpar[s]))) return rc;
             }
             if (t == 0) b->border_skipped[s] = 0;
             if (pc->has_ref) {
@@ -645,7 +781,11 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         side_ctx sc_;
         sc_.b = b; sc_.pics = pics;
         if (serial && !abr_out) return DSVG_ERR_ARG;
+        if (serial && b->chains) return DSVG_ERR_ARG;
         if (serial) dsv1_par_for(S, prefix_stream, &sc_);      /* ABR assembles every picture as soon as it is coded */
+        if (b->chains) {
+            if ((rc = code_chains(b, pics, nf, par))) return rc;
+        } else
         for (t = 0; t < nf; t++) {
             for (s = 0; s < S; s++) {
                 pic_t *pc = &pics[s * F + t];
@@ -682,10 +822,11 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                     if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s], &b->sc0))) return rc;
             }
         }
-        if (!serial && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
+        if (!serial && !b->chains && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
         HP_MARK(HP_ENQUEUE);
         /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
-        if (!serial) dsv1_par_for(S, prefix_stream, &sc_);
+        if (b->chains) dsv1_par_for(nf, prefix_picture, &sc_);      /* (one stream: the pictures are the independent items) */
+        else if (!serial) dsv1_par_for(S, prefix_stream, &sc_);
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
         b->nf_pending[par] = nf;
     }
@@ -834,17 +975,22 @@ void dsv_enc_start(DSV_ENCODER *enc)                       /* dsv_encoder.c:724-
 void dsv_enc_set_metadata(DSV_ENCODER *enc, DSV_META *md) { memcpy(&enc->vidmeta, md, sizeof(DSV_META)); }
 void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
 
-/* Session behind the frame-at-a-time API.  CRF streams are PIPELINED: dsv_enc copies the frame into a pinned host batch
- * (the CLI reuses its picture buffer, dsv_main.c:506-520), and every F frames one batch goes to the device with
- * dsv1_batch_submit while the batch before it is collected; the finished packets wait in a backlog that later calls hand
- * out (at most two buffers per call, as the reference does: metadata + picture, dsv_encoder.c:804-810).  A caller may get
- * 0 buffers for a while -- dsv_main.c:521-531 loops over whatever count comes back -- and dsv_enc_end_of_stream returns
- * the rest of the backlog in front of the EOS packet, in one buffer: the bytes that reach the file are those of the
- * frame-synchronous encoder.  ABR needs every packet's size before the next quantiser and keeps one frame per call
- * (DSV1_ENC_PIPELINE=0 forces that for CRF too). */
+/* Session behind the frame-at-a-time API.  CRF streams are PIPELINED and GOP-PARALLEL: dsv_enc copies the frame into a
+ * pinned host batch (the CLI reuses its picture buffer, dsv_main.c:506-520), and every F frames -- a lookahead of several GOPs,
+ * DSV1_ENC_LOOKAHEAD frames, by default 16 GOPs within 768 MB of pinned memory per half -- one batch goes to the device with
+ * dsv1_batch_submit while the batch before it is collected.  The batch runs in chain mode (dsv1_stream_open): analysis of all
+ * its frames, the encoder's serial state machine (GOP starts, scene changes, forced-intra pictures, stability) replayed on
+ * the host, then the chains of pictures between I pictures coded side by side -- byte for byte the frame-serial stream, for
+ * any CRF configuration.  The finished packets wait in a backlog that later calls hand out (at most two buffers per call, as
+ * the reference does: metadata + picture, dsv_encoder.c:804-810).  A caller gets 0 buffers while the lookahead fills --
+ * dsv_main.c:521-531 loops over whatever count comes back -- and dsv_enc_end_of_stream returns the rest of the backlog in
+ * front of the EOS packet, in one buffer: the bytes that reach the file are those of the frame-synchronous encoder.  Changes
+ * the caller makes to the encoder's public fields (quality, force_metadata) take effect up to F frames late.  ABR needs every
+ * packet's size before the next quantiser and keeps one frame per call (DSV1_ENC_PIPELINE=0 forces that for CRF too).
+ * A device error ends the session: every later dsv_enc returns 0 buffers (and logs), nothing is written out of bounds. */
 typedef struct {
     dsv1_batch *b;
-    int pipelined, F, fill, cur, inflight;
+    int pipelined, F, fill, cur, inflight, failed;
     uint8_t *pin[2];
     size_t fb;
     DSV_BUF backlog;            /* finished packets not handed out yet */
@@ -866,7 +1012,13 @@ static void sess_free(enc_sess *ss)
 
 void dsv_enc_free(DSV_ENCODER *enc)
 {
-    if (enc->ref) { sess_free((enc_sess *)enc->ref); enc->ref = NULL; }
+    if (enc->ref) {
+        enc_sess *ss = (enc_sess *)enc->ref;
+        if (ss->pipelined && !ss->failed && (ss->fill > 0 || ss->inflight > 0 || ss->backlog.len > ss->off))
+            dsv1_log(1, "dsv_enc_free without dsv_enc_end_of_stream: %d buffered frame(s) and %d batch(es) in flight are dropped", ss->fill, ss->inflight);
+        sess_free(ss);
+        enc->ref = NULL;
+    }
     if (enc->stability) { dsv_free(enc->stability); enc->stability = NULL; }
     if (enc->stable_blocks) { dsv_free(enc->stable_blocks); enc->stable_blocks = NULL; }
 }
@@ -876,9 +1028,9 @@ static int sess_collect(enc_sess *ss)
 {
     DSV_BUF tmp = {NULL, 0};
     int rc = dsv1_batch_collect(ss->b, &tmp);
+    if (!rc) ss->inflight--;                            /* (a failed collect leaves the batch pending: the session is marked failed) */
     if (!rc && tmp.len) rc = dsv1_buf_append(&ss->backlog, tmp.data, tmp.len) ? DSVG_ERR_ARG : DSVG_OK;
     dsv_buf_free(&tmp);
-    ss->inflight--;
     return rc;
 }
 
@@ -917,7 +1069,7 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:7
     enc_sess *ss = (enc_sess *)enc->ref;
     uint8_t eos[DSV_PACKET_HDR_SIZE];
     unsigned rest = 0;
-    if (ss && ss->pipelined) {
+    if (ss && ss->pipelined && !ss->failed) {
         /* flush: the frames still waiting for a full batch, then everything in flight, oldest first */
         int rc = DSVG_OK;
         if (ss->fill > 0) {
@@ -925,7 +1077,7 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:7
             if (!rc) rc = sess_submit(ss);
         }
         while (!rc && ss->inflight > 0) rc = sess_collect(ss);
-        if (rc) dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error());
+        if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; }
     }
     if (ss) rest = ss->backlog.len - ss->off;
     memset(eos, 0, sizeof(eos));
@@ -940,20 +1092,57 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:7
     memcpy(bufs[0].data + rest, eos, sizeof(eos));
 }
 
+/* frame -> pinned batch memory, the rows of its three planes shared out over the worker pool (a 1080p frame is 3 MB: one
+ * thread copies it in ~0.3 ms, which would cap a single stream at ~3000 frames/s) */
+typedef struct { const DSV_FRAME *f; uint8_t *dst; int rows, parts; } copy_ctx;
+static void copy_part(void *ctx, int i, int tid)
+{
+    const copy_ctx *c = (const copy_ctx *)ctx;
+    int r0 = (int)((long)c->rows * i / c->parts), r1 = (int)((long)c->rows * (i + 1) / c->parts), p, base = 0;
+    uint8_t *o = c->dst;
+    (void)tid;
+    for (p = 0; p < 3; p++) {
+        const DSV_PLANE *pl = &c->f->planes[p];
+        int y0 = r0 - base, y1 = r1 - base, y;
+        if (y0 < 0) y0 = 0;
+        if (y1 > pl->h) y1 = pl->h;
+        if (y0 < y1) {
+            if (pl->stride == pl->w) memcpy(o + (size_t)y0 * pl->w, pl->data + (size_t)y0 * pl->stride, (size_t)(y1 - y0) * pl->w);
+            else for (y = y0; y < y1; y++) memcpy(o + (size_t)y * pl->w, pl->data + (size_t)y * pl->stride, (size_t)pl->w);
+        }
+        base += pl->h;
+        o += (size_t)pl->w * pl->h;
+    }
+}
+
 int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
 {
     enc_sess *ss;
-    uint8_t *o;
-    int c, y, rc;
+    int c, rc;
 
     if (!bufs) { dsv1_log(1, "null buffer list passed to encoder!"); return 0; }
     if (!enc->ref) {
-        const char *e = getenv("DSV1_ENC_PIPELINE");
+        const char *e = getenv("DSV1_ENC_PIPELINE"), *la = getenv("DSV1_ENC_LOOKAHEAD");
+        int chains = 0;
         ss = (enc_sess *)calloc(1, sizeof(*ss));
+        if (!ss) { dsv1_log(1, "out of memory"); dsv_frame_ref_dec(frame); return 0; }
         ss->pipelined = enc->rc_mode == DSV_RATE_CONTROL_CRF && !(e && atoi(e) == 0);
-        /* one GOP per batch (the motion search of a whole batch is one launch per pyramid level), within 8..32 frames */
-        ss->F = !ss->pipelined ? 1 : (enc->gop >= 8 && enc->gop <= 32 ? enc->gop : 16);
-        if ((rc = batch_open_on(&ss->b, enc, 0, dsv1_device, 1, ss->F))) {
+        ss->F = 1;
+        if (ss->pipelined) {
+            /* lookahead: 16 GOPs (intra-only streams: 64 pictures), at least 8 frames, within 768 MB of pinned memory per half */
+            const DSV_META *m = &enc->vidmeta;
+            const int hs = (m->subsamp >> 2) & 3, vs = m->subsamp & 3;
+            const size_t fbytes = (size_t)m->width * m->height + 2 * (size_t)((m->width + (1 << hs) - 1) >> hs) * (size_t)((m->height + (1 << vs) - 1) >> vs);
+            const int g = enc->gop > 0 ? (int)enc->gop : 1;
+            long want = la ? atol(la) : (enc->gop > 0 ? 16L * g : 64L), cap = (long)(((size_t)768 << 20) / (fbytes ? fbytes : 1));
+            if (want > cap) want = cap;
+            if (want > 1024) want = 1024;
+            if (want < 8) want = 8;
+            ss->F = (int)want;
+            chains = enc->gop > 0 ? (ss->F + g - 1) / g + 1 : ss->F;
+            if (chains > 64) chains = 64;
+        }
+        if ((rc = batch_open_on(&ss->b, enc, 0, dsv1_device, 1, ss->F, chains))) {
             dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
             free(ss);
             dsv_frame_ref_dec(frame);
@@ -970,11 +1159,22 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         enc->ref = ss;
     }
     ss = (enc_sess *)enc->ref;
+    if (ss->failed || ss->fill >= ss->F) {
+        /* an earlier device error ended the session (never copy past the pinned batch) */
+        if (!ss->failed) { ss->failed = 1; ss->fill = 0; }
+        dsv1_log(1, "GPU session failed earlier: frame dropped");
+        dsv_frame_ref_dec(frame);
+        return 0;
+    }
     /* the frame is copied now: the caller may reuse its pixel memory as soon as this returns */
-    o = ss->pin[ss->cur] + (size_t)ss->fill * ss->fb;
-    for (c = 0; c < 3; c++)
-        for (y = 0; y < frame->planes[c].h; y++, o += frame->planes[c].w)
-            memcpy(o, frame->planes[c].data + (size_t)y * frame->planes[c].stride, (size_t)frame->planes[c].w);
+    {
+        copy_ctx cc;
+        cc.f = frame; cc.dst = ss->pin[ss->cur] + (size_t)ss->fill * ss->fb;
+        cc.rows = frame->planes[0].h + frame->planes[1].h + frame->planes[2].h;
+        cc.parts = ss->fb >= ((size_t)1 << 20) ? 8 : 1;
+        if (cc.parts > 1) dsv1_par_for(cc.parts, copy_part, &cc);
+        else copy_part(&cc, 0, 0);
+    }
     dsv_frame_ref_dec(frame);                           /* the encoder owns the frame (dsv_encoder.c:38-40) */
     ss->fill++;
     if (!ss->pipelined) {
@@ -983,7 +1183,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         rc = dsv1_batch_encode(ss->b, ss->pin[0], 0, &acc);
         if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
         dsv_buf_free(&acc);
-        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); return 0; }
+        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); ss->failed = 1; return 0; }
         return sess_pop(ss, bufs, 2);
     }
     if (ss->fill == ss->F) {
@@ -992,7 +1192,12 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         if (ss->inflight == 2) rc = sess_collect(ss);
         if (!rc) rc = sess_submit(ss);
         if (!rc && ss->inflight == 2) rc = sess_collect(ss);
-        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); return 0; }
+        if (rc) {
+            /* the session is over: no later call may copy into the batch or touch the device again */
+            dsv1_log(1, "GPU encode failed: %s", dsvg_last_error());
+            ss->failed = 1; ss->fill = 0;
+            return sess_pop(ss, bufs, 2);
+        }
     }
     return sess_pop(ss, bufs, 2);
 }

@@ -110,7 +110,15 @@ void dsv_enc_free(DSV_ENCODER *enc);
 void dsv_enc_set_metadata(DSV_ENCODER *enc, DSV_META *md);
 void dsv_enc_force_metadata(DSV_ENCODER *enc);
 void dsv_enc_start(DSV_ENCODER *enc);
-int  dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs);     /* takes ownership of frame */
+/* dsv_enc takes ownership of frame (its pixels are copied before the call returns).  CRF streams are coded with a LOOKAHEAD
+ * (DSV1_ENC_LOOKAHEAD frames, default 16 GOPs): the call returns 0 buffers while the lookahead fills, then up to two packets
+ * per call (metadata + picture, as the reference), always whole packets in stream order; dsv_enc_end_of_stream returns every
+ * packet still owed followed by the EOS packet in bufs[0] (ONE buffer holding several packets: a caller that needs one
+ * packet per DSV_BUF splits it on the packets' next-link words, or sets DSV1_ENC_PIPELINE=0 for the frame-synchronous
+ * behaviour: one picture per call, same bytes).  Changes to the encoder's public fields between calls (quality,
+ * dsv_enc_force_metadata) act on the frames not yet submitted, i.e. up to a lookahead late.  dsv_enc_free without
+ * dsv_enc_end_of_stream drops the frames still buffered (and logs it).  ABR streams are frame-synchronous. */
+int  dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs);
 void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs);
 
 /* ---- decoder (dsv_decoder.h:51-59) ---- */
@@ -144,6 +152,13 @@ typedef struct dsv1_batch dsv1_batch;
 /* cfg: a DSV_ENCODER filled like dsv_main.c:463-489 would (dsv_enc_init + fields + vidmeta);
  * nstreams independent streams, frames_per_call frames each per call. */
 int  dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int nstreams, int frames_per_call);
+/* ONE stream, GOP-parallel (the always-exact scheme): every call takes frames_per_call CONSECUTIVE frames of
+ * the stream (yuv: [frame]; a last, shorter call is not supported here -- dsv_enc does that) and codes the chains of pictures
+ * between I pictures side by side, max_chains at a time, after replaying the encoder's serial decisions (GOP starts,
+ * scene changes, forced-intra pictures, stability flags: all functions of source pixels) on the host.  The stream equals
+ * the frame-serial encoder's for every CRF configuration (dsv_encoder.c:345-399,538-552,624-653); ABR is refused.  Used
+ * with dsv1_batch_encode / submit / collect / eos / close like a batch of one stream. */
+int  dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int frames_per_call, int max_chains);
 void dsv1_batch_close(dsv1_batch *b);
 void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
 /* Encode frames_per_call frames of every stream.  yuv: [stream][frame] tightly packed planar frames,

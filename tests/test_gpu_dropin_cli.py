@@ -43,3 +43,32 @@ def test_reference_cli_on_gpu_library(flags):
         x = np.fromfile(os.path.join(td, "ref_dec.yuv"), dtype=np.uint8)
         y = np.fromfile(os.path.join(td, "gpu_dec.yuv"), dtype=np.uint8)
         A.assert_same("decoded yuv", y, x)
+
+
+@pytest.mark.parametrize("look", ["24", None])
+def test_reference_cli_1080p_scene_cuts_cli_defaults(look):
+    """ONE long-ish 1080p stream with scene cuts through the unmodified dsv_main.c on our library -- CLI defaults (-scd1,
+    dsv_main.c:121) apart from CRF -- byte-equal to the all-reference CLI: the GOP-parallel chain mode behind dsv_enc is
+    exact where plain GOP sharding is not"""
+    if not (os.path.exists(DROPIN) and os.path.exists(A.REF_CLI)):
+        pytest.skip("oracle/_ref binaries were not built (no /root/reference at build time)")
+    w, h, fmt, n = 1920, 1080, A.SUBSAMP_420, 40
+    clip = A.gen_clip(w, h, fmt, 0x10800333, n, style=3)
+    env = dict(os.environ)
+    env["LD_LIBRARY_PATH"] = A.PKG_DIR + ":" + env.get("LD_LIBRARY_PATH", "")
+    if look:
+        env["DSV1_ENC_LOOKAHEAD"] = look
+    else:
+        env.pop("DSV1_ENC_LOOKAHEAD", None)
+    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+        inp = os.path.join(td, "in.yuv")
+        clip.tofile(inp)
+        common = ["-y", "-inp_" + inp, "-w%d" % w, "-h%d" % h, "-fmt2", "-gop12", "-qp85", "-rc_mode1"]
+        rc1, log1 = run(A.REF_CLI, ["e", "-out_" + os.path.join(td, "ref.dsv")] + common)
+        rc2, log2 = run(DROPIN, ["e", "-out_" + os.path.join(td, "gpu.dsv")] + common, env)
+        assert rc1 == 0 and rc2 == 0, log2
+        a = open(os.path.join(td, "ref.dsv"), "rb").read()
+        b = open(os.path.join(td, "gpu.dsv"), "rb").read()
+        assert a == b, "drop-in CLI stream differs (%d vs %d bytes)\n%s" % (len(b), len(a), log2[-400:])
+        pics = [p for p in A.split_packets(a) if p[5] & 4]
+        assert sum(1 for p in pics if not (p[5] & 1)) > 4, "the clip has no scene change the encoder detects"

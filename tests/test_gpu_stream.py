@@ -191,9 +191,10 @@ def _drive_dsv_enc(pkg, clip, w, h, fmt, **cli):
     (21, dict(qp=85, gop=0, rc_mode_cli=1)),                 # intra-only CRF: batches of 16
     (9, dict(qp=60, gop=12, rc_mode_cli=0)),                 # ABR: one frame per call, packets come back at once
 ])
-def test_drop_in_dsv_enc_api(pkg, orc, n, cli):
+def test_drop_in_dsv_enc_api(pkg, orc, monkeypatch, n, cli):
     """frame-at-a-time dsv_enc_* API (dsv_encoder.h:112-121): CRF streams are pipelined in batches behind it (deferred
     output, flushed by dsv_enc_end_of_stream), ABR is served frame by frame -- the bytes are the serial encoder's"""
+    monkeypatch.setenv("DSV1_ENC_LOOKAHEAD", "12" if cli["gop"] else "16")     # batches of a GOP, as the comments of the cases say
     w, h, fmt = 352, 288, A.SUBSAMP_420
     clip = A.gen_clip(w, h, fmt, 0xD209 + n, n, style=2)
     want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli))
