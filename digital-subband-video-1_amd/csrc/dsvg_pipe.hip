@@ -487,9 +487,9 @@ extern "C" int dsvg_host_free(dsvg_ctx *c, void *hptr)
     return DSVG_OK;
 }
 
-extern "C" int dsvg_ingest_begin(dsvg_ctx *c, const void *yuv_host, size_t bytes, void **dptr)
+// reserve the next ingest buffer for a clip of `bytes` bytes; the copy stream waits for the buffer's last readers
+static int ingest_reserve(dsvg_ctx *c, size_t bytes, int *kout)
 {
-    if (!c || !yuv_host || !dptr || !bytes) { dsvg_set_error("bad ingest arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     if (!c->st_h) {
         HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
@@ -512,11 +512,47 @@ extern "C" int dsvg_ingest_begin(dsvg_ctx *c, const void *yuv_host, size_t bytes
         c->used_valid[k] = false;
     }
     if (c->used_valid[k]) HIPCHK(hipStreamWaitEvent(c->st_h, c->ev_used[k], 0));    // its last readers (analysis stream)
+    *kout = k;
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_ingest_begin(dsvg_ctx *c, const void *yuv_host, size_t bytes, void **dptr)
+{
+    if (!c || !yuv_host || !dptr || !bytes) { dsvg_set_error("bad ingest arguments"); return DSVG_ERR_ARG; }
+    int k;
+    OPCHK(ingest_reserve(c, bytes, &k));
     HIPCHK(hipMemcpyAsync(c->ingest[k], yuv_host, bytes, hipMemcpyHostToDevice, c->st_h));
     HIPCHK(hipEventRecord(c->ev_up[k], c->st_h));
     c->up_pending[k] = true;
     *dptr = c->ingest[k];
     return DSVG_OK;
+}
+
+// The same for a clip that arrives piece by piece (dsv_enc: a frame per call): open reserves the buffer, every part is
+// queued on the copy stream as soon as the caller has it -- the link is busy while the caller gathers the next frames, not
+// in one burst when the batch is complete.  A load from the buffer waits for the parts queued before it.
+extern "C" int dsvg_ingest_open(dsvg_ctx *c, size_t bytes, void **dptr)
+{
+    if (!c || !dptr || !bytes) { dsvg_set_error("bad ingest arguments"); return DSVG_ERR_ARG; }
+    int k;
+    OPCHK(ingest_reserve(c, bytes, &k));
+    *dptr = c->ingest[k];
+    return DSVG_OK;
+}
+extern "C" int dsvg_ingest_part(dsvg_ctx *c, void *dptr, size_t offset, const void *host, size_t bytes)
+{
+    if (!c || !dptr || !host || !bytes) { dsvg_set_error("bad ingest arguments"); return DSVG_ERR_ARG; }
+    for (int k = 0; k < 2; k++)
+        if (c->ingest[k] && dptr == (void *)c->ingest[k]) {
+            if (offset + bytes > c->ingest_bytes[k]) { dsvg_set_error("ingest part beyond the reserved clip"); return DSVG_ERR_ARG; }
+            HIPCHK(hipSetDevice(c->device));
+            HIPCHK(hipMemcpyAsync(c->ingest[k] + offset, host, bytes, hipMemcpyHostToDevice, c->st_h));
+            HIPCHK(hipEventRecord(c->ev_up[k], c->st_h));
+            c->up_pending[k] = true;
+            return DSVG_OK;
+        }
+    dsvg_set_error("not an open ingest buffer");
+    return DSVG_ERR_ARG;
 }
 
 // a frame source inside an ingest buffer: the analysis stream waits for the upload; returns the buffer index or -1

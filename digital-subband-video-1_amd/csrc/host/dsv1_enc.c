@@ -992,6 +992,7 @@ typedef struct {
     dsv1_batch *b;
     int pipelined, F, fill, cur, inflight, failed;
     uint8_t *pin[2];
+    void *dev;                  /* device buffer the frames of the batch being gathered are uploaded into, one by one (dsvg_ingest_open / _part) */
     size_t fb;
     DSV_BUF backlog;            /* finished packets not handed out yet */
     unsigned off;               /* first byte of the backlog not handed out */
@@ -1038,7 +1039,9 @@ static int sess_collect(enc_sess *ss)
 static int sess_submit(enc_sess *ss)
 {
     int rc;
-    if ((rc = batch_submit_impl(ss->b, ss->pin[ss->cur], 0, NULL, ss->fill))) return rc;
+    /* the frames are on the device already (or on their way: the load waits for the last part on the device) */
+    if ((rc = batch_submit_impl(ss->b, ss->dev, 1, NULL, ss->fill))) return rc;
+    ss->dev = NULL;
     ss->inflight++;
     ss->cur ^= 1;
     ss->fill = 0;
@@ -1176,6 +1179,13 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         else copy_part(&cc, 0, 0);
     }
     dsv_frame_ref_dec(frame);                           /* the encoder owns the frame (dsv_encoder.c:38-40) */
+    if (ss->pipelined) {
+        /* its upload starts now, under the caller's reading of the next frame -- not in one burst when the batch is full */
+        rc = DSVG_OK;
+        if (!ss->dev) rc = dsvg_ingest_open(ss->b->ctx, ss->fb * (size_t)ss->F, &ss->dev);
+        if (!rc) rc = dsvg_ingest_part(ss->b->ctx, ss->dev, (size_t)ss->fill * ss->fb, ss->pin[ss->cur] + (size_t)ss->fill * ss->fb, ss->fb);
+        if (rc) { dsv1_log(1, "frame upload failed: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; return sess_pop(ss, bufs, 2); }
+    }
     ss->fill++;
     if (!ss->pipelined) {
         DSV_BUF acc = {NULL, 0};

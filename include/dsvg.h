@@ -142,6 +142,12 @@ int dsvg_dev_download(dsvg_ctx *ctx, void *dst, const void *dptr, size_t bytes);
 int dsvg_host_alloc(dsvg_ctx *ctx, void **hptr, size_t bytes);
 int dsvg_host_free(dsvg_ctx *ctx, void *hptr);
 int dsvg_ingest_begin(dsvg_ctx *ctx, const void *yuv_host, size_t bytes, void **dptr);
+/* The same for a clip that arrives piece by piece (dsv_enc takes a frame per call): dsvg_ingest_open reserves the next of the
+ * two buffers for `bytes` bytes and returns it; dsvg_ingest_part queues the upload of one piece (host memory, pinned for an
+ * asynchronous copy) to dptr + offset as soon as the caller has it.  A load from the buffer waits, on the device, for the
+ * parts queued before it. */
+int dsvg_ingest_open(dsvg_ctx *ctx, size_t bytes, void **dptr);
+int dsvg_ingest_part(dsvg_ctx *ctx, void *dptr, size_t offset, const void *host, size_t bytes);
 
 /* Tightly packed planar frames -> resident source slots [first_slot, first_slot+n):
  * copy into the bordered reference layout, replicate borders (dsv_clone_frame/dsv_extend_frame),
