@@ -519,11 +519,11 @@ def main():
                                                  config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: serial per frame), 2 streams x 30 frames per step")
                 # the content that leaves the lean kernels: flat moving objects force a third of the blocks intra (whole-grid
                 # k_fwd_mc_pix, k_mc for the intra blocks, dense symbols) -- same shape and batch as the headline
-                wc = A.gen_clip(W, H, FMT, 0x10800003, 4, style=1)
-                shapes["cfg3_style1_worstcase"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 3, 0x10800003, 12, style=1, qp=QP, gop=GOP, rc_mode_cli=1),
-                                                       config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1, %d closed GOPs x 12 frames per step, clip style 1 "
-                                                              "(flat square + flat band changing every frame)" % args.gops,
-                                                       intra_blocks_pct_of_P_pictures=intra_block_pct(A, wc, W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1))
+                wc = A.gen_clip(W, H, FMT, 0x10800003, 4, style=4)
+                shapes["cfg3_worstcase"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 3, 0x10800003, 12, style=4, qp=QP, gop=GOP, rc_mode_cli=1, scd=0),
+                                                       config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, %d closed GOPs x 12 frames per step, clip style 4 "
+                                                              "(pan + texture with a flat square of a third of the height and a flat band over the bottom quarter, both changing every frame)" % args.gops,
+                                                       intra_blocks_pct_of_P_pictures=intra_block_pct(A, wc, W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1, scd=0))
                 shapes["decode_1080p_batched"] = dict(decode_bench(pkg, A, dev, 64, 2),
                                                       config="1920x1080 4:2:0 GOP=12 stream, dsv1_decbatch_*: 64 streams side by side, one picture of each per call")
             except Exception as e:                       # the headline stands on its own

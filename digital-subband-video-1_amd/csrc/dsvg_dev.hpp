@@ -147,6 +147,11 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     unsigned *stat;          // null, or [4][64] diagnostic counters (64 shards each: one address takes ~90 atomics/us): inverse tiles on the general path {luma, chroma}, on the zero path {luma, chroma}
     int dec_sym[3];          // decoder, P pictures: 1 = the plane's detail entries are scattered as int16 symbols into the (zero-kept) symbol plane and the
                              // fused inverse dequantises them (planes without shared scan cells); 0 = dequantised int32 coefficients
+    int *dec_flag;           // decoder: one word per job, set by the scatter when the sparse symbol path cannot represent the picture exactly (bit 0: a symbol
+                             // beyond int16; bit 1: a cell shared by two scan regions keeps the EARLIER region's value, hzcc.c:295-435) -- the host then
+                             // decodes the call again on the int32 coefficient path (dsvg_decode_pictures)
+    int dec_lim[16];         // decoder, sparse path: largest |dequantised value| a P picture of 8-bit video can hold at transform level k ([0]: the DC) --
+                             // twice the forward transform's gain bound (tests/test_symbol_range.py); beyond it the packed int16 inverse is not exact
     int pf_off[3];           // offset of each plane in pflag (= CoefLayout.s3off)
     int fused;               // 1: forward transform already quantised the detail bands (P pictures)
     int32_t *llsym;          // encoder, llq: quantised symbols of the LL region (scan cells below hz[c].r[1].base), int32, plane c at ll_off[c] + scan position;

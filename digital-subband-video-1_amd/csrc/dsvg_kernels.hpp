@@ -43,6 +43,7 @@ void launch_hz_quant(hipStream_t st, const JobDev *jobs, int njobs, int job_chun
 void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ndense = -1);
 void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf = nullptr);
 void launch_dec_clear(hipStream_t st, const JobDev *jobs, int njobs);                       // decoder: zero what the scatter leaves untouched
+void launch_hz_dec_resolve(hipStream_t st, const JobDev *jobs, int njobs, int c0, int nplanes);
 void launch_hz_unscatter(hipStream_t st, const JobDev *jobs, int njobs, int max_entries);   // decoder: take the scattered symbols down again
 int  hz_scan_items_max();
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);

@@ -138,6 +138,21 @@ struct dsvg_ctx {
     size_t dec_cap[2] = {0, 0};
     hipEvent_t ev_dec[2] = {nullptr, nullptr};   // uploads of the call that last used that parity
     int dec_par = 0;
+    // Decoder, sparse symbol path: a call is enqueued optimistically; its scatter stage flags pictures the int16 symbol planes
+    // cannot represent exactly (JobDev.dec_flag).  The flags come back asynchronously and are looked at when the next decoder
+    // call starts or a result is read (dec_resolve): a flagged call is decoded again on the int32 coefficient path, and a
+    // device-side pack of its pictures that was already enqueued is repeated.
+    int *dec_flag_d = nullptr, *dec_flag_h = nullptr;    // [2][max_jobs]
+    hipEvent_t ev_flag[2] = {nullptr, nullptr};
+    struct DecPending {
+        bool active = false, in_redo = false;
+        int parity = 0, njobs = 0;
+        std::vector<dsvg_dec_job> jobs;                  // the call's jobs in device order, pointing into the parity's pinned staging
+        bool have_pack = false;
+        std::vector<int> pack_slots; void *pack_out = nullptr; size_t pack_pitch = 0;
+    } dec_pending;
+    bool dec_ov[2] = {false, false};    // luma / chroma planes have cells shared between scan regions (k_hz_dec_resolve)
+    long dec_redone = 0;                // calls decoded again on the int32 path (tests)
     HzParseChunk *dec_meta = nullptr;            // decoder: k_hz_parse -> k_hz_codes records of one call
     size_t dec_meta_cap = 0;
     uint8_t *yuv_stage = nullptr;    // device staging for host-resident input frames
@@ -159,10 +174,14 @@ struct dsvg_ctx {
     Prof prof;
 };
 
+static int dec_resolve(dsvg_ctx *c);     // decoder: settle the flags of the last call (defined with dsvg_decode_pictures)
+
 static void ctx_free(dsvg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->dec_flag_d) (void)hipFree(c->dec_flag_d);
+    if (c->dec_flag_h) (void)hipHostFree(c->dec_flag_h);
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
@@ -185,6 +204,7 @@ static void ctx_free(dsvg_ctx *c)
         if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
         if (c->ev_used[i]) (void)hipEventDestroy(c->ev_used[i]);
         if (c->ev_dec[i]) (void)hipEventDestroy(c->ev_dec[i]);
+        if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
     }
     for (hipEvent_t e : c->ev_coded) (void)hipEventDestroy(e);
     delete c;
@@ -273,7 +293,8 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
         HzPlane hp; make_hz_plane(hp, CL.w[g2 ? 1 : 0], CL.h[g2 ? 1 : 0], 100, 1, g2, c->nbh, c->nbv);
         const bool ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
         // (the fused inverse from symbol planes also wants the level-1 bands 4-aligned and the plane's LL5 path as usual)
-        c->dec_sym_ok[g2] = !ov && (CL.off[g2 ? 1 : 0] & 3) == 0 && (CL.off[2] & 3) == 0;
+        c->dec_sym_ok[g2] = (CL.off[g2 ? 1 : 0] & 3) == 0 && (CL.off[2] & 3) == 0 && !(ov && getenv("DSV1_NO_DEC_SYM_OV"));
+        c->dec_ov[g2] = ov;
     }
     // two coding streams by default: with the analysis and fetch streams that is four, the number of hardware queues
     // the runtime maps streams onto (three coding streams measured 18.5 ms per step against 14.3 with two and 15.4 with one)
@@ -408,6 +429,7 @@ extern "C" int dsvg_ctx_sync(dsvg_ctx *c)
 {
     if (!c) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    OPCHK(dec_resolve(c));
     if (c->st_h) HIPCHK(hipStreamSynchronize(c->st_h));
     for (int g = 1; g < DSVG_MAX_CODE_STREAMS; g++) if (c->stx[g]) HIPCHK(hipStreamSynchronize(c->stx[g]));
     HIPCHK(hipStreamSynchronize(c->st_a));
@@ -1154,6 +1176,7 @@ extern "C" int dsvg_download_recon(dsvg_ctx *c, int recon_slot, uint8_t *yuv_out
 {
     if (!c || !yuv_out || recon_slot < 0 || recon_slot >= c->n_recon) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    OPCHK(dec_resolve(c));
     const size_t fb = (size_t)c->L[0].w[0] * c->L[0].h[0] + 2 * (size_t)c->L[0].w[1] * c->L[0].h[1];
     if (c->yuv_stage_bytes < fb) {
         if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
@@ -1186,6 +1209,7 @@ extern "C" int dsvg_download_recon_asis(dsvg_ctx *c, int recon_slot, uint8_t *ra
 {
     if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    OPCHK(dec_resolve(c));
     OPCHK(dsvg_ctx_sync(c));
     HIPCHK(hipMemcpy(raw_out, c->recon.p + (size_t)recon_slot * c->L[0].pitch, bytes, hipMemcpyDeviceToHost));
     return DSVG_OK;
@@ -1204,6 +1228,7 @@ extern "C" int dsvg_download_recon_raw(dsvg_ctx *c, int recon_slot, uint8_t *raw
 {
     if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
+    OPCHK(dec_resolve(c));
     OPCHK(dsvg_ctx_sync(c));
     OPCHK(dsvg_extend_recon(c, recon_slot));            // the encoder writes only the part of the border that is read
     OPCHK(dsvg_ctx_sync(c));
@@ -1219,6 +1244,13 @@ extern "C" int dsvg_pack_recons(dsvg_ctx *c, int n, const int *recon_slots, void
     if (out_pitch < fb) { dsvg_set_error("output pitch smaller than a frame"); return DSVG_ERR_ARG; }
     for (int i = 0; i < n; i++)
         if (recon_slots[i] < 0 || recon_slots[i] >= c->n_recon) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
+    if (!out_on_device) OPCHK(dec_resolve(c));          // (the call synchronises anyway: a flagged decoder call is repeated first)
+    else if (c->dec_pending.active && !c->dec_pending.in_redo && !c->dec_pending.have_pack) {
+        // device output of a decoder call whose flags are not back yet: packed optimistically, repeated by dec_resolve if need be
+        c->dec_pending.have_pack = true;
+        c->dec_pending.pack_slots.assign(recon_slots, recon_slots + n);
+        c->dec_pending.pack_out = yuv_out; c->dec_pending.pack_pitch = out_pitch;
+    } else if (c->dec_pending.active && !c->dec_pending.in_redo) OPCHK(dec_resolve(c));   // a second pack of the same call: settle it now
     if (!c->ptab_d) HIPCHK(hipMalloc((void **)&c->ptab_d, sizeof(int) * (size_t)c->n_recon + 64));
     HIPCHK(hipMemcpyAsync(c->ptab_d, recon_slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st));   // pageable: staged by the runtime
     if (out_on_device) {
@@ -1253,9 +1285,44 @@ struct Rd {                          // MSB-first reader (bs.c:111-125,148-157,2
 };
 }
 
+static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool force32);
+
+// look at the flags of the last decoder call (see dsvg_ctx::dec_pending); decode it again on the int32 path if it asks for it
+static int dec_resolve(dsvg_ctx *c)
+{
+    dsvg_ctx::DecPending &P = c->dec_pending;
+    if (!P.active || P.in_redo) return DSVG_OK;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_flag[P.parity]));
+    P.active = false;
+    int any = 0;
+    for (int t = 0; t < P.njobs; t++) any |= c->dec_flag_h[(size_t)P.parity * c->max_jobs + t];
+    if (!any) return DSVG_OK;
+    static const bool verbose = getenv("DSV1_DEC_VERBOSE") != nullptr;
+    if (verbose) fprintf(stderr, "[dsvg decode] flags %#x: the call's %d picture(s) are decoded again from int32 coefficients\n", any, P.njobs);
+    P.in_redo = true;
+    c->dec_redone++;
+    std::vector<dsvg_dec_job> jobs = P.jobs;             // (decode_impl overwrites the pending record)
+    const bool pack = P.have_pack;
+    std::vector<int> slots = P.pack_slots; void *out = P.pack_out; const size_t pitch = P.pack_pitch;
+    int rc = decode_impl(c, (int)jobs.size(), jobs.data(), true);
+    if (!rc && pack) rc = dsvg_pack_recons(c, (int)slots.size(), slots.data(), out, pitch, 1);
+    P.in_redo = false;
+    P.active = false;
+    return rc;
+}
+
+extern "C" long dsvg_ctx_decoder_redone(const dsvg_ctx *c) { return c ? c->dec_redone : 0; }
+
 extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs)
 {
     if (!c || !jobs || njobs < 1 || njobs > c->max_jobs) { dsvg_set_error("bad decode_pictures arguments"); return DSVG_ERR_ARG; }
+    OPCHK(dec_resolve(c));                               // the call before may have to be decoded again first (its pictures are references)
+    return decode_impl(c, njobs, jobs, false);
+}
+
+static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool force32)
+{
     HIPCHK(hipSetDevice(c->device));
     std::vector<int> ord;
     for (int i = 0; i < njobs; i++) if (jobs[i].ref_recon_slot < 0) ord.push_back(i);
@@ -1271,7 +1338,8 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     for (int t = 0; t < njobs; t++)
         for (int p = 0; p < 3; p++) {
             const dsvg_dec_job &j = jobs[ord[t]];
-            if (!j.plane_data[p] || (size_t)j.plane_len[p] + 64 > c->bits_cap[p]) { dsvg_set_error("plane %d of decode job %d: bad length", p, ord[t]); return DSVG_ERR_ARG; }
+            // the reference's bound (dsv_decoder.c:397-398: twice the int32 coefficient plane), not the encoder's output capacity
+            if (!j.plane_data[p] || (size_t)j.plane_len[p] > (size_t)c->CL.w[p] * c->CL.h[p] * 8) { dsvg_set_error("plane %d of decode job %d: bad length", p, ord[t]); return DSVG_ERR_ARG; }
             blob += ((size_t)j.plane_len[p] + 64 + 15) & ~(size_t)15;
         }
     if (blob > c->dec_cap[k]) {
@@ -1294,6 +1362,15 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         c->dec_meta_cap = cap;
     }
     const size_t hb = (size_t)k * c->max_jobs;          // this parity's part of the pinned tables
+    const bool sparse = !c->no_dec_sym && !force32;
+    if (!c->dec_flag_d) {
+        HIPCHK(hipMalloc((void **)&c->dec_flag_d, sizeof(int) * 2 * (size_t)c->max_jobs));
+        HIPCHK(hipHostMalloc((void **)&c->dec_flag_h, sizeof(int) * 2 * (size_t)c->max_jobs, hipHostMallocDefault));
+        for (int i = 0; i < 2; i++) HIPCHK(hipEventCreateWithFlags(&c->ev_flag[i], hipEventDisableTiming));
+    }
+    dsvg_ctx::DecPending &P = c->dec_pending;
+    const bool was_redo = P.in_redo;
+    if (!was_redo) { P.jobs.resize((size_t)njobs); P.have_pack = false; }
     int max_entries = 0, max_chunks = 0;
     size_t moff = 0;
     const CoefLayout &CL = c->CL;
@@ -1308,11 +1385,24 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         fill_job(c, jb, t, isP, j.quant);
         jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
         jb.recon = c->recon.p + (size_t)j.recon_slot * c->L[0].pitch;
-        if (isP && !c->no_dec_sym) {
+        jb.dec_flag = c->dec_flag_d + hb + t;
+        {   // range of a P picture of 8-bit video per transform level: detail <= 4 x the LL below, LL = 4/5 of that (level 1 of a
+            // P picture unscaled), a dequantised value <= twice its coefficient (hzcc.c:94-128: a non-zero symbol needs 2|v| > q)
+            long ll = 512;
+            jb.dec_lim[1] = 2 * 510;
+            for (int lv = 2; lv < 16; lv++) {
+                const long det = 4 * ll;
+                jb.dec_lim[lv] = (int)std::min<long>(2 * det, 0x3fffffff);
+                ll = std::min<long>(det * 4 / 5, 0x1fffffff);
+            }
+            jb.dec_lim[0] = (int)std::min<long>(2 * ll, 0x3fffffff);
+        }
+        if (isP && sparse) {
             // sparse decode of P pictures: the detail entries go to the zero-kept int16 symbol planes and the fused inverse
             // of the encoder reconstructs from them (no 12 MB of int32 coefficients to clear and to read per picture); a
-            // plane whose scan regions share cells keeps the coefficient path (an absent later symbol must leave the
-            // earlier region's VALUE in place there, hzcc.c:295-435)
+            // plane whose scan regions share cells takes it too: k_hz_dec_resolve flags the rare picture in which an absent later
+            // symbol must leave the earlier region's VALUE in place (hzcc.c:295-435), and that call is decoded again from
+            // int32 coefficients (dec_resolve)
             jb.sym = c->symP + (size_t)t * c->nz_total;
             jb.nzf = c->nzf + (size_t)t * (c->nz_total >> 2);          // (marks the job as sparse for the inverse; the flags themselves are the encoder's)
             for (int p = 0; p < 3; p++) jb.dec_sym[p] = c->dec_sym_ok[p < 1 ? 0 : 1];
@@ -1321,6 +1411,12 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
         c->slots_h[hb + t] = j.recon_slot;
         memcpy(c->stable_h + (hb + t) * c->nblk, j.stable_blocks, (size_t)c->nblk);
         if (isP) memcpy(c->mv_h + (hb + t) * c->nblk, j.mvs, (size_t)c->nblk * sizeof(DMV));
+        if (!was_redo) {                                // what a repetition of this call needs, out of the pinned staging (intact until the parity comes round again)
+            dsvg_dec_job &sj = P.jobs[(size_t)t];
+            sj = j;
+            sj.stable_blocks = c->stable_h + (hb + t) * c->nblk;
+            sj.mvs = reinterpret_cast<const dsvg_mv *>(c->mv_h + (hb + t) * c->nblk);
+        }
         jb.bits = c->dec_d[k];                          // the payloads of the call travel as one blob
         for (int p = 0; p < 3; p++) {
             // the host reads only the plane header (hzcc.c:479-483,307-311): SEG(DC), the 32-bit run count; the
@@ -1339,6 +1435,7 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
             max_chunks = std::max(max_chunks, (int)(j.plane_len[p] / 16 + 2));
             jb.bits_off[p] = off;
             uint8_t *stage = c->dec_h[k] + off;
+            if (!was_redo) P.jobs[(size_t)t].plane_data[p] = stage;
             memcpy(stage, j.plane_data[p], j.plane_len[p]);
             memset(stage + j.plane_len[p], 0, 64);
             off += ((size_t)j.plane_len[p] + 64 + 15) & ~(size_t)15;
@@ -1350,12 +1447,21 @@ extern "C" int dsvg_decode_pictures(dsvg_ctx *c, int njobs, const dsvg_dec_job *
     HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h + hb * c->nblk, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h + hb, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
+    const int insym = !sparse ? 0 : (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
+    if (insym && njobs > nI) HIPCHK(hipMemsetAsync(c->dec_flag_d + hb, 0, sizeof(int) * (size_t)njobs, c->st));
     launch_dec_clear(c->st, c->jobs_d, njobs);
     launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof);
+    if (insym && njobs > nI) {
+        // what the symbol planes cannot hold (JobDev.dec_flag): shared cells that keep the earlier region's value; symbols
+        // beyond int16 were flagged by the scatter itself.  The flags travel back now and are read by dec_resolve later.
+        if ((c->dec_ov[0] && c->dec_sym_ok[0]) || (c->dec_ov[1] && c->dec_sym_ok[1])) launch_hz_dec_resolve(c->st, c->jobs_d + nI, njobs - nI, 0, 3);
+        HIPCHK(hipMemcpyAsync(c->dec_flag_h + hb, c->dec_flag_d + hb, sizeof(int) * (size_t)njobs, hipMemcpyDeviceToHost, c->st));
+        HIPCHK(hipEventRecord(c->ev_flag[k], c->st));
+        if (!was_redo) { P.active = true; P.parity = k; P.njobs = njobs; }
+    } else if (!was_redo) P.active = false;
     if (njobs > nI) {
         launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }
-    const int insym = c->no_dec_sym ? 0 : (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
     OPCHK(enqueue_recon(c, nI, njobs, 0, insym));
     if (insym && njobs > nI) launch_hz_unscatter(c->st, c->jobs_d + nI, njobs - nI, max_entries);
     HIPCHK(hipGetLastError());

@@ -126,8 +126,15 @@ static int parse_picture_body(bitw *r, uint8_t *data, unsigned len, const dsvg_g
         bw_align(r);
         plen = (int)br_bits(r, 32);
         bw_align(r);
-        /* one limit with the device side (dsvg_decode_pictures stages plane_len + 64 bytes per plane) */
-        if (plen <= 0 || (size_t)plen + 64 > g->plane_out_cap[c] || !sub_fits(r, (unsigned)plen, len)) {
+        /* the reference's bound (dsv_decoder.c:389-400: twice the int32 coefficient plane, chroma dimensions rounded up to
+         * even) -- dsvg_decode_pictures applies the same; the packet's own length is the bound that keeps the reads safe */
+        {
+            const int hs = c ? (g->subsamp >> 2) & 3 : 0, vs = c ? g->subsamp & 3 : 0;
+            size_t pw = (size_t)((g->width + (1 << hs) - 1) >> hs), phh = (size_t)((g->height + (1 << vs) - 1) >> vs);
+            if (c) { pw = (pw + 1) & ~(size_t)1; phh = (phh + 1) & ~(size_t)1; }
+            if (plen > 0 && (size_t)plen > pw * phh * 8) plen = -1;
+        }
+        if (plen <= 0 || !sub_fits(r, (unsigned)plen, len)) {
             dsv1_log(1, "plane length was strange: %d", plen);
             return -1;
         }

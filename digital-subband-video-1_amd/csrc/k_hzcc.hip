@@ -1348,19 +1348,71 @@ __global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict_
     if (p < 0 || p >= hp.nscan) return;
     const int ph = p >= hp.r[7].base ? 2 : (p >= hp.r[4].base ? 1 : 0);
     if (ph != phase) return;
-    if (p == 0) { (jb.coef + jb.hz_coef_off[c])[0] = v; return; }     // unquantised DC (hzcc.c:495)
+    if (p == 0) {                                                     // unquantised DC (hzcc.c:495)
+        (jb.coef + jb.hz_coef_off[c])[0] = v;
+        if (jb.dec_sym[c] && (v < -jb.dec_lim[0] || v > jb.dec_lim[0])) atomicOr(jb.dec_flag, 1);
+        return;
+    }
     const HzRegion r = hp.r[find_region(hp, p)];
     const int local = p - r.base;
     const int y = local / r.sw, x = local - y * r.sw;
+    const int tq = cell_tq(r, jb.stable, hp.nbh, x, y);
+    const int dq = dequant_any(r, v, tq);
+    if (jb.dec_sym[c]) {
+        // The sparse path ends in the encoder's fused inverse, whose packed int16 level 1 is exact for what an ENCODER of 8-bit
+        // video can produce (range chain: tests/test_symbol_range.py).  A parsable stream may hold anything, and the reference
+        // decodes it in 32 bits (hzcc.c:295-435): a value beyond the encoder's range at its level -- a symbol beyond int16
+        // included -- flags the picture, and its call is decoded again from int32 coefficients (dsvg_decode_pictures).
+        int lvl = 3 - r.level;                                       // scan levels 0, 1, 2 = transform levels 3, 2, 1
+        if (r.level < 0) {                                           // LL region: the band of level k starts at column w_k or row h_k
+            lvl = 4;
+            while (lvl < 15 && x < DSVG_RSU(hp.w, lvl) && y < DSVG_RSU(hp.h, lvl)) lvl++;
+        }
+        if (dq < -jb.dec_lim[lvl] || dq > jb.dec_lim[lvl] || v < -32767 || v > 32767) { atomicOr(jb.dec_flag, 1); if (r.level >= 0) return; }
+    }
     if (jb.dec_sym[c] && r.level >= 0) {
         // sparse decode: the SYMBOL goes to its scan slot (the fused inverse dequantises it: levels 1-3 never exist as
         // int32 coefficients), and the 8x8-pixel patch it belongs to is flagged for the inverse's symbol fetch
-        (jb.sym + jb.nz_off[c])[p] = (int16_t)(v < -32767 ? -32767 : (v > 32767 ? 32767 : v));    // (beyond int16: not a symbol of 8-bit video)
+        (jb.sym + jb.nz_off[c])[p] = (int16_t)v;
         jb.pflag[jb.pf_off[c] + (y >> r.level) * hp.r[0].sw + (x >> r.level)] = 1;
         return;
     }
-    const int tq = cell_tq(r, jb.stable, hp.nbh, x, y);
-    (jb.coef + jb.hz_coef_off[c])[(size_t)(r.y0 + y) * hp.w + r.x0 + x] = dequant_any(r, v, tq);
+    (jb.coef + jb.hz_coef_off[c])[(size_t)(r.y0 + y) * hp.w + r.x0 + x] = dq;
+}
+
+// decoder, sparse symbol path on a plane whose scan regions share cells (960x540, 250x130): the inverse reads a
+// shared cell through the LATER region's slot.  The reference decoder (hzcc.c:295-435) writes non-zero symbols only, so a
+// cell whose later symbol is absent keeps the EARLIER region's dequantised value -- which no symbol of the later region's
+// quantiser expresses.  Rare (the later, finer quantiser must map a value the earlier one kept to zero): such a picture is
+// flagged and decoded again on the int32 coefficient path.  One thread per shared cell, geometry as hz_fix_overlaps.
+__global__ __launch_bounds__(256) void k_hz_dec_resolve(const JobDev *__restrict__ jobs, int c0)
+{
+    const int c = c0 + (int)blockIdx.y;
+    const JobDev &jb = jobs[blockIdx.x];
+    if (!jb.dec_sym[c]) return;
+    const HzPlane &hp = jb.hz[c];
+    const int16_t *sym = jb.sym + jb.nz_off[c];
+    for (int l = 0; l < 2; l++) {
+        const int cw = 2 * hp.s_w[l], ch = 2 * hp.s_h[l];
+        const bool col = cw > hp.s_w[l + 1], row = ch > hp.s_h[l + 1];
+        const int ncol = col ? ch : 0, nrow = row ? cw : 0;
+        for (int i = threadIdx.x; i < ncol + nrow; i += 256) {
+            int gx, gy;
+            if (i < ncol) { gx = hp.s_w[l + 1]; gy = i; }
+            else {
+                gx = i - ncol; gy = hp.s_h[l + 1];
+                if (col && gx == hp.s_w[l + 1]) continue;
+            }
+            const int ex = gx >= hp.s_w[l], ey = gy >= hp.s_h[l];
+            if (!(ex + ey)) continue;
+            const HzRegion &e = hp.r[1 + 3 * l + (ex + 2 * ey) - 1];
+            const int lx = gx >= hp.s_w[l + 1], ly = gy >= hp.s_h[l + 1];
+            const HzRegion &r = hp.r[1 + 3 * (l + 1) + (lx + 2 * ly) - 1];
+            const int es = sym[e.base + (gy - e.y0) * e.sw + (gx - e.x0)];
+            const int ls = sym[r.base + (gy - r.y0) * r.sw + (gx - r.x0)];
+            if (es != 0 && ls == 0) atomicOr(jb.dec_flag, 2);
+        }
+    }
 }
 
 // decoder, after the reconstruction: the symbols scattered by k_hz_scatter_lv are taken down again (the planes stay zero)
@@ -1406,6 +1458,10 @@ __global__ __launch_bounds__(256) void k_dec_clear(const JobDev *__restrict__ jo
 void launch_dec_clear(hipStream_t st, const JobDev *jobs, int njobs)
 {
     hipLaunchKernelGGL(k_dec_clear, dim3(64, njobs, 3), dim3(256), 0, st, jobs);
+}
+void launch_hz_dec_resolve(hipStream_t st, const JobDev *jobs, int njobs, int c0, int nplanes)
+{
+    hipLaunchKernelGGL(k_hz_dec_resolve, dim3(njobs, nplanes), dim3(256), 0, st, jobs, c0);
 }
 void launch_hz_unscatter(hipStream_t st, const JobDev *jobs, int njobs, int max_entries)
 {

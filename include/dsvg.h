@@ -241,6 +241,12 @@ typedef struct {
     uint32_t plane_len[3];
 } dsvg_dec_job;
 int dsvg_decode_pictures(dsvg_ctx *ctx, int njobs, const dsvg_dec_job *jobs);
+/* P pictures are decoded through int16 symbol planes (the encoder's fused inverse).  A picture those cannot hold exactly -- a
+ * symbol beyond int16 (not producible from 8-bit video, but parsable), or a cell shared by two scan regions that must keep
+ * the earlier region's value (hzcc.c:295-435) -- is detected on the device and its call decoded again from int32 coefficients
+ * before anything reads or predicts from the result (the next decode call, dsvg_ctx_sync, the downloads, a host-side pack).
+ * dsvg_ctx_decoder_redone: how many calls took that second pass (tests). */
+long dsvg_ctx_decoder_redone(const dsvg_ctx *ctx);
 
 /* Kernel timing hook for bench.py: every launch of the kernels selected by `kernel_mask` (bit i =
  * kernel id i, names from dsvg_prof_kernel_name) is bracketed by HIP events on the pipeline stream.

@@ -29,6 +29,20 @@ STREAM_CASES = {
     "cfg5_4k_444_abr": (3840, 2160, A.SUBSAMP_444, 7, 0, 0x21600005, ["-gop30", "-qp85", "-kbps20000"], dict(qp=85, gop=30, rc_mode_cli=0, kbps=20000)),
 }
 
+# Full-length streams of the BASELINE configs, hashes only (tests/golden/long_streams.json), run under -m gpu only: the CPU
+# oracle would take minutes on them.  Same tuple layout as STREAM_CASES.
+LONG_STREAM_CASES = {
+    # config 5 complete: 60 frames = 2 GOPs of 30, 4K 4:4:4, ABR feedback from every packet into the next quantiser, the CLI's
+    # stable_refresh of 14 against a GOP of 30
+    "cfg5_4k_444_abr_60": (3840, 2160, A.SUBSAMP_444, 60, 0, 0x21600005, ["-gop30", "-qp85", "-kbps20000"], dict(qp=85, gop=30, rc_mode_cli=0, kbps=20000)),
+    # config 4: two closed 4K GOPs (also coded GOP-sharded and in chain mode: all three must give these bytes)
+    "cfg4_4k_gop12_24": (3840, 2160, A.SUBSAMP_420, 24, 0, 0x21600004, ["-gop12", "-qp85", "-rc_mode1", "-scd0"], dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
+    # one 1080p stream with scene cuts, CLI defaults apart from CRF: plain GOP sharding is NOT exact here, chain mode is
+    "1080p_gop12_scenecuts_36": (1920, 1080, A.SUBSAMP_420, 36, 3, 0x10800333, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    # GOP 30 CRF: the stability accumulators (refresh every 14 P pictures) cross GOP boundaries
+    "1080p_gop30_crf_45": (1920, 1080, A.SUBSAMP_420, 45, 0, 0x10800030, ["-gop30", "-qp85", "-rc_mode1"], dict(qp=85, gop=30, rc_mode_cli=1)),
+}
+
 # operator-level known answers: name -> dict describing a seeded input
 OP_CASES = {
     "sbt_352x288_P": dict(op="sbt", w=352, h=288, isP=1, seed=11),

@@ -27,7 +27,7 @@ def test_bench_line_has_the_contract_fields():
     r = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
-    assert r["bound"] in ("hbm", "mfma") and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
     c = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -43,7 +43,10 @@ def test_bench_line_carries_the_other_shapes():
     assert d["value_host_pinned"]["value"] > 0 and d["value_host_pinned"]["value"] < d["value"] * 1.5
     sh = d["shapes"]
     assert "error" not in sh, sh
-    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg5_4k_444_abr", "decode_1080p_batched"):
+    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg5_4k_444_abr", "cfg3_worstcase", "decode_1080p_batched"):
         assert sh[k]["Mpix_s"] > 0 and sh[k]["bit_exact_vs_cpu"] is True, (k, sh[k])
+    assert sh["cfg3_worstcase"]["intra_blocks_pct_of_P_pictures"] > 25          # the clip really leaves the lean path
+    if "pipeline" in d:                                  # (needs profiles/pmc_traffic.json with the per-step sum)
+        assert d["pipeline"]["bound"] == "hbm" and 0 < d["pipeline"]["frac"] < 1
     c = d["cpu_baseline"]
     assert c["nproc"] >= 1 and isinstance(c["cpu_model"], str)

@@ -45,3 +45,43 @@ def test_gpu_stream_matches_reference_golden(pkg, name):
 def test_gpu_operator_matches_reference_golden(pkg, orc, name):
     got = G.run_op_case(G.OP_CASES[name], "prod", A.load_prod(), orc=orc)
     assert got == OPS[name]
+
+
+with open(os.path.join(GOLD, "long_streams.json")) as f:
+    LONG = json.load(f)
+
+
+def _check_long(name, got):
+    want = LONG[name]
+    pk = A.split_packets(got)
+    assert [sha(p) for p in pk[:4]] == want["first_packets"], "%s: the stream differs within its first packets" % name
+    assert len(got) == want["len"] and len(pk) == want["packets"]
+    assert [sha(p) for p in pk[-3:]] == want["last_packets"]
+    assert sha(got) == want["sha256"]
+
+
+@pytest.mark.parametrize("name", sorted(G.LONG_STREAM_CASES))
+def test_gpu_full_length_stream_matches_reference_golden(pkg, name):
+    """BASELINE configs 4 and 5 at full length (cfg5: both GOPs, the ABR loop over 60 packets) and the two 1080p streams only the
+    always-exact scheme shards correctly -- frame-serial session (ABR) / chain mode (CRF) against the reference CLI's bytes"""
+    w, h, fmt, n, style, seed, flags, kw = G.LONG_STREAM_CASES[name]
+    clip = A.gen_clip(w, h, fmt, seed, n, style=style)
+    if kw["rc_mode_cli"] == 0:
+        got = pkg.encode_clip(clip, w, h, fmt, **kw)                 # ABR: serial per frame by definition
+    else:
+        fpc = 12 if n % 12 == 0 else 15
+        got = pkg.encode_stream(clip, w, h, fmt, fpc, 3, **kw)       # GOP-parallel, calls that end in mid-GOP for GOP 30
+    _check_long(name, got)
+    if name.startswith("cfg4"):
+        _check_long(name, pkg.encode_gops(clip, w, h, fmt, 12, qp=kw["qp"], rc_mode_cli=1, scd=0))    # GOP-sharded batch == serial
+        _check_long(name, pkg.encode_clip(clip, w, h, fmt, **kw))                                      # frame-serial
+
+
+def test_plain_gop_sharding_is_not_exact_on_scene_cuts_but_chain_mode_is(pkg):
+    """why SURVEY 8(e) asks for the two-pass scheme: GOP sharding of the scene-cut stream gives other bytes (stability and
+    scene-change state cross GOP boundaries) -- the golden above pins chain mode to the reference on the same clip"""
+    name = "1080p_gop12_scenecuts_36"
+    w, h, fmt, n, style, seed, flags, kw = G.LONG_STREAM_CASES[name]
+    clip = A.gen_clip(w, h, fmt, seed, n, style=style)
+    sharded = pkg.encode_gops(clip, w, h, fmt, 12, qp=kw["qp"], rc_mode_cli=1)
+    assert sha(sharded) != LONG[name]["sha256"]

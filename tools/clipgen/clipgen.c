@@ -13,6 +13,8 @@
  *   style 2: static background (no pan), a fast TEXTURED bright square (blocks it half covers
  *   become intra with partial sub-block masks) and a global +14 luma step from frame 5 on
  *   (scene-change detection).
+ *   style 4: style 1 with a flat square of a third of the frame height and a flat band over its bottom quarter (a third
+ *   of all blocks intra, no picture forced intra: the content that leaves the encoder's lean kernels).
  *   style 3: style 0 with SCENE CUTS: every 7 frames the texture is another one and the brightness steps by 12 (the mean
  *   luma of the smallest pyramid level moves by more than the default scene_change_delta of 4: dsv_encoder.c:538-554).
  */
@@ -54,6 +56,8 @@ size_t clipgen_frame_bytes(int w, int h, int subsamp)
 void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t, int style)
 {
     int lift = 0;                                   /* style 3: brightness step of the scene */
+    int big = 0;                                    /* style 4: style 1 with flat objects that cover a third of the frame */
+    if (style == 4) { big = 1; style = 1; }
     if (style == 3) {
         const int scene = t / 7;
         seed ^= mix(0x5CE9Eu + (uint32_t)scene);
@@ -61,33 +65,44 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
         style = 0;
     }
     const int TW = w + 2 * MARGIN, TH = h + 2 * MARGIN;
-    uint8_t *noise = (uint8_t *)malloc((size_t)TW * TH);
-    uint8_t *tex = (uint8_t *)malloc((size_t)TW * TH);
-    uint16_t *colsum = (uint16_t *)malloc((size_t)TW * sizeof(uint16_t));
-
-    for (int y = 0; y < TH; y++)
-        for (int x = 0; x < TW; x++)
-            noise[(size_t)y * TW + x] = (uint8_t)(hash3((uint32_t)x, (uint32_t)y, seed) >> 24);
-    /* 5x5 box blur, clamped addressing, rounded */
-    for (int y = 0; y < TH; y++) {
-        for (int x = 0; x < TW; x++) {
-            int s = 0;
-            for (int dy = -2; dy <= 2; dy++) {
-                int yy = y + dy; yy = yy < 0 ? 0 : (yy >= TH ? TH - 1 : yy);
-                s += noise[(size_t)yy * TW + x];
+    /* the texture depends on (w, h, seed) only: kept from one frame of a clip to the next (one entry; callers are single
+     * threaded -- the tests and bench.py generate their clips up front) */
+    static uint8_t *tex_cache = NULL;
+    static int cw_ = 0, ch_ = 0;
+    static uint32_t cseed_ = 0;
+    uint8_t *tex;
+    if (tex_cache && cw_ == w && ch_ == h && cseed_ == seed) tex = tex_cache;
+    else {
+        uint8_t *noise = (uint8_t *)malloc((size_t)TW * TH);
+        uint16_t *colsum = (uint16_t *)malloc((size_t)TW * sizeof(uint16_t));
+        free(tex_cache);
+        tex = tex_cache = (uint8_t *)malloc((size_t)TW * TH);
+        cw_ = w; ch_ = h; cseed_ = seed;
+        for (int y = 0; y < TH; y++)
+            for (int x = 0; x < TW; x++)
+                noise[(size_t)y * TW + x] = (uint8_t)(hash3((uint32_t)x, (uint32_t)y, seed) >> 24);
+        /* 5x5 box blur, clamped addressing, rounded */
+        for (int y = 0; y < TH; y++) {
+            for (int x = 0; x < TW; x++) {
+                int s = 0;
+                for (int dy = -2; dy <= 2; dy++) {
+                    int yy = y + dy; yy = yy < 0 ? 0 : (yy >= TH ? TH - 1 : yy);
+                    s += noise[(size_t)yy * TW + x];
+                }
+                colsum[x] = (uint16_t)s;
             }
-            colsum[x] = (uint16_t)s;
-        }
-        for (int x = 0; x < TW; x++) {
-            int s = 0;
-            for (int dx = -2; dx <= 2; dx++) {
-                int xx = x + dx; xx = xx < 0 ? 0 : (xx >= TW ? TW - 1 : xx);
-                s += colsum[xx];
+            for (int x = 0; x < TW; x++) {
+                int s = 0;
+                for (int dx = -2; dx <= 2; dx++) {
+                    int xx = x + dx; xx = xx < 0 ? 0 : (xx >= TW ? TW - 1 : xx);
+                    s += colsum[xx];
+                }
+                /* stretch contrast a little so the texture survives quantisation */
+                int v = (s + 12) / 25;
+                tex[(size_t)y * TW + x] = sat8(128 + (v - 128) * 3);
             }
-            /* stretch contrast a little so the texture survives quantisation */
-            int v = (s + 12) / 25;
-            tex[(size_t)y * TW + x] = sat8(128 + (v - 128) * 3);
         }
+        free(noise); free(colsum);
     }
 
     const int hx = style == 2 ? 0 : 3 * t, ypan = style == 2 ? 0 : t;   /* half-pel x shift, integer y shift */
@@ -104,12 +119,12 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
         }
     }
     if (style == 1) {
-        int sq = w < 192 ? w / 4 : 96;
+        int sq = big ? h / 3 : (w < 192 ? w / 4 : 96);
         if (sq > h - 8) sq = h - 8;                   /* very flat frames: keep the square inside */
         int sx = (37 * t) % (w - sq), sy = (23 * t) % (h - sq);
         int lvl = 40 + 15 * t; if (lvl > 250) lvl = 250;
         for (int y = 0; y < sq; y++) memset(Y + (size_t)(sy + y) * w + sx, lvl, (size_t)sq);
-        int band = h / 8, bl = 100 + 12 * (t % 3);
+        int band = big ? h / 4 : h / 8, bl = 100 + 12 * (t % 3);
         for (int y = h - band; y < h; y++) memset(Y + (size_t)y * w, bl, (size_t)w);
     }
 
@@ -135,11 +150,10 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
             V[(size_t)y * cw + x] = sat8(104 + tri(y - 2 * t, 48) * 2 + tri(x + y, 90) / 2 + (tv >> 6));
         }
     if (style == 1) {
-        int band = ch / 8;
+        int band = big ? ch / 4 : ch / 8;
         for (int y = ch - band; y < ch; y++) {
             memset(U + (size_t)y * cw, 120 + 6 * (t % 3), (size_t)cw);
             memset(V + (size_t)y * cw, 136 - 5 * (t % 3), (size_t)cw);
         }
     }
-    free(noise); free(tex); free(colsum);
 }

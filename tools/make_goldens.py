@@ -8,6 +8,8 @@ A fixture is data: inputs come from the committed integer generator (tools/clipg
 test time from (w,h,fmt,seed,style)), expected outputs are produced here by the reference:
   * streams.json   -- for each stream case: CLI flags, sha256 + length of the whole .dsv, sha256 of every
                       packet, sha256 of every decoded frame (reference decoder)
+  * long_streams.json -- full-length streams of BASELINE configs 4 and 5 and two 1080p streams that need the always-exact
+                      scheme (scene cuts; GOP 30): length, sha256, packet count, hashes of the first / last packets
   * cif_gop12.dsv  -- one complete small stream kept verbatim (config-1 size, 6 frames)
   * ops.json       -- operator-level known answers: sha256 of dsv_fwd_sbt / dsv_inv_sbt / dsv_encode_plane
                       / dsv_sub_pred / dsv_hme outputs on seeded inputs
@@ -77,6 +79,20 @@ def main():
             print(name, len(dsv), streams[name]["sha256"][:16])
     with open(os.path.join(OUT, "streams.json"), "w") as f:
         json.dump(streams, f, indent=1, sort_keys=True)
+
+    if "--skip-long" not in sys.argv:
+        longs = {}
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            for name, (w, h, fmt, n, style, seed, flags, kw) in G.LONG_STREAM_CASES.items():
+                clip = A.gen_clip(w, h, fmt, seed, n, style=style)
+                dsv = A.ref_cli_encode(clip, w, h, A.FMT_CLI[fmt], flags, td)
+                pk = A.split_packets(dsv)
+                longs[name] = {"len": len(dsv), "sha256": sha(dsv), "packets": len(pk),
+                               "intra_pictures": sum(1 for p in pk if (p[5] & 4) and not (p[5] & 1)),
+                               "first_packets": [sha(p) for p in pk[:4]], "last_packets": [sha(p) for p in pk[-3:]]}
+                print(name, len(dsv), longs[name]["sha256"][:16], "I pictures:", longs[name]["intra_pictures"])
+        with open(os.path.join(OUT, "long_streams.json"), "w") as f:
+            json.dump(longs, f, indent=1, sort_keys=True)
 
     ops = {}
     for name, case in G.OP_CASES.items():
