@@ -38,9 +38,9 @@ LONG_STREAM_CASES = {
     # config 4: two closed 4K GOPs (also coded GOP-sharded and in chain mode: all three must give these bytes)
     "cfg4_4k_gop12_24": (3840, 2160, A.SUBSAMP_420, 24, 0, 0x21600004, ["-gop12", "-qp85", "-rc_mode1", "-scd0"], dict(qp=85, gop=12, rc_mode_cli=1, scd=0)),
     # one 1080p stream with scene cuts, CLI defaults apart from CRF: plain GOP sharding is NOT exact here, chain mode is
-    "1080p_gop12_scenecuts_36": (1920, 1080, A.SUBSAMP_420, 36, 3, 0x10800333, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
+    "1080p_gop12_scenecuts_36": (1920, 1080, A.SUBSAMP_420, 36, 5, 0x10800333, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
     # GOP 30 CRF: the stability accumulators (refresh every 14 P pictures) cross GOP boundaries
-    "1080p_gop30_crf_45": (1920, 1080, A.SUBSAMP_420, 45, 0, 0x10800030, ["-gop30", "-qp85", "-rc_mode1"], dict(qp=85, gop=30, rc_mode_cli=1)),
+    "1080p_gop30_crf_45": (1920, 1080, A.SUBSAMP_420, 45, 5, 0x10800030, ["-gop30", "-qp85", "-rc_mode1"], dict(qp=85, gop=30, rc_mode_cli=1)),
 }
 
 # operator-level known answers: name -> dict describing a seeded input

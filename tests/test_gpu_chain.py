@@ -23,15 +23,15 @@ def pkg():
 
 CASES = [
     # w, h, fmt, frames, style, frames_per_call, chains, CLI-style flags
-    (352, 288, A.SUBSAMP_420, 48, 3, 24, 3, dict(qp=85, gop=12, rc_mode_cli=1)),            # scene cuts every 7 frames, CLI defaults otherwise (scd on)
-    (352, 288, A.SUBSAMP_420, 48, 3, 16, 2, dict(qp=85, gop=12, rc_mode_cli=1)),            # more chains in a call than run side by side; calls that end in mid-GOP
+    (352, 288, A.SUBSAMP_420, 48, 5, 24, 3, dict(qp=85, gop=12, rc_mode_cli=1)),            # scene cuts every 7 frames, fast pan, CLI defaults otherwise (scd on)
+    (352, 288, A.SUBSAMP_420, 48, 5, 16, 2, dict(qp=85, gop=12, rc_mode_cli=1)),            # more chains in a call than run side by side; calls that end in mid-GOP
     (176, 144, A.SUBSAMP_420, 60, 0, 20, 2, dict(qp=85, gop=30, rc_mode_cli=1)),            # GOP 30: stable_refresh 14, stability state crosses GOPs and calls
-    (176, 144, A.SUBSAMP_420, 60, 3, 30, 4, dict(qp=70, gop=30, rc_mode_cli=1)),
+    (176, 144, A.SUBSAMP_420, 60, 5, 30, 4, dict(qp=70, gop=30, rc_mode_cli=1)),
     (352, 288, A.SUBSAMP_420, 24, 1, 12, 2, dict(qp=85, gop=12, rc_mode_cli=1, ipct=20)),   # forced-intra P pictures (many intra blocks)
     (352, 288, A.SUBSAMP_420, 24, 2, 8, 3, dict(qp=85, gop=12, rc_mode_cli=1)),             # luma step: a scene change inside a call
     (320, 240, A.SUBSAMP_444, 16, 3, 8, 8, dict(qp=85, gop=0, rc_mode_cli=1)),              # intra-only: every picture its own chain
     (352, 288, A.SUBSAMP_422, 36, 3, 12, 1, dict(qp=60, gop=5, rc_mode_cli=1, scd=0)),      # one chain at a time = the serial order
-    (704, 480, A.SUBSAMP_420, 24, 3, 12, 4, dict(qp=85, gop=8, rc_mode_cli=1)),
+    (704, 480, A.SUBSAMP_420, 24, 5, 12, 4, dict(qp=85, gop=8, rc_mode_cli=1)),
 ]
 
 
@@ -42,7 +42,7 @@ def test_chain_mode_equals_serial_encoder(pkg, orc, case):
     want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw))
     got = pkg.encode_stream(clip, w, h, fmt, fpc, chains, **kw)
     assert got == want, explain(got, want)
-    if style == 3 and kw.get("scd", 1) and kw["gop"]:
+    if style in (3, 5) and kw.get("scd", 1) and kw["gop"]:
         # the clip really has scene changes: more I pictures than GOP starts
         pk = A.split_packets(want)
         pics = [p for p in pk if p[5] & 4]
@@ -74,8 +74,8 @@ def test_chain_mode_reconstruction_carried_across_calls(pkg, orc):
 
 
 @pytest.mark.parametrize("n,look,style,cli", [
-    (50, "16", 3, dict(qp=85, gop=12, rc_mode_cli=1)),       # lookahead 16: three full batches + a tail of 2, scene cuts, calls ending in mid-GOP
-    (45, "30", 3, dict(qp=85, gop=30, rc_mode_cli=1)),       # GOP 30 with the CLI's stable_refresh of 14
+    (50, "16", 5, dict(qp=85, gop=12, rc_mode_cli=1)),       # lookahead 16: three full batches + a tail of 2, scene cuts, calls ending in mid-GOP
+    (45, "30", 5, dict(qp=85, gop=30, rc_mode_cli=1)),       # GOP 30 with the CLI's stable_refresh of 14
     (31, "12", 1, dict(qp=85, gop=12, rc_mode_cli=1)),
     (20, "8", 2, dict(qp=85, gop=0, rc_mode_cli=1)),
     (30, None, 3, dict(qp=85, gop=12, rc_mode_cli=1)),       # default lookahead (16 GOPs): everything comes out at end of stream

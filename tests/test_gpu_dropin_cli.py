@@ -53,7 +53,7 @@ def test_reference_cli_1080p_scene_cuts_cli_defaults(look):
     if not (os.path.exists(DROPIN) and os.path.exists(A.REF_CLI)):
         pytest.skip("oracle/_ref binaries were not built (no /root/reference at build time)")
     w, h, fmt, n = 1920, 1080, A.SUBSAMP_420, 40
-    clip = A.gen_clip(w, h, fmt, 0x10800333, n, style=3)
+    clip = A.gen_clip(w, h, fmt, 0x10800333, n, style=5)
     env = dict(os.environ)
     env["LD_LIBRARY_PATH"] = A.PKG_DIR + ":" + env.get("LD_LIBRARY_PATH", "")
     if look:

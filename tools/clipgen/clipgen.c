@@ -15,6 +15,7 @@
  *   (scene-change detection).
  *   style 4: style 1 with a flat square of a third of the frame height and a flat band over its bottom quarter (a third
  *   of all blocks intra, no picture forced intra: the content that leaves the encoder's lean kernels).
+ *   style 5: style 3 with a four times faster pan (the blocks' stability accumulators leave zero).
  *   style 3: style 0 with SCENE CUTS: every 7 frames the texture is another one and the brightness steps by 12 (the mean
  *   luma of the smallest pyramid level moves by more than the default scene_change_delta of 4: dsv_encoder.c:538-554).
  */
@@ -58,6 +59,8 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
     int lift = 0;                                   /* style 3: brightness step of the scene */
     int big = 0;                                    /* style 4: style 1 with flat objects that cover a third of the frame */
     if (style == 4) { big = 1; style = 1; }
+    int fast = 1;                                   /* style 5: style 3 with a pan of (6, 4) pixels per frame -- the stability */
+    if (style == 5) { fast = 4; style = 3; }        /* accumulators (|mv| >> 2 per block and picture, dsv_encoder.c:367-372) fill up */
     if (style == 3) {
         const int scene = t / 7;
         seed ^= mix(0x5CE9Eu + (uint32_t)scene);
@@ -105,7 +108,7 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
         free(noise); free(colsum);
     }
 
-    const int hx = style == 2 ? 0 : 3 * t, ypan = style == 2 ? 0 : t;   /* half-pel x shift, integer y shift */
+    const int hx = style == 2 ? 0 : 3 * t * fast, ypan = style == 2 ? 0 : t * fast;   /* half-pel x shift, integer y shift */
     const int xo = hx >> 1, xfrac = hx & 1;
     uint8_t *Y = out;
     for (int y = 0; y < h; y++) {

@@ -26,7 +26,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1536
 NREF = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 W, H, FMT = 1920, 1080, A.SUBSAMP_420
 DROPIN = os.path.join(A.ROOT, "oracle", "_ref", "dsv1_dropin")
-base = A.gen_clip(W, H, FMT, 0x10800333, 48, style=3)          # scene cuts every 7 frames (and at every repetition)
+base = A.gen_clip(W, H, FMT, 0x10800333, 48, style=5)          # scene cuts every 7 frames (and at every repetition)
 clip = np.concatenate([base] * ((N + 47) // 48), axis=0)[:N]
 env = dict(os.environ)
 env["LD_LIBRARY_PATH"] = A.PKG_DIR + ":" + env.get("LD_LIBRARY_PATH", "")
