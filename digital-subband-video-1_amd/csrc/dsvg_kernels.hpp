@@ -41,8 +41,9 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
                       int nplain = -1, int ll_chunks = 1);
 void launch_hz_quant(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ll_chunks);
 void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunks, Prof *pf, double samples, int nplain, int ndense = -1);
-void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf = nullptr);
+void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf = nullptr, bool all_sparse = false);
 void launch_dec_clear(hipStream_t st, const JobDev *jobs, int njobs);                       // decoder: zero what the scatter leaves untouched
+void launch_mc_patch(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, const McGeo &MG, const DMV *mvs0, int ex0, int ey0, Prof *pf);
 void launch_hz_dec_resolve(hipStream_t st, const JobDev *jobs, int njobs, int c0, int nplanes);
 void launch_hz_unscatter(hipStream_t st, const JobDev *jobs, int njobs, int max_entries);   // decoder: take the scattered symbols down again
 int  hz_scan_items_max();

@@ -1450,7 +1450,7 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
     const int insym = !sparse ? 0 : (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
     if (insym && njobs > nI) HIPCHK(hipMemsetAsync(c->dec_flag_d + hb, 0, sizeof(int) * (size_t)njobs, c->st));
     launch_dec_clear(c->st, c->jobs_d, njobs);
-    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof);
+    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof, insym == 6 && nI == 0);
     if (insym && njobs > nI) {
         // what the symbol planes cannot hold (JobDev.dec_flag): shared cells that keep the earlier region's value; symbols
         // beyond int16 were flagged by the scatter itself.  The flags travel back now and are read by dec_resolve later.
@@ -1460,7 +1460,31 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
         if (!was_redo) { P.active = true; P.parity = k; P.njobs = njobs; }
     } else if (!was_redo) P.active = false;
     if (njobs > nI) {
-        launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
+        static const bool no_mc_patch = getenv("DSV1_NO_MC_PATCH") != nullptr;
+        if (c->mc_fused && c->ilist_h && !no_mc_patch) {
+            // the encoder's lean motion compensation by itself (k_mc_patch: a thread per 8x8 patch) for the inter blocks; k_mc, by
+            // list, for the intra blocks and for the block columns / rows from (ex0, ey0) on, which hold ragged patches in some
+            // plane (the two kernels share that predicate)
+            const McGeo &M = c->MG;
+            int ex0 = M.nbh, ey0 = M.nbv;
+            for (int p = 0; p < 3; p++) {
+                const int bw = M.blk_w >> (p ? M.hs : 0), bh = M.blk_h >> (p ? M.vs : 0);
+                if (M.w[p] & 7) ex0 = std::min(ex0, (M.w[p] & ~7) / bw);
+                if (M.h[p] & 7) ey0 = std::min(ey0, (M.h[p] & ~7) / bh);
+            }
+            int *il = c->ilist_h + hb * c->nblk, iln = 0;
+            for (int t = nI; t < njobs; t++) {
+                const DMV *mv = c->mv_h + (hb + t) * c->nblk;
+                for (int b = 0; b < c->nblk; b++)
+                    if (mv[b].mode != 0 || b % M.nbh >= ex0 || b / M.nbh >= ey0) il[iln++] = (t - nI) * c->nblk + b;
+            }
+            const DMV *mv0 = c->mvs + (size_t)nI * c->nblk;
+            if (iln) {
+                HIPCHK(hipMemcpyAsync(c->ilist_d + hb * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
+                launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof, mv0, c->ilist_d + hb * c->nblk, iln);
+            }
+            launch_mc_patch(c->st, c->jobs_d + nI, njobs - nI, c->G, c->MG, mv0, ex0, ey0, &c->prof);
+        } else launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }
     OPCHK(enqueue_recon(c, nI, njobs, 0, insym));
     if (insym && njobs > nI) launch_hz_unscatter(c->st, c->jobs_d + nI, njobs - nI, max_entries);

@@ -1335,7 +1335,7 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_positions(JobDev *__restri
 }
 
 // scatter of one level group of the parsed entries (the groups go in order: a cell two scan regions share takes the
-// later region's value): phase 0 = LL + level 0, 1 = level 1, 2 = level 2
+// later region's value): phase -1 / 0 = LL + level 0, 1 = level 1, 2 = level 2
 __global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict__ jobs, int c0, int phase)
 {
     const int c = c0 + (int)blockIdx.z;
@@ -1347,7 +1347,9 @@ __global__ __launch_bounds__(256) void k_hz_scatter_lv(const JobDev *__restrict_
     const int v = jb.nzval[jb.nz_off[c] + i];
     if (p < 0 || p >= hp.nscan) return;
     const int ph = p >= hp.r[7].base ? 2 : (p >= hp.r[4].base ? 1 : 0);
-    if (ph != phase) return;
+    // phase -1 (the first launch): every entry of a sparse plane -- its symbols land in slots of their own, nothing to order --
+    // and level group 0 of the others; launches 1, 2 then only serve the planes that keep int32 coefficients
+    if (phase < 0 ? (!jb.dec_sym[c] && ph != 0) : (jb.dec_sym[c] || ph != phase)) return;
     if (p == 0) {                                                     // unquantised DC (hzcc.c:495)
         (jb.coef + jb.hz_coef_off[c])[0] = v;
         if (jb.dec_sym[c] && (v < -jb.dec_lim[0] || v > jb.dec_lim[0])) atomicOr(jb.dec_flag, 1);
@@ -1534,7 +1536,7 @@ void launch_hz_encode(hipStream_t st, const JobDev *jobs, int njobs, int job_chu
 // planes [c, c + nplanes) of every job: the serial scan (a workgroup per picture and plane), the code decode spread over
 // the chip (max_chunks = most 128-bit chunks any of the payloads has), the run -> position pass, then the three ordered
 // scatter phases; max_entries = the largest entry count announced by any of those planes
-void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf)
+void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int nplanes, int max_entries, int max_chunks, Prof *pf, bool all_sparse)
 {
     PB(KID_HZ_PARSE, 0.0);
     hipLaunchKernelGGL(k_hz_parse, dim3(njobs, nplanes), dim3(PARSE_THREADS), 0, st, jobs, c);
@@ -1548,7 +1550,8 @@ void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int
     hipLaunchKernelGGL(k_hz_positions, dim3(njobs, nplanes), dim3(PARSE_THREADS), 0, st, jobs, c);
     PE();
     if (max_entries <= 0) return;
-    for (int ph = 0; ph < 3; ph++) {
+    // all_sparse: every plane of every job of the call takes the symbol path (a call of P pictures): one launch instead of three
+    for (int ph = -1; ph < (all_sparse ? 0 : 3); ph += (ph < 0 ? 2 : 1)) {
         PB(KID_HZ_SCATTER, 0.0);
         hipLaunchKernelGGL(k_hz_scatter_lv, dim3((max_entries + 255) / 256, njobs, nplanes), dim3(256), 0, st, jobs, c, ph);
         PE();

@@ -991,6 +991,58 @@ __global__ __launch_bounds__(256) FAST_WPE_C_ATTR void k_fwd_mc_fast<1>(const Jo
     fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
 }
 
+// ---- decoder: prediction only (compensate bmc.c:204-302 without subf), the lean kernel's motion compensation by itself ----
+// One thread per 8x8 patch that lies wholly inside the picture, in an INTER block left of block column ex0 and above block row
+// ey0 (the blocks from there on hold ragged patches in some plane; they and the intra blocks are k_mc's, by list: the two
+// kernels share the predicate).  Same row emitters as k_fwd_mc_fast: one body for all half-pel phases, stages dropping out
+// wave-uniformly; the prediction goes straight to JobDev.pred.
+template <int CH>
+__global__ __launch_bounds__(256) void k_mc_patch(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0,
+                                                  int gx, int gy, int gz, int ex0, int ey0)
+{
+    Blk3 B;
+    if (!d_xcd_blk3(gx, gy, gz, B)) return;
+    const int job = B.z / npl, c = c0 + B.z % npl;
+    const SbtGeo g = G.g[c];
+    const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
+    if (I >= g.w3 || J >= g.h3) return;
+    const JobDev &jb = jobs[job];
+    const int sh = CH ? MG.hs : 0, sv = CH ? MG.vs : 0;
+    const int bw = MG.blk_w >> sh, bh = MG.blk_h >> sv;
+    const int pw = MG.w[c], ph = g.ph, stride = g.pstride;
+    const int x0 = 8 * I, y0 = 8 * J;
+    if (x0 + 8 > pw || y0 + 8 > ph) return;                 // a ragged patch: its block is on k_mc's list
+    const int bi = (int)(((float)I + 0.5f) * __builtin_amdgcn_rcpf((float)(bw >> 3)));
+    const int bj = (int)(((float)J + 0.5f) * __builtin_amdgcn_rcpf((float)(bh >> 3)));
+    if (bi >= ex0 || bj >= ey0) return;
+    const int nblk = MG.nbh * MG.nbv, blk = bj * MG.nbh + bi;
+    const DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
+    if (mv.mode != 0) return;                               // intra blocks: k_mc (block means, bmc.c:176-189)
+    const int dx = mv.x >> sh, dy = mv.y >> sv;
+    const int xb = bi * bw, yb = bj * bh;
+    const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
+    const int wy = d_clamp(yb + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1) + (y0 - yb);
+    const bool xh = dx & 1, yh = dy & 1;
+    const auto gr = dsvg_global(static_cast<const uint8_t *>(jb.ref + g.poff)) + ((wy - 1) * stride + (wx - 1));
+    const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;
+    const auto pp = dsvg_global(jb.pred + g.poff);
+    auto emit = [&](int r, unsigned plo, unsigned phi) { dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi)); };
+    auto emit_pk = [&](int r, const PkRow &P) {
+        unsigned plo, phi;
+        pk_bytes8(P, plo, phi);
+        dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi));
+    };
+    if (CH == 0) {
+        if (any_y && any_x) mc_luma_patch_vpk<true>(gr, stride, xh, yh, emit_pk);
+        else if (any_y) mc_luma_patch_vpk<false>(gr, stride, xh, yh, emit_pk);
+        else if (any_x) mc_luma_patch_hpk(gr, stride, xh, emit_pk);
+        else mc_luma_patch<false, false>(gr, stride, xh, yh, emit);
+    } else {
+        if (any_x || any_y) mc_chroma_patch_pk(gr, stride, xh, yh, emit_pk);
+        else mc_chroma_patch<false>(gr, stride, xh, yh, emit);
+    }
+}
+
 // four waves per SIMD (128 VGPRs, a few dwords spilled) measured against three without spills: luma the same, chroma 4 % faster
 #ifndef MC_WPE
 #define MC_WPE 4
@@ -2953,6 +3005,23 @@ void launch_tail_q(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 
     }
     PB(KID_TAIL_Q, s3 * 8.0);
     hipLaunchKernelGGL(k_tail_q, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
+    PE();
+}
+
+// decoder: the prediction of every inter block left of block column ex0 / above block row ey0 (see k_mc_patch), luma then chroma
+void launch_mc_patch(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, const McGeo &MG, const DMV *mvs0, int ex0, int ey0, Prof *pf)
+{
+    double smp = 0;
+    for (int c = 0; c < 3; c++) smp += (double)G.g[c].W * G.g[c].H;
+    PB(KID_MC, smp * njobs * 2.0);                       // reference in, prediction out
+    {
+        const dim3 fg = grid3(G.g[0].w3, G.g[0].h3, njobs);
+        hipLaunchKernelGGL((k_mc_patch<0>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, MG, 0, 1, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, ex0, ey0);
+    }
+    {
+        const dim3 fg = grid3(G.g[1].w3, G.g[1].h3, 2 * njobs);
+        hipLaunchKernelGGL((k_mc_patch<1>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, MG, 1, 2, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, ex0, ey0);
+    }
     PE();
 }
 
