@@ -114,6 +114,8 @@ struct HzParseChunk {
 
 struct JobDev {              // everything a kernel needs to find one picture job's buffers
     const uint8_t *src;      // source frame (bordered, extended)
+    const uint8_t *srcp[3];  // pixel (0,0) of each SOURCE plane and its row stride: the bordered frame above, or -- chroma of frames loaded
+    int srcs[3];             // "in place" (dsvg_load_frames_map_ex) -- the caller's packed planar clip (stride = plane width: no border, never read outside the picture)
     const uint8_t *ref;      // reference reconstruction (bordered, extended) or nullptr
     uint8_t *recon;          // where the extended reconstruction is kept, or nullptr
     uint8_t *xf;             // work frame: residual in, reconstruction out

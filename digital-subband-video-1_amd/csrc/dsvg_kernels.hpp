@@ -18,6 +18,10 @@ struct HmeArgs {
     FrameLayout L[6];        // level 0 = full frames, level i = pyramid level i
     const uint8_t *slab[6];
     const int *cur_slots, *ref_slots;
+    // chroma planes of every source slot (level 0's variance test, hme.c:269-300,667-681): pixel (0,0) of U / V and the row stride --
+    // the bordered frame's, or the caller's packed clip for frames loaded in place (dsvg_load_frames_map_ex)
+    const unsigned long long *slot_cu, *slot_cv;
+    const int *slot_cs;
     DMV *mvf;                // [pair][level][nblk]
     unsigned *aux_tex;       // [pair][nblk] block texture (for the high_detail pass)
     int *aux_var;            // [pair][nblk] centre-window variance

@@ -121,6 +121,7 @@ extern "C" int dsvg_op_fwd_sbt(const dsvg_plane *src, dsvg_coefs *dst, int isP)
     OPCHK(S.dev(&ds5, (size_t)rsu(W, 5) * rsu(H, 5) + 8));
     JobDev jb; memset(&jb, 0, sizeof(jb));
     jb.src = dpx; jb.xf = dpx; jb.coef = dco; jb.s3 = ds3; jb.s1 = ds1; jb.s5 = ds5; jb.isP = isP;
+    jb.srcp[0] = dpx; jb.srcs[0] = dstride;
     JobDev *djb; OPCHK(S.dev(&djb, 1, false));
     HIPCHK(hipMemcpyAsync(djb, &jb, sizeof(jb), hipMemcpyHostToDevice, S.st));
     SbtGeo3 G; memset(&G, 0, sizeof(G));
@@ -289,6 +290,7 @@ static int op_pred(const dsvg_mv *mv, const dsvg_params *p, dsvg_frame *dif, dsv
     jb.ref = dr; jb.mvs = dmv;
     if (sub) { jb.pred = dd; jb.src = di; jb.xf = di; }          // dif <- prediction, inp <- residual (in place)
     else     { jb.pred = di; jb.src = di; jb.xf = di; }          // out <- prediction, then out += dif - 128
+    for (int pl = 0; pl < 3; pl++) { jb.srcp[pl] = jb.src + G.off[pl]; jb.srcs[pl] = G.stride[pl]; }
     JobDev *djb; OPCHK(S.dev(&djb, 1, false));
     HIPCHK(hipMemcpyAsync(djb, &jb, sizeof(jb), hipMemcpyHostToDevice, S.st));
     launch_mc(S.st, djb, 1, G, sub);
@@ -391,6 +393,20 @@ extern "C" int dsvg_op_hme(dsvg_hme *h, int *intra_pct)
     const int slots[2] = {0, 1};
     HIPCHK(hipMemcpyAsync(dslots, slots, sizeof(slots), hipMemcpyHostToDevice, S.st));
     A.cur_slots = dslots; A.ref_slots = dslots + 1;
+    {   // chroma planes of the two level-0 frames (slots 0, 1 of the level's slab)
+        unsigned long long hcu[2], hcv[2]; int hcs[2];
+        for (int k = 0; k < 2; k++) {
+            hcu[k] = (unsigned long long)(uintptr_t)(A.slab[0] + (size_t)k * A.L[0].pitch + A.L[0].off[1]);
+            hcv[k] = (unsigned long long)(uintptr_t)(A.slab[0] + (size_t)k * A.L[0].pitch + A.L[0].off[2]);
+            hcs[k] = A.L[0].stride[1];
+        }
+        unsigned long long *dcu; int *dcs;
+        OPCHK(S.dev(&dcu, 4)); OPCHK(S.dev(&dcs, 2));
+        HIPCHK(hipMemcpyAsync(dcu, hcu, sizeof(hcu), hipMemcpyHostToDevice, S.st));
+        HIPCHK(hipMemcpyAsync(dcu + 2, hcv, sizeof(hcv), hipMemcpyHostToDevice, S.st));
+        HIPCHK(hipMemcpyAsync(dcs, hcs, sizeof(hcs), hipMemcpyHostToDevice, S.st));
+        A.slot_cu = dcu; A.slot_cv = dcu + 2; A.slot_cs = dcs;
+    }
     OPCHK(S.dev(&A.mvf, (size_t)(h->levels + 1) * nblk));
     OPCHK(S.dev(&A.aux_tex, (size_t)nblk));
     OPCHK(S.dev(&A.aux_var, (size_t)nblk));

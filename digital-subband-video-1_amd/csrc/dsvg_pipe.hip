@@ -137,6 +137,15 @@ struct dsvg_ctx {
     uint8_t *dec_h[2] = {nullptr, nullptr}, *dec_d[2] = {nullptr, nullptr};   // decoder: payload blob of one call (pinned / device), by call parity
     size_t dec_cap[2] = {0, 0};
     hipEvent_t ev_dec[2] = {nullptr, nullptr};   // uploads of the call that last used that parity
+    // Chroma planes of every source slot: the bordered copy in the source slab, or -- frames loaded "in place"
+    // (dsvg_load_frames_map_ex) -- the caller's packed planar clip: pixel (0,0) of U / V and the row stride, host truth + the
+    // device tables the motion search reads (HmeArgs.slot_cu ..)
+    std::vector<const uint8_t *> slot_cu, slot_cv;
+    std::vector<int> slot_cs;
+    unsigned long long *slot_cu_h = nullptr, *slot_cv_h = nullptr, *slot_cu_d = nullptr, *slot_cv_d = nullptr;
+    int *slot_cs_h = nullptr, *slot_cs_d = nullptr;
+    bool cdirect_ok = false;         // the geometry allows in-place chroma (even chroma planes, rows of whole 8-byte patches)
+    long cdirect_frames = 0;         // frames loaded that way (tests)
     int dec_par = 0;
     // Decoder, sparse symbol path: a call is enqueued optimistically; its scatter stage flags pictures the int16 symbol planes
     // cannot represent exactly (JobDev.dec_flag).  The flags come back asynchronously and are looked at when the next decoder
@@ -180,6 +189,12 @@ static void ctx_free(dsvg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->slot_cu_d) (void)hipFree(c->slot_cu_d);
+    if (c->slot_cv_d) (void)hipFree(c->slot_cv_d);
+    if (c->slot_cs_d) (void)hipFree(c->slot_cs_d);
+    if (c->slot_cu_h) (void)hipHostFree(c->slot_cu_h);
+    if (c->slot_cv_h) (void)hipHostFree(c->slot_cv_h);
+    if (c->slot_cs_h) (void)hipHostFree(c->slot_cs_h);
     if (c->dec_flag_d) (void)hipFree(c->dec_flag_d);
     if (c->dec_flag_h) (void)hipHostFree(c->dec_flag_h);
     for (int i = 0; i < 6; i++) c->src[i].release();
@@ -403,6 +418,25 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
         if ((rc = hmalloc(&c->ilist_h, (size_t)c->nblk * std::max(S, O)))) return fail(rc);
         if ((rc = dmalloc(&c->ilist_d, (size_t)c->nblk * std::max(S, O), false))) return fail(rc);
     }
+    {   // every source slot's chroma starts as the bordered copy in the slab
+        const size_t ns = (size_t)n_src_slots;
+        c->slot_cu.resize(ns); c->slot_cv.resize(ns); c->slot_cs.assign(ns, c->L[0].stride[1]);
+        if (hipHostMalloc((void **)&c->slot_cu_h, 8 * ns + 64, hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&c->slot_cv_h, 8 * ns + 64, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&c->slot_cs_h, 4 * ns + 64, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&c->slot_cu_d, 8 * ns + 64) != hipSuccess ||
+            hipMalloc((void **)&c->slot_cv_d, 8 * ns + 64) != hipSuccess || hipMalloc((void **)&c->slot_cs_d, 4 * ns + 64) != hipSuccess) { dsvg_set_error("slot tables: out of memory"); return fail(DSVG_ERR_HIP); }
+        for (size_t sl = 0; sl < ns; sl++) {
+            c->slot_cu[sl] = c->src[0].p + sl * c->L[0].pitch + c->L[0].off[1];
+            c->slot_cv[sl] = c->src[0].p + sl * c->L[0].pitch + c->L[0].off[2];
+            c->slot_cu_h[sl] = (unsigned long long)(uintptr_t)c->slot_cu[sl]; c->slot_cv_h[sl] = (unsigned long long)(uintptr_t)c->slot_cv[sl];
+            c->slot_cs_h[sl] = c->slot_cs[sl];
+        }
+        if (hipMemcpy(c->slot_cu_d, c->slot_cu_h, 8 * ns, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(c->slot_cv_d, c->slot_cv_h, 8 * ns, hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(c->slot_cs_d, c->slot_cs_h, 4 * ns, hipMemcpyHostToDevice) != hipSuccess) { dsvg_set_error("slot tables: upload failed"); return fail(DSVG_ERR_HIP); }
+        // in place: the forward transforms read whole 8-byte patch rows and never leave the picture when the chroma planes are
+        // even (no extra coefficient column: frame.c:39-42) and a multiple of 8 wide; both chroma planes alike
+        c->cdirect_ok = (c->L[0].w[1] % 8) == 0 && (c->L[0].h[1] % 2) == 0 && c->L[0].w[1] == c->L[0].w[2] && c->L[0].h[1] == c->L[0].h[2] &&
+                        c->L[0].stride[1] == c->L[0].stride[2] && !getenv("DSV1_NO_CHROMA_IN_PLACE");
+    }
     (void)J;
     // the pipeline streams are non-blocking (no implicit ordering against the NULL stream the memsets above ran on)
     if (hipDeviceSynchronize() != hipSuccess) { dsvg_set_error("hipDeviceSynchronize failed"); return fail(DSVG_ERR_HIP); }
@@ -603,6 +637,22 @@ static int ingest_release(dsvg_ctx *c, int k)
 // ------------------------------------------------------------------------------------------------
 static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d)
 {
+    if (!tab_d) {       // contiguous slots, chroma copied: those slots' chroma is the bordered copy (again)
+        bool changed = false;
+        for (int sl = first_slot; sl < first_slot + n; sl++) {
+            const uint8_t *u = c->src[0].p + (size_t)sl * c->L[0].pitch + c->L[0].off[1], *v = c->src[0].p + (size_t)sl * c->L[0].pitch + c->L[0].off[2];
+            if (c->slot_cu[sl] != u || c->slot_cs[sl] != c->L[0].stride[1]) {
+                c->slot_cu[sl] = u; c->slot_cv[sl] = v; c->slot_cs[sl] = c->L[0].stride[1];
+                c->slot_cu_h[sl] = (unsigned long long)(uintptr_t)u; c->slot_cv_h[sl] = (unsigned long long)(uintptr_t)v; c->slot_cs_h[sl] = c->L[0].stride[1];
+                changed = true;
+            }
+        }
+        if (changed) {
+            HIPCHK(hipMemcpyAsync(c->slot_cu_d, c->slot_cu_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+            HIPCHK(hipMemcpyAsync(c->slot_cv_d, c->slot_cv_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+            HIPCHK(hipMemcpyAsync(c->slot_cs_d, c->slot_cs_h, 4 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+        }
+    }
     // the first pyramid level comes out of the unpack kernel when the luma plane allows it (one read of the frame less)
     // (the kernel's fused path needs 16-byte aligned frames: a caller's odd device pointer takes the separate passes)
     const bool fuse1 = with_pyramid && c->levels >= 1 && unpack_fuses_level1(c->L[0]) && ((uintptr_t)dsrc & 15) == 0 && (pitch & 15) == 0;
@@ -660,19 +710,56 @@ extern "C" int dsvg_load_frames_strided(dsvg_ctx *c, int first_slot, int n, cons
     return load_core(c, first_slot, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, nullptr);
 }
 
-extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid)
+// Frame i (at yuv_dev + i * frame_pitch) goes to source slot slots[i].  chroma_in_place (one flag per frame, or null): the
+// frame's chroma planes are NOT copied -- the forward transform and the motion search's chroma test read them from the
+// caller's packed clip, which only the luma plane leaves (bordered copy + pyramid: what a frame needs as a motion search
+// REFERENCE).  The caller keeps the clip unchanged until the pictures coded from those slots have been fetched and until the
+// next frame of each stream has been analysed; refused (plain copy) where the geometry or the clip's alignment does not allow it.
+extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid,
+                                       const unsigned char *chroma_in_place)
 {
     if (!c || !yuv_dev || !slots || n < 1 || n > c->n_src) { dsvg_set_error("bad load_frames arguments"); return DSVG_ERR_ARG; }
     HIPCHK(hipSetDevice(c->device));
     for (int i = 0; i < n; i++)
         if (slots[i] < 0 || slots[i] >= c->n_src) { dsvg_set_error("slot out of range"); return DSVG_ERR_ARG; }
     if (!c->ltab_d) HIPCHK(hipMalloc((void **)&c->ltab_d, sizeof(int) * (size_t)c->n_src + 64));
-    HIPCHK(hipMemcpyAsync(c->ltab_d, slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_a));   // pageable: staged by the runtime
+    const size_t ysz = (size_t)c->L[0].w[0] * c->L[0].h[0], csz = (size_t)c->L[0].w[1] * c->L[0].h[1];
+    const bool can = chroma_in_place && c->cdirect_ok && ((uintptr_t)yuv_dev % 16) == 0 && (frame_pitch % 16) == 0 && (ysz % 16) == 0 && (csz % 16) == 0;
+    std::vector<int> tab((size_t)n);
+    bool changed = false;
+    for (int i = 0; i < n; i++) {
+        const int sl = slots[i];
+        const bool direct = can && chroma_in_place[i];
+        const uint8_t *fr = (const uint8_t *)yuv_dev + (size_t)i * frame_pitch;
+        const uint8_t *u = direct ? fr + ysz : c->src[0].p + (size_t)sl * c->L[0].pitch + c->L[0].off[1];
+        const uint8_t *v = direct ? fr + ysz + csz : c->src[0].p + (size_t)sl * c->L[0].pitch + c->L[0].off[2];
+        const int st = direct ? c->L[0].w[1] : c->L[0].stride[1];
+        if (c->slot_cu[sl] != u || c->slot_cv[sl] != v || c->slot_cs[sl] != st) {
+            c->slot_cu[sl] = u; c->slot_cv[sl] = v; c->slot_cs[sl] = st;
+            c->slot_cu_h[sl] = (unsigned long long)(uintptr_t)u; c->slot_cv_h[sl] = (unsigned long long)(uintptr_t)v; c->slot_cs_h[sl] = st;
+            changed = true;
+        }
+        tab[(size_t)i] = sl | (direct ? 0x40000000 : 0);
+        c->cdirect_frames += direct;
+    }
+    if (changed) {
+        // (the pinned mirrors are only rewritten here, and every load is followed by a host wait on this stream -- the luma
+        // sums or the motion search -- before the next one: no copy of an older state is still in flight)
+        HIPCHK(hipMemcpyAsync(c->slot_cu_d, c->slot_cu_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+        HIPCHK(hipMemcpyAsync(c->slot_cv_d, c->slot_cv_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+        HIPCHK(hipMemcpyAsync(c->slot_cs_d, c->slot_cs_h, 4 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+    }
+    HIPCHK(hipMemcpyAsync(c->ltab_d, tab.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_a));   // pageable: staged by the runtime
     const int k = ingest_acquire(c, yuv_dev);
     if (k == -2) { dsvg_set_error("hipStreamWaitEvent failed"); return DSVG_ERR_HIP; }
     const int rc = load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d);
     return rc ? rc : ingest_release(c, k);
 }
+extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid)
+{
+    return dsvg_load_frames_map_ex(c, n, slots, yuv_dev, frame_pitch, with_pyramid, nullptr);
+}
+extern "C" long dsvg_ctx_chroma_in_place_frames(const dsvg_ctx *c) { return c ? c->cdirect_frames : 0; }
 
 extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *sums_out)
 {
@@ -711,6 +798,7 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     HmeArgs A; memset(&A, 0, sizeof(A));
     for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
+    A.slot_cu = c->slot_cu_d; A.slot_cv = c->slot_cv_d; A.slot_cs = c->slot_cs_d;
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
     launch_hme(c->st_a, A, npairs, &c->prof);
@@ -950,6 +1038,8 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             jb.psum = c->psum + (size_t)j.out_slot * 3;
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
+            jb.srcp[0] = jb.src + c->L[0].off[0]; jb.srcs[0] = c->L[0].stride[0];
+            jb.srcp[1] = c->slot_cu[(size_t)j.src_slot]; jb.srcp[2] = c->slot_cv[(size_t)j.src_slot]; jb.srcs[1] = jb.srcs[2] = c->slot_cs[(size_t)j.src_slot];
             jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
             jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;
             // the reconstruction goes to another slot than the reference: the prediction is written straight into it and the

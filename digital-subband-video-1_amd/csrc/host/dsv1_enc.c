@@ -669,7 +669,7 @@ static void asm_piece(void *ctx, int first, int count)
 static int stage_n(dsv1_batch *b, const void *yuv_host, int nf);
 static int code_chains(dsv1_batch *b, pic_t *pics, int nf, int par);
 static void prefix_picture(void *ctx, int t, int tid);
-static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out, int nf)
+static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out, int nf, int inplace_ok)
 {
     int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0, par;
     size_t fb;
@@ -705,7 +705,19 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     /* 1. source-only preparation for every frame: bordered layout, pyramid, mean luma */
     for (s = 0; s < S; s++)
         for (t = 0; t < nf; t++) b->slots_cur[s * F + t] = slot_of(b, s, b->gcount + (unsigned)t);
-    if ((rc = dsvg_load_frames_map(b->ctx, S * nf, b->slots_cur, dyuv, fb, with_pyr))) return rc;     /* nf < F only with S == 1 */
+    {
+        /* A clip in the CALLER's device memory stays where it is as far as chroma goes (dsvg_load_frames_map_ex): the forward
+         * transform and the motion search read it there, only luma is copied (bordered + pyramid).  Each stream's last frame
+         * of the call is copied whole: the first frame of the next call may search against it when this clip is gone. */
+        unsigned char *inpl = NULL;
+        if (inplace_ok && yuv_on_device && (inpl = (unsigned char *)malloc((size_t)S * nf))) {
+            for (s = 0; s < S; s++)
+                for (t = 0; t < nf; t++) inpl[s * nf + t] = (unsigned char)(t + 1 < nf);
+        }
+        rc = dsvg_load_frames_map_ex(b->ctx, S * nf, b->slots_cur, dyuv, fb, with_pyr, inpl);     /* nf < F only with S == 1 */
+        free(inpl);
+        if (rc) return rc;
+    }
     if (with_pyr && e0->do_scd)
         if ((rc = dsvg_get_luma_sums(b->ctx, 0, b->rows * S, b->luma))) return rc;
 
@@ -850,7 +862,7 @@ int dsv1_batch_stage(dsv1_batch *b, const void *yuv_host) { return stage_n(b, yu
 
 int dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
 {
-    return batch_submit_impl(b, yuv, yuv_on_device, out, 0);
+    return batch_submit_impl(b, yuv, yuv_on_device, out, 0, 1);
 }
 
 /* Collect the OLDEST submitted batch: one gathered device-to-host copy, then packet assembly in
@@ -887,7 +899,7 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
     int rc;
     if (!b || !out) return DSVG_ERR_ARG;
     if (b->pending[0] || b->pending[1]) { dsv1_log(1, "dsv1_batch_encode with batches in flight"); return DSVG_ERR_ARG; }
-    if ((rc = batch_submit_impl(b, yuv, yuv_on_device, out, 0))) return rc;
+    if ((rc = batch_submit_impl(b, yuv, yuv_on_device, out, 0, 1))) return rc;
     return dsv1_batch_collect(b, out);
 }
 
@@ -1040,7 +1052,7 @@ static int sess_submit(enc_sess *ss)
 {
     int rc;
     /* the frames are on the device already (or on their way: the load waits for the last part on the device) */
-    if ((rc = batch_submit_impl(ss->b, ss->dev, 1, NULL, ss->fill))) return rc;
+    if ((rc = batch_submit_impl(ss->b, ss->dev, 1, NULL, ss->fill, 0))) return rc;      /* (the ingest buffer is reused two batches on: chroma is copied) */
     ss->dev = NULL;
     ss->inflight++;
     ss->cur ^= 1;

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     const int sh = c ? G.hs : 0, sv = c ? G.vs : 0;
     const int bw = G.blk_w >> sh, bh = G.blk_h >> sv;
     const int pw = G.w[c], ph = G.h[c], stride = G.stride[c];
+    const int sstride = jb.srcs[c];                     // the source plane has its own stride (in-place chroma: dsvg_load_frames_map_ex)
     const int bi = blk % G.nbh, bj = blk / G.nbh;
     const int x = bi * bw, y = bj * bh;
     if (x >= pw || y >= ph) return;
@@ -80,10 +81,10 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     const int x40 = 4 * (tid & ((1 << lq0) - 1)), rpp0 = MC_NT >> lq0;
     unsigned s_pre[4] = {0u, 0u, 0u, 0u};
     if (do_sub && x40 + 4 <= cw) {
-        const uint8_t *sp0 = jb.src + G.off[c];
+        const uint8_t *sp0 = jb.srcp[c];
 #pragma unroll
         for (int u = 0; u < 4; u++)
-            s_pre[u] = *reinterpret_cast<const unsigned *>(sp0 + (size_t)(y + min((tid >> lq0) + u * rpp0, ch - 1)) * stride + x + x40);
+            s_pre[u] = *reinterpret_cast<const unsigned *>(sp0 + (size_t)(y + min((tid >> lq0) + u * rpp0, ch - 1)) * sstride + x + x40);
     }
     // one vector per block: make its fields wave-uniform (SGPRs) so that the path selection below is scalar branching
     DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
@@ -108,7 +109,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
         // to back (one memory round trip), then filters, subtracts and stores.
         uint8_t *pp = jb.pred + G.off[c];
         uint8_t *xp = jb.xf + G.off[c];
-        const uint8_t *sp = jb.src + G.off[c];
+        const uint8_t *sp = jb.srcp[c];
         const int nq = (cw + 3) >> 2;
         const int lq = bw > 32 ? 4 : (bw > 16 ? 3 : 2);
         const int x4 = 4 * (tid & ((1 << lq) - 1)), rpp = MC_NT >> lq;
@@ -127,7 +128,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
                 const long ro = (long)yy * sdw;
                 d0[u] = ga[ro]; d1[u] = ga[ro + 1]; d2[u] = ga[ro + 2];
                 sv4[u] = y0 == (tid >> lq) ? s_pre[u]
-                                           : ((do_sub && full4) ? *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy) * stride + x + x4) : 0u);
+                                           : ((do_sub && full4) ? *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy) * sstride + x + x4) : 0u);
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -148,9 +149,9 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
                     for (int k = 0; k < 4; k++) pv[k] = (RB(k + 1) + RB(k + 2) + 1) >> 1;
                 }
 #undef RB
-                mc_store4(pp, xp, sp, (size_t)(y + yy) * stride + x + x4, pv, cw - x4, do_sub, sv4[u]);
+                mc_store4(pp, xp, sp + (size_t)(y + yy) * sstride - (size_t)(y + yy) * stride, (size_t)(y + yy) * stride + x + x4, pv, cw - x4, do_sub, sv4[u]);
                 if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
-                    xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * stride + pw - 1];
+                    xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * sstride + pw - 1];
             }
         }
         return;
@@ -215,7 +216,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
 
     uint8_t *pp = jb.pred + G.off[c];
     uint8_t *xp = jb.xf + G.off[c];
-    const uint8_t *sp = jb.src + G.off[c];
+    const uint8_t *sp = jb.srcp[c];
     const int nq = (cw + 3) >> 2;
     // 8 reference bytes b0..b7 = ref(wx + x4 - 1 .. wx + x4 + 6) of window row rr as two dwords (the window
     // is stored as aligned dwords; `mis` is the same for every row, so one v_alignbyte pair re-aligns it)
@@ -238,7 +239,7 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
     for (int yy = tid >> lq; yy < ch; yy += MC_NT >> lq) {
         unsigned s_next = 0;
         if (do_sub && full4 && yy + (MC_NT >> lq) < ch)
-            s_next = *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy + (MC_NT >> lq)) * stride + x + x4);
+            s_next = *reinterpret_cast<const unsigned *>(sp + (size_t)(y + yy + (MC_NT >> lq)) * sstride + x + x4);
         int pv[4];
         if (mv.mode == 0) {
             if (c == 0) {
@@ -293,11 +294,11 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
             }
         }
         const size_t o = (size_t)(y + yy) * stride + x + x4;
-        mc_store4(pp, xp, sp, o, pv, cw - x4, do_sub, s_cur);
+        mc_store4(pp, xp, sp + (size_t)(y + yy) * sstride - (size_t)(y + yy) * stride, o, pv, cw - x4, do_sub, s_cur);
         // odd plane width whose coefficient plane is one wider: the transform reads column pw of the
         // residual frame, which in the reference still holds the replicated source edge (frame.c:199-221)
         if (do_sub && G.cw_extra[c] && x + cw == pw && x4 + 4 >= cw)
-            xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * stride + pw - 1];
+            xp[(size_t)(y + yy) * stride + pw] = sp[(size_t)(y + yy) * sstride + pw - 1];
         s_cur = s_next;
     }
 }

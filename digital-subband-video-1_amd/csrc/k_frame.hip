@@ -18,7 +18,11 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
     // takes a 16-byte path): they complete the 128-byte lines the row's first and last pixels lie in, where a separate
     // border kernel writes half lines; the rows above and below the picture are left to k_extend16
     const int c = blockIdx.y, f = blockIdx.z;
-    const int slot = slot_tab ? slot_tab[f] : first_slot + f;
+    // slot table entries: bit 30 = this frame's chroma stays where the caller has it (dsvg_load_frames_map_ex, "in place"):
+    // only its luma plane is unpacked, bordered and fed to the pyramid
+    const int raw = slot_tab ? slot_tab[f] : first_slot + f;
+    const int slot = raw & 0x3fffffff;
+    if ((raw & 0x40000000) && c > 0) return;
     const int w = L.w[c], h = L.h[c];
     size_t poff = 0;
     for (int k = 0; k < c; k++) poff += (size_t)L.w[k] * L.h[k];
@@ -219,8 +223,10 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
 {
     const int c = blockIdx.y;
     if (c >= nplanes) return;
-    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
-    if (f < 0) return;
+    const int raw = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
+    if (raw < 0) return;
+    const int f = raw & 0x3fffffff;
+    if ((raw & 0x40000000) && c > 0) return;            // (source frames whose chroma stays in the caller's clip: see k_unpack)
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
     const int B = DSVG_BORDER;
@@ -273,8 +279,10 @@ __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, Fr
     // width of the allocation (corners included), as copies of the bordered first / last row
     const int c = blockIdx.y;
     if (c >= nplanes) return;
-    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
-    if (f < 0) return;
+    const int raw = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
+    if (raw < 0) return;
+    const int f = raw & 0x3fffffff;
+    if ((raw & 0x40000000) && c > 0) return;            // (source frames whose chroma stays in the caller's clip: see k_unpack)
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
     const int B = DSVG_BORDER;
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab,
 {
     // sides: the level's width is a multiple of 16: the threads of a row's first and last pixels also write its 64-byte side
     // borders (whole 128-byte lines; k_extend16 then adds the rows above and below only)
-    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
+    const int f = (slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z) & 0x3fffffff;
     const uint8_t *sp = sslab + (size_t)f * SL.pitch + SL.off[0];
     uint8_t *dp = dslab + (size_t)f * DL.pitch + DL.off[0];
     const int dw = DL.w[0], dh = DL.h[0];
@@ -368,7 +376,7 @@ __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab,
 __global__ __launch_bounds__(256) void k_luma_sum(const uint8_t *__restrict__ slab, FrameLayout L, int first,
                                                   unsigned *__restrict__ sums, const int *__restrict__ slot_tab)
 {
-    const int f = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
+    const int f = (slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z) & 0x3fffffff;
     const uint8_t *p = slab + (size_t)f * L.pitch + L.off[0];
     const int w = L.w[0], h = L.h[0];
     unsigned acc = 0;

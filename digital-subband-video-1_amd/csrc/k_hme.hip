@@ -489,28 +489,31 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         const FrameLayout &L0 = A.L[0];
         const int cbw = bw >> L0.hs, cbh = bh >> L0.vs, ndw = cbw >> 2, rpp = ndw ? NT / ndw : NT + 1;
         const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
-        const uint8_t *fbs = A.slab[0] + (size_t)cur * L0.pitch, *fbr = A.slab[0] + (size_t)rf * L0.pitch;
-        cpre_ok = (((unsigned)L0.off[1] | (unsigned)L0.off[2] | (unsigned)L0.stride[1] | (unsigned)cbx | (unsigned)(uintptr_t)fbs | (unsigned)(uintptr_t)fbr | (unsigned)cbw) & 3u) == 0 &&
-                  ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4 && L0.stride[1] == L0.stride[2];
+        const uint8_t *su = reinterpret_cast<const uint8_t *>(A.slot_cu[cur]), *sv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[cur]);
+        const uint8_t *ru = reinterpret_cast<const uint8_t *>(A.slot_cu[rf]), *rv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[rf]);
+        const int ss = A.slot_cs[cur], rs = A.slot_cs[rf];          // (source and reference may differ: in place / bordered)
+        cpre_ok = (((unsigned)ss | (unsigned)rs | (unsigned)cbx | (unsigned)(uintptr_t)su | (unsigned)(uintptr_t)sv_ | (unsigned)(uintptr_t)ru | (unsigned)(uintptr_t)rv_ | (unsigned)cbw) & 3u) == 0 &&
+                  ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4;
         if (cpre_ok) {
             // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
             const int sh = 31 - __clz(ndw), npass = cbh / rpp;
             // (wave-uniform bases + one 32-bit lane offset, as the luma rows)
-            const long ob = (long)cby * L0.stride[1] + cbx, adv = (long)rpp * L0.stride[1];
-            const unsigned clo = (unsigned)((tid >> sh) * L0.stride[1] + 4 * (tid & (ndw - 1)));
-            auto q0 = dsvg_global(fbs + L0.off[1] + ob), q1 = dsvg_global(fbs + L0.off[2] + ob), q2 = dsvg_global(fbr + L0.off[1] + ob), q3 = dsvg_global(fbr + L0.off[2] + ob);
+            const long obs = (long)cby * ss + cbx, obr = (long)cby * rs + cbx, advs = (long)rpp * ss, advr = (long)rpp * rs;
+            const unsigned clos = (unsigned)((tid >> sh) * ss + 4 * (tid & (ndw - 1))), clor = (unsigned)((tid >> sh) * rs + 4 * (tid & (ndw - 1)));
+            auto q0 = dsvg_global(su + obs), q1 = dsvg_global(sv_ + obs), q2 = dsvg_global(ru + obr), q3 = dsvg_global(rv_ + obr);
 #pragma unroll
             for (int u = 0; u < 4; u++) {
                 cpre[u][0] = cpre[u][1] = cpre[u][2] = cpre[u][3] = 0u;
                 if (u < npass) {                                       // wave-uniform
-                    unsigned c2 = clo;
+                    unsigned c2 = clos, c3 = clor;
                     HME_LRO_BARRIER(16, c2);                               // (per block of code: see lane_ro)
+                    HME_LRO_BARRIER(16, c3);
                     cpre[u][0] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q0 + c2);
                     cpre[u][1] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q1 + c2);
-                    cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c2);
-                    cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c2);
+                    cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c3);
+                    cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c3);
                 }
-                q0 += adv; q1 += adv; q2 += adv; q3 += adv;
+                q0 += advs; q1 += advs; q2 += advr; q3 += advr;
             }
         }
     }
@@ -676,9 +679,12 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 #pragma unroll
         for (int k = 0; k < 8; k++) cs[k] = 0;
         const int ndw = (cbw + 3) >> 2;
-        const uint8_t *fbs = A.slab[0] + (size_t)cur * L0.pitch, *fbr = A.slab[0] + (size_t)rf * L0.pitch;
-        const bool aligned = (((unsigned)L0.off[1] | (unsigned)L0.off[2] | (unsigned)L0.stride[1] | (unsigned)L0.stride[2] | (unsigned)cbx |
-                               (unsigned)(uintptr_t)fbs | (unsigned)(uintptr_t)fbr) & 3u) == 0;
+        // (chroma planes by the per-slot tables: the bordered frame, or the caller's packed clip for frames loaded in place)
+        const uint8_t *cpl[4] = {reinterpret_cast<const uint8_t *>(A.slot_cu[cur]), reinterpret_cast<const uint8_t *>(A.slot_cv[cur]),
+                                 reinterpret_cast<const uint8_t *>(A.slot_cu[rf]), reinterpret_cast<const uint8_t *>(A.slot_cv[rf])};
+        const int cst[4] = {A.slot_cs[cur], A.slot_cs[cur], A.slot_cs[rf], A.slot_cs[rf]};
+        const bool aligned = (((unsigned)cst[0] | (unsigned)cst[2] | (unsigned)cbx | (unsigned)(uintptr_t)cpl[0] | (unsigned)(uintptr_t)cpl[1] |
+                               (unsigned)(uintptr_t)cpl[2] | (unsigned)(uintptr_t)cpl[3]) & 3u) == 0;
         bool done_c = false;
         if constexpr (FAST) {
             if (cpre_ok) {                                             // requested at the top of the level-0 section
@@ -707,9 +713,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 cm[it] = !ok ? 0u : (nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u));
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    const uint8_t *fb = (k & 2) ? fbr : fbs;
-                    const int pl = 1 + (k & 1);
-                    cw4[it][k] = *reinterpret_cast<const unsigned *>(fb + L0.off[pl] + (long)(cby + y) * L0.stride[pl] + cbx + xd);
+                    cw4[it][k] = *reinterpret_cast<const unsigned *>(cpl[k] + (long)(cby + y) * cst[k] + cbx + xd);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -729,10 +733,9 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             const unsigned m = nb >= 4 ? 0xffffffffu : ((1u << (8 * nb)) - 1u);
 #pragma unroll
             for (int side = 0; side < 2; side++) {
-                const uint8_t *fb = A.slab[0] + (size_t)(side ? rf : cur) * L0.pitch;
 #pragma unroll
                 for (int pl = 1; pl <= 2; pl++) {
-                    const unsigned w = ldg_u32_unaligned(fb + L0.off[pl] + (long)(cby + y) * L0.stride[pl] + cbx + xd) & m;
+                    const unsigned w = ldg_u32_unaligned(cpl[side * 2 + pl - 1] + (long)(cby + y) * cst[side * 2] + cbx + xd) & m;
                     const int o = side * 4 + (pl - 1) * 2;
                     cs[o] = __builtin_amdgcn_sad_u8(w, 0u, cs[o]);
                     cs[o + 1] = __builtin_amdgcn_udot4(w, w, cs[o + 1], false);

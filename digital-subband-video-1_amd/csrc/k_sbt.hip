@@ -401,7 +401,8 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
     const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
     if (I >= g.w3 || J >= g.h3) return;
     const JobDev &jb = jobs[job];
-    const uint8_t *px = (from_src ? jb.src : jb.xf) + g.poff;
+    const uint8_t *px = from_src ? jb.srcp[c] : jb.xf + g.poff;
+    const int pxs = from_src ? jb.srcs[c] : g.pstride;
     int32_t *coef = jb.coef + g.coff;
 
     int a[8][8];
@@ -409,7 +410,7 @@ __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__
     for (int r = 0; r < 8; r++) {
         const int y = 8 * J + r;
         uint2 v = make_uint2(0x80808080u, 0x80808080u);         // rows >= ph stay zero (p2sbc skips them)
-        if (y < g.ph) v = *reinterpret_cast<const uint2 *>(px + (size_t)y * g.pstride + 8 * I);
+        if (y < g.ph) v = *reinterpret_cast<const uint2 *>(px + (size_t)y * pxs + 8 * I);
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             a[r][i] = (int)((v.x >> (8 * i)) & 0xff) - 128;
@@ -867,10 +868,11 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
 #pragma unroll
     for (int j = 0; j < 2; j++) f2[j] = q.stable[S.i2[j]];
     const int f3 = q.stable[S.i3];
-    const auto sp = dsvg_global(static_cast<const uint8_t *>(jb.src + g.poff));
+    const auto sp = dsvg_global(jb.srcp[c]);
+    const int sstride = jb.srcs[c];
     uint2 sw[8];
 #pragma unroll
-    for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)((y0 + r) * stride + x0));
+    for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)((y0 + r) * sstride + x0));
     FwdFastQ fq;
 #pragma unroll
     for (int j = 0; j < 4; j++) fq.sh1[j] = f1[j] ? L1.sh1 : L1.sh0;
@@ -1108,10 +1110,11 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
         }
     } else {
         // the source rows depend on nothing: requested first
-        const auto sp = dsvg_global(static_cast<const uint8_t *>(jb.src + g.poff));
+        const auto sp = dsvg_global(jb.srcp[c]);
+        const int sstride = jb.srcs[c];
         uint2 sw[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)(min(y0 + r, ph - 1) * stride + x0));
+        for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)(min(y0 + r, ph - 1) * sstride + x0));
         const int dx = mv.x >> sh, dy = mv.y >> sv;
         const int xb = bi * bw, yb = bj * bh;
         const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
@@ -1178,7 +1181,8 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
     const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
     if (8 * I >= W || 8 * J >= H) return;
     const JobDev &jb = jobs[job];
-    const uint8_t *px = (from_src ? jb.src : jb.xf) + g.poff;
+    const uint8_t *px = from_src ? jb.srcp[c] : jb.xf + g.poff;
+    const int pxs = from_src ? jb.srcs[c] : g.pstride;     // (an in-place chroma plane has no border: the window's edge bytes are fixed up below, never used as read)
     int32_t *coef = jb.coef + g.coff;
     const int hw = W >> 1, hh = H >> 1;
 
@@ -1226,7 +1230,7 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
                 y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
                 unsigned lo = 0x80808080u, mi = 0x80808080u, hi = 0x80808080u;      // bytes x = 8I-1 .. 8I+2, +3 .. +6, +7 .. (sample 0 = byte 128)
                 if (y < g.ph) {
-                    const unsigned ro = (unsigned)(y * g.pstride + 8 * I);
+                    const unsigned ro = (unsigned)(y * pxs + 8 * I);
                     const uint2 mm = dsvg_ld2(pxg + ro);
                     const unsigned lft = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro - 4u);
                     const unsigned rgt = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro + 8u);
@@ -1307,7 +1311,7 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
         y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
         int v[10];                                          // v[k] = sample at x = 8I-1+k
         if (y < g.ph) {
-            const uint8_t *row = px + (size_t)y * g.pstride + 8 * I;
+            const uint8_t *row = px + (size_t)y * pxs + 8 * I;
             const uint2 m = *reinterpret_cast<const uint2 *>(row);
             const unsigned lft = *reinterpret_cast<const unsigned *>(row - 4);
             const unsigned rgt = *reinterpret_cast<const unsigned *>(row + 8);

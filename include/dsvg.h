@@ -158,6 +158,15 @@ int dsvg_load_frames(dsvg_ctx *ctx, int first_slot, int n, const void *yuv, int 
 int dsvg_load_frames_strided(dsvg_ctx *ctx, int first_slot, int n, const void *yuv_dev, size_t frame_pitch, int with_pyramid);
 /* same, frame i (at yuv_dev + i*frame_pitch) goes to source slot slots[i]: one launch set for a whole batch */
 int dsvg_load_frames_map(dsvg_ctx *ctx, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid);
+/* same with chroma_in_place (one flag per frame, or NULL): a flagged frame's chroma planes are not copied -- the forward
+ * transform and the motion search's chroma test read them from the caller's clip; only its luma gets the bordered copy and
+ * the pyramid (what a frame needs as a motion search REFERENCE; frame.c:122-164,240-327, hme.c:667-681).  The clip must stay
+ * unchanged until the pictures coded from those slots have been fetched AND the frame that follows each of them in its stream
+ * has been analysed.  Needs even chroma planes a multiple of 8 wide and a 16-byte aligned clip; otherwise (or with
+ * DSV1_NO_CHROMA_IN_PLACE) the frames are copied whole.  dsvg_ctx_chroma_in_place_frames: how many frames took it (tests). */
+int dsvg_load_frames_map_ex(dsvg_ctx *ctx, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid,
+                            const unsigned char *chroma_in_place);
+long dsvg_ctx_chroma_in_place_frames(const dsvg_ctx *ctx);
 int dsvg_get_luma_sums(dsvg_ctx *ctx, int first_slot, int n, unsigned *sums_out);   /* raw sums, syncs */
 int dsvg_get_avg_luma(dsvg_ctx *ctx, int first_slot, int n, int *avg_out);           /* syncs */
 
