@@ -2758,17 +2758,19 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
 // dequantised here (shift quantiser hzcc.c:221-224) -- the dequantised int32 bands are then neither written by the forward
 // transform nor read back (3 + 3 B/sample less)
 template <bool SYM>
-__global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+__global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int gx, int gy, int gz, int plain)
 {
     __shared__ int VL[2 * BT_C][BT_VW];     // column-pass output, low-horizontal half
     __shared__ int VH[2 * BT_C][BT_VW];     // column-pass output, high-horizontal half
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    Blk3 B;                                 // one-dimensional launch in XCD order (d_xcd_blk3): a tile shares its halo columns / rows and
+    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;     // the lines its rows straddle with the neighbours in the same L2
+    const int job = B.z / npl, c = c0 + B.z % npl;
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int W = g.W, H = g.H, hw = W >> 1, hh = H >> 1;
     const int32_t *coef = jb.coef + g.coff;
     const int32_t *s1 = jb.s1 + g.s1off;
-    const int k0 = blockIdx.x * BT_C, m0 = blockIdx.y * BT_C;
+    const int k0 = B.x * BT_C, m0 = B.y * BT_C;
     const int tid = threadIdx.x;
 
     // phase A: vertical pass for columns k0-1..k0+BT_C (clamped) of both halves, rows 2*m0 .. 2*m0+2*BT_C-1.
@@ -3121,8 +3123,8 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
         PB(insym ? KID_INV_B4T_SYM : KID_INV_B4T, smp * (insym ? 3.5 : 5.0));           // LL1 1 + details 3 (symbols: 1.5) in, 1 out
-        if (insym) hipLaunchKernelGGL((k_inv_b4t<true>), bg, dim3(256), 0, st, jobs, G, c0, npl);
-        else       hipLaunchKernelGGL((k_inv_b4t<false>), bg, dim3(256), 0, st, jobs, G, c0, npl);
+        if (insym) hipLaunchKernelGGL((k_inv_b4t<true>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, (int)bg.x, (int)bg.y, (int)bg.z, xcd_plain());
+        else       hipLaunchKernelGGL((k_inv_b4t<false>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, (int)bg.x, (int)bg.y, (int)bg.z, xcd_plain());
         PE();
     }
 }

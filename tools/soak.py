@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Random stream-parity soak on the GPU box (encoder; every third case the decoder too): geometries (with an emphasis on multiples of 8 / 16 / 128, where the edge
 tiles of the fast inverse kernel and the 16-byte border paths apply), formats, quantisers, GOP lengths, content styles and
-batch shapes (several streams side by side, frames per call) -- product stream against the oracle's, byte for byte.
+batch shapes (several streams side by side, frames per call; host clips, device clips with in-place chroma, one stream in
+GOP-parallel chain mode) -- product stream against the oracle's, byte for byte.
 usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case)"""
 import importlib, os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
@@ -30,7 +31,8 @@ for k in range(N):
     n = rng.choice([3, 4, 5, 7])
     S = rng.choice([1, 1, 2, 5, 17, 33, 64])
     F = rng.choice([f for f in (1, 2, 3, n) if n % f == 0])        # (the batch API takes whole batches)
-    style = rng.choice([0, 1, 2])
+    style = rng.choice([0, 1, 2, 3, 4, 5])
+    mode = rng.choice(['host', 'host', 'device', 'chain'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode
     cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
     seed = rng.randrange(1 << 30)
     clips = [A.gen_clip(w, h, fmt, seed + s, n, style=style) for s in range(min(S, 3))]
@@ -38,6 +40,20 @@ for k in range(N):
         want = [A.orc_encode(c, A.orc_cfg(w, h, fmt, **cli), eos=False)[0] for c in clips]
     except Exception as e:
         print("case %d skipped (oracle: %s)" % (k, e)); continue
+    if mode == 'chain':
+        # ONE stream, GOP-parallel (dsv1_stream_open): calls of F frames, a random number of chains side by side
+        n2 = rng.choice([8, 12, 18])
+        Fc = rng.choice([f for f in (2, 3, 4, 6) if n2 % f == 0])
+        clip = A.gen_clip(w, h, fmt, seed, n2, style=style)
+        try:
+            want1 = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli))[0]
+        except Exception as e:
+            print("case %d skipped (oracle: %s)" % (k, e)); continue
+        got1 = pkg.encode_stream(clip, w, h, fmt, Fc, rng.choice([1, 2, 3, 5]), **cli)
+        if got1 != want1:
+            bad += 1
+            print("CHAIN MISMATCH case %d: %dx%d fmt %d n %d F %d style %d %s seed %d" % (k, w, h, fmt, n2, Fc, style, cli, seed))
+        continue
     b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), S, F)
     try:
         got = [b""] * S
@@ -45,14 +61,14 @@ for k in range(N):
         while t < n:
             f = F
             fr = np.stack([clips[s % len(clips)][t:t + f] for s in range(S)]).reshape(S, f, -1)
-            pk = b.encode(fr)
+            pk = b.encode(b.upload(fr), on_device=True) if mode == 'device' else b.encode(fr)
             for s in range(S):
                 got[s] += pk[s]
             t += f
         for s in range(S):
             if got[s] != want[s % len(clips)]:
                 bad += 1
-                print("MISMATCH case %d: %dx%d fmt %d n %d S %d F %d style %d %s seed %d stream %d" % (k, w, h, fmt, n, S, F, style, cli, seed, s))
+                print("MISMATCH case %d (%s): %dx%d fmt %d n %d S %d F %d style %d %s seed %d stream %d" % (k, mode, w, h, fmt, n, S, F, style, cli, seed, s))
                 break
     finally:
         b.close()
