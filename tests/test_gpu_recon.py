@@ -90,6 +90,9 @@ CASES = [
     (640, 360, A.SUBSAMP_420, 4, 2, dict(qp=70, gop=12, rc_mode_cli=1)),
     (768, 576, A.SUBSAMP_444, 3, 1, dict(qp=85, gop=12, rc_mode_cli=1)),              # 4:4:4: the chroma planes take the luma-sized kernels
     (1024, 768, A.SUBSAMP_422, 3, 0, dict(qp=60, gop=12, rc_mode_cli=1)),
+    # BASELINE configs 4 / 5 geometry: 3840x2160, 64x64 blocks, 480x270 level-3 cells (30 x 34 tiles, both edge-tile bodies)
+    (3840, 2160, A.SUBSAMP_420, 3, 2, dict(qp=85, gop=12, rc_mode_cli=1)),
+    (3840, 2160, A.SUBSAMP_444, 2, 1, dict(qp=85, gop=30, rc_mode_cli=1)),
 ]
 
 
