@@ -433,10 +433,13 @@ bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *sl
     return ok;
 }
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
-                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2)
+                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2, int n_chroma)
 {
     FrameLayout dummy = L;
-    if (pf) pf->begin(st, KID_UNPACK, 2.0 * n * ((double)L.w[0] * L.h[0] + 2.0 * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0) + (slab2 ? 0.0625 * n * L.w[0] * L.h[0] : 0.0));
+    // algorithmic bytes: every copied plane read once and written once (n_chroma: the frames whose chroma is copied too -- the
+    // others keep it in the caller's clip), + the pyramid levels written
+    if (n_chroma < 0) n_chroma = n;
+    if (pf) pf->begin(st, KID_UNPACK, 2.0 * ((double)n * L.w[0] * L.h[0] + 2.0 * n_chroma * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0) + (slab2 ? 0.0625 * n * L.w[0] * L.h[0] : 0.0));
     hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
                        slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0) | (sides && sides2 ? 4 : 0), slab2, L2 ? *L2 : dummy);
     if (pf) pf->end(st);
