@@ -108,6 +108,7 @@ struct dsvg_ctx {
     unsigned *stat = nullptr;        // [4][64] inverse-transform tile counters (general luma / chroma, zero luma / chroma), sharded
     bool stats_on = false;
     bool no_patch_kernel = false;    // DSV1_NO_PATCH_KERNEL: chroma of P pictures stays on the tile kernel (A/B switch)
+    bool no_dec_sym_I = false;       // DSV1_NO_DEC_SYM_I: the decoder's I pictures keep int32 coefficients (A/B switch)
     bool no_dec_sym = false;         // DSV1_NO_DEC_SYM: the decoder keeps int32 coefficients for P pictures too (A/B switch)
     bool dec_sym_ok[2] = {false, false};   // luma / chroma planes have no cell shared between scan regions
     bool fetch_shared = false;       // DSV1_FETCH_ON_ANALYSIS: st_c is st_a           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
@@ -301,6 +302,7 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
     c->mc_fused = mc_fusable(MG) && !getenv("DSV1_NO_MC_FUSION");
     c->no_inplace_pred = getenv("DSV1_NO_INPLACE_PRED") != nullptr;
     c->no_dec_sym = getenv("DSV1_NO_DEC_SYM") != nullptr;
+    c->no_dec_sym_I = getenv("DSV1_NO_DEC_SYM_I") != nullptr;
     c->no_patch_kernel = getenv("DSV1_NO_PATCH_KERNEL") != nullptr;
     c->no_list_pack = getenv("DSV1_NO_LIST_PACK") != nullptr;
     c->no_lazy_border = getenv("DSV1_NO_LAZY_BORDER") != nullptr;
@@ -1489,6 +1491,15 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
             }
             jb.dec_lim[0] = (int)std::min<long>(2 * ll, 0x3fffffff);
         }
+        // I pictures (round 3): symbols into the zero-kept planes as well -- the encoder's I-picture inverse (k_inv_haar_tile<.,1,true>,
+        // k_inv_b4t<true>) dequantises them in 32 bits, so the only thing they cannot hold is a symbol beyond int16; needs both
+        // plane kinds on the symbol path (the I kernels take luma and chroma alike)
+        const bool sparseI = sparse && c->dec_sym_ok[0] && c->dec_sym_ok[1] && !c->no_dec_sym_I;
+        if (!isP && sparseI) {
+            jb.sym = c->symP + (size_t)t * c->nz_total;
+            for (int p = 0; p < 3; p++) jb.dec_sym[p] = 1;
+            for (int lv = 0; lv < 16; lv++) jb.dec_lim[lv] = 0x3fffffff;
+        }
         if (isP && sparse) {
             // sparse decode of P pictures: the detail entries go to the zero-kept int16 symbol planes and the fused inverse
             // of the encoder reconstructs from them (no 12 MB of int32 coefficients to clear and to read per picture); a
@@ -1539,14 +1550,17 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
     HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h + hb * c->nblk, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h + hb, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
-    const int insym = !sparse ? 0 : (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
-    if (insym && njobs > nI) HIPCHK(hipMemsetAsync(c->dec_flag_d + hb, 0, sizeof(int) * (size_t)njobs, c->st));
+    const bool symI = sparse && c->dec_sym_ok[0] && c->dec_sym_ok[1] && !c->no_dec_sym_I && nI > 0;      // the call's I pictures are on the symbol path
+    const int insym = !sparse ? 0 : (symI ? 1 : 0) | (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
+    const int f0 = symI ? 0 : nI;                      // first job that may raise a flag / holds symbols to take down again
+    const bool anysym = ((insym & 6) && njobs > nI) || symI;
+    if (anysym) HIPCHK(hipMemsetAsync(c->dec_flag_d + hb, 0, sizeof(int) * (size_t)njobs, c->st));
     launch_dec_clear(c->st, c->jobs_d, njobs);
-    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof, insym == 6 && nI == 0);
-    if (insym && njobs > nI) {
+    launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof, (insym & 6) == 6 && (nI == 0 || symI));
+    if (anysym) {
         // what the symbol planes cannot hold (JobDev.dec_flag): shared cells that keep the earlier region's value; symbols
         // beyond int16 were flagged by the scatter itself.  The flags travel back now and are read by dec_resolve later.
-        if ((c->dec_ov[0] && c->dec_sym_ok[0]) || (c->dec_ov[1] && c->dec_sym_ok[1])) launch_hz_dec_resolve(c->st, c->jobs_d + nI, njobs - nI, 0, 3);
+        if ((c->dec_ov[0] && c->dec_sym_ok[0]) || (c->dec_ov[1] && c->dec_sym_ok[1])) launch_hz_dec_resolve(c->st, c->jobs_d + f0, njobs - f0, 0, 3);
         HIPCHK(hipMemcpyAsync(c->dec_flag_h + hb, c->dec_flag_d + hb, sizeof(int) * (size_t)njobs, hipMemcpyDeviceToHost, c->st));
         HIPCHK(hipEventRecord(c->ev_flag[k], c->st));
         if (!was_redo) { P.active = true; P.parity = k; P.njobs = njobs; }
@@ -1579,7 +1593,7 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
         } else launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
     }
     OPCHK(enqueue_recon(c, nI, njobs, 0, insym));
-    if (insym && njobs > nI) launch_hz_unscatter(c->st, c->jobs_d + nI, njobs - nI, max_entries);
+    if (anysym) launch_hz_unscatter(c->st, c->jobs_d + f0, njobs - f0, max_entries);
     HIPCHK(hipGetLastError());
     return DSVG_OK;
 }

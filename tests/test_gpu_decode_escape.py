@@ -199,6 +199,20 @@ def _two_picture_stream(w, h, fmt, seed):
     return pk, pics[1]
 
 
+@pytest.mark.parametrize("plane", [0, 2])
+@pytest.mark.parametrize("sym", [40000, -33000, 32767, 9])
+def test_intra_picture_symbols_beyond_int16(pkg, orc, plane, sym):
+    """I pictures take the symbol planes too; their inverse dequantises in 32 bits, so only a symbol beyond int16 needs the int32 pass"""
+    w, h, fmt = 352, 288, A.SUBSAMP_444
+    pk, ip = _two_picture_stream(w, h, fmt, 0xE5CA9F)
+    ii = [i for i, p in enumerate(pk) if (p[5] & 4) and not (p[5] & 1)][0]
+    b2, sw2 = region_base(w, h, 2, 3)                  # level-2 HH: shift quantiser
+    b0, sw0 = region_base(w, h, 0, 1)                  # level-0 LH
+    entries = sorted([(3, -4), (b0 + 2 * sw0 + 5, 6), (b2 + 17 * sw2 + 40, sym), (b2 + 60 * sw2 + 3, -2)])
+    pk[ii] = splice(pk[ii], {plane: plane_payload(-11, entries)})
+    _expect_and_decode(pkg, b"".join(pk), w, h, fmt, want_redone=abs(sym) > 32767)
+
+
 @pytest.mark.parametrize("plane", [0, 1])
 @pytest.mark.parametrize("sym", [40000, -70000, 32767, 500, 1])
 def test_symbol_beyond_the_encoders_range_is_decoded_like_the_reference(pkg, orc, plane, sym):
