@@ -162,7 +162,8 @@ int  dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int 
 void dsv1_batch_close(dsv1_batch *b);
 void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
 /* Encode frames_per_call frames of every stream.  yuv: [stream][frame] tightly packed planar frames,
- * host or device memory.  For each stream s the packets are appended to out[s] (a growing buffer the
+ * host or device memory.  A DEVICE clip (yuv_on_device = 1) must stay unchanged until the batch has been collected: its
+ * chroma planes are read in place by the coding kernels (dsvg_load_frames_map_ex) -- only luma is copied.  For each stream s the packets are appended to out[s] (a growing buffer the
  * caller owns: data = NULL / len = 0 to start; freed with dsv_free).  Returns 0 or a DSVG_ERR_*. */
 int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
 /* Pipelined form (CRF): submit enqueues a batch and returns while its residual coding still runs on
