@@ -101,6 +101,7 @@ struct dsvg_ctx {
     int32_t *llsym = nullptr;        // per work job: LL-region symbols of the encoder (JobDev.llsym)
     int ll_off[3] = {0, 0, 0};
     size_t ll_total = 0;
+    int defer_T = 0;                 // DSV1_DEFER_ENTROPY=<frame steps>: the entropy stage of P frame steps runs after the call's last reconstruction (symbol / flag planes per step)
     bool llq = true;                 // the LL quantiser runs inside k_fwd_haar_mid<4> / k_tail_q (DSV1_NO_LLQ=1: k_hz_quant<true>, A/B)
     int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
@@ -384,15 +385,17 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
     if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->sym, c->nz_total * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->nzf, (c->nz_total >> 2) * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->symP, c->nz_total * J, true))) return fail(rc);
+    { const char *e = getenv("DSV1_DEFER_ENTROPY"); c->defer_T = e ? std::max(0, atoi(e)) : 0; }
+    const size_t DT = (size_t)std::max(1, c->defer_T);
+    if ((rc = dmalloc(&c->nzf, (c->nz_total >> 2) * J * DT, true))) return fail(rc);
+    if ((rc = dmalloc(&c->symP, c->nz_total * J * DT, true))) return fail(rc);
     if ((rc = dmalloc(&c->pflag, CL.s3total * J, true))) return fail(rc);
-    if ((rc = dmalloc(&c->cflag, (size_t)c->chunks_per_job * J, true))) return fail(rc);
+    if ((rc = dmalloc(&c->cflag, (size_t)c->chunks_per_job * J * DT, true))) return fail(rc);
     {   // LL symbol planes (int32, scan order), each plane's share padded to 8 entries (16-byte reads in k_hz_collect*)
         size_t o = 0;
         for (int p = 0; p < 3; p++) { c->ll_off[p] = (int)o; o += ((size_t)CL.w3[p] * CL.h3[p] + 7) & ~(size_t)7; }
         c->ll_total = o;
-        if ((rc = dmalloc(&c->llsym, c->ll_total * J, true))) return fail(rc);
+        if ((rc = dmalloc(&c->llsym, c->ll_total * J * DT, true))) return fail(rc);
     }
     c->llq = !getenv("DSV1_NO_LLQ");
     if ((rc = dmalloc(&c->stat, 4 * 64, true))) return fail(rc);
@@ -985,6 +988,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             for (int r = 0; r < c->n_recon; r++) if (now[r] >= 0) writer[r] = now[r];
         }
     }
+    const bool defer = c->defer_T > 0 && nsteps > 1 && nsteps <= c->defer_T;     // (experiment: DSV1_DEFER_ENTROPY)
     int gk[DSVG_MAX_CODE_STREAMS + 1];                        // device jobs [gk[g], gk[g+1]) of every step -> stream g
     for (int g = 0; g <= NG; g++) gk[g] = (int)((long)njobs * g / NG);
     std::vector<int> ioff((size_t)NG * nsteps, 0), icnt((size_t)NG * nsteps, 0);
@@ -1023,7 +1027,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     }
     {   // the job records themselves (quantiser tables of three planes, pointers, copies of the block tables): independent per
         // job, built on the session layer's worker pool (1 920 jobs: 1.5 ms on one thread)
-        struct BuildCtx { dsvg_ctx *c; const std::vector<const dsvg_pic_job *> *dj; int base, njobs; } bc = {c, &dj, base, njobs};
+        struct BuildCtx { dsvg_ctx *c; const std::vector<const dsvg_pic_job *> *dj; int base, njobs; bool defer; } bc = {c, &dj, base, njobs, defer};
         dsv1_par_for(total, [](void *vp, int idx, int) {
             BuildCtx &B = *static_cast<BuildCtx *>(vp);
             dsvg_ctx *c = B.c;
@@ -1034,11 +1038,14 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
             jb.llq = c->llq ? 1 : 0;           // ... and the LL region's into the kernels that produce it
-            jb.llsym = c->llsym + (size_t)k * c->ll_total;
+            // (deferred entropy stage: every frame step of the call has symbol / flag planes of its own)
+            const size_t kk = B.defer ? (size_t)(idx / B.njobs) * (size_t)c->max_jobs + (size_t)k : (size_t)k;
+            jb.llsym = c->llsym + kk * c->ll_total;
             for (int p = 0; p < 3; p++) jb.ll_off[p] = c->ll_off[p];
+            jb.cflag = c->cflag + kk * c->chunks_per_job;
             // P pictures run sparse: zero-kept symbol planes + non-zero flags (k_hz_collect takes both down again)
-            jb.nzf = isP ? c->nzf + (size_t)k * (c->nz_total >> 2) : nullptr;
-            if (isP) jb.sym = c->symP + (size_t)k * c->nz_total;
+            jb.nzf = isP ? c->nzf + kk * (c->nz_total >> 2) : nullptr;
+            if (isP) jb.sym = c->symP + kk * c->nz_total;
             jb.psum = c->psum + (size_t)j.out_slot * 3;
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
@@ -1144,9 +1151,18 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             bool keeps = false;
             for (int k = k0; k < k0 + n && !keeps; k++) keeps = dj[(size_t)t * njobs + k]->recon_slot >= 0;
             if (keeps) OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true, c->llq));
-            launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
+            if (!(defer && nIs[t] == 0)) launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
         }
     }
+    if (defer)      // the entropy stage of the P frame steps, off the chain reconstruction(t) -> forward(t + 1)
+        for (int t = 0; t < nsteps; t++) {
+            if (nIs[t] != 0) continue;
+            for (int g = 0; g < NG; g++) {
+                hipStream_t st = g ? c->stx[g] : c->st;
+                const int k0 = gk[g], n = gk[g + 1] - gk[g];
+                launch_hz_pack(st, c->jobs_d + base + t * njobs + k0, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : 0);
+            }
+        }
     for (int g = 1; g < NG; g++) {
         HIPCHK(hipEventRecord(c->ev_join[g], c->stx[g]));
         HIPCHK(hipStreamWaitEvent(c->st, c->ev_join[g], 0));

@@ -124,6 +124,7 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
     if (style == 1) {
         int sq = big ? h / 3 : (w < 192 ? w / 4 : 96);
         if (sq > h - 8) sq = h - 8;                   /* very flat frames: keep the square inside */
+        if (sq > w - 8) sq = w - 8;                   /* ... and narrow ones (style 4's square is a third of the height) */
         int sx = (37 * t) % (w - sq), sy = (23 * t) % (h - sq);
         int lvl = 40 + 15 * t; if (lvl > 250) lvl = 250;
         for (int y = 0; y < sq; y++) memset(Y + (size_t)(sy + y) * w + sx, lvl, (size_t)sq);

@@ -35,6 +35,8 @@ for k in range(N):
     mode = rng.choice(['host', 'host', 'device', 'chain'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode
     cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
     seed = rng.randrange(1 << 30)
+    if os.environ.get('SOAK_VERBOSE'):
+        print('case %d: %s %dx%d fmt %d n %d S %d F %d style %d %s seed %d' % (k, mode, w, h, fmt, n, S, F, style, cli, seed), flush=True)
     clips = [A.gen_clip(w, h, fmt, seed + s, n, style=style) for s in range(min(S, 3))]
     try:
         want = [A.orc_encode(c, A.orc_cfg(w, h, fmt, **cli), eos=False)[0] for c in clips]
