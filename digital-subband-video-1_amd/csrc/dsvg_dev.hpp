@@ -219,6 +219,42 @@ static __device__ __forceinline__ bool d_xcd_blk3(int gx, int gy, int gz, Blk3 &
     return true;
 }
 
+// ---- diagnostic builds only (make EXTRA=-DDSVG_CLOCK_PROBE, tools/ab/clock_probe.sh): the shader clock a kernel runs at.
+// Thread 0 of one workgroup in 128 stamps s_memtime (shader clock) and s_memrealtime (100 MHz) on entry and exit and adds the two
+// differences to its kernel's slot; clock = sum(dt) / sum(dr) x 100 MHz.  The library prints the slots when a context is
+// destroyed.  Nothing of this exists in the shipped build.
+#ifdef DSVG_CLOCK_PROBE
+#define DSVG_CLK_SLOTS 16
+static __device__ unsigned long long dsvg_clk_acc[DSVG_CLK_SLOTS][3];
+struct ClkStamp { unsigned long long t, r; };
+static __device__ __forceinline__ ClkStamp d_clk_begin()
+{
+    ClkStamp s;
+    s.t = __builtin_amdgcn_s_memtime(); s.r = __builtin_amdgcn_s_memrealtime();
+    return s;
+}
+static __device__ __forceinline__ void d_clk_end(int slot, const ClkStamp &s)
+{
+    const unsigned long long t = __builtin_amdgcn_s_memtime() - s.t, r = __builtin_amdgcn_s_memrealtime() - s.r;
+    if (threadIdx.x == 0 && (blockIdx.x & 127) == 5) {           // one workgroup in 128: every workgroup's atomics on one line slowed the step 5x
+        atomicAdd(&dsvg_clk_acc[slot][0], t); atomicAdd(&dsvg_clk_acc[slot][1], r); atomicAdd(&dsvg_clk_acc[slot][2], 1ull);
+    }
+}
+#define DSVG_CLK_BEGIN() const ClkStamp clk_stamp_ = d_clk_begin()
+#define DSVG_CLK_END(slot) d_clk_end(slot, clk_stamp_)
+// host side, one per kernel file: prints and clears that file's slots
+#define DSVG_CLK_DUMP_FN(fn, ...) extern "C" void fn() { \
+    static const char *names[] = {__VA_ARGS__}; unsigned long long h[DSVG_CLK_SLOTS][3]; \
+    if (hipMemcpyFromSymbol(h, HIP_SYMBOL(dsvg_clk_acc), sizeof(h)) != hipSuccess) return; \
+    for (unsigned i = 0; i < sizeof(names) / sizeof(names[0]); i++) if (h[i][1]) \
+        { if (h[i][2]) fprintf(stderr, "[clock probe] %-28s %8.1f MHz  (%llu workgroups, %.2f us each)\n", names[i], 100.0 * (double)h[i][0] / (double)h[i][1], h[i][2], 0.01 * (double)h[i][1] / (double)h[i][2]); \
+          else fprintf(stderr, "[clock probe] %-34s %9.0f cycles per block\n", names[i], (double)h[i][0] / (double)h[i][1]); } \
+    memset(h, 0, sizeof(h)); (void)hipMemcpyToSymbol(HIP_SYMBOL(dsvg_clk_acc), h, sizeof(h)); }
+#else
+#define DSVG_CLK_BEGIN() do { } while (0)
+#define DSVG_CLK_END(slot) do { } while (0)
+#endif
+
 // ---- HZCC quantiser arithmetic shared by the transform-fused path (k_sbt.hip) and k_hzcc.hip -----------
 #define HZ_MINQ 16
 static __device__ __forceinline__ int hzq_lo(int v, int q)            // quant hzcc.c:94-112

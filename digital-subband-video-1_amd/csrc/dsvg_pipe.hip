@@ -449,7 +449,13 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
     return DSVG_OK;
 }
 
+#ifdef DSVG_CLOCK_PROBE
+extern "C" void dsvg_clk_dump_sbt();
+extern "C" void dsvg_clk_dump_hme();
+extern "C" void dsvg_ctx_destroy(dsvg_ctx *ctx) { if (ctx) { (void)hipDeviceSynchronize(); dsvg_clk_dump_sbt(); dsvg_clk_dump_hme(); } ctx_free(ctx); }
+#else
 extern "C" void dsvg_ctx_destroy(dsvg_ctx *ctx) { ctx_free(ctx); }
+#endif
 
 extern "C" int dsvg_ctx_geom(const dsvg_ctx *c, dsvg_geom *g)
 {

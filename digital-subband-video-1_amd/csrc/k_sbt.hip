@@ -984,13 +984,17 @@ template <>
 __global__ __launch_bounds__(256) FAST_WPE_L_ATTR void k_fwd_mc_fast<0>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
                                                                         const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
 {
+    DSVG_CLK_BEGIN();
     fwd_mc_fast_body<0>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
+    DSVG_CLK_END(1);
 }
 template <>
 __global__ __launch_bounds__(256) FAST_WPE_C_ATTR void k_fwd_mc_fast<1>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
                                                                         const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
 {
+    DSVG_CLK_BEGIN();
     fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
+    DSVG_CLK_END(2);
 }
 
 // ---- decoder: prediction only (compensate bmc.c:204-302 without subf), the lean kernel's motion compensation by itself ----
@@ -2325,10 +2329,12 @@ __global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev
     const int job = B.z / npl, c = c0 + B.z % npl;
     const int I0 = B.x * IT_TX, J0 = B.y * IT_TY;
     const bool er = B.x == er_col, eb = B.y == eb_row;      // (eb_row: the last tile row, likewise)
+    DSVG_CLK_BEGIN();
     if (er && eb) inv_p_fast<FILT, true, true>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
     else if (er) inv_p_fast<FILT, true, false>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
     else if (eb) inv_p_fast<FILT, false, true>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
     else inv_p_fast<FILT, false, false>(jobs[job], G.g[c], c, I0, J0, threadIdx.x, A3, A2, A1p);
+    DSVG_CLK_END(0);
 }
 
 // MODE 0: levels 3,2,1 from s3 -> pixels (P pictures).  MODE 1: levels 3,2 from s3 -> LL1 in s1 (I pictures,
@@ -3135,3 +3141,7 @@ void sbt_set_func_attributes()
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_inv_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
+
+#ifdef DSVG_CLOCK_PROBE
+DSVG_CLK_DUMP_FN(dsvg_clk_dump_sbt, "k_inv_p_tile", "k_fwd_mc_fast<0>", "k_fwd_mc_fast<1>")
+#endif

@@ -37,25 +37,7 @@
 #else
 #define HME_MARK(i) do { } while (0)
 #endif
-#define NT 64              // threads per block of the picture = ONE wave: 16 column groups x 4 row groups, no cross-wave exchange
-// Waves per workgroup: each wave takes a block of its own, the workgroup HME_WPG horizontally adjacent ones.  The waves never
-// talk to each other -- they share the CU's L1: a 64-pixel block row is half a 128-byte line and a chroma block row a quarter,
-// so neighbours in separate workgroups (separate CUs) each pull the whole line out of L2.
-#ifndef HME_WPG
-#define HME_WPG 4
-#endif
-#ifndef HME_PG
-#define HME_PG HME_WPG          // frame pairs that walk the block grid together (see k_hme_level)
-#endif
-#define HME_TID ((int)(threadIdx.x & 63u))
-// LDS hand-over inside ONE wave (its DS instructions execute in order): nothing for the hardware to wait for, the compiler
-// must not move accesses across
-static __device__ __forceinline__ void hme_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+#define NT 64              // threads per workgroup = ONE wave per block: 16 column groups x 4 row groups, no cross-wave exchange
 #define NRG (NT / 16)
 #define NK (64 / NRG)       // rows per thread
 #define NW (NT / 64)        // waves per workgroup
@@ -79,7 +61,7 @@ static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_
     const uint8_t *g0 = plane + (long)oy * stride + ox;
     const int mis = (int)(((uintptr_t)g0) & 3);
     const int ndw = (mis + nw + 3) >> 2;
-    const int d = HME_TID & (TPR - 1), rb = HME_TID / TPR;
+    const int d = threadIdx.x & (TPR - 1), rb = threadIdx.x / TPR;
     if (d < ndw) {
         // loads are issued in batches of up to 9 before their stores: a memory round trip per batch, not per row
         constexpr int BATCH = 9;
@@ -209,8 +191,8 @@ static __device__ const int HP_Y[8] = {0, 0, 1, -1, -1, -1, 1, 1};
 static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, int mis, unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
 {
     gh = gv = s1 = s2 = 0;
-    const int r = HME_TID >> 2, d = HME_TID & 3;
-    if (HME_TID < 4 * WIN) {
+    const int r = threadIdx.x >> 2, d = threadIdx.x & 3;
+    if (threadIdx.x < 4 * WIN) {
         const unsigned sh = (unsigned)(mis & 3);
         const unsigned *w = reinterpret_cast<const unsigned *>(p + r * P) + (mis >> 2) + d;
         const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
@@ -243,7 +225,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 #endif
     HME_MARK(0);
     constexpr int NKR = FAST ? NKB : NK;                // rows a lane may own
-    const int tid = HME_TID;
+    const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;             // column group (4 px) / row group
     const int step = 1 << level;
     const FrameLayout &L = A.L[level];
@@ -294,21 +276,15 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     if (parent) {
         const unsigned pmask = ~(unsigned)((step << 1) - 1);
         const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
-        // all five fetched before any is looked at (a neighbour outside the grid is fetched at the clamped position and counts
-        // as the zero vector): one scalar-memory round trip instead of five in a row -- the vectors were written by the
-        // previous launch, so each fetch goes to L2, and with a branch per neighbour the wave spent a third of its life here
         int par[5];
-        bool pok[5];
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
             const int x = pi + ox * step, y = pj + oy * step;
-            pok[m] = x >= 0 && x < A.nxb && y >= 0 && y < A.nyb;
-            const int idx = min(max(x, 0), A.nxb - 1) + min(max(y, 0), A.nyb - 1) * A.nxb;      // DMV starts with int16 x, y: one dword = x | y << 16
-            par[m] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(parent + idx));
+            par[m] = 0;
+            if (x >= 0 && x < A.nxb && y >= 0 && y < A.nyb)      // DMV starts with int16 x, y: one dword = x | y << 16
+                par[m] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(parent + x + y * A.nxb));
         }
-#pragma unroll
-        for (int m = 0; m < 5; m++) par[m] = pok[m] ? par[m] : 0;
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             const int all = par[m];
@@ -326,10 +302,6 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     HME_MARK(1);
     // best inherited candidate by SAD, all candidates in one pass, reference pixels straight from HBM/L2
     int pick = n - 1;
-    // level 0, full blocks: sum and sum of squares of the zero-motion reference block (hme.c:181-300), taken from the zero
-    // vector's rows while they are here for its SAD -- the statistics stage then has no rows of its own to fetch
-    unsigned zc1 = 0, zc2 = 0;
-    bool have_z = false;
 #ifdef AB_HME_NO_CAND
     if (0) {
 #else
@@ -358,15 +330,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                         for (int u = 0; u < NKB; u++) { w[u] = dsvg_ld2(q + lro); q += stride; }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < NKB; u++) {
-                            const unsigned rw = __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh);
-                            acc[k] = __builtin_amdgcn_sad_u8(srcw[u], rw, acc[k]);
-                            if (LEVEL0 && k == 0) {                // the zero vector's rows are the zero-motion block of the statistics
-                                zc1 = __builtin_amdgcn_sad_u8(rw, 0u, zc1);
-                                zc2 = __builtin_amdgcn_udot4(rw, rw, zc2, false);
-                            }
-                        }
-                        if (LEVEL0 && k == 0) have_z = true;
+                        for (int u = 0; u < NKB; u++) acc[k] = __builtin_amdgcn_sad_u8(srcw[u], __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh), acc[k]);
                         __builtin_amdgcn_sched_barrier(0);
                     } else
                     if (cmask && r0 < bh) {
@@ -448,13 +412,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 struct __attribute__((aligned(4))) U3 { unsigned x, y, z; } d[HB];
 #pragma unroll
                 for (int u = 0; u < HB; u++)
-#if defined(AB_HME_NINE_X2)
-                    if (b0 + u < NR) { const uint2 t2 = dsvg_ld2(q + lro); d[u] = U3{t2.x, t2.y, t2.y}; q += stride; }
-#elif defined(AB_HME_NINE_X1)
-                    if (b0 + u < NR) { const unsigned t1 = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q + lro); d[u] = U3{t1, t1, t1}; q += stride; }
-#else
                     if (b0 + u < NR) { const dsvg_u32x3a4 t3 = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x3a4 *>(q + lro); d[u] = U3{t3.x, t3.y, t3.z}; q += stride; }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < HB; u++) {
@@ -545,19 +503,46 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         return;
     }
     // ------------------------------------------------------------------ level 0 only
-    // Full blocks: the rows of the zero-motion reference block depend on no decision -- requested now, consumed by the
-    // statistics further down, so their memory round trip runs under the half-pel stage.  (The four chroma blocks of the
-    // variance test were requested here too until round 3: their 16 registers, held across the half-pel stage, were what
-    // put the kernel at 75 VGPRs = 6 waves per SIMD; fetched where they are used it fits 8.)
-    unsigned zpre[NKR];
+    // Full blocks: the rows of the zero-motion reference block and of the four chroma blocks (source / reference, U / V)
+    // depend on no decision -- requested now, consumed by the statistics and the chroma variance test further down, so
+    // their memory round trips run under the half-pel stage instead of at the tail of the wave.
+    unsigned zpre[NKR], cpre[4][4];
+    bool cpre_ok = false;
     if constexpr (FAST) {
         auto zq = dsvg_global(rp + (long)by * stride + bx);
         unsigned lro = lane_ro;
         HME_LRO_BARRIER(8, lro);
 #pragma unroll
-        for (int kk = 0; kk < NKR; kk++) {
-            zpre[kk] = 0u;
-            if (!have_z) { zpre[kk] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }      // (wave-uniform)
+        for (int kk = 0; kk < NKR; kk++) { zpre[kk] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }
+        const FrameLayout &L0 = A.L[0];
+        const int cbw = bw >> L0.hs, cbh = bh >> L0.vs, ndw = cbw >> 2, rpp = ndw ? NT / ndw : NT + 1;
+        const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
+        const uint8_t *su = reinterpret_cast<const uint8_t *>(A.slot_cu[cur]), *sv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[cur]);
+        const uint8_t *ru = reinterpret_cast<const uint8_t *>(A.slot_cu[rf]), *rv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[rf]);
+        const int ss = A.slot_cs[cur], rs = A.slot_cs[rf];          // (source and reference may differ: in place / bordered)
+        cpre_ok = (((unsigned)ss | (unsigned)rs | (unsigned)cbx | (unsigned)(uintptr_t)su | (unsigned)(uintptr_t)sv_ | (unsigned)(uintptr_t)ru | (unsigned)(uintptr_t)rv_ | (unsigned)cbw) & 3u) == 0 &&
+                  ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4;
+        if (cpre_ok) {
+            // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
+            const int sh = 31 - __clz(ndw), npass = cbh / rpp;
+            // (wave-uniform bases + one 32-bit lane offset, as the luma rows)
+            const long obs = (long)cby * ss + cbx, obr = (long)cby * rs + cbx, advs = (long)rpp * ss, advr = (long)rpp * rs;
+            const unsigned clos = (unsigned)((tid >> sh) * ss + 4 * (tid & (ndw - 1))), clor = (unsigned)((tid >> sh) * rs + 4 * (tid & (ndw - 1)));
+            auto q0 = dsvg_global(su + obs), q1 = dsvg_global(sv_ + obs), q2 = dsvg_global(ru + obr), q3 = dsvg_global(rv_ + obr);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cpre[u][0] = cpre[u][1] = cpre[u][2] = cpre[u][3] = 0u;
+                if (u < npass) {                                       // wave-uniform
+                    unsigned c2 = clos, c3 = clor;
+                    HME_LRO_BARRIER(16, c2);                               // (per block of code: see lane_ro)
+                    HME_LRO_BARRIER(16, c3);
+                    cpre[u][0] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q0 + c2);
+                    cpre[u][1] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q1 + c2);
+                    cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c3);
+                    cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c3);
+                }
+                q0 += advs; q1 += advs; q2 += advr; q3 += advr;
+            }
         }
     }
     const unsigned yarea = (unsigned)(bw * bh), yareasq = yarea * yarea;
@@ -573,7 +558,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     int pmis;
     if (do_hp) pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
     else       pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
-    hme_sync();
+    __syncthreads();
     HME_MARK(4);
     bool have_hp = false;
     // lane = (row y, dword d) of a 14x14 window: 4 pixels per lane, the last dword of a row holds two
@@ -634,7 +619,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ob) : "v"(__builtin_bit_cast(unsigned, vo)));
             reinterpret_cast<unsigned *>(S.u.hp.vb + wy_ * 16)[wd_] = __builtin_amdgcn_perm(ob, eb, 0x05010400u);      // bytes e0 o0 e1 o1
         }
-        hme_sync();
+        __syncthreads();
         // stage D: lane = (column li = 0..15, four rows lj = 4g .. 4g+3): seven h values serve four vertical taps
         {
             const int c = tid & 15, g4 = tid >> 4;
@@ -646,7 +631,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             for (int q = 0; q < 4; q++)
                 S.u.hp.db[(4 * g4 + q) * 16 + c] = (uint8_t)d_sat8((9 * (hv[q + 1] + hv[q + 2]) - (hv[q] + hv[q + 3]) + 128) >> 8);
         }
-        hme_sync();
+        __syncthreads();
         // the eight candidates (HP_X, HP_Y order): H(x+1,y+1) H(x,y+1) V(x+1,y+1) V(x+1,y) D(x,y) D(x+1,y) D(x,y+1) D(x+1,y+1)
         unsigned acc[8];
 #pragma unroll
@@ -693,15 +678,15 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     }
     if (!have_hp) {
         if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
-            hme_sync();
+            __syncthreads();
             pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
-            hme_sync();
+            __syncthreads();
         }
         copy_win(S.u.hp.patch, 24, pmis);
     }
     // the zero-motion reference block (variance test, veto, quadrant votes) is read straight from global memory:
     // bx + 4cg is dword aligned, every thread takes the rows it owns
-    hme_sync();                                    // rwin complete
+    __syncthreads();                                    // rwin complete
     HME_MARK(5);
     unsigned zrow[NKR];
     if constexpr (FAST) {
@@ -743,15 +728,12 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 if (r > 0) st[1] = __builtin_amdgcn_sad_u8(curw, upw, st[1]);
                 st[2] = __builtin_amdgcn_sad_u8(curw, 0u, st[2]);
                 st[3] = __builtin_amdgcn_udot4(curw, curw, st[3], false);
-                if (!have_z) {
-                    const unsigned zw = zrow[kk] & cmask;
-                    st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
-                    st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
-                }
+                const unsigned zw = zrow[kk] & cmask;
+                st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
+                st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
             }
             upw = curw;
         }
-        if (have_z) { st[4] = zc1; st[5] = zc2; }
     }
     // block statistics and the two 14x14 window statistics share one reduction
     unsigned ws[14];
@@ -804,37 +786,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                                (unsigned)(uintptr_t)cpl[2] | (unsigned)(uintptr_t)cpl[3]) & 3u) == 0;
         bool done_c = false;
         if constexpr (FAST) {
-            unsigned cpre[4][4];
-            bool cpre_ok = false;
-            const int rpp = ndw ? NT / ndw : NT + 1;
-            const uint8_t *su = reinterpret_cast<const uint8_t *>(A.slot_cu[cur]), *sv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[cur]);
-            const uint8_t *ru = reinterpret_cast<const uint8_t *>(A.slot_cu[rf]), *rv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[rf]);
-            const int ss = A.slot_cs[cur], rs = A.slot_cs[rf];          // (source and reference may differ: in place / bordered)
-            cpre_ok = (((unsigned)ss | (unsigned)rs | (unsigned)cbx | (unsigned)(uintptr_t)su | (unsigned)(uintptr_t)sv_ | (unsigned)(uintptr_t)ru | (unsigned)(uintptr_t)rv_ | (unsigned)cbw) & 3u) == 0 &&
-                      ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4;
-            if (cpre_ok) {
-                // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
-                const int sh = 31 - __clz(ndw), npass = cbh / rpp;
-                // (wave-uniform bases + one 32-bit lane offset, as the luma rows)
-                const long obs = (long)cby * ss + cbx, obr = (long)cby * rs + cbx, advs = (long)rpp * ss, advr = (long)rpp * rs;
-                const unsigned clos = (unsigned)((tid >> sh) * ss + 4 * (tid & (ndw - 1))), clor = (unsigned)((tid >> sh) * rs + 4 * (tid & (ndw - 1)));
-                auto q0 = dsvg_global(su + obs), q1 = dsvg_global(sv_ + obs), q2 = dsvg_global(ru + obr), q3 = dsvg_global(rv_ + obr);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    cpre[u][0] = cpre[u][1] = cpre[u][2] = cpre[u][3] = 0u;
-                    if (u < npass) {                                       // wave-uniform
-                        unsigned c2 = clos, c3 = clor;
-                        HME_LRO_BARRIER(16, c2);                               // (per block of code: see lane_ro)
-                        HME_LRO_BARRIER(16, c3);
-                        cpre[u][0] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q0 + c2);
-                        cpre[u][1] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q1 + c2);
-                        cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c3);
-                        cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c3);
-                    }
-                    q0 += advs; q1 += advs; q2 += advr; q3 += advr;
-                }
-            }
-            if (cpre_ok) {
+            if (cpre_ok) {                                             // requested at the top of the level-0 section
 #pragma unroll
                 for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -975,32 +927,16 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 // specialised body alone: 64 SGPRs, no spills).  PART 0: every block, generic body (geometries without full blocks).
 // PART 3: every block, either body (the small upper levels of the pyramid: a second launch costs more than it saves).
 template <bool LEVEL0, int NKBF, int PART>
-__global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
+__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
 {
-    __shared__ HmeShared SS[HME_WPG];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    HmeShared &S = SS[wave];
+    __shared__ HmeShared S;
     const int step = 1 << level;
     const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
     const int per = PART == 1 ? fullx * fully : (PART == 2 ? nvx * nvy - fullx * fully : nvx * nvy);      // blocks of a pair in this launch
-    const int nwg = (per * npairs + HME_WPG - 1) / HME_WPG;
-    const int wg = d_xcd_remap(blockIdx.x, nwg);
-    const int item = wg * HME_WPG + wave;
-    if (wg >= nwg || item >= per * npairs) return;
-    // item -> (pair, block).  HME_PG consecutive frame pairs take a block position one after the other (with HME_PG = HME_WPG: the
-    // waves of a workgroup): the current frame of pair p is the reference of pair p + 1, so the block's source rows and the
-    // next pair's reference rows around the same position are the same lines -- fetched from HBM once per group instead of
-    // once per pair
-    int pair, vb, vi, vj;
-    if (HME_PG > 1) {
-        const int gsz = HME_PG * per, q = item / gsz, r = item - q * gsz;
-        const int gl = min(HME_PG, npairs - q * HME_PG);        // pairs in this group (the last one may be short)
-        vb = r / gl;
-        pair = q * HME_PG + (r - vb * gl);
-    } else {
-        pair = item / per;
-        vb = item - pair * per;
-    }
+    const int item = d_xcd_remap(blockIdx.x, per * npairs);
+    if (item >= per * npairs) return;
+    const int pair = item / per;
+    int vb = item - pair * per, vi, vj;
     if (PART == 1) { vj = vb / fullx; vi = vb - vj * fullx; }
     else if (PART == 2) {
         const int nr = (nvx - fullx) * nvy;                 // right strip (all rows), then the bottom strip under the full blocks
@@ -1058,14 +994,14 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         if (level == 0)             // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681)
             px += 2.0 * npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]);
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
-        const dim3 blk(NT * HME_WPG);
+        const dim3 blk(NT);
         // rows per lane of a full block (64 wide, blk_h = 4 * rows): those blocks take the specialised body, in a launch of
         // their own; the partial blocks at the right / bottom edge of the level's frame the generic one
         const int nkbf = (A.blk_w == 64 && (A.blk_h == 64 || A.blk_h == 48 || A.blk_h == 32) && (A.L[level].stride[0] & 3) == 0) ? A.blk_h / 4 : 0;
         const int fw = A.L[level].w[0], fh = A.L[level].h[0];
         const int fullx = nkbf ? std::min(nvx, fw / 64) : 0, fully = nkbf ? std::min(nvy, fh / A.blk_h) : 0;
         const int nfull = fullx * fully, nrest = nvx * nvy - nfull;
-#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid(((cnt) * npairs + HME_WPG - 1) / HME_WPG)), blk, 0, st, A, level, npairs, fullx, fully)
+#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid((cnt) * npairs)), blk, 0, st, A, level, npairs, fullx, fully)
 #define HME_FULL(L0) do { switch (nkbf) { case 16: HME_LAUNCH(L0, 16, 1, nfull); break; case 12: HME_LAUNCH(L0, 12, 1, nfull); break; \
                                           default: HME_LAUNCH(L0, 8, 1, nfull); } } while (0)
         (void)nrest;

@@ -31,31 +31,7 @@
 #define HME_SADDR_SITES 14
 #endif
 #define HME_LRO_BARRIER(site, x) do { if ((HME_SADDR_SITES) & (site)) asm volatile("" : "+v"(x)); } while (0)
-// diagnostic builds (DSVG_CLOCK_PROBE): shader-clock stamps at the stage boundaries of a level-0 block, summed per stage
-#ifdef DSVG_CLOCK_PROBE
-#define HME_MARK(i) do { if (LEVEL0) clk_m_[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
-#else
-#define HME_MARK(i) do { } while (0)
-#endif
-#define NT 64              // threads per block of the picture = ONE wave: 16 column groups x 4 row groups, no cross-wave exchange
-// Waves per workgroup: each wave takes a block of its own, the workgroup HME_WPG horizontally adjacent ones.  The waves never
-// talk to each other -- they share the CU's L1: a 64-pixel block row is half a 128-byte line and a chroma block row a quarter,
-// so neighbours in separate workgroups (separate CUs) each pull the whole line out of L2.
-#ifndef HME_WPG
-#define HME_WPG 4
-#endif
-#ifndef HME_PG
-#define HME_PG HME_WPG          // frame pairs that walk the block grid together (see k_hme_level)
-#endif
-#define HME_TID ((int)(threadIdx.x & 63u))
-// LDS hand-over inside ONE wave (its DS instructions execute in order): nothing for the hardware to wait for, the compiler
-// must not move accesses across
-static __device__ __forceinline__ void hme_sync()
-{
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
+#define NT 64              // threads per workgroup = ONE wave per block: 16 column groups x 4 row groups, no cross-wave exchange
 #define NRG (NT / 16)
 #define NK (64 / NRG)       // rows per thread
 #define NW (NT / 64)        // waves per workgroup
@@ -79,7 +55,7 @@ static __device__ __forceinline__ int load_win(uint8_t *dst, int P, const uint8_
     const uint8_t *g0 = plane + (long)oy * stride + ox;
     const int mis = (int)(((uintptr_t)g0) & 3);
     const int ndw = (mis + nw + 3) >> 2;
-    const int d = HME_TID & (TPR - 1), rb = HME_TID / TPR;
+    const int d = threadIdx.x & (TPR - 1), rb = threadIdx.x / TPR;
     if (d < ndw) {
         // loads are issued in batches of up to 9 before their stores: a memory round trip per batch, not per row
         constexpr int BATCH = 9;
@@ -117,15 +93,12 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 }
 
 struct HmeShared {
-    // half-pel stage: the 19x20 reference patch (or the full-pel 14x14 window), the unrounded horizontal taps of its rows
-    // (int16, pitch 16) and the three half-pel sample planes of the search (bytes, pitch 16): horizontal, vertical, diagonal
+    // the 9-point window is dead once its SADs are reduced; the half-pel patch + lattice reuse its space
+    // until the zero-motion block is staged there for the statistics
     struct {
         struct {
             __attribute__((aligned(16))) uint8_t patch[20 * 24];
-            __attribute__((aligned(16))) short h16[20 * 16];
-            __attribute__((aligned(16))) uint8_t hb[14 * 16 + 16];
-            __attribute__((aligned(16))) uint8_t vb[16 * 16];
-            __attribute__((aligned(16))) uint8_t db[16 * 16 + 16];
+            __attribute__((aligned(16))) uint8_t lat[LAT * LAT];
         } hp;
     } u;
     __attribute__((aligned(16))) uint8_t swin[WIN * 24];
@@ -209,8 +182,8 @@ static __device__ const int HP_Y[8] = {0, 0, 1, -1, -1, -1, 1, 1};
 static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, int mis, unsigned &gh, unsigned &gv, unsigned &s1, unsigned &s2)
 {
     gh = gv = s1 = s2 = 0;
-    const int r = HME_TID >> 2, d = HME_TID & 3;
-    if (HME_TID < 4 * WIN) {
+    const int r = threadIdx.x >> 2, d = threadIdx.x & 3;
+    if (threadIdx.x < 4 * WIN) {
         const unsigned sh = (unsigned)(mis & 3);
         const unsigned *w = reinterpret_cast<const unsigned *>(p + r * P) + (mis >> 2) + d;
         const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
@@ -238,12 +211,8 @@ template <bool LEVEL0, int NKB>
 static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, int pair, int i, int j, HmeShared &S)
 {
     constexpr bool FAST = NKB > 0;
-#ifdef DSVG_CLOCK_PROBE
-    unsigned clk_m_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-#endif
-    HME_MARK(0);
     constexpr int NKR = FAST ? NKB : NK;                // rows a lane may own
-    const int tid = HME_TID;
+    const int tid = threadIdx.x;
     const int cg = tid & 15, rg = tid >> 4;             // column group (4 px) / row group
     const int step = 1 << level;
     const FrameLayout &L = A.L[level];
@@ -294,21 +263,15 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     if (parent) {
         const unsigned pmask = ~(unsigned)((step << 1) - 1);
         const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
-        // all five fetched before any is looked at (a neighbour outside the grid is fetched at the clamped position and counts
-        // as the zero vector): one scalar-memory round trip instead of five in a row -- the vectors were written by the
-        // previous launch, so each fetch goes to L2, and with a branch per neighbour the wave spent a third of its life here
         int par[5];
-        bool pok[5];
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
             const int x = pi + ox * step, y = pj + oy * step;
-            pok[m] = x >= 0 && x < A.nxb && y >= 0 && y < A.nyb;
-            const int idx = min(max(x, 0), A.nxb - 1) + min(max(y, 0), A.nyb - 1) * A.nxb;      // DMV starts with int16 x, y: one dword = x | y << 16
-            par[m] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(parent + idx));
+            par[m] = 0;
+            if (x >= 0 && x < A.nxb && y >= 0 && y < A.nyb)      // DMV starts with int16 x, y: one dword = x | y << 16
+                par[m] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(parent + x + y * A.nxb));
         }
-#pragma unroll
-        for (int m = 0; m < 5; m++) par[m] = pok[m] ? par[m] : 0;
 #pragma unroll
         for (int m = 0; m < 5; m++) {
             const int all = par[m];
@@ -323,18 +286,9 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         }
     }
     int phase = 0;
-    HME_MARK(1);
     // best inherited candidate by SAD, all candidates in one pass, reference pixels straight from HBM/L2
     int pick = n - 1;
-    // level 0, full blocks: sum and sum of squares of the zero-motion reference block (hme.c:181-300), taken from the zero
-    // vector's rows while they are here for its SAD -- the statistics stage then has no rows of its own to fetch
-    unsigned zc1 = 0, zc2 = 0;
-    bool have_z = false;
-#ifdef AB_HME_NO_CAND
-    if (0) {
-#else
     if (n > 1) {
-#endif
         unsigned acc[6];
         unsigned validmask = 0;
         const bool src_ok = !frame_invalid(fw, fh, bx, by, bw, bh);
@@ -358,15 +312,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                         for (int u = 0; u < NKB; u++) { w[u] = dsvg_ld2(q + lro); q += stride; }
                         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                        for (int u = 0; u < NKB; u++) {
-                            const unsigned rw = __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh);
-                            acc[k] = __builtin_amdgcn_sad_u8(srcw[u], rw, acc[k]);
-                            if (LEVEL0 && k == 0) {                // the zero vector's rows are the zero-motion block of the statistics
-                                zc1 = __builtin_amdgcn_sad_u8(rw, 0u, zc1);
-                                zc2 = __builtin_amdgcn_udot4(rw, rw, zc2, false);
-                            }
-                        }
-                        if (LEVEL0 && k == 0) have_z = true;
+                        for (int u = 0; u < NKB; u++) acc[k] = __builtin_amdgcn_sad_u8(srcw[u], __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh), acc[k]);
                         __builtin_amdgcn_sched_barrier(0);
                     } else
                     if (cmask && r0 < bh) {
@@ -411,7 +357,6 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         for (int k = 0; k < 6; k++)
             if (k < n && ((validmask >> k) & 1u) && best_score > (int)acc[k]) { best_score = (int)acc[k]; pick = k; }
     }
-    HME_MARK(2);
     int dx, dy;
     {
         int all = cand[0];
@@ -431,11 +376,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         unsigned acc[9];
 #pragma unroll
         for (int k = 0; k < 9; k++) acc[k] = 0;
-#ifdef AB_HME_NO_NINE
-        if constexpr (false) {
-#else
         if constexpr (FAST) {
-#endif
             const uint8_t *g0 = rp + (long)(by + dy - 1) * stride + (bx + dx - 1);
             const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
             auto q = dsvg_global(g0 - mis);
@@ -448,13 +389,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 struct __attribute__((aligned(4))) U3 { unsigned x, y, z; } d[HB];
 #pragma unroll
                 for (int u = 0; u < HB; u++)
-#if defined(AB_HME_NINE_X2)
-                    if (b0 + u < NR) { const uint2 t2 = dsvg_ld2(q + lro); d[u] = U3{t2.x, t2.y, t2.y}; q += stride; }
-#elif defined(AB_HME_NINE_X1)
-                    if (b0 + u < NR) { const unsigned t1 = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q + lro); d[u] = U3{t1, t1, t1}; q += stride; }
-#else
                     if (b0 + u < NR) { const dsvg_u32x3a4 t3 = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x3a4 *>(q + lro); d[u] = U3{t3.x, t3.y, t3.z}; q += stride; }
-#endif
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < HB; u++) {
@@ -474,11 +409,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 __builtin_amdgcn_sched_barrier(0);
             }
         } else
-#ifdef AB_HME_NO_NINE
-        if (0) {
-#else
         if (cmask && r0 < bh) {
-#endif
             const uint8_t *g0 = rp + (long)(by + dy - 1 + r0) * stride + (bx + dx - 1 + xcol);
             const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
             const unsigned *ga = reinterpret_cast<const unsigned *>(g0 - mis);
@@ -532,7 +463,6 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         for (int k = 0; k < 9; k++)
             if (best > (int)acc[k]) { best = (int)acc[k]; bestk = k; }
     }
-    HME_MARK(3);
     dx += FP_X[bestk];
     dy += FP_Y[bestk];
     int mvx = (int)(int16_t)(dx << level), mvy = (int)(int16_t)(dy << level);
@@ -545,19 +475,46 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         return;
     }
     // ------------------------------------------------------------------ level 0 only
-    // Full blocks: the rows of the zero-motion reference block depend on no decision -- requested now, consumed by the
-    // statistics further down, so their memory round trip runs under the half-pel stage.  (The four chroma blocks of the
-    // variance test were requested here too until round 3: their 16 registers, held across the half-pel stage, were what
-    // put the kernel at 75 VGPRs = 6 waves per SIMD; fetched where they are used it fits 8.)
-    unsigned zpre[NKR];
+    // Full blocks: the rows of the zero-motion reference block and of the four chroma blocks (source / reference, U / V)
+    // depend on no decision -- requested now, consumed by the statistics and the chroma variance test further down, so
+    // their memory round trips run under the half-pel stage instead of at the tail of the wave.
+    unsigned zpre[NKR], cpre[4][4];
+    bool cpre_ok = false;
     if constexpr (FAST) {
         auto zq = dsvg_global(rp + (long)by * stride + bx);
         unsigned lro = lane_ro;
         HME_LRO_BARRIER(8, lro);
 #pragma unroll
-        for (int kk = 0; kk < NKR; kk++) {
-            zpre[kk] = 0u;
-            if (!have_z) { zpre[kk] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }      // (wave-uniform)
+        for (int kk = 0; kk < NKR; kk++) { zpre[kk] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }
+        const FrameLayout &L0 = A.L[0];
+        const int cbw = bw >> L0.hs, cbh = bh >> L0.vs, ndw = cbw >> 2, rpp = ndw ? NT / ndw : NT + 1;
+        const int cbx = i * (BW >> L0.hs), cby = j * (BH >> L0.vs);
+        const uint8_t *su = reinterpret_cast<const uint8_t *>(A.slot_cu[cur]), *sv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[cur]);
+        const uint8_t *ru = reinterpret_cast<const uint8_t *>(A.slot_cu[rf]), *rv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[rf]);
+        const int ss = A.slot_cs[cur], rs = A.slot_cs[rf];          // (source and reference may differ: in place / bordered)
+        cpre_ok = (((unsigned)ss | (unsigned)rs | (unsigned)cbx | (unsigned)(uintptr_t)su | (unsigned)(uintptr_t)sv_ | (unsigned)(uintptr_t)ru | (unsigned)(uintptr_t)rv_ | (unsigned)cbw) & 3u) == 0 &&
+                  ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4;
+        if (cpre_ok) {
+            // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
+            const int sh = 31 - __clz(ndw), npass = cbh / rpp;
+            // (wave-uniform bases + one 32-bit lane offset, as the luma rows)
+            const long obs = (long)cby * ss + cbx, obr = (long)cby * rs + cbx, advs = (long)rpp * ss, advr = (long)rpp * rs;
+            const unsigned clos = (unsigned)((tid >> sh) * ss + 4 * (tid & (ndw - 1))), clor = (unsigned)((tid >> sh) * rs + 4 * (tid & (ndw - 1)));
+            auto q0 = dsvg_global(su + obs), q1 = dsvg_global(sv_ + obs), q2 = dsvg_global(ru + obr), q3 = dsvg_global(rv_ + obr);
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                cpre[u][0] = cpre[u][1] = cpre[u][2] = cpre[u][3] = 0u;
+                if (u < npass) {                                       // wave-uniform
+                    unsigned c2 = clos, c3 = clor;
+                    HME_LRO_BARRIER(16, c2);                               // (per block of code: see lane_ro)
+                    HME_LRO_BARRIER(16, c3);
+                    cpre[u][0] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q0 + c2);
+                    cpre[u][1] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q1 + c2);
+                    cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c3);
+                    cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c3);
+                }
+                q0 += advs; q1 += advs; q2 += advr; q3 += advr;
+            }
         }
     }
     const unsigned yarea = (unsigned)(bw * bh), yareasq = yarea * yarea;
@@ -573,101 +530,33 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     int pmis;
     if (do_hp) pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
     else       pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
-    hme_sync();
-    HME_MARK(4);
+    __syncthreads();
     bool have_hp = false;
-    // lane = (row y, dword d) of a 14x14 window: 4 pixels per lane, the last dword of a row holds two
-    const int wy_ = tid >> 2, wd_ = tid & 3;
-    // 14 rows x 4 dwords of a byte plane in LDS (pitch P, first pixel at byte `mis` of the row) -> rwin (pitch 16)
-    auto copy_win = [&](const uint8_t *pl, int P, int mis) {
-        if (tid < 4 * WIN) {
-            const int b = mis + 4 * wd_;
-            const unsigned *w = reinterpret_cast<const unsigned *>(pl + wy_ * P) + (b >> 2);
-            reinterpret_cast<unsigned *>(S.rwin + wy_ * 16)[wd_] = __builtin_amdgcn_alignbyte(w[1], w[0], (unsigned)(b & 3));
-        }
-    };
     if (do_hp) {
-        static_assert(NT == 64, "the half-pel stage maps its items onto one wave");
-        // The reference builds a 32x32 lattice of the 16x16 patch cells (full-pel F, horizontal H, vertical V, diagonal D
-        // sample of every cell, hpel hme.c:350-376) and reads eight shifted 14x14 windows out of it (hme.c:551-591).  Only
-        // H of cells (0..14, 1..14), V of (1..14, 0..14) and D of (0..14, 0..14) are ever read, and the 4-tap filters are
-        // byte dot products: with patch row R, column c as P[R][c], cell (li, lj) has
-        //   h(li, R) = 9 (P[R][li+1] + P[R][li+2]) - (P[R][li] + P[R][li+3])          (two v_dot4_u32_u8 on a window dword)
-        //   H = sat8((h(li, lj+1) + 8) >> 4),  D = sat8((9 (h(li,lj+1) + h(li,lj+2)) - (h(li,lj) + h(li,lj+3)) + 128) >> 8)
-        //   V = sat8((9 (P[lj+1][li+1] + P[lj+2][li+1]) - (P[lj][li+1] + P[lj+3][li+1]) + 8) >> 4)   (int16 pairs)
-        // stage A: lane = (patch row R, five columns): h -> h16[R][li], H of rows 2..15 -> hb[R-2][li]
-        if (tid < 60) {
-            const int R = tid / 3, g = tid - 3 * R;
-            const int b0 = pmis + 5 * g;
-            const unsigned *w = reinterpret_cast<const unsigned *>(S.u.hp.patch + R * 24) + (b0 >> 2);
-            const unsigned sh = (unsigned)(b0 & 3);
-            const unsigned w0 = w[0], w1 = w[1], w2 = w[2];
-            const unsigned lo = __builtin_amdgcn_alignbyte(w1, w0, sh), hi = __builtin_amdgcn_alignbyte(w2, w1, sh);
-            const unsigned win[5] = {lo, __builtin_amdgcn_alignbyte(hi, lo, 1u), __builtin_amdgcn_alignbyte(hi, lo, 2u), __builtin_amdgcn_alignbyte(hi, lo, 3u), hi};
-            short *hrow = S.u.hp.h16 + R * 16 + 5 * g;
-            const bool hrow_ok = R >= 2 && R < 16;
-#pragma unroll
-            for (int q = 0; q < 5; q++) {
-                const int h = (int)__builtin_amdgcn_udot4(win[q], 0x00090900u, 0u, false) - (int)__builtin_amdgcn_udot4(win[q], 0x01000001u, 0u, false);
-                hrow[q] = (short)h;
-                if (hrow_ok) S.u.hp.hb[(R - 2) * 16 + 5 * g + q] = (uint8_t)d_sat8((h + 8) >> 4);
-            }
+        for (int cell = tid; cell < 256; cell += NT) {   // lattice cells (j,i): F, H, V, D
+            const int lj = cell >> 4, li = cell & 15;
+            const uint8_t *p = S.u.hp.patch + (lj + 1) * 24 + pmis + li + 1;       // -> patch sample (li, lj)
+            const int F = p[0];
+            const int Hh = d_sat8((tap4(p[-1], p[0], p[1], p[2]) + 8) >> 4);
+            const int V = d_sat8((tap4(p[-24], p[0], p[24], p[48]) + 8) >> 4);
+            const int hm = tap4(p[-24 - 1], p[-24], p[-24 + 1], p[-24 + 2]);
+            const int h0 = tap4(p[-1], p[0], p[1], p[2]);
+            const int h1 = tap4(p[24 - 1], p[24], p[24 + 1], p[24 + 2]);
+            const int h2 = tap4(p[48 - 1], p[48], p[48 + 1], p[48 + 2]);
+            const int D = d_sat8((tap4(hm, h0, h1, h2) + 128) >> 8);
+            uint8_t *e = S.u.hp.lat + (2 * lj) * LAT + 2 * li;
+            e[0] = (uint8_t)F; e[1] = (uint8_t)Hh; e[LAT] = (uint8_t)V; e[LAT + 1] = (uint8_t)D;
         }
-        // stage V: lane = (row lj = 0..15, four columns li = 4d+1 .. 4d+4): vertical taps on int16 pairs -> vb[lj][li-1]
-        {
-            typedef short v2s __attribute__((ext_vector_type(2)));
-            const int b0 = pmis + 4 * wd_ + 2;
-            const unsigned sh = (unsigned)(b0 & 3);
-            v2s e[4], o[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const unsigned *w = reinterpret_cast<const unsigned *>(S.u.hp.patch + (wy_ + q) * 24) + (b0 >> 2);
-                const unsigned x = __builtin_amdgcn_alignbyte(w[1], w[0], sh);
-                e[q] = __builtin_bit_cast(v2s, x & 0x00ff00ffu);
-                o[q] = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, x, 0x0c030c01u));
-            }
-            const v2s nine = {9, 9}, eight = {8, 8};
-            const v2s ve = ((e[1] + e[2]) * nine + eight - (e[0] + e[3])) >> 4;
-            const v2s vo = ((o[1] + o[2]) * nine + eight - (o[0] + o[3])) >> 4;
-            unsigned eb, ob;
-            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(eb) : "v"(__builtin_bit_cast(unsigned, ve)));
-            asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ob) : "v"(__builtin_bit_cast(unsigned, vo)));
-            reinterpret_cast<unsigned *>(S.u.hp.vb + wy_ * 16)[wd_] = __builtin_amdgcn_perm(ob, eb, 0x05010400u);      // bytes e0 o0 e1 o1
-        }
-        hme_sync();
-        // stage D: lane = (column li = 0..15, four rows lj = 4g .. 4g+3): seven h values serve four vertical taps
-        {
-            const int c = tid & 15, g4 = tid >> 4;
-            const short *hc = S.u.hp.h16 + (4 * g4) * 16 + c;
-            int hv[7];
-#pragma unroll
-            for (int q = 0; q < 7; q++) hv[q] = hc[q * 16];
-#pragma unroll
-            for (int q = 0; q < 4; q++)
-                S.u.hp.db[(4 * g4 + q) * 16 + c] = (uint8_t)d_sat8((9 * (hv[q + 1] + hv[q + 2]) - (hv[q] + hv[q + 3]) + 128) >> 8);
-        }
-        hme_sync();
-        // the eight candidates (HP_X, HP_Y order): H(x+1,y+1) H(x,y+1) V(x+1,y+1) V(x+1,y) D(x,y) D(x+1,y) D(x,y+1) D(x+1,y+1)
+        __syncthreads();
         unsigned acc[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) acc[k] = 0;
-        if (tid < 4 * WIN) {
-            const int b = smis + 4 * wd_;
-            const unsigned *sw = reinterpret_cast<const unsigned *>(S.swin + wy_ * 24) + (b >> 2);
-            const unsigned m = wd_ == 3 ? 0xffffu : 0xffffffffu;
-            const unsigned sv = __builtin_amdgcn_alignbyte(sw[1], sw[0], (unsigned)(b & 3)) & m;
-            const unsigned *ph = reinterpret_cast<const unsigned *>(S.u.hp.hb + wy_ * 16) + wd_;
-            const unsigned *pv = reinterpret_cast<const unsigned *>(S.u.hp.vb + wy_ * 16) + wd_;
-            const unsigned *pd = reinterpret_cast<const unsigned *>(S.u.hp.db + wy_ * 16) + wd_;
-            const unsigned h0 = ph[0], h1 = ph[1], v0 = pv[0], v1 = pv[4], d0 = pd[0], d1 = pd[1], d2 = pd[4], d3 = pd[5];
-            acc[0] = __builtin_amdgcn_sad_u8(sv, __builtin_amdgcn_alignbyte(h1, h0, 1u) & m, 0u);
-            acc[1] = __builtin_amdgcn_sad_u8(sv, h0 & m, 0u);
-            acc[2] = __builtin_amdgcn_sad_u8(sv, v1 & m, 0u);
-            acc[3] = __builtin_amdgcn_sad_u8(sv, v0 & m, 0u);
-            acc[4] = __builtin_amdgcn_sad_u8(sv, d0 & m, 0u);
-            acc[5] = __builtin_amdgcn_sad_u8(sv, __builtin_amdgcn_alignbyte(d1, d0, 1u) & m, 0u);
-            acc[6] = __builtin_amdgcn_sad_u8(sv, d2 & m, 0u);
-            acc[7] = __builtin_amdgcn_sad_u8(sv, __builtin_amdgcn_alignbyte(d3, d2, 1u) & m, 0u);
+        for (int t = tid; t < WIN * WIN; t += NT) {
+            const int y = t / WIN, x = t - y * WIN;
+            const int s = S.swin[y * 24 + smis + x];
+            const uint8_t *c = S.u.hp.lat + 2 + 2 * LAT + 2 * x + y * 2 * LAT;
+#pragma unroll
+            for (int k = 0; k < 8; k++) acc[k] += (unsigned)abs(s - (int)c[HP_X[k] + HP_Y[k] * LAT]);
         }
         block_sum_n<8>(acc, S.part, phase);
         int best_hp = (int)udiv_rd((unsigned)(best * (WIN * WIN)), ryarea);
@@ -681,10 +570,10 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             best = (int)((unsigned)best_hp * yarea / (WIN * WIN));
             mvx = (int)(int16_t)(mvx + HP_X[hm]);
             mvy = (int)(int16_t)(mvy + HP_Y[hm]);
-            // the winner's window: its plane, first row (0 / 1) and first column (0 / 1)
-            const uint8_t *pl = hm < 2 ? S.u.hp.hb : (hm < 4 ? S.u.hp.vb : S.u.hp.db);
-            const int ro = (hm == 2 || hm >= 6) ? 1 : 0, co = (hm == 0 || hm == 5 || hm == 7) ? 1 : 0;
-            copy_win(pl + ro * 16, 16, co);
+            for (int t = tid; t < WIN * WIN; t += NT) {
+                const int y = t / WIN, x = t - y * WIN;
+                S.rwin[y * 16 + x] = S.u.hp.lat[2 + 2 * LAT + HP_X[hm] + HP_Y[hm] * LAT + 2 * x + y * 2 * LAT];
+            }
             have_hp = true;
         }
     } else {
@@ -693,16 +582,18 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     }
     if (!have_hp) {
         if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
-            hme_sync();
+            __syncthreads();
             pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
-            hme_sync();
+            __syncthreads();
         }
-        copy_win(S.u.hp.patch, 24, pmis);
+        for (int t = tid; t < WIN * WIN; t += NT) {
+            const int y = t / WIN, x = t - y * WIN;
+            S.rwin[y * 16 + x] = S.u.hp.patch[y * 24 + pmis + x];
+        }
     }
     // the zero-motion reference block (variance test, veto, quadrant votes) is read straight from global memory:
     // bx + 4cg is dword aligned, every thread takes the rows it owns
-    hme_sync();                                    // rwin complete
-    HME_MARK(5);
+    __syncthreads();                                    // rwin complete
     unsigned zrow[NKR];
     if constexpr (FAST) {
 #pragma unroll
@@ -730,11 +621,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             // horizontal neighbours: bytes x+1..x+4 of the same row; the 4th comes from the next column group = lane + 1
             // of the same 16-lane row (DPP row_shl:1, zero past the row's end -- masked by pm there anyway)
             const unsigned nxt = (unsigned)__builtin_amdgcn_update_dpp(0, (int)curw, 0x101, 0xf, 0xf, true);
-#ifdef AB_HME_NO_STATS
-            if (0) {
-#else
             if (cmask && ROWOK(kk)) {
-#endif
                 const unsigned right = __builtin_amdgcn_alignbyte(nxt, curw, 1u);
                 // pairs (x,x+1) count only while x+1 < bw
                 const int npair = min(4, bw - 1 - xcol);
@@ -743,15 +630,12 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 if (r > 0) st[1] = __builtin_amdgcn_sad_u8(curw, upw, st[1]);
                 st[2] = __builtin_amdgcn_sad_u8(curw, 0u, st[2]);
                 st[3] = __builtin_amdgcn_udot4(curw, curw, st[3], false);
-                if (!have_z) {
-                    const unsigned zw = zrow[kk] & cmask;
-                    st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
-                    st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
-                }
+                const unsigned zw = zrow[kk] & cmask;
+                st[4] = __builtin_amdgcn_sad_u8(zw, 0u, st[4]);
+                st[5] = __builtin_amdgcn_udot4(zw, zw, st[5], false);
             }
             upw = curw;
         }
-        if (have_z) { st[4] = zc1; st[5] = zc2; }
     }
     // block statistics and the two 14x14 window statistics share one reduction
     unsigned ws[14];
@@ -760,7 +644,6 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 #pragma unroll
     for (int k = 0; k < 6; k++) ws[8 + k] = st[k];
     block_sum_n<14>(ws, S.part, phase);
-    HME_MARK(6);
 #pragma unroll
     for (int k = 0; k < 6; k++) st[k] = ws[8 + k];
     const unsigned luma_tex = udiv_rd((st[0] + st[1]) / 2, ryarea);
@@ -804,37 +687,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                                (unsigned)(uintptr_t)cpl[2] | (unsigned)(uintptr_t)cpl[3]) & 3u) == 0;
         bool done_c = false;
         if constexpr (FAST) {
-            unsigned cpre[4][4];
-            bool cpre_ok = false;
-            const int rpp = ndw ? NT / ndw : NT + 1;
-            const uint8_t *su = reinterpret_cast<const uint8_t *>(A.slot_cu[cur]), *sv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[cur]);
-            const uint8_t *ru = reinterpret_cast<const uint8_t *>(A.slot_cu[rf]), *rv_ = reinterpret_cast<const uint8_t *>(A.slot_cv[rf]);
-            const int ss = A.slot_cs[cur], rs = A.slot_cs[rf];          // (source and reference may differ: in place / bordered)
-            cpre_ok = (((unsigned)ss | (unsigned)rs | (unsigned)cbx | (unsigned)(uintptr_t)su | (unsigned)(uintptr_t)sv_ | (unsigned)(uintptr_t)ru | (unsigned)(uintptr_t)rv_ | (unsigned)cbw) & 3u) == 0 &&
-                      ndw >= 4 && (ndw & (ndw - 1)) == 0 && ndw <= 16 && cbh % rpp == 0 && cbh / rpp <= 4;
-            if (cpre_ok) {
-                // lane = (row, dword) of a pass of 64 / ndw rows; at most four passes
-                const int sh = 31 - __clz(ndw), npass = cbh / rpp;
-                // (wave-uniform bases + one 32-bit lane offset, as the luma rows)
-                const long obs = (long)cby * ss + cbx, obr = (long)cby * rs + cbx, advs = (long)rpp * ss, advr = (long)rpp * rs;
-                const unsigned clos = (unsigned)((tid >> sh) * ss + 4 * (tid & (ndw - 1))), clor = (unsigned)((tid >> sh) * rs + 4 * (tid & (ndw - 1)));
-                auto q0 = dsvg_global(su + obs), q1 = dsvg_global(sv_ + obs), q2 = dsvg_global(ru + obr), q3 = dsvg_global(rv_ + obr);
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    cpre[u][0] = cpre[u][1] = cpre[u][2] = cpre[u][3] = 0u;
-                    if (u < npass) {                                       // wave-uniform
-                        unsigned c2 = clos, c3 = clor;
-                        HME_LRO_BARRIER(16, c2);                               // (per block of code: see lane_ro)
-                        HME_LRO_BARRIER(16, c3);
-                        cpre[u][0] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q0 + c2);
-                        cpre[u][1] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q1 + c2);
-                        cpre[u][2] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q2 + c3);
-                        cpre[u][3] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(q3 + c3);
-                    }
-                    q0 += advs; q1 += advs; q2 += advr; q3 += advr;
-                }
-            }
-            if (cpre_ok) {
+            if (cpre_ok) {                                             // requested at the top of the level-0 section
 #pragma unroll
                 for (int u = 0; u < 4; u++)
 #pragma unroll
@@ -899,7 +752,6 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         if (cvr > 4 * cvs) want_intra = true;
     }
 
-    HME_MARK(7);
     if (want_intra) {
         // representability veto + the four quadrant votes in one pass, one 9-value reduction
         const int mean = (int)udiv_rd(zs1, ryarea);
@@ -959,13 +811,6 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         A.aux_tex[(size_t)pair * A.nblk + i + j * A.nxb] = luma_tex;
         A.aux_var[(size_t)pair * A.nblk + i + j * A.nxb] = src_var;
     }
-#ifdef DSVG_CLOCK_PROBE
-    HME_MARK(8);
-    if (FAST && tid == 0 && (blockIdx.x & 127) == 5) {
-#pragma unroll
-        for (int q = 0; q < 8; q++) { atomicAdd(&dsvg_clk_acc[8 + q][0], (unsigned long long)(clk_m_[q + 1] - clk_m_[q])); atomicAdd(&dsvg_clk_acc[8 + q][1], 1ull); }
-    }
-#endif
 }
 
 // one wave per visited block and frame pair; NKBF = rows per lane of a FULL block of this geometry (0: none is special)
@@ -975,32 +820,16 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 // specialised body alone: 64 SGPRs, no spills).  PART 0: every block, generic body (geometries without full blocks).
 // PART 3: every block, either body (the small upper levels of the pyramid: a second launch costs more than it saves).
 template <bool LEVEL0, int NKBF, int PART>
-__global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
+__global__ __launch_bounds__(NT) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
 {
-    __shared__ HmeShared SS[HME_WPG];
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    HmeShared &S = SS[wave];
+    __shared__ HmeShared S;
     const int step = 1 << level;
     const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
     const int per = PART == 1 ? fullx * fully : (PART == 2 ? nvx * nvy - fullx * fully : nvx * nvy);      // blocks of a pair in this launch
-    const int nwg = (per * npairs + HME_WPG - 1) / HME_WPG;
-    const int wg = d_xcd_remap(blockIdx.x, nwg);
-    const int item = wg * HME_WPG + wave;
-    if (wg >= nwg || item >= per * npairs) return;
-    // item -> (pair, block).  HME_PG consecutive frame pairs take a block position one after the other (with HME_PG = HME_WPG: the
-    // waves of a workgroup): the current frame of pair p is the reference of pair p + 1, so the block's source rows and the
-    // next pair's reference rows around the same position are the same lines -- fetched from HBM once per group instead of
-    // once per pair
-    int pair, vb, vi, vj;
-    if (HME_PG > 1) {
-        const int gsz = HME_PG * per, q = item / gsz, r = item - q * gsz;
-        const int gl = min(HME_PG, npairs - q * HME_PG);        // pairs in this group (the last one may be short)
-        vb = r / gl;
-        pair = q * HME_PG + (r - vb * gl);
-    } else {
-        pair = item / per;
-        vb = item - pair * per;
-    }
+    const int item = d_xcd_remap(blockIdx.x, per * npairs);
+    if (item >= per * npairs) return;
+    const int pair = item / per;
+    int vb = item - pair * per, vi, vj;
     if (PART == 1) { vj = vb / fullx; vi = vb - vj * fullx; }
     else if (PART == 2) {
         const int nr = (nvx - fullx) * nvy;                 // right strip (all rows), then the bottom strip under the full blocks
@@ -1014,10 +843,8 @@ __global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level
     if constexpr (PART == 3) {                              // every block in one launch, each with the body that fits it
         if (fw - bx >= 64 && fh - by >= 4 * NKBF) { hme_block<LEVEL0, NKBF>(A, level, pair, i, j, S); return; }
     }
-    DSVG_CLK_BEGIN();
     if constexpr (PART == 1) hme_block<LEVEL0, NKBF>(A, level, pair, i, j, S);
     else hme_block<LEVEL0, 0>(A, level, pair, i, j, S);
-    DSVG_CLK_END(LEVEL0 ? (PART == 1 ? 0 : 1) : 2);
 }
 
 // second pass of level 0: high_detail from the causal neighbours' final flags (hme.c:621-648)
@@ -1058,14 +885,14 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         if (level == 0)             // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681)
             px += 2.0 * npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]);
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
-        const dim3 blk(NT * HME_WPG);
+        const dim3 blk(NT);
         // rows per lane of a full block (64 wide, blk_h = 4 * rows): those blocks take the specialised body, in a launch of
         // their own; the partial blocks at the right / bottom edge of the level's frame the generic one
         const int nkbf = (A.blk_w == 64 && (A.blk_h == 64 || A.blk_h == 48 || A.blk_h == 32) && (A.L[level].stride[0] & 3) == 0) ? A.blk_h / 4 : 0;
         const int fw = A.L[level].w[0], fh = A.L[level].h[0];
         const int fullx = nkbf ? std::min(nvx, fw / 64) : 0, fully = nkbf ? std::min(nvy, fh / A.blk_h) : 0;
         const int nfull = fullx * fully, nrest = nvx * nvy - nfull;
-#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid(((cnt) * npairs + HME_WPG - 1) / HME_WPG)), blk, 0, st, A, level, npairs, fullx, fully)
+#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid((cnt) * npairs)), blk, 0, st, A, level, npairs, fullx, fully)
 #define HME_FULL(L0) do { switch (nkbf) { case 16: HME_LAUNCH(L0, 16, 1, nfull); break; case 12: HME_LAUNCH(L0, 12, 1, nfull); break; \
                                           default: HME_LAUNCH(L0, 8, 1, nfull); } } while (0)
         (void)nrest;
@@ -1083,9 +910,3 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
     hipLaunchKernelGGL(k_hme_detail, dim3((A.nblk + 255) / 256, npairs), dim3(256), 0, st, A);
     if (pf) pf->end(st);
 }
-
-#ifdef DSVG_CLOCK_PROBE
-DSVG_CLK_DUMP_FN(dsvg_clk_dump_hme, "k_hme_level<true> full", "k_hme_level<true> edge", "k_hme_level<false>", "", "", "", "", "",
-                 "hme0 stage: source+parents", "hme0 stage: candidates", "hme0 stage: nine-point", "hme0 stage: windows in", "hme0 stage: half-pel",
-                 "hme0 stage: statistics", "hme0 stage: intra tests+chroma", "hme0 stage: vote+store")
-#endif
