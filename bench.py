@@ -220,8 +220,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--gops", type=int, default=160, help="closed GOPs per GPU per step (same box, round 2: 96: 131.9, 128: 135.3, 160: 139.0, 192: 142.2 Gpix/s -- "
-                                                          "the per-step latency-bound kernels and host round trips amortise; 160 GOPs keep ~50 GB of HBM and 6 GB of host memory)")
+    ap.add_argument("--gops", type=int, default=320, help="closed GOPs per GPU per step (same box, round 3: 160: 191.5, 256: 194.9, 320: 197.9, 384: 200.4, 416: 189 Gpix/s -- "
+                                                          "the per-step latency-bound kernels and host round trips amortise, beyond 400 the streams stop overlapping; 320 GOPs keep ~100 GB of HBM and 12 GB of host memory)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events (auto = the largest; none = no brackets, no roofline: counter passes)")

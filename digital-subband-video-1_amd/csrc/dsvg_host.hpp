@@ -55,7 +55,7 @@ struct Slab {
 // roofline entry can be held against the committed --kernel-trace --stats summary line by line.
 #define DSVG_KERNEL_IDS(X) \
     X(KID_UNPACK, "k_unpack") X(KID_EXTEND, "k_extend") X(KID_EXTEND16, "k_extend16") X(KID_DS2X, "k_ds2x") X(KID_LUMA_SUM, "k_luma_sum") X(KID_PACK16, "void k_pack_n<true>") X(KID_PACK, "void k_pack_n<false>") \
-    X(KID_HME_LEVEL, "void k_hme_level<false>") X(KID_HME_LEVEL0, "void k_hme_level<true>") X(KID_HME_DETAIL, "k_hme_detail") \
+    X(KID_HME_LEVEL, "void k_hme_level<false>") X(KID_HME_LEVEL0, "void k_hme_level<true>") X(KID_HME_DETAIL, "k_hme_detail") X(KID_HME_CSUM, "k_hme_csum") \
     X(KID_MC, "k_mc") \
     X(KID_FWD_HAAR_PIX, "void k_fwd_haar_pix<false>") X(KID_FWD_HAAR_PIX_Q, "void k_fwd_haar_pix<true>") X(KID_FWD_MC_PIX_Y, "void k_fwd_mc_pix<0>") X(KID_FWD_MC_PIX_C, "void k_fwd_mc_pix<1>") \
     X(KID_FWD_MC_FAST_Y, "void k_fwd_mc_fast<0>") X(KID_FWD_MC_FAST_C, "void k_fwd_mc_fast<1>") \

@@ -25,6 +25,9 @@ struct HmeArgs {
     DMV *mvf;                // [pair][level][nblk]
     unsigned *aux_tex;       // [pair][nblk] block texture (for the high_detail pass)
     int *aux_var;            // [pair][nblk] centre-window variance
+    // [slot][nblk][4]: sum / sum of squares of the U and of the V block of every FULL block of a source slot (k_hme_csum), or nullptr:
+    // level 0's chroma variance test then fetches the blocks itself
+    unsigned *csum;
     int levels, nxb, nyb, nblk, blk_w, blk_h;
 };
 

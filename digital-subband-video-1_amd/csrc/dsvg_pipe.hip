@@ -124,6 +124,7 @@ struct dsvg_ctx {
     // motion estimation
     DMV *mvf = nullptr;
     unsigned *aux_tex = nullptr;
+    unsigned *csum = nullptr;        // [n_src][nblk][4] chroma block sums of every source slot (k_hme_csum)
     int *aux_var = nullptr;
     int *slots_d = nullptr;          // [3 * max_jobs]: cur, ref, recon tables
     unsigned *luma_sums = nullptr;   // [n_src]
@@ -202,7 +203,7 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat, c->llsym};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->csum, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat, c->llsym};
     for (void *p : d) if (p) (void)hipFree(p);
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
@@ -407,6 +408,7 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
     if ((rc = dmalloc(&c->mvf, (size_t)(c->levels + 1) * c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->aux_tex, (size_t)c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->aux_var, (size_t)c->nblk * O, true))) return fail(rc);
+    if ((rc = dmalloc(&c->csum, (size_t)c->nblk * 4 * (size_t)n_src_slots, true))) return fail(rc);
     if ((rc = dmalloc(&c->slots_d, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->luma_sums, (size_t)n_src_slots, true))) return fail(rc);
     if ((rc = hmalloc(&c->jobs_h, std::max(S, O)))) return fail(rc);
@@ -813,6 +815,7 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
     A.slot_cu = c->slot_cu_d; A.slot_cv = c->slot_cv_d; A.slot_cs = c->slot_cs_d;
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
+    A.csum = getenv("DSV1_NO_CHROMA_SUMS") ? nullptr : c->csum;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
     launch_hme(c->st_a, A, npairs, &c->prof);
     HIPCHK(hipMemcpy2DAsync(c->amv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),

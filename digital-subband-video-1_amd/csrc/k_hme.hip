@@ -802,8 +802,18 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         const int cst[4] = {A.slot_cs[cur], A.slot_cs[cur], A.slot_cs[rf], A.slot_cs[rf]};
         const bool aligned = (((unsigned)cst[0] | (unsigned)cst[2] | (unsigned)cbx | (unsigned)(uintptr_t)cpl[0] | (unsigned)(uintptr_t)cpl[1] |
                                (unsigned)(uintptr_t)cpl[2] | (unsigned)(uintptr_t)cpl[3]) & 3u) == 0;
-        bool done_c = false;
+        bool done_c = false, cs_from_table = false;
         if constexpr (FAST) {
+            if (A.csum && ((((unsigned)cst[0] | (unsigned)cst[2] | (unsigned)(uintptr_t)cpl[0] | (unsigned)(uintptr_t)cpl[1] | (unsigned)(uintptr_t)cpl[2] |
+                             (unsigned)(uintptr_t)cpl[3]) & 3u) == 0) && (cbw & 15) == 0 && A.nxb <= 64) {
+                // the sums of this block's chroma blocks in both frames, from k_hme_csum's table (the same conditions as there)
+                const unsigned *ts = A.csum + ((size_t)cur * A.nblk + i + j * A.nxb) * 4, *tr = A.csum + ((size_t)rf * A.nblk + i + j * A.nxb) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) { cs[k] = (unsigned)__builtin_amdgcn_readfirstlane((int)ts[k]); cs[4 + k] = (unsigned)__builtin_amdgcn_readfirstlane((int)tr[k]); }
+                done_c = cs_from_table = true;
+            }
+        }
+        if constexpr (FAST) if (!done_c) {
             unsigned cpre[4][4];
             bool cpre_ok = false;
             const int rpp = ndw ? NT / ndw : NT + 1;
@@ -889,7 +899,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 }
             }
         }
-        block_sum_n<8>(cs, S.part, phase);
+        if (!cs_from_table) block_sum_n<8>(cs, S.part, phase);
         const unsigned carea = (unsigned)(cbw * cbh);
         // full block: the chroma area is the luma area over a power of two -- the reciprocal is an exact scaling of ryarea
         const double rcarea = FAST ? ryarea * (double)(1 << (L0.hs + L0.vs)) : 1.0 / (double)carea;
@@ -1020,6 +1030,48 @@ __global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level
     DSVG_CLK_END(LEVEL0 ? (PART == 1 ? 0 : 1) : 2);
 }
 
+// Sums of the chroma blocks (c_maxvar's inputs, hme.c:269-300), once per source frame.  The variance test reads a frame's blocks twice -- as
+// the current frame of one pair and as the reference frame of the next -- and a wave reads them as 32-byte pieces of 128-byte lines
+// (12 loads, 96 L2 requests per block: 0.9 ms of the level-0 kernel by ablation).  Here a workgroup streams one row of chroma blocks of one
+// frame, whole lines, both planes, and leaves four numbers per block; the motion search fetches eight scalars.
+// Grid: (block row, 2 * pair + role); role 0 = the pair's current frame, role 1 = its reference frame unless the pair before has it as its
+// current frame.  Only full luma blocks (i < fullx, j < fully) and planes / strides / block widths that are multiples of 4.
+__global__ __launch_bounds__(256) void k_hme_csum(HmeArgs A, int fullx, int fully)
+{
+    __shared__ unsigned acc[64 * 4];
+    const int j = blockIdx.x, pr = blockIdx.y, pair = pr >> 1, role = pr & 1;
+    const int slot = role ? A.ref_slots[pair] : A.cur_slots[pair];
+    if (role && pair > 0 && A.cur_slots[pair - 1] == slot) return;
+    const FrameLayout &L0 = A.L[0];
+    const int cbw = A.blk_w >> L0.hs, cbh = A.blk_h >> L0.vs;
+    const int cstr = A.slot_cs[slot];
+    const unsigned long long pu = A.slot_cu[slot], pv = A.slot_cv[slot];
+    if ((((unsigned)cstr | (unsigned)pu | (unsigned)pv) & 3u) || (cbw & 15) || fullx > 64) return;      // (the search then fetches the blocks itself)
+    for (int t = threadIdx.x; t < fullx * 4; t += 256) acc[t] = 0;
+    __syncthreads();
+    // item = (row y, block i): the block's row piece, cbw bytes in 16-byte loads -- neighbouring lanes read neighbouring pieces of the row
+    const size_t row0 = (size_t)j * cbh * cstr;
+    const auto bu = dsvg_global(reinterpret_cast<const uint8_t *>(pu) + row0), bv = dsvg_global(reinterpret_cast<const uint8_t *>(pv) + row0);
+    for (int c = threadIdx.x; c < fullx * cbh; c += 256) {
+        const int y = c / fullx, i = c - y * fullx;
+        const unsigned o = (unsigned)(y * cstr + i * cbw);
+        unsigned s[4] = {0, 0, 0, 0};
+        for (int k = 0; k < cbw; k += 16) {
+            const dsvg_u32x4a4 wu = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(bu + o + k), wv = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(bv + o + k);
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                s[0] = __builtin_amdgcn_sad_u8(wu[q], 0u, s[0]); s[1] = __builtin_amdgcn_udot4(wu[q], wu[q], s[1], false);
+                s[2] = __builtin_amdgcn_sad_u8(wv[q], 0u, s[2]); s[3] = __builtin_amdgcn_udot4(wv[q], wv[q], s[3], false);
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) atomicAdd(&acc[i * 4 + q], s[q]);
+    }
+    __syncthreads();
+    unsigned *out = A.csum + ((size_t)slot * A.nblk + (size_t)j * A.nxb) * 4;
+    for (int t = threadIdx.x; t < fullx * 4; t += 256) out[t] = acc[t];
+}
+
 // second pass of level 0: high_detail from the causal neighbours' final flags (hme.c:621-648)
 __global__ __launch_bounds__(256) void k_hme_detail(HmeArgs A)
 {
@@ -1051,11 +1103,21 @@ __global__ __launch_bounds__(256) void k_hme_detail(HmeArgs A)
 
 void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
 {
+    if (A.csum) {
+        // (full level-0 blocks, as the level loop below defines them)
+        const bool fullb = A.blk_w == 64 && (A.blk_h == 64 || A.blk_h == 48 || A.blk_h == 32) && (A.L[0].stride[0] & 3) == 0;
+        const int fullx = fullb ? std::min(A.nxb, A.L[0].w[0] / 64) : 0, fully = fullb ? std::min(A.nyb, A.L[0].h[0] / A.blk_h) : 0;
+        if (fullx > 0 && fully > 0) {
+            if (pf) pf->begin(st, KID_HME_CSUM, (double)npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]));      // every frame's chroma once
+            hipLaunchKernelGGL(k_hme_csum, dim3(fully, 2 * npairs), dim3(256), 0, st, A, fullx, fully);
+            if (pf) pf->end(st);
+        }
+    }
     for (int level = A.levels; level >= 0; level--) {
         const int step = 1 << level;
         const int nvx = (A.nxb + step - 1) / step, nvy = (A.nyb + step - 1) / step;
         double px = 2.0 * npairs * (double)A.L[level].w[0] * A.L[level].h[0];           // src + ref luma once
-        if (level == 0)             // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681)
+        if (level == 0 && !A.csum)  // level 0 also reads both frames' chroma planes (c_maxvar hme.c:269-300,669-681) unless k_hme_csum has read them
             px += 2.0 * npairs * ((double)A.L[0].w[1] * A.L[0].h[1] + (double)A.L[0].w[2] * A.L[0].h[2]);
         if (pf) pf->begin(st, level > 0 ? KID_HME_LEVEL : KID_HME_LEVEL0, px);
         const dim3 blk(NT * HME_WPG);

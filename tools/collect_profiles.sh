@@ -5,7 +5,7 @@
 #   2. the default bench line; 3. rocprofv3 --kernel-trace --stats of the same command.
 # Everything lands in gpurun_out/$TAG/ ; copy what should be judged into profiles/.
 TAG=${1:-r01}
-GOPS=${2:-160}
+GOPS=${2:-320}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"

@@ -4,7 +4,7 @@
 #   2. one rocprofv3 pass with the SQ busy / active-instruction counters over bench.py --steps 1 -> per-kernel summary
 # Copy what should be judged into profiles/.
 TAG=${1:-r03}
-GOPS=${2:-160}
+GOPS=${2:-320}
 REPO=$PWD
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
