@@ -64,6 +64,13 @@ static __device__ __forceinline__ void hme_sync()
 #define SP 64              // pitch of the source block in LDS (bytes)
 #define RP 72              // pitch of reference windows in LDS (bytes, 18 dwords)
 #define RROWS 67
+// the +-1 search of a full block stages its window in LDS with a few wide loads (lanes = 16-byte pieces of whole rows) instead of
+// fourteen 12-byte loads per lane straight from memory: the kernel pays per vector-memory instruction
+#ifndef HME_NINE_LDS
+#define HME_NINE_LDS 1
+#endif
+#define NINE_P 20          // dwords per staged row: 66 window bytes + up to 3 of misalignment, in five 16-byte pieces
+#define NINE_ROWS 66       // 4 * 16 + 2
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
 
@@ -119,7 +126,9 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 struct HmeShared {
     // half-pel stage: the 19x20 reference patch (or the full-pel 14x14 window), the unrounded horizontal taps of its rows
     // (int16, pitch 16) and the three half-pel sample planes of the search (bytes, pitch 16): horizontal, vertical, diagonal
-    struct {
+    union {
+        // the +-1 search's reference window (full blocks: 4 * NKB + 2 rows of 20 dwords), dead before the half-pel stage begins
+        __attribute__((aligned(16))) unsigned nine[NINE_ROWS * NINE_P];
         struct {
             __attribute__((aligned(16))) uint8_t patch[20 * 24];
             __attribute__((aligned(16))) short h16[20 * 16];
@@ -443,6 +452,44 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             HME_LRO_BARRIER(4, lro);
             constexpr int NR = NKB + 2, HB = (NR + 2) / 3;     // reference rows, rows per batch (three batches: registers)
             unsigned v[3][3];                                  // rolling: v[t % 3][ox] = reference row t, offset ox
+#if HME_NINE_LDS
+            {
+                // stage rows 0 .. 4 NKB + 1 of the window: lane = (row of a pass of twelve, 16-byte piece 0..4)
+                constexpr int WR = 4 * NKB + 2, NP = (WR + 11) / 12;
+                const int prow = (tid * 205) >> 10, pc = tid - 5 * prow;           // tid / 5, tid % 5 (tid < 64)
+                dsvg_u32x4a4 pw[NP];
+                {
+                    auto qs = q + (unsigned)(prow * stride + 16 * pc);
+#pragma unroll
+                    for (int u = 0; u < NP; u++) {
+                        if (tid < 60 && 12 * u + prow < WR) pw[u] = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(qs);
+                        qs += 12 * stride;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NP; u++)
+                    if (tid < 60 && 12 * u + prow < WR) *reinterpret_cast<dsvg_u32x4a4 *>(S.u.nine + (12 * u + prow) * NINE_P + 4 * pc) = pw[u];
+                hme_sync();
+                const unsigned *nl = S.u.nine + r0 * NINE_P + cg;
+#pragma unroll
+                for (int t = 0; t < NR; t++) {
+                    const unsigned dx_ = nl[t * NINE_P], dy_ = nl[t * NINE_P + 1], dz_ = nl[t * NINE_P + 2];
+                    const unsigned lo = __builtin_amdgcn_alignbyte(dy_, dx_, mis);       // window bytes 0..3 of the row
+                    const unsigned hi = __builtin_amdgcn_alignbyte(dz_, dy_, mis);       //              4..7
+                    v[t % 3][0] = lo;
+                    v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u);
+                    v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u);
+                    const int k = t - 2;                           // source row whose three reference rows are now complete
+                    if (k >= 0) {
+#pragma unroll
+                        for (int c9 = 0; c9 < 9; c9++) acc[c9] = __builtin_amdgcn_sad_u8(srcw[k], v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
+                    }
+                }
+                hme_sync();                                        // (the half-pel stage reuses the space)
+            }
+            if (false)
+#endif
 #pragma unroll
             for (int b0 = 0; b0 < NR; b0 += HB) {
                 struct __attribute__((aligned(4))) U3 { unsigned x, y, z; } d[HB];
