@@ -156,6 +156,82 @@ __global__ __launch_bounds__(MC_NT) void k_mc(const JobDev *__restrict__ jobs, M
         }
         return;
     }
+    if (mv.mode != 0) {
+        // Intra blocks that are complete, 16 / 32 / 64 pixels wide and dword aligned (every block of a 1080p or 4K picture but the
+        // partial ones at the edges): no window in LDS.  lane = (row of a pass, dword): the co-located reference rows and the source
+        // rows of ALL passes are requested back to back, the four quadrant sums are v_sad_u8 against zero + DPP row sums, the
+        // prediction of a row piece is its quadrant's mean replicated (or the reference dword itself where the submask keeps the
+        // zero-vector prediction, bmc.c:176-189,254-283) and the residual is formed on int16 pairs.  The staged path below spent
+        // ~1 500 instructions, two barriers and a byte loop per block on the same thing (content with a third of its blocks intra
+        // had k_mc as its largest kernel).
+        const int lqi = bw == 64 ? 4 : (bw == 32 ? 3 : (bw == 16 ? 2 : -1));
+        const int rppi = lqi >= 0 ? MC_NT >> lqi : 1, npass = lqi >= 0 ? bh / rppi : 99;
+        const uint8_t *r0p = rp + (size_t)y * stride + x;
+        const uint8_t *s0p = jb.srcp[c] + (size_t)y * sstride + x;
+        if (lqi >= 0 && cw == bw && ch == bh && bh == npass * rppi && npass <= 16 && !(ch & 1) && (stride & 3) == 0 &&
+            ((unsigned)(uintptr_t)r0p & 3u) == 0 && (!do_sub || ((((unsigned)(uintptr_t)s0p | (unsigned)sstride) & 3u) == 0))) {
+            const int x4i = 4 * (tid & ((1 << lqi) - 1)), yr = tid >> lqi;
+            const int qwi = bw >> 1, qhi = bh >> 1;
+            unsigned rw[16], sw[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                rw[u] = sw[u] = 0u;
+                if (u < npass) {                                // (wave-uniform)
+                    rw[u] = *reinterpret_cast<const unsigned *>(r0p + (size_t)(yr + u * rppi) * stride + x4i);
+                    if (do_sub) sw[u] = *reinterpret_cast<const unsigned *>(s0p + (size_t)(yr + u * rppi) * sstride + x4i);
+                }
+            }
+            unsigned at = 0, ab = 0;                            // this lane's share of its column half: rows above / below the middle
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (u < npass) {
+                    const unsigned sm = __builtin_amdgcn_sad_u8(rw[u], 0u, 0u);
+                    if (yr + u * rppi < qhi) at += sm; else ab += sm;
+                }
+            const bool right = x4i >= qwi;
+            unsigned qs[4] = {right ? 0u : at, right ? at : 0u, right ? 0u : ab, right ? ab : 0u};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                unsigned t = qs[k];
+                t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0xB1, 0xf, 0xf, true);
+                t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x4E, 0xf, 0xf, true);
+                t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x141, 0xf, 0xf, true);
+                t += (unsigned)__builtin_amdgcn_update_dpp(0, (int)t, 0x140, 0xf, 0xf, true);
+                qs[k] = (unsigned)__builtin_amdgcn_readlane((int)t, 0) + (unsigned)__builtin_amdgcn_readlane((int)t, 16) +
+                        (unsigned)__builtin_amdgcn_readlane((int)t, 32) + (unsigned)__builtin_amdgcn_readlane((int)t, 48);
+            }
+            const unsigned mfull = (((qs[0] + qs[1] + qs[2] + qs[3]) / (unsigned)(cw * ch)) & 0xffu) * 0x01010101u;
+            unsigned mq[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) mq[k] = ((qs[k] / (unsigned)(qwi * qhi)) & 0xffu) * 0x01010101u;
+            uint8_t *pp = jb.pred + G.off[c];
+            uint8_t *xp = jb.xf + G.off[c];
+            typedef short v2s __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int u = 0; u < 16; u++)
+                if (u < npass) {
+                    const int yy = yr + u * rppi;
+                    const int q = (right ? 1 : 0) + (yy >= qhi ? 2 : 0);
+                    const unsigned pv = mv.submask == 0xF ? mfull : (((mv.submask >> q) & 1) ? mq[q] : rw[u]);
+                    const size_t o = (size_t)(y + yy) * stride + x + x4i;
+                    *reinterpret_cast<unsigned *>(pp + o) = pv;
+                    if (do_sub) {
+                        // clamp(src - pred + 128) on the even and the odd bytes as int16 pairs (bmc.c:43-55)
+                        const v2s c128 = {128, 128};
+                        const v2s e = __builtin_bit_cast(v2s, sw[u] & 0x00ff00ffu) - __builtin_bit_cast(v2s, pv & 0x00ff00ffu) + c128;
+                        const v2s od = __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, sw[u], 0x0c030c01u)) -
+                                       __builtin_bit_cast(v2s, __builtin_amdgcn_perm(0u, pv, 0x0c030c01u)) + c128;
+                        unsigned eb, ob;
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(eb) : "v"(__builtin_bit_cast(unsigned, e)));
+                        asm("v_sat_pk_u8_i16 %0, %1" : "=v"(ob) : "v"(__builtin_bit_cast(unsigned, od)));
+                        *reinterpret_cast<unsigned *>(xp + o) = __builtin_amdgcn_perm(ob, eb, 0x05010400u);
+                        if (G.cw_extra[c] && x + cw == pw && x4i + 4 >= cw)
+                            xp[(size_t)(y + yy) * stride + pw] = jb.srcp[c][(size_t)(y + yy) * sstride + pw - 1];
+                    }
+                }
+            return;
+        }
+    }
     // stage rows wy-1 .. wy+ch+1, columns wx-1 .. wx+cw+1 with aligned dword loads
     const long rowbase = (long)(wy - 1) * stride + (wx - 1);
     const uint8_t *g0 = rp + rowbase;
