@@ -803,7 +803,12 @@ static __device__ __forceinline__ void fwd_fast_level(const QCtx &q, const QLeve
 // which patches take the lean kernel: sparse P picture, inter block, the whole 8x8 patch inside the picture, no cell shared
 // between scan regions (they sit in the first row / column of patches), and ONE stability flag per level -- the cells of
 // the patch lie in one block of the map except where the fixed-point block steps of hzcc.c:196-197 round across an edge
-struct FwdFastSel { bool ok; QLevel L1, L2, L3; int i1[4], i2[2], i3; };
+// (FWD_FAST_INTRA: the lean kernel also takes the patches of INTRA blocks that meet the other conditions -- their residual is in the work
+// frame already, written by k_mc with the block means as prediction; 0 = they go to the general kernel, over the whole grid, as before)
+#ifndef FWD_FAST_INTRA
+#define FWD_FAST_INTRA 1
+#endif
+struct FwdFastSel { bool ok, intra; QLevel L1, L2, L3; int i1[4], i2[2], i3; };
 static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, const HzPlane &hp, bool any_ov, int mode, int I, int J,
                                                           int x0, int y0, int pw, int ph)
 {
@@ -811,12 +816,12 @@ static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, cons
     // a multiple of the block height makes them drift against the real block grid, so a patch often spans two map rows.
     // One flag per CELL ROW of each level covers that; only a patch that spans two map COLUMNS goes to the general kernel.
     FwdFastSel S;
-    S.ok = false;
+    S.ok = false; S.intra = mode != 0;
     // cells shared between scan regions (hzcc.c:30-48 rounds the region sizes up at every level): column 0 of the LH / HH
     // bands of a level whose width is odd, row 0 of its HL / HH bands when its height is odd -- first column / row of patches
     const bool ovx = any_ov && ((2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_w[1] > hp.s_w[2]));
     const bool ovy = any_ov && ((2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_h[1] > hp.s_h[2]));
-    if (jb.nzf != nullptr && mode == 0 && x0 + 8 <= pw && y0 + 8 <= ph && !(ovx && I == 0) && !(ovy && J == 0)) {
+    if (jb.nzf != nullptr && (FWD_FAST_INTRA || mode == 0) && x0 + 8 <= pw && y0 + 8 <= ph && !(ovx && I == 0) && !(ovy && J == 0)) {
         S.L1 = q_level<2>(hp); S.L2 = q_level<1>(hp); S.L3 = q_level<0>(hp);
         const int nbh = hp.nbh;
         const int b1x = (4 * I * S.L1.dbx) >> 14, b2x = (2 * I * S.L2.dbx) >> 14;
@@ -871,8 +876,14 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
     const auto sp = dsvg_global(jb.srcp[c]);
     const int sstride = jb.srcs[c];
     uint2 sw[8];
+    if (S.intra) {                                      // an intra block's patch: the residual rows, from the work frame (k_mc wrote them and the prediction)
+        const auto px = dsvg_global(static_cast<const uint8_t *>(jb.xf + g.poff));
 #pragma unroll
-    for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)((y0 + r) * sstride + x0));
+        for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(px + (unsigned)((y0 + r) * stride + x0));
+    } else {
+#pragma unroll
+        for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)((y0 + r) * sstride + x0));
+    }
     FwdFastQ fq;
 #pragma unroll
     for (int j = 0; j < 4; j++) fq.sh1[j] = f1[j] ? L1.sh1 : L1.sh0;
@@ -887,9 +898,9 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
     const int xb = bi * bw, yb = bj * bh;
     const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
     const int wy = d_clamp(yb + (dy >> 1), -DSVG_BORDER, ph - bh + DSVG_BORDER - 1) + (y0 - yb);
-    const bool xh = dx & 1, yh = dy & 1;
+    const bool xh = !S.intra && (dx & 1), yh = !S.intra && (dy & 1);
     const auto gr = dsvg_global(static_cast<const uint8_t *>(jb.ref + g.poff)) + ((wy - 1) * stride + (wx - 1));
-    const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;     // over the lanes on this path
+    const bool any_x = __ballot(xh) != 0ull, any_y = __ballot(yh) != 0ull;     // over the lanes on this path that predict
     const auto pp = dsvg_global(jb.pred + g.poff);
 #ifndef FWD_FAST_NO_PK
     // residual rows and level 1 on two samples per instruction; the half-pel paths of the bench's kind (luma: horizontal
@@ -911,6 +922,17 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
         pk_bytes8(P, plo, phi);
         emit_core(r, P, plo, phi);
     };
+    if (S.intra) {
+        // p2sbc of the stored residual: byte - 128 (sbt.c:576) -- the rows the inter path forms from source and prediction
+        const s16x2 c128 = s16x2{128, 128};
+#pragma unroll
+        for (int r = 0; r < 8; r++) {
+            const PkRow X = pk_unpack8(sw[r].x, sw[r].y);
+            PkRow &R = rp[r & 1];
+            R.e0 = X.e0 - c128; R.e1 = X.e1 - c128; R.o0 = X.o0 - c128; R.o1 = X.o1 - c128;
+            if (r & 1) fwd_fast_rows1_pk(q, L1, fq.sh1[r >> 1], 4 * I, 4 * J + (r >> 1), rp[0], rp[1], l1[r >> 1]);
+        }
+    } else
     // (the vertical filter's 17-bit sums stay in 32-bit lanes: its samples arrive as ints and are paired up here -- never
     // through packed bytes: the compiler turns sat8(x >> 8) pairs followed by a byte merge into v_ashr_pk_u8_i32 and takes
     // bits 31:16 of its result for zero, which gfx950 leaves as they were; see the ISA check in the Makefile)
@@ -2933,7 +2955,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         // last row or column of patches (cells shared between scan regions, a ragged picture edge) -- unless a patch can
         // span two columns of the stability map, which depends on the geometry alone.  The general kernel is launched
         // over the whole grid, over the strips that can hold such patches, or not at all.
-        bool whole = general_whole != 0, top = false, bottom = false, left = false, right = false;
+        bool whole = general_whole != 0 && !FWD_FAST_INTRA, top = false, bottom = false, left = false, right = false;
         for (int c = c0; c < c0 + npl; c++) {
             const SbtGeo &gc = G.g[c];
             const int sw0 = DSVG_RSU(gc.W, 3), sw1 = DSVG_RSU(gc.W, 2), sw2 = DSVG_RSU(gc.W, 1);
