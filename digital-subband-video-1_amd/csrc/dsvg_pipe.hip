@@ -809,7 +809,9 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     }
     HIPCHK(hipMemcpyAsync(c->slots_d, c->aslots_h, sizeof(int) * 2 * c->out_slots, hipMemcpyHostToDevice, c->st_a));
     const size_t per = (size_t)(c->levels + 1) * c->nblk;
-    HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st_a));
+    // (every vector a later level, k_hme_detail or the copy below reads is written by the launch of its level -- blocks beyond a
+    // pyramid level's frame write their zero vector themselves: no clearing of the field, 116 MB per 320-GOP step through a slow fill)
+    if (getenv("DSV1_CLEAR_MVF")) HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st_a));
     HmeArgs A; memset(&A, 0, sizeof(A));
     for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;

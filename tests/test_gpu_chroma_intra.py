@@ -94,3 +94,27 @@ def test_table_and_in_kernel_sums_equal_oracle(pkg, orc, monkeypatch, w, h, fmt)
     # the content does what it is for: the chroma test alone turns blocks intra (the same clip with flat chroma everywhere: next to none)
     assert intra_pct(clip, w, h, fmt, **kw) > 10.0
     assert intra_pct(chroma_event_clip(w, h, fmt, 0xC5A0 + w, n, chroma_events=False), w, h, fmt, **kw) < 1.0
+
+
+@pytest.mark.parametrize("w,h,fmt", [(1920, 1080, A.SUBSAMP_420), (1600, 900, A.SUBSAMP_444), (1920, 1080, A.SUBSAMP_422), (1920, 1088, A.SUBSAMP_411),
+                                     (1928, 1084, A.SUBSAMP_420), (3840, 2160, A.SUBSAMP_420)])
+def test_intra_heavy_content_on_64_wide_blocks(pkg, orc, w, h, fmt):
+    """a third of the P blocks intra (clip style 4) at the sizes whose blocks are 64 wide: k_mc's complete intra blocks take the path
+    without the LDS window (quadrant means by v_sad_u8, bmc.c:176-189,254-283), their patches the lean forward kernel; the partial
+    blocks of 1928x1084 keep the staged path, side by side"""
+    n = 4
+    kw = dict(qp=85, gop=12, rc_mode_cli=1, scd=0)
+    clip = A.gen_clip(w, h, fmt, 0x1A7A + w, n, style=4)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw), eos=False)
+    assert intra_pct(clip, w, h, fmt, **kw) > 15.0
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **kw), 2, n)
+    try:
+        got = b.encode(np.stack([clip, clip]))
+    finally:
+        b.close()
+    assert got[0] == want and got[1] == want
+    # ... and the decoder's intra blocks (k_mc without the residual) give the oracle's frames
+    from test_gpu_stream import product_decode
+    frames = product_decode(pkg, want)
+    ref = A.orc_decode(want, w, h, fmt)
+    assert len(frames) == len(ref) == n and all((f == r).all() for f, r in zip(frames, ref))
