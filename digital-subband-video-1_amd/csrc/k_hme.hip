@@ -332,6 +332,18 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         }
     }
     int phase = 0;
+#ifdef AB_HME_DUMMY_SALU        // sensitivity probes (timing only): N extra scalar / vector instructions per block
+    { int ds_ = level;
+#pragma unroll
+      for (int u = 0; u < AB_HME_DUMMY_SALU; u++) asm volatile("s_add_u32 %0, %0, 1" : "+s"(ds_));
+      if (ds_ == 0x7fffffff) return; }
+#endif
+#ifdef AB_HME_DUMMY_VALU
+    { unsigned dv_ = srcw[0];
+#pragma unroll
+      for (int u = 0; u < AB_HME_DUMMY_VALU; u++) asm volatile("v_sad_u8 %0, %0, %1, %0" : "+v"(dv_) : "v"(srcw[1]));
+      if (dv_ == 0x12345u) return; }
+#endif
     HME_MARK(1);
     // best inherited candidate by SAD, all candidates in one pass, reference pixels straight from HBM/L2
     int pick = n - 1;
