@@ -903,6 +903,15 @@ int dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF
     return dsv1_batch_collect(b, out);
 }
 
+/* the same for the first nf frames of a single stream's batch (the tail of a clip) */
+static int batch_encode_n(dsv1_batch *b, const void *yuv, int nf, DSV_BUF *out)
+{
+    int rc;
+    if (b->pending[0] || b->pending[1]) { dsv1_log(1, "batch encode with batches in flight"); return DSVG_ERR_ARG; }
+    if ((rc = batch_submit_impl(b, yuv, 0, out, nf, 1))) return rc;
+    return dsv1_batch_collect(b, out);
+}
+
 int dsv1_batch_eos(dsv1_batch *b, int stream, DSV_BUF *out)
 {
     DSV_BUF tmp;
@@ -998,11 +1007,14 @@ void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
  * dsv_main.c:521-531 loops over whatever count comes back -- and dsv_enc_end_of_stream returns the rest of the backlog in
  * front of the EOS packet, in one buffer: the bytes that reach the file are those of the frame-synchronous encoder.  Changes
  * the caller makes to the encoder's public fields (quality, force_metadata) take effect up to F frames late.  ABR needs every
- * packet's size before the next quantiser and keeps one frame per call (DSV1_ENC_PIPELINE=0 forces that for CRF too).
+ * packet's size before the next quantiser: its pictures are coded one after the other, but 32 frames (DSV1_ENC_LOOKAHEAD) are
+ * gathered and ANALYSED together first, and the group's packets come out of the call that completes it
+ * (DSV1_ENC_PIPELINE=0: one frame per call, CRF and ABR).
  * A device error ends the session: every later dsv_enc returns 0 buffers (and logs), nothing is written out of bounds. */
 typedef struct {
     dsv1_batch *b;
     int pipelined, F, fill, cur, inflight, failed;
+    int gathered;               /* ABR: frames are gathered F at a time (analysis of the whole group at once, coding frame by frame) */
     uint8_t *pin[2];
     void *dev;                  /* device buffer the frames of the batch being gathered are uploaded into, one by one (dsvg_ingest_open / _part) */
     size_t fb;
@@ -1027,7 +1039,7 @@ void dsv_enc_free(DSV_ENCODER *enc)
 {
     if (enc->ref) {
         enc_sess *ss = (enc_sess *)enc->ref;
-        if (ss->pipelined && !ss->failed && (ss->fill > 0 || ss->inflight > 0 || ss->backlog.len > ss->off))
+        if ((ss->pipelined || ss->gathered) && !ss->failed && (ss->fill > 0 || ss->inflight > 0 || ss->backlog.len > ss->off))
             dsv1_log(1, "dsv_enc_free without dsv_enc_end_of_stream: %d buffered frame(s) and %d batch(es) in flight are dropped", ss->fill, ss->inflight);
         sess_free(ss);
         enc->ref = NULL;
@@ -1094,6 +1106,15 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:7
         while (!rc && ss->inflight > 0) rc = sess_collect(ss);
         if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; }
     }
+    if (ss && !ss->pipelined && !ss->failed && ss->fill > 0) {
+        /* ABR: the frames gathered since the last complete group */
+        DSV_BUF acc = {NULL, 0};
+        int rc = batch_encode_n(ss->b, ss->pin[0], ss->fill, &acc);
+        if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
+        dsv_buf_free(&acc);
+        ss->fill = 0;
+        if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; }
+    }
     if (ss) rest = ss->backlog.len - ss->off;
     memset(eos, 0, sizeof(eos));
     bw_init(&w, eos);
@@ -1156,6 +1177,21 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
             ss->F = (int)want;
             chains = enc->gop > 0 ? (ss->F + g - 1) / g + 1 : ss->F;
             if (chains > 64) chains = 64;
+        } else if (enc->rc_mode != DSV_RATE_CONTROL_CRF && !(e && atoi(e) == 0)) {
+            /* ABR (the reference CLI's default): every packet's size feeds the next quantiser, so the pictures are coded one after
+             * the other -- but padding, pyramid, motion search and the GOP / scene-change decisions depend on source pixels only:
+             * frames are gathered 32 at a time (DSV1_ENC_LOOKAHEAD, within 256 MB) and analysed in one go, as dsv1_batch_encode
+             * does for an ABR batch; the packets of a group come out of the call that completes it, byte for byte the
+             * frame-synchronous encoder's (dsv_encoder.c:84-132,728-764) */
+            const DSV_META *m = &enc->vidmeta;
+            const int hs = (m->subsamp >> 2) & 3, vs = m->subsamp & 3;
+            const size_t fbytes = (size_t)m->width * m->height + 2 * (size_t)((m->width + (1 << hs) - 1) >> hs) * (size_t)((m->height + (1 << vs) - 1) >> vs);
+            long want = la ? atol(la) : 32L, cap = (long)(((size_t)256 << 20) / (fbytes ? fbytes : 1));
+            if (want > cap) want = cap;
+            if (want > 256) want = 256;
+            if (want < 1) want = 1;
+            ss->F = (int)want;
+            ss->gathered = ss->F > 1;
         }
         if ((rc = batch_open_on(&ss->b, enc, 0, dsv1_device, 1, ss->F, chains))) {
             dsv1_log(1, "GPU session could not be opened: %s", dsvg_last_error());
@@ -1201,6 +1237,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
     ss->fill++;
     if (!ss->pipelined) {
         DSV_BUF acc = {NULL, 0};
+        if (ss->fill < ss->F) return sess_pop(ss, bufs, 2);     /* (ABR: the group is not complete yet) */
         ss->fill = 0;
         rc = dsv1_batch_encode(ss->b, ss->pin[0], 0, &acc);
         if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;

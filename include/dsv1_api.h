@@ -117,7 +117,9 @@ void dsv_enc_start(DSV_ENCODER *enc);
  * packet per DSV_BUF splits it on the packets' next-link words, or sets DSV1_ENC_PIPELINE=0 for the frame-synchronous
  * behaviour: one picture per call, same bytes).  Changes to the encoder's public fields between calls (quality,
  * dsv_enc_force_metadata) act on the frames not yet submitted, i.e. up to a lookahead late.  dsv_enc_free without
- * dsv_enc_end_of_stream drops the frames still buffered (and logs it).  ABR streams are frame-synchronous. */
+ * dsv_enc_end_of_stream drops the frames still buffered (and logs it).  ABR streams (their pictures are coded one after the
+ * other: every packet's size feeds the next quantiser) gather 32 frames (DSV1_ENC_LOOKAHEAD) for a common analysis pass: the same
+ * contract with a shorter lookahead, the same bytes as the frame-synchronous encoder. */
 int  dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs);
 void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs);
 

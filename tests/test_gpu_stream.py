@@ -189,29 +189,30 @@ def _drive_dsv_enc(pkg, clip, w, h, fmt, **cli):
     (31, dict(qp=85, gop=12, rc_mode_cli=1)),                # two full batches + a tail of 7, a forced-intra style clip
     (40, dict(qp=70, gop=9, rc_mode_cli=1, scd=0)),
     (21, dict(qp=85, gop=0, rc_mode_cli=1)),                 # intra-only CRF: batches of 16
-    (9, dict(qp=60, gop=12, rc_mode_cli=0)),                 # ABR: one frame per call, packets come back at once
+    (9, dict(qp=60, gop=12, rc_mode_cli=0)),                 # ABR: shorter than one analysis group -- everything at end of stream
+    (31, dict(qp=60, gop=12, rc_mode_cli=0, kbps=900)),      # ABR: two groups of 12 + a tail of 7, the rate control working against a tight budget
 ])
 def test_drop_in_dsv_enc_api(pkg, orc, monkeypatch, n, cli):
     """frame-at-a-time dsv_enc_* API (dsv_encoder.h:112-121): CRF streams are pipelined in batches behind it (deferred
-    output, flushed by dsv_enc_end_of_stream), ABR is served frame by frame -- the bytes are the serial encoder's"""
+    output, flushed by dsv_enc_end_of_stream); ABR streams gather a group of frames for a common analysis pass and code them
+    one after the other (every packet's size feeds the next quantiser) -- the bytes are the serial encoder's"""
     monkeypatch.setenv("DSV1_ENC_LOOKAHEAD", "12" if cli["gop"] else "16")     # batches of a GOP, as the comments of the cases say
     w, h, fmt = 352, 288, A.SUBSAMP_420
     clip = A.gen_clip(w, h, fmt, 0xD209 + n, n, style=2)
     want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli))
     out, counts = _drive_dsv_enc(pkg, clip, w, h, fmt, **cli)
     assert out == want, explain(out, want)
-    if cli["rc_mode_cli"] == 0:
-        assert all(c >= 1 for c in counts)
-    else:
-        assert counts[0] == 0 and max(counts) <= 2          # deferred, never more than the reference's two buffers
+    assert counts[0] == 0 and max(counts) <= 2              # deferred, never more than the reference's two buffers
 
 
-def test_drop_in_dsv_enc_unpipelined_switch(pkg, orc, monkeypatch):
+@pytest.mark.parametrize("rc", [1, 0])
+def test_drop_in_dsv_enc_unpipelined_switch(pkg, orc, monkeypatch, rc):
+    """DSV1_ENC_PIPELINE=0: one picture per call, CRF and ABR"""
     monkeypatch.setenv("DSV1_ENC_PIPELINE", "0")
     w, h, fmt, n = 352, 288, A.SUBSAMP_420, 7
     clip = A.gen_clip(w, h, fmt, 0xD209, n, style=2)
-    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1))
-    out, counts = _drive_dsv_enc(pkg, clip, w, h, fmt, qp=85, gop=12, rc_mode_cli=1)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=rc))
+    out, counts = _drive_dsv_enc(pkg, clip, w, h, fmt, qp=85, gop=12, rc_mode_cli=rc)
     assert out == want and all(c >= 1 for c in counts)
 
 
