@@ -794,7 +794,10 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         sc_.b = b; sc_.pics = pics;
         if (serial && !abr_out) return DSVG_ERR_ARG;
         if (serial && b->chains) return DSVG_ERR_ARG;
-        if (serial) dsv1_par_for(S, prefix_stream, &sc_);      /* ABR assembles every picture as soon as it is coded */
+        if (serial) {                                           /* ABR assembles every picture as soon as it is coded */
+            if (S == 1 && nf > 1) dsv1_par_for(nf, prefix_picture, &sc_);   /* (one stream, a gathered group: its pictures are the parallel items) */
+            else dsv1_par_for(S, prefix_stream, &sc_);
+        }
         if (b->chains) {
             if ((rc = code_chains(b, pics, nf, par))) return rc;
         } else
@@ -1109,7 +1112,12 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:7
     if (ss && !ss->pipelined && !ss->failed && ss->fill > 0) {
         /* ABR: the frames gathered since the last complete group */
         DSV_BUF acc = {NULL, 0};
-        int rc = batch_encode_n(ss->b, ss->pin[0], ss->fill, &acc);
+        int rc;
+        if (ss->gathered && ss->dev) {
+            rc = batch_submit_impl(ss->b, ss->dev, 1, &acc, ss->fill, 0);
+            ss->dev = NULL;
+            if (!rc) rc = dsv1_batch_collect(ss->b, &acc);
+        } else rc = batch_encode_n(ss->b, ss->pin[0], ss->fill, &acc);
         if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
         dsv_buf_free(&acc);
         ss->fill = 0;
@@ -1227,7 +1235,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         else copy_part(&cc, 0, 0);
     }
     dsv_frame_ref_dec(frame);                           /* the encoder owns the frame (dsv_encoder.c:38-40) */
-    if (ss->pipelined) {
+    if (ss->pipelined || ss->gathered) {
         /* its upload starts now, under the caller's reading of the next frame -- not in one burst when the batch is full */
         rc = DSVG_OK;
         if (!ss->dev) rc = dsvg_ingest_open(ss->b->ctx, ss->fb * (size_t)ss->F, &ss->dev);
@@ -1239,7 +1247,11 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         DSV_BUF acc = {NULL, 0};
         if (ss->fill < ss->F) return sess_pop(ss, bufs, 2);     /* (ABR: the group is not complete yet) */
         ss->fill = 0;
-        rc = dsv1_batch_encode(ss->b, ss->pin[0], 0, &acc);
+        if (ss->gathered) {                                     /* the group's frames are on the device already (or on their way) */
+            rc = batch_submit_impl(ss->b, ss->dev, 1, &acc, ss->F, 0);
+            ss->dev = NULL;
+            if (!rc) rc = dsv1_batch_collect(ss->b, &acc);
+        } else rc = dsv1_batch_encode(ss->b, ss->pin[0], 0, &acc);
         if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
         dsv_buf_free(&acc);
         if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); ss->failed = 1; return 0; }

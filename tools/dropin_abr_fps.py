@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Frames/s of ONE 1080p 4:2:0 stream with the reference CLI's DEFAULT rate control (ABR, -scd1, GOP 12) through dsv_enc on the GPU
 library, frames in host memory: gathered analysis (default) against one frame per call (DSV1_ENC_PIPELINE=0), both checked against
-the oracle encoder's bytes.   usage: dropin_abr_fps.py [frames=768]"""
+the oracle encoder's bytes.   usage: dropin_abr_fps.py [frames=768] [gathered|serial]"""
 import ctypes as C, importlib, os, sys, time
 ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -45,7 +45,10 @@ def drive(frames, env):
 
 drive(clip[:40], {})
 want, _ = A.orc_encode(clip[:60], A.orc_cfg(W, H, FMT, **cli))
-for name, env in (("gathered analysis (32 frames)", {}), ("one frame per call", {"DSV1_ENC_PIPELINE": "0"})):
+MODES = (("gathered analysis (32 frames)", {}), ("one frame per call", {"DSV1_ENC_PIPELINE": "0"}))
+if len(sys.argv) > 2:                 # "gathered" / "serial": one mode only (e.g. under DSV1_HOST_PROF=1, which reports the last session)
+    MODES = MODES[:1] if sys.argv[2].startswith("g") else MODES[1:]
+for name, env in MODES:
     t_half, _ = drive(clip[:N // 2], env)
     t_all, s_all = drive(clip, env)
     _, s60 = drive(clip[:60], env)
