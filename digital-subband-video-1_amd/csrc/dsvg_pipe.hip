@@ -1213,13 +1213,13 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
     static const bool fprof = getenv("DSV1_HOST_PROF") != nullptr;
     const auto tnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
     const double tf0 = fprof ? tnow() : 0.0;
-    // One picture (the frame-serial callers: ABR, dsv_enc without lookahead): its plane summaries and the first 16 KB of every
-    // plane's payload come back in ONE round trip -- a P picture's planes are a few KB -- instead of sizes, gather table, gather
-    // kernel and payload in two.  A plane that is longer (I pictures) sends the call down the general path below.
-    if (n == 1 && !cb) {
-        constexpr size_t K = 16384;
-        const int o = out_slots[0];
-        if (c->gath_cap < 3 * K + 64) {
+    // A few pictures (the frame-serial callers: ABR streams, dsv_enc without lookahead): their plane summaries and the first 64 KB of
+    // every plane's payload come back in ONE round trip -- a P picture's planes are a few KB -- instead of sizes, gather table,
+    // gather kernel and payload in two.  A plane that is longer (I pictures) sends the call down the general path below.
+    static const bool no_fast_fetch = getenv("DSV1_NO_FETCH_FAST") != nullptr;     // (A/B)
+    if (n <= 4 && !cb && !no_fast_fetch) {
+        constexpr size_t K = 65536;
+        if (c->gath_cap < 4 * 3 * K + 64) {
             if (c->gath_d) (void)hipFree(c->gath_d);
             if (c->gath_h) (void)hipHostFree(c->gath_h);
             c->gath_d = nullptr; c->gath_h = nullptr;
@@ -1227,26 +1227,33 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
             HIPCHK(hipMalloc((void **)&c->gath_d, c->gath_cap));
             HIPCHK(hipHostMalloc((void **)&c->gath_h, c->gath_cap, hipHostMallocDefault));
         }
-        HIPCHK(hipMemcpyAsync(c->psum_h + 3 * (size_t)o, c->psum + 3 * (size_t)o, sizeof(HzPlaneSum) * 3, hipMemcpyDeviceToHost, c->st_c));
-        for (int p = 0; p < 3; p++)
-            HIPCHK(hipMemcpyAsync(c->gath_h + p * K, c->bits + (size_t)o * c->bits_per_job + c->bits_off[p], std::min(K, c->bits_cap[p]), hipMemcpyDeviceToHost, c->st_c));
+        for (int i = 0; i < n; i++) {
+            const int o = out_slots[i];
+            HIPCHK(hipMemcpyAsync(c->psum_h + 3 * (size_t)o, c->psum + 3 * (size_t)o, sizeof(HzPlaneSum) * 3, hipMemcpyDeviceToHost, c->st_c));
+            for (int p = 0; p < 3; p++)
+                HIPCHK(hipMemcpyAsync(c->gath_h + (3 * (size_t)i + p) * K, c->bits + (size_t)o * c->bits_per_job + c->bits_off[p], std::min(K, c->bits_cap[p]),
+                                      hipMemcpyDeviceToHost, c->st_c));
+        }
         HIPCHK(hipStreamSynchronize(c->st_c));
         HIPCHK(hipGetLastError());
         bool fits = true;
-        for (int p = 0; p < 3; p++) {
-            const HzPlaneSum &ps = c->psum_h[3 * (size_t)o + p];
-            if (ps.overflow) { dsvg_set_error("packed plane %d of out slot %d exceeds %zu bytes", p, o, c->bits_cap[p]); return DSVG_ERR_OVERFLOW; }
-            fits = fits && (size_t)((ps.total_bits + 7) >> 3) <= std::min(K, c->bits_cap[p]);
-        }
-        if (fits) {
-            dsvg_pic_out &po = outs[0];
+        for (int i = 0; i < n; i++)
             for (int p = 0; p < 3; p++) {
-                const HzPlaneSum &ps = c->psum_h[3 * (size_t)o + p];
-                po.dc[p] = ps.dc; po.nruns[p] = ps.nruns;
-                po.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
-                po.payload[p] = c->gath_h + p * K;
+                const HzPlaneSum &ps = c->psum_h[3 * (size_t)out_slots[i] + p];
+                if (ps.overflow) { dsvg_set_error("packed plane %d of out slot %d exceeds %zu bytes", p, out_slots[i], c->bits_cap[p]); return DSVG_ERR_OVERFLOW; }
+                fits = fits && (size_t)((ps.total_bits + 7) >> 3) <= std::min(K, c->bits_cap[p]);
             }
-            if (fprof) fprintf(stderr, "[dsvg fetch] one picture, one round trip: %.2f ms\n", tnow() - tf0);
+        if (fits) {
+            for (int i = 0; i < n; i++) {
+                dsvg_pic_out &po = outs[i];
+                for (int p = 0; p < 3; p++) {
+                    const HzPlaneSum &ps = c->psum_h[3 * (size_t)out_slots[i] + p];
+                    po.dc[p] = ps.dc; po.nruns[p] = ps.nruns;
+                    po.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
+                    po.payload[p] = c->gath_h + (3 * (size_t)i + p) * K;
+                }
+            }
+            if (fprof) fprintf(stderr, "[dsvg fetch] %d picture(s), one round trip: %.2f ms\n", n, tnow() - tf0);
             return DSVG_OK;
         }
     }
