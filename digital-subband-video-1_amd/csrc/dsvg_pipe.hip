@@ -1203,11 +1203,17 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
     // wait for the coding calls that produce these slots ON THE HOST (this call blocks for its results anyway) -- later
     // batches already enqueued on the coding streams keep running, and the fetch stream never holds a pending wait: its
     // hardware queue may be shared with a busy stream, which a queued wait would stall for the rest of the batch
-    {
+    static const bool no_fast_fetch = getenv("DSV1_NO_FETCH_FAST") != nullptr;     // (A/B)
+    const bool few = n <= 4 && !cb && !no_fast_fetch;          // the frame-serial callers (see below): nothing else is in flight, the wait
+    {                                                          // can sit in the fetch stream and the host makes ONE round trip
         std::vector<char> seen(c->ev_coded.size(), 0);
         for (int i = 0; i < n; i++) {
             const int e = c->slot_ev[out_slots[i]];
-            if (e >= 0 && !seen[e]) { seen[e] = 1; HIPCHK(hipEventSynchronize(c->ev_coded[e])); }
+            if (e >= 0 && !seen[e]) {
+                seen[e] = 1;
+                if (few) HIPCHK(hipStreamWaitEvent(c->st_c, c->ev_coded[e], 0));
+                else HIPCHK(hipEventSynchronize(c->ev_coded[e]));
+            }
         }
     }
     static const bool fprof = getenv("DSV1_HOST_PROF") != nullptr;
@@ -1216,8 +1222,7 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
     // A few pictures (the frame-serial callers: ABR streams, dsv_enc without lookahead): their plane summaries and the first 64 KB of
     // every plane's payload come back in ONE round trip -- a P picture's planes are a few KB -- instead of sizes, gather table,
     // gather kernel and payload in two.  A plane that is longer (I pictures) sends the call down the general path below.
-    static const bool no_fast_fetch = getenv("DSV1_NO_FETCH_FAST") != nullptr;     // (A/B)
-    if (n <= 4 && !cb && !no_fast_fetch) {
+    if (few) {
         constexpr size_t K = 65536;
         if (c->gath_cap < 4 * 3 * K + 64) {
             if (c->gath_d) (void)hipFree(c->gath_d);
