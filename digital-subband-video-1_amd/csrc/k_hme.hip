@@ -45,7 +45,12 @@
 #define HME_WPG 4
 #endif
 #ifndef HME_PG
-#define HME_PG HME_WPG          // frame pairs that walk the block grid together (see k_hme_level)
+// frame pairs that walk the block grid together (see k_hme_level).  1: the waves of a workgroup take horizontally adjacent blocks of ONE
+// pair (they share half lines of the source and reference rows); HME_WPG: consecutive pairs at one block position (they share frames).
+// Pairs together were ahead while every block fetched the chroma blocks and the zero-motion rows of both frames (4.21 against 4.28 ms);
+// since those come from k_hme_csum's table and the zero vector's rows, neighbours are: 6.43-6.51 against 6.59-6.73 ms per 320-GOP step,
+// the upper levels 1.05-1.07 against 1.14-1.16
+#define HME_PG 1
 #endif
 #define HME_TID ((int)(threadIdx.x & 63u))
 // LDS hand-over inside ONE wave (its DS instructions execute in order): nothing for the hardware to wait for, the compiler

@@ -27,7 +27,7 @@ def f(name):
 
 out = []
 m, gb, va, sa, iw = f("void k_hme_level<true>")
-out.append(f"| `k_hme_level<true>` | {m:.2f} ({m/2:.2f}; 3.27 on the fastest box seen; `r03z` 4.41) | {gb:.1f} GB → {gb/m:.1f} (14.6 GB algorithmic at 2 B/luma-px: consecutive frame pairs share a workgroup) | {va:.2f} (scalar unit {sa:.2f}) | {iw} (1 227) |")
+out.append(f"| `k_hme_level<true>` | {m:.2f} ({m/2:.2f}; 3.27 on the fastest box seen; `r03z` 4.41) | {gb:.1f} GB → {gb/m:.1f} (14.6 GB algorithmic at 2 B/luma-px) | {va:.2f} (scalar unit {sa:.2f}) | {iw} (1 227) |")
 for name, lab in (("void k_inv_p_tile<true>", "`k_inv_p_tile<true>`"), ("void k_fwd_mc_fast<0>", "`k_fwd_mc_fast<0>`"), ("k_unpack", "`k_unpack`"),
                   ("void k_fwd_mc_fast<1>", "`k_fwd_mc_fast<1>`"), ("k_inv_patch_c", "`k_inv_patch_c`"), ("void k_inv_b4t<true>", "`k_inv_b4t<true>`")):
     m, gb, va, sa, iw = f(name)
