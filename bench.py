@@ -95,6 +95,44 @@ def cpu_baseline(clips, pkg, A, reps=1):
                       % (clips.shape[0], GOP, nd, dt)}, streams[:nd]
 
 
+def first_picture_fnum(A, stream):
+    """frame number of the first picture packet of a .dsv byte string (32 bits after the 14-byte packet header, B.2.3)"""
+    for p in A.split_packets(bytes(stream)):
+        if p[5] & 4:
+            return int.from_bytes(p[14:18], "big")
+    raise ValueError("no picture packet")
+
+
+def continuing_gop(A, fresh):
+    """what a closed GOP looks like when it is NOT the first of its stream, derived from a FRESH reference encode of the same
+    GOP at the same frame numbers: the only field that differs is prev_link of the GOP's first picture packet, which links to
+    the last packet of the GOP before (set_link_offsets, dsv_encoder.c:171-192; metadata packets carry 0).  The GOP before
+    holds the same clip at other frame numbers -- a fixed 32-bit field -- so its last packet is as long as this GOP's own."""
+    pk = [bytearray(p) for p in A.split_packets(fresh)]
+    pics = [p for p in pk if p[5] & 4]
+    pics[0][6:10] = len(pics[-1]).to_bytes(4, "big")
+    return b"".join(bytes(p) for p in pk)
+
+
+def joined_gops(A, fresh, ngops, gop, eos=False):
+    """the serial stream of `ngops` closed GOPs that all hold the clip of `fresh` (ONE reference encode, frame numbers 0..gop-1),
+    derived packet by packet: picture k of GOP g carries frame number g*gop + k (32 bits at byte 14) and prev_link = the length
+    of the picture packet before it (0 for the stream's first), metadata packets carry prev_link 0 (dsv_encoder.c:171-192,804-810);
+    eos: + the end-of-stream packet dsv_enc_end_of_stream appends (header only, type 0x10, next_link 0: dsv_encoder.c:766-778)"""
+    out, prev = [], 0
+    for g in range(ngops):
+        for p in A.split_packets(fresh):
+            p = bytearray(p)
+            if p[5] & 4:
+                p[14:18] = (int.from_bytes(p[14:18], "big") + g * gop).to_bytes(4, "big")
+                p[6:10] = prev.to_bytes(4, "big")
+                prev = len(p)
+            out.append(bytes(p))
+    if eos:
+        out.append(b"DSV1" + bytes([0, 0x10]) + prev.to_bytes(4, "big") + (0).to_bytes(4, "big"))
+    return b"".join(out)
+
+
 def intra_block_pct(A, clip, w, h, fmt, **cli):
     """share of intra blocks in the P pictures of `clip`, from the motion fields of the oracle encoder (checker role: it
     describes the content of a shape, nothing timed goes through it)"""
@@ -166,6 +204,68 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
     return res
 
 
+def cfg4_sharded(pkg, A, shard, torch, dist, dev, rank, world, shared, steps, ngops):
+    """BASELINE config 4 as it is written: `ngops` (64) closed 3840x2160 4:2:0 GOPs of 12 frames sharded over the ranks by
+    shard.gop_range (8 per GPU on a full node), no data-path collective.  Every rank codes its GOPs with their frame numbers;
+    a step = all `ngops` GOPs once, timed like the headline (barrier + sync on both sides, MAX over ranks).  The streams of the
+    first pass are gathered on rank 0 (host bytes), joined by dsv1_concat_gops and compared with the serial stream derived from
+    ONE reference encode of the GOP clip (joined_gops).  Collective: every rank calls it."""
+    w, h, fmt, gop = 3840, 2160, 0x5, 12
+    lo, hi = shard.gop_range(ngops, world, rank)
+    n = hi - lo
+    clip = A.gen_clip(w, h, fmt, 0x21600004, gop, style=0)
+    cli = dict(qp=85, gop=gop, rc_mode_cli=1, scd=0)
+    tmax, first = 0.0, []
+    if n > 0:
+        batch_in = np.empty((n, gop, A.frame_bytes(w, h, fmt)), dtype=np.uint8)
+        batch_in[:] = clip
+        b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), n, gop, device=dev)
+    try:
+        if n > 0:
+            d = b.upload(batch_in)
+            for s_ in range(n):
+                b.set_fnum(s_, (lo + s_) * gop)
+            first = [(lo + s_, bytes(o)) for s_, o in enumerate(b.encode(d, on_device=True))]
+            b.submit(d, on_device=True)
+            b.sync()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        if n > 0:
+            for _ in range(steps):
+                b.submit(d, on_device=True)
+                b.collect(copy=False)
+            b.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        tmax = time.perf_counter() - t0
+        if n > 0:
+            b.collect(copy=False)
+    finally:
+        if n > 0:
+            b.close()
+    if world > 1:
+        t = torch.tensor([tmax], dtype=torch.float64, device="cpu" if shared else "cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        tmax = float(t.item())
+    parts = shard.gather_streams(first, dist if world > 1 else None)
+    if rank != 0:
+        return None
+    joined = pkg.concat_gops(parts)
+    fresh, kind = ref_encode(pkg, A, clip, w, h, fmt, **cli)
+    want = joined_gops(A, fresh, ngops, gop, eos=True)          # (dsv1_concat_gops ends the joined stream)
+    return {"config": "3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, %d closed GOPs x 12 frames per step sharded over %d rank(s) by shard.gop_range "
+                      "(%d per GPU), no data-path collective; raw frames resident in HBM" % (ngops, world, -(-ngops // world)),
+            "Mpix_s": round(steps * ngops * gop * w * h / tmax / 1e6, 1), "ms_per_step": round(1e3 * tmax / steps, 3), "steps": steps,
+            "gops": ngops, "gops_per_gpu": -(-ngops // world), "n_gpus": world,
+            "joined_stream_bytes": len(joined), "sha256": hashlib.sha256(joined).hexdigest(), "sha256_expected": hashlib.sha256(want).hexdigest(),
+            "bit_exact_vs_cpu": bool(joined == want),
+            "checked": "the %d gathered GOPs joined by dsv1_concat_gops vs the serial stream derived from one %s encode of the GOP clip "
+                       "(frame numbers and prev_link rewritten per packet, dsv_encoder.c:171-192)" % (ngops, kind)}
+
+
 def decode_bench(pkg, A, dev, streams, reps):
     """batched decoder (dsv1_decbatch_*): `streams` copies of a 1080p GOP=12 stream side by side, one packet of each per
     call, decoded frames left in HBM; every frame of stream 0 compared with the oracle decoder's"""
@@ -226,6 +326,8 @@ def main():
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events (auto = the largest; none = no brackets, no roofline: counter passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive figure and the other shapes (configs 2, 4, 5, batched decode) reported after the headline")
+    ap.add_argument("--cfg4-gops", type=int, default=64, help="closed 4K GOPs of the config-4 leg that runs sharded over the ranks when --gpus > 1 (or with --cfg4-sharded); 0 = skip")
+    ap.add_argument("--cfg4-sharded", action="store_true", help="run the sharded config-4 leg on one GPU too (all its GOPs on this GPU)")
     ap.add_argument("--input", choices=["hbm", "host", "pinned"], default="hbm",
                     help="where the raw frames are when a step starts: hbm (the metric), or host memory (pageable / pinned) "
                          "uploaded over PCIe inside the timed region (diagnostic, DESIGN.md section 7)")
@@ -303,11 +405,16 @@ def main():
     if rank == 0 and prof_kernel != "none":     # "none": no event brackets at all (the counter passes of tools/collect_profiles.sh)
         b.code_streams(1)
         b.prof_enable(names)
+        b.encode(src, on_device=ondev)
+        b.sync()
+        table = {k: b.prof_get(k) for k in names}
+        # ... and one more untimed step that COUNTS what the sparse inverse kernels moved (tiles, flagged patches): the counting
+        # costs atomics, so it has a step of its own and no kernel is timed while it is on
+        b.prof_enable([])
         b.tile_stats()
         b.encode(src, on_device=ondev)
         b.sync()
         tiles = b.tile_stats(enable=False)
-        table = {k: b.prof_get(k) for k in names}
         # the sparse inverse transform moves data only for tiles that carry a residual: price it at what it really moved
         # (general tile: 128x64 samples x 2.5 B = prediction 1 + reconstruction 1 + level-2/3 symbols 0.47 + flags; the level-1
         # symbols are only fetched for flagged patches; every tile: its 20x12 LL3 values and patch flags, 5 B each)
@@ -322,11 +429,23 @@ def main():
         if fy == nty - 1 and H % 8 == 0:
             fy += 1                                 # ... and the last tile row
         ffast = (fx * fy) / float(ntx * nty)
+        # Round 4: + the level-1 symbols of the patches whose flag is up (96 bytes per 8x8 patch, counted by the kernel itself in this
+        # step: `flagged_patches_luma`) -- input the kernel cannot avoid reading, which the figure left out until now while the
+        # counters showed it (round 3: 24.9 GB by counters against 19.5 GB priced).
         for kname, share in (("void k_inv_p_tile<true>", ffast), ("void k_inv_haar_tile<true, 0, true>", 1.0 - ffast)):
             tg, tz = tiles["general_luma"] * share, tiles["zero_luma"] * share
             if kname in table and table[kname][1]:
                 m_, n_, _ = table[kname]
-                table[kname] = (m_, n_, tg * 128.0 * 64.0 * 2.5 + (tg + tz) * 240.0 * 5.0)
+                sym1 = tiles["flagged_patches_luma"] * 96.0 if kname == "void k_inv_p_tile<true>" else 0.0
+                table[kname] = (m_, n_, tg * 128.0 * 64.0 * 2.5 + (tg + tz) * 240.0 * 5.0 + sym1)
+        # the chroma patch kernel likewise at what it moved: LL3 value + flag of every patch (5 B), prediction in / reconstruction out
+        # (128 B) of the patches it rewrote, and the symbols of the three levels (16 + 4 + 1 cells x 3 bands x 2 B = 126 B) of the flagged ones
+        kname = "k_inv_patch_c"
+        if kname in table and table[kname][1]:
+            m_, n_, by_ = table[kname]
+            npatch = by_ / 128.0
+            fl, mv = tiles["flagged_patches_chroma"], tiles["moved_unflagged_patches_chroma"]
+            table[kname] = (m_, n_, npatch * 5.0 + (fl + mv) * 128.0 + fl * 126.0)
         if prof_kernel == "auto":
             prof_kernel = max(table, key=lambda k: table[k][0])
         b.code_streams(nstreams)
@@ -343,6 +462,15 @@ def main():
         outs = b.collect(copy=False)                # the finished packets stay in the buffers they were assembled in
     sync_all()
     dt = time.perf_counter() - t0
+    # the bytes the LAST TIMED step produced (all streams, in stream order), hashed before anything reuses their buffers;
+    # compared further down with bytes derived from the reference encoder's output for the same clips and frame numbers
+    timed_sha = timed_fnum = None
+    if rank == 0:
+        hh = hashlib.sha256()
+        for o in outs:
+            hh.update(o.view())
+        timed_sha = hh.hexdigest()
+        timed_fnum = first_picture_fnum(A, outs[0].view())
     b.collect(copy=False)                           # drain
     kinfo = None
     if rank == 0 and prof_kernel != "none":
@@ -354,6 +482,8 @@ def main():
                  "avg_launch_us": round(1000.0 * ms / max(nl, 1), 2),
                  "alg_bytes_per_launch": round(by / max(nl, 1)),
                  "coding_streams": nstreams,
+                 "regime": "timed region: %d coding streams + the analysis and fetch streams share the chip (a launch covers 1/%d of a frame step's pictures)" % (nstreams, nstreams),
+                 "all_kernels_ms_one_step_regime": "exclusive: one coding stream, the untimed selection step, each kernel alone on the chip",
                  "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]},
                  "sparse_inverse_tiles_one_step": tiles}
         # the other large kernels, each alone on the chip (same untimed step): algorithmic bytes / HIP-event time
@@ -361,13 +491,15 @@ def main():
         for k, (m_, n_, b_) in sorted(table.items(), key=lambda kv: -kv[1][0]):
             if k != prof_kernel and n_ and m_ > 0 and b_ > 0 and len(oth) < 6:
                 a_ = b_ / (m_ * 1e-3) / 1e9
-                oth.append({"kernel": k, "achieved": round(a_, 1), "frac": round(a_ / HBM_PEAK_GBS, 4), "avg_launch_us": round(1000.0 * m_ / n_, 2)})
+                oth.append({"kernel": k, "achieved": round(a_, 1), "frac": round(a_ / HBM_PEAK_GBS, 4), "avg_launch_us": round(1000.0 * m_ / n_, 2),
+                            "ms_one_step": round(m_, 3), "regime": "exclusive (one coding stream, untimed selection step)"})
         kinfo["others_exclusive"] = oth
         if prof_kernel in table and table[prof_kernel][0] > 0:
             xm, xn, xb = table[prof_kernel]         # the same kernel alone on the chip (one coding stream, untimed step)
             xa = xb / (xm * 1e-3) / 1e9
             kinfo["exclusive"] = {"achieved": round(xa, 1), "frac": round(xa / HBM_PEAK_GBS, 4), "launches": xn,
                                   "avg_launch_us": round(1000.0 * xm / max(xn, 1), 2), "alg_bytes_per_launch": round(xb / max(xn, 1)),
+                                  "regime": "exclusive (one coding stream, untimed selection step)",
                                   "note": "one coding stream: the kernel has the chip to itself; `achieved` above is measured in the timed region, where two coding streams overlap"}
 
         # HBM traffic of that kernel: PMC counters cannot be read from inside this process, so the figure comes
@@ -413,7 +545,7 @@ def main():
 
     # ---- after the headline, outside its timed region: the same loop fed from pinned HOST memory ("frames
     # pre-loaded in host RAM"; the upload of each batch over PCIe rides inside the step), never `value`
-    extras = rank == 0 and world == 1 and not args.no_extras and args.input == "hbm"
+    extras = rank == 0 and world == 1 and not args.no_extras and args.input == "hbm" and os.environ.get("DSV1_BENCH_SKIP_SHAPES") != "1"
     host_pinned = None
     if extras:
         ps = 3
@@ -448,6 +580,7 @@ def main():
     # parity spot check + CPU baseline on rank 0 only
     cpu = None
     bit_exact = None
+    timed_check = None
     if rank == 0:
         ncpu = min(args.cpu_gops, nd)
         if ncpu > 0:
@@ -462,6 +595,18 @@ def main():
             # the timed CPU sample is reported at N=1 only; at N>1 one pass still serves as the parity spot check
             cpu, cpu_streams = cpu_baseline(distinct[:ncpu], pkg, A, reps=max(1, args.cpu_gops // ncpu) if world == 1 else 1)
             bit_exact = all(gpu_streams[s] == cpu_streams[s % ncpu] for s in range(nchk))
+            # ... and the output of the last TIMED step itself: every stream of that batch is GOP number timed_fnum / 12 of its
+            # stream, so the expected bytes are the reference's encode of the same clip at those frame numbers, as a GOP
+            # that continues a stream (continuing_gop)
+            want = [continuing_gop(A, ref_encode(pkg, A, distinct[g], W, H, FMT, start_fnum=timed_fnum, qp=QP, gop=GOP, rc_mode_cli=1)[0]) for g in range(nd)]
+            hw = hashlib.sha256()
+            for s in range(args.gops):
+                hw.update(want[s % nd])
+            timed_check = {"sha256": timed_sha, "sha256_expected": hw.hexdigest(), "equal": timed_sha == hw.hexdigest(), "streams": args.gops,
+                           "first_frame_number": timed_fnum,
+                           "expected_from": "the reference encoder (%s) on the %d distinct clips at the timed step's frame numbers; prev_link of each GOP's first "
+                                            "picture packet set to the length of the GOP's last packet (the GOP before holds the same clip)" % (cpu["kind"], nd)}
+            bit_exact = bit_exact and timed_check["equal"]
             if world > 1:
                 cpu = None
         out_bytes = sum(len(o) for o in outs)
@@ -476,7 +621,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "u8/int32",
+            "dtype": "u8/int16+int32 (bit-exact; packed int16 inside a proven range, int32 escape)",
             "data": "synthetic",
             "config": {"workload": "1920x1080 4:2:0 GOP=12 CRF qp85, %d closed GOPs (x12 frames) per GPU per step, %s, output = finished .dsv packets"
                        % (args.gops, {"hbm": "raw frames resident in HBM", "host": "raw frames uploaded from pageable host memory each step (PCIe inclusive, diagnostic)",
@@ -486,6 +631,7 @@ def main():
                        "host_cores_rank0": len(my_cores),
                        "streams_on_own_hw_queue": L.dsvg_ctx_streams_apart(b.ctx)},
             "bit_exact_vs_cpu": bit_exact,
+            "bit_exact_timed_output": timed_check,
             "roofline": kinfo,
             "cpu_baseline": cpu,
         }
@@ -504,6 +650,20 @@ def main():
                                    "note": "counter bytes = (2 x FETCH_SIZE + WRITE_SIZE) of every kernel of a step (profiles/pmc_traffic.json, "
                                            "FETCH_SIZE tallies 128-byte requests at 64 bytes: profiles/r03_fetch_calib.txt); algorithmic = SURVEY 8(d)'s 41.2 B per luma pixel of the "
                                            "unfused reference pipeline -- the fused kernels move less than that"}
+                # the same step against the VALU issue roof: wave64 instructions of every kernel of a step (SQ_INSTS_VALU) / the measured
+                # issue rate of the integer / byte / packed forms these kernels are made of -- the step's other roof, and which one binds
+                vi = st_.get("valu_insts")
+                if vi is None:
+                    vi = sum(e.get("valu_insts_per_launch", 0.0) * e.get("launches", 0) for k, e in T["kernels"].items()
+                             if not k.startswith("__amd") and k != "k_spin") / max(1, st_.get("steps_profiled", 1))
+                if vi:
+                    vi = vi * args.gops / T["gops"]
+                    vms = vi / (VALU_PEAK_GI * 1e9) * 1e3
+                    hms = hb / (6300.0 * 1e9) * 1e3
+                    res["pipeline"]["valu"] = {"wave_instr_per_step": round(vi), "peak": VALU_PEAK_GI, "unit": "G wave-instr/s", "ms_at_peak": round(vms, 3),
+                                               "frac": round(vms / res["ms_per_step"], 4), "source": "sum of SQ_INSTS_VALU over the kernels of a step, profiles/pmc_traffic.json"}
+                    res["pipeline"]["hbm_ms_at_achievable_6300GBs"] = round(hms, 3)
+                    res["pipeline"]["binding_roof"] = "valu" if vms > hms else "hbm"
         if extras:
             # the other shapes of BASELINE.json and the batched decoder, each with its own bit-exact check (measured
             # after the headline; the headline's context is closed first so that every shape has the GPU to itself)
@@ -515,6 +675,8 @@ def main():
                                                   config="1920x1080 4:2:0 -gop0 -qp85 -rc_mode1, 64 streams x 12 frames per step")
                 shapes["cfg4_4k_gop12"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 16, 12, 4, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
                                                config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 16 closed GOPs x 12 frames per step")
+                shapes["cfg4_8gops"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 8, 12, 6, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
+                                            config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 8 closed GOPs x 12 frames per step: one GPU's share of config 4's 64 GOPs on an 8-GPU node")
                 shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 2, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
                                                  config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: serial per frame), 2 streams x 30 frames per step")
                 # the content that leaves the lean kernels: flat moving objects force a third of the blocks intra (whole-grid
@@ -529,8 +691,18 @@ def main():
             except Exception as e:                       # the headline stands on its own
                 shapes["error"] = repr(e)
             res["shapes"] = shapes
-        print(json.dumps(res))
     b.close()
+    # BASELINE config 4 (64 closed 4K GOPs over the node's GPUs): runs sharded over the ranks whenever there is more than one
+    # (every rank takes part; the headline's context is closed first so the leg has each GPU to itself)
+    if (world > 1 or args.cfg4_sharded) and args.cfg4_gops > 0 and not args.no_extras and args.input == "hbm":
+        try:
+            c4 = cfg4_sharded(pkg, A, shard, torch, dist, dev, rank, world, shared, max(2, min(args.steps, 4)), args.cfg4_gops)
+        except Exception as e:                               # the headline stands on its own
+            c4 = {"error": repr(e)}
+        if rank == 0:
+            res["cfg4_sharded"] = c4
+    if rank == 0:
+        print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()
 

@@ -9,7 +9,8 @@ import os as _os
 import numpy as _np
 
 _HERE = _os.path.dirname(_os.path.abspath(__file__))
-SO_PATH = _os.path.join(_HERE, "libdsv1_mi355x.so")
+# DSV1_SO: another build of the same library (A/B variants of tools/ab/variants.sh); never a different implementation
+SO_PATH = _os.environ.get("DSV1_SO") or _os.path.join(_HERE, "libdsv1_mi355x.so")
 _lib = None
 
 SUBSAMP_444, SUBSAMP_422, SUBSAMP_420, SUBSAMP_411 = 0x0, 0x4, 0x5, 0x8
@@ -67,6 +68,7 @@ def lib():
         L.dsvg_ctx_code_streams.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_ctx_streams_apart.argtypes = [_C.c_void_p]
         L.dsvg_ctx_tile_stats.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
+        L.dsvg_ctx_tile_stats2.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
         L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
         L.dsvg_host_alloc.argtypes = [_C.c_void_p, _C.POINTER(_C.c_void_p), _C.c_size_t]
         L.dsvg_host_free.argtypes = [_C.c_void_p, _C.c_void_p]
@@ -253,9 +255,10 @@ class Batch:
         """inverse-transform tiles of P pictures since the previous call: dict general_luma / general_chroma (computed)
         and zero_luma / zero_chroma (found empty: reconstruction = prediction); counting continues only if `enable`.
         Syncs and clears the counters."""
-        v = (_C.c_ulonglong * 4)()
-        _chk(self.L.dsvg_ctx_tile_stats(self.ctx, v, 1 if enable else 0), "dsvg_ctx_tile_stats")
-        return {"general_luma": v[0], "general_chroma": v[1], "zero_luma": v[2], "zero_chroma": v[3]}
+        v = (_C.c_ulonglong * 8)()
+        _chk(self.L.dsvg_ctx_tile_stats2(self.ctx, v, 1 if enable else 0), "dsvg_ctx_tile_stats2")
+        return {"general_luma": v[0], "general_chroma": v[1], "zero_luma": v[2], "zero_chroma": v[3],
+                "flagged_patches_luma": v[4], "flagged_patches_chroma": v[5], "moved_unflagged_patches_chroma": v[6]}
 
     def kernel_names(self):
         return [self.L.dsvg_prof_kernel_name(i).decode() for i in range(self.L.dsvg_prof_kernels())]

@@ -399,7 +399,7 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
         if ((rc = dmalloc(&c->llsym, c->ll_total * J * DT, true))) return fail(rc);
     }
     c->llq = !getenv("DSV1_NO_LLQ");
-    if ((rc = dmalloc(&c->stat, 4 * 64, true))) return fail(rc);
+    if ((rc = dmalloc(&c->stat, 8 * 64, true))) return fail(rc);
     if ((rc = dmalloc(&c->psum, 3 * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->bits, c->bits_per_job * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
@@ -494,21 +494,29 @@ extern "C" int dsvg_ctx_code_streams(dsvg_ctx *c, int n)
     return old;
 }
 extern "C" int dsvg_ctx_streams_apart(const dsvg_ctx *c) { return c ? c->streams_apart : 0; }
-extern "C" int dsvg_ctx_tile_stats(dsvg_ctx *c, unsigned long long out[4], int enable)
+extern "C" int dsvg_ctx_tile_stats2(dsvg_ctx *c, unsigned long long out[8], int enable)
 {
     if (!c || !out) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
     OPCHK(dsvg_ctx_sync(c));
-    unsigned v[4 * 64];
+    unsigned v[8 * 64];
     HIPCHK(hipMemcpyAsync(v, c->stat, sizeof(v), hipMemcpyDeviceToHost, c->st));
     HIPCHK(hipMemsetAsync(c->stat, 0, sizeof(v), c->st));
     HIPCHK(hipStreamSynchronize(c->st));
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < 8; i++) {
         out[i] = 0;
         for (int k = 0; k < 64; k++) out[i] += v[64 * i + k];
     }
     c->stats_on = enable != 0;
     return DSVG_OK;
+}
+extern "C" int dsvg_ctx_tile_stats(dsvg_ctx *c, unsigned long long out[4], int enable)
+{
+    unsigned long long v[8];
+    if (!out) return DSVG_ERR_ARG;
+    const int rc = dsvg_ctx_tile_stats2(c, v, enable);
+    if (rc == DSVG_OK) for (int i = 0; i < 4; i++) out[i] = v[i];
+    return rc;
 }
 extern "C" void *dsvg_ctx_stream(dsvg_ctx *c) { return c ? (void *)c->st : nullptr; }
 

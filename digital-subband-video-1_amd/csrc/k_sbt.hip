@@ -2239,7 +2239,14 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         }
         return;
     }
-    if (tid == 0 && jb.stat) atomicAdd(jb.stat + 64 * (c != 0) + (((blockIdx.x >> 3) + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+    if (jb.stat) {                                      // (wave-uniform; counting is on in bench.py's untimed selection step and in tests only)
+        if (tid == 0) atomicAdd(jb.stat + 64 * (c != 0) + (((blockIdx.x >> 3) + 5 * blockIdx.y + 11 * blockIdx.z) & 63), 1u);
+        // the 8x8 patches of this tile whose level-1 symbols were fetched (96 bytes each): a patch's flag sits in the four items of
+        // its four cell rows -- count it in the first
+        const bool top = ((utid >> 4) & 3u) == 0u;
+        const unsigned nfl = (unsigned)__popcll(__ballot(top && pf1[0] != 0)) + (unsigned)__popcll(__ballot(top && pf1[1] != 0));
+        if ((tid & 63) == 0 && nfl) atomicAdd(jb.stat + 64 * 4 + (((blockIdx.x >> 3) + (tid >> 6)) & 63), nfl);
+    }
 
     // ---- level 3: cells I0-1 .. I0+TX (halo 1) -> LL2 values, scaled up, in A2u
     if (ER && ok3 && I0 - 1 + lx3 >= w3) {
@@ -2253,6 +2260,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         d[1] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> s3hh, HZ_MINQ)));
         d[W2] = 0; d[W2 + 1] = 0;
     } else
+#ifdef AB_INVP_NO_L3                   // timing probes (wrong pictures): a level reduced to copying its LL value
+    if (ok3) {
+        const int LL = A3u[(ly3 + 1) * W3 + lx3 + 1];
+        int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
+        d[0] = d[1] = d[W2] = d[W2 + 1] = LL;
+    } else
+#endif
     if (ok3) {
         const int *pA = A3u + (ly3 + 1) * W3 + lx3 + 1;
         const int LL = pA[0];
@@ -2292,6 +2306,9 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         }
         const int *pA = A2u + (ly + 1) * W2 + lx + 1;
         const int LL = pA[0];
+#ifdef AB_INVP_NO_L2
+        { unsigned *d = A1p + (2 * ly) * WP + lx; d[0] = d[WP] = pk_i16(LL >> 4, LL >> 4); continue; }
+#endif
         int LH = 0, HL = 0, HH = 0;
         if (__ballot((s2lh[u] | s2hl[u] | s2hh[u]) != 0)) {
             const int q = max(Q2.qp >> k2[u], HZ_MINQ);
@@ -2311,6 +2328,12 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     // ---- level 1 + sbc2int + prediction add: an item = four adjacent cells = 8 pixels x 2 rows, as two int16 pairs.
     // An item none of whose lanes has a flagged patch (the usual one in a sparse picture) takes the body without details.
     const short hq1 = (short)jb.hqp[1];
+#ifdef AB_INVP_DUMMY_VALU               // sensitivity probe: N extra packed instructions per thread in a dependent chain
+    { unsigned dv_ = pv[0][0].x;
+#pragma unroll
+      for (int u = 0; u < AB_INVP_DUMMY_VALU; u++) asm volatile("v_pk_add_i16 %0, %0, %1" : "+v"(dv_) : "v"(pv[0][1].x));
+      if (dv_ == 0x12345u) return; }
+#endif
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int it = tid + 256 * u, ly = it >> 4, gx = it & 15;
@@ -2318,6 +2341,14 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         unsigned row0[2], row1[2];
         if (EB && !v1[u]) continue;
         const bool zero1 = __ballot(pf1[u] != 0) == 0ull;
+#if defined(AB_INVP_NO_L1)
+        row0[0] = pv[u][0].x ^ row[0]; row0[1] = pv[u][0].y; row1[0] = pv[u][1].x; row1[1] = pv[u][1].y;
+        if (false)
+#elif defined(AB_INVP_NO_L1F)
+        if (zero1) inv_l1_item<false, true>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
+        else inv_l1_item<false, false>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
+        if (false)
+#endif
         if (zero1) inv_l1_item<FILT, true>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
         else inv_l1_item<FILT, false>(row, WP, d1lh[u], d1hl[u], d1hh[u], shv[u], pv[u], hq1, gx | I0, ly | J0, row0, row1);
         const auto dst = outp + poff[u];
@@ -2684,6 +2715,14 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     const auto outp = dsvg_global((jb.recon ? jb.recon : jb.xf) + g.poff);
     const bool inplace = (const DSVG_GLOBAL uint8_t *)outp == pred;
     const unsigned stride = (unsigned)g.pstride, p0 = (unsigned)(8 * J) * stride + 8u * (unsigned)I;
+    if (jb.stat) {                                      // (counting on: bench.py's untimed selection step, tests) flagged patches / patches moved
+        const int v1_ = d_div4<true>(d_div4<true>(d_ll_up_t<true>(d_div4<true>(d_ll_up_t<true>(ll3)))));
+        const unsigned nfl = (unsigned)__popcll(__ballot(pf != 0)), nmv = (unsigned)__popcll(__ballot(pf == 0 && (d_clamp(v1_, -128, 127) != 0 || !inplace)));
+        if ((threadIdx.x & 63) == 0) {
+            if (nfl) atomicAdd(jb.stat + 64 * 5 + ((blockIdx.x + threadIdx.y) & 63), nfl);
+            if (nmv) atomicAdd(jb.stat + 64 * 6 + ((blockIdx.x + threadIdx.y) & 63), nmv);
+        }
+    }
     if (!pf) {
         const int v3 = d_div4<true>(d_ll_up_t<true>(ll3));
         const int v2 = d_div4<true>(d_ll_up_t<true>(v3));

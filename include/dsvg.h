@@ -127,6 +127,12 @@ void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the first coding hipStream_t (op
  * again with enable = 0 (one atomic per tile).  Syncs the context and clears the counters.  bench.py uses it to price
  * the kernel at the bytes it really moved. */
 int dsvg_ctx_tile_stats(dsvg_ctx *ctx, unsigned long long out[4], int enable);
+/* the same plus what the symbol fetches of the sparse inverse amount to (round 4: bench.py prices the kernels at ALL the bytes they
+ * must move): out[4] = 8x8 luma patches of computed tiles whose flag was up (their 96 bytes of level-1 symbols were fetched by
+ * k_inv_p_tile), out[5] = chroma patches with a flag (k_inv_patch_c fetched their 126 bytes of symbols of the three levels),
+ * out[6] = chroma patches without a flag that were still rewritten (non-zero LL3 residual, or prediction not in place: 64 bytes
+ * in, 64 out), out[7] = 0. */
+int dsvg_ctx_tile_stats2(dsvg_ctx *ctx, unsigned long long out[8], int enable);
 
 /* device memory helpers for callers that keep the raw clip in HBM (bench.py) */
 int dsvg_dev_alloc(dsvg_ctx *ctx, void **dptr, size_t bytes);

@@ -24,7 +24,12 @@ def test_bench_line_has_the_contract_fields():
     assert d["n_gpus"] == 1 and d["steps"] == 1 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
     assert d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic" and "workload" in d["config"]
     assert d["bit_exact_vs_cpu"] is True
+    # the bytes of the last TIMED step, all streams, against reference-derived bytes (round 4)
+    t = d["bit_exact_timed_output"]
+    assert t["equal"] is True and t["sha256"] == t["sha256_expected"] and t["streams"] == 8 and t["first_frame_number"] >= 36
+    assert "int16" in d["dtype"] and "int32" in d["dtype"]
     r = d["roofline"]
+    assert "regime" in r and all("regime" in o for o in r["others_exclusive"])
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] in ("hbm", "mfma", "valu") and r["unit"] == "GB/s" and 0 < r["frac"] < 1 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
@@ -43,10 +48,24 @@ def test_bench_line_carries_the_other_shapes():
     assert d["value_host_pinned"]["value"] > 0 and d["value_host_pinned"]["value"] < d["value"] * 1.5
     sh = d["shapes"]
     assert "error" not in sh, sh
-    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg5_4k_444_abr", "cfg3_worstcase", "decode_1080p_batched"):
+    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg4_8gops", "cfg5_4k_444_abr", "cfg3_worstcase", "decode_1080p_batched"):
         assert sh[k]["Mpix_s"] > 0 and sh[k]["bit_exact_vs_cpu"] is True, (k, sh[k])
     assert sh["cfg3_worstcase"]["intra_blocks_pct_of_P_pictures"] > 25          # the clip really leaves the lean path
     if "pipeline" in d:                                  # (needs profiles/pmc_traffic.json with the per-step sum)
         assert d["pipeline"]["bound"] == "hbm" and 0 < d["pipeline"]["frac"] < 1
+        assert d["pipeline"]["valu"]["wave_instr_per_step"] > 0 and d["pipeline"]["binding_roof"] in ("valu", "hbm")
     c = d["cpu_baseline"]
     assert c["nproc"] >= 1 and isinstance(c["cpu_model"], str)
+
+
+def test_cfg4_sharded_leg_on_one_gpu():
+    """BASELINE config 4's own harness (closed 4K GOPs sharded by shard.gop_range, gathered, joined, compared with the serial
+    stream derived from one reference encode) on the one GPU of the box: 6 GOPs instead of 64"""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--gops", "4", "--cpu-gops", "0",
+                        "--cfg4-sharded", "--cfg4-gops", "6"], capture_output=True, text=True, timeout=900, cwd=ROOT,
+                       env=dict(os.environ, DSV1_BENCH_SKIP_SHAPES="1"))
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([l for l in p.stdout.splitlines() if l.startswith("{")][0])
+    c = d["cfg4_sharded"]
+    assert "error" not in c, c
+    assert c["bit_exact_vs_cpu"] is True and c["sha256"] == c["sha256_expected"] and c["gops"] == 6 and c["Mpix_s"] > 0

@@ -43,7 +43,7 @@ def test_bench_ranks_on_one_gpu(ranks, gops):
     steps = 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(A.ROOT, "bench.py"), "--gpus", str(ranks), "--steps", str(steps), "--warmup", "1",
-           "--gops", str(gops), "--cpu-gops", "2"]
+           "--gops", str(gops), "--cpu-gops", "2", "--cfg4-gops", "16"]
     r = subprocess.run(cmd, cwd=A.ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=1400)
     assert r.returncode == 0, r.stderr[-3000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -53,6 +53,10 @@ def test_bench_ranks_on_one_gpu(ranks, gops):
     assert d["bit_exact_vs_cpu"] is True
     assert d["cpu_baseline"] is None                     # the timed CPU sample belongs to N=1
     assert "shapes" not in d
+    # config 4's leg: 16 closed 4K GOPs sharded over the ranks (gop_range), gathered, joined, equal to the serial stream
+    c4 = d["cfg4_sharded"]
+    assert "error" not in c4, c4
+    assert c4["bit_exact_vs_cpu"] is True and c4["gops"] == 16 and c4["n_gpus"] == ranks and c4["gops_per_gpu"] == 16 // ranks and c4["Mpix_s"] > 0
     pix = gops * 12 * 1920 * 1080
     want = ranks * pix * steps / (d["ms_per_step"] * 1e-3 * steps) / 1e6      # whole job: all ranks' pixels over the MAX time
     assert abs(d["value"] - want) <= 0.01 * want

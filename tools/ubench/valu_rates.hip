@@ -19,14 +19,16 @@
 enum { OP_ADD, OP_SAD_U8, OP_SAD_U16, OP_ALIGNBYTE, OP_PERM, OP_DOT4, OP_MUL_LO, OP_MUL_U24, OP_MAD_U24, OP_PK_ADD_I16, OP_PK_MUL_LO_U16,
        OP_PK_MAX_I16, OP_PK_ASHR_I16, OP_MAX_I32, OP_MED3_I32, OP_BFE, OP_LSHL_ADD, OP_ADD3, OP_CNDMASK, OP_DPP_ADD, OP_READLANE,
        OP_SALU, OP_VALU_SALU, OP_VALU_SALU2, OP_LSHL_ADD_U64, OP_MOV, OP_SAT_PK_U8, OP_CNDMASK_VCCSET, OP_CNDMASK_SGPR, OP_CNDMASK_NODEP,
-       OP_SAD_SALU, OP_CND_E64_VCC, OP_CND_MIX4, OP_ADDC, OP_CMP_VCC, OP_CMP_SGPR, OP_CND_VCC_S_MOV, OP_CND_MIX_CMP, OP_SUB, OP_AND, OP_LSHLREV, OP_ASHRREV, OP_BFI, OP_AND_OR, OP_MIN_U32, OP_PK_SUB_I16, OP_PK_LSHL, OP_PK_MAD_I16, OP_MAD_I32_I24, OP_XOR, OP_N };
+       OP_SAD_SALU, OP_CND_E64_VCC, OP_CND_MIX4, OP_ADDC, OP_CMP_VCC, OP_CMP_SGPR, OP_CND_VCC_S_MOV, OP_CND_MIX_CMP, OP_SUB, OP_AND, OP_LSHLREV, OP_ASHRREV, OP_BFI, OP_AND_OR, OP_MIN_U32, OP_PK_SUB_I16, OP_PK_LSHL, OP_PK_MAD_I16, OP_MAD_I32_I24, OP_XOR, OP_QSAD, OP_MQSAD, OP_MSAD_U8, OP_SAD_HI_U8, OP_OR, OP_LSHRREV, OP_PK_MIN_I16, OP_MED3_I16, OP_ADD_U16, OP_LERP_U8, OP_PK_ADD_U16_CLAMP, OP_QSAD_INDEP, OP_N };
 static const char *names[OP_N] = { "v_add_u32", "v_sad_u8", "v_sad_u16", "v_alignbyte_b32", "v_perm_b32", "v_dot4_u32_u8", "v_mul_lo_u32",
        "v_mul_u32_u24", "v_mad_u32_u24", "v_pk_add_i16", "v_pk_mul_lo_u16", "v_pk_max_i16", "v_pk_ashrrev_i16", "v_max_i32", "v_med3_i32",
        "v_bfe_u32", "v_lshl_add_u32", "v_add3_u32", "v_cndmask_b32", "v_add_u32 dpp row_shr:1", "v_readlane_b32 (+s use)",
        "s_add_u32 alone", "v_add_u32 + s_add_u32 1:1", "v_add_u32 + 2 s_add_u32", "v_lshl_add_u64", "v_mov_b32", "v_sat_pk_u8_i16", "v_cndmask_b32 (vcc from v_cmp)", "v_cndmask_b32_e64 (sgpr pair)",
        "v_cndmask_b32 (no dependence)", "v_sad_u8 + s_add_u32 1:1", "v_cndmask_b32_e64 (vcc)", "1 v_cndmask e32 vcc + 3 v_add_u32", "v_addc_co_u32 (vcc in/out)",
        "v_cmp_gt_u32 -> vcc", "v_cmp_gt_u32_e64 -> sgpr pair", "v_cndmask_b32 e32 (vcc = s_mov -1)", "v_cmp -> vcc + v_cndmask e32 vcc", "v_sub_u32", "v_and_b32", "v_lshlrev_b32",
-       "v_ashrrev_i32", "v_bfi_b32", "v_and_or_b32", "v_min_u32", "v_pk_sub_i16", "v_pk_lshlrev_b16", "v_pk_mad_i16", "v_mad_i32_i24", "v_xor_b32" };
+       "v_ashrrev_i32", "v_bfi_b32", "v_and_or_b32", "v_min_u32", "v_pk_sub_i16", "v_pk_lshlrev_b16", "v_pk_mad_i16", "v_mad_i32_i24", "v_xor_b32",
+       "v_qsad_pk_u16_u8 (acc chain)", "v_mqsad_pk_u16_u8 (acc chain)", "v_msad_u8", "v_sad_hi_u8", "v_or_b32", "v_lshrrev_b32", "v_pk_min_i16", "v_med3_i16", "v_add_u16",
+       "v_lerp_u8", "v_pk_add_u16 clamp", "v_qsad_pk_u16_u8 (acc = 0)" };
 
 #define A1(s) asm volatile(s : "+v"(a[i]) : "v"(b), "v"(c))
 template <int OP>
@@ -42,6 +44,7 @@ __global__ __launch_bounds__(1024) void k(unsigned *out, unsigned long long *cyc
     if (seed == 0x7fffffffu) lds[threadIdx.x] = b;              // keeps the allocation
     __syncthreads();
     unsigned long long m64 = 0x5555555555555555ull * seed;
+    const unsigned long long m64v = 0x0102030405060708ull * (seed + threadIdx.x);
     if (OP == OP_CNDMASK_VCCSET) asm volatile("v_cmp_gt_u32 vcc, %0, %1" : : "v"(b), "v"(c) : "vcc");
     if (OP == OP_CND_VCC_S_MOV) asm volatile("s_mov_b64 vcc, -1" : : : "vcc");
     const unsigned long long t0 = __builtin_readcyclecounter();
@@ -97,6 +100,18 @@ __global__ __launch_bounds__(1024) void k(unsigned *out, unsigned long long *cyc
             if (OP == OP_PK_LSHL) A1("v_pk_lshlrev_b16 %0, 1, %0");
             if (OP == OP_PK_MAD_I16) A1("v_pk_mad_i16 %0, %0, %1, %2");
             if (OP == OP_MAD_I32_I24) A1("v_mad_i32_i24 %0, %0, %1, %2");
+            if (OP == OP_QSAD) asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(w[i]) : "v"(m64v), "v"(b));
+            if (OP == OP_MQSAD) asm volatile("v_mqsad_pk_u16_u8 %0, %1, %2, %0" : "+v"(w[i]) : "v"(m64v), "v"(b));
+            if (OP == OP_QSAD_INDEP) asm volatile("v_qsad_pk_u16_u8 %0, %1, %2, 0" : "=&v"(w[i]) : "v"(m64v), "v"(b));
+            if (OP == OP_MSAD_U8) A1("v_msad_u8 %0, %0, %1, %2");
+            if (OP == OP_SAD_HI_U8) A1("v_sad_hi_u8 %0, %0, %1, %2");
+            if (OP == OP_OR) A1("v_or_b32 %0, %0, %1");
+            if (OP == OP_LSHRREV) A1("v_lshrrev_b32 %0, 1, %0");
+            if (OP == OP_PK_MIN_I16) A1("v_pk_min_i16 %0, %0, %1");
+            if (OP == OP_MED3_I16) A1("v_med3_i16 %0, %0, %1, %2");
+            if (OP == OP_ADD_U16) A1("v_add_u16 %0, %0, %1");
+            if (OP == OP_LERP_U8) A1("v_lerp_u8 %0, %0, %1, %2");
+            if (OP == OP_PK_ADD_U16_CLAMP) A1("v_pk_add_u16 %0, %0, %1 clamp");
             if (OP == OP_LSHL_ADD_U64) asm volatile("v_lshl_add_u64 %0, %0, 1, %0" : "+v"(w[i]));
         }
     }
@@ -157,7 +172,7 @@ template <int OP> void sweep(unsigned *d, unsigned long long *dc, unsigned *dh, 
 template <int OP> struct All { static void go(unsigned *d, unsigned long long *dc, unsigned *dh, int ncu, double mhz) { sweep<OP>(d, dc, dh, ncu, mhz); All<OP + 1>::go(d, dc, dh, ncu, mhz); } };
 template <> struct All<OP_N> { static void go(unsigned *, unsigned long long *, unsigned *, int, double) {} };
 
-int main()
+int main(int argc, char **argv)
 {
     hipDeviceProp_t p; (void)hipGetDeviceProperties(&p, 0);
     const int ncu = p.multiProcessorCount; const double mhz = p.clockRate / 1000.0;
@@ -166,6 +181,7 @@ int main()
     printf("# peak if 4 cycles: %.1f G wave-instr/s ; if 2 cycles: %.1f\n", ncu * 4 * mhz / 4e3, ncu * 4 * mhz / 2e3);
     unsigned *d; unsigned long long *dc; unsigned *dh;
     (void)hipMalloc(&d, (size_t)ncu * 2 * 1024 * 4); (void)hipMalloc(&dc, (size_t)ncu * 32 * 8); (void)hipMalloc(&dh, (size_t)ncu * 32 * 4);
-    All<0>::go(d, dc, dh, ncu, mhz);
+    if (argc > 1 && !strcmp(argv[1], "new")) All<OP_QSAD>::go(d, dc, dh, ncu, mhz);      // the forms added in round 4 only
+    else All<0>::go(d, dc, dh, ncu, mhz);
     return 0;
 }
