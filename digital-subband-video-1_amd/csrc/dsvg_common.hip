@@ -34,22 +34,10 @@ extern "C" int dsvg_set_device(int device)
 }
 int dsvg_op_device() { return g_op_device; }
 
-int lb2u(unsigned n)                                   // dsv_lb2 hzcc.c:437-447
-{
-    unsigned i = 1;
-    int l = 0;
-    while (i < n) { i <<= 1; l++; }
-    return l;
-}
+int lb2u(unsigned n) { return dsvg_lb2u(n); }            // dsv_lb2 hzcc.c:437-447 (dsvg_dev.hpp: shared with the device)
 extern "C" int dsvg_lb2(unsigned n) { return lb2u(n); }
 
-int get_quant(int q, int isP, int level)               // dsv_get_quant hzcc.c:77-92
-{
-    if (isP) q = q * 3 / 2;
-    if (level == 1) q = q * 2 / 3;
-    else if (level == 2) q = q * 3 / 2;
-    return q < 16 ? 16 : q;
-}
+int get_quant(int q, int isP, int level) { return dsvg_level_quant(q, isP, level); }   // dsv_get_quant hzcc.c:77-92
 extern "C" int dsvg_get_quant(int q, int isP, int level) { return get_quant(q, isP, level); }
 
 void make_frame_layout(FrameLayout &L, int fmt, int w, int h)
@@ -134,27 +122,20 @@ void make_sbt_geo(SbtGeo &g, int W, int H, int pw, int ph, int pstride, size_t p
 void make_hz_plane(HzPlane &hp, int w, int h, int q, int isP, int cur_plane, int nbh, int nbv)
 {
     memset(&hp, 0, sizeof(hp));
-    if (cur_plane > 0 && q > 512) q = 512;                     // fix_quant hzcc.c:50-57
     int n = 0, base = 0;
     HzRegion *r = hp.r;
     r[n].x0 = 0; r[n].y0 = 0; r[n].sw = rsu(w, 3); r[n].sh = rsu(h, 3);
-    r[n].level = -1; r[n].qp = get_quant(q, isP, 0); r[n].base = 0;
+    r[n].level = -1; r[n].base = 0;
     base += r[n].sw * r[n].sh;
     n++;
     for (int l = 0; l < 3; l++) {
         const int sw = rsu(w, 3 - l), sh = rsu(h, 3 - l);
-        int qp = get_quant(q, isP, l), qp_h = 0;
-        if (l == 2) {
-            qp = lb2u((unsigned)qp);
-            qp_h = qp - (isP ? 1 : 3);                         // DSV_QP_P / DSV_QP_I
-            qp_h = qp_h < 1 ? 1 : (qp_h > 24 ? 24 : qp_h);
-        }
         hp.s_w[l] = sw; hp.s_h[l] = sh;
         for (int s = 1; s < 4; s++, n++) {
             r[n].x0 = (s & 1) ? sw : 0;
             r[n].y0 = (s & 2) ? sh : 0;
             r[n].sw = sw; r[n].sh = sh;
-            r[n].level = l; r[n].qp = qp; r[n].qp_h = qp_h;
+            r[n].level = l;
             r[n].dbx = (nbh << 14) / sw;
             r[n].dby = (nbv << 14) / sh;
             r[n].base = base;
@@ -164,27 +145,10 @@ void make_hz_plane(HzPlane &hp, int w, int h, int q, int isP, int cur_plane, int
     hp.nscan = base;
     hp.nchunks = (base + HZ_CHUNK - 1) / HZ_CHUNK;
     hp.w = w; hp.h = h; hp.nbh = nbh;
+    dsvg_plane_set_quant(hp, q, isP, cur_plane);               // the region quantisers (shared with the device: dsvg_dev.hpp)
 }
 
-void make_hqp(int hqp[16], int q, int isP)                     // sbt.c:677-696
-{
-    const int llq = get_quant(q, isP, 0) / 2;
-    for (int i = 0; i < 16; i++) {
-        int v;
-        if (i > 3 || i == 0) v = llq;
-        else {
-            v = get_quant(q, isP, 3 - i);
-            if (i == 1) {
-                v = lb2u((unsigned)v);
-                v -= isP ? 1 : 3;
-                v = v < 1 ? 1 : (v > 24 ? 24 : v);
-                v = (1 << v) >> 1;
-            }
-            v /= 2;
-        }
-        hqp[i] = v;
-    }
-}
+void make_hqp(int hqp[16], int q, int isP) { dsvg_set_hqp(hqp, q, isP); }      // sbt.c:677-696
 
 void block_geometry(int w, int h, int *bw, int *bh, int *nbh, int *nbv)
 {

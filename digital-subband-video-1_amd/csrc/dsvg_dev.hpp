@@ -103,7 +103,10 @@ struct HzPlaneSum {          // written by hz_scan per plane
     int dc;
     int overflow;
     int last_chunk;          // last chunk holding a non-zero (-1 if the plane is empty)
+    int rc;                  // device-resident rate control (k_rc, written after k_hz_scan): plane 0 = the frame quantiser the picture was
+                             // coded with, plane 1 = the bytes of its packet as the device computed them, plane 2 = 0 (was padding)
 };
+static_assert(sizeof(HzPlaneSum) == 32, "HzPlaneSum travels to the host as 32-byte records");
 
 // decoder: k_hz_parse -> k_hz_codes hand-over for one 128-bit chunk of a plane payload
 struct HzParseChunk {
@@ -164,6 +167,74 @@ struct JobDev {              // everything a kernel needs to find one picture jo
     int hqp[16];             // luma smoothing bound per level (sbt.c:677-696), index = level
     int isP;
     int quant;
+};
+
+// ---- everything a picture's frame quantiser determines in its job record: the HZCC region quantisers of the three planes
+// (hzcc.c:50-57 fix_quant, :77-92 dsv_get_quant, :190-205) and the smoothing bounds of the luma inverse (sbt.c:677-696).
+// ONE implementation for the host's fill_job (make_hz_plane / make_hqp) and for k_rc, which rewrites these fields of the
+// NEXT picture's record on the device once the rate control knows its quantiser.
+static __host__ __device__ inline int dsvg_lb2u(unsigned n)                     // dsv_lb2 hzcc.c:437-447
+{
+    unsigned i = 1;
+    int l = 0;
+    while (i < n) { i <<= 1; l++; }
+    return l;
+}
+static __host__ __device__ inline int dsvg_level_quant(int q, int isP, int level)   // dsv_get_quant hzcc.c:77-92
+{
+    if (isP) q = q * 3 / 2;
+    if (level == 1) q = q * 2 / 3;
+    else if (level == 2) q = q * 3 / 2;
+    return q < 16 ? 16 : q;
+}
+static __host__ __device__ inline void dsvg_plane_set_quant(HzPlane &hp, int q, int isP, int cur_plane)
+{
+    if (cur_plane > 0 && q > 512) q = 512;                     // fix_quant hzcc.c:50-57
+    hp.r[0].qp = dsvg_level_quant(q, isP, 0); hp.r[0].qp_h = 0;
+    for (int l = 0; l < 3; l++) {
+        int qp = dsvg_level_quant(q, isP, l), qp_h = 0;
+        if (l == 2) {
+            qp = dsvg_lb2u((unsigned)qp);
+            qp_h = qp - (isP ? 1 : 3);                         // DSV_QP_P / DSV_QP_I
+            qp_h = qp_h < 1 ? 1 : (qp_h > 24 ? 24 : qp_h);
+        }
+        for (int s = 1; s < 4; s++) { hp.r[3 * l + s].qp = qp; hp.r[3 * l + s].qp_h = qp_h; }
+    }
+}
+static __host__ __device__ inline void dsvg_set_hqp(int *hqp, int q, int isP)   // sbt.c:677-696
+{
+    const int llq = dsvg_level_quant(q, isP, 0) / 2;
+    for (int i = 0; i < 16; i++) {
+        int v;
+        if (i > 3 || i == 0) v = llq;
+        else {
+            v = dsvg_level_quant(q, isP, 3 - i);
+            if (i == 1) {
+                v = dsvg_lb2u((unsigned)v);
+                v -= isP ? 1 : 3;
+                v = v < 1 ? 1 : (v > 24 ? 24 : v);
+                v = (1 << v) >> 1;
+            }
+            v /= 2;
+        }
+        hqp[i] = v;
+    }
+}
+static __host__ __device__ inline void dsvg_job_set_quant(JobDev &jb, int quant)
+{
+    for (int p = 0; p < 3; p++) dsvg_plane_set_quant(jb.hz[p], quant, jb.isP, p);
+    dsvg_set_hqp(jb.hqp, quant, jb.isP);
+    jb.quant = quant;
+}
+
+// rate control shared with the C session layer (include/dsvg_rc.h): the same statements on both sides
+#define DSVG_RC_FN static __host__ __device__ inline
+#include "../../include/dsvg_rc.h"
+struct RcJobDev {            // per device job of a rate-controlled call (dsvg_code_batch_rc)
+    int slot;                // rate-control state of the job's stream: rc_state[slot]
+    int prefix_len;          // bytes of the packet in front of the quantiser field
+    int forced_intra;        // quality2quant's argument
+    int next;                // device job (absolute index) of the stream's next picture in this call, -1 = none
 };
 
 struct SbtGeo {              // per-plane constants for the transform kernels

@@ -55,6 +55,9 @@ void launch_hz_dec_resolve(hipStream_t st, const JobDev *jobs, int njobs, int c0
 void launch_hz_unscatter(hipStream_t st, const JobDev *jobs, int njobs, int max_entries);   // decoder: take the scattered symbols down again
 int  hz_scan_items_max();
 void launch_gather_bits(hipStream_t st, const uint8_t *bits, const unsigned long long *tab, int nitems, uint8_t *dst);
+// k_rc.hip: device-resident ABR -- mode 0: quantiser of jobs [d0, d0 + n) from their streams' state; mode 1: after their k_hz_scan,
+// packet size -> statistics -> quantiser tables of each stream's next job (RcJobDev.next)
+void launch_rc(hipStream_t st, JobDev *jobs, const RcJobDev *rcj, dsvg_rc_state *state, int d0, int n, int mode);
 // k_bmc.hip
 // mvs0: the jobs' vector arrays when they are contiguous (job j at mvs0 + j * nblocks), else null (JobDev.mvs is used)
 void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, int do_sub, Prof *pf = nullptr, const DMV *mvs0 = nullptr,

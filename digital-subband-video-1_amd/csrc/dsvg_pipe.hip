@@ -118,6 +118,10 @@ struct dsvg_ctx {
     DMV *mvs = nullptr;
     uint8_t *stable = nullptr;
     JobDev *jobs_d = nullptr, *jobs_h = nullptr;
+    // device-resident rate control (dsvg_code_batch_rc): per-stream state, per-job tables (indexed like jobs_h / jobs_d)
+    dsvg_rc_state *rc_state_d = nullptr;
+    RcJobDev *rcj_d = nullptr, *rcj_h = nullptr;
+    int rc_slots = 0;
     size_t nz_off[3] = {0, 0, 0}, nz_total = 0;
     int chunk_off[3] = {0, 0, 0}, chunks_per_job = 0, max_chunks = 0;
     size_t bits_off[3] = {0, 0, 0}, bits_cap[3] = {0, 0, 0}, bits_per_job = 0;
@@ -203,9 +207,9 @@ static void ctx_free(dsvg_ctx *c)
     for (int i = 0; i < 6; i++) c->src[i].release();
     c->recon.release(); c->xf.release(); c->pred.release();
     void *d[] = {c->coef, c->s3, c->s1, c->s5, c->sym, c->nzpos, c->nzval, c->chunks, c->psum, c->bits, c->mvs, c->stable,
-                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->csum, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat, c->llsym};
+                 c->jobs_d, c->mvf, c->aux_tex, c->aux_var, c->csum, c->slots_d, c->luma_sums, c->yuv_stage, c->gtab_d, c->gath_d, c->ltab_d, c->ptab_d, c->ingest[0], c->ingest[1], c->dec_d[0], c->dec_d[1], c->dec_meta, c->ilist_d, c->nzf, c->symP, c->pflag, c->cflag, c->stat, c->llsym, c->rc_state_d, c->rcj_d};
     for (void *p : d) if (p) (void)hipFree(p);
-    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h};
+    void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h, c->rcj_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
     if (c->st_a) (void)hipStreamDestroy(c->st_a);
@@ -405,6 +409,10 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
     if ((rc = dmalloc(&c->mvs, (size_t)c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->stable, (size_t)c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->jobs_d, O, true))) return fail(rc);
+    c->rc_slots = std::max(n_recon_slots, max_jobs);
+    if ((rc = dmalloc(&c->rc_state_d, (size_t)c->rc_slots, true))) return fail(rc);
+    if ((rc = dmalloc(&c->rcj_d, O, true))) return fail(rc);
+    if ((rc = hmalloc(&c->rcj_h, std::max(S, O)))) return fail(rc);
     if ((rc = dmalloc(&c->mvf, (size_t)(c->levels + 1) * c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->aux_tex, (size_t)c->nblk * O, true))) return fail(rc);
     if ((rc = dmalloc(&c->aux_var, (size_t)c->nblk * O, true))) return fail(rc);
@@ -938,11 +946,20 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
 // reconstructions step k produces.  All host-built tables of the whole call travel in ONE set of
 // host-to-device copies up front, then the kernel chains of the steps follow back to back.
 // The out slots of the call must form one contiguous block (they also index the device tables).
-extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_job *jobs)
+// rcj (dsvg_code_batch_rc): the frame quantisers are chosen ON THE DEVICE by the rate control of each job's stream -- k_rc before
+// the first frame step and after every step's k_hz_scan (k_rc.hip); jobs[].quant is ignored
+static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_job *jobs, const dsvg_rc_job *rcj)
 {
     if (!c || !jobs || nsteps < 1 || njobs < 1 || njobs > c->max_jobs || nsteps * njobs > c->out_slots) {
         dsvg_set_error("bad code_batch arguments"); return DSVG_ERR_ARG;
     }
+    if (rcj)
+        for (int i = 0; i < nsteps * njobs; i++) {
+            if (rcj[i].rc_slot < 0 || rcj[i].rc_slot >= c->rc_slots || rcj[i].prefix_len < 0) { dsvg_set_error("bad rate-control job %d", i); return DSVG_ERR_ARG; }
+            if (i >= njobs && rcj[i].rc_slot != rcj[i - njobs].rc_slot) { dsvg_set_error("a stream must keep its position from frame step to frame step (rate-control job %d)", i); return DSVG_ERR_ARG; }
+            for (int k = i - i % njobs; k < i; k++)
+                if (rcj[k].rc_slot == rcj[i].rc_slot) { dsvg_set_error("two pictures of one rate-controlled stream in one frame step (jobs %d, %d)", k, i); return DSVG_ERR_ARG; }
+        }
     HIPCHK(hipSetDevice(c->device));
     static const bool cprof = getenv("DSV1_HOST_PROF") != nullptr;
     const auto cnow = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; };
@@ -1007,7 +1024,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             for (int r = 0; r < c->n_recon; r++) if (now[r] >= 0) writer[r] = now[r];
         }
     }
-    const bool defer = c->defer_T > 0 && nsteps > 1 && nsteps <= c->defer_T;     // (experiment: DSV1_DEFER_ENTROPY)
+    const bool defer = c->defer_T > 0 && nsteps > 1 && nsteps <= c->defer_T && !rcj;     // (experiment: DSV1_DEFER_ENTROPY)
     int gk[DSVG_MAX_CODE_STREAMS + 1];                        // device jobs [gk[g], gk[g+1]) of every step -> stream g
     for (int g = 0; g <= NG; g++) gk[g] = (int)((long)njobs * g / NG);
     std::vector<int> ioff((size_t)NG * nsteps, 0), icnt((size_t)NG * nsteps, 0);
@@ -1015,6 +1032,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     int *il = c->ilist_h + (size_t)base * c->nblk;         // intra blocks of each (step, group)'s P pictures (mc_fused)
     int iln = 0;
     std::vector<const dsvg_pic_job *> dj((size_t)total);   // the caller's job behind every device job
+    std::vector<int> dpos(rcj ? (size_t)total : 0);        // rate control: device position of the caller's job i of step t
     for (int t = 0; t < nsteps; t++) {
         const dsvg_pic_job *js = jobs + (size_t)t * njobs;
         // device order inside a step: intra jobs first, then inter jobs (kernels are specialised per type)
@@ -1033,6 +1051,7 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
                 dsvg_set_error("bad picture job (step %d job %d)", t, order[k]); return DSVG_ERR_ARG;
             }
             dj[(size_t)t * njobs + k] = &j;
+            if (rcj) dpos[(size_t)t * njobs + order[k]] = k;
             if (isP && !c->mc_fused) noint[NG * t + g] = 0;
             if (isP && c->mc_fused && !j.no_intra_blocks) {
                 // index relative to the first P job of the group's launch
@@ -1112,6 +1131,18 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
     if (c->slot_ext.size() != (size_t)c->n_recon * 8) c->slot_ext.assign((size_t)c->n_recon * 8, (short)DSVG_BORDER);
     for (int i = 0; i < total; i++)                             // (what dsvg_recon_border reports)
         if (dj[i]->recon_slot >= 0) memcpy(&c->slot_ext[(size_t)dj[i]->recon_slot * 8], c->jobs_h[base + i].ext, sizeof(short) * 8);
+    if (rcj) {
+        // the rate-control table of every device job: its stream's state, the bytes in front of the quantiser field, and the
+        // device job of the stream's next picture (same caller position in the next frame step)
+        for (int t = 0; t < nsteps; t++)
+            for (int i = 0; i < njobs; i++) {
+                RcJobDev &r = c->rcj_h[base + t * njobs + dpos[(size_t)t * njobs + i]];
+                const dsvg_rc_job &q = rcj[(size_t)t * njobs + i];
+                r.slot = q.rc_slot; r.prefix_len = q.prefix_len; r.forced_intra = q.forced_intra;
+                r.next = t + 1 < nsteps ? base + (t + 1) * njobs + dpos[(size_t)(t + 1) * njobs + i] : -1;
+            }
+        HIPCHK(hipMemcpyAsync(c->rcj_d + base, c->rcj_h + base, sizeof(RcJobDev) * total, hipMemcpyHostToDevice, c->st));
+    }
     const double tc1 = cprof ? cnow() : 0.0;
     if (iln) HIPCHK(hipMemcpyAsync(c->ilist_d + (size_t)base * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
@@ -1129,6 +1160,8 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             HIPCHK(hipStreamWaitEvent(c->stx[g], c->ev_fork, 0));
         }
     }
+    if (rcj)       // the quantisers of the first frame step, from the state the streams' last packets left
+        for (int g = 0; g < NG; g++) launch_rc(g ? c->stx[g] : c->st, c->jobs_d, c->rcj_d, c->rc_state_d, base + gk[g], gk[g + 1] - gk[g], 0);
     for (int t = 0; t < nsteps; t++) {
         for (int g = 0; g < NG; g++) {
             hipStream_t st = g ? c->stx[g] : c->st;
@@ -1171,6 +1204,8 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
             for (int k = k0; k < k0 + n && !keeps; k++) keeps = dj[(size_t)t * njobs + k]->recon_slot >= 0;
             if (keeps) OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true, c->llq));
             if (!(defer && nIs[t] == 0)) launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
+            // rate control: the sizes of these packets -> the quantiser tables of the same streams' pictures of the next step
+            if (rcj) launch_rc(st, c->jobs_d, c->rcj_d, c->rc_state_d, d0, n, 1);
         }
     }
     if (defer)      // the entropy stage of the P frame steps, off the chain reconstruction(t) -> forward(t + 1)
@@ -1193,6 +1228,30 @@ extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pi
         for (int i = 0; i < total; i++) c->slot_ev[base + i] = e;
     }
     HIPCHK(hipGetLastError());
+    return DSVG_OK;
+}
+
+extern "C" int dsvg_code_batch(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_job *jobs) { return code_batch_impl(c, nsteps, njobs, jobs, nullptr); }
+extern "C" int dsvg_code_batch_rc(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_job *jobs, const dsvg_rc_job *rc)
+{
+    if (!rc) { dsvg_set_error("dsvg_code_batch_rc without rate-control jobs"); return DSVG_ERR_ARG; }
+    return code_batch_impl(c, nsteps, njobs, jobs, rc);
+}
+extern "C" int dsvg_rc_upload(dsvg_ctx *c, int first_slot, int n, const dsvg_rc_state *states)
+{
+    if (!c || !states || first_slot < 0 || n < 1 || first_slot + n > c->rc_slots) { dsvg_set_error("bad rate-control slots"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    // ordered on the first coding stream like the tables of a coding call (the other coding streams fork from it after those)
+    HIPCHK(hipMemcpyAsync(c->rc_state_d + first_slot, states, sizeof(dsvg_rc_state) * (size_t)n, hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));               // (pageable source: the caller's array may go away)
+    return DSVG_OK;
+}
+extern "C" int dsvg_rc_download(dsvg_ctx *c, int first_slot, int n, dsvg_rc_state *states)
+{
+    if (!c || !states || first_slot < 0 || n < 1 || first_slot + n > c->rc_slots) { dsvg_set_error("bad rate-control slots"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    OPCHK(dsvg_ctx_sync(c));
+    HIPCHK(hipMemcpy(states, c->rc_state_d + first_slot, sizeof(dsvg_rc_state) * (size_t)n, hipMemcpyDeviceToHost));
     return DSVG_OK;
 }
 
@@ -1265,6 +1324,7 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
                     po.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
                     po.payload[p] = c->gath_h + (3 * (size_t)i + p) * K;
                 }
+                po.rc_quant = c->psum_h[3 * (size_t)out_slots[i]].rc; po.rc_pkt_len = (uint32_t)c->psum_h[3 * (size_t)out_slots[i] + 1].rc;
             }
             if (fprof) fprintf(stderr, "[dsvg fetch] %d picture(s), one round trip: %.2f ms\n", n, tnow() - tf0);
             return DSVG_OK;
@@ -1314,6 +1374,7 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
             po.nbytes[p] = (uint32_t)((ps.total_bits + 7) >> 3);
             po.payload[p] = c->gath_h + c->gtab_h[3 * (3 * (size_t)i + p) + 1];
         }
+        po.rc_quant = c->psum_h[3 * (size_t)o].rc; po.rc_pkt_len = (uint32_t)c->psum_h[3 * (size_t)o + 1].rc;
     }
     // 3. the copy, in nchunks pieces that end on multiples of `align` pictures: the caller's work on a piece (packet
     //    assembly) runs while the later pieces are still on the link

@@ -13,6 +13,7 @@
  * the same code one frame step at a time. */
 #include <stdio.h>
 #include "dsv1_host.h"
+#include "dsvg_rc.h"              /* the rate control, shared with the device (k_rc.hip) */
 
 typedef struct {
     DSV_FNUM fnum;
@@ -53,6 +54,12 @@ struct dsv1_batch {
     dsvg_pic_job *jobs;
     dsvg_pic_out *outs;
     pkt_scratch sc0;                 /* packet staging of the serial (ABR / single-frame) path */
+    /* ABR with the rate control ON THE DEVICE (round 4, include/dsvg_rc.h + k_rc): the whole call is enqueued like a CRF call, k_rc
+     * turns every packet's size into the next picture's quantiser tables; the host replays the same code when it assembles the
+     * packets and refuses a batch whose quantisers differ.  DSV1_ABR_SERIAL=1: the frame-by-frame host path of rounds 1-3. */
+    int abr_dev;
+    int rc_seeded;                   /* the device holds the streams' rate-control state (seeded from enc[] by the first call) */
+    dsvg_rc_job *rcjobs;
     /* CHAIN MODE (dsv1_stream_open): ONE stream, the residual coding of a call's frames runs GOP-parallel.  A chain = an I
      * picture and the P pictures that follow it; `chains` = how many are coded side by side (0: the mode is off).  Everything
      * that decides what a chain is -- GOP starts, scene changes, forced-intra P pictures, the stability flags -- depends on
@@ -115,7 +122,7 @@ void dsv1_batch_close(dsv1_batch *b)
     }
     free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
-    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped);
+    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->rcjobs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped);
     free(b->ch_start); free(b->ch_len); free(b->ch_pair); free(b->ch_cur);
     free(b);
 }
@@ -158,6 +165,8 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
     b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
     b->outs = (dsvg_pic_out *)calloc((size_t)np, sizeof(dsvg_pic_out));
+    b->rcjobs = (dsvg_rc_job *)calloc((size_t)np, sizeof(dsvg_rc_job));
+    { const char *e = getenv("DSV1_ABR_SERIAL"); b->abr_dev = !chains && !(e && atoi(e) != 0); }
     if (chains) {
         b->ch_start = (int *)calloc((size_t)F + 1, sizeof(int));
         b->ch_len = (int *)calloc((size_t)F + 1, sizeof(int));
@@ -215,73 +224,45 @@ void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum)
     if (b && stream >= 0 && stream < b->nstreams) b->enc[stream].next_fnum = next_fnum;
 }
 
-/* ---- rate control (quality2quant dsv_encoder.c:70-168) ------------------------------------------ */
+/* ---- rate control: quality2quant dsv_encoder.c:70-168 and the statistics of dsv_enc :816-848 live in include/dsvg_rc.h -- one
+ * piece of code for this layer and for the device (k_rc); here they run on the encoder struct's own fields ------------------- */
+static void rc_load(dsvg_rc_state *r, const DSV_ENCODER *e)
+{
+    r->rc_quant = e->rc_quant; r->bpf_total = e->bpf_total; r->bpf_reset = e->bpf_reset;
+    r->bpf_avg = e->bpf_avg; r->total_P_frame_q = e->total_P_frame_q; r->avg_P_frame_q = e->avg_P_frame_q;
+    r->last_P_frame_over = e->last_P_frame_over; r->back_into_range = e->back_into_range;
+    r->bitrate = e->bitrate; r->fps_num = e->vidmeta.fps_num; r->fps_den = e->vidmeta.fps_den;
+    r->rc_high_motion_nudge = e->rc_high_motion_nudge; r->max_q_step = e->max_q_step;
+    r->min_quality = e->min_quality; r->max_quality = e->max_quality; r->min_I_frame_quality = e->min_I_frame_quality;
+}
+static void rc_store(DSV_ENCODER *e, const dsvg_rc_state *r)
+{
+    e->rc_quant = r->rc_quant; e->bpf_total = r->bpf_total; e->bpf_reset = r->bpf_reset;
+    e->bpf_avg = r->bpf_avg; e->total_P_frame_q = r->total_P_frame_q; e->avg_P_frame_q = r->avg_P_frame_q;
+    e->last_P_frame_over = r->last_P_frame_over; e->back_into_range = r->back_into_range;
+    e->max_q_step = r->max_q_step;
+}
 static int pick_quant(DSV_ENCODER *e, int isP, int forced_intra)
 {
-    int q = (int)e->rc_quant;
     if (e->rc_mode != DSV_RATE_CONTROL_CRF) {
-        const DSV_META *vm = &e->vidmeta;
-        int fps = (vm->fps_num << 5) / vm->fps_den, need, bpf, dir, delta, nudged = 0, cap, low_p, minq;
-        if (fps == 0) fps = 1;
-        need = (int)(((e->bitrate << 5) / (unsigned)fps) >> 3);
-        bpf = e->bpf_avg ? e->bpf_avg : need;
-        dir = (bpf - need) > 0 ? -1 : 1;
-        delta = (abs(bpf - need) << 9) / need;
-        if (dir == 1) delta *= 2;
-        if (e->rc_high_motion_nudge) {
-            if (isP && e->last_P_frame_over) { delta = (delta + 1) * 2; dir = -1; nudged = 1; }
-            else if (e->back_into_range)     { delta = (delta + 1) * 2; dir = 1;  nudged = 1; }
-        }
-        delta = (q * delta) >> 9;
-        e->max_q_step = CLAMPI(e->max_q_step, 1, DSV_MAX_QUALITY);
-        cap = nudged ? e->max_q_step * 16 : e->max_q_step;
-        if (delta > cap) delta = cap;
-        q += delta * dir;
-        low_p = CLAMPI(e->avg_P_frame_q - DSV_QUALITY_PERCENT(4), e->min_quality, e->max_quality);
-        minq = isP ? low_p : e->min_I_frame_quality;
-        if (forced_intra) {
-            if (q < DSV_QUALITY_PERCENT(60)) q += DSV_QUALITY_PERCENT(15);
-            else if (q < DSV_QUALITY_PERCENT(70)) q += DSV_QUALITY_PERCENT(8);
-            else if (q < DSV_QUALITY_PERCENT(75)) q += DSV_QUALITY_PERCENT(3);
-            q = CLAMPI(q, 0, e->max_quality - DSV_QUALITY_PERCENT(5));
-        }
-        q = CLAMPI(q, minq, e->max_quality);
-        q = CLAMPI(q, 0, DSV_MAX_QUALITY);
-    } else {
-        q = e->quality;
+        dsvg_rc_state r;
+        int fq;
+        rc_load(&r, e);
+        fq = dsvg_rc_pick(&r, isP, forced_intra);
+        rc_store(e, &r);
+        return fq;
     }
-    e->rc_quant = (unsigned)q;
-    return DSV_MAX_QUALITY - ((DSV_MAX_QUALITY - 5) * q / DSV_MAX_QUALITY);
+    e->rc_quant = (unsigned)e->quality;
+    return DSV_MAX_QUALITY - ((DSV_MAX_QUALITY - 5) * e->quality / DSV_MAX_QUALITY);
 }
 
 static void rc_after_packet(DSV_ENCODER *e, int isP, unsigned pkt_len)        /* dsv_encoder.c:816-848 */
 {
+    dsvg_rc_state r;
     if (e->rc_mode == DSV_RATE_CONTROL_CRF) return;
-    e->bpf_total += pkt_len;
-    e->bpf_reset++;
-    if (isP) {
-        unsigned fps, need;
-        int under, over;
-        e->total_P_frame_q += (int)e->rc_quant;
-        e->avg_P_frame_q = (int)((unsigned)e->total_P_frame_q / e->bpf_reset);
-        fps = (unsigned)(e->vidmeta.fps_num << 5) / (unsigned)e->vidmeta.fps_den;
-        if (fps == 0) fps = 1;
-        need = ((e->bitrate << 5) / fps) >> 3;
-        under = pkt_len < (need * 3 / 4);
-        need = need * 7 / 8;
-        over = pkt_len > need;
-        e->back_into_range = (e->last_P_frame_over && under);
-        e->last_P_frame_over = over;
-    } else {
-        e->last_P_frame_over = 0;
-        e->back_into_range = 0;
-    }
-    e->bpf_avg = (int)(e->bpf_total / e->bpf_reset);
-    if (e->bpf_reset >= 256) {
-        e->bpf_total = (unsigned)e->bpf_avg;
-        e->total_P_frame_q = (int)((unsigned)e->total_P_frame_q / e->bpf_reset);
-        e->bpf_reset = 1;
-    }
+    rc_load(&r, e);
+    dsvg_rc_after(&r, isP, pkt_len);
+    rc_store(e, &r);
 }
 
 /* ---- side information --------------------------------------------------------------------------- */
@@ -431,6 +412,15 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
         const unsigned n = write_meta_packet(e, mb);
         if (dsv1_buf_append(out, mb, n)) return DSVG_ERR_ARG;
     }
+    if (b->abr_dev && e->rc_mode != DSV_RATE_CONTROL_CRF) {
+        /* the device chose this picture's quantiser (k_rc): replay the choice here -- it also advances this stream's host-side
+         * state -- and refuse the batch if the two disagree (same code on both sides: include/dsvg_rc.h) */
+        pc->quant = pick_quant(e, pc->isP, pc->forced_intra);
+        if (pc->quant != po->rc_quant) {
+            dsv1_log(1, "rate control: stream %d picture %u: the device coded with quantiser %d, the host replay says %d", s, (unsigned)pc->fnum, (int)po->rc_quant, pc->quant);
+            return DSVG_ERR_HIP;
+        }
+    }
     /* the packet is built in place at the end of the stream buffer: the payloads (the bulk) are copied once, straight
      * from the fetch buffer; only the few header bytes the bit writer ORs into are cleared first */
     if (dsv1_buf_reserve(out, (unsigned)need)) return DSVG_ERR_ARG;
@@ -459,6 +449,10 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     }
     bw_align(&w);
     len = bw_bytes(&w);
+    if (b->abr_dev && e->rc_mode != DSV_RATE_CONTROL_CRF && len != po->rc_pkt_len) {
+        dsv1_log(1, "rate control: stream %d picture %u: packet of %u bytes, the device counted %u", s, (unsigned)pc->fnum, len, (unsigned)po->rc_pkt_len);
+        return DSVG_ERR_HIP;
+    }
     rc_after_packet(e, pc->isP, len);
     link_packet(e, pkt, len, 0);
     out->len += len;
@@ -789,12 +783,14 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     }
     /* 5. residual coding, frame step by frame step across all streams */
     {
-        const int serial = e0->rc_mode != DSV_RATE_CONTROL_CRF;
+        const int abr = e0->rc_mode != DSV_RATE_CONTROL_CRF;
+        const int devrc = abr && b->abr_dev;                    /* rate control on the device: enqueued like a CRF call */
+        const int serial = abr && !devrc;
         side_ctx sc_;
         sc_.b = b; sc_.pics = pics;
         if (serial && !abr_out) return DSVG_ERR_ARG;
-        if (serial && b->chains) return DSVG_ERR_ARG;
-        if (serial) {                                           /* ABR assembles every picture as soon as it is coded */
+        if (abr && b->chains) return DSVG_ERR_ARG;
+        if (abr) {                                              /* ABR: the length of every packet prefix feeds the rate control */
             if (S == 1 && nf > 1) dsv1_par_for(nf, prefix_picture, &sc_);   /* (one stream, a gathered group: its pictures are the parallel items) */
             else dsv1_par_for(S, prefix_stream, &sc_);
         }
@@ -805,7 +801,8 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
             for (s = 0; s < S; s++) {
                 pic_t *pc = &pics[s * F + t];
                 dsvg_pic_job *j = &b->jobs[(serial ? 0 : t * S) + s];
-                pc->quant = pick_quant(&b->enc[s], pc->isP, pc->forced_intra);
+                pc->quant = devrc ? 0 : pick_quant(&b->enc[s], pc->isP, pc->forced_intra);
+                if (devrc) { dsvg_rc_job *q = &b->rcjobs[t * S + s]; q->rc_slot = s; q->prefix_len = pc->prefix_len; q->forced_intra = pc->forced_intra; }
                 j->src_slot = pc->cur_slot;
                 /* two reconstruction slots per stream, used alternately: a P picture's prediction is written straight
                  * into the slot its reconstruction will live in (the reference sits in the other one), so the inverse
@@ -837,11 +834,23 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                     if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s], &b->sc0))) return rc;
             }
         }
+        if (devrc) {
+            if (!b->rc_seeded) {                                /* the device takes over the streams' rate-control state */
+                dsvg_rc_state *st = (dsvg_rc_state *)calloc((size_t)S, sizeof(dsvg_rc_state));
+                if (!st) return DSVG_ERR_ARG;
+                for (s = 0; s < S; s++) rc_load(&st[s], &b->enc[s]);
+                rc = dsvg_rc_upload(b->ctx, 0, S, st);
+                free(st);
+                if (rc) return rc;
+                b->rc_seeded = 1;
+            }
+            if ((rc = dsvg_code_batch_rc(b->ctx, nf, S, b->jobs, b->rcjobs))) return rc;
+        } else
         if (!serial && !b->chains && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
         HP_MARK(HP_ENQUEUE);
         /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
         if (b->chains) dsv1_par_for(nf, prefix_picture, &sc_);      /* (one stream: the pictures are the independent items) */
-        else if (!serial) dsv1_par_for(S, prefix_stream, &sc_);
+        else if (!abr) dsv1_par_for(S, prefix_stream, &sc_);
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
         b->nf_pending[par] = nf;
     }

@@ -206,6 +206,8 @@ typedef struct {
     uint32_t nruns[3];       /* number of (run,value) pairs */
     uint32_t nbytes[3];      /* payload length in bytes (bit count rounded up) */
     const uint8_t *payload[3]; /* host (pinned) pointers, valid until the next dsvg_fetch_pictures */
+    int32_t rc_quant;        /* pictures coded by dsvg_code_batch_rc: the frame quantiser the device's rate control chose ... */
+    uint32_t rc_pkt_len;     /* ... and the bytes of the picture packet as it computed them (0 / 0 for other pictures) */
 } dsvg_pic_out;
 
 /* Residual coding of njobs pictures in one batch: frame copy, dsv_sub_pred, then per plane
@@ -219,6 +221,19 @@ int dsvg_code_pictures(dsvg_ctx *ctx, int njobs, const dsvg_pic_job *jobs);
  * step are shared out by position; a call in which a reconstruction slot would be written and read (or written twice) by
  * jobs of different shares is run on one stream instead -- always correct, fastest when stream s keeps position s. */
 int dsvg_code_batch(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs);
+/* Device-resident average-bitrate rate control (round 4; quality2quant dsv_encoder.c:70-168 + the statistics of dsv_enc
+ * :816-848 as include/dsvg_rc.h, run by k_rc on the device): the same as dsvg_code_batch for streams whose every quantiser
+ * depends on the size of the packet before -- jobs[].quant is ignored, rc[step*njobs + j] says which stream's state
+ * (rc_slot, < max(n_recon_slots, max_jobs)) picture j of a step belongs to, how many bytes of its packet precede the quantiser
+ * field (prefix_len: header + side information, known before the picture is coded) and quality2quant's forced_intra.  A stream
+ * keeps its position j from step to step.  The state lives on the device from call to call: dsvg_rc_upload seeds it (once, or when
+ * the caller changed the stream's parameters), dsvg_rc_download reads it back (syncs).  dsvg_pic_out.rc_quant / rc_pkt_len return
+ * what the device chose and computed for every picture. */
+typedef struct { int rc_slot; int prefix_len; int forced_intra; } dsvg_rc_job;
+struct dsvg_rc_state;
+int dsvg_code_batch_rc(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs, const dsvg_rc_job *rc);
+int dsvg_rc_upload(dsvg_ctx *ctx, int first_slot, int n, const struct dsvg_rc_state *states);
+int dsvg_rc_download(dsvg_ctx *ctx, int first_slot, int n, struct dsvg_rc_state *states);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 /* The same with the device-to-host copy cut into `nchunks` pieces that end on multiples of `align` pictures: as soon as a
  * piece has arrived, cb(arg, first, count) is called for its pictures (outs[first .. first+count) are valid then) while the

@@ -172,6 +172,35 @@ int  orc_dec_packet(orc_decoder *d, const uint8_t *pkt, size_t len, uint8_t *yuv
 void orc_dec_get_meta(const orc_decoder *d, orc_meta *m);
 void orc_dec_close(orc_decoder *d);
 
+/* Coverage of the decision points SURVEY.md Appendix F lists (round 4, tests/test_appendix_f_coverage.py): the oracle counts how
+ * often each branch of the level-0 motion search (hme.c:544-721) and of the encoder's per-picture decisions (dsv_encoder.c:
+ * 236-252,330-408,538-554) is taken while it encodes -- process-wide counters, test infrastructure only. */
+enum {
+    ORC_COV_HP_SKIPPED,        /* best <= bw*bh: no half-pel search (hme.c:551,587-591) */
+    ORC_COV_HP_KEPT_FULLPEL,   /* searched, no half-pel candidate better (m == -1) */
+    ORC_COV_HP_REFINED,        /* a half-pel candidate won */
+    ORC_COV_NB0_PLAIN, ORC_COV_NB1_PLAIN, ORC_COV_NB2_PLAIN, ORC_COV_NB3_PLAIN,   /* 0..3 qualifying neighbours, high_detail = 0 (hme.c:621-648) */
+    ORC_COV_NB0_HD, ORC_COV_NB1_HD, ORC_COV_NB2_HD, ORC_COV_NB3_HD,               /* ... high_detail = 1 */
+    ORC_COV_INTRA_ZEROVAR, ORC_COV_INTRA_REFVAR, ORC_COV_INTRA_FLATSRC, ORC_COV_INTRA_AVG, ORC_COV_INTRA_BADSAD, ORC_COV_INTRA_CHROMA,   /* the six tests of hme.c:652-682, first one that fires */
+    ORC_COV_INTRA_NONE,        /* no test fired: inter */
+    ORC_COV_VETO_TAKEN,        /* block_intra_test sent the block back to inter (hme.c:685-687) */
+    ORC_COV_VETO_NOT_TAKEN,
+    ORC_COV_LOWTEX_ALL_INTRA,  /* src_tex <= 1: no quadrant vote, submask 0xF (hme.c:691-692) */
+    ORC_COV_QUAD_VOTE,         /* the four quadrants voted */
+    ORC_COV_SUBMASK0,          /* + m: final submask m of a block that reached the vote (0 = every quadrant preferred inter: the block stays inter) */
+    ORC_COV_LO_TEX = ORC_COV_SUBMASK0 + 16, ORC_COV_LO_VAR, ORC_COV_LO_NEITHER,
+    ORC_COV_FORCED_INTRA_IPCT, /* intra_pct > ipct turned a P picture into an I picture (dsv_encoder.c:248-252) */
+    ORC_COV_FORCED_INTRA_SCENE,/* scene change (dsv_encoder.c:546-551) */
+    ORC_COV_P_KEPT,            /* a P picture stayed a P picture */
+    ORC_COV_STAB_REFRESH,      /* refresh_ctr reached stable_refresh: accumulators cleared (dsv_encoder.c:345-348) */
+    ORC_COV_STAB_RESET_LO,     /* lo_tex / lo_var block: accumulators set to 0x3fff (:388-391) */
+    ORC_COV_STABLE_BY_HD, ORC_COV_STABLE_BY_AVG, ORC_COV_UNSTABLE_INTER, ORC_COV_INTRA_BLOCK_FLAG, ORC_COV_STABLE_I, ORC_COV_UNSTABLE_I,
+    ORC_COV_N
+};
+extern unsigned long long orc_cov[ORC_COV_N];
+void orc_cov_reset(void);
+int  orc_cov_read(unsigned long long *out, int n);      /* copies min(n, ORC_COV_N) counters, returns ORC_COV_N */
+
 /* (the synthetic clip generator lives in tools/clipgen/clipgen.c: it is input data, not part of the checker) */
 
 #ifdef __cplusplus

@@ -228,6 +228,7 @@ static void write_stability(orc_encoder *e, orc_bs *bs, const orc_mv *mvs, int i
     if (e->refresh_ctr >= e->c.stable_refresh) {
         e->refresh_ctr = 0;
         memset(e->acc, 0, sizeof(int16_t) * 2 * (size_t)nblk);
+        orc_cov[ORC_COV_STAB_REFRESH]++;
     }
     int div = (int)e->refresh_ctr;
     if (div <= 0) div = 1;
@@ -242,12 +243,15 @@ static void write_stability(orc_encoder *e, orc_bs *bs, const orc_mv *mvs, int i
                 a[1] = (int16_t)(a[1] + (abs(mv->u.mv.y) >> 2));
                 stable = mv->high_detail;
                 stable |= (a[0] / div == 0 && a[1] / div == 0 && !mv->lo_tex && !mv->lo_var);
+                orc_cov[mv->high_detail ? ORC_COV_STABLE_BY_HD : (stable ? ORC_COV_STABLE_BY_AVG : ORC_COV_UNSTABLE_INTER)]++;
             } else {
                 intra = 1;
+                orc_cov[ORC_COV_INTRA_BLOCK_FLAG]++;
             }
-            if (mv->lo_tex || mv->lo_var) { a[0] = 0x3fff; a[1] = 0x3fff; }
+            if (mv->lo_tex || mv->lo_var) { a[0] = 0x3fff; a[1] = 0x3fff; orc_cov[ORC_COV_STAB_RESET_LO]++; }
         } else {
             stable = (a[0] / div == 0 && a[1] / div == 0);
+            orc_cov[stable ? ORC_COV_STABLE_I : ORC_COV_UNSTABLE_I]++;
         }
         e->stable[i] = (unsigned char)(stable | (intra << 1));
         orc_rle_put(&rle, e->stable[i] & 1);
@@ -372,6 +376,7 @@ size_t orc_enc_frame(orc_encoder *e, const uint8_t *yuv, uint8_t **out, size_t *
         if (e->c.do_scd) {
             int al = orc_frame_avg_luma(cur.pyr[e->c.pyramid_levels - 1]);
             if (abs(e->prev_avg_luma - al) > e->c.scene_change_delta) {
+                if (prm.has_ref) orc_cov[ORC_COV_FORCED_INTRA_SCENE]++;
                 prm.has_ref = 0;
                 forced_intra = 1;
             }
@@ -397,6 +402,7 @@ size_t orc_enc_frame(orc_encoder *e, const uint8_t *yuv, uint8_t **out, size_t *
             prm.has_ref = 0;
             forced_intra = 1;
         }
+        orc_cov[forced_intra ? ORC_COV_FORCED_INTRA_IPCT : ORC_COV_P_KEPT]++;
     }
     const int isP = prm.has_ref;
     const int quant = pick_quant(e, isP, forced_intra);

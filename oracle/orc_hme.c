@@ -125,6 +125,14 @@ static unsigned chroma_maxvar(const orc_plane *planes, int x, int y, int w, int 
 }
 
 /* 1 if some pixel of the block cannot be reproduced by "mean + clamped residual" */
+unsigned long long orc_cov[ORC_COV_N];
+void orc_cov_reset(void) { memset(orc_cov, 0, sizeof orc_cov); }
+int orc_cov_read(unsigned long long *out, int n)
+{
+    for (int i = 0; i < n && i < ORC_COV_N; i++) out[i] = orc_cov[i];
+    return ORC_COV_N;
+}
+
 static int intra_unrepresentable(const uint8_t *src, int ss, const uint8_t *ref, int rs, int w, int h)
 {
     int mean = 0;
@@ -263,6 +271,7 @@ static int refine(orc_hme *hme, int level)
                 }
                 mv->u.mv.x = (int16_t)(mv->u.mv.x << 1);
                 mv->u.mv.y = (int16_t)(mv->u.mv.y << 1);
+                orc_cov[hm >= 0 ? ORC_COV_HP_REFINED : ORC_COV_HP_KEPT_FULLPEL]++;
                 if (hm >= 0) {
                     const uint8_t *l = centre + HP_X[hm] + HP_Y[hm] * LAT;
                     mv->u.mv.x = (int16_t)(mv->u.mv.x + HP_X[hm]);
@@ -273,6 +282,7 @@ static int refine(orc_hme *hme, int level)
                     best = (int)((unsigned)best_hp * yarea / (WIN * WIN));
                 }
             } else {
+                orc_cov[ORC_COV_HP_SKIPPED]++;
                 mv->u.mv.x = (int16_t)(mv->u.mv.x << 1);
                 mv->u.mv.y = (int16_t)(mv->u.mv.y << 1);
             }
@@ -305,26 +315,32 @@ static int refine(orc_hme *hme, int level)
                 if (nb->mode == 0 && !nb->lo_tex && !nb->lo_var) { thr_var *= WIN / 4; thr_tex++; }
             }
             mv->high_detail = (luma_tex > thr_tex && src_var > thr_var);
+            orc_cov[(mv->high_detail ? ORC_COV_NB0_HD : ORC_COV_NB0_PLAIN) + (int)thr_tex - 1]++;
+            orc_cov[mv->lo_tex ? ORC_COV_LO_TEX : (mv->lo_var ? ORC_COV_LO_VAR : ORC_COV_LO_NEITHER)]++;
+            if (mv->lo_tex && mv->lo_var) orc_cov[ORC_COV_LO_VAR]++;
 
             /* ---------------- intra decision ---------------- */
             int want_intra = 0;
             if (src_tex < 2 && sq_var(zref, rp->stride, bw, bh) > luma_var * 2) want_intra = 1;
-            else if (ref_var > src_var * 2) want_intra = 1;
-            else if (src_tex == 0 && ref_tex != 0) want_intra = 1;
-            else if (abs(src_avg - ref_avg) > 8) want_intra = 1;
-            else if (luma_tex <= 10 && (unsigned)best > yareasq / 16) want_intra = 1;
+            else if (ref_var > src_var * 2) want_intra = 2;
+            else if (src_tex == 0 && ref_tex != 0) want_intra = 3;
+            else if (abs(src_avg - ref_avg) > 8) want_intra = 4;
+            else if (luma_tex <= 10 && (unsigned)best > yareasq / 16) want_intra = 5;
             else {
                 int fmt = prm->vidmeta->subsamp;
                 int cbx = i * (BW >> ORC_HSHIFT(fmt)), cby = j * (BH >> ORC_VSHIFT(fmt));
                 int cbw = bw >> ORC_HSHIFT(fmt), cbh = bh >> ORC_VSHIFT(fmt);
                 unsigned cs = chroma_maxvar(src->planes, cbx, cby, cbw, cbh);
                 unsigned cr = chroma_maxvar(ref->planes, cbx, cby, cbw, cbh);
-                if (cr > 4 * cs) want_intra = 1;
+                if (cr > 4 * cs) want_intra = 6;
             }
+            orc_cov[want_intra ? ORC_COV_INTRA_ZEROVAR + want_intra - 1 : ORC_COV_INTRA_NONE]++;
             if (!want_intra) continue;
-            if (intra_unrepresentable(sblk, sp->stride, zref, rp->stride, bw, bh)) continue;
+            if (intra_unrepresentable(sblk, sp->stride, zref, rp->stride, bw, bh)) { orc_cov[ORC_COV_VETO_TAKEN]++; continue; }
+            orc_cov[ORC_COV_VETO_NOT_TAKEN]++;
 
             mv->submask = 0xF;
+            orc_cov[src_tex > 1 ? ORC_COV_QUAD_VOTE : ORC_COV_LOWTEX_ALL_INTRA]++;
             if (src_tex > 1) {
                 const int qw = bw / 2, qh = bh / 2;
                 for (int k = 0; k < 4; k++) {
@@ -334,6 +350,7 @@ static int refine(orc_hme *hme, int level)
                         mv->submask &= (uint8_t)~(1u << k);
                 }
             }
+            if (src_tex > 1) orc_cov[ORC_COV_SUBMASK0 + mv->submask]++;
             if (mv->submask) {
                 mv->mode = 1;
                 nintra++;

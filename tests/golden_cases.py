@@ -20,6 +20,8 @@ STREAM_CASES = {
     "qvga_422_abr": (320, 240, A.SUBSAMP_422, 6, 1, 0x00C1F006, ["-gop12", "-qp85", "-kbps800"], dict(qp=85, gop=12, rc_mode_cli=0, kbps=800)),
     "cif_411": (352, 288, A.SUBSAMP_411, 4, 0, 0x00C1F007, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
     "lowq_chroma_cap": (352, 288, A.SUBSAMP_420, 5, 2, 0x00C1F008, ["-gop12", "-qp10", "-rc_mode1"], dict(qp=10, gop=12, rc_mode_cli=1)),
+    # every partial intra submask (clip style 6: static noise, cells that change in chosen quadrants)
+    "cif_submasks_style6": (352, 288, A.SUBSAMP_420, 5, 6, 0x00C1F009, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),
     # BASELINE config 2 / 3 shapes, short
     "cfg2_1080p_intra": (1920, 1080, A.SUBSAMP_420, 2, 1, 0x10800001, ["-gop0", "-qp85", "-rc_mode1"], dict(qp=85, gop=0, rc_mode_cli=1)),
     "cfg3_1080p_gop12": (1920, 1080, A.SUBSAMP_420, 13, 0, 0x10800003, ["-gop12", "-qp85", "-rc_mode1"], dict(qp=85, gop=12, rc_mode_cli=1)),

@@ -20,7 +20,8 @@ class PicJob(C.Structure):
 
 
 class PicOut(C.Structure):
-    _fields_ = [("dc", C.c_int32 * 3), ("nruns", C.c_uint32 * 3), ("nbytes", C.c_uint32 * 3), ("payload", C.c_void_p * 3)]
+    _fields_ = [("dc", C.c_int32 * 3), ("nruns", C.c_uint32 * 3), ("nbytes", C.c_uint32 * 3), ("payload", C.c_void_p * 3),
+                ("rc_quant", C.c_int32), ("rc_pkt_len", C.c_uint32)]
 
 
 @pytest.fixture(scope="module")

@@ -16,6 +16,10 @@
  *   style 4: style 1 with a flat square of a third of the frame height and a flat band over its bottom quarter (a third
  *   of all blocks intra, no picture forced intra: the content that leaves the encoder's lean kernels).
  *   style 5: style 3 with a four times faster pan (the blocks' stability accumulators leave zero).
+ *   style 6 (round 4): a STATIC noise texture cut into 16x16 cells (the block size of frames up to 352 wide);
+ *   a third of the cells change between consecutive frames in a chosen subset of their four 8x8 quadrants (brightness +-60),
+ *   the subset being a fixed function of the cell: every partial intra submask of hme.c:689-716 occurs, including "all four
+ *   quadrants prefer the zero vector" (the whole cell changes by +-10 over a texture strong enough for intra_metric).
  *   style 3: style 0 with SCENE CUTS: every 7 frames the texture is another one and the brightness steps by 12 (the mean
  *   luma of the smallest pyramid level moves by more than the default scene_change_delta of 4: dsv_encoder.c:538-554).
  */
@@ -56,6 +60,24 @@ size_t clipgen_frame_bytes(int w, int h, int subsamp)
 
 void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t, int style)
 {
+    if (style == 6) {
+        const int cw6 = RSHIFT_UP(w, HSHIFT(subsamp)), ch6 = RSHIFT_UP(h, VSHIFT(subsamp));
+        for (int y = 0; y < h; y++)
+            for (int x = 0; x < w; x++) {
+                const int bi = x >> 4, bj = y >> 4;
+                int v = 80 + (int)(hash3((uint32_t)x, (uint32_t)y, seed) % 96u);              /* static, strong texture */
+                if ((bi + bj) % 3 == 0) {                                                     /* an active cell */
+                    const uint32_t hc = hash3((uint32_t)bi, (uint32_t)bj, seed ^ 0x6A5Cu);
+                    const int m = (int)(hc & 15u), on = (t + (int)((hc >> 4) & 1u)) & 1;      /* half of the cells are up on even frames, half on odd ones: the frame mean stays (no scene cut) */
+                    const int q = ((x >> 3) & 1) | (((y >> 3) & 1) << 1);                     /* quadrant: bit 0 = right, bit 1 = lower */
+                    if (m == 0) v += on ? 10 : 0;
+                    else if ((m >> q) & 1) v += on ? 60 : 0;
+                }
+                out[(size_t)y * w + x] = sat8(v);
+            }
+        memset(out + (size_t)w * h, 128, 2 * (size_t)cw6 * ch6);
+        return;
+    }
     int lift = 0;                                   /* style 3: brightness step of the scene */
     int big = 0;                                    /* style 4: style 1 with flat objects that cover a third of the frame */
     if (style == 4) { big = 1; style = 1; }
