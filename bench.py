@@ -169,11 +169,14 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
         d = b.upload(batch_in)
         first = b.encode(d, on_device=True)
         crf = cli.get("rc_mode_cli", 1) == 1
-        if crf:
+        # ABR streams are pipelined like CRF ones since round 4: their rate control runs on the device (k_rc), the state goes from
+        # call to call there, so the analysis of batch i + 1 overlaps the coding of batch i (DSV1_ABR_SERIAL=1: plain encode calls)
+        piped = crf or os.environ.get("DSV1_ABR_SERIAL", "0") in ("", "0")
+        if piped:
             b.submit(d, on_device=True)                  # fill the pipeline (as the headline loop does)
         b.sync()
         t0 = time.perf_counter()
-        if crf:
+        if piped:
             for _ in range(steps):
                 b.submit(d, on_device=True)
                 outs = b.collect(copy=False)
@@ -678,7 +681,7 @@ def main():
                 shapes["cfg4_8gops"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 8, 12, 6, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
                                             config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 8 closed GOPs x 12 frames per step: one GPU's share of config 4's 64 GOPs on an 8-GPU node")
                 shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 2, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
-                                                 config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: serial per frame), 2 streams x 30 frames per step")
+                                                 config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: every quantiser from the packet before, rate control on the device), 2 streams x 30 frames per step")
                 # the content that leaves the lean kernels: flat moving objects force a third of the blocks intra (whole-grid
                 # k_fwd_mc_pix, k_mc for the intra blocks, dense symbols) -- same shape and batch as the headline
                 wc = A.gen_clip(W, H, FMT, 0x10800003, 4, style=4)

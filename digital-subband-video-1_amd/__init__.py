@@ -219,9 +219,11 @@ class Batch:
                 _chk(self.L.dsv1_batch_eos(self.h, s, _C.byref(bufs[s])), "dsv1_batch_eos")
         return [_take(bufs[s]) for s in range(self.nstreams)]
 
-    def submit(self, yuv, on_device=False):
+    def submit(self, yuv, on_device=False, held=True):
         """pipelined form: enqueue one batch (returns while its residual coding still runs on the GPU).
-        At most two batches may be in flight: steady state is submit(i+1); collect(i)."""
+        At most two batches may be in flight: steady state is submit(i+1); collect(i).
+        held (device clips): the caller keeps the clip unchanged until collect() of this batch returned (DSV1_CLIP_HELD: its
+        chroma is read in place); held=False: the clip is copied whole and may change as soon as submit() returns"""
         if on_device:
             ptr = yuv
         else:
@@ -232,7 +234,7 @@ class Batch:
         if not hasattr(self, "_abr"):
             self._abr = []
         bufs = (Buf * self.nstreams)()
-        _chk(self.L.dsv1_batch_submit(self.h, ptr, 1 if on_device else 0, bufs), "dsv1_batch_submit")
+        _chk(self.L.dsv1_batch_submit(self.h, ptr, (2 if held else 1) if on_device else 0, bufs), "dsv1_batch_submit")
         self._abr.append(bufs)
 
     def collect(self, copy=True):

@@ -10,6 +10,7 @@
 #include "dsvg_host.hpp"
 #include <ctime>
 extern "C" void dsv1_par_for(int S, void (*fn)(void *ctx, int s, int tid), void *ctx);     // host/dsv1_util.c: the worker pool
+extern "C" void dsv1_par_for_long(int S, void (*fn)(void *ctx, int s, int tid), void *ctx);
 
 #define OPCHK(x) do { int rc_ = (x); if (rc_) return rc_; } while (0)
 
@@ -118,6 +119,7 @@ struct dsvg_ctx {
     DMV *mvs = nullptr;
     uint8_t *stable = nullptr;
     JobDev *jobs_d = nullptr, *jobs_h = nullptr;
+    std::vector<char> slot_isP;      // per out slot: the picture coded into it last was a P picture (dsvg_fetch_pictures' fast path)
     // device-resident rate control (dsvg_code_batch_rc): per-stream state, per-job tables (indexed like jobs_h / jobs_d)
     dsvg_rc_state *rc_state_d = nullptr;
     RcJobDev *rcj_d = nullptr, *rcj_h = nullptr;
@@ -991,6 +993,10 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
         nIs[t] = nI;
     }
     int NG = std::min(std::min(c->code_streams, DSVG_MAX_CODE_STREAMS), njobs / 8);
+    // Small frame steps (ABR streams, a GPU's share of a few 4K GOPs, one stream's chains) are bound by the latency of the chain's
+    // dozen launches, not by the chip: two halves on two streams run side by side (round 4; DSV1_NO_SMALL_SPLIT=1: one stream)
+    static const bool no_small_split = getenv("DSV1_NO_SMALL_SPLIT") != nullptr;
+    if (NG < 2 && njobs >= 2 && c->code_streams >= 2 && !no_small_split) NG = 2;
     if (NG < 1) NG = 1;
     bool anyP = false;
     for (int t = 0; t < nsteps; t++) {
@@ -1051,6 +1057,8 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
                 dsvg_set_error("bad picture job (step %d job %d)", t, order[k]); return DSVG_ERR_ARG;
             }
             dj[(size_t)t * njobs + k] = &j;
+            if (c->slot_isP.size() != (size_t)c->out_slots) c->slot_isP.assign((size_t)c->out_slots, 0);
+            c->slot_isP[(size_t)j.out_slot] = (char)isP;
             if (rcj) dpos[(size_t)t * njobs + order[k]] = k;
             if (isP && !c->mc_fused) noint[NG * t + g] = 0;
             if (isP && c->mc_fused && !j.no_intra_blocks) {
@@ -1160,11 +1168,14 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
             HIPCHK(hipStreamWaitEvent(c->stx[g], c->ev_fork, 0));
         }
     }
-    if (rcj)       // the quantisers of the first frame step, from the state the streams' last packets left
-        for (int g = 0; g < NG; g++) launch_rc(g ? c->stx[g] : c->st, c->jobs_d, c->rcj_d, c->rc_state_d, base + gk[g], gk[g + 1] - gk[g], 0);
-    for (int t = 0; t < nsteps; t++) {
-        for (int g = 0; g < NG; g++) {
-            hipStream_t st = g ? c->stx[g] : c->st;
+    // The launch sequence of one coding stream (group g), frame step by frame step.  The groups' sequences are independent of each
+    // other (different HIP streams, disjoint jobs), so for calls with many small frame steps -- where the HOST's enqueue rate is
+    // what the device waits for: 13 launches x 30 steps x 4 us -- each group is enqueued by a thread of its own (round 4).
+    auto enqueue_steps = [&](int g, int t_first, int t_end) -> int {
+        hipStream_t st = g ? c->stx[g] : c->st;
+        if (rcj && t_first == 0)       // the quantisers of the first frame step, from the state the streams' last packets left
+            launch_rc(st, c->jobs_d, c->rcj_d, c->rc_state_d, base + gk[g], gk[g + 1] - gk[g], 0);
+        for (int t = t_first; t < t_end; t++) {
             const int k0 = gk[g], n = gk[g + 1] - gk[g];                                // device jobs [k0, k0 + n) of the step
             const int d0 = base + t * njobs + k0;
             const int nI = std::min(std::max(nIs[t] - k0, 0), n);                       // I jobs among them come first
@@ -1206,6 +1217,23 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
             if (!(defer && nIs[t] == 0)) launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
             // rate control: the sizes of these packets -> the quantiser tables of the same streams' pictures of the next step
             if (rcj) launch_rc(st, c->jobs_d, c->rcj_d, c->rc_state_d, d0, n, 1);
+        }
+        return DSVG_OK;
+    };
+    {
+        static const bool no_par_enqueue = getenv("DSV1_NO_PAR_ENQUEUE") != nullptr;      // (A/B)
+        // (the event brackets of the profiling hooks are kept in one list: profiled calls are enqueued by this thread alone)
+        if (NG > 1 && nsteps * 13 >= 100 && njobs < 64 && !c->prof.mask && !no_par_enqueue) {
+            struct PE { decltype(enqueue_steps) *f; int device, nsteps, rc[DSVG_MAX_CODE_STREAMS]; } pe = {&enqueue_steps, c->device, nsteps, {0}};
+            dsv1_par_for_long(NG, [](void *vp, int g, int) {
+                PE &P = *static_cast<PE *>(vp);
+                if (hipSetDevice(P.device) != hipSuccess) { P.rc[g] = DSVG_ERR_HIP; return; }      // (the current device is per thread)
+                P.rc[g] = (*P.f)(g, 0, P.nsteps);
+            }, &pe);
+            for (int g = 0; g < NG; g++) if (pe.rc[g]) return pe.rc[g];
+        } else {
+            for (int t = 0; t < nsteps; t++)
+                for (int g = 0; g < NG; g++) OPCHK(enqueue_steps(g, t, t + 1));
         }
     }
     if (defer)      // the entropy stage of the P frame steps, off the chain reconstruction(t) -> forward(t + 1)
@@ -1271,8 +1299,17 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
     // batches already enqueued on the coding streams keep running, and the fetch stream never holds a pending wait: its
     // hardware queue may be shared with a busy stream, which a queued wait would stall for the rest of the batch
     static const bool no_fast_fetch = getenv("DSV1_NO_FETCH_FAST") != nullptr;     // (A/B)
-    const bool few = n <= 4 && !cb && !no_fast_fetch;          // the frame-serial callers (see below): nothing else is in flight, the wait
-    {                                                          // can sit in the fetch stream and the host makes ONE round trip
+    // the frame-serial callers (see below): the wait can sit in the fetch stream and the host makes ONE round trip -- but only when
+    // NOTHING else is in flight (every slot comes from the newest coding call: a queued wait on a fetch stream that shares its
+    // hardware queue with a busy coding stream would stall that stream) and no slot holds an I picture (their planes exceed the
+    // 64 KB the fast path brings back: it would pay the round trip twice)  [advisor, round 3]
+    bool few = n <= 4 && !cb && !no_fast_fetch;
+    for (int i = 0; i < n && few; i++) {
+        const int e = c->slot_ev[out_slots[i]];
+        if (e >= 0 && e != (int)((c->ncalls - 1) % (long)c->ev_coded.size())) few = false;
+        if ((size_t)out_slots[i] < c->slot_isP.size() && !c->slot_isP[(size_t)out_slots[i]]) few = false;
+    }
+    {
         std::vector<char> seen(c->ev_coded.size(), 0);
         for (int i = 0; i < n; i++) {
             const int e = c->slot_ev[out_slots[i]];

@@ -459,7 +459,7 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     return DSVG_OK;
 }
 
-typedef struct { dsv1_batch *b; pic_t *pics; } side_ctx;
+typedef struct { dsv1_batch *b; pic_t *pics; volatile int rc; } side_ctx;   /* rc: a worker's failure (scratch allocation), checked after the parallel loop */
 /* what the coding work needs of the side information, per stream in coding order: intra decisions, the stability flags
  * (accumulators), the vectors' reach.  The bits of the packet prefix are written by prefix_stream AFTER the coding work
  * has been enqueued: the GPU has nothing else to do while this runs. */
@@ -506,6 +506,7 @@ static void prefix_stream(void *ctx, int s, int tid)
     uint8_t *tmp = (uint8_t *)malloc(((size_t)nblk * 8 + 64) * 4 + 64);
     int t;
     (void)tid;
+    if (!tmp) { c->rc = DSVG_ERR_ARG; return; }         /* (a stale prefix would go out as a corrupt packet: the submit fails instead) */
     for (t = 0; t < b->nf_cur; t++) prefix_one(b, &c->pics[s * F + t], tmp);
     free(tmp);
 }
@@ -536,7 +537,7 @@ static void prefix_picture(void *ctx, int t, int tid)
     side_ctx *c = (side_ctx *)ctx;
     uint8_t *tmp = (uint8_t *)malloc(((size_t)c->b->nblk * 8 + 64) * 4 + 64);
     (void)tid;
-    if (!tmp) return;
+    if (!tmp) { c->rc = DSVG_ERR_ARG; return; }
     prefix_one(c->b, &c->pics[t], tmp);
     free(tmp);
 }
@@ -787,12 +788,15 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         const int devrc = abr && b->abr_dev;                    /* rate control on the device: enqueued like a CRF call */
         const int serial = abr && !devrc;
         side_ctx sc_;
-        sc_.b = b; sc_.pics = pics;
+        sc_.b = b; sc_.pics = pics; sc_.rc = DSVG_OK;
         if (serial && !abr_out) return DSVG_ERR_ARG;
         if (abr && b->chains) return DSVG_ERR_ARG;
         if (abr) {                                              /* ABR: the length of every packet prefix feeds the rate control */
-            if (S == 1 && nf > 1) dsv1_par_for(nf, prefix_picture, &sc_);   /* (one stream, a gathered group: its pictures are the parallel items) */
+            /* the pictures are the parallel items (a picture's prefix depends on nothing but its own side information): the GPU
+             * waits for this -- with two 4K streams of 30 frames a loop over streams took 5 ms on two threads */
+            if (S == 1 || nf == F) dsv1_par_for(S * nf, prefix_picture, &sc_);
             else dsv1_par_for(S, prefix_stream, &sc_);
+            if (sc_.rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); return sc_.rc; }
         }
         if (b->chains) {
             if ((rc = code_chains(b, pics, nf, par))) return rc;
@@ -851,6 +855,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
         if (b->chains) dsv1_par_for(nf, prefix_picture, &sc_);      /* (one stream: the pictures are the independent items) */
         else if (!abr) dsv1_par_for(S, prefix_stream, &sc_);
+        if (sc_.rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); return sc_.rc; }
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
         b->nf_pending[par] = nf;
     }
@@ -874,7 +879,10 @@ int dsv1_batch_stage(dsv1_batch *b, const void *yuv_host) { return stage_n(b, yu
 
 int dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out)
 {
-    return batch_submit_impl(b, yuv, yuv_on_device, out, 0, 1);
+    /* a device clip's chroma stays where it is (the coding kernels read it until the batch is collected) only when the caller
+     * said it holds the clip that long: DSV1_CLIP_HELD.  A plain device clip is copied whole -- the call is done with it when
+     * it returns, as it was before round 3 (advisor, round 3) */
+    return batch_submit_impl(b, yuv, yuv_on_device != 0, out, 0, yuv_on_device == DSV1_CLIP_HELD);
 }
 
 /* Collect the OLDEST submitted batch: one gathered device-to-host copy, then packet assembly in
@@ -1102,12 +1110,10 @@ static int sess_pop(enc_sess *ss, DSV_BUF *bufs, int max)
     return n;
 }
 
-void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:766-778 */
+/* everything the session still holds -- frames waiting for a full batch, batches in flight -- coded and collected into the
+ * backlog (end of stream, or the caller's flush calls dsv_enc(enc, NULL, bufs)) */
+static void sess_flush(enc_sess *ss)
 {
-    bitw w;
-    enc_sess *ss = (enc_sess *)enc->ref;
-    uint8_t eos[DSV_PACKET_HDR_SIZE];
-    unsigned rest = 0;
     if (ss && ss->pipelined && !ss->failed) {
         /* flush: the frames still waiting for a full batch, then everything in flight, oldest first */
         int rc = DSVG_OK;
@@ -1132,6 +1138,17 @@ void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:7
         ss->fill = 0;
         if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; }
     }
+}
+
+void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs)   /* dsv_encoder.c:766-778 */
+{
+    bitw w;
+    enc_sess *ss = (enc_sess *)enc->ref;
+    uint8_t eos[DSV_PACKET_HDR_SIZE];
+    unsigned rest = 0;
+    /* (a caller that drained the session with dsv_enc(enc, NULL, bufs) calls finds nothing left here: bufs[0] is then the EOS
+     * packet alone, exactly the reference's contract) */
+    sess_flush(ss);
     if (ss) rest = ss->backlog.len - ss->off;
     memset(eos, 0, sizeof(eos));
     bw_init(&w, eos);
@@ -1174,6 +1191,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
     int c, rc;
 
     if (!bufs) { dsv1_log(1, "null buffer list passed to encoder!"); return 0; }
+    if (!frame && !enc->ref) return 0;                   /* a flush call before the first frame: nothing is owed */
     if (!enc->ref) {
         const char *e = getenv("DSV1_ENC_PIPELINE"), *la = getenv("DSV1_ENC_LOOKAHEAD");
         int chains = 0;
@@ -1227,6 +1245,13 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         enc->ref = ss;
     }
     ss = (enc_sess *)enc->ref;
+    if (!frame) {
+        /* FLUSH CALL (an extension: the reference would dereference the null frame): code and collect everything the session
+         * still holds, then hand out the packets owed like any other call -- at most two per call (metadata + picture), one
+         * packet per DSV_BUF; 0 = drained.  After that dsv_enc_end_of_stream returns exactly one EOS packet. */
+        sess_flush(ss);
+        return sess_pop(ss, bufs, 2);
+    }
     if (ss->failed || ss->fill >= ss->F) {
         /* an earlier device error ended the session (never copy past the pinned batch) */
         if (!ss->failed) { ss->failed = 1; ss->fill = 0; }

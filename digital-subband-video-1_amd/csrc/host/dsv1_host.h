@@ -85,6 +85,7 @@ extern int dsv1_device;
  * half of this process's share of the cores)) */
 typedef void (*dsv1_par_fn)(void *ctx, int s, int tid);
 void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx);
+void dsv1_par_for_long(int S, dsv1_par_fn fn, void *ctx);      /* the same for a few long items (two already run in parallel) */
 /* the default size of that pool as a function of the host (dsv1_util.c); exported so that the rule can be tested without the host it is for */
 int dsv1_host_threads_rule(long online, long allowed, long ranks, int pinned_by_launcher);
 

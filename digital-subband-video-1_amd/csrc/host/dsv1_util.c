@@ -357,11 +357,15 @@ static void *pool_worker(void *p)
     }
     return NULL;
 }
-void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx)
+static void par_for_min(int S, dsv1_par_fn fn, void *ctx, int min_items);
+void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx) { par_for_min(S, fn, ctx, 4); }   /* (a wake-up costs ~30 us: small loops stay on the caller) */
+/* the same for a FEW LONG items (the coding streams' launch sequences of a call: milliseconds each): two items already go parallel */
+void dsv1_par_for_long(int S, dsv1_par_fn fn, void *ctx) { par_for_min(S, fn, ctx, 2); }
+static void par_for_min(int S, dsv1_par_fn fn, void *ctx, int min_items)
 {
     const int nthr = par_threads(S);
     int i;
-    if (nthr <= 1 || S < 4) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }     /* (a wake-up costs ~30 us: ABR codes one picture of a stream or two per call) */
+    if (nthr <= 1 || S < min_items) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }
     pthread_mutex_lock(&g_pool.call);
     pthread_mutex_lock(&g_pool.mu);
     {

@@ -587,13 +587,18 @@ static __device__ void hz_fix_overlaps(const JobDev &jb, const HzPlane &hp, int 
 // chip, on the critical path of every frame step.  Planes with more than 2048 chunks are walked in tiles with carries.
 #define SCAN_THREADS 256
 #define SCAN_ITEMS 8            // chunks per thread and tile
-#define SCAN_TILE (SCAN_THREADS * SCAN_ITEMS)
 
-__global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restrict__ jobs)
+// Round 4: the scan sits on the critical path of every frame step of a small batch (27 us per 4K 4:4:4 picture) for its latency:
+// a thread read its eight chunk summaries one dependent load after the other, twice.  Now every field a pass needs of the
+// thread's chunks is requested in ONE batch of independent loads (nnz; then first / last position, last value, inner bits), the
+// only dependent fetch left is the carried-in predecessor's two words, and a launch with few workgroups takes NT = 1024 threads.
+template <int NT>
+__global__ __launch_bounds__(NT) void k_hz_scan(const JobDev *__restrict__ jobs)
 {
+    constexpr int TILE = NT * SCAN_ITEMS;
     __shared__ unsigned long long s_u64[16];
     __shared__ int s_i[16];
-    __shared__ int s_incl_ne[SCAN_THREADS];
+    __shared__ int s_incl_ne[NT];
     __shared__ int s_c_ne, s_c_nnz;                            // carries into the next tile: last non-empty chunk, entries so far,
     __shared__ unsigned long long s_c_bits;                    // bits so far
     const int job = blockIdx.y, c = blockIdx.x;
@@ -601,25 +606,33 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
     const HzPlane &hp = jb.hz[c];
     HzChunkSum *cs = jb.chunks + jb.chunk_off[c];
     const int n = hp.nchunks;
-    if (n > 0 && !jb.fused) hz_fix_overlaps(jb, hp, c, SCAN_THREADS);   // the fused path stores final values itself
+    if (n > 0 && !jb.fused) hz_fix_overlaps(jb, hp, c, NT);   // the fused path stores final values itself
     if (threadIdx.x == 0) { s_c_ne = -1; s_c_nnz = 0; s_c_bits = 0ull; }
     __syncthreads();
-    for (int t0 = 0; t0 < n; t0 += SCAN_TILE) {
-        const int limit = min(n, t0 + SCAN_TILE);
-        const int per = (limit - t0 + SCAN_THREADS - 1) / SCAN_THREADS;     // <= SCAN_ITEMS
+    for (int t0 = 0; t0 < n; t0 += TILE) {
+        const int limit = min(n, t0 + TILE);
+        const int per = (limit - t0 + NT - 1) / NT;     // <= SCAN_ITEMS
         const int first = t0 + threadIdx.x * per;
         const int c_ne = s_c_ne, c_nnz = s_c_nnz;
         const unsigned long long c_bits = s_c_bits;
 
         // pass 1: index of the last non-empty chunk at or before each chunk (max-scan), nnz prefix
+        int z[SCAN_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) z[i] = (i < per && first + i < limit) ? cs[first + i].nnz : 0;
         int lastne = -1, nnzsum = 0;
-        for (int i = 0; i < per; i++) {
-            const int ch = first + i;
-            if (ch < limit) {
-                const int z = cs[ch].nnz;
-                if (z > 0) lastne = ch;
-                nnzsum += z;
-            }
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            if (z[i] > 0) lastne = first + i;
+            nnzsum += z[i];
+        }
+        // the fields pass 2 needs of this thread's non-empty chunks: requested now, under the two block scans
+        int fpos[SCAN_ITEMS], lpos[SCAN_ITEMS], lval[SCAN_ITEMS];
+        unsigned inner[SCAN_ITEMS];
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; i++) {
+            fpos[i] = lpos[i] = lval[i] = 0; inner[i] = 0;
+            if (z[i] > 0) { const HzChunkSum &q = cs[first + i]; fpos[i] = q.first_pos; lpos[i] = q.last_pos; lval[i] = q.last_val; inner[i] = q.bits_inner; }
         }
         const int incl_ne = max(block_scan_incl<int>(lastne, -1, OpMaxI(), s_i), c_ne);
         __syncthreads();
@@ -627,32 +640,27 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
         __syncthreads();
         // exclusive: last non-empty chunk strictly before this thread's first chunk
         const int carry_ne = threadIdx.x ? s_incl_ne[threadIdx.x - 1] : c_ne;
+        int ppos = -1, pval = 0;                               // ... and its last entry (the one dependent fetch of the tile)
+        if (carry_ne >= 0) { ppos = cs[carry_ne].last_pos; pval = cs[carry_ne].last_val; }
 
         const int incl_nnz = block_scan_incl<int>(nnzsum, 0, OpAddI(), s_i);
         int nzbase = c_nnz + incl_nnz - nnzsum;
 
         // pass 2: per chunk first-symbol length, chunk bit totals
         unsigned long long mybits = 0;
-        int prev_ne = carry_ne;
+        bool have_prev = carry_ne >= 0;
         unsigned long long cb[SCAN_ITEMS];
         int pp[SCAN_ITEMS], pvv[SCAN_ITEMS];
 #pragma unroll
         for (int i = 0; i < SCAN_ITEMS; i++) {
-            cb[i] = 0; pp[i] = -1; pvv[i] = 0;
-            const int ch = first + i;
-            if (i < per && ch < limit) {
-                const HzChunkSum s = cs[ch];
-                int ppos = -1, pval = 0;
-                if (prev_ne >= 0) { ppos = cs[prev_ne].last_pos; pval = cs[prev_ne].last_val; }
-                pp[i] = ppos; pvv[i] = pval;
-                if (s.nnz > 0) {
-                    unsigned b = (unsigned)len_ueg((unsigned)(s.first_pos - ppos - 1));
-                    if (prev_ne >= 0) b += (unsigned)len_neg(pval);
-                    cb[i] = (unsigned long long)b + s.bits_inner;
-                    prev_ne = ch;
-                }
-                mybits += cb[i];
+            cb[i] = 0; pp[i] = ppos; pvv[i] = pval;
+            if (z[i] > 0) {
+                unsigned b = (unsigned)len_ueg((unsigned)(fpos[i] - ppos - 1));
+                if (have_prev) b += (unsigned)len_neg(pval);
+                cb[i] = (unsigned long long)b + inner[i];
+                have_prev = true; ppos = lpos[i]; pval = lval[i];
             }
+            mybits += cb[i];
         }
         const unsigned long long incl_bits = block_scan_incl<unsigned long long>(mybits, 0ull, OpAddU64(), s_u64);
         unsigned long long off = c_bits + incl_bits - mybits;
@@ -665,11 +673,11 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
                 cs[ch].prev_val = pvv[i];
                 cs[ch].nz_base = nzbase;
                 off += cb[i];
-                nzbase += cs[ch].nnz;
+                nzbase += z[i];
             }
         }
         __syncthreads();                                       // every thread has read the carries of this tile
-        if (threadIdx.x == SCAN_THREADS - 1) { s_c_ne = incl_ne; s_c_nnz = c_nnz + incl_nnz; s_c_bits = c_bits + incl_bits; }
+        if (threadIdx.x == NT - 1) { s_c_ne = incl_ne; s_c_nnz = c_nnz + incl_nnz; s_c_bits = c_bits + incl_bits; }
         __syncthreads();
     }
     __shared__ unsigned long long s_total;
@@ -688,7 +696,7 @@ __global__ __launch_bounds__(SCAN_THREADS) void k_hz_scan(const JobDev *__restri
     // the emit kernel ORs into the payload (bs.c:50-63 semantics): clear exactly the words it will touch
     unsigned *out32 = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
     const unsigned nwords = (unsigned)((s_total + 31) >> 5) + 4;
-    for (unsigned i = threadIdx.x; i < nwords; i += SCAN_THREADS) out32[i] = 0;
+    for (unsigned i = threadIdx.x; i < nwords; i += NT) out32[i] = 0;
 }
 
 // compact the packed planes of many pictures into one contiguous buffer (one D2H instead of 3 per picture)
@@ -1511,7 +1519,9 @@ void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunk
         PE();
     }
     PB(KID_HZ_SCAN, 0.0);
-    hipLaunchKernelGGL(k_hz_scan, dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
+    // few workgroups (small batches: a link of a latency-bound chain): 1024 threads per plane; many: 256 (see above)
+    if (3 * njobs <= 96) hipLaunchKernelGGL((k_hz_scan<1024>), dim3(3, njobs), dim3(1024), 0, st, jobs);
+    else hipLaunchKernelGGL((k_hz_scan<SCAN_THREADS>), dim3(3, njobs), dim3(SCAN_THREADS), 0, st, jobs);
     PE();
     if (nplain + ndense > 0) {
         PB(KID_HZ_EMIT, 0.0);

@@ -1615,26 +1615,48 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restr
 
 // encoder: forward tail, the LL quantiser on its band, inverse tail -- one kernel, the band never leaves LDS in between
 // (k_fwd_tail + k_hz_quant<true>'s share + k_inv_tail).  Cell 0 is the DC, which travels unquantised (hzcc.c:161,457-460).
-__global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
+// Round 4: on the critical path of every frame step of a SMALL batch this kernel was the longest link (46 us per 4K 4:4:4
+// picture: config 5) -- for its latency, not its work: the band came in by one dependent load per iteration (32 round trips),
+// every cell index cost two 32-bit divisions by a runtime width, the quantiser one more per cell.  Now: the band arrives in
+// batches of TQ_LD independent loads per thread, cell -> (row, column) is a multiply-high (exact: cell * width < 2^32), the
+// quantiser's division by the region's ONE quantiser is a multiply-high with two correction steps, a level's loop ends with its
+// cells, and a launch with few workgroups (NT = 1024: the small batches) puts four times the threads on each band.
+#define TQ_LD 8
+static __device__ __forceinline__ unsigned tq_div(unsigned n, unsigned d, unsigned inv) // n / d with inv = ceil(2^32 / d) (wraps to 0 for d = 1): exact for n * d < 2^32
+{
+    return d == 1u ? n : __umulhi(n, inv);
+}
+template <int NT>
+__global__ __launch_bounds__(NT) void k_tail_q(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     extern __shared__ int T[];
+    constexpr int MAXC = TAIL_MAXC * TAIL_THREADS / NT;          // cells per thread at the first tail level (host checks the total)
     const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
-    int32_t *s5 = jb.s5 + g.s5off;
-    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) T[i] = s5[i];
+    const auto s5 = dsvg_global(jb.s5 + g.s5off);
+    const int tid = threadIdx.x;
+    for (int i0 = 0; i0 < n3; i0 += NT * TQ_LD) {                 // batches of independent loads: one round trip per batch
+        int v[TQ_LD];
+#pragma unroll
+        for (int u = 0; u < TQ_LD; u++) { const int i = i0 + tid + NT * u; v[u] = i < n3 ? s5[i] : 0; }
+#pragma unroll
+        for (int u = 0; u < TQ_LD; u++) { const int i = i0 + tid + NT * u; if (i < n3) T[i] = v[u]; }
+    }
     __syncthreads();
     for (int lvl = TAIL_LV; lvl <= g.lvls; lvl++) {
         const int ws = DSVG_RSU(W, lvl - 1), hs = DSVG_RSU(H, lvl - 1);
         const int wo = DSVG_RSU(W, lvl), ho = DSVG_RSU(H, lvl);
         const int ncell = wo * ho;
-        int ll[TAIL_MAXC], lh[TAIL_MAXC], hl[TAIL_MAXC], hh[TAIL_MAXC];
+        const unsigned inv = 0xFFFFFFFFu / (unsigned)wo + 1u;
+        int ll[MAXC], lh[MAXC], hl[MAXC], hh[MAXC];
 #pragma unroll
-        for (int k = 0; k < TAIL_MAXC; k++) {
-            const int cell = threadIdx.x + k * TAIL_THREADS;
+        for (int k = 0; k < MAXC; k++) {
+            if (k * NT >= ncell) break;                            // (workgroup-uniform)
+            const int cell = tid + k * NT;
             if (cell < ncell) {
-                const int cy = cell / wo, cx = cell - cy * wo;
+                const int cy = (int)tq_div((unsigned)cell, (unsigned)wo, inv), cx = cell - cy * wo;
                 const bool hasR = 2 * cx + 1 < ws, hasB = 2 * cy + 1 < hs;
                 const int *p = T + 2 * cy * w3 + 2 * cx;
                 const int a = p[0];
@@ -1649,10 +1671,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restric
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TAIL_MAXC; k++) {
-            const int cell = threadIdx.x + k * TAIL_THREADS;
+        for (int k = 0; k < MAXC; k++) {
+            if (k * NT >= ncell) break;
+            const int cell = tid + k * NT;
             if (cell < ncell) {
-                const int cy = cell / wo, cx = cell - cy * wo;
+                const int cy = (int)tq_div((unsigned)cell, (unsigned)wo, inv), cx = cell - cy * wo;
                 const bool hasR = 2 * cx + 1 < ws, hasB = 2 * cy + 1 < hs;
                 T[cy * w3 + cx] = ll[k];
                 if (hasR) T[cy * w3 + wo + cx] = lh[k];
@@ -1662,14 +1685,25 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restric
         }
         __syncthreads();
     }
-    {   // the quantiser: symbols out, dequantised values stay in LDS
+    {   // the quantiser (quant hzcc.c:94-112 with the region's one quantiser): symbols out, dequantised values stay in LDS
         const HzRegion &r0 = jb.hz[c].r[0];
         const int qp = r0.qp, sw = r0.sw;
-        int32_t *ls = jb.llsym + jb.ll_off[c];
-        for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) {
-            const int y = i / w3, x = i - y * w3;
+        const unsigned q2 = (unsigned)qp << 1, qinv = 0xFFFFFFFFu / q2;             // floor((2^32 - 1) / 2q): the estimate below is never too large
+        const unsigned winv = 0xFFFFFFFFu / (unsigned)w3 + 1u;
+        const auto ls = dsvg_global(jb.llsym + jb.ll_off[c]);
+        for (int i = tid; i < n3; i += NT) {
+            const int y = (int)tq_div((unsigned)i, (unsigned)w3, winv), x = i - y * w3;
             if (i == 0) { jb.psum[c].dc = T[0]; ls[0] = 0; continue; }
-            const int v = hzq_lo(T[i], qp);
+            const int tv = T[i];
+            const unsigned m = (unsigned)(tv < 0 ? -tv : tv) << 1;
+            int v = 0;
+            if (m > (unsigned)qp) {
+                const unsigned n1 = m + 1u;
+                unsigned e = __umulhi(n1, qinv), r = n1 - e * q2;                    // e <= n1 / 2q <= e + 2
+                if (r >= q2) { e++; r -= q2; }
+                if (r >= q2) { e++; r -= q2; }
+                v = tv < 0 ? -(int)e : (int)e;
+            }
             ls[y * sw + x] = v;
             T[i] = v ? hzdq_lo(v, qp) : 0;
         }
@@ -1682,12 +1716,14 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restric
         const int wfull = ws & ~1, hfull = hs & ~1;
         const int ncell = wo * ho;
         const int hqp = jb.hqp[lvl];
-        int o0[TAIL_MAXC], o1[TAIL_MAXC], o2[TAIL_MAXC], o3[TAIL_MAXC];
+        const unsigned inv = 0xFFFFFFFFu / (unsigned)wo + 1u;
+        int o0[MAXC], o1[MAXC], o2[MAXC], o3[MAXC];
 #pragma unroll
-        for (int k = 0; k < TAIL_MAXC; k++) {
-            const int cell = threadIdx.x + k * TAIL_THREADS;
+        for (int k = 0; k < MAXC; k++) {
+            if (k * NT >= ncell) break;
+            const int cell = tid + k * NT;
             if (cell < ncell) {
-                const int cy = cell / wo, cx = cell - cy * wo;
+                const int cy = (int)tq_div((unsigned)cell, (unsigned)wo, inv), cx = cell - cy * wo;
                 const int x = 2 * cx, y = 2 * cy;
                 const bool hasR = x + 1 < ws, hasB = y + 1 < hs;
                 const int *pLL = T + cy * w3 + cx;
@@ -1707,10 +1743,11 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restric
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < TAIL_MAXC; k++) {
-            const int cell = threadIdx.x + k * TAIL_THREADS;
+        for (int k = 0; k < MAXC; k++) {
+            if (k * NT >= ncell) break;
+            const int cell = tid + k * NT;
             if (cell < ncell) {
-                const int cy = cell / wo, cx = cell - cy * wo;
+                const int cy = (int)tq_div((unsigned)cell, (unsigned)wo, inv), cx = cell - cy * wo;
                 const int x = 2 * cx, y = 2 * cy;
                 const bool hasR = x + 1 < ws, hasB = y + 1 < hs;
                 int *o = T + y * w3 + x;
@@ -1724,7 +1761,7 @@ __global__ __launch_bounds__(TAIL_THREADS) void k_tail_q(const JobDev *__restric
         }
         __syncthreads();
     }
-    for (int i = threadIdx.x; i < n3; i += TAIL_THREADS) s5[i] = T[i];
+    for (int i = tid; i < n3; i += NT) s5[i] = T[i];
 }
 
 // --------------------------------------------------------------------------------------------
@@ -3077,7 +3114,10 @@ void launch_tail_q(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 
         s3 += (double)G.g[c].w5 * G.g[c].h5 * njobs;
     }
     PB(KID_TAIL_Q, s3 * 8.0);
-    hipLaunchKernelGGL(k_tail_q, dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
+    // few workgroups (a small batch: the kernel is a link of a latency-bound chain): 1024 threads per band; many: 256 -- a
+    // 16-wave workgroup would wait for a whole CU's worth of free wave slots beside the other coding stream's kernels
+    if (njobs * npl <= 96) hipLaunchKernelGGL((k_tail_q<1024>), dim3(njobs * npl), dim3(1024), lds, st, jobs, G, c0, npl);
+    else hipLaunchKernelGGL((k_tail_q<TAIL_THREADS>), dim3(njobs * npl), dim3(TAIL_THREADS), lds, st, jobs, G, c0, npl);
     PE();
 }
 
@@ -3200,7 +3240,8 @@ void sbt_set_func_attributes()
 {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_fwd_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_inv_tail), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_q), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_q<TAIL_THREADS>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k_tail_q<1024>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256);
 }
 
 #ifdef DSVG_CLOCK_PROBE

@@ -119,7 +119,13 @@ void dsv_enc_start(DSV_ENCODER *enc);
  * dsv_enc_force_metadata) act on the frames not yet submitted, i.e. up to a lookahead late.  dsv_enc_free without
  * dsv_enc_end_of_stream drops the frames still buffered (and logs it).  ABR streams (their pictures are coded one after the
  * other: every packet's size feeds the next quantiser) gather 32 frames (DSV1_ENC_LOOKAHEAD) for a common analysis pass: the same
- * contract with a shorter lookahead, the same bytes as the frame-synchronous encoder. */
+ * contract with a shorter lookahead, the same bytes as the frame-synchronous encoder.
+ * THE REFERENCE'S PACKET CONTRACT (dsv_encoder.c:766-810: one packet per DSV_BUF, at most two per dsv_enc call, exactly one EOS
+ * packet from dsv_enc_end_of_stream) for a library caller that cannot split a buffer: before dsv_enc_end_of_stream, call
+ *     while ((n = dsv_enc(enc, NULL, bufs)) > 0) { ...write bufs[0 .. n-1]... }
+ * -- a FLUSH CALL (frame == NULL, an extension: the reference would crash on it).  The first one codes and collects everything
+ * the session still holds; each returns up to two whole packets, one per DSV_BUF, in stream order; 0 = drained.
+ * dsv_enc_end_of_stream then returns the 14-byte EOS packet alone. */
 int  dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs);
 void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs);
 
@@ -164,8 +170,9 @@ int  dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int 
 void dsv1_batch_close(dsv1_batch *b);
 void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
 /* Encode frames_per_call frames of every stream.  yuv: [stream][frame] tightly packed planar frames,
- * host or device memory.  A DEVICE clip (yuv_on_device = 1) must stay unchanged until the batch has been collected: its
- * chroma planes are read in place by the coding kernels (dsvg_load_frames_map_ex) -- only luma is copied.  For each stream s the packets are appended to out[s] (a growing buffer the
+ * host (yuv_on_device = 0) or device memory (1).  The call has finished with the clip when it returns (a device clip's chroma
+ * planes are read in place by the coding kernels, dsvg_load_frames_map_ex, only luma is copied -- and the call returns after
+ * the batch has been collected).  For each stream s the packets are appended to out[s] (a growing buffer the
  * caller owns: data = NULL / len = 0 to start; freed with dsv_free).  Returns 0 or a DSVG_ERR_*. */
 int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
 /* Pipelined form (CRF): submit enqueues a batch and returns while its residual coding still runs on
@@ -174,6 +181,11 @@ int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BU
  * pyramid, motion estimation: source pixels only) then overlaps the residual coding of batch i on a
  * second HIP stream, and the host packet assembly overlaps both.  With ABR, submit already assembles
  * into out (each quantiser needs the previous packet size) and collect only releases the slot. */
+/* yuv_on_device for dsv1_batch_submit: 0 = host memory, 1 = device memory, copied whole -- submit has finished with the clip
+ * when it returns; DSV1_CLIP_HELD = device memory that the caller keeps UNCHANGED until dsv1_batch_collect of this batch has
+ * returned: chroma is then read in place by the coding kernels and only luma is copied (what bench.py times: 21 % less traffic
+ * in the load stage).  Opt-in since round 4: a caller that reuses its clip right after submit gets correct streams with 1. */
+#define DSV1_CLIP_HELD 2
 int  dsv1_batch_submit(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *out);
 int  dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out);
 /* Host-resident input (the .yuv reader of dsv_main.c:394-421): announce the host clip of a coming submit.  Its

@@ -63,3 +63,34 @@ def test_switch_gives_the_same_bytes(pkg, orc, monkeypatch):
         finally:
             b.close()
     assert outs[0] == outs[1]
+
+
+def test_plain_device_clip_may_change_right_after_submit(pkg, orc):
+    """dsv1_batch_submit(.., yuv_on_device = 1): the call has finished with the clip when it returns (advisor, round 3: the in-place
+    chroma of a HELD clip is opt-in) -- the clip is overwritten between submit and collect and the streams still equal the oracle's;
+    with DSV1_CLIP_HELD the same misuse is the caller's error and is not exercised here"""
+    L = pkg.lib()
+    L.dsvg_ctx_chroma_in_place_frames.restype = C.c_long
+    L.dsvg_ctx_chroma_in_place_frames.argtypes = [C.c_void_p]
+    w, h, fmt, S, F = 352, 288, A.SUBSAMP_420, 3, 6
+    kw = dict(qp=85, gop=12, rc_mode_cli=1)
+    clips = [A.gen_clip(w, h, fmt, 0xC1AE0 + s, 2 * F, style=s) for s in range(S)]
+    want = [A.orc_encode(clips[s], A.orc_cfg(w, h, fmt, **kw), eos=False)[0] for s in range(S)]
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **kw), S, F)
+    try:
+        got = [b""] * S
+        dev = b.upload(np.stack([clips[s][:F] for s in range(S)]))
+        garbage = np.full(S * F * clips[0].shape[1], 0x3C, dtype=np.uint8)
+        b.submit(dev, on_device=True, held=False)
+        A.chk(L, L.dsvg_dev_upload(b.ctx, dev, garbage.ctypes.data, garbage.nbytes))          # the clip is gone before the batch is collected
+        nxt = np.ascontiguousarray(np.stack([clips[s][F:] for s in range(S)]))
+        A.chk(L, L.dsvg_dev_upload(b.ctx, dev, nxt.ctypes.data, nxt.nbytes))                  # ... and reused for the next batch at once
+        b.submit(dev, on_device=True, held=False)
+        A.chk(L, L.dsvg_dev_upload(b.ctx, dev, garbage.ctypes.data, garbage.nbytes))
+        for _ in range(2):
+            got = [g + p for g, p in zip(got, b.collect())]
+        assert L.dsvg_ctx_chroma_in_place_frames(b.ctx) == 0
+    finally:
+        b.close()
+    for s in range(S):
+        assert got[s] == want[s], "stream %d differs" % s

@@ -205,6 +205,57 @@ def test_drop_in_dsv_enc_api(pkg, orc, monkeypatch, n, cli):
     assert counts[0] == 0 and max(counts) <= 2              # deferred, never more than the reference's two buffers
 
 
+@pytest.mark.parametrize("n,cli", [
+    (31, dict(qp=85, gop=12, rc_mode_cli=1)),                # CRF: two full batches + a tail
+    (31, dict(qp=60, gop=12, rc_mode_cli=0, kbps=900)),      # ABR
+    (5, dict(qp=85, gop=12, rc_mode_cli=1)),                 # shorter than one batch: everything is owed when the input ends
+])
+def test_drop_in_reference_packet_contract_with_flush_calls(pkg, orc, monkeypatch, n, cli):
+    """dsv_encoder.c:766-810 for a library caller: one packet per DSV_BUF, at most two per call, exactly ONE EOS packet from
+    dsv_enc_end_of_stream -- reached by draining the session with flush calls dsv_enc(enc, NULL, bufs) first (dsv1_api.h)"""
+    monkeypatch.setenv("DSV1_ENC_LOOKAHEAD", "12")
+    w, h, fmt = 352, 288, A.SUBSAMP_420
+    clip = A.gen_clip(w, h, fmt, 0xD209 + n, n, style=2)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli))
+    L = pkg.lib()
+    enc = pkg.make_encoder_cfg(w, h, fmt, **cli)
+    L.dsv_enc_start(C.byref(enc))
+    L.dsv_load_planar_frame.restype = C.c_void_p
+    L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    bufs = (pkg.Buf * 4)()
+    pk = []
+
+    def take(nb):
+        assert 0 <= nb <= 2
+        for i in range(nb):
+            b_ = C.string_at(bufs[i].data, bufs[i].len)
+            assert len(A.split_packets(b_)) == 1 and len(A.split_packets(b_)[0]) == len(b_)     # ONE whole packet per buffer
+            pk.append(b_)
+            L.dsv_buf_free(C.byref(bufs[i]))
+
+    assert L.dsv_enc(C.byref(enc), None, bufs) == 0          # a flush call before the first frame owes nothing
+    for t in range(n):
+        take(L.dsv_enc(C.byref(enc), L.dsv_load_planar_frame(fmt, clip[t].ctypes.data, w, h), bufs) & 3)
+    flushes = 0
+    while True:
+        nb = L.dsv_enc(C.byref(enc), None, bufs) & 3
+        if nb == 0:
+            break
+        take(nb)
+        flushes += 1
+    assert flushes >= 1
+    L.dsv_enc_end_of_stream(C.byref(enc), bufs)
+    eos = C.string_at(bufs[0].data, bufs[0].len)
+    L.dsv_buf_free(C.byref(bufs[0]))
+    L.dsv_enc_free(C.byref(enc))
+    assert len(eos) == 14 and eos[5] == 0x10                 # the EOS packet alone
+    out = b"".join(pk) + eos
+    assert out == want, explain(out, want)
+    # a metadata packet never travels without the picture that follows it (dsv_encoder.c:804-810)
+    assert all(not (p[5] == 0 and i + 1 < len(pk) and not (pk[i + 1][5] & 4)) for i, p in enumerate(pk))
+
+
 @pytest.mark.parametrize("rc", [1, 0])
 def test_drop_in_dsv_enc_unpipelined_switch(pkg, orc, monkeypatch, rc):
     """DSV1_ENC_PIPELINE=0: one picture per call, CRF and ABR"""

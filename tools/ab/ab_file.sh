@@ -8,7 +8,11 @@ d=json.loads(sys.stdin.read()); t=d['roofline']['all_kernels_ms_one_step']
 ks='$KS'.split()
 print('$1', d['value'], d['ms_per_step'], 'sum %.2f' % sum(t.values()), {k:v for k,v in t.items() if any(x in k for x in ks)})"; }
 one new; one new
-cp $F /tmp/ab_keep; cp $ALT $F
+cp $F /tmp/ab_keep
+# the source and the shipped build come back whatever happens in between (a failed alt build, an interrupt)
+restore() { cp /tmp/ab_keep $F; touch $F; make -C digital-subband-video-1_amd/csrc -j8 > /dev/null 2>&1; }
+trap restore EXIT
+cp $ALT $F
 make -C digital-subband-video-1_amd/csrc -j8 > /dev/null 2>&1
 one alt; one alt
 cp /tmp/ab_keep $F

@@ -1,6 +1,7 @@
+#!/bin/bash
 # one counter pass WITH the kernel trace of the same run: are GRBM_GUI_ACTIVE / SQ_BUSY_CYCLES consistent with the dispatch durations?
 cd /tmp && export TMPDIR=/tmp
-REPO=$GRAFT_REPO_ROOT
+REPO=${GRAFT_REPO_ROOT:-$OLDPWD}
 OUT=$REPO/gpurun_out/clk
 mkdir -p $OUT
 PB="python3 $REPO/bench.py --cpu-gops 0 --steps 1 --warmup 1 --gops 160 --prof-kernel none --no-extras"

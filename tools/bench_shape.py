@@ -24,7 +24,7 @@ b = pkg.Batch(cfg, gops, F, device=0)
 d = b.upload(batch_in)
 b.encode(d, on_device=True)
 t0 = time.perf_counter()
-if rc == 1:
+if rc == 1 or os.environ.get('DSV1_ABR_SERIAL', '0') in ('', '0'):      # ABR pipelines too since round 4 (rate control on the device)
     b.submit(d, on_device=True)
     for _ in range(steps):
         b.submit(d, on_device=True); outs = b.collect(copy=False)
