@@ -65,7 +65,7 @@ struct Slab {
     X(KID_HZ_QUANT, "void k_hz_quant<false>") X(KID_HZ_QUANT_LL, "void k_hz_quant<true>") X(KID_HZ_COLLECT, "k_hz_collect") X(KID_TAIL_Q, "k_tail_q") X(KID_INV_P_TILE_F, "void k_inv_p_tile<true>") X(KID_INV_P_TILE, "void k_inv_p_tile<false>") X(KID_HZ_COLLECT_LIST, "k_hz_collect_list") X(KID_HZ_EMIT_LIST, "k_hz_emit_list") X(KID_HZ_SCAN, "k_hz_scan") \
     X(KID_HZ_EMIT, "k_hz_emit") X(KID_HZ_PARSE, "k_hz_parse") X(KID_HZ_CODES, "k_hz_codes") X(KID_HZ_POSITIONS, "k_hz_positions") X(KID_HZ_SCATTER, "k_hz_scatter_lv") \
     X(KID_INV_TAIL, "k_inv_tail") X(KID_INV_PATCH_C, "k_inv_patch_c") \
-    X(KID_INV_TILE_54_F, "void k_inv_haar_tile<true, 2, false>") X(KID_INV_TILE_54, "void k_inv_haar_tile<false, 2, false>") \
+    X(KID_INV_TILE_54_F, "void k_inv_haar_tile<true, 2, false>") X(KID_INV_TILE_54, "void k_inv_haar_tile<false, 2, false>") X(KID_INV_TILE_54_ALL, "k_inv_tile54_all") \
     X(KID_INV_TILE_PIX_SYM_F, "void k_inv_haar_tile<true, 0, true>") X(KID_INV_TILE_PIX_SYM, "void k_inv_haar_tile<false, 0, true>") \
     X(KID_INV_TILE_PIX_F, "void k_inv_haar_tile<true, 0, false>") X(KID_INV_TILE_PIX, "void k_inv_haar_tile<false, 0, false>") \
     X(KID_INV_TILE_S1_F, "void k_inv_haar_tile<true, 1, false>") X(KID_INV_TILE_S1, "void k_inv_haar_tile<false, 1, false>") \

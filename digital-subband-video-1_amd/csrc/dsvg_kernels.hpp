@@ -40,6 +40,7 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
 bool mc_fusable(const struct McGeo &MG);
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1,
                     int insym = 0, int patch_kernel = 0);   // patch_kernel: sparse P pictures (flags valid, prediction given): unfiltered planes take k_inv_patch_c
+void launch_inv54_all(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, Prof *pf = nullptr);   // levels 5..4 of all planes: then launch_inv_sbt(.., with_tail | 2)
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
 void launch_fwd_mid4(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, bool llq, Prof *pf = nullptr);   // levels 4..5: launch_fwd_sbt does it itself unless fused >= 3
 void launch_tail_q(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, Prof *pf = nullptr);   // fused >= 2 pictures: forward tail + LL quantiser + inverse tail

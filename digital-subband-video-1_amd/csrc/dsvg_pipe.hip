@@ -932,13 +932,17 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
     if (!st) st = c->st;
     const JobDev *jd = c->jobs_d + d0;
     if (!tail_done) launch_sbt_tail(st, jd, n, c->G, 0, 3, 1, &c->prof);      // all planes, I and P jobs alike (encoder with llq: k_tail_q did it)
+    // levels 5..4 of every plane of every job (I and P alike) in ONE launch (round 4: up to three launches less per frame step)
+    static const bool no54all = getenv("DSV1_NO_INV54_ALL") != nullptr;       // (A/B)
+    const int wt = no54all ? 0 : 2;
+    if (wt) launch_inv54_all(st, jd, n, c->G, &c->prof);
     if (nI > 0) {
-        launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, 0, insym & 1);
-        launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, 0, insym & 1);
+        launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, wt, insym & 1);
+        launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, wt, insym & 1);
     }
     if (n > nI) {
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, 0, (insym >> 1) & 1, ((insym >> 1) & 1) && !c->no_patch_kernel);
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, 0, (insym >> 2) & 1, ((insym >> 2) & 1) && !c->no_patch_kernel);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, wt, (insym >> 1) & 1, ((insym >> 1) & 1) && !c->no_patch_kernel);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, wt, (insym >> 2) & 1, ((insym >> 2) & 1) && !c->no_patch_kernel);
     }
     launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof, lazy_border ? jd : nullptr);
     return DSVG_OK;

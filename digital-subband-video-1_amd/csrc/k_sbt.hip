@@ -2431,14 +2431,12 @@ __global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev
 // whose level 1 is the B4T kernel below).  MODE 2: levels 5,4 from s5 -> LL3 in s3 (every picture; feeds the
 // other two modes).  The tile is IT_TX x IT_TY cells of the mode's top level.
 template <bool FILT, int MODE, bool SYM>
-__global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int bxofs, int byofs)
+static __device__ __forceinline__ void inv_haar_tile_body(const JobDev *__restrict__ jobs, const SbtGeo3 &G, int c0, int npl, int bxofs, int byofs,
+                                                          int *__restrict__ A3, int *__restrict__ A2, int *__restrict__ A1)
 {
     static_assert(!SYM || MODE != 2, "levels >= 4 live in the LL region: int32 coefficients");
     constexpr bool TO_PIX = (MODE == 0);
     constexpr int TOP = (MODE == 2) ? 5 : 3;
-    __shared__ int A3[A3H * A3W];
-    __shared__ int A2[A2H * A2W];
-    __shared__ int A1[A1H * A1W];
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
@@ -2459,6 +2457,8 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
     const int I0 = bx * IT_TX, J0 = by * IT_TY;
     const int tid = threadIdx.x;
     const bool isP = jb.isP != 0;
+    // (k_inv_tile54_all: one grid sized for the largest plane serves all three -- a tile beyond this plane's band has nothing to do)
+    if (MODE == 2 && g.lvls >= 5 && (I0 >= inw || J0 >= inh)) return;
 
     if (MODE == 2 && g.lvls < 5) {
         // tiny planes (<= 16 samples a side): level 5 (and 4) do not exist, the 1x1 band passes through
@@ -2724,6 +2724,25 @@ __global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict_
             }
         }
     }
+}
+
+template <bool FILT, int MODE, bool SYM>
+__global__ __launch_bounds__(256) void k_inv_haar_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int bxofs, int byofs)
+{
+    __shared__ int A3[A3H * A3W];
+    __shared__ int A2[A2H * A2W];
+    __shared__ int A1[A1H * A1W];
+    inv_haar_tile_body<FILT, MODE, SYM>(jobs, G, c0, npl, bxofs, byofs, A3, A2, A1);
+}
+// levels 5, 4 (LL5 -> LL3) of ALL THREE planes of every job in one launch (round 4: a launch less on the chain of every frame
+// step): blockIdx.z = 3 * job + plane, the grid is the luma band's; luma takes the filtered body (sbt.c:438-574), chroma the plain one
+__global__ __launch_bounds__(256) void k_inv_tile54_all(const JobDev *__restrict__ jobs, SbtGeo3 G)
+{
+    __shared__ int A3[A3H * A3W];
+    __shared__ int A2[A2H * A2W];
+    __shared__ int A1[A1H * A1W];
+    if (blockIdx.z % 3 == 0) inv_haar_tile_body<true, 2, false>(jobs, G, 0, 3, 0, 0, A3, A2, A1);
+    else inv_haar_tile_body<false, 2, false>(jobs, G, 0, 3, 0, 0, A3, A2, A1);
 }
 
 // --------------------------------------------------------------------------------------------
@@ -3138,6 +3157,20 @@ void launch_mc_patch(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
     PE();
 }
 
+// levels 5..4 of all three planes of njobs pictures (I and P alike) in one launch; the callers then pass with_tail | 2 to launch_inv_sbt
+void launch_inv54_all(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, Prof *pf)
+{
+    int mw = 0, mh = 0;
+    double s3 = 0;
+    for (int c = 0; c < 3; c++) {
+        mw = std::max(mw, G.g[c].w5); mh = std::max(mh, G.g[c].h5);
+        s3 += (double)G.g[c].w3 * G.g[c].h3 * njobs;
+    }
+    PB(KID_INV_TILE_54_ALL, s3 * 8.0);
+    hipLaunchKernelGGL(k_inv_tile54_all, dim3((mw + IT_TX - 1) / IT_TX, (mh + IT_TY - 1) / IT_TY, 3 * njobs), dim3(256), 0, st, jobs, G);
+    PE();
+}
+
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail,
                     int insym, int patch_kernel)
 {
@@ -3145,12 +3178,12 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
     const bool filt = (c0 == 0);
-    if (with_tail) {
+    if (with_tail & 1) {
         PB(KID_INV_TAIL, (double)g.w5 * g.h5 * nz * 8.0);
         hipLaunchKernelGGL(k_inv_tail, dim3(nz), dim3(TAIL_THREADS), (size_t)g.w5 * g.h5 * 4, st, jobs, G, c0, npl);
         PE();
     }
-    {   // levels 5..4 (LL5 -> LL3) for every picture type
+    if (!(with_tail & 2)) {   // levels 5..4 (LL5 -> LL3) for every picture type (with_tail & 2: launch_inv54_all did them for all planes)
         const dim3 mg((g.w5 + IT_TX - 1) / IT_TX, (g.h5 + IT_TY - 1) / IT_TY, nz);
         PB(filt ? KID_INV_TILE_54_F : KID_INV_TILE_54, s3 * 8.0);
         if (filt) hipLaunchKernelGGL((k_inv_haar_tile<true, 2, false>), mg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
