@@ -1197,8 +1197,26 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         int chains = 0;
         ss = (enc_sess *)calloc(1, sizeof(*ss));
         if (!ss) { dsv1_log(1, "out of memory"); dsv_frame_ref_dec(frame); return 0; }
-        ss->pipelined = enc->rc_mode == DSV_RATE_CONTROL_CRF && !(e && atoi(e) == 0);
+        {
+            /* ABR streams are pipelined like CRF ones since round 4: their rate control runs on the device (k_rc), so a group of
+             * frames is enqueued whole and the next group's upload and analysis overlap it (DSV1_ABR_SERIAL=1: the gathered,
+             * frame-by-frame path of round 3) */
+            const char *as = getenv("DSV1_ABR_SERIAL");
+            const int abr_dev = enc->rc_mode != DSV_RATE_CONTROL_CRF && !(as && atoi(as) != 0);
+            ss->pipelined = (enc->rc_mode == DSV_RATE_CONTROL_CRF || abr_dev) && !(e && atoi(e) == 0);
+        }
         ss->F = 1;
+        if (ss->pipelined && enc->rc_mode != DSV_RATE_CONTROL_CRF) {
+            /* ABR: groups of 32 frames (DSV1_ENC_LOOKAHEAD, within 256 MB of pinned memory per half), one stream, no chains */
+            const DSV_META *m = &enc->vidmeta;
+            const int hs = (m->subsamp >> 2) & 3, vs = m->subsamp & 3;
+            const size_t fbytes = (size_t)m->width * m->height + 2 * (size_t)((m->width + (1 << hs) - 1) >> hs) * (size_t)((m->height + (1 << vs) - 1) >> vs);
+            long want = la ? atol(la) : 32L, cap = (long)(((size_t)256 << 20) / (fbytes ? fbytes : 1));
+            if (want > cap) want = cap;
+            if (want > 256) want = 256;
+            if (want < 2) want = 2;
+            ss->F = (int)want;
+        } else
         if (ss->pipelined) {
             /* lookahead: 16 GOPs (intra-only streams: 64 pictures), at least 8 frames, within 768 MB of pinned memory per half */
             const DSV_META *m = &enc->vidmeta;
