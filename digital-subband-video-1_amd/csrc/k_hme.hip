@@ -128,10 +128,28 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
     return __builtin_amdgcn_alignbyte(hi, lo, sh);
 }
 
-struct HmeShared {
+// Round 4 -- ONE reference window for a level-0 block's inherited candidates, its +-1 search and its half-pel patch.  A wave's life was
+// a chain of dependent memory round trips: source + parents -> candidate rows -> +-1 window -> half-pel patch (-> full-pel window again
+// when no half-pel candidate won); by ablation the +-1 search alone cost 44 % of the kernel for 17 % of its instructions, the
+// candidates 23 %.  The inherited candidates of a block are the parents' vectors: they lie close together.  When the non-zero ones fit
+// a box of UW_SPX x UW_SPY pixels, the union of their block footprints plus one pixel all round is staged in LDS by six 16-byte loads
+// per lane (instead of 12 loads per candidate + 5 for the +-1 window + 3 for the patch), the zero vector's rows come with the source
+// rows in the very first round trip (they are dword aligned and double as the zero-motion block of the statistics), and every later
+// stage reads LDS: two round trips per block instead of four or five.  Blocks whose candidates spread further keep the old path.
+#ifndef HME_UNION
+#define HME_UNION 1
+#endif
+#define UW_P 24            // dwords per staged row: 96 bytes = 66 + spread (<= 24) + misalignment (<= 3), six 16-byte pieces
+#define UW_SPX 24
+#define UW_SPY 14
+#define UW_ROWS(NKB) (4 * (NKB) + 2 + UW_SPY)
+template <int NKB>
+struct HmeSharedT {
     // half-pel stage: the 19x20 reference patch (or the full-pel 14x14 window), the unrounded horizontal taps of its rows
     // (int16, pitch 16) and the three half-pel sample planes of the search (bytes, pitch 16): horizontal, vertical, diagonal
     union {
+        // the union window (see above), dead once the half-pel patch has been taken out of it
+        __attribute__((aligned(16))) unsigned win[(NKB > 0 && HME_UNION) ? UW_ROWS(NKB) * UW_P : 4];
         // the +-1 search's reference window (full blocks: 4 * NKB + 2 rows of 20 dwords), dead before the half-pel stage begins
         __attribute__((aligned(16))) unsigned nine[NINE_ROWS * NINE_P];
         struct {
@@ -248,10 +266,11 @@ static __device__ __forceinline__ void win_partial(const uint8_t *p, int P, int 
 // exactly NKB rows) -- row counts, masks and "does this row exist" are compile-time facts, so the search loops carry no
 // per-row scalar state (the generic form keeps ~40 row offsets and row-exists masks in SGPRs, which the compiler spills
 // to VGPR lanes and reads back with two v_readlane per row).  NKB == 0: any block (edges, small frames).
-template <bool LEVEL0, int NKB>
-static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, int pair, int i, int j, HmeShared &S)
+template <bool LEVEL0, int NKB, typename SHARED>
+static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, int pair, int i, int j, SHARED &S)
 {
     constexpr bool FAST = NKB > 0;
+    constexpr bool UNI = FAST && LEVEL0 && HME_UNION != 0;     // the union-window path (HmeSharedT)
 #ifdef DSVG_CLOCK_PROBE
     unsigned clk_m_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -300,6 +319,17 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
             srcw[k] &= cmask;
         }
+    }
+    // UNI: the zero vector's reference rows = the co-located block (bx + 4cg is dword aligned): requested with the source rows, in the
+    // block's FIRST round trip -- they are the zero candidate's rows, the zero-motion block of the statistics (hme.c:181-300) and of
+    // the veto / quadrant votes, and they depend on no decision
+    unsigned zw[NKR];
+    if constexpr (UNI) {
+        auto zq = dsvg_global(rp + (long)by * stride + bx);
+        unsigned lro = lane_ro;
+        HME_LRO_BARRIER(8, lro);
+#pragma unroll
+        for (int k = 0; k < NKR; k++) { zw[k] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }
     }
     // parents (hme.c:452-480): every lane reads the same five vectors (wave-uniform addresses -> SGPRs) and
     // de-duplicates them in registers in the reference's order -- no LDS hand-off, no barrier
@@ -356,6 +386,11 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     // vector's rows while they are here for its SAD -- the statistics stage then has no rows of its own to fetch
     unsigned zc1 = 0, zc2 = 0;
     bool have_z = false;
+    // UNI: the union window of the non-zero candidates (pixels relative to (bx, by): columns xmin - 1 .. xmax + bw, rows ymin - 1 ..
+    // ymax + bh), staged at S.u.win with `wmis` bytes of misalignment in front of column xmin - 1
+    bool have_win = false;
+    int uxmin = 0, uxmax = 0, uymin = 0, uymax = 0;
+    unsigned wmis = 0;
 #ifdef AB_HME_NO_CAND
     if (0) {
 #else
@@ -364,6 +399,66 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         unsigned acc[6];
         unsigned validmask = 0;
         const bool src_ok = !frame_invalid(fw, fh, bx, by, bw, bh);
+        if constexpr (UNI) {
+            // which candidates count, and the box of the non-zero ones
+            int xmn = 0x7fffffff, xmx = -0x7fffffff, ymn = 0x7fffffff, ymx = -0x7fffffff;
+#pragma unroll
+            for (int k = 0; k < 6; k++) {
+                acc[k] = 0;
+                if (k < n) {
+                    const int all = cand[k];
+                    const int cdx = ((int)(int16_t)(all & 0xffff)) >> level, cdy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
+                    if (src_ok && !frame_invalid(fw, fh, bx + cdx, by + cdy, bw, bh)) {
+                        validmask |= 1u << k;
+                        if (k > 0) { xmn = min(xmn, cdx); xmx = max(xmx, cdx); ymn = min(ymn, cdy); ymx = max(ymx, cdy); }
+                    }
+                }
+            }
+            have_win = (validmask >> 1) != 0u && xmx - xmn <= UW_SPX && ymx - ymn <= UW_SPY;
+            if (have_win) {
+                uxmin = xmn; uxmax = xmx; uymin = ymn; uymax = ymx;
+                const uint8_t *g0 = rp + (long)(by + ymn - 1) * stride + (bx + xmn - 1);
+                wmis = (unsigned)(((uintptr_t)g0) & 3);
+                auto q = dsvg_global(g0 - wmis);
+                const int nrows = 4 * NKB + 2 + (ymx - ymn);                 // <= UW_ROWS(NKB)
+                constexpr int NPW = (UW_ROWS(NKB) * 6 + 63) / 64;            // 16-byte pieces per lane (six per row)
+                dsvg_u32x4a4 pw[NPW];
+#pragma unroll
+                for (int u = 0; u < NPW; u++) {
+                    const int p_ = tid + 64 * u, prow = (p_ * 43691) >> 18, pc = p_ - 6 * prow;        // p / 6, p % 6
+                    if (prow < nrows) pw[u] = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(q + (unsigned)(prow * stride + 16 * pc));
+                }
+                // (under the window's round trip: the zero candidate from the rows that came with the source block)
+                if (validmask & 1u) {
+#pragma unroll
+                    for (int u = 0; u < NKB; u++) acc[0] = __builtin_amdgcn_sad_u8(srcw[u], zw[u], acc[0]);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < NPW; u++) {
+                    const int p_ = tid + 64 * u, prow = (p_ * 43691) >> 18, pc = p_ - 6 * prow;
+                    if (prow < nrows) *reinterpret_cast<dsvg_u32x4a4 *>(S.u.win + prow * UW_P + 4 * pc) = pw[u];
+                }
+                hme_sync();
+#pragma unroll
+                for (int k = 1; k < 6; k++) {
+                    if ((validmask >> k) & 1u) {
+                        const int all = cand[k];
+                        const int cdx = ((int)(int16_t)(all & 0xffff)) >> level, cdy = ((int)(int16_t)((unsigned)all >> 16)) >> level;
+                        const int ox = cdx - xmn + 1 + (int)wmis;            // byte of the staged row the candidate's column 0 sits at
+                        const unsigned sh = (unsigned)(ox & 3);
+                        const unsigned *wl = S.u.win + (cdy - ymn + 1 + r0) * UW_P + (ox >> 2) + cg;
+#pragma unroll
+                        for (int u = 0; u < NKB; u++) {
+                            const unsigned rw = __builtin_amdgcn_alignbyte(wl[u * UW_P + 1], wl[u * UW_P], sh);
+                            acc[k] = __builtin_amdgcn_sad_u8(srcw[u], rw, acc[k]);
+                        }
+                    }
+                }
+            }
+        }
+        const bool via_win = UNI && have_win;
+        if (!via_win) {
 #pragma unroll
         for (int k = 0; k < 6; k++) {
             acc[k] = 0;
@@ -373,6 +468,11 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 if (src_ok && !frame_invalid(fw, fh, bx + cdx, by + cdy, bw, bh)) {
                     validmask |= 1u << k;
                     if constexpr (FAST) {
+                        if (UNI && k == 0) {                       // (the zero vector's rows are in registers)
+#pragma unroll
+                            for (int u = 0; u < NKB; u++) acc[0] = __builtin_amdgcn_sad_u8(srcw[u], zw[u], acc[0]);
+                            continue;
+                        }
                         // every row exists in every lane: NKB 8-byte loads back to back off a running pointer, then the SADs
                         const uint8_t *ub = rp + (long)(by + cdy) * stride + (bx + cdx);
                         const unsigned sh = (unsigned)(((uintptr_t)ub) & 3);
@@ -387,12 +487,12 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                         for (int u = 0; u < NKB; u++) {
                             const unsigned rw = __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh);
                             acc[k] = __builtin_amdgcn_sad_u8(srcw[u], rw, acc[k]);
-                            if (LEVEL0 && k == 0) {                // the zero vector's rows are the zero-motion block of the statistics
+                            if (LEVEL0 && !UNI && k == 0) {        // the zero vector's rows are the zero-motion block of the statistics
                                 zc1 = __builtin_amdgcn_sad_u8(rw, 0u, zc1);
                                 zc2 = __builtin_amdgcn_udot4(rw, rw, zc2, false);
                             }
                         }
-                        if (LEVEL0 && k == 0) have_z = true;
+                        if (LEVEL0 && !UNI && k == 0) have_z = true;
                         __builtin_amdgcn_sched_barrier(0);
                     } else
                     if (cmask && r0 < bh) {
@@ -404,10 +504,10 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                         constexpr int CB = 8;                      // rows per batch (registers)
                         // uni: bh is a multiple of the row groups, so "row k exists" is the wave-uniform k < nkb -- rows past
                         // nkb are skipped by scalar branches and no per-lane select is needed
-                        auto score = [&](auto UNI) {
+                        auto score = [&](auto UNI_) {
 #pragma unroll
                             for (int b0 = 0; b0 < NK; b0 += CB) {
-                                if (decltype(UNI)::value && b0 >= nkb) break;
+                                if (decltype(UNI_)::value && b0 >= nkb) break;
                                 unsigned lo[CB], hi[CB];
 #pragma unroll
                                 for (int u = 0; u < CB; u++) {
@@ -417,10 +517,10 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                                 for (int u = 0; u < CB; u++) {
-                                    if (decltype(UNI)::value && b0 + u >= nkb) break;
+                                    if (decltype(UNI_)::value && b0 + u >= nkb) break;
                                     const unsigned rw = __builtin_amdgcn_alignbyte(hi[u], lo[u], sh) & cmask;
                                     const unsigned a6 = __builtin_amdgcn_sad_u8(srcw[b0 + u], rw, acc[k]);
-                                    if (decltype(UNI)::value) acc[k] = a6;
+                                    if (decltype(UNI_)::value) acc[k] = a6;
                                     else acc[k] = ROWOK(b0 + u) ? a6 : acc[k];
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
@@ -431,11 +531,18 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 }
             }
         }
+        }
         block_sum_n<6>(acc, S.part, phase);
         int best_score = 0x7fffffff;
 #pragma unroll
         for (int k = 0; k < 6; k++)
             if (k < n && ((validmask >> k) & 1u) && best_score > (int)acc[k]) { best_score = (int)acc[k]; pick = k; }
+    }
+    if constexpr (UNI) {
+        // the zero-motion block's sum and sum of squares (the statistics stage, hme.c:181-300) from the same rows
+#pragma unroll
+        for (int u = 0; u < NKB; u++) { zc1 = __builtin_amdgcn_sad_u8(zw[u], 0u, zc1); zc2 = __builtin_amdgcn_udot4(zw[u], zw[u], zc2, false); }
+        have_z = true;
     }
     HME_MARK(2);
     int dx, dy;
@@ -462,13 +569,39 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 #else
         if constexpr (FAST) {
 #endif
+            constexpr int NR = NKB + 2, HB = (NR + 2) / 3;     // reference rows, rows per batch (three batches: registers)
+            unsigned v[3][3];                                  // rolling: v[t % 3][ox] = reference row t, offset ox
+            // the 9 SADs of this lane's rows from a staged window: row t of the lane's NR rows at nl[t * pitch .. + 2], the window's
+            // column 0 at byte m9 of the first dword
+            auto nine_lds = [&](const unsigned *nl, int pitch, unsigned m9) {
+#pragma unroll
+                for (int t = 0; t < NR; t++) {
+                    const unsigned dx_ = nl[t * pitch], dy_ = nl[t * pitch + 1], dz_ = nl[t * pitch + 2];
+                    const unsigned lo = __builtin_amdgcn_alignbyte(dy_, dx_, m9);        // window bytes 0..3 of the row
+                    const unsigned hi = __builtin_amdgcn_alignbyte(dz_, dy_, m9);        //              4..7
+                    v[t % 3][0] = lo;
+                    v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u);
+                    v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u);
+                    const int k = t - 2;                           // source row whose three reference rows are now complete
+                    if (k >= 0) {
+#pragma unroll
+                        for (int c9 = 0; c9 < 9; c9++) acc[c9] = __builtin_amdgcn_sad_u8(srcw[k], v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
+                    }
+                }
+            };
+            // UNI: the picked vector's (bw + 2) x (bh + 2) window lies inside the union window whenever the vector lies in the
+            // candidates' box (always, unless the zero vector won from outside it): no memory access at all
+            if (UNI && have_win && !(dx >= uxmin && dx <= uxmax && dy >= uymin && dy <= uymax)) have_win = false;
+            const bool nine_in_win = UNI && have_win;
+            if (nine_in_win) {
+                const int ob = dx - uxmin + (int)wmis;             // byte of the staged row that window column 0 (pixel dx - 1) sits at
+                nine_lds(S.u.win + (dy - uymin + r0) * UW_P + (ob >> 2) + cg, UW_P, (unsigned)(ob & 3));
+            } else {
             const uint8_t *g0 = rp + (long)(by + dy - 1) * stride + (bx + dx - 1);
             const unsigned mis = (unsigned)(((uintptr_t)g0) & 3);
             auto q = dsvg_global(g0 - mis);
             unsigned lro = lane_ro;
             HME_LRO_BARRIER(4, lro);
-            constexpr int NR = NKB + 2, HB = (NR + 2) / 3;     // reference rows, rows per batch (three batches: registers)
-            unsigned v[3][3];                                  // rolling: v[t % 3][ox] = reference row t, offset ox
 #if HME_NINE_LDS
             {
                 // stage rows 0 .. 4 NKB + 1 of the window: lane = (row of a pass of twelve, 16-byte piece 0..4)
@@ -488,21 +621,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 for (int u = 0; u < NP; u++)
                     if (tid < 60 && 12 * u + prow < WR) *reinterpret_cast<dsvg_u32x4a4 *>(S.u.nine + (12 * u + prow) * NINE_P + 4 * pc) = pw[u];
                 hme_sync();
-                const unsigned *nl = S.u.nine + r0 * NINE_P + cg;
-#pragma unroll
-                for (int t = 0; t < NR; t++) {
-                    const unsigned dx_ = nl[t * NINE_P], dy_ = nl[t * NINE_P + 1], dz_ = nl[t * NINE_P + 2];
-                    const unsigned lo = __builtin_amdgcn_alignbyte(dy_, dx_, mis);       // window bytes 0..3 of the row
-                    const unsigned hi = __builtin_amdgcn_alignbyte(dz_, dy_, mis);       //              4..7
-                    v[t % 3][0] = lo;
-                    v[t % 3][1] = __builtin_amdgcn_alignbyte(hi, lo, 1u);
-                    v[t % 3][2] = __builtin_amdgcn_alignbyte(hi, lo, 2u);
-                    const int k = t - 2;                           // source row whose three reference rows are now complete
-                    if (k >= 0) {
-#pragma unroll
-                        for (int c9 = 0; c9 < 9; c9++) acc[c9] = __builtin_amdgcn_sad_u8(srcw[k], v[(k + 1 + FY[c9]) % 3][1 + FX[c9]], acc[c9]);
-                    }
-                }
+                nine_lds(S.u.nine + r0 * NINE_P + cg, NINE_P, mis);
                 hme_sync();                                        // (the half-pel stage reuses the space)
             }
             if (false)
@@ -537,6 +656,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
+            }       // (not from the union window)
         } else
 #ifdef AB_HME_NO_NINE
         if (0) {
@@ -614,7 +734,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     // variance test were requested here too until round 3: their 16 registers, held across the half-pel stage, were what
     // put the kernel at 75 VGPRs = 6 waves per SIMD; fetched where they are used it fits 8.)
     unsigned zpre[NKR];
-    if constexpr (FAST) {
+    if constexpr (FAST && !UNI) {
         auto zq = dsvg_global(rp + (long)by * stride + bx);
         unsigned lro = lane_ro;
         HME_LRO_BARRIER(8, lro);
@@ -633,8 +753,40 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     const bool do_hp = best > BW * BH;
 #endif
     // stage: source 14x14 window, and either the 19x20 patch for the lattice or the full-pel 14x14 window
-    const int smis = load_win<8, WIN>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
-    int pmis;
+    int smis, pmis;
+    if constexpr (UNI) {
+        // the source window's 14 rows x 4 dwords are in the registers of the lanes that own them (columns 24..39 = column groups 6..9,
+        // rows 2 NKB - 7 ..): no load
+        constexpr int WYO = 2 * NKB - WIN / 2;
+        if (cg >= 6 && cg <= 9) {
+#pragma unroll
+            for (int k = 0; k < NKB; k++) {
+                const int r = r0 + k - WYO;
+                if (r >= 0 && r < WIN) reinterpret_cast<unsigned *>(S.swin)[r * 6 + (cg - 6)] = srcw[k];
+            }
+        }
+        smis = 1;                                              // pixel wx = bx + 25 sits at byte 1 of the staged dwords
+    } else smis = load_win<8, WIN>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
+    if (UNI && have_win) {
+        // ... and the reference patch (19x20 around the vector for the lattice, or the full-pel 14x14 window) lies inside the union
+        // window: taken out of it through registers (the patch's storage overlaps the window's)
+        constexpr int WYO = 2 * NKB - WIN / 2;
+        const int e = do_hp ? 2 : 0, nrp = do_hp ? 20 : WIN;
+        const int prow = WYO + mvy - e - (uymin - 1), pcb = ((bw >> 1) - WIN / 2) + mvx - e - (uxmin - 1) + (int)wmis;
+        unsigned pv[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int jj = tid + 64 * u, R = (jj * 43691) >> 18, d = jj - 6 * R;
+            pv[u] = jj < 6 * nrp ? S.u.win[(prow + R) * UW_P + (pcb >> 2) + d] : 0u;
+        }
+        hme_sync();
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int jj = tid + 64 * u;
+            if (jj < 6 * nrp) reinterpret_cast<unsigned *>(S.u.hp.patch)[jj] = pv[u];
+        }
+        pmis = pcb & 3;
+    } else
     if (do_hp) pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx - 2, wy + mvy - 2, 19, 20);
     else       pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + mvx, wy + mvy, WIN, WIN);
     hme_sync();
@@ -756,19 +908,20 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         mvy = (int)(int16_t)(mvy << 1);
     }
     if (!have_hp) {
-        if (do_hp) {            // half-pel search found nothing better: full-pel window at the (doubled) vector
-            hme_sync();
-            pmis = load_win<8, 20>(S.u.hp.patch, 24, rp, stride, wx + (mvx >> 1), wy + (mvy >> 1), WIN, WIN);
-            hme_sync();
-        }
-        copy_win(S.u.hp.patch, 24, pmis);
+        // half-pel search found nothing better: the full-pel window at the (doubled) vector is rows / columns 2 .. 15 of the 19x20
+        // patch that is still staged (round 4: it was fetched again until now -- one more round trip for every such block)
+        if (do_hp) copy_win(S.u.hp.patch + 2 * 24, 24, pmis + 2);
+        else copy_win(S.u.hp.patch, 24, pmis);
     }
     // the zero-motion reference block (variance test, veto, quadrant votes) is read straight from global memory:
     // bx + 4cg is dword aligned, every thread takes the rows it owns
     hme_sync();                                    // rwin complete
     HME_MARK(5);
     unsigned zrow[NKR];
-    if constexpr (FAST) {
+    if constexpr (UNI) {
+#pragma unroll
+        for (int kk = 0; kk < NKR; kk++) zrow[kk] = zw[kk];
+    } else if constexpr (FAST) {
 #pragma unroll
         for (int kk = 0; kk < NKR; kk++) zrow[kk] = zpre[kk];
     } else {
@@ -1051,6 +1204,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 template <bool LEVEL0, int NKBF, int PART>
 __global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
 {
+    typedef HmeSharedT<(LEVEL0 && PART != 2 && PART != 0) ? NKBF : 0> HmeShared;      // (the window is sized for the launch's full blocks)
     __shared__ HmeShared SS[HME_WPG];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     HmeShared &S = SS[wave];
