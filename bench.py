@@ -479,6 +479,12 @@ def main():
     if rank == 0 and prof_kernel != "none":
         ms, nl, by = b.prof_get(prof_kernel)
         b.prof_enable([])
+        if prof_kernel in table and table[prof_kernel][1] and nl:
+            # the algorithmic bytes of a launch as the selection step priced them (for the sparse inverse kernels: what the counted
+            # tiles and flagged patches really moved), shared out over the launches the timed region needs for the same pictures
+            # (a coding-stream kernel's launch covers 1 / coding_streams of a frame step there; an analysis kernel's the whole step)
+            xm_, xn_, xb_ = table[prof_kernel]
+            by = xb_ * (args.steps + 1)                   # (the brackets also cover the batch that fills the pipeline)
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         kinfo = {"kernel": prof_kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": nl,

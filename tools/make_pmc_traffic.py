@@ -21,6 +21,7 @@ def kid(name):
     """rocprofv3 prints k_hme_level<true, 12, 1> (second argument: rows per lane of a full block, picked per geometry by the
     launcher; third: 1 = the launch over the full blocks, 2 = the partial blocks at the frame's edge); the profiling API of
     the library and bench.py name the kernel by its first argument only"""
+    name = re.sub(r"^void (k_tail_q|k_hz_scan)<\d+>$", r"\1", name)                             # (round 4: templated on the workgroup size the launcher picks)
     name = re.sub(r"k_hme_level<(true|false), \d+, [013]>", r"k_hme_level<\1>", name)          # the full blocks (or every block)
     return re.sub(r"k_hme_level<(true|false), \d+, 2>", r"k_hme_level<\1> (partial blocks)", name)
 
@@ -57,5 +58,9 @@ steps = max(1, out["kernels"].get("k_unpack", {}).get("launches", 1))
 tot = sum(e.get("hbm_bytes_per_launch", 0) * e["launches"] for k, e in out["kernels"].items() if not k.startswith("__amd") and k != "k_spin")
 raw = sum(e.get("hbm_bytes_per_launch_raw", 0) * e["launches"] for k, e in out["kernels"].items() if not k.startswith("__amd") and k != "k_spin")
 out["step"] = {"steps_profiled": steps, "hbm_bytes": round(tot / steps), "hbm_bytes_raw": round(raw / steps)}
+# the step against the VALU issue roof (bench.py `pipeline.valu`): wave64 instructions of every kernel of a step
+vi = sum(e.get("valu_insts_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if not k.startswith("__amd") and k != "k_spin")
+if vi:
+    out["step"]["valu_insts"] = round(vi / steps)
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out["kernels"]), "kernels")
