@@ -78,6 +78,13 @@ static __device__ __forceinline__ void hme_sync()
 #define NINE_ROWS 66       // 4 * 16 + 2
 
 static __device__ __forceinline__ int tap4(int m, int a, int b, int p) { return 9 * (a + b) - (m + p); }
+#ifdef AB_HME_COUNT          // diagnostic build: how many full level-0 blocks take the union window, and what the others fail on
+__device__ unsigned long long g_hme_cnt[8];
+extern "C" void dsvg_hme_counts(unsigned long long *out) { (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_hme_cnt), sizeof(g_hme_cnt)); }
+#define HME_COUNT(i) do { if (tid == 0) atomicAdd(&g_hme_cnt[i], 1ull); } while (0)
+#else
+#define HME_COUNT(i) do { } while (0)
+#endif
 
 // stage rows [oy,oy+nh) x cols [ox,ox+nw) of a plane into LDS (pitch P) as ALIGNED dwords; returns the
 // byte shift `mis` such that dst[r*P + mis + k] == plane(ox+k, oy+r).  TPR threads share a row (the window
@@ -139,8 +146,20 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 #ifndef HME_UNION
 #define HME_UNION 1
 #endif
-#define UW_P 24            // dwords per staged row: 96 bytes = 66 + spread (<= 24) + misalignment (<= 3), six 16-byte pieces
-#define UW_SPX 24
+#ifndef HME_UNION_UPPER
+#define HME_UNION_UPPER 0
+#endif
+// Row pitch: 20 dwords = 80 bytes = 66 + spread (<= 8) + misalignment (<= 3), five 16-byte pieces.  The four row groups of a wave read rows
+// 12 apart: 12 * 20 dwords = 16 banks of 32 apart -- conflict-free per half wave, like the +-1 search's own window of round 3; a pitch of
+// 24 (spreads up to 24 pixels) put all four groups on the same banks (12 * 24 = 0 mod 32) and cost more than the wider boxes brought
+#ifndef UW_P
+#define UW_P 20
+#endif
+#ifndef UW_SPX
+#define UW_SPX (4 * UW_P - 72)
+#endif
+#define UW_PPR (UW_P / 4)                                    // 16-byte pieces per staged row
+#define UW_PDIV(p) (((p) * ((262144 + UW_PPR - 1) / UW_PPR)) >> 18)     // p / UW_PPR for p < 1024
 #define UW_SPY 14
 #define UW_ROWS(NKB) (4 * (NKB) + 2 + UW_SPY)
 template <int NKB>
@@ -270,7 +289,10 @@ template <bool LEVEL0, int NKB, typename SHARED>
 static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, int pair, int i, int j, SHARED &S)
 {
     constexpr bool FAST = NKB > 0;
-    constexpr bool UNI = FAST && LEVEL0 && HME_UNION != 0;     // the union-window path (HmeSharedT)
+    // the union-window path (HmeSharedT): full blocks of level 0 (on the upper levels -- HME_UNION_UPPER -- it is parity-clean and changes
+    // nothing: 1.18 against 1.12-1.19 ms per 320-GOP step)
+    constexpr bool UNI = FAST && (LEVEL0 || HME_UNION_UPPER != 0) && HME_UNION != 0;
+    constexpr bool ZE = UNI && LEVEL0;                         // ... and the zero vector's rows in the first round trip (level 0: they are the statistics' rows too)
 #ifdef DSVG_CLOCK_PROBE
     unsigned clk_m_[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
@@ -324,7 +346,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     // block's FIRST round trip -- they are the zero candidate's rows, the zero-motion block of the statistics (hme.c:181-300) and of
     // the veto / quadrant votes, and they depend on no decision
     unsigned zw[NKR];
-    if constexpr (UNI) {
+    if constexpr (ZE) {
         auto zq = dsvg_global(rp + (long)by * stride + bx);
         unsigned lro = lane_ro;
         HME_LRO_BARRIER(8, lro);
@@ -415,28 +437,40 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 }
             }
             have_win = (validmask >> 1) != 0u && xmx - xmn <= UW_SPX && ymx - ymn <= UW_SPY;
+            HME_COUNT(0);                                      // blocks with candidates beside the zero vector
+            if (have_win) HME_COUNT(1);
+            else if ((validmask >> 1) == 0u) HME_COUNT(2);     // none of them valid
+            else HME_COUNT(3);                                 // spread too wide
             if (have_win) {
                 uxmin = xmn; uxmax = xmx; uymin = ymn; uymax = ymx;
                 const uint8_t *g0 = rp + (long)(by + ymn - 1) * stride + (bx + xmn - 1);
                 wmis = (unsigned)(((uintptr_t)g0) & 3);
                 auto q = dsvg_global(g0 - wmis);
                 const int nrows = 4 * NKB + 2 + (ymx - ymn);                 // <= UW_ROWS(NKB)
-                constexpr int NPW = (UW_ROWS(NKB) * 6 + 63) / 64;            // 16-byte pieces per lane (six per row)
+                constexpr int NPW = (UW_ROWS(NKB) * UW_PPR + 63) / 64;       // 16-byte pieces per lane
                 dsvg_u32x4a4 pw[NPW];
 #pragma unroll
                 for (int u = 0; u < NPW; u++) {
-                    const int p_ = tid + 64 * u, prow = (p_ * 43691) >> 18, pc = p_ - 6 * prow;        // p / 6, p % 6
+                    const int p_ = tid + 64 * u, prow = UW_PDIV(p_), pc = p_ - UW_PPR * prow;
                     if (prow < nrows) pw[u] = *reinterpret_cast<const DSVG_GLOBAL dsvg_u32x4a4 *>(q + (unsigned)(prow * stride + 16 * pc));
                 }
-                // (under the window's round trip: the zero candidate from the rows that came with the source block)
+                // (under the window's round trip: the zero candidate from the rows that came with the source block -- level 0 -- or from
+                // loads of its own in the same batch: the co-located rows are dword aligned)
                 if (validmask & 1u) {
+                    if constexpr (!ZE) {
+                        auto zq = dsvg_global(rp + (long)by * stride + bx);
+                        unsigned lro = lane_ro;
+                        HME_LRO_BARRIER(8, lro);
+#pragma unroll
+                        for (int u = 0; u < NKB; u++) { zw[u] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(zq + lro); zq += stride; }
+                    }
 #pragma unroll
                     for (int u = 0; u < NKB; u++) acc[0] = __builtin_amdgcn_sad_u8(srcw[u], zw[u], acc[0]);
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int u = 0; u < NPW; u++) {
-                    const int p_ = tid + 64 * u, prow = (p_ * 43691) >> 18, pc = p_ - 6 * prow;
+                    const int p_ = tid + 64 * u, prow = UW_PDIV(p_), pc = p_ - UW_PPR * prow;
                     if (prow < nrows) *reinterpret_cast<dsvg_u32x4a4 *>(S.u.win + prow * UW_P + 4 * pc) = pw[u];
                 }
                 hme_sync();
@@ -468,7 +502,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 if (src_ok && !frame_invalid(fw, fh, bx + cdx, by + cdy, bw, bh)) {
                     validmask |= 1u << k;
                     if constexpr (FAST) {
-                        if (UNI && k == 0) {                       // (the zero vector's rows are in registers)
+                        if (ZE && k == 0) {                        // (the zero vector's rows are in registers)
 #pragma unroll
                             for (int u = 0; u < NKB; u++) acc[0] = __builtin_amdgcn_sad_u8(srcw[u], zw[u], acc[0]);
                             continue;
@@ -487,12 +521,12 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                         for (int u = 0; u < NKB; u++) {
                             const unsigned rw = __builtin_amdgcn_alignbyte(w[u].y, w[u].x, sh);
                             acc[k] = __builtin_amdgcn_sad_u8(srcw[u], rw, acc[k]);
-                            if (LEVEL0 && !UNI && k == 0) {        // the zero vector's rows are the zero-motion block of the statistics
+                            if (LEVEL0 && !ZE && k == 0) {         // the zero vector's rows are the zero-motion block of the statistics
                                 zc1 = __builtin_amdgcn_sad_u8(rw, 0u, zc1);
                                 zc2 = __builtin_amdgcn_udot4(rw, rw, zc2, false);
                             }
                         }
-                        if (LEVEL0 && !UNI && k == 0) have_z = true;
+                        if (LEVEL0 && !ZE && k == 0) have_z = true;
                         __builtin_amdgcn_sched_barrier(0);
                     } else
                     if (cmask && r0 < bh) {
@@ -538,7 +572,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         for (int k = 0; k < 6; k++)
             if (k < n && ((validmask >> k) & 1u) && best_score > (int)acc[k]) { best_score = (int)acc[k]; pick = k; }
     }
-    if constexpr (UNI) {
+    if constexpr (ZE) {
         // the zero-motion block's sum and sum of squares (the statistics stage, hme.c:181-300) from the same rows
 #pragma unroll
         for (int u = 0; u < NKB; u++) { zc1 = __builtin_amdgcn_sad_u8(zw[u], 0u, zc1); zc2 = __builtin_amdgcn_udot4(zw[u], zw[u], zc2, false); }
@@ -593,6 +627,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             // candidates' box (always, unless the zero vector won from outside it): no memory access at all
             if (UNI && have_win && !(dx >= uxmin && dx <= uxmax && dy >= uymin && dy <= uymax)) have_win = false;
             const bool nine_in_win = UNI && have_win;
+            if (UNI) { HME_COUNT(4); if (nine_in_win) HME_COUNT(5); if (n == 1) HME_COUNT(6); }
             if (nine_in_win) {
                 const int ob = dx - uxmin + (int)wmis;             // byte of the staged row that window column 0 (pixel dx - 1) sits at
                 nine_lds(S.u.win + (dy - uymin + r0) * UW_P + (ob >> 2) + cg, UW_P, (unsigned)(ob & 3));
@@ -1204,7 +1239,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 template <bool LEVEL0, int NKBF, int PART>
 __global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
 {
-    typedef HmeSharedT<(LEVEL0 && PART != 2 && PART != 0) ? NKBF : 0> HmeShared;      // (the window is sized for the launch's full blocks)
+    typedef HmeSharedT<((LEVEL0 || HME_UNION_UPPER != 0) && PART != 2 && PART != 0) ? NKBF : 0> HmeShared;      // (the window is sized for the launch's full blocks)
     __shared__ HmeShared SS[HME_WPG];
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     HmeShared &S = SS[wave];
