@@ -482,11 +482,18 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                         const int ox = cdx - xmn + 1 + (int)wmis;            // byte of the staged row the candidate's column 0 sits at
                         const unsigned sh = (unsigned)(ox & 3);
                         const unsigned *wl = S.u.win + (cdy - ymn + 1 + r0) * UW_P + (ox >> 2) + cg;
+                        // (all of the candidate's rows requested before the first is used: one LDS round trip per candidate -- left to
+                        // itself the compiler waited for every row's two dwords in turn, twelve round trips in a chain)
+                        unsigned lo_[NKB], hi_[NKB];
+#pragma unroll
+                        for (int u = 0; u < NKB; u++) { lo_[u] = wl[u * UW_P]; hi_[u] = wl[u * UW_P + 1]; }
+                        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                         for (int u = 0; u < NKB; u++) {
-                            const unsigned rw = __builtin_amdgcn_alignbyte(wl[u * UW_P + 1], wl[u * UW_P], sh);
+                            const unsigned rw = __builtin_amdgcn_alignbyte(hi_[u], lo_[u], sh);
                             acc[k] = __builtin_amdgcn_sad_u8(srcw[u], rw, acc[k]);
                         }
+                        __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
