@@ -2959,15 +2959,20 @@ __global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs
         const int y = 2 * m0 + yl;
         if (y >= H || y >= g.ph) continue;
         unsigned lo = 0, hi = 0;
+        // the item's six columns of both halves (local columns 4gx .. 4gx + 5: cells 4gx .. 4gx + 3 and one neighbour on each side), read
+        // once.  Phase A filled the halo columns with CLAMPED plane columns, so the neighbour of the plane's first / last cell is the cell
+        // itself there already (inv_b4t_h's edges, sbt.c:137-165): no edge select here (round 4: each cell read its three columns
+        // again behind two selects)
+        int vl[6], vh[6];
+#pragma unroll
+        for (int q = 0; q < 6; q++) { vl[q] = VL[yl][4 * gx + q]; vh[q] = VH[yl][4 * gx + q]; }
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int kl = 4 * gx + q, k = k0 + kl;
             int e = 0, o = 0;
             if (k < hw) {
-                // local column index of k is kl+1; neighbours clamp at the plane edges
-                const int cm = (k > 0) ? kl : kl + 1, cp = (k < hw - 1) ? kl + 2 : kl + 1;
-                const int Lp = VL[yl][cm], L0 = VL[yl][kl + 1], Ln = VL[yl][cp];
-                const int Hp = VH[yl][cm], H0 = VH[yl][kl + 1], Hn = VH[yl][cp];
+                const int Lp = vl[q], L0 = vl[q + 1], Ln = vl[q + 2];
+                const int Hp = vh[q], H0 = vh[q + 1], Hn = vh[q + 2];
                 e = d_sat8(d_rdiv8(Lp + 3 * L0 + Hp - 3 * H0) + 128);
                 o = d_sat8(d_rdiv8(3 * L0 + Ln + 3 * H0 - Hn) + 128);
             }
