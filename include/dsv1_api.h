@@ -179,8 +179,13 @@ int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BU
  * the device; collect fetches + assembles the OLDEST submitted batch.  At most two batches may be in
  * flight, so the steady state is  submit(i+1); collect(i);  -- the analysis of batch i+1 (frame load,
  * pyramid, motion estimation: source pixels only) then overlaps the residual coding of batch i on a
- * second HIP stream, and the host packet assembly overlaps both.  With ABR, submit already assembles
- * into out (each quantiser needs the previous packet size) and collect only releases the slot. */
+ * second HIP stream, and the host packet assembly overlaps both.  ABR streams pipeline the same way since round 4: every
+ * quantiser still follows from the size of the packet before, but that chain runs on the device (k_rc, include/dsvg_rc.h) and
+ * the streams' rate-control state stays there from call to call; the session layer replays it on the host when it assembles the
+ * packets (the encoder structs stay in step) and fails the batch if the two ever disagree.  The rate-control PARAMETERS
+ * (bitrate, quality bounds, max_q_step, rc_high_motion_nudge, frame rate) are taken from the configuration when the first
+ * batch is submitted.  DSV1_ABR_SERIAL=1: rounds 1-3's path -- submit codes frame by frame, assembles into out, and collect
+ * only releases the slot. */
 /* yuv_on_device for dsv1_batch_submit: 0 = host memory, 1 = device memory, copied whole -- submit has finished with the clip
  * when it returns; DSV1_CLIP_HELD = device memory that the caller keeps UNCHANGED until dsv1_batch_collect of this batch has
  * returned: chroma is then read in place by the coding kernels and only luma is copied (what bench.py times: 21 % less traffic
