@@ -2754,8 +2754,12 @@ __global__ __launch_bounds__(256) void k_inv_tile54_all(const JobDev *__restrict
 // -- a small LL3 -- the reconstruction is the prediction that is already in place: nothing is loaded or stored.
 // Patches [0, imax) x [0, jmax): whole patches inside the picture; the tile kernel takes the strips beyond.
 // --------------------------------------------------------------------------------------------
+// jpart (round 4): patch row jpart = jmax - 1 is the plane's last and holds FOUR pixel rows (plane height = 8k + 4: the chroma of 1080 lines).  Then
+// levels 1 and 2 are complete for those rows and only level 3's last cell row is the odd one (sbt.c:392-431: LL and LH alone, outputs (LL +- LH) / 4):
+// the patch is the same closed computation with half of its rows.  Until now the whole last TILE row went to the general tile kernel for it --
+// 6 % of the plane at a quarter of this kernel's rate, and a launch per frame step.  -1: every patch of the launch is whole.
 __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax,
-                                                     int gx, int gy, int gz, int plain)
+                                                     int gx, int gy, int gz, int plain, int jpart)
 {
     Blk3 B;                                                 // one-dimensional launch in XCD order (d_xcd_blk3)
     if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
@@ -2763,6 +2767,11 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     const SbtGeo g = G.g[c];
     const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if (I >= imax || J >= jmax) return;
+    // (the patch row is wave-uniform -- a wave is one row of patches: the partial row takes a body of its own, the whole patches' body
+    // carries none of its tests)
+    auto run = [&](auto PART_) {
+    constexpr bool part = decltype(PART_)::value;
+    constexpr int nrow = part ? 4 : 8;
     const JobDev &jb = jobs[job];
     const unsigned pidx = (unsigned)(J * g.w3 + I);
     const int ll3 = dsvg_at(dsvg_global(static_cast<const int32_t *>(jb.s3 + g.s3off)), pidx);
@@ -2787,15 +2796,16 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
         if (cv == 0) {                                          // reconstruction = prediction
             if (inplace) return;
 #pragma unroll
-            for (int r = 0; r < 8; r++) dsvg_st2(outp + (p0 + r * stride), dsvg_ld2(pred + (p0 + r * stride)));
+            for (int r = 0; r < 8; r++) if (r < nrow) dsvg_st2(outp + (p0 + r * stride), dsvg_ld2(pred + (p0 + r * stride)));
             return;
         }
         const s16x2 cc = s16x2{(short)cv, (short)cv};
         uint2 pv[8];
 #pragma unroll
-        for (int r = 0; r < 8; r++) pv[r] = dsvg_ld2(pred + (p0 + r * stride));
+        for (int r = 0; r < 8; r++) pv[r] = r < nrow ? dsvg_ld2(pred + (p0 + r * stride)) : make_uint2(0u, 0u);
 #pragma unroll
         for (int r = 0; r < 8; r++) {
+            if (r >= nrow) break;
             unsigned o[2];
 #pragma unroll
             for (int h = 0; h < 2; h++) {
@@ -2821,8 +2831,9 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     {
         const int f = flag(Q3, I, J), q = max(Q3.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ);
         const unsigned o = (unsigned)(J * Q3.sw + I);
-        const int LL = d_ll_up_t<true>(ll3), LH = dq_lo24(dsvg_at(sym, (unsigned)Q3.base0 + o), q), HL = dq_lo24(dsvg_at(sym, (unsigned)Q3.base1 + o), q),
-                  HH = dq_lo24(dsvg_at(sym, (unsigned)Q3.base2 + o), q);
+        // (part: the band's odd last cell row -- no HL / HH, two outputs; sbt.c:418-431)
+        const int LL = d_ll_up_t<true>(ll3), LH = dq_lo24(dsvg_at(sym, (unsigned)Q3.base0 + o), q),
+                  HL = part ? 0 : dq_lo24(dsvg_at(sym, (unsigned)Q3.base1 + o), q), HH = part ? 0 : dq_lo24(dsvg_at(sym, (unsigned)Q3.base2 + o), q);
         l2[0][0] = d_div4<true>(LL + LH + HL + HH); l2[0][1] = d_div4<true>(LL - LH + HL - HH);
         l2[1][0] = d_div4<true>(LL + LH - HL - HH); l2[1][1] = d_div4<true>(LL - LH - HL + HH);
     }
@@ -2830,6 +2841,7 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     for (int j = 0; j < 2; j++)
 #pragma unroll
         for (int i = 0; i < 2; i++) {
+            if (part && j == 1) { l1[2][2 * i] = l1[2][2 * i + 1] = l1[3][2 * i] = l1[3][2 * i + 1] = 0; continue; }   // (level-2 cell row 2J + 1 does not exist)
             const int cx = 2 * I + i, cy = 2 * J + j;
             const int f = flag(Q2, cx, cy), q = max(Q2.qp >> ((f & 2) ? 2 : (f != 0)), HZ_MINQ);
             const unsigned o = (unsigned)(cy * Q2.sw + cx);
@@ -2841,6 +2853,7 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     // level 1 + pixels one cell row (two pixel rows) at a time: few values alive (this path sets the kernel's registers)
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+        if (part && j >= 2) break;                              // (level-1 cell rows 4J + 2, 4J + 3 do not exist)
         int r0[8], r1[8];
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -2866,6 +2879,8 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
             dsvg_st2(outp + (p0 + r * stride), make_uint2(lo, hi));
         }
     }
+    };
+    if (J == jpart) run(std::true_type{}); else run(std::false_type{});
 }
 
 // --------------------------------------------------------------------------------------------
@@ -3203,12 +3218,18 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             // no smoothing filter: patches are closed computations -- the lean kernel takes every whole patch that does not lie
             // in a tile of the last tile row / column with a ragged edge, the tile kernel those strips
             const int fullc = G.g[c0].pw / 8, fullr = G.g[c0].ph / 8;
-            const int tcx = fullc >= g.w3 ? (int)tg.x : fullc / IT_TX, tcy = fullr >= g.h3 ? (int)tg.y : fullr / IT_TY;   // first tile column / row of the strips
+            // a last patch row of exactly four pixel rows (plane height 8k + 4 -- 1080 lines of 4:2:0 / 4:2:2 chroma: 540) stays with the lean
+            // kernel (k_inv_patch_c, jpart); every plane of the launch must have it (they share one grid): 4:2:0 and 4:4:4 do
+            static const bool no_part = getenv("DSV1_NO_PATCH_PART") != nullptr;       // (A/B)
+            bool part4 = !no_part && fullr == g.h3 - 1 && fullr >= 1;
+            for (int c = c0; c < c0 + npl; c++) part4 = part4 && G.g[c].ph == G.g[c0].ph && (G.g[c].ph & 7) == 4 && (G.g[c].H & 7) == 4 && G.g[c].h3 == g.h3;
+            const int tcx = fullc >= g.w3 ? (int)tg.x : fullc / IT_TX, tcy = (fullr >= g.h3 || part4) ? (int)tg.y : fullr / IT_TY;   // first tile column / row of the strips
             const int imax = tcx >= (int)tg.x ? g.w3 : tcx * IT_TX, jmax = tcy >= (int)tg.y ? g.h3 : tcy * IT_TY;
             if (imax > 0 && jmax > 0) {
                 PB(KID_INV_PATCH_C, 64.0 * imax * jmax * nz * 2.0);          // prediction in, reconstruction out (+ 5 B per patch: LL3, flag)
                 const int cgx = (imax + 63) / 64, cgy = (jmax + 3) / 4;
-                hipLaunchKernelGGL(k_inv_patch_c, tile_grid(cgx, cgy, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax, cgx, cgy, nz, xcd_plain());
+                hipLaunchKernelGGL(k_inv_patch_c, tile_grid(cgx, cgy, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax, cgx, cgy, nz, xcd_plain(),
+                                   part4 ? g.h3 - 1 : -1);
                 PE();
             }
             if (tcx < (int)tg.x || tcy < (int)tg.y) {
