@@ -95,7 +95,7 @@ struct HzChunkSum {          // written by hz_quant per chunk
     unsigned long long bit_off; // bit offset of the chunk's first symbol in the plane payload
     int prev_pos, prev_val;  // last non-zero before this chunk (-1 / 0 if none)
     int nz_base;             // index of the chunk's first non-zero in the whole plane
-    int pad;
+    int packed;              // the chunk's list holds one word per entry: (symbol << 16) | position in the chunk (collect_round_pk); else nzpos / nzval
 };
 struct HzPlaneSum {          // written by hz_scan per plane
     unsigned long long total_bits;

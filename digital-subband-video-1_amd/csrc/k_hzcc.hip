@@ -238,6 +238,7 @@ __global__ __launch_bounds__(256) void k_hz_quant(const JobDev *__restrict__ job
         cs.first_pos = total ? s_pos[fw * 512] : -1;
         cs.last_pos = total ? s_pos[lw * 512 + s_wcnt[lw] - 1] : -1;
         cs.last_val = total ? s_val[lw * 512 + s_wcnt[lw] - 1] : 0;
+        cs.packed = 0;
     }
 }
 
@@ -324,7 +325,7 @@ static __device__ __forceinline__ void collect_round(CollectState &st, const int
     st.cpos = __builtin_amdgcn_readlane(lpos, lastl); st.cval = __builtin_amdgcn_readlane(lval, lastl);
     st.run += __builtin_amdgcn_readlane(incl, 63);
 }
-static __device__ __forceinline__ void collect_finish(const JobDev &jb, int c, int chunk, int lane, CollectState &st)
+static __device__ __forceinline__ void collect_finish(const JobDev &jb, int c, int chunk, int lane, CollectState &st, int packed = 0)
 {
     unsigned bits = st.bits;
 #pragma unroll
@@ -336,7 +337,48 @@ static __device__ __forceinline__ void collect_finish(const JobDev &jb, int c, i
         cs.first_pos = st.run ? st.first_pos : -1;
         cs.last_pos = st.run ? st.cpos : -1;
         cs.last_val = st.run ? st.cval : 0;
+        cs.packed = packed;
     }
+}
+
+// Round 4: the detail chunks' lists in ONE word per entry -- (symbol << 16) | position inside the chunk (11 bits; the symbols
+// of the detail regions are int16 by construction: jb.sym) -- and compacted through the wave's LDS window first.  The lanes
+// used to store their up to eight entries of a round one by one (eight predicated position / value store pairs per round: 64
+// vector-memory instructions per chunk, most of them for a few lanes -- the kernel ran at the rate the CU takes such
+// instructions, 0.42 of the HBM peak and half of the VALU issue rate); now a round's entries leave as full 64-lane stores, and
+// the in-chunk code lengths are taken from the compacted list (an entry and its predecessor sit next to each other) instead
+// of along each lane's serial chain.  rw: the lane's eight int16 symbols as loaded, p0rel: the first one's position in the chunk
+#define COLL_STAGE_WORDS 512
+static __device__ __forceinline__ void collect_round_pk(CollectState &st, const uint4 &rw, int p0rel, int cbase, int lane, unsigned *stg,
+                                                         DSVG_GLOBAL unsigned *gent)
+{
+    const unsigned w[4] = {rw.x, rw.y, rw.z, rw.w};
+    int cnt = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt += ((w[j] & 0xffffu) != 0u) + ((w[j] >> 16) != 0u);
+    const unsigned incl = wave_scan_incl((unsigned)cnt);
+    const int n = __builtin_amdgcn_readlane((int)incl, 63);
+    unsigned at = incl - (unsigned)cnt;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        if ((w[j] & 0xffffu) != 0u) stg[at++] = (w[j] << 16) | (unsigned)(p0rel + 2 * j);
+        if ((w[j] >> 16) != 0u) stg[at++] = (w[j] & 0xffff0000u) | (unsigned)(p0rel + 2 * j + 1);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
+    const unsigned cent = ((unsigned)st.cval << 16) | (unsigned)(st.cpos - cbase);      // last entry of the rounds before (if any)
+    for (int i = lane; i < n; i += 64) {
+        const unsigned e = stg[i], pe = i ? stg[i - 1] : cent;
+        gent[(unsigned)(st.run + i)] = e;
+        if (st.run + i > 0) st.bits += (unsigned)(len_ueg((e & 0x7ffu) - (pe & 0x7ffu) - 1u) + len_neg((int)pe >> 16));
+    }
+    const unsigned e0 = stg[0], el = stg[n - 1];                  // (broadcast reads)
+    if (st.first_pos < 0) st.first_pos = cbase + (int)(__builtin_amdgcn_readfirstlane((int)e0) & 0x7ff);
+    const int eli = __builtin_amdgcn_readfirstlane((int)el);
+    st.cpos = cbase + (eli & 0x7ff); st.cval = eli >> 16;
+    st.run += n;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront", "local");
+    __builtin_amdgcn_wave_barrier();
 }
 
 // a chunk that reaches into the LL region of a job whose LL symbols were written by the transform (jb.llq): cells below
@@ -394,13 +436,12 @@ static __device__ __forceinline__ void collect_chunk_ll(const JobDev &jb, int c,
     COLL_T1(st.run, 1);
 }
 
-static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, int chunk, int lane)
+static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
 {
     const HzPlane &hp = jb.hz[c];
     const int ll_end = hp.r[1].base, nscan = hp.nscan;
     const int16_t *sym = jb.sym + jb.nz_off[c];
     int32_t *gpos = jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
-    int32_t *gval = jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK;
     const int cbase = chunk * HZ_CHUNK;
     int16_t *symw = jb.sym + jb.nz_off[c];
     uint8_t *cfl = jb.nzf ? jb.cflag + jb.chunk_off[c] + chunk : nullptr;
@@ -462,24 +503,24 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
     }
     }
     CollectState st;
+    DSVG_GLOBAL unsigned *gent = dsvg_global(reinterpret_cast<unsigned *>(gpos));
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         const int p0 = cbase + k * 512 + 8 * lane;
-        const uint4 rw = raw[k];
-        // most rounds of a P picture hold no symbol at all: one OR and a ballot decide that before anything is unpacked
-        // (cells past the end of the scan sit in the zero padding of the plane or are masked below)
-        if (__ballot((rw.x | rw.y | rw.z | rw.w) != 0u) == 0ull) continue;
-        int v[8];
-        v[0] = (int16_t)(rw.x & 0xffff); v[1] = (int)rw.x >> 16; v[2] = (int16_t)(rw.y & 0xffff); v[3] = (int)rw.y >> 16;
-        v[4] = (int16_t)(rw.z & 0xffff); v[5] = (int)rw.z >> 16; v[6] = (int16_t)(rw.w & 0xffff); v[7] = (int)rw.w >> 16;
-        if (p0 + 8 > nscan) {
+        uint4 rw = raw[k];
+        if (p0 + 8 > nscan) {           // cells past the end of the scan (the plane's last chunk)
+            unsigned *w = reinterpret_cast<unsigned *>(&rw);
 #pragma unroll
-            for (int j = 0; j < 8; j++)
-                if (p0 + j >= nscan) v[j] = 0;
+            for (int j = 0; j < 4; j++) {
+                if (p0 + 2 * j >= nscan) w[j] = 0u;
+                else if (p0 + 2 * j + 1 >= nscan) w[j] &= 0xffffu;
+            }
         }
-        collect_round(st, v, p0, lane, gpos, gval);
+        // most rounds of a P picture hold no symbol at all: one OR and a ballot decide that before anything else
+        if (__ballot((rw.x | rw.y | rw.z | rw.w) != 0u) == 0ull) continue;
+        collect_round_pk(st, rw, k * 512 + 8 * lane, cbase, lane, stg, gent);
     }
-    collect_finish(jb, c, chunk, lane, st);
+    collect_finish(jb, c, chunk, lane, st, 1);
     COLL_T1(st.run, 0);
 }
 
@@ -487,8 +528,9 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
 {
     const JobDev &jb = jobs[blockIdx.y];
     int c, chunk;
+    __shared__ unsigned s_cstage[4][COLL_STAGE_WORDS];
     if (!flat_chunk(jb, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c, chunk)) return;
-    collect_chunk(jb, c, chunk, threadIdx.x & 63);
+    collect_chunk(jb, c, chunk, threadIdx.x & 63, s_cstage[threadIdx.x >> 6]);
 }
 
 // Sparse pictures: 93 % of a P picture's chunks hold nothing, and a launch of one wave per chunk is bound by the rate at
@@ -502,6 +544,7 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
 #endif
 __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restrict__ jobs)
 {
+    __shared__ unsigned s_cstage[4][COLL_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int c = 0, chunk = 0;
@@ -524,7 +567,7 @@ __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restric
         const int l = __ffsll((long long)m) - 1;
         m &= m - 1;
         if ((k & 3) != wv) continue;
-        collect_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane);      // (scalars: the job table is then read with scalar loads)
+        collect_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane, s_cstage[wv]);      // (scalars: the job table is then read with scalar loads)
     }
 }
 
@@ -790,7 +833,8 @@ __device__ unsigned g_emit_dump[128];
 // the next round's first word.  Only the chunk's first and last word can be shared with a neighbouring chunk: those two
 // go out as global atomicOr after the loop.  Nothing in a round waits for a store: the serial path of a dense chunk
 // (32 rounds) is arithmetic + LDS only.
-static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
+template <bool PK>
+static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
 {
 #ifdef EMIT_STATS
     const unsigned long long t_in = wall_clock64();
@@ -809,7 +853,15 @@ static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int c
         bool first_pending = true;                       // the chunk's first word has not been taken out of the stage yet
         // a lane reads its own entry only -- the predecessor comes from the lane below (the last lane's of the round before
         // is carried) -- and the next round's entries are requested before this round is assembled
-        int npos = dsvg_at(gpos, (unsigned)min(lane, nnz - 1)), nval = dsvg_at(gval, (unsigned)min(lane, nnz - 1));
+        // PK: one word per entry, (symbol << 16) | position in the chunk (collect_round_pk) -- one load per lane and round
+        const int cbase = chunk * HZ_CHUNK;
+        const DSVG_GLOBAL unsigned *gent = reinterpret_cast<const DSVG_GLOBAL unsigned *>(gpos);
+        auto fetch = [&](unsigned idx, int &p, int &v) {
+            if (PK) { const unsigned e = dsvg_at(gent, idx); p = cbase + (int)(e & 0x7ffu); v = (int)e >> 16; }
+            else { p = dsvg_at(gpos, idx); v = dsvg_at(gval, idx); }
+        };
+        int npos, nval;
+        fetch((unsigned)min(lane, nnz - 1), npos, nval);
         int cpos = cs.prev_pos, cval = cs.prev_val;
         // (the same two stores behind the first loads as behind every round's: the loop head then waits for exactly "all
         // but the two youngest operations")
@@ -818,7 +870,7 @@ static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int c
         for (int base = 0; base < nnz; base += 64) {
             const int j = base + lane;
             const int pos = npos, val = nval;
-            npos = dsvg_at(gpos, (unsigned)min(j + 64, nnz - 1)); nval = dsvg_at(gval, (unsigned)min(j + 64, nnz - 1));
+            fetch((unsigned)min(j + 64, nnz - 1), npos, nval);
             int ppos = __builtin_amdgcn_update_dpp(0, pos, 0x138, 0xf, 0xf, true);      // wave_shr:1
             int pval = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, true);
             if (lane == 0) { ppos = cpos; pval = cval; }
@@ -956,6 +1008,12 @@ static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int c
         atomicAdd(&g_emit_stat[7][sh], (unsigned long long)cs.nnz);
     }
 #endif
+}
+
+static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
+{
+    if (jb.chunks[jb.chunk_off[c] + chunk].packed) emit_chunk_t<true>(jb, c, chunk, lane, stg);      // (wave-uniform)
+    else emit_chunk_t<false>(jb, c, chunk, lane, stg);
 }
 
 __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs)
