@@ -823,7 +823,7 @@ static __device__ __forceinline__ void or_bits_lds(unsigned *w32, unsigned pos, 
 #else
 #define EMIT_FENCE(o) __builtin_amdgcn_fence(o, "wavefront", "local")
 #endif
-#define EMIT_STAGE_WORDS 200            // 64 symbols x (<= 47 + 49 bits) = 6144 bits = 192 words, + straddle
+#define EMIT_STAGE_WORDS 256            // rounds of 64 entries: 64 x (<= 47 + 49 bits) = 6144 bits = 192 words, + straddle; of 256 entries with codes <= 31 bits: 249
 // lanes that have no word to store in a round store here instead: every round then issues the same vector-memory
 // operations, which lets the compiler wait for the prefetched entries alone (s_waitcnt vmcnt(1)) instead of for everything
 __device__ unsigned g_emit_dump[128];
@@ -833,6 +833,148 @@ __device__ unsigned g_emit_dump[128];
 // the next round's first word.  Only the chunk's first and last word can be shared with a neighbouring chunk: those two
 // go out as global atomicOr after the loop.  Nothing in a round waits for a store: the serial path of a dense chunk
 // (32 rounds) is arithmetic + LDS only.
+struct EmitState {
+    unsigned at0, wbase;             // bit position relative to the chunk's first word; that word's index in the payload
+    unsigned carry, firstv;          // the incomplete last word so far; the chunk's first word once it is complete
+    bool first_pending;              // the chunk's first word has not been taken out of the stage yet
+    int cpos, cval;                  // the entry before the round's first one (before the first round: the chunk's predecessor)
+};
+// entry j = (pos, val) of this lane; prev_in: the chunk has a predecessor in the plane (cs.prev_pos >= 0)
+static __device__ __forceinline__ void emit_round64(EmitState &S, bool prev_in, int j, int nnz, int pos, int val, int lane, unsigned *stg,
+                                                    DSVG_GLOBAL unsigned *out32)
+{
+    int ppos = __builtin_amdgcn_update_dpp(0, pos, 0x138, 0xf, 0xf, true);      // wave_shr:1
+    int pval = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, true);
+    if (lane == 0) { ppos = S.cpos; pval = S.cval; }
+    S.cpos = __builtin_amdgcn_readlane(pos, 63); S.cval = __builtin_amdgcn_readlane(val, 63);
+    const bool valid = j < nnz, hasn = valid && (j > 0 || prev_in);
+    const unsigned m = valid ? (unsigned)(pos - ppos - 1) + 1u : 1u;              // UEG codes run + 1
+    const unsigned mag = hasn ? (unsigned)(pval < 0 ? -pval : pval) : 1u;         // NEG codes UEG(|v| - 1), then the sign
+    const unsigned at0 = S.at0, wbase = S.wbase, carry = S.carry;
+    const bool first_pending = S.first_pending;
+    const unsigned o0 = at0 & 31, w0 = at0 >> 5;
+    unsigned tot;
+    if (__ballot(m >= 256u || mag >= 256u) == 0ull) {
+        // the common round: runs and values below 256, i.e. at most 15 + 16 bits per lane -- both codes in one 32-bit
+        // pattern (both bit spreads in one go), a round of at most 63 words, two LDS atomics per lane
+        const int k1 = 31 - __clz((int)m), k2 = 31 - __clz((int)mag);
+        unsigned x = ((m & ((1u << k1) - 1u)) << 16) | (mag & ((1u << k2) - 1u));
+        x = (x | (x << 4)) & 0x0F0F0F0Fu;
+        x = (x | (x << 2)) & 0x33333333u;
+        x = (x | (x << 1)) & 0x55555555u;
+        unsigned pat = ((x >> 16) << 1) | 1u;
+        unsigned len = valid ? 2u * k1 + 1u : 0u;
+        if (hasn) {
+            pat = (pat << (2 * k2 + 2)) | ((((x & 0xffffu) << 1) | 1u) << 1) | (pval < 0 ? 1u : 0u);
+            len += 2u * k2 + 2u;
+        }
+        const unsigned incl = wave_scan_incl(len);
+        tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        stg[lane] = lane ? 0u : carry;
+        if (lane < 2) stg[64 + lane] = 0;
+        EMIT_FENCE(__ATOMIC_RELEASE);
+        __builtin_amdgcn_wave_barrier();
+        if (len) {
+            const unsigned rel = o0 + (incl - len);
+            const unsigned long long hi = (unsigned long long)pat << (64 - (rel & 31) - len);
+            const unsigned h0 = (unsigned)(hi >> 32), h1 = (unsigned)hi;
+            if (h0) atomicOr(stg + (rel >> 5), h0);
+            if (h1) atomicOr(stg + (rel >> 5) + 1, h1);
+        }
+        EMIT_FENCE(__ATOMIC_ACQ_REL);
+        __builtin_amdgcn_wave_barrier();
+        const int nfull = (int)((o0 + tot) >> 5);                     // complete words of the round, <= 63
+        const unsigned v = stg[lane];
+        S.carry = (unsigned)__builtin_amdgcn_readlane((int)v, nfull & 63);
+        if (nfull == 64) S.carry = 0;                                 // (cannot happen: 31 + 64 * 31 bits)
+        const bool mine = lane < nfull && !(first_pending && lane == 0);
+        DSVG_GLOBAL unsigned *d = mine ? out32 + (wbase + w0 + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + lane;
+        *d = __builtin_bswap32(v);
+        ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;         // (every path of the round: two stores per lane)
+        if (first_pending && nfull > 0) { S.firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)v); S.first_pending = false; }
+    } else if (__ballot(m >= 32768u || mag >= 32768u) == 0ull) {
+        // runs and values below 2^15 (the LL region of a picture): codes of at most 29 + 30 bits in one 64-bit pattern,
+        // a round of at most 120 words, two words per lane
+        const int k1 = 31 - __clz((int)m), k2 = 31 - __clz((int)mag);
+        unsigned x1 = m & ((1u << k1) - 1u), x2 = mag & ((1u << k2) - 1u);
+        x1 = (x1 | (x1 << 8)) & 0x00FF00FFu; x2 = (x2 | (x2 << 8)) & 0x00FF00FFu;
+        x1 = (x1 | (x1 << 4)) & 0x0F0F0F0Fu; x2 = (x2 | (x2 << 4)) & 0x0F0F0F0Fu;
+        x1 = (x1 | (x1 << 2)) & 0x33333333u; x2 = (x2 | (x2 << 2)) & 0x33333333u;
+        x1 = (x1 | (x1 << 1)) & 0x55555555u; x2 = (x2 | (x2 << 1)) & 0x55555555u;
+        unsigned long long pat = ((unsigned long long)x1 << 1) | 1ull;
+        unsigned len = valid ? 2u * k1 + 1u : 0u;
+        if (hasn) {
+            pat = (pat << (2 * k2 + 2)) | ((((unsigned long long)x2 << 1) | 1ull) << 1) | (pval < 0 ? 1ull : 0ull);
+            len += 2u * k2 + 2u;
+        }
+        const unsigned incl = wave_scan_incl(len);
+        tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        stg[lane] = lane ? 0u : carry;
+        stg[64 + lane] = 0;
+        EMIT_FENCE(__ATOMIC_RELEASE);
+        __builtin_amdgcn_wave_barrier();
+        if (len) or_bits_lds(stg, o0 + (incl - len), pat, (int)len);
+        EMIT_FENCE(__ATOMIC_ACQ_REL);
+        __builtin_amdgcn_wave_barrier();
+        const int nfull = (int)((o0 + tot) >> 5);                     // <= 118
+        const unsigned v0 = stg[lane], v1 = stg[64 + lane];
+        S.carry = stg[nfull];
+        const bool mine0 = lane < nfull && !(first_pending && lane == 0), mine1 = 64 + lane < nfull;
+        DSVG_GLOBAL unsigned *d0 = mine0 ? out32 + (wbase + w0 + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + lane;
+        DSVG_GLOBAL unsigned *d1 = mine1 ? out32 + (wbase + w0 + 64u + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + 64 + lane;
+        *d0 = __builtin_bswap32(v0);
+        *d1 = __builtin_bswap32(v1);
+        if (first_pending && nfull > 0) { S.firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)v0); S.first_pending = false; }
+    } else {
+        int l1 = 0, l2 = 0;
+        unsigned long long p1 = 0, p2 = 0;
+        if (valid) {
+            p1 = pat_ueg(m - 1u, l1);
+            if (hasn) p2 = pat_neg(pval, l2);
+        }
+        const unsigned len = (unsigned)(l1 + l2);
+        const unsigned incl = wave_scan_incl(len);
+        tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+        const int nw = (int)((o0 + tot + 31) >> 5);                   // words touched, <= 193
+        for (int i = lane; i < nw + 2; i += 64) stg[i] = i ? 0u : carry;
+        EMIT_FENCE(__ATOMIC_RELEASE);
+        __builtin_amdgcn_wave_barrier();
+        const unsigned rel = o0 + (incl - len);
+        if (l1) or_bits_lds(stg, rel, p1, l1);
+        if (l2) or_bits_lds(stg, rel + l1, p2, l2);
+        EMIT_FENCE(__ATOMIC_ACQ_REL);
+        __builtin_amdgcn_wave_barrier();
+        const int nfull = (int)((o0 + tot) >> 5);
+        for (int i = lane; i < nfull; i += 64)
+            if (!(first_pending && i == 0)) out32[wbase + w0 + (unsigned)i] = __builtin_bswap32(stg[i]);
+        S.carry = stg[nfull];
+        if (first_pending && nfull > 0) { S.firstv = stg[0]; S.first_pending = false; }
+        ((DSVG_GLOBAL unsigned *)g_emit_dump)[lane] = 0;              // (two stores at the end of every path: see above)
+        ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;
+    }
+    EMIT_FENCE(__ATOMIC_ACQ_REL);
+    __builtin_amdgcn_wave_barrier();
+    S.at0 += tot;
+}
+
+// Round 4, packed chunks (collect_round_pk): a round takes 256 entries, four CONSECUTIVE ones per lane (one 16-byte load).  The
+// per-round work that does not depend on the number of entries -- the wave scan of the code lengths, clearing and reading the
+// stage, fences, the carried word, the loads and stores themselves -- is paid once per 256 entries instead of once per 64, a
+// lane's four codes (<= 31 bits each in the common case) are joined in registers to two strings of <= 62 bits before they go
+// to the stage (<= 6 LDS atomics instead of 8), and a round's complete words leave as <= 4 coalesced stores that are issued at
+// the start of the NEXT round, behind that round's entries: the loop never waits for a store it has just issued.
+// A round with a run or a value of 256 or more (rare outside the LL chunks, which are not packed) is done as four rounds of 64.
+struct EmitPend { unsigned w[4]; unsigned base; int n; bool skip0; };
+static __device__ __forceinline__ void emit_flush_pend(const EmitPend &P, int lane, DSVG_GLOBAL unsigned *out32)
+{
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (64 * k >= P.n) break;                                     // (wave-uniform)
+        const int i = lane + 64 * k;
+        if (i < P.n && !(P.skip0 && i == 0)) out32[P.base + (unsigned)i] = __builtin_bswap32(P.w[k]);
+    }
+}
+
 template <bool PK>
 static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
 {
@@ -847,148 +989,129 @@ static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int
     const DSVG_GLOBAL int32_t *gval = dsvg_global(jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK);
     const int nnz = cs.nnz;
     if (nnz > 0) {
-        unsigned at0 = (unsigned)(cs.bit_off & 31);      // bit position relative to the chunk's first word
-        const unsigned wbase = (unsigned)(cs.bit_off >> 5);
-        unsigned carry = 0, firstv = 0;
-        bool first_pending = true;                       // the chunk's first word has not been taken out of the stage yet
-        // a lane reads its own entry only -- the predecessor comes from the lane below (the last lane's of the round before
-        // is carried) -- and the next round's entries are requested before this round is assembled
-        // PK: one word per entry, (symbol << 16) | position in the chunk (collect_round_pk) -- one load per lane and round
-        const int cbase = chunk * HZ_CHUNK;
-        const DSVG_GLOBAL unsigned *gent = reinterpret_cast<const DSVG_GLOBAL unsigned *>(gpos);
-        auto fetch = [&](unsigned idx, int &p, int &v) {
-            if (PK) { const unsigned e = dsvg_at(gent, idx); p = cbase + (int)(e & 0x7ffu); v = (int)e >> 16; }
-            else { p = dsvg_at(gpos, idx); v = dsvg_at(gval, idx); }
-        };
-        int npos, nval;
-        fetch((unsigned)min(lane, nnz - 1), npos, nval);
-        int cpos = cs.prev_pos, cval = cs.prev_val;
-        // (the same two stores behind the first loads as behind every round's: the loop head then waits for exactly "all
-        // but the two youngest operations")
-        ((DSVG_GLOBAL unsigned *)g_emit_dump)[lane] = 0;
-        ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;
-        for (int base = 0; base < nnz; base += 64) {
-            const int j = base + lane;
-            const int pos = npos, val = nval;
-            fetch((unsigned)min(j + 64, nnz - 1), npos, nval);
-            int ppos = __builtin_amdgcn_update_dpp(0, pos, 0x138, 0xf, 0xf, true);      // wave_shr:1
-            int pval = __builtin_amdgcn_update_dpp(0, val, 0x138, 0xf, 0xf, true);
-            if (lane == 0) { ppos = cpos; pval = cval; }
-            cpos = __builtin_amdgcn_readlane(pos, 63); cval = __builtin_amdgcn_readlane(val, 63);
-            const bool valid = j < nnz, hasn = valid && (j > 0 || cs.prev_pos >= 0);
-            const unsigned m = valid ? (unsigned)(pos - ppos - 1) + 1u : 1u;              // UEG codes run + 1
-            const unsigned mag = hasn ? (unsigned)(pval < 0 ? -pval : pval) : 1u;         // NEG codes UEG(|v| - 1), then the sign
-            const unsigned o0 = at0 & 31, w0 = at0 >> 5;
-            unsigned tot;
-            if (__ballot(m >= 256u || mag >= 256u) == 0ull) {
-                // the common round: runs and values below 256, i.e. at most 15 + 16 bits per lane -- both codes in one 32-bit
-                // pattern (both bit spreads in one go), a round of at most 63 words, two LDS atomics per lane
-                const int k1 = 31 - __clz((int)m), k2 = 31 - __clz((int)mag);
-                unsigned x = ((m & ((1u << k1) - 1u)) << 16) | (mag & ((1u << k2) - 1u));
-                x = (x | (x << 4)) & 0x0F0F0F0Fu;
-                x = (x | (x << 2)) & 0x33333333u;
-                x = (x | (x << 1)) & 0x55555555u;
-                unsigned pat = ((x >> 16) << 1) | 1u;
-                unsigned len = valid ? 2u * k1 + 1u : 0u;
-                if (hasn) {
-                    pat = (pat << (2 * k2 + 2)) | ((((x & 0xffffu) << 1) | 1u) << 1) | (pval < 0 ? 1u : 0u);
-                    len += 2u * k2 + 2u;
+        EmitState S;
+        S.at0 = (unsigned)(cs.bit_off & 31);
+        S.wbase = (unsigned)(cs.bit_off >> 5);
+        S.carry = 0; S.firstv = 0; S.first_pending = true;
+        S.cpos = cs.prev_pos; S.cval = cs.prev_val;
+        const bool prev_in = cs.prev_pos >= 0;
+        if (PK) {
+            const int cbase = chunk * HZ_CHUNK;
+            const DSVG_GLOBAL unsigned *gent = reinterpret_cast<const DSVG_GLOBAL unsigned *>(gpos);
+            EmitPend P;
+            P.w[0] = P.w[1] = P.w[2] = P.w[3] = 0; P.base = 0; P.n = 0; P.skip0 = false;
+            // rounds of 256 while more than 128 entries remain, rounds of 64 for the rest (a sparse picture's chunk holds a few
+            // dozen entries: one round of 64, one 4-byte load); the entries of a round are requested one round ahead
+            uint4 nev = make_uint4(0u, 0u, 0u, 0u);
+            unsigned ne1 = 0u;
+            auto request = [&](int b) {
+                if (nnz - b > 128) nev = dsvg_ld4(gent + (b + 4 * lane));       // (the chunk's slot holds HZ_CHUNK words: no load leaves it)
+                else if (b < nnz) ne1 = dsvg_at(gent, (unsigned)min(b + lane, nnz - 1));
+            };
+            request(0);
+            for (int base = 0; base < nnz;) {
+                const uint4 ev = nev;
+                const unsigned e1 = ne1;
+                emit_flush_pend(P, lane, out32);
+                P.n = 0;
+                if (nnz - base <= 128) {
+                    request(base + 64);
+                    emit_round64(S, prev_in, base + lane, nnz, cbase + (int)(e1 & 0x7ffu), (int)e1 >> 16, lane, stg, out32);
+                    base += 64;
+                    continue;
                 }
-                const unsigned incl = wave_scan_incl(len);
-                tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-                stg[lane] = lane ? 0u : carry;
-                if (lane < 2) stg[64 + lane] = 0;
+                request(base + 256);
+                const int base0 = base;
+                base += 256;
+                const unsigned e[4] = {ev.x, ev.y, ev.z, ev.w};
+                const unsigned pe3 = (unsigned)__builtin_amdgcn_update_dpp(0, (int)e[3], 0x138, 0xf, 0xf, true);      // wave_shr:1
+                int pos[4], val[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { pos[t] = cbase + (int)(e[t] & 0x7ffu); val[t] = (int)e[t] >> 16; }
+                int ppos0 = cbase + (int)(pe3 & 0x7ffu), pval0 = (int)pe3 >> 16;
+                if (lane == 0) { ppos0 = S.cpos; pval0 = S.cval; }
+                unsigned m[4], mag[4];
+                bool valid[4], hasn[4], neg[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int j = base0 + 4 * lane + t, pp = t ? pos[t - 1] : ppos0, pv = t ? val[t - 1] : pval0;
+                    valid[t] = j < nnz; hasn[t] = valid[t] && (j > 0 || prev_in);
+                    m[t] = valid[t] ? (unsigned)(pos[t] - pp) : 1u;
+                    mag[t] = hasn[t] ? (unsigned)(pv < 0 ? -pv : pv) : 1u;
+                    neg[t] = pv < 0;
+                }
+                if (__ballot((m[0] | m[1] | m[2] | m[3] | mag[0] | mag[1] | mag[2] | mag[3]) >= 256u) != 0ull) {
+                    // (rare) as four rounds of 64: every lane fetches the entries again in that arrangement
+                    for (int r = 0; r < 4 && base0 + 64 * r < nnz; r++) {
+                        const int j = base0 + 64 * r + lane;
+                        const unsigned en = dsvg_at(gent, (unsigned)min(j, nnz - 1));
+                        emit_round64(S, prev_in, j, nnz, cbase + (int)(en & 0x7ffu), (int)en >> 16, lane, stg, out32);
+                    }
+                    continue;
+                }
+                S.cpos = __builtin_amdgcn_readlane(pos[3], 63); S.cval = __builtin_amdgcn_readlane(val[3], 63);
+                unsigned pat[4], len[4];
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const int k1 = 31 - __clz((int)m[t]), k2 = 31 - __clz((int)mag[t]);
+                    unsigned x = ((m[t] & ((1u << k1) - 1u)) << 16) | (mag[t] & ((1u << k2) - 1u));
+                    x = (x | (x << 4)) & 0x0F0F0F0Fu;
+                    x = (x | (x << 2)) & 0x33333333u;
+                    x = (x | (x << 1)) & 0x55555555u;
+                    pat[t] = ((x >> 16) << 1) | 1u;
+                    len[t] = valid[t] ? 2u * k1 + 1u : 0u;
+                    if (hasn[t]) {
+                        pat[t] = (pat[t] << (2 * k2 + 2)) | ((((x & 0xffffu) << 1) | 1u) << 1) | (neg[t] ? 1u : 0u);
+                        len[t] += 2u * k2 + 2u;
+                    }
+                    if (!valid[t]) pat[t] = 0u;
+                }
+                const unsigned long long sa = ((unsigned long long)pat[0] << len[1]) | pat[1], sb = ((unsigned long long)pat[2] << len[3]) | pat[3];
+                const unsigned la = len[0] + len[1], lb = len[2] + len[3];
+                const unsigned incl = wave_scan_incl(la + lb);
+                const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+                const unsigned o0 = S.at0 & 31, w0 = S.at0 >> 5;
+                reinterpret_cast<uint4 *>(stg)[lane] = make_uint4(lane ? 0u : S.carry, 0u, 0u, 0u);      // 256 words: <= 31 + 64 * 124 bits
                 EMIT_FENCE(__ATOMIC_RELEASE);
                 __builtin_amdgcn_wave_barrier();
-                if (len) {
-                    const unsigned rel = o0 + (incl - len);
-                    const unsigned long long hi = (unsigned long long)pat << (64 - (rel & 31) - len);
-                    const unsigned h0 = (unsigned)(hi >> 32), h1 = (unsigned)hi;
-                    if (h0) atomicOr(stg + (rel >> 5), h0);
-                    if (h1) atomicOr(stg + (rel >> 5) + 1, h1);
-                }
+                const unsigned rel = o0 + (incl - (la + lb));
+                if (la) or_bits_lds(stg, rel, sa, (int)la);
+                if (lb) or_bits_lds(stg, rel + la, sb, (int)lb);
                 EMIT_FENCE(__ATOMIC_ACQ_REL);
                 __builtin_amdgcn_wave_barrier();
-                const int nfull = (int)((o0 + tot) >> 5);                     // complete words of the round, <= 63
-                const unsigned v = stg[lane];
-                carry = (unsigned)__builtin_amdgcn_readlane((int)v, nfull & 63);
-                if (nfull == 64) carry = 0;                                   // (cannot happen: 31 + 64 * 31 bits)
-                const bool mine = lane < nfull && !(first_pending && lane == 0);
-                DSVG_GLOBAL unsigned *d = mine ? out32 + (wbase + w0 + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + lane;
-                *d = __builtin_bswap32(v);
-                ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;         // (every path of the round: two stores per lane)
-                if (first_pending && nfull > 0) { firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)v); first_pending = false; }
-            } else if (__ballot(m >= 32768u || mag >= 32768u) == 0ull) {
-                // runs and values below 2^15 (the LL region of a picture): codes of at most 29 + 30 bits in one 64-bit pattern,
-                // a round of at most 120 words, two words per lane
-                const int k1 = 31 - __clz((int)m), k2 = 31 - __clz((int)mag);
-                unsigned x1 = m & ((1u << k1) - 1u), x2 = mag & ((1u << k2) - 1u);
-                x1 = (x1 | (x1 << 8)) & 0x00FF00FFu; x2 = (x2 | (x2 << 8)) & 0x00FF00FFu;
-                x1 = (x1 | (x1 << 4)) & 0x0F0F0F0Fu; x2 = (x2 | (x2 << 4)) & 0x0F0F0F0Fu;
-                x1 = (x1 | (x1 << 2)) & 0x33333333u; x2 = (x2 | (x2 << 2)) & 0x33333333u;
-                x1 = (x1 | (x1 << 1)) & 0x55555555u; x2 = (x2 | (x2 << 1)) & 0x55555555u;
-                unsigned long long pat = ((unsigned long long)x1 << 1) | 1ull;
-                unsigned len = valid ? 2u * k1 + 1u : 0u;
-                if (hasn) {
-                    pat = (pat << (2 * k2 + 2)) | ((((unsigned long long)x2 << 1) | 1ull) << 1) | (pval < 0 ? 1ull : 0ull);
-                    len += 2u * k2 + 2u;
-                }
-                const unsigned incl = wave_scan_incl(len);
-                tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-                stg[lane] = lane ? 0u : carry;
-                stg[64 + lane] = 0;
-                EMIT_FENCE(__ATOMIC_RELEASE);
-                __builtin_amdgcn_wave_barrier();
-                if (len) or_bits_lds(stg, o0 + (incl - len), pat, (int)len);
+                const int nfull = (int)((o0 + tot) >> 5);             // complete words of the round, <= 249
+#pragma unroll
+                for (int k = 0; k < 4; k++) P.w[k] = stg[lane + 64 * k];
+                S.carry = (unsigned)__builtin_amdgcn_readfirstlane((int)stg[nfull]);
+                P.base = S.wbase + w0; P.n = nfull; P.skip0 = S.first_pending;
+                if (S.first_pending && nfull > 0) { S.firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)P.w[0]); S.first_pending = false; }
                 EMIT_FENCE(__ATOMIC_ACQ_REL);
                 __builtin_amdgcn_wave_barrier();
-                const int nfull = (int)((o0 + tot) >> 5);                     // <= 118
-                const unsigned v0 = stg[lane], v1 = stg[64 + lane];
-                carry = stg[nfull];
-                const bool mine0 = lane < nfull && !(first_pending && lane == 0), mine1 = 64 + lane < nfull;
-                DSVG_GLOBAL unsigned *d0 = mine0 ? out32 + (wbase + w0 + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + lane;
-                DSVG_GLOBAL unsigned *d1 = mine1 ? out32 + (wbase + w0 + 64u + (unsigned)lane) : (DSVG_GLOBAL unsigned *)g_emit_dump + 64 + lane;
-                *d0 = __builtin_bswap32(v0);
-                *d1 = __builtin_bswap32(v1);
-                if (first_pending && nfull > 0) { firstv = (unsigned)__builtin_amdgcn_readfirstlane((int)v0); first_pending = false; }
-            } else {
-                int l1 = 0, l2 = 0;
-                unsigned long long p1 = 0, p2 = 0;
-                if (valid) {
-                    p1 = pat_ueg(m - 1u, l1);
-                    if (hasn) p2 = pat_neg(pval, l2);
-                }
-                const unsigned len = (unsigned)(l1 + l2);
-                const unsigned incl = wave_scan_incl(len);
-                tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
-                const int nw = (int)((o0 + tot + 31) >> 5);                   // words touched, <= 193
-                for (int i = lane; i < nw + 2; i += 64) stg[i] = i ? 0u : carry;
-                EMIT_FENCE(__ATOMIC_RELEASE);
-                __builtin_amdgcn_wave_barrier();
-                const unsigned rel = o0 + (incl - len);
-                if (l1) or_bits_lds(stg, rel, p1, l1);
-                if (l2) or_bits_lds(stg, rel + l1, p2, l2);
-                EMIT_FENCE(__ATOMIC_ACQ_REL);
-                __builtin_amdgcn_wave_barrier();
-                const int nfull = (int)((o0 + tot) >> 5);
-                for (int i = lane; i < nfull; i += 64)
-                    if (!(first_pending && i == 0)) out32[wbase + w0 + (unsigned)i] = __builtin_bswap32(stg[i]);
-                carry = stg[nfull];
-                if (first_pending && nfull > 0) { firstv = stg[0]; first_pending = false; }
-                ((DSVG_GLOBAL unsigned *)g_emit_dump)[lane] = 0;              // (two stores at the end of every path: see above)
-                ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;
+                S.at0 += tot;
             }
-            EMIT_FENCE(__ATOMIC_ACQ_REL);
-            __builtin_amdgcn_wave_barrier();
-            at0 += tot;
+            emit_flush_pend(P, lane, out32);
+        } else {
+            // a lane reads its own entry only -- the predecessor comes from the lane below (the last lane's of the round before
+            // is carried) -- and the next round's entries are requested before this round is assembled
+            int npos = dsvg_at(gpos, (unsigned)min(lane, nnz - 1)), nval = dsvg_at(gval, (unsigned)min(lane, nnz - 1));
+            // (the same two stores behind the first loads as behind every round's: the loop head then waits for exactly "all
+            // but the two youngest operations")
+            ((DSVG_GLOBAL unsigned *)g_emit_dump)[lane] = 0;
+            ((DSVG_GLOBAL unsigned *)g_emit_dump)[64 + lane] = 0;
+            for (int base = 0; base < nnz; base += 64) {
+                const int j = base + lane;
+                const int pos = npos, val = nval;
+                npos = dsvg_at(gpos, (unsigned)min(j + 64, nnz - 1)); nval = dsvg_at(gval, (unsigned)min(j + 64, nnz - 1));
+                emit_round64(S, prev_in, j, nnz, pos, val, lane, stg, out32);
+            }
         }
         if (lane == 0) {
             // the first and the last word of the chunk, possibly shared with the neighbouring chunks (or with each other)
             unsigned *og = reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]);
-            if (first_pending) { if (carry) atomicOr(og + wbase, __builtin_bswap32(carry)); }
+            if (S.first_pending) { if (S.carry) atomicOr(og + S.wbase, __builtin_bswap32(S.carry)); }
             else {
-                if (firstv) atomicOr(og + wbase, __builtin_bswap32(firstv));
-                if (carry) atomicOr(og + (wbase + (at0 >> 5)), __builtin_bswap32(carry));
+                if (S.firstv) atomicOr(og + S.wbase, __builtin_bswap32(S.firstv));
+                if (S.carry) atomicOr(og + (S.wbase + (S.at0 >> 5)), __builtin_bswap32(S.carry));
             }
         }
     }
@@ -1010,15 +1133,23 @@ static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int
 #endif
 }
 
+#ifndef EMIT_WPE
+#define EMIT_WPE 6
+#endif
+#if EMIT_WPE
+#define EMIT_WPE_ATTR __attribute__((amdgpu_waves_per_eu(EMIT_WPE, EMIT_WPE)))
+#else
+#define EMIT_WPE_ATTR
+#endif
 static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
 {
     if (jb.chunks[jb.chunk_off[c] + chunk].packed) emit_chunk_t<true>(jb, c, chunk, lane, stg);      // (wave-uniform)
     else emit_chunk_t<false>(jb, c, chunk, lane, stg);
 }
 
-__global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs)
+__global__ __launch_bounds__(256) EMIT_WPE_ATTR void k_hz_emit(const JobDev *__restrict__ jobs)
 {
-    __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
+    __shared__ __attribute__((aligned(16))) unsigned s_stage[4][EMIT_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     int c, chunk;
     if (!flat_chunk(jb, blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), c, chunk)) return;
@@ -1027,9 +1158,9 @@ __global__ __launch_bounds__(256) void k_hz_emit(const JobDev *__restrict__ jobs
 
 // the same for sparse pictures, organised like k_hz_collect_list: a lane per chunk reads the entry count of its summary,
 // the waves share out the chunks that have entries
-__global__ __launch_bounds__(256) void k_hz_emit_list(const JobDev *__restrict__ jobs)
+__global__ __launch_bounds__(256) EMIT_WPE_ATTR void k_hz_emit_list(const JobDev *__restrict__ jobs)
 {
-    __shared__ unsigned s_stage[4][EMIT_STAGE_WORDS];
+    __shared__ __attribute__((aligned(16))) unsigned s_stage[4][EMIT_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int c = 0, chunk = 0;
