@@ -1042,6 +1042,9 @@ static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int
                 }
                 if (__ballot((m[0] | m[1] | m[2] | m[3] | mag[0] | mag[1] | mag[2] | mag[3]) >= 256u) != 0ull) {
                     // (rare) as four rounds of 64: every lane fetches the entries again in that arrangement
+#ifdef AB_EMIT_BREAK_FALLBACK              // (test of the tests: tests/test_gpu_stream.py::test_dense_chunks_... must fail with this)
+                    S.carry |= 1u;
+#endif
                     for (int r = 0; r < 4 && base0 + 64 * r < nnz; r++) {
                         const int j = base0 + 64 * r + lane;
                         const unsigned en = dsvg_at(gent, (unsigned)min(j, nnz - 1));

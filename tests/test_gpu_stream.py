@@ -88,6 +88,30 @@ def test_1080p_intra_bit_exact(pkg, orc):
     assert got == want, explain(got, want)
 
 
+@pytest.mark.parametrize("gop,qp", [(0, 100), (0, 97), (12, 100)])
+def test_dense_chunks_with_long_runs_and_large_symbols(pkg, orc, gop, qp):
+    """hzcc.c:137-293 / bs.c:129-206 on the chunks the packed emit path has a detour for: a 1280-wide picture whose left half is
+    full-range noise and whose right half is flat -- every level-1 subband row is 320 symbols of several hundred (quantiser 1 at
+    -qp 100) followed by a run of 320 zeros, so a chunk of 2048 scan cells holds far more than 128 entries (rounds of 256 entries)
+    AND codes past the 31 bits those rounds join in registers (a round of 256 then falls back to four rounds of 64)"""
+    w, h, fmt, n = 1280, 256, A.SUBSAMP_420, 3
+    rng = np.random.default_rng(0xDE45E + gop + qp)
+    cw, ch = A.chroma_dims(w, h, fmt)
+    clip = np.empty((n, A.frame_bytes(w, h, fmt)), dtype=np.uint8)
+    for t in range(n):
+        y = np.full((h, w), 128, dtype=np.uint8)
+        y[:, : w // 2] = rng.integers(0, 256, size=(h, w // 2), dtype=np.uint8)
+        if t:
+            y[:, w // 2:] = 128 + 8 * t                                  # (P pictures: a flat residual on the right, noise on the left)
+        c = np.full((2, ch, cw), 128, dtype=np.uint8)
+        c[:, :, : cw // 2] = rng.integers(0, 256, size=(2, ch, cw // 2), dtype=np.uint8)
+        clip[t] = np.concatenate([y.ravel(), c.ravel()])
+    kw = dict(qp=qp, gop=gop, rc_mode_cli=1, scd=0)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **kw))
+    got = pkg.encode_clip(clip, w, h, fmt, **kw)
+    assert got == want, explain(got, want)
+
+
 def test_gop_sharding_matches_serial_cif(pkg, orc):
     w, h, fmt = 352, 288, A.SUBSAMP_420
     clip = A.gen_clip(w, h, fmt, 0x5A4D, 36, style=0)
