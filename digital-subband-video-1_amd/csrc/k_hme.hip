@@ -34,6 +34,8 @@
 // diagnostic builds (DSVG_CLOCK_PROBE): shader-clock stamps at the stage boundaries of a level-0 block, summed per stage
 #ifdef DSVG_CLOCK_PROBE
 #define HME_MARK(i) do { if (LEVEL0) clk_m_[i] = (unsigned)__builtin_amdgcn_s_memtime(); } while (0)
+#elif defined(AB_HME_ASMMARK)              // region markers in the assembly listing (static instruction counts per stage: tools/ab/hme_asm_regions.py)
+#define HME_MARK(i) asm volatile("; HMEMARK " #i)
 #else
 #define HME_MARK(i) do { } while (0)
 #endif

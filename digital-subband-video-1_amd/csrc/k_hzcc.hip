@@ -534,40 +534,57 @@ __global__ __launch_bounds__(256) void k_hz_collect(const JobDev *__restrict__ j
 }
 
 // Sparse pictures: 93 % of a P picture's chunks hold nothing, and a launch of one wave per chunk is bound by the rate at
-// which waves can be started (121 k waves that read one flag byte each).  Here a workgroup owns HZ_LIST_CPW chunks, spread
+// which waves can be started (121 k waves that read one flag byte each).  Here a workgroup owns 64 * Q chunks, spread
 // over the picture (chunk = workgroup + k * workgroups: flagged chunks cluster where something moves); every wave reads
-// the same HZ_LIST_CPW chunk flags, one per lane, and takes every fourth flagged chunk -- no LDS, no barrier, and on
+// the same 64 * Q chunk flags, Q per lane, and takes every fourth flagged chunk -- no LDS, no barrier, and on
 // average well under one chunk per wave, so nothing is serialised.  Chunks without a flag get their empty summary from
 // wave 0.  (A dense job in such a launch -- a scene change inside a step -- is handled too: every chunk counts as flagged.)
-#ifndef HZ_LIST_CPW
-#define HZ_LIST_CPW 64
+#ifndef HZ_LIST_Q
+#define HZ_LIST_Q 1               // chunks per workgroup / 64 of the large launches (measured per 320-GOP step, collect + emit: Q = 1 1.26 + 0.80 ms, 2: 1.24 + 0.80, 4: 1.23 + 0.80, 8: 1.24 + 0.85 -- not worth a second variant)
 #endif
+#ifndef HZ_LIST_Q_MIN_WGS
+#define HZ_LIST_Q_MIN_WGS 4096     // ... which are those that still start this many workgroups
+#endif
+// Q: the workgroup owns 64 * Q chunks (Q flags per lane).  Fewer than 64 chunks per workgroup cost workgroup starts (per 320-GOP
+// step: 16 chunks 1.84 ms, 32: 1.45, 64: 1.28); more than 64 gain nothing (HZ_LIST_Q), what is left is the flagged chunks' chain
+// of dependent fetches (chunk flags, group flags, symbols) at two waves' lifetimes per launch
+template <int Q>
 __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restrict__ jobs)
 {
     __shared__ unsigned s_cstage[4][COLL_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int c = 0, chunk = 0;
-    const bool have = lane < HZ_LIST_CPW && flat_chunk(jb, (int)blockIdx.x + lane * (int)gridDim.x, c, chunk);
-    bool work = false;
-    if (have) {
-        const int ll_end = jb.hz[c].r[1].base, cbase = chunk * HZ_CHUNK;
-        const bool fl = jb.nzf ? jb.cflag[jb.chunk_off[c] + chunk] != 0 : true;
-        if (cbase < ll_end) work = jb.llq || (jb.nzf && cbase + HZ_CHUNK > ll_end && fl);   // llq: the LL chunks are compacted here; else only the straddling chunk's cleanup
-        else {
-            work = fl;
-            if (!fl && wv == 0) jb.chunks[jb.chunk_off[c] + chunk].nnz = 0;     // (of an empty chunk's summary only the count is ever read)
+    int c[Q], chunk[Q];
+    unsigned long long m[Q];
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        c[q] = chunk[q] = 0;
+        const bool have = flat_chunk(jb, (int)blockIdx.x + (64 * q + lane) * (int)gridDim.x, c[q], chunk[q]);
+        bool work = false;
+        if (have) {
+            const int ll_end = jb.hz[c[q]].r[1].base, cbase = chunk[q] * HZ_CHUNK;
+            const bool fl = jb.nzf ? jb.cflag[jb.chunk_off[c[q]] + chunk[q]] != 0 : true;
+            if (cbase < ll_end) work = jb.llq || (jb.nzf && cbase + HZ_CHUNK > ll_end && fl);   // llq: the LL chunks are compacted here; else only the straddling chunk's cleanup
+            else {
+                work = fl;
+                if (!fl && wv == 0) jb.chunks[jb.chunk_off[c[q]] + chunk[q]].nnz = 0;     // (of an empty chunk's summary only the count is ever read)
+            }
         }
+        m[q] = __ballot(work);
     }
-    unsigned long long m = __ballot(work);
     // collect_chunk takes the chunk flags down: every wave must have its view of them before any wave starts (a late wave
     // would count fewer flagged chunks, take the wrong ones, and overwrite a finished summary with an empty one)
     __syncthreads();
-    for (int k = 0; m; k++) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if ((k & 3) != wv) continue;
-        collect_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane, s_cstage[wv]);      // (scalars: the job table is then read with scalar loads)
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        unsigned long long mm = m[q];
+        for (; mm; k++) {
+            const int l = __ffsll((long long)mm) - 1;
+            mm &= mm - 1;
+            if ((k & 3) != wv) continue;
+            collect_chunk(jb, __builtin_amdgcn_readlane(c[q], l), __builtin_amdgcn_readlane(chunk[q], l), lane, s_cstage[wv]);      // (scalars: the job table is then read with scalar loads)
+        }
     }
 }
 
@@ -1161,20 +1178,25 @@ __global__ __launch_bounds__(256) EMIT_WPE_ATTR void k_hz_emit(const JobDev *__r
 
 // the same for sparse pictures, organised like k_hz_collect_list: a lane per chunk reads the entry count of its summary,
 // the waves share out the chunks that have entries
+template <int Q>
 __global__ __launch_bounds__(256) EMIT_WPE_ATTR void k_hz_emit_list(const JobDev *__restrict__ jobs)
 {
     __shared__ __attribute__((aligned(16))) unsigned s_stage[4][EMIT_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    int c = 0, chunk = 0;
-    const bool have = lane < HZ_LIST_CPW && flat_chunk(jb, (int)blockIdx.x + lane * (int)gridDim.x, c, chunk);
-    const bool work = have && jb.chunks[jb.chunk_off[c] + chunk].nnz > 0;
-    unsigned long long m = __ballot(work);
-    for (int k = 0; m; k++) {
-        const int l = __ffsll((long long)m) - 1;
-        m &= m - 1;
-        if ((k & 3) != wv) continue;
-        emit_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane, s_stage[wv]);
+    int k = 0;
+#pragma unroll
+    for (int q = 0; q < Q; q++) {
+        int c = 0, chunk = 0;
+        const bool have = flat_chunk(jb, (int)blockIdx.x + (64 * q + lane) * (int)gridDim.x, c, chunk);
+        const bool work = have && jb.chunks[jb.chunk_off[c] + chunk].nnz > 0;
+        unsigned long long m = __ballot(work);
+        for (; m; k++) {
+            const int l = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            if ((k & 3) != wv) continue;
+            emit_chunk(jb, __builtin_amdgcn_readlane(c, l), __builtin_amdgcn_readlane(chunk, l), lane, s_stage[wv]);
+        }
     }
 }
 
@@ -1699,7 +1721,8 @@ void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunk
     // sparse (P pictures: most chunks empty: k_hz_*_list)
     if (ndense < 0 || ndense > njobs - nplain) ndense = njobs - nplain;
     const int nsparse = njobs - nplain - ndense;
-    const int list_wgs = (job_chunks + HZ_LIST_CPW - 1) / HZ_LIST_CPW;
+    const bool bigq = (long)((job_chunks + 64 * HZ_LIST_Q - 1) / (64 * HZ_LIST_Q)) * nsparse >= HZ_LIST_Q_MIN_WGS;
+    const int list_wgs = bigq ? (job_chunks + 64 * HZ_LIST_Q - 1) / (64 * HZ_LIST_Q) : (job_chunks + 63) / 64;
     if (ndense > 0) {
         PB(KID_HZ_COLLECT, samples * ndense * 2.0);             // 2 B/sample of symbols in
         hipLaunchKernelGGL(k_hz_collect, dim3((job_chunks + 3) / 4, ndense), dim3(256), 0, st, jobs + nplain);
@@ -1707,7 +1730,8 @@ void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunk
     }
     if (nsparse > 0) {
         PB(KID_HZ_COLLECT_LIST, 0.0);
-        hipLaunchKernelGGL(k_hz_collect_list, dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
+        if (bigq) hipLaunchKernelGGL((k_hz_collect_list<HZ_LIST_Q>), dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
+        else hipLaunchKernelGGL((k_hz_collect_list<1>), dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
         PE();
     }
     PB(KID_HZ_SCAN, 0.0);
@@ -1722,7 +1746,8 @@ void launch_hz_pack(hipStream_t st, const JobDev *jobs, int njobs, int job_chunk
     }
     if (nsparse > 0) {
         PB(KID_HZ_EMIT_LIST, 0.0);
-        hipLaunchKernelGGL(k_hz_emit_list, dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
+        if (bigq) hipLaunchKernelGGL((k_hz_emit_list<HZ_LIST_Q>), dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
+        else hipLaunchKernelGGL((k_hz_emit_list<1>), dim3(list_wgs, nsparse), dim3(256), 0, st, jobs + nplain + ndense);
         PE();
     }
 }

@@ -2054,7 +2054,11 @@ static __device__ __forceinline__ s16x2 pk_nudge0(s16x2 ll, s16x2 lp, s16x2 ln, 
     const s16x2 mx = pk_min(pk_max(a, b), z), mn = pk_max(pk_min(a, b), z);
     const s16x2 n = pk_rdiv2(pk_min(pk_max(pk_rdiv4(lp - ln), mx), mn));
     const s16x2 h = {hqp, hqp}, nh = {(short)-hqp, (short)-hqp};
+#ifdef AB_INVP_NUDGE0_MASK
     return pk_min(pk_max(n, nh), h) & ((mx - mn) >> 15) & pm;          // mx <= 0 <= mn, mn - mx <= 28000
+#else
+    return pk_min(pk_max(n, nh), h) & pm;          // (d_nudge's "mx == mn: no nudge" needs no mask here: mx <= 0 <= mn, so mx == mn means both are 0, the clamp gives 0 and rdiv2(0) = 0)
+#endif
 }
 // level 1 of one item of inv_p_fast: four adjacent cells (two int16 pairs) of one cell row -> 8 pixels x 2 rows.
 // row: the item's first LL1 pair in LDS (one pair of halo on each side, rows above / below at -WP / +WP); ZERO: no detail

@@ -21,12 +21,23 @@ def kid(name):
     """rocprofv3 prints k_hme_level<true, 12, 1> (second argument: rows per lane of a full block, picked per geometry by the
     launcher; third: 1 = the launch over the full blocks, 2 = the partial blocks at the frame's edge); the profiling API of
     the library and bench.py name the kernel by its first argument only"""
-    name = re.sub(r"^void (k_tail_q|k_hz_scan)<\d+>$", r"\1", name)                             # (round 4: templated on the workgroup size the launcher picks)
+    name = re.sub(r"^void (k_tail_q|k_hz_scan|k_hz_collect_list|k_hz_emit_list)<\d+>$", r"\1", name)                             # (round 4: templated on the workgroup size the launcher picks)
     name = re.sub(r"k_hme_level<(true|false), \d+, [013]>", r"k_hme_level<\1>", name)          # the full blocks (or every block)
     return re.sub(r"k_hme_level<(true|false), \d+, 2>", r"k_hme_level<\1> (partial blocks)", name)
 
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+def main_variant(rows):
+    """kernels templated on a size the launcher picks per batch (k_tail_q, k_hz_scan, the list kernels) show up once per variant;
+    the timed batch's variant is the one with the most launches (the bench's small check batches take the other): keep that row"""
+    best = {}
+    for r in rows:
+        k = kid(r["kernel"])
+        if k not in best or int(r["launches"]) > int(best[k]["launches"]):
+            best[k] = r
+    return list(best.values())
+
+
+rows = main_variant(list(csv.DictReader(open(sys.argv[1]))))
 out = {"gops": int(sys.argv[2]),
        "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --gops %s --steps 1`; "
                  "(2*FETCH_SIZE + WRITE_SIZE) KiB per launch, read side doubled: FETCH_SIZE tallies each 128-byte request at 64 bytes "
@@ -39,7 +50,7 @@ for r in rows:
                                    "hbm_bytes_per_launch": round((2 * f + w) * 1024),
                                    "hbm_bytes_per_launch_raw": round((f + w) * 1024)}
 if len(sys.argv) > 4:
-    for r in csv.DictReader(open(sys.argv[4])):
+    for r in main_variant(list(csv.DictReader(open(sys.argv[4])))):
         e = out["kernels"].setdefault(kid(r["kernel"]), {"launches": int(r["launches"])})
         e["valu_insts_per_launch"] = float(r.get("SQ_INSTS_VALU_per_launch", 0) or 0)
         e["salu_insts_per_launch"] = float(r.get("SQ_INSTS_SALU_per_launch", 0) or 0)
@@ -47,7 +58,7 @@ if len(sys.argv) > 4:
 if len(sys.argv) > 5:
     # SQ_ACTIVE_INST_VALU counts quad-cycles summed over the SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs:
     # busy fraction of the 1024 SIMDs = 4 * ACTIVE_INST_VALU / (128 * GUI_ACTIVE)
-    for r in csv.DictReader(open(sys.argv[5])):
+    for r in main_variant(list(csv.DictReader(open(sys.argv[5])))):
         e = out["kernels"].setdefault(kid(r["kernel"]), {"launches": int(r["launches"])})
         g = float(r.get("GRBM_GUI_ACTIVE_per_launch", 0) or 0)
         if g > 0:
