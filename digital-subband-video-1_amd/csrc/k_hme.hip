@@ -362,9 +362,12 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     if (parent) {
         const unsigned pmask = ~(unsigned)((step << 1) - 1);
         const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
-        // all five fetched before any is looked at (a neighbour outside the grid is fetched at the clamped position and counts
-        // as the zero vector): one scalar-memory round trip instead of five in a row -- the vectors were written by the
-        // previous launch, so each fetch goes to L2, and with a branch per neighbour the wave spent a third of its life here
+        // Lanes 0..4 fetch one parent each (a neighbour outside the grid counts as the zero vector) and de-duplicate among themselves:
+        // a vector is new iff it is non-zero and differs from the (up to four) parents before it -- the same set, in the same order,
+        // as comparing against the accepted candidates one by one.  The scalar form of this (five s_load, a chain of scalar compares
+        // and selects per parent) was ~230 of the kernel's ~970 scalar instructions per block, and the kernel pays for scalar
+        // instructions what it pays for vector ones (profiles/r04_hme_issue_probe.txt)
+#ifdef HME_SCALAR_PARENTS
         int par[5];
         bool pok[5];
 #pragma unroll
@@ -389,6 +392,40 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                 n++;
             }
         }
+#else
+        int par_l = 0;
+        if constexpr (LEVEL0) {
+            const int m = tid;
+            const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
+            const int x = pi + ox * step, y = pj + oy * step;
+            if (m < 5 && x >= 0 && x < A.nxb && y >= 0 && y < A.nyb)
+                par_l = *reinterpret_cast<const DSVG_GLOBAL int *>(dsvg_global(parent) + (x + y * A.nxb));      // DMV starts with int16 x, y: one dword = x | y << 16
+        } else {
+            // the upper levels' blocks are small and wait for their parents: those keep the scalar fetches (the scalar cache answers
+            // faster than the vector path: 1.14 against 1.43 ms per 320-GOP step), only the de-duplication moves to the lanes
+            int par[5];
+#pragma unroll
+            for (int m = 0; m < 5; m++) {
+                const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
+                const int x = pi + ox * step, y = pj + oy * step;
+                const bool ok = x >= 0 && x < A.nxb && y >= 0 && y < A.nyb;
+                const int idx = min(max(x, 0), A.nxb - 1) + min(max(y, 0), A.nyb - 1) * A.nxb;
+                par[m] = __builtin_amdgcn_readfirstlane(*reinterpret_cast<const int *>(parent + idx));
+                par[m] = ok ? par[m] : 0;
+            }
+            par_l = tid == 0 ? par[0] : (tid == 1 ? par[1] : (tid == 2 ? par[2] : (tid == 3 ? par[3] : (tid == 4 ? par[4] : 0))));
+        }
+        const int s1 = __builtin_amdgcn_update_dpp(0, par_l, 0x111, 0xf, 0xf, true), s2 = __builtin_amdgcn_update_dpp(0, par_l, 0x112, 0xf, 0xf, true);      // row_shr:1..4,
+        const int s3 = __builtin_amdgcn_update_dpp(0, par_l, 0x113, 0xf, 0xf, true), s4 = __builtin_amdgcn_update_dpp(0, par_l, 0x114, 0xf, 0xf, true);      // zero shifted in
+        unsigned um = (unsigned)__ballot(par_l != 0 && par_l != s1 && par_l != s2 && par_l != s3 && par_l != s4) & 0x1fu;
+        n = 1 + __popc(um);
+#pragma unroll
+        for (int k = 1; k < 6; k++) {
+            const int l = __ffs((int)um) - 1;
+            cand[k] = um ? __builtin_amdgcn_readlane(par_l, l & 63) : 0;
+            um &= um - 1u;
+        }
+#endif
     }
     int phase = 0;
 #ifdef AB_HME_DUMMY_SALU        // sensitivity probes (timing only): N extra scalar / vector instructions per block
@@ -576,10 +613,14 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
         }
         }
         block_sum_n<6>(acc, S.part, phase);
-        int best_score = 0x7fffffff;
+        // first minimum over the valid candidates (hme.c:503-506): the minimum of (score << 3 | index) -- a SAD is below 2^20
+        unsigned bestkey = 0x7fffffffu;
 #pragma unroll
-        for (int k = 0; k < 6; k++)
-            if (k < n && ((validmask >> k) & 1u) && best_score > (int)acc[k]) { best_score = (int)acc[k]; pick = k; }
+        for (int k = 0; k < 6; k++) {
+            const unsigned key = (k < n && ((validmask >> k) & 1u)) ? ((acc[k] << 3) | (unsigned)k) : 0x7fffffffu;
+            bestkey = min(bestkey, key);
+        }
+        if (bestkey != 0x7fffffffu) pick = (int)(bestkey & 7u);
     }
     if constexpr (ZE) {
         // the zero-motion block's sum and sum of squares (the statistics stage, hme.c:181-300) from the same rows
@@ -1245,8 +1286,17 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
 // own: in one kernel the register allocation is the generic body's (106 SGPRs + 246 spilled to VGPR lanes, 79 VGPRs; the
 // specialised body alone: 64 SGPRs, no spills).  PART 0: every block, generic body (geometries without full blocks).
 // PART 3: every block, either body (the small upper levels of the pyramid: a second launch costs more than it saves).
+// n / d for n < 2^32 with inv = min(floor(2^32 / d), 2^32 - 1) from the launcher: the estimate is the quotient or one below it
+// (the item -> pair / block row / block column divisions of every wave were two ~25-instruction division sequences)
+static __device__ __forceinline__ unsigned hme_udiv(unsigned n, unsigned d, unsigned inv, unsigned &r)
+{
+    unsigned q = __umulhi(n, inv);
+    r = n - q * d;
+    if (r >= d) { q++; r -= d; }
+    return q;
+}
 template <bool LEVEL0, int NKBF, int PART>
-__global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully)
+__global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully, unsigned inv_per, unsigned inv_row)
 {
     typedef HmeSharedT<((LEVEL0 || HME_UNION_UPPER != 0) && PART != 2 && PART != 0) ? NKBF : 0> HmeShared;      // (the window is sized for the launch's full blocks)
     __shared__ HmeShared SS[HME_WPG];
@@ -1270,15 +1320,16 @@ __global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level
         vb = r / gl;
         pair = q * HME_PG + (r - vb * gl);
     } else {
-        pair = item / per;
-        vb = item - pair * per;
+        unsigned r_;
+        pair = (int)hme_udiv((unsigned)item, (unsigned)per, inv_per, r_);
+        vb = (int)r_;
     }
-    if (PART == 1) { vj = vb / fullx; vi = vb - vj * fullx; }
+    if (PART == 1) { unsigned r_; vj = (int)hme_udiv((unsigned)vb, (unsigned)fullx, inv_row, r_); vi = (int)r_; }
     else if (PART == 2) {
         const int nr = (nvx - fullx) * nvy;                 // right strip (all rows), then the bottom strip under the full blocks
         if (vb < nr) { vj = vb / (nvx - fullx); vi = fullx + vb - vj * (nvx - fullx); }
         else { vb -= nr; vj = vb / fullx; vi = vb - vj * fullx; vj += fully; }
-    } else { vi = vb % nvx; vj = vb / nvx; }
+    } else { unsigned r_; vj = (int)hme_udiv((unsigned)vb, (unsigned)nvx, inv_row, r_); vi = (int)r_; }
     const int i = vi * step, j = vj * step;
     const int fw = A.L[level].w[0], fh = A.L[level].h[0];
     const int bx = (i * A.blk_w) >> level, by = (j * A.blk_h) >> level;
@@ -1396,7 +1447,10 @@ void launch_hme(hipStream_t st, const HmeArgs &A, int npairs, Prof *pf)
         const int fw = A.L[level].w[0], fh = A.L[level].h[0];
         const int fullx = nkbf ? std::min(nvx, fw / 64) : 0, fully = nkbf ? std::min(nvy, fh / A.blk_h) : 0;
         const int nfull = fullx * fully, nrest = nvx * nvy - nfull;
-#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid(((cnt) * npairs + HME_WPG - 1) / HME_WPG)), blk, 0, st, A, level, npairs, fullx, fully)
+        auto uinv = [](int d) { return (unsigned)std::min<unsigned long long>(0x100000000ull / (unsigned long long)std::max(d, 1), 0xffffffffull); };
+        // (inv_row: the row length the launch's block index is split by -- PART 1: fullx; PART 0 / 3: nvx; PART 2 divides by its two strip widths itself)
+#define HME_LAUNCH(L0, N, P, cnt) hipLaunchKernelGGL((k_hme_level<L0, N, P>), dim3(xcd_grid(((cnt) * npairs + HME_WPG - 1) / HME_WPG)), blk, 0, st, A, level, npairs, fullx, fully, \
+                                                     uinv(cnt), uinv((P) == 1 ? fullx : nvx))
 #define HME_FULL(L0) do { switch (nkbf) { case 16: HME_LAUNCH(L0, 16, 1, nfull); break; case 12: HME_LAUNCH(L0, 12, 1, nfull); break; \
                                           default: HME_LAUNCH(L0, 8, 1, nfull); } } while (0)
         (void)nrest;

@@ -9,7 +9,7 @@ nkb = sys.argv[1] if len(sys.argv) > 1 else "12"
 s_path = "/tmp/k_hme_mark.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DAB_HME_ASMMARK",
                        os.path.join(repo, "digital-subband-video-1_amd/csrc/k_hme.hip"), "-o", s_path], stderr=subprocess.DEVNULL, cwd="/tmp")
-name = "_Z11k_hme_levelILb1ELi%sELi1EEv7HmeArgsiiii" % nkb
+name = "_Z11k_hme_levelILb1ELi%sELi1EEv7HmeArgsiiiijj" % nkb
 lines = open(s_path).read().split("\n")
 i0 = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
 i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith("\t.section") or lines[i].startswith(".Lfunc_end"))
