@@ -162,7 +162,10 @@ static __device__ __forceinline__ unsigned ldg_u32_unaligned(const uint8_t *p)
 #endif
 #define UW_PPR (UW_P / 4)                                    // 16-byte pieces per staged row
 #define UW_PDIV(p) (((p) * ((262144 + UW_PPR - 1) / UW_PPR)) >> 18)     // p / UW_PPR for p < 1024
-#define UW_SPY 14
+// (vertical spread, measured per 320-GOP step: 14 rows 5.57-5.64 ms, 8: 5.41-5.45, 5: 5.44-5.46, 3: 5.46-5.53, 2: 5.44-5.52, 0: 5.84-5.89)
+#ifndef UW_SPY
+#define UW_SPY 8
+#endif
 #define UW_ROWS(NKB) (4 * (NKB) + 2 + UW_SPY)
 template <int NKB>
 struct HmeSharedT {
@@ -172,7 +175,7 @@ struct HmeSharedT {
         // the union window (see above), dead once the half-pel patch has been taken out of it
         __attribute__((aligned(16))) unsigned win[(NKB > 0 && HME_UNION) ? UW_ROWS(NKB) * UW_P : 4];
         // the +-1 search's reference window (full blocks: 4 * NKB + 2 rows of 20 dwords), dead before the half-pel stage begins
-        __attribute__((aligned(16))) unsigned nine[NINE_ROWS * NINE_P];
+        __attribute__((aligned(16))) unsigned nine[(NKB > 0 ? 4 * NKB + 2 : NINE_ROWS) * NINE_P];
         struct {
             __attribute__((aligned(16))) uint8_t patch[20 * 24];
             __attribute__((aligned(16))) short h16[20 * 16];
@@ -307,7 +310,10 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     const int fw = L.w[0], fh = L.h[0], stride = L.stride[0];
     const int BW = A.blk_w, BH = A.blk_h;
     const int bx = (i * BW) >> level, by = (j * BH) >> level;
-    const int cur = A.cur_slots[pair], rf = A.ref_slots[pair];
+    // (the slot tables were written by the host before the launch: read through the constant address space they come by scalar
+    // loads -- as generic pointers the compiler took the vector path for them, a memory round trip in front of the block's first rows)
+    typedef const __attribute__((address_space(4))) int *HmeCInt;
+    const int cur = ((HmeCInt)A.cur_slots)[pair], rf = ((HmeCInt)A.ref_slots)[pair];
     const uint8_t *sp = A.slab[level] + (size_t)cur * L.pitch + L.off[0];
     const uint8_t *rp = A.slab[level] + (size_t)rf * L.pitch + L.off[0];
     const int bw = FAST ? 64 : min(max(fw - bx, 0), BW), bh = FAST ? 4 * NKB : min(max(fh - by, 0), BH);
@@ -1295,8 +1301,13 @@ static __device__ __forceinline__ unsigned hme_udiv(unsigned n, unsigned d, unsi
     if (r >= d) { q++; r -= d; }
     return q;
 }
+#ifdef HME_WPE
+#define HME_WPE_ATTR __attribute__((amdgpu_waves_per_eu(HME_WPE, HME_WPE)))
+#else
+#define HME_WPE_ATTR
+#endif
 template <bool LEVEL0, int NKBF, int PART>
-__global__ __launch_bounds__(NT * HME_WPG) void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully, unsigned inv_per, unsigned inv_row)
+__global__ __launch_bounds__(NT * HME_WPG) HME_WPE_ATTR void k_hme_level(HmeArgs A, int level, int npairs, int fullx, int fully, unsigned inv_per, unsigned inv_row)
 {
     typedef HmeSharedT<((LEVEL0 || HME_UNION_UPPER != 0) && PART != 2 && PART != 0) ? NKBF : 0> HmeShared;      // (the window is sized for the launch's full blocks)
     __shared__ HmeShared SS[HME_WPG];
