@@ -809,21 +809,33 @@ static __device__ __forceinline__ void fwd_fast_level(const QCtx &q, const QLeve
 #define FWD_FAST_INTRA 1
 #endif
 struct FwdFastSel { bool ok, intra; QLevel L1, L2, L3; int i1[4], i2[2], i3; };
-static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, const HzPlane &hp, bool any_ov, int mode, int I, int J,
-                                                          int x0, int y0, int pw, int ph)
+// what a patch's selection and quantiser need of the job table (HzPlane of its plane): read in ONE batch by the callers that care
+// (k_fwd_mc_fast: the compiler otherwise fetches each field where it is first used, behind the short-circuit tests below -- a dozen
+// dependent scalar-memory round trips in front of the patch's first pixel load)
+struct FwdFastHp { QLevel L1, L2, L3; int nbh; bool ovx, ovy, sparse; };
+static __device__ __forceinline__ FwdFastHp fwd_fast_hp(const JobDev &jb, const HzPlane &hp)
+{
+    FwdFastHp H;
+    const int sw0 = hp.s_w[0], sw1 = hp.s_w[1], sw2 = hp.s_w[2], sh0 = hp.s_h[0], sh1 = hp.s_h[1], sh2 = hp.s_h[2];
+    H.L1 = q_level<2>(hp); H.L2 = q_level<1>(hp); H.L3 = q_level<0>(hp);
+    H.nbh = hp.nbh;
+    // cells shared between scan regions (hzcc.c:30-48 rounds the region sizes up at every level): column 0 of the LH / HH
+    // bands of a level whose width is odd, row 0 of its HL / HH bands when its height is odd -- first column / row of patches
+    H.ovx = (int)(2 * sw0 > sw1) | (int)(2 * sw1 > sw2);
+    H.ovy = (int)(2 * sh0 > sh1) | (int)(2 * sh1 > sh2);
+    H.sparse = jb.nzf != nullptr;
+    return H;
+}
+static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const FwdFastHp &H, int mode, int I, int J, int x0, int y0, int pw, int ph)
 {
     // The map's block rows are hp.nbv / region height apart in coefficient space, not blk_h: a picture whose height is not
     // a multiple of the block height makes them drift against the real block grid, so a patch often spans two map rows.
     // One flag per CELL ROW of each level covers that; only a patch that spans two map COLUMNS goes to the general kernel.
     FwdFastSel S;
     S.ok = false; S.intra = mode != 0;
-    // cells shared between scan regions (hzcc.c:30-48 rounds the region sizes up at every level): column 0 of the LH / HH
-    // bands of a level whose width is odd, row 0 of its HL / HH bands when its height is odd -- first column / row of patches
-    const bool ovx = any_ov && ((2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_w[1] > hp.s_w[2]));
-    const bool ovy = any_ov && ((2 * hp.s_h[0] > hp.s_h[1]) || (2 * hp.s_h[1] > hp.s_h[2]));
-    if (jb.nzf != nullptr && (FWD_FAST_INTRA || mode == 0) && x0 + 8 <= pw && y0 + 8 <= ph && !(ovx && I == 0) && !(ovy && J == 0)) {
-        S.L1 = q_level<2>(hp); S.L2 = q_level<1>(hp); S.L3 = q_level<0>(hp);
-        const int nbh = hp.nbh;
+    if (H.sparse && (FWD_FAST_INTRA || mode == 0) && x0 + 8 <= pw && y0 + 8 <= ph && !(H.ovx && I == 0) && !(H.ovy && J == 0)) {
+        S.L1 = H.L1; S.L2 = H.L2; S.L3 = H.L3;
+        const int nbh = H.nbh;
         const int b1x = (4 * I * S.L1.dbx) >> 14, b2x = (2 * I * S.L2.dbx) >> 14;
         S.ok = b1x == ((4 * I + 3) * S.L1.dbx) >> 14 && b2x == ((2 * I + 1) * S.L2.dbx) >> 14;
 #pragma unroll
@@ -833,6 +845,12 @@ static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, cons
         S.i3 = ((J * S.L3.dby) >> 14) * nbh + ((I * S.L3.dbx) >> 14);
     }
     return S;
+}
+static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, const HzPlane &hp, bool any_ov, int mode, int I, int J,
+                                                          int x0, int y0, int pw, int ph)
+{
+    (void)any_ov;
+    return fwd_fast_sel(fwd_fast_hp(jb, hp), mode, I, J, x0, y0, pw, ph);
 }
 
 template <int CH>
@@ -855,16 +873,31 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
     const int bi = (int)(((float)I + 0.5f) * __builtin_amdgcn_rcpf((float)(bw >> 3)));
     const int bj = (int)(((float)J + 0.5f) * __builtin_amdgcn_rcpf((float)(bh >> 3)));
     const int nblk = MG.nbh * MG.nbv, blk = bj * MG.nbh + bi;
-    const DMV mv = mvs0 ? mvs0[(size_t)job * nblk + blk] : jb.mvs[blk];
+    // the job table's part of this patch, requested in one go (FwdFastHp) and held where it is: the pins keep the compiler from moving
+    // each fetch down to its first use
     const HzPlane &hp = jb.hz[c];
+    FwdFastHp H = fwd_fast_hp(jb, hp);
+    const DMV *mvtab = jb.mvs;
+    const uint8_t *stable_p = jb.stable, *srcp_p = jb.srcp[c];
+    int sstride = jb.srcs[c];
+#define FWD_PIN(x) asm volatile("" : "+s"(x))
+#ifndef FWD_FAST_NO_PIN
+    FWD_PIN(H.L1.sh0); FWD_PIN(H.L1.sh1); FWD_PIN(H.L1.dbx); FWD_PIN(H.L1.dby); FWD_PIN(H.L2.qp); FWD_PIN(H.L2.dbx); FWD_PIN(H.L2.dby);
+    FWD_PIN(H.L3.qp); FWD_PIN(H.L3.dbx); FWD_PIN(H.L3.dby); FWD_PIN(H.nbh); FWD_PIN(mvtab); FWD_PIN(stable_p); FWD_PIN(srcp_p); FWD_PIN(sstride);
+#endif
+    DMV mv;                                              // (x, y, mode: global loads -- through the generic pointer they were flat loads, which the flag loads behind them cannot overtake)
+    {
+        const auto mq = reinterpret_cast<const DSVG_GLOBAL char *>(dsvg_global(mvs0 ? mvs0 + (size_t)job * nblk : mvtab)) + (unsigned)blk * (unsigned)sizeof(DMV);
+        const unsigned xy = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(mq);
+        mv.x = (int16_t)(xy & 0xffffu); mv.y = (int16_t)(xy >> 16); mv.mode = *reinterpret_cast<const DSVG_GLOBAL uint8_t *>(mq + 4);
+    }
     QCtx q;
-    q.hp = &hp; q.stable = dsvg_global(jb.stable);
+    q.hp = &hp; q.stable = dsvg_global(stable_p);
     q.sym = dsvg_global(jb.sym + jb.nz_off[c]);
-    q.any_ov = (2 * hp.s_w[0] > hp.s_w[1]) || (2 * hp.s_h[0] > hp.s_h[1]) ||
-               (2 * hp.s_w[1] > hp.s_w[2]) || (2 * hp.s_h[1] > hp.s_h[2]);
-    q.nzf = jb.nzf ? dsvg_global(jb.nzf + (jb.nz_off[c] >> 2)) : nullptr;
-    q.cfl = jb.nzf ? dsvg_global(jb.cflag + jb.chunk_off[c]) : nullptr;
-    const FwdFastSel S = fwd_fast_sel(jb, hp, q.any_ov, mv.mode, I, J, x0, y0, pw, ph);
+    q.any_ov = H.ovx | H.ovy;
+    q.nzf = H.sparse ? dsvg_global(jb.nzf + (jb.nz_off[c] >> 2)) : nullptr;
+    q.cfl = H.sparse ? dsvg_global(jb.cflag + jb.chunk_off[c]) : nullptr;
+    const FwdFastSel S = fwd_fast_sel(H, mv.mode, I, J, x0, y0, pw, ph);
     if (!S.ok) return;                                   // k_fwd_mc_pix takes these
     const QLevel &L1 = S.L1, &L2 = S.L2, &L3 = S.L3;
     int f1[4], f2[2];
@@ -873,8 +906,7 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
 #pragma unroll
     for (int j = 0; j < 2; j++) f2[j] = q.stable[S.i2[j]];
     const int f3 = q.stable[S.i3];
-    const auto sp = dsvg_global(jb.srcp[c]);
-    const int sstride = jb.srcs[c];
+    const auto sp = dsvg_global(srcp_p);
     uint2 sw[8];
     if (S.intra) {                                      // an intra block's patch: the residual rows, from the work frame (k_mc wrote them and the prediction)
         const auto px = dsvg_global(static_cast<const uint8_t *>(jb.xf + g.poff));
