@@ -2162,6 +2162,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     auto ldu8 = [](auto base, unsigned off) { return (int)*(base + off); };
     auto lds16 = [](auto base, unsigned idx) { return (int)dsvg_at(base, idx); };
     auto flagidx = [&](const QLevel &Q, unsigned cx, unsigned cy) { return __umul24(__umul24(cy, (unsigned)Q.dby) >> 14, (unsigned)nbh) + (__umul24(cx, (unsigned)Q.dbx) >> 14); };
+    // The stability flags fetched in phase 0 stay RAW until their level is computed: turning a flag into its quantiser class (or
+    // shift) where it is fetched put an s_waitcnt behind every group of loads -- four memory round trips one after the other in a
+    // phase whose point is to have every load of the tile in flight at once
+    auto CLS = [](int f) { return (f & 2) ? 2 : (f != 0); };                    // tmq4pos hzcc.c:64-74
+    auto SH1 = [&](int f) { return f ? Q1.sh1 : Q1.sh0; };                      // hzcc.c:221-224
     int pf1[2];
     bool v1[2];                                         // the item's cell row exists (EB: the band may end inside the tile)
 #pragma unroll
@@ -2208,20 +2213,20 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
             s3lh = lds16(sym, (unsigned)Q2.base0 + __umul24(2u * (unsigned)cy, (unsigned)Q2.sw));
             s3hl = lds16(sym, (unsigned)Q2.base0 + __umul24(2u * (unsigned)cy + 1u, (unsigned)Q2.sw));
             const int fa = ldu8(stable, flagidx(Q2, 0u, 2u * (unsigned)cy)), fb = ldu8(stable, flagidx(Q2, 0u, 2u * (unsigned)cy + 1u));
-            k3 = (fa & 2) ? 2 : (fa != 0); s3hh = (fb & 2) ? 2 : (fb != 0);
+            k3 = fa; s3hh = fb;                       // (raw flags: see CLS below)
         } else
         if (EB && ok3 && cy >= h3) {
             // the non-existent cell row below the band: its LL2 outputs are the HL2 values of row 0 of level-2 columns 2cx, 2cx+1
             s3lh = lds16(sym, (unsigned)Q2.base1 + 2u * (unsigned)cx);
             s3hl = lds16(sym, (unsigned)Q2.base1 + 2u * (unsigned)cx + 1u);
             const int fa = ldu8(stable, flagidx(Q2, 2u * (unsigned)cx, 0u)), fb = ldu8(stable, flagidx(Q2, 2u * (unsigned)cx + 1u, 0u));
-            k3 = (fa & 2) ? 2 : (fa != 0); s3hh = (fb & 2) ? 2 : (fb != 0);
+            k3 = fa; s3hh = fb;                       // (raw flags: see CLS below)
         } else
         if (ok3) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)Q3.sw) + (unsigned)cx;
             s3lh = lds16(sym, (unsigned)Q3.base0 + o); s3hl = lds16(sym, (unsigned)Q3.base1 + o); s3hh = lds16(sym, (unsigned)Q3.base2 + o);
             const int f = ldu8(stable, flagidx(Q3, (unsigned)cx, (unsigned)cy));
-            k3 = (f & 2) ? 2 : (f != 0);
+            k3 = f;
         }
     }
     constexpr int N2 = ((2 * IT_TY + 2) * (2 * IT_TX + 2) + 255) / 256;
@@ -2241,20 +2246,20 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
             s2hl[u] = lds16(sym, (unsigned)Q1.base0 + __umul24(2u * (unsigned)cy + 1u, (unsigned)Q1.sw));
             const unsigned bya = __umul24(__umul24(2u * (unsigned)cy, (unsigned)Q1.dby) >> 14, (unsigned)nbh),
                            byb = __umul24(__umul24(2u * (unsigned)cy + 1u, (unsigned)Q1.dby) >> 14, (unsigned)nbh);
-            k2[u] = ldu8(stable, bya) ? Q1.sh1 : Q1.sh0; s2hh[u] = ldu8(stable, byb) ? Q1.sh1 : Q1.sh0;
+            k2[u] = ldu8(stable, bya); s2hh[u] = ldu8(stable, byb);
         } else
         if (EB && ok2[u] && cy >= 2 * h3) {
             // below the band at level 2: the LL1 halo values are the HL1 values of row 0 of level-1 columns 2cx, 2cx+1
             s2lh[u] = lds16(sym, (unsigned)Q1.base1 + 2u * (unsigned)cx);
             s2hl[u] = lds16(sym, (unsigned)Q1.base1 + 2u * (unsigned)cx + 1u);
-            k2[u] = ldu8(stable, __umul24(2u * (unsigned)cx, (unsigned)Q1.dbx) >> 14) ? Q1.sh1 : Q1.sh0;
-            s2hh[u] = ldu8(stable, __umul24(2u * (unsigned)cx + 1u, (unsigned)Q1.dbx) >> 14) ? Q1.sh1 : Q1.sh0;
+            k2[u] = ldu8(stable, __umul24(2u * (unsigned)cx, (unsigned)Q1.dbx) >> 14);
+            s2hh[u] = ldu8(stable, __umul24(2u * (unsigned)cx + 1u, (unsigned)Q1.dbx) >> 14);
         } else
         if (ok2[u]) {
             const unsigned o = __umul24((unsigned)cy, (unsigned)Q2.sw) + (unsigned)cx;
             s2lh[u] = lds16(sym, (unsigned)Q2.base0 + o); s2hl[u] = lds16(sym, (unsigned)Q2.base1 + o); s2hh[u] = lds16(sym, (unsigned)Q2.base2 + o);
             const int f = ldu8(stable, flagidx(Q2, (unsigned)cx, (unsigned)cy));
-            k2[u] = (f & 2) ? 2 : (f != 0);
+            k2[u] = f;
         }
     }
     uint2 pv[2][2];
@@ -2270,11 +2275,15 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         }
     }
     uint2 d1lh[2], d1hl[2], d1hh[2];
-    s16x2 shv[2][2];
+    int fr1[2][4];                                      // the level-1 flags of the item's four cells, raw (see CLS above)
+    // (both items' patch flags are looked at HERE: behind the first item's conditional loads the compiler has to assume the worst
+    // about what is in flight and would wait for nearly everything before it tests the second flag)
+    unsigned long long any1[2] = {__ballot(pf1[0] != 0), __ballot(pf1[1] != 0)};
+    asm volatile("" : "+s"(any1[0]), "+s"(any1[1]));
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         d1lh[u] = d1hl[u] = d1hh[u] = make_uint2(0u, 0u);
-        shv[u][0] = shv[u][1] = s16x2{0, 0};
+        fr1[u][0] = fr1[u][1] = fr1[u][2] = fr1[u][3] = 0;
         if (pf1[u]) {
             const unsigned it = utid + 256u * u, ly = it >> 4, gx = it & 15u;
             const unsigned cy = 4u * (unsigned)J0 + ly, cx0 = 4u * ((unsigned)I0 + gx);
@@ -2285,15 +2294,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
             d1hh[u] = dsvg_ld2(sb + 2u * ((unsigned)Q1.base2 + o));
             const unsigned by = __umul24(__umul24(cy, (unsigned)Q1.dby) >> 14, (unsigned)nbh);
             const unsigned bx0 = __umul24(cx0, (unsigned)Q1.dbx) >> 14, bx3 = __umul24(cx0 + 3u, (unsigned)Q1.dbx) >> 14;
-            const int f0 = ldu8(stable, by + bx0);
-            int f1 = f0, f2 = f0, f3 = f0;
+            fr1[u][0] = ldu8(stable, by + bx0);
+            fr1[u][1] = fr1[u][2] = fr1[u][3] = -1;         // "as cell 0" (a copy of the loaded flag would wait for it here)
             if (bx0 != bx3) {
-                f1 = ldu8(stable, by + (__umul24(cx0 + 1u, (unsigned)Q1.dbx) >> 14));
-                f2 = ldu8(stable, by + (__umul24(cx0 + 2u, (unsigned)Q1.dbx) >> 14));
-                f3 = ldu8(stable, by + bx3);
+                fr1[u][1] = ldu8(stable, by + (__umul24(cx0 + 1u, (unsigned)Q1.dbx) >> 14));
+                fr1[u][2] = ldu8(stable, by + (__umul24(cx0 + 2u, (unsigned)Q1.dbx) >> 14));
+                fr1[u][3] = ldu8(stable, by + bx3);
             }
-            shv[u][0] = s16x2{(short)(f0 ? Q1.sh1 : Q1.sh0), (short)(f1 ? Q1.sh1 : Q1.sh0)};
-            shv[u][1] = s16x2{(short)(f2 ? Q1.sh1 : Q1.sh0), (short)(f3 ? Q1.sh1 : Q1.sh0)};
         }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -2324,13 +2331,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
     // ---- level 3: cells I0-1 .. I0+TX (halo 1) -> LL2 values, scaled up, in A2u
     if (ER && ok3 && I0 - 1 + lx3 >= w3) {
         int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
-        d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> k3, HZ_MINQ))); d[1] = 0;
-        d[W2] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> s3hh, HZ_MINQ))); d[W2 + 1] = 0;
+        d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> CLS(k3), HZ_MINQ))); d[1] = 0;
+        d[W2] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> CLS(s3hh), HZ_MINQ))); d[W2 + 1] = 0;
     } else
     if (EB && ok3 && J0 - 1 + ly3 >= h3) {
         int *d = A2u + (2 * ly3) * W2 + 2 * lx3;
-        d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> k3, HZ_MINQ)));
-        d[1] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> s3hh, HZ_MINQ)));
+        d[0] = d_ll_up_t<true>(dq_lo24(s3lh, max(Q2.qp >> CLS(k3), HZ_MINQ)));
+        d[1] = d_ll_up_t<true>(dq_lo24(s3hl, max(Q2.qp >> CLS(s3hh), HZ_MINQ)));
         d[W2] = 0; d[W2 + 1] = 0;
     } else
 #ifdef AB_INVP_NO_L3                   // timing probes (wrong pictures): a level reduced to copying its LL value
@@ -2345,7 +2352,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const int LL = pA[0];
         int LH = 0, HL = 0, HH = 0;
         if (__ballot((s3lh | s3hl | s3hh) != 0)) {           // (a wave without a level-3 symbol: no dequantiser)
-            const int q = max(Q3.qp >> k3, HZ_MINQ);
+            const int q = max(Q3.qp >> CLS(k3), HZ_MINQ);
             LH = dq_lo24(s3lh, q); HL = dq_lo24(s3hl, q); HH = dq_lo24(s3hh, q);
         }
         if (FILT) {
@@ -2367,13 +2374,13 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const int ly = (int)((i * 241u) >> 13), lx = (int)i - ly * (2 * IT_TX + 2);
         if (ER && 2 * I0 - 1 + lx >= 2 * w3) {
             unsigned *d = A1p + (2 * ly) * WP + lx;
-            d[0] = pk_i16((int)((unsigned)s2lh[u] << k2[u]), 0);
-            d[WP] = pk_i16((int)((unsigned)s2hl[u] << s2hh[u]), 0);
+            d[0] = pk_i16((int)((unsigned)s2lh[u] << SH1(k2[u])), 0);
+            d[WP] = pk_i16((int)((unsigned)s2hl[u] << SH1(s2hh[u])), 0);
             continue;
         }
         if (EB && 2 * J0 - 1 + ly >= 2 * h3) {
             unsigned *d = A1p + (2 * ly) * WP + lx;
-            d[0] = pk_i16((int)((unsigned)s2lh[u] << k2[u]), (int)((unsigned)s2hl[u] << s2hh[u]));
+            d[0] = pk_i16((int)((unsigned)s2lh[u] << SH1(k2[u])), (int)((unsigned)s2hl[u] << SH1(s2hh[u])));
             d[WP] = 0;
             continue;
         }
@@ -2384,7 +2391,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 #endif
         int LH = 0, HL = 0, HH = 0;
         if (__ballot((s2lh[u] | s2hl[u] | s2hh[u]) != 0)) {
-            const int q = max(Q2.qp >> k2[u], HZ_MINQ);
+            const int q = max(Q2.qp >> CLS(k2[u]), HZ_MINQ);
             LH = dq_lo24(s2lh[u], q); HL = dq_lo24(s2hl[u], q); HH = dq_lo24(s2hh[u], q);
         }
         if (FILT) {
@@ -2413,7 +2420,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
         const unsigned *row = A1p + (ly + 2) * WP + 2 * gx;          // pairs 2gx .. 2gx+3 hold LL1 columns 4gx .. 4gx+7 (halo 2)
         unsigned row0[2], row1[2];
         if (EB && !v1[u]) continue;
-        const bool zero1 = __ballot(pf1[u] != 0) == 0ull;
+        const bool zero1 = any1[u] == 0ull;
+        s16x2 shv[2][2];
+        auto fcell = [&](int k) { return fr1[u][k] < 0 ? fr1[u][0] : fr1[u][k]; };
+        shv[u][0] = s16x2{(short)SH1(fr1[u][0]), (short)SH1(fcell(1))};
+        shv[u][1] = s16x2{(short)SH1(fcell(2)), (short)SH1(fcell(3))};
 #if defined(AB_INVP_NO_L1)
         row0[0] = pv[u][0].x ^ row[0]; row0[1] = pv[u][0].y; row1[0] = pv[u][1].x; row1[1] = pv[u][1].y;
         if (false)
