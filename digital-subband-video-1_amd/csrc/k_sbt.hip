@@ -1282,21 +1282,40 @@ __global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs
                 for (int h = 0; h < 2; h++)      // 16-bit shifts take four bits: |value| < 2^12, so 15 stands for anything larger
                     shv[m][h] = s16x2{(short)min(cls[m][2 * h] ? Lq.sh1 : Lq.sh0, 15), (short)min(cls[m][2 * h + 1] ? Lq.sh1 : Lq.sh0, 15)};
             const s16x2 c512 = s16x2{512, 512};
+            // The ten rows of the patch's window are requested FB4T_AHEAD rows ahead of the row pass (per 320 I pictures: under the branch
+            // 0.92-0.94 ms; 2 rows ahead 0.86, 3: 0.82-0.83, 5: 0.92, all ten: 0.85 -- the registers cost waves per SIMD: 78 / 89 / 99 / 101).  (A coefficient row past the picture's last pixel row -- odd heights -- reads that
+            // last row and is replaced by sample 0 = byte 128 afterwards: with the loads under that test, and the cell rows' stores and
+            // branches between them, each row was fetched, waited for and consumed before the next one was requested.)
+#ifndef FB4T_AHEAD
+#define FB4T_AHEAD 3
+#endif
+            uint2 mmv[10];
+            unsigned lfv[10], rgv[10];
+            auto request = [&](int r) {
+                int y = 8 * J - 1 + r;
+                y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
+                const unsigned ro = (unsigned)(min(y, g.ph - 1) * pxs + 8 * I);
+                mmv[r] = dsvg_ld2(pxg + ro);
+                lfv[r] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro - 4u);
+                rgv[r] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro + 8u);
+            };
+#pragma unroll
+            for (int r = 0; r < FB4T_AHEAD && r < 10; r++) request(r);
 #pragma unroll
             for (int r = 0; r < 10; r++) {
                 int y = 8 * J - 1 + r;
-                y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
-                unsigned lo = 0x80808080u, mi = 0x80808080u, hi = 0x80808080u;      // bytes x = 8I-1 .. 8I+2, +3 .. +6, +7 .. (sample 0 = byte 128)
-                if (y < g.ph) {
-                    const unsigned ro = (unsigned)(y * pxs + 8 * I);
-                    const uint2 mm = dsvg_ld2(pxg + ro);
-                    const unsigned lft = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro - 4u);
-                    const unsigned rgt = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro + 8u);
+                y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);
+                if (r + FB4T_AHEAD < 10) request(r + FB4T_AHEAD);
+                unsigned lo, mi, hi;                                // bytes x = 8I-1 .. 8I+2, +3 .. +6, +7 ..
+                {
+                    const uint2 mm = mmv[r];
+                    const unsigned lft = lfv[r], rgt = rgv[r];
                     lo = __builtin_amdgcn_alignbyte(mm.x, lft, 3u);
                     mi = __builtin_amdgcn_alignbyte(mm.y, mm.x, 3u);
                     hi = __builtin_amdgcn_alignbyte(rgt, mm.y, 3u);
                     if (ledge) lo = __builtin_amdgcn_perm(0u, lo, 0x03020102u);       // x[-1] = x[1]
                     if (redge) hi = __builtin_amdgcn_perm(0u, hi, 0x03020000u);       // x[W] = x[W-1]
+                    if (y >= g.ph) lo = mi = hi = 0x80808080u;
                 }
                 // A[j] = (byte j, byte j + 2): cell k reads bytes 2k .. 2k+3 as xm, x0, x1, xp
                 const s16x2 A0 = PK_EVEN(0u, lo), A1 = PK_ODD(0u, lo), A2 = PK_E2(mi, lo), A3 = PK_O2(mi, lo), A4 = PK_EVEN(0u, mi), A5 = PK_ODD(0u, mi),
@@ -1819,29 +1838,35 @@ static __device__ __forceinline__ LvlGeo mk_lvl(int W, int H, int lvl, int hqp, 
 //                  encoder) -- dequantised here (hzcc.c:121-128,221-224), so the dequantised coefficients
 //                  never exist in HBM.  The value of a cell two scan regions share is the later region's
 //                  dequantised symbol, which is the region of the band the cell physically sits in.
-struct Raw3 { int lh, hl, hh, k; };                 // the three details of one cell as fetched (+ flag class)
+struct Raw3 { int lh, hl, hh, k, m; };              // the three details of one cell as fetched, its stability flag (raw), m: bit 0 / 1 = the cell has an LH / HL band
 template <bool SYM> struct Raw4;                    // the same for four adjacent complete level-1 cells
 template <> struct Raw4<false> { int4 lh, hl, hh; };
 template <> struct Raw4<true> { uint2 lh, hl, hh; int k0, k1, k2, k3; };
 template <bool SYM, int HZL> struct Det;
 template <int HZL> struct Det<false, HZL> {
-    const int32_t *coef; int W, wo, ho;
+    const DSVG_GLOBAL int32_t *coef; int W, wo, ho;          // (global address space: flat loads would tie the fetches to every scalar-load wait, see dsvg_global)
     __device__ __forceinline__ Raw3 fetch(int cx, int cy, bool hasR, bool hasB) const
     {
+        // (a band the cell does not have is fetched at the plane's first coefficient and dropped in finish(): a select on the
+        // loaded value here would make the fetch wait for it -- the tile kernels request every level's cells before they use any)
         Raw3 r;
-        r.lh = hasR ? coef[(size_t)cy * W + wo + cx] : 0;
-        r.hl = hasB ? coef[(size_t)(ho + cy) * W + cx] : 0;
-        r.hh = (hasR && hasB) ? coef[(size_t)(ho + cy) * W + wo + cx] : 0;
-        r.k = 0;
+        r.lh = coef[hasR ? (size_t)cy * W + wo + cx : 0];
+        r.hl = coef[hasB ? (size_t)(ho + cy) * W + cx : 0];
+        r.hh = coef[(hasR && hasB) ? (size_t)(ho + cy) * W + wo + cx : 0];
+        r.k = 0; r.m = (hasR ? 1 : 0) | (hasB ? 2 : 0);
         return r;
     }
-    __device__ __forceinline__ void finish(const Raw3 &r, int &LH, int &HL, int &HH) const { LH = r.lh; HL = r.hl; HH = r.hh; }
+    __device__ __forceinline__ void finish(const Raw3 &r, int &LH, int &HL, int &HH) const
+    {
+        LH = (r.m & 1) ? r.lh : 0; HL = (r.m & 2) ? r.hl : 0; HH = r.m == 3 ? r.hh : 0;
+    }
     __device__ __forceinline__ Raw4<false> fetch4(int cx0, int cy) const
     {
         Raw4<false> r;
-        r.lh = *reinterpret_cast<const int4 *>(coef + (size_t)cy * W + wo + cx0);
-        r.hl = *reinterpret_cast<const int4 *>(coef + (size_t)(ho + cy) * W + cx0);
-        r.hh = *reinterpret_cast<const int4 *>(coef + (size_t)(ho + cy) * W + wo + cx0);
+        auto ld = [](const DSVG_GLOBAL int32_t *q) { const uint4 t = dsvg_ld4(q); return make_int4((int)t.x, (int)t.y, (int)t.z, (int)t.w); };
+        r.lh = ld(coef + (size_t)cy * W + wo + cx0);
+        r.hl = ld(coef + (size_t)(ho + cy) * W + cx0);
+        r.hh = ld(coef + (size_t)(ho + cy) * W + wo + cx0);
         return r;
     }
     __device__ __forceinline__ void finish4(const Raw4<false> &r, int (&lhv)[4], int (&hlv)[4], int (&hhv)[4]) const
@@ -1860,53 +1885,55 @@ template <int HZL> struct Det<false, HZL> {
     }
 };
 template <int HZL> struct Det<true, HZL> {
-    const int16_t *sym; const uint8_t *stable; int nbh; QLevel L;
+    const DSVG_GLOBAL int16_t *sym; const DSVG_GLOBAL uint8_t *stable; int nbh; QLevel L;
     __device__ __forceinline__ Raw3 fetch(int cx, int cy, bool hasR, bool hasB) const
     {
         Raw3 r;
         const int o = cy * L.sw + cx;
-        r.k = cls(cx, cy);
-        r.lh = hasR ? (int)sym[L.base0 + o] : 0;
-        r.hl = hasB ? (int)sym[L.base1 + o] : 0;
-        r.hh = (hasR && hasB) ? (int)sym[L.base2 + o] : 0;
+        // RAW flag and symbols: the class is taken and missing bands are dropped in finish() -- done here, either would make every
+        // fetch wait for its loads (a missing band is fetched at the level's first symbol)
+        r.k = flag(cx, cy); r.m = (hasR ? 1 : 0) | (hasB ? 2 : 0);
+        r.lh = (int)sym[L.base0 + (hasR ? o : 0)];
+        r.hl = (int)sym[L.base1 + (hasB ? o : 0)];
+        r.hh = (int)sym[L.base2 + ((hasR && hasB) ? o : 0)];
         return r;
     }
     __device__ __forceinline__ void finish(const Raw3 &r, int &LH, int &HL, int &HH) const
     {
-        LH = dq(r.lh, r.k); HL = dq(r.hl, r.k); HH = dq(r.hh, r.k);
+        const int k = kcls(r.k);
+        LH = (r.m & 1) ? dq(r.lh, k) : 0; HL = (r.m & 2) ? dq(r.hl, k) : 0; HH = r.m == 3 ? dq(r.hh, k) : 0;
     }
     __device__ __forceinline__ Raw4<true> fetch4(int cx0, int cy) const
     {
         Raw4<true> r;
         const int o = cy * L.sw + cx0;
-        r.lh = *reinterpret_cast<const uint2 *>(sym + L.base0 + o);
-        r.hl = *reinterpret_cast<const uint2 *>(sym + L.base1 + o);
-        r.hh = *reinterpret_cast<const uint2 *>(sym + L.base2 + o);
+        r.lh = dsvg_ld2(sym + L.base0 + o);
+        r.hl = dsvg_ld2(sym + L.base1 + o);
+        r.hh = dsvg_ld2(sym + L.base2 + o);
         const int by = ((cy * L.dby) >> 14) * nbh;
         const int bx0 = (cx0 * L.dbx) >> 14, bx3 = ((cx0 + 3) * L.dbx) >> 14;
-        r.k0 = stable[by + bx0] != 0;
-        if (bx0 == bx3) r.k1 = r.k2 = r.k3 = r.k0;
-        else {
-            r.k1 = stable[by + (((cx0 + 1) * L.dbx) >> 14)] != 0;
-            r.k2 = stable[by + (((cx0 + 2) * L.dbx) >> 14)] != 0;
-            r.k3 = stable[by + bx3] != 0;
+        r.k0 = stable[by + bx0];                  // raw flags; -1: "as cell 0" (a copy of the loaded value would wait for it)
+        r.k1 = r.k2 = r.k3 = -1;
+        if (bx0 != bx3) {
+            r.k1 = stable[by + (((cx0 + 1) * L.dbx) >> 14)];
+            r.k2 = stable[by + (((cx0 + 2) * L.dbx) >> 14)];
+            r.k3 = stable[by + bx3];
         }
         return r;
     }
     __device__ __forceinline__ void finish4(const Raw4<true> &r, int (&lhv)[4], int (&hlv)[4], int (&hhv)[4]) const
     {
-        lhv[0] = dq((int16_t)(r.lh.x & 0xffff), r.k0); lhv[1] = dq((int)r.lh.x >> 16, r.k1);
-        lhv[2] = dq((int16_t)(r.lh.y & 0xffff), r.k2); lhv[3] = dq((int)r.lh.y >> 16, r.k3);
-        hlv[0] = dq((int16_t)(r.hl.x & 0xffff), r.k0); hlv[1] = dq((int)r.hl.x >> 16, r.k1);
-        hlv[2] = dq((int16_t)(r.hl.y & 0xffff), r.k2); hlv[3] = dq((int)r.hl.y >> 16, r.k3);
-        hhv[0] = dq((int16_t)(r.hh.x & 0xffff), r.k0); hhv[1] = dq((int)r.hh.x >> 16, r.k1);
-        hhv[2] = dq((int16_t)(r.hh.y & 0xffff), r.k2); hhv[3] = dq((int)r.hh.y >> 16, r.k3);
+        const int k0 = kcls(r.k0), k1 = r.k1 < 0 ? k0 : kcls(r.k1), k2 = r.k2 < 0 ? k0 : kcls(r.k2), k3 = r.k3 < 0 ? k0 : kcls(r.k3);
+        lhv[0] = dq((int16_t)(r.lh.x & 0xffff), k0); lhv[1] = dq((int)r.lh.x >> 16, k1);
+        lhv[2] = dq((int16_t)(r.lh.y & 0xffff), k2); lhv[3] = dq((int)r.lh.y >> 16, k3);
+        hlv[0] = dq((int16_t)(r.hl.x & 0xffff), k0); hlv[1] = dq((int)r.hl.x >> 16, k1);
+        hlv[2] = dq((int16_t)(r.hl.y & 0xffff), k2); hlv[3] = dq((int)r.hl.y >> 16, k3);
+        hhv[0] = dq((int16_t)(r.hh.x & 0xffff), k0); hhv[1] = dq((int)r.hh.x >> 16, k1);
+        hhv[2] = dq((int16_t)(r.hh.y & 0xffff), k2); hhv[3] = dq((int)r.hh.y >> 16, k3);
     }
-    __device__ __forceinline__ int cls(int cx, int cy) const
-    {
-        const int f = stable[((cy * L.dby) >> 14) * nbh + ((cx * L.dbx) >> 14)];
-        return HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0));
-    }
+    __device__ __forceinline__ int flag(int cx, int cy) const { return stable[((cy * L.dby) >> 14) * nbh + ((cx * L.dbx) >> 14)]; }
+    static __device__ __forceinline__ int kcls(int f) { return HZL == 2 ? (f != 0) : ((f & 2) ? 2 : (f != 0)); }
+    __device__ __forceinline__ int cls(int cx, int cy) const { return kcls(flag(cx, cy)); }
     __device__ __forceinline__ int dq(int v, int k) const
     {
         if (HZL == 2) return (int)((unsigned)v << (k ? L.sh1 : L.sh0));
@@ -1930,9 +1957,9 @@ static __device__ __forceinline__ Det<SYM, HZL> mk_det(const JobDev &jb, int c, 
     Det<SYM, HZL> D;
     if constexpr (SYM) {
         const HzPlane &hp = jb.hz[c];
-        D.sym = jb.sym + jb.nz_off[c]; D.stable = jb.stable; D.nbh = hp.nbh; D.L = q_level<HZL>(hp);
+        D.sym = dsvg_global(static_cast<const int16_t *>(jb.sym + jb.nz_off[c])); D.stable = dsvg_global(static_cast<const uint8_t *>(jb.stable)); D.nbh = hp.nbh; D.L = q_level<HZL>(hp);
     } else {
-        D.coef = coef; D.W = W; D.wo = L.wo; D.ho = L.ho;
+        D.coef = dsvg_global(coef); D.W = W; D.wo = L.wo; D.ho = L.ho;
     }
     return D;
 }
@@ -2575,7 +2602,7 @@ static __device__ __forceinline__ void inv_haar_tile_body(const JobDev *__restri
         const int ly = tid / (IT_TX + 2), lx = tid - ly * (IT_TX + 2);
         const int cx = I0 - 1 + lx, cy = J0 - 1 + ly;
         ok3 = tid < (IT_TY + 2) * (IT_TX + 2) && cx >= 0 && cy >= 0 && cx < L3.wo && cy < L3.ho;
-        q3.lh = q3.hl = q3.hh = q3.k = 0;
+        q3.lh = q3.hl = q3.hh = q3.k = q3.m = 0;
         if (ok3) q3 = D3.fetch(cx, cy, 2 * cx + 1 < L3.ws, 2 * cy + 1 < L3.hs);
     }
     const LvlGeo L2 = mk_lvl(W, H, TOP - 1, jb.hqp[TOP - 1], true);
@@ -2587,7 +2614,7 @@ static __device__ __forceinline__ void inv_haar_tile_body(const JobDev *__restri
         const int ly = i / (2 * IT_TX + 2), lx = i - ly * (2 * IT_TX + 2);
         const int cx = 2 * I0 - 1 + lx, cy = 2 * J0 - 1 + ly;
         ok2[u] = i < (2 * IT_TY + 2) * (2 * IT_TX + 2) && cx >= 0 && cy >= 0 && cx < L2.wo && cy < L2.ho;
-        q2[u].lh = q2[u].hl = q2[u].hh = q2[u].k = 0;
+        q2[u].lh = q2[u].hl = q2[u].hh = q2[u].k = q2[u].m = 0;
         if (ok2[u]) q2[u] = D2.fetch(cx, cy, 2 * cx + 1 < L2.ws, 2 * cy + 1 < L2.hs);
     }
     // level 1 (MODE 0): the vector-loadable groups and their prediction pixels
