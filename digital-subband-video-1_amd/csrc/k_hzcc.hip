@@ -556,18 +556,23 @@ __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restric
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     int c[Q], chunk[Q];
     unsigned long long m[Q];
+    const int ll0 = jb.hz[0].r[1].base, ll1 = jb.hz[1].r[1].base, ll2 = jb.hz[2].r[1].base;
+    const int co0 = jb.chunk_off[0], co1 = jb.chunk_off[1], co2 = jb.chunk_off[2];
+    const bool sparse = jb.nzf != nullptr;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         c[q] = chunk[q] = 0;
         const bool have = flat_chunk(jb, (int)blockIdx.x + (64 * q + lane) * (int)gridDim.x, c[q], chunk[q]);
         bool work = false;
         if (have) {
-            const int ll_end = jb.hz[c[q]].r[1].base, cbase = chunk[q] * HZ_CHUNK;
-            const bool fl = jb.nzf ? jb.cflag[jb.chunk_off[c[q]] + chunk[q]] != 0 : true;
-            if (cbase < ll_end) work = jb.llq || (jb.nzf && cbase + HZ_CHUNK > ll_end && fl);   // llq: the LL chunks are compacted here; else only the straddling chunk's cleanup
+            // (the plane's facts by scalar loads and a select: indexed by the lane's plane they were vector loads from the job table,
+            // a memory round trip in front of the chunk flag's own)
+            const int ll_end = c[q] == 0 ? ll0 : (c[q] == 1 ? ll1 : ll2), coff = c[q] == 0 ? co0 : (c[q] == 1 ? co1 : co2), cbase = chunk[q] * HZ_CHUNK;
+            const bool fl = sparse ? dsvg_global(static_cast<const uint8_t *>(jb.cflag))[(unsigned)(coff + chunk[q])] != 0 : true;
+            if (cbase < ll_end) work = jb.llq || (sparse && cbase + HZ_CHUNK > ll_end && fl);   // llq: the LL chunks are compacted here; else only the straddling chunk's cleanup
             else {
                 work = fl;
-                if (!fl && wv == 0) jb.chunks[jb.chunk_off[c[q]] + chunk[q]].nnz = 0;     // (of an empty chunk's summary only the count is ever read)
+                if (!fl && wv == 0) jb.chunks[coff + chunk[q]].nnz = 0;     // (of an empty chunk's summary only the count is ever read)
             }
         }
         m[q] = __ballot(work);
@@ -981,6 +986,19 @@ static __device__ __forceinline__ void emit_round64(EmitState &S, bool prev_in, 
 // to the stage (<= 6 LDS atomics instead of 8), and a round's complete words leave as <= 4 coalesced stores that are issued at
 // the start of the NEXT round, behind that round's entries: the loop never waits for a store it has just issued.
 // A round with a run or a value of 256 or more (rare outside the LL chunks, which are not packed) is done as four rounds of 64.
+// a record at a wave-uniform address, read through the constant address space (scalar loads): only for data no kernel writes while this one runs
+template <typename T>
+static __device__ __forceinline__ T emit_sload(const T *p)
+{
+    static_assert(sizeof(T) % 4 == 0, "dwords");
+    typedef const __attribute__((address_space(4))) unsigned *CU;
+    const CU q = (CU)p;
+    T v;
+    unsigned *d = reinterpret_cast<unsigned *>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) d[i] = q[i];
+    return v;
+}
 struct EmitPend { unsigned w[4]; unsigned base; int n; bool skip0; };
 static __device__ __forceinline__ void emit_flush_pend(const EmitPend &P, int lane, DSVG_GLOBAL unsigned *out32)
 {
@@ -998,9 +1016,11 @@ static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int
 #ifdef EMIT_STATS
     const unsigned long long t_in = wall_clock64();
 #endif
-    const HzPlaneSum ps = jb.psum[c];
+    // the plane's and the chunk's summaries (written by k_hz_scan, the launch before): both requested at once, by scalar loads -- c and
+    // chunk are wave-uniform -- instead of two vector round trips one after the other in front of the chunk's first entries
+    const HzPlaneSum ps = emit_sload(jb.psum + c);
+    const HzChunkSum cs = emit_sload(jb.chunks + (jb.chunk_off[c] + chunk));
     if (ps.overflow) return;
-    const HzChunkSum cs = jb.chunks[jb.chunk_off[c] + chunk];
     DSVG_GLOBAL unsigned *out32 = dsvg_global(reinterpret_cast<unsigned *>(jb.bits + jb.bits_off[c]));
     const DSVG_GLOBAL int32_t *gpos = dsvg_global(jb.nzpos + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK);
     const DSVG_GLOBAL int32_t *gval = dsvg_global(jb.nzval + jb.nz_off[c] + (size_t)chunk * HZ_CHUNK);
@@ -1163,7 +1183,7 @@ static __device__ __forceinline__ void emit_chunk_t(const JobDev &jb, int c, int
 #endif
 static __device__ __forceinline__ void emit_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
 {
-    if (jb.chunks[jb.chunk_off[c] + chunk].packed) emit_chunk_t<true>(jb, c, chunk, lane, stg);      // (wave-uniform)
+    if (emit_sload(&jb.chunks[jb.chunk_off[c] + chunk].packed)) emit_chunk_t<true>(jb, c, chunk, lane, stg);      // (wave-uniform)
     else emit_chunk_t<false>(jb, c, chunk, lane, stg);
 }
 
@@ -1184,12 +1204,14 @@ __global__ __launch_bounds__(256) EMIT_WPE_ATTR void k_hz_emit_list(const JobDev
     __shared__ __attribute__((aligned(16))) unsigned s_stage[4][EMIT_STAGE_WORDS];
     const JobDev &jb = jobs[blockIdx.y];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int co0 = jb.chunk_off[0], co1 = jb.chunk_off[1], co2 = jb.chunk_off[2];
     int k = 0;
 #pragma unroll
     for (int q = 0; q < Q; q++) {
         int c = 0, chunk = 0;
         const bool have = flat_chunk(jb, (int)blockIdx.x + (64 * q + lane) * (int)gridDim.x, c, chunk);
-        const bool work = have && jb.chunks[jb.chunk_off[c] + chunk].nnz > 0;
+        const int coff = c == 0 ? co0 : (c == 1 ? co1 : co2);           // (scalar loads + select, see k_hz_collect_list)
+        const bool work = have && jb.chunks[coff + chunk].nnz > 0;
         unsigned long long m = __ballot(work);
         for (; m; k++) {
             const int l = __ffsll((long long)m) - 1;
