@@ -334,6 +334,21 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     // takes its copy through an empty asm, or the hoisted 64-bit pair ends in a v_lshl_add_u64 per row again.
     const unsigned lane_ro = (unsigned)(r0 * stride + xcol);
     const unsigned cmask = FAST ? 0xffffffffu : (xcol >= bw ? 0u : (xcol + 4 <= bw ? 0xffffffffu : ((1u << (8 * (bw - xcol))) - 1u)));
+    // level 0: the parents' vectors (one per lane, lanes 0..4) are requested BEFORE the block's rows: memory answers in order, so the
+    // candidates can be set up and the union window requested while the source rows are still on their way (behind the rows, waiting
+    // for the vectors meant waiting for all 25 loads of the block's first round trip)
+    int par_early = 0;
+    if constexpr (LEVEL0) {
+        if (parent) {
+            const unsigned pmask = ~(unsigned)((step << 1) - 1);
+            const int pi = (int)((unsigned)i & pmask), pj = (int)((unsigned)j & pmask);
+            const int m = tid;
+            const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
+            const int x = pi + ox * step, y = pj + oy * step;
+            if (m < 5 && x >= 0 && x < A.nxb && y >= 0 && y < A.nyb)
+                par_early = *reinterpret_cast<const DSVG_GLOBAL int *>(dsvg_global(parent) + (x + y * A.nxb));      // DMV starts with int16 x, y: one dword = x | y << 16
+        }
+    }
     unsigned srcw[NKR];
     if constexpr (FAST) {
         auto sq = dsvg_global(sp + (long)by * stride + bx);
@@ -399,14 +414,8 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             }
         }
 #else
-        int par_l = 0;
-        if constexpr (LEVEL0) {
-            const int m = tid;
-            const int ox = m == 1 ? -2 : (m == 2 ? 2 : 0), oy = m == 3 ? -2 : (m == 4 ? 2 : 0);
-            const int x = pi + ox * step, y = pj + oy * step;
-            if (m < 5 && x >= 0 && x < A.nxb && y >= 0 && y < A.nyb)
-                par_l = *reinterpret_cast<const DSVG_GLOBAL int *>(dsvg_global(parent) + (x + y * A.nxb));      // DMV starts with int16 x, y: one dword = x | y << 16
-        } else {
+        int par_l = par_early;
+        if constexpr (!LEVEL0) {
             // the upper levels' blocks are small and wait for their parents: those keep the scalar fetches (the scalar cache answers
             // faster than the vector path: 1.14 against 1.43 ms per 320-GOP step), only the de-duplication moves to the lanes
             int par[5];

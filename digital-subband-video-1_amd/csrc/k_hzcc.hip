@@ -436,6 +436,8 @@ static __device__ __forceinline__ void collect_chunk_ll(const JobDev &jb, int c,
     COLL_T1(st.run, 1);
 }
 
+// FLAGGED: the caller has seen the chunk's flag up (k_hz_collect_list): it is not fetched again -- a memory round trip in front of the group flags'
+template <bool FLAGGED = false>
 static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, int chunk, int lane, unsigned *stg)
 {
     const HzPlane &hp = jb.hz[c];
@@ -449,7 +451,7 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
     if (cbase < ll_end) {
         // chunks that reach into the LL region were compacted by k_hz_quant<true>; in sparse mode the detail symbols of
         // the chunk that straddles the end of the LL region still have to be taken down (this kernel is their last reader)
-        if (cfl && cbase + HZ_CHUNK > ll_end && *cfl) {
+        if (cfl && cbase + HZ_CHUNK > ll_end && (FLAGGED || *cfl)) {
             uint8_t *nzf = jb.nzf + (jb.nz_off[c] >> 2);
 #pragma unroll
             for (int k = 0; k < 4; k++) {
@@ -463,7 +465,7 @@ static __device__ __forceinline__ void collect_chunk(const JobDev &jb, int c, in
         }
         return;
     }
-    if (cfl && *cfl == 0) {             // sparse mode: nothing was stored into this chunk
+    if (!FLAGGED && cfl && *cfl == 0) { // sparse mode: nothing was stored into this chunk
         if (lane == 0) {
             HzChunkSum &cs = jb.chunks[jb.chunk_off[c] + chunk];
             cs.nnz = 0; cs.bits_inner = 0; cs.first_pos = -1; cs.last_pos = -1; cs.last_val = 0;
@@ -588,7 +590,8 @@ __global__ __launch_bounds__(256) void k_hz_collect_list(const JobDev *__restric
             const int l = __ffsll((long long)mm) - 1;
             mm &= mm - 1;
             if ((k & 3) != wv) continue;
-            collect_chunk(jb, __builtin_amdgcn_readlane(c[q], l), __builtin_amdgcn_readlane(chunk[q], l), lane, s_cstage[wv]);      // (scalars: the job table is then read with scalar loads)
+            if (sparse) collect_chunk<true>(jb, __builtin_amdgcn_readlane(c[q], l), __builtin_amdgcn_readlane(chunk[q], l), lane, s_cstage[wv]);
+            else collect_chunk<false>(jb, __builtin_amdgcn_readlane(c[q], l), __builtin_amdgcn_readlane(chunk[q], l), lane, s_cstage[wv]);      // (scalars: the job table is then read with scalar loads)
         }
     }
 }
