@@ -900,12 +900,7 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
     const FwdFastSel S = fwd_fast_sel(H, mv.mode, I, J, x0, y0, pw, ph);
     if (!S.ok) return;                                   // k_fwd_mc_pix takes these
     const QLevel &L1 = S.L1, &L2 = S.L2, &L3 = S.L3;
-    int f1[4], f2[2];
-#pragma unroll
-    for (int j = 0; j < 4; j++) f1[j] = q.stable[S.i1[j]];
-#pragma unroll
-    for (int j = 0; j < 2; j++) f2[j] = q.stable[S.i2[j]];
-    const int f3 = q.stable[S.i3];
+    // (the source rows are requested before the stability flags: whatever the compiler then waits for on the flags' account does not hold them back)
     const auto sp = dsvg_global(srcp_p);
     uint2 sw[8];
     if (S.intra) {                                      // an intra block's patch: the residual rows, from the work frame (k_mc wrote them and the prediction)
@@ -916,6 +911,12 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
 #pragma unroll
         for (int r = 0; r < 8; r++) sw[r] = dsvg_ld2(sp + (unsigned)((y0 + r) * sstride + x0));
     }
+    int f1[4], f2[2];
+#pragma unroll
+    for (int j = 0; j < 4; j++) f1[j] = q.stable[S.i1[j]];
+#pragma unroll
+    for (int j = 0; j < 2; j++) f2[j] = q.stable[S.i2[j]];
+    const int f3 = q.stable[S.i3];
     FwdFastQ fq;
 #pragma unroll
     for (int j = 0; j < 4; j++) fq.sh1[j] = f1[j] ? L1.sh1 : L1.sh0;
