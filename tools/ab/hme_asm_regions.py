@@ -6,10 +6,11 @@ the map of where the scalar half goes.  usage: hme_asm_regions.py [NKB]   (cross
 import collections, os, re, subprocess, sys
 repo = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
 nkb = sys.argv[1] if len(sys.argv) > 1 else "12"
+lvl0, part = (sys.argv[2], sys.argv[3]) if len(sys.argv) > 3 else ("1", "1")      # [NKB [LEVEL0 PART]]: 12 0 3 = the upper levels' kernel
 s_path = "/tmp/k_hme_mark.s"
 subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", "-DAB_HME_ASMMARK",
                        os.path.join(repo, "digital-subband-video-1_amd/csrc/k_hme.hip"), "-o", s_path], stderr=subprocess.DEVNULL, cwd="/tmp")
-name = "_Z11k_hme_levelILb1ELi%sELi1EEv7HmeArgsiiiijj" % nkb
+name = "_Z11k_hme_levelILb%sELi%sELi%sEEv7HmeArgsiiiijj" % (lvl0, nkb, part)
 lines = open(s_path).read().split("\n")
 i0 = next(i for i, l in enumerate(lines) if l.startswith(name + ":"))
 i1 = next(i for i in range(i0, len(lines)) if lines[i].startswith("\t.section") or lines[i].startswith(".Lfunc_end"))
