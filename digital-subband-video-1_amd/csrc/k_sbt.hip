@@ -1230,8 +1230,16 @@ __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__
 // --------------------------------------------------------------------------------------------
 // forward, I pictures: level 1 = biorthogonal 4-tap, rows then columns (fwd_b4t_2d sbt.c:240-251)
 // --------------------------------------------------------------------------------------------
+#ifndef FWD_B4T_WPE
+#define FWD_B4T_WPE 6             // 89 VGPRs by themselves (5 waves); 77 under this limit, no spills: 0.85 -> 0.79-0.80 ms per 320 I pictures
+#endif
+#if FWD_B4T_WPE
+#define FWD_B4T_ATTR __attribute__((amdgpu_waves_per_eu(FWD_B4T_WPE, FWD_B4T_WPE)))
+#else
+#define FWD_B4T_ATTR
+#endif
 template <bool Q>
-__global__ __launch_bounds__(256) void k_fwd_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
+__global__ __launch_bounds__(256) FWD_B4T_ATTR void k_fwd_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
                                                  int from_src)
 {
     const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
@@ -2470,8 +2478,11 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 }
 
 
-#ifdef INV_P_TILE_W8
-#define INV_P_TILE_ATTR __attribute__((amdgpu_waves_per_eu(8, 8)))
+#ifndef INV_P_TILE_WPE
+#define INV_P_TILE_WPE 7          // 73 VGPRs by themselves: one over the seven-wave limit (measured: 6 waves 5.89-6.04 ms, 7: 5.70-5.84, 8 -- spills -- 6.8-7.0)
+#endif
+#if INV_P_TILE_WPE
+#define INV_P_TILE_ATTR __attribute__((amdgpu_waves_per_eu(INV_P_TILE_WPE, INV_P_TILE_WPE)))
 #else
 #define INV_P_TILE_ATTR
 #endif
@@ -2970,8 +2981,16 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
 // SYM (the encoder's I pictures): the level-1 details come from the int16 symbol planes k_fwd_b4t<true> left behind and are
 // dequantised here (shift quantiser hzcc.c:221-224) -- the dequantised int32 bands are then neither written by the forward
 // transform nor read back (3 + 3 B/sample less)
+#ifndef INV_B4T_WPE
+#define INV_B4T_WPE 0
+#endif
+#if INV_B4T_WPE
+#define INV_B4T_ATTR __attribute__((amdgpu_waves_per_eu(INV_B4T_WPE, INV_B4T_WPE)))
+#else
+#define INV_B4T_ATTR
+#endif
 template <bool SYM>
-__global__ __launch_bounds__(256) void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int gx, int gy, int gz, int plain)
+__global__ __launch_bounds__(256) INV_B4T_ATTR void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int gx, int gy, int gz, int plain)
 {
     __shared__ int VL[2 * BT_C][BT_VW];     // column-pass output, low-horizontal half
     __shared__ int VH[2 * BT_C][BT_VW];     // column-pass output, high-horizontal half
