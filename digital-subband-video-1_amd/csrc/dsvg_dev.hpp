@@ -281,13 +281,40 @@ static inline int xcd_grid(int total) { return 8 * ((total + 7) / 8); }
 // (x, y, z), x fastest -- an XCD then walks whole rows of neighbouring tiles, whose shared cache lines (halo rows, lines
 // that straddle two tiles) are fetched into its L2 once instead of once per XCD.  false: a padding workgroup.
 struct Blk3 { int x, y, z; };
-static __device__ __forceinline__ bool d_xcd_blk3(int gx, int gy, int gz, Blk3 &b, bool plain = false)
+// The logical grid as the launcher hands it over: its extents and their reciprocals, min(floor(2^32 / d), 2^32 - 1) -- every wave of every
+// workgroup splits its index by gx and gy, and as integer divisions that was two ~25-instruction sequences (float reciprocal, two correction
+// steps each) at the head of each wave's dependency chain; with the reciprocal the estimate is the quotient or one below it
+struct XcdGrid { int gx, gy, gz; unsigned igx, igy; };
+static inline XcdGrid mk_xcd_grid(int gx, int gy, int gz)
 {
-    const int total = gx * gy * gz, item = plain ? (int)blockIdx.x : d_xcd_remap((int)blockIdx.x, total);   // plain: the hardware's round robin (A/B)
+    auto inv = [](int d) { const unsigned long long q = 0x100000000ull / (unsigned long long)(d > 0 ? d : 1); return (unsigned)(q > 0xffffffffull ? 0xffffffffull : q); };
+    XcdGrid g;
+    g.gx = gx; g.gy = gy; g.gz = gz; g.igx = inv(gx); g.igy = inv(gy);
+    return g;
+}
+static __device__ __forceinline__ unsigned d_udiv_r(unsigned n, unsigned d, unsigned inv, unsigned &rem)
+{
+    unsigned q = __umulhi(n, inv);
+    rem = n - q * d;
+    if (rem >= d) { q++; rem -= d; }
+    return q;
+}
+static __device__ __forceinline__ bool d_xcd_blk3(const XcdGrid &G, Blk3 &b, bool plain = false)
+{
+    const int total = G.gx * G.gy * G.gz, item = plain ? (int)blockIdx.x : d_xcd_remap((int)blockIdx.x, total);   // plain: the hardware's round robin (A/B)
     if (item >= total) return false;
-    const int r = item / gx;
-    b.x = item - r * gx; b.z = r / gy; b.y = r - b.z * gy;
+    unsigned x, y;
+    const unsigned r = d_udiv_r((unsigned)item, (unsigned)G.gx, G.igx, x);
+    b.z = (int)d_udiv_r(r, (unsigned)G.gy, G.igy, y);
+    b.x = (int)x; b.y = (int)y;
     return true;
+}
+// plane and job of a grid layer (npl planes per job: 1 or 2 in every launch of the encoder)
+static __device__ __forceinline__ void d_job_plane(int z, int npl, int c0, int &job, int &c)
+{
+    if (npl == 1) { job = z; c = c0; }
+    else if (npl == 2) { job = z >> 1; c = c0 + (z & 1); }
+    else { job = z / npl; c = c0 + z % npl; }
 }
 
 // ---- diagnostic builds only (make EXTRA=-DDSVG_CLOCK_PROBE, tools/ab/clock_probe.sh): the shader clock a kernel runs at.

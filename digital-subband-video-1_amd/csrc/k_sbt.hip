@@ -855,13 +855,14 @@ static __device__ __forceinline__ FwdFastSel fwd_fast_sel(const JobDev &jb, cons
 
 template <int CH>
 static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict__ jobs, const SbtGeo3 &G, const McGeo &MG, int c0, int npl,
-                                                        const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
+                                                        const DMV *__restrict__ mvs0, XcdGrid XG, int plain)
 {
     // one-dimensional launch in XCD order (d_xcd_blk3): the reference rows above and below a workgroup's 32 pixel rows and the
     // lines its rows share with the workgroup beside it are in the same L2 as the neighbour that reads them too
     Blk3 B;
-    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
-    const int job = B.z / npl, c = c0 + B.z % npl;
+    if (!d_xcd_blk3(XG, B, plain != 0)) return;
+    int job, c;
+    d_job_plane(B.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if (I >= g.w3 || J >= g.h3) return;
@@ -1034,21 +1035,21 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
 #define FAST_WPE_C_ATTR
 #endif
 template <int CH>
-__global__ void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain);
+__global__ void k_fwd_mc_fast(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0, XcdGrid XG, int plain);
 template <>
 __global__ __launch_bounds__(256) FAST_WPE_L_ATTR void k_fwd_mc_fast<0>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
-                                                                        const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
+                                                                        const DMV *__restrict__ mvs0, XcdGrid XG, int plain)
 {
     DSVG_CLK_BEGIN();
-    fwd_mc_fast_body<0>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
+    fwd_mc_fast_body<0>(jobs, G, MG, c0, npl, mvs0, XG, plain);
     DSVG_CLK_END(1);
 }
 template <>
 __global__ __launch_bounds__(256) FAST_WPE_C_ATTR void k_fwd_mc_fast<1>(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
-                                                                        const DMV *__restrict__ mvs0, int gx, int gy, int gz, int plain)
+                                                                        const DMV *__restrict__ mvs0, XcdGrid XG, int plain)
 {
     DSVG_CLK_BEGIN();
-    fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0, gx, gy, gz, plain);
+    fwd_mc_fast_body<1>(jobs, G, MG, c0, npl, mvs0, XG, plain);
     DSVG_CLK_END(2);
 }
 
@@ -1059,11 +1060,12 @@ __global__ __launch_bounds__(256) FAST_WPE_C_ATTR void k_fwd_mc_fast<1>(const Jo
 // wave-uniformly; the prediction goes straight to JobDev.pred.
 template <int CH>
 __global__ __launch_bounds__(256) void k_mc_patch(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl, const DMV *__restrict__ mvs0,
-                                                  int gx, int gy, int gz, int ex0, int ey0)
+                                                  XcdGrid XG, int ex0, int ey0)
 {
     Blk3 B;
-    if (!d_xcd_blk3(gx, gy, gz, B)) return;
-    const int job = B.z / npl, c = c0 + B.z % npl;
+    if (!d_xcd_blk3(XG, B)) return;
+    int job, c;
+    d_job_plane(B.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if (I >= g.w3 || J >= g.h3) return;
@@ -2493,7 +2495,7 @@ static __device__ __forceinline__ void inv_p_fast(const JobDev &jb, const SbtGeo
 // interior tiles (as a launch of its own the column's 16 x 160 workgroups took as long as the general kernel's strip did)
 template <bool FILT>
 __global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int er_col, int eb_row,
-                                                                    int gx, int gy, int gz, int plain)
+                                                                    XcdGrid XG, int plain)
 {
     __shared__ int A3[A3H * A3W];
     __shared__ int A2[A2H * A2W];
@@ -2501,8 +2503,9 @@ __global__ __launch_bounds__(256) INV_P_TILE_ATTR void k_inv_p_tile(const JobDev
     // one-dimensional launch, tiles dealt to the XCDs in contiguous runs (d_xcd_blk3): a tile shares the 128-byte lines its
     // pixel rows straddle (the 64-pixel border shifts them by half a line) and its halo rows of symbols with its neighbours
     Blk3 B;
-    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
-    const int job = B.z / npl, c = c0 + B.z % npl;
+    if (!d_xcd_blk3(XG, B, plain != 0)) return;
+    int job, c;
+    d_job_plane(B.z, npl, c0, job, c);
     const int I0 = B.x * IT_TX, J0 = B.y * IT_TY;
     const bool er = B.x == er_col, eb = B.y == eb_row;      // (eb_row: the last tile row, likewise)
     DSVG_CLK_BEGIN();
@@ -2845,11 +2848,12 @@ __global__ __launch_bounds__(256) void k_inv_tile54_all(const JobDev *__restrict
 // the patch is the same closed computation with half of its rows.  Until now the whole last TILE row went to the general tile kernel for it --
 // 6 % of the plane at a quarter of this kernel's rate, and a launch per frame step.  -1: every patch of the launch is whole.
 __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax,
-                                                     int gx, int gy, int gz, int plain, int jpart)
+                                                     XcdGrid XG, int plain, int jpart)
 {
     Blk3 B;                                                 // one-dimensional launch in XCD order (d_xcd_blk3)
-    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;
-    const int job = B.z / npl, c = c0 + B.z % npl;
+    if (!d_xcd_blk3(XG, B, plain != 0)) return;
+    int job, c;
+    d_job_plane(B.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if (I >= imax || J >= jmax) return;
@@ -2990,13 +2994,14 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
 #define INV_B4T_ATTR
 #endif
 template <bool SYM>
-__global__ __launch_bounds__(256) INV_B4T_ATTR void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int gx, int gy, int gz, int plain)
+__global__ __launch_bounds__(256) INV_B4T_ATTR void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, XcdGrid XG, int plain)
 {
     __shared__ int VL[2 * BT_C][BT_VW];     // column-pass output, low-horizontal half
     __shared__ int VH[2 * BT_C][BT_VW];     // column-pass output, high-horizontal half
     Blk3 B;                                 // one-dimensional launch in XCD order (d_xcd_blk3): a tile shares its halo columns / rows and
-    if (!d_xcd_blk3(gx, gy, gz, B, plain != 0)) return;     // the lines its rows straddle with the neighbours in the same L2
-    const int job = B.z / npl, c = c0 + B.z % npl;
+    if (!d_xcd_blk3(XG, B, plain != 0)) return;     // the lines its rows straddle with the neighbours in the same L2
+    int job, c;
+    d_job_plane(B.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int W = g.W, H = g.H, hw = W >> 1, hh = H >> 1;
@@ -3157,8 +3162,8 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         // (picture edges, intra blocks, cells shared between scan regions) and returns at once for the common ones
         PB(c0 == 0 ? KID_FWD_MC_FAST_Y : KID_FWD_MC_FAST_C, smp * 3.0);
         const dim3 fg = grid3(g.w3, g.h3, nz);
-        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_fast<0>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, xcd_plain());
-        else         hipLaunchKernelGGL((k_fwd_mc_fast<1>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, xcd_plain());
+        if (c0 == 0) hipLaunchKernelGGL((k_fwd_mc_fast<0>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, mk_xcd_grid((int)fg.x, (int)fg.y, (int)fg.z), xcd_plain());
+        else         hipLaunchKernelGGL((k_fwd_mc_fast<1>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, *mc, c0, npl, mvs0, mk_xcd_grid((int)fg.x, (int)fg.y, (int)fg.z), xcd_plain());
         PE();
         // Where can a patch fail fwd_fast_sel?  Intra blocks (anywhere: the caller knows), otherwise only in the first /
         // last row or column of patches (cells shared between scan regions, a ragged picture edge) -- unless a patch can
@@ -3262,11 +3267,11 @@ void launch_mc_patch(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo
     PB(KID_MC, smp * njobs * 2.0);                       // reference in, prediction out
     {
         const dim3 fg = grid3(G.g[0].w3, G.g[0].h3, njobs);
-        hipLaunchKernelGGL((k_mc_patch<0>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, MG, 0, 1, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, ex0, ey0);
+        hipLaunchKernelGGL((k_mc_patch<0>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, MG, 0, 1, mvs0, mk_xcd_grid((int)fg.x, (int)fg.y, (int)fg.z), ex0, ey0);
     }
     {
         const dim3 fg = grid3(G.g[1].w3, G.g[1].h3, 2 * njobs);
-        hipLaunchKernelGGL((k_mc_patch<1>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, MG, 1, 2, mvs0, (int)fg.x, (int)fg.y, (int)fg.z, ex0, ey0);
+        hipLaunchKernelGGL((k_mc_patch<1>), tile_grid(fg.x, fg.y, fg.z), dim3(64, 4), 0, st, jobs, G, MG, 1, 2, mvs0, mk_xcd_grid((int)fg.x, (int)fg.y, (int)fg.z), ex0, ey0);
     }
     PE();
 }
@@ -3322,7 +3327,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             if (imax > 0 && jmax > 0) {
                 PB(KID_INV_PATCH_C, 64.0 * imax * jmax * nz * 2.0);          // prediction in, reconstruction out (+ 5 B per patch: LL3, flag)
                 const int cgx = (imax + 63) / 64, cgy = (jmax + 3) / 4;
-                hipLaunchKernelGGL(k_inv_patch_c, tile_grid(cgx, cgy, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax, cgx, cgy, nz, xcd_plain(),
+                hipLaunchKernelGGL(k_inv_patch_c, tile_grid(cgx, cgy, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax, mk_xcd_grid(cgx, cgy, nz), xcd_plain(),
                                    part4 ? g.h3 - 1 : -1);
                 PE();
             }
@@ -3349,8 +3354,8 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
                 const double fsmp = 64.0 * std::min(fxg * IT_TX, g.w3) * std::min(fyg * IT_TY, g.h3) * nz;   // samples of the fast tiles
                 PB(filt ? KID_INV_P_TILE_F : KID_INV_P_TILE, fsmp * 2.5);
                 const dim3 pg = tile_grid(fxg, fyg, nz);
-                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), pg, dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1, fxg, fyg, nz, xcd_plain());
-                else      hipLaunchKernelGGL((k_inv_p_tile<false>), pg, dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1, fxg, fyg, nz, xcd_plain());
+                if (filt) hipLaunchKernelGGL((k_inv_p_tile<true>), pg, dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1, mk_xcd_grid(fxg, fyg, nz), xcd_plain());
+                else      hipLaunchKernelGGL((k_inv_p_tile<false>), pg, dim3(256), 0, st, jobs, G, c0, npl, er ? fx : -1, eb ? fy : -1, mk_xcd_grid(fxg, fyg, nz), xcd_plain());
                 PE();
                 const int nrest = ((int)tg.x - fxg) * (int)tg.y + fxg * ((int)tg.y - fyg);      // right strip + bottom strip, one launch
                 if (nrest > 0) {
@@ -3383,8 +3388,8 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
         PE();
         const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
         PB(insym ? KID_INV_B4T_SYM : KID_INV_B4T, smp * (insym ? 3.5 : 5.0));           // LL1 1 + details 3 (symbols: 1.5) in, 1 out
-        if (insym) hipLaunchKernelGGL((k_inv_b4t<true>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, (int)bg.x, (int)bg.y, (int)bg.z, xcd_plain());
-        else       hipLaunchKernelGGL((k_inv_b4t<false>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, (int)bg.x, (int)bg.y, (int)bg.z, xcd_plain());
+        if (insym) hipLaunchKernelGGL((k_inv_b4t<true>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, mk_xcd_grid((int)bg.x, (int)bg.y, (int)bg.z), xcd_plain());
+        else       hipLaunchKernelGGL((k_inv_b4t<false>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, mk_xcd_grid((int)bg.x, (int)bg.y, (int)bg.z), xcd_plain());
         PE();
     }
 }
