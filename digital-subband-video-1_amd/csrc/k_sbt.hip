@@ -396,7 +396,8 @@ template <bool Q>
 __global__ __launch_bounds__(256) void k_fwd_haar_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
                                                       int from_src)
 {
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
     if (I >= g.w3 || J >= g.h3) return;
@@ -1119,7 +1120,8 @@ template <int CH>
 __global__ __launch_bounds__(256) MC_WPE_ATTR void k_fwd_mc_pix(const JobDev *__restrict__ jobs, SbtGeo3 G, McGeo MG, int c0, int npl,
                                                     const DMV *__restrict__ mvs0, int skip_fast, int bxofs, int byofs, int bxstep, int bystep)
 {
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     // (strips of the grid: block columns bxofs + k * bxstep, block rows byofs + k * bystep)
     const int I = (bxofs + (int)blockIdx.x * bxstep) * 64 + threadIdx.x, J = (byofs + (int)blockIdx.y * bystep) * 4 + threadIdx.y;
@@ -1244,7 +1246,8 @@ template <bool Q>
 __global__ __launch_bounds__(256) FWD_B4T_ATTR void k_fwd_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl,
                                                  int from_src)
 {
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int W = g.W, H = g.H;
     const int I = blockIdx.x * 64 + threadIdx.x, J = blockIdx.y * 4 + threadIdx.y;
@@ -1483,7 +1486,8 @@ __global__ __launch_bounds__(256) FWD_B4T_ATTR void k_fwd_b4t(const JobDev *__re
 template <int LV, bool Q, bool LQ = false>
 __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int W = g.W, H = g.H;
     const int ow = DSVG_RSU(W, LV + 1), oh = DSVG_RSU(H, LV + 1);           // output LL band
@@ -1541,7 +1545,8 @@ __global__ __launch_bounds__(256) void k_fwd_haar_mid(const JobDev *__restrict__
 __global__ __launch_bounds__(TAIL_THREADS) void k_fwd_tail(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     extern __shared__ int T[];
-    const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.x, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
@@ -1611,7 +1616,8 @@ static __device__ __forceinline__ int d_nudge(int ll, int lp, int ln, int det, i
 __global__ __launch_bounds__(TAIL_THREADS) void k_inv_tail(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl)
 {
     extern __shared__ int T[];
-    const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.x, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
@@ -1693,7 +1699,8 @@ __global__ __launch_bounds__(NT) void k_tail_q(const JobDev *__restrict__ jobs, 
 {
     extern __shared__ int T[];
     constexpr int MAXC = TAIL_MAXC * TAIL_THREADS / NT;          // cells per thread at the first tail level (host checks the total)
-    const int job = blockIdx.x / npl, c = c0 + blockIdx.x % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.x, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int w3 = g.w5, h3 = g.h5, n3 = w3 * h3, W = g.W, H = g.H;      // the band this kernel owns
@@ -2526,7 +2533,8 @@ static __device__ __forceinline__ void inv_haar_tile_body(const JobDev *__restri
     static_assert(!SYM || MODE != 2, "levels >= 4 live in the LL region: int32 coefficients");
     constexpr bool TO_PIX = (MODE == 0);
     constexpr int TOP = (MODE == 2) ? 5 : 3;
-    const int job = blockIdx.z / npl, c = c0 + blockIdx.z % npl;
+    int job, c;
+    d_job_plane((int)blockIdx.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const JobDev &jb = jobs[job];
     const int W = g.W, H = g.H;
