@@ -79,6 +79,8 @@ static inline unsigned get_be32(const uint8_t *p)
 /* append n bytes to a dsv_alloc-backed growing DSV_BUF (capacity kept in a hidden word before data) */
 int  dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n);
 int  dsv1_buf_reserve(DSV_BUF *b, unsigned n);
+/* dsv_alloc without the zeroing (a buffer the library fills itself); freed with dsv_free like any other */
+void *dsv1_alloc_raw(int size);
 void dsv1_log(int level, const char *fmt, ...);
 extern int dsv1_device;
 /* parallel loop over S independent items on a persistent worker pool: fn(ctx, s, worker) for every s; DSV1_HOST_THREADS workers (default min(12,

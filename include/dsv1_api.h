@@ -142,6 +142,9 @@ void dsv_frame_ref_dec(DSV_FRAME *frame);
 void dsv_mk_buf(DSV_BUF *buf, int size);
 void dsv_buf_free(DSV_BUF *buf);
 void *dsv_alloc(int size);
+/* Extension: dsv_free keeps blocks of 256 KB .. 64 MB (a batch's packet buffers) for the next dsv_alloc instead of returning their pages
+ * to the system -- at most 1 GiB (DSV1_NO_RECYCLE=1: never); this gives them back. */
+void dsv1_release_parked(void);
 void dsv_free(void *ptr);
 void dsv_memory_report(void);
 void dsv_set_log_level(int level);
