@@ -919,16 +919,9 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
 #pragma unroll
     for (int j = 0; j < 2; j++) f2[j] = q.stable[S.i2[j]];
     const int f3 = q.stable[S.i3];
+    // (the stability flags stay raw until a level needs them: turned into shifts / quantisers here, they were waited for before the
+    // reference rows below could be requested -- a second memory round trip behind the source rows')
     FwdFastQ fq;
-#pragma unroll
-    for (int j = 0; j < 4; j++) fq.sh1[j] = f1[j] ? L1.sh1 : L1.sh0;
-#pragma unroll
-    for (int j = 0; j < 2; j++) {
-        fq.q2[j] = max(L2.qp >> ((f2[j] & 2) ? 2 : (f2[j] != 0)), HZ_MINQ);
-        fq.rc2[j] = __builtin_amdgcn_rcpf((float)(fq.q2[j] << 1));
-    }
-    fq.q3 = max(L3.qp >> ((f3 & 2) ? 2 : (f3 != 0)), HZ_MINQ);
-    fq.rc3 = __builtin_amdgcn_rcpf((float)(fq.q3 << 1));
     const int dx = mv.x >> sh, dy = mv.y >> sv;
     const int xb = bi * bw, yb = bj * bh;
     const int wx = d_clamp(xb + (dx >> 1), -DSVG_BORDER, pw - bw + DSVG_BORDER - 1) + (x0 - xb);
@@ -949,7 +942,7 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
         R.e0 = pk_min(pk_max(Sr.e0 - P.e0, cmin), cmax); R.e1 = pk_min(pk_max(Sr.e1 - P.e1, cmin), cmax);       // subf bmc.c:43-55 + p2sbc sbt.c:576
         R.o0 = pk_min(pk_max(Sr.o0 - P.o0, cmin), cmax); R.o1 = pk_min(pk_max(Sr.o1 - P.o1, cmin), cmax);
         dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi));
-        if (r & 1) fwd_fast_rows1_pk(q, L1, fq.sh1[r >> 1], 4 * I, 4 * J + (r >> 1), rp[0], rp[1], l1[r >> 1]);
+        if (r & 1) fwd_fast_rows1_pk(q, L1, f1[r >> 1] ? L1.sh1 : L1.sh0, 4 * I, 4 * J + (r >> 1), rp[0], rp[1], l1[r >> 1]);
     };
     auto emit = [&](int r, unsigned plo, unsigned phi) { emit_core(r, pk_unpack8(plo, phi), plo, phi); };
     auto emit_pk = [&](int r, const PkRow &P) {
@@ -965,7 +958,7 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
             const PkRow X = pk_unpack8(sw[r].x, sw[r].y);
             PkRow &R = rp[r & 1];
             R.e0 = X.e0 - c128; R.e1 = X.e1 - c128; R.o0 = X.o0 - c128; R.o1 = X.o1 - c128;
-            if (r & 1) fwd_fast_rows1_pk(q, L1, fq.sh1[r >> 1], 4 * I, 4 * J + (r >> 1), rp[0], rp[1], l1[r >> 1]);
+            if (r & 1) fwd_fast_rows1_pk(q, L1, f1[r >> 1] ? L1.sh1 : L1.sh0, 4 * I, 4 * J + (r >> 1), rp[0], rp[1], l1[r >> 1]);
         }
     } else
     // (the vertical filter's 17-bit sums stay in 32-bit lanes: its samples arrive as ints and are paired up here -- never
@@ -998,7 +991,7 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
             row[i] = d_clamp(sv_ - pv_, -128, 127);       // subf bmc.c:43-55 + p2sbc sbt.c:576
         }
         dsvg_st2(pp + (unsigned)((y0 + r) * stride + x0), make_uint2(plo, phi));
-        if (r & 1) fwd_fast_rows1(q, L1, fq.sh1[r >> 1], 4 * I, 4 * J + (r >> 1), ra[0], ra[1], l1[r >> 1]);
+        if (r & 1) fwd_fast_rows1(q, L1, f1[r >> 1] ? L1.sh1 : L1.sh0, 4 * I, 4 * J + (r >> 1), ra[0], ra[1], l1[r >> 1]);
     };
     if (CH == 0) {
         if (any_y) mc_luma_patch<true, true>(gr, stride, xh, yh, emit);
@@ -1009,6 +1002,13 @@ static __device__ __forceinline__ void fwd_mc_fast_body(const JobDev *__restrict
         else mc_chroma_patch<false>(gr, stride, xh, yh, emit);
     }
 #endif
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        fq.q2[j] = max(L2.qp >> ((f2[j] & 2) ? 2 : (f2[j] != 0)), HZ_MINQ);
+        fq.rc2[j] = __builtin_amdgcn_rcpf((float)(fq.q2[j] << 1));
+    }
+    fq.q3 = max(L3.qp >> ((f3 & 2) ? 2 : (f3 != 0)), HZ_MINQ);
+    fq.rc3 = __builtin_amdgcn_rcpf((float)(fq.q3 << 1));
     int l2[2][2], l3[1][1];
     fwd_fast_level<4, 1>(q, L2, fq.q2, fq.rc2, 2 * I, 2 * J, l1, l2);
     const int q3v[1] = {fq.q3};
