@@ -440,7 +440,13 @@ void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t
     // others keep it in the caller's clip), + the pyramid levels written
     if (n_chroma < 0) n_chroma = n;
     if (pf) pf->begin(st, KID_UNPACK, 2.0 * ((double)n * L.w[0] * L.h[0] + 2.0 * n_chroma * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0) + (slab2 ? 0.0625 * n * L.w[0] * L.h[0] : 0.0));
-    hipLaunchKernelGGL(k_unpack, dim3(nblk((long)L.w[0] * L.h[0] / 16, 512), 3, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
+    // The grid is sized for the work there is (the kernel's loops stride by the grid, so any size is correct): the fused luma body takes
+    // 4 rows x 16 pixels per thread, and a batch whose chroma stays in the caller's clip has no chroma planes to copy -- sized for 16
+    // pixels per thread and three planes, five workgroups in six of the bench's launch found nothing to do (2.4 million per step).
+    const bool fused = slab1 && slab2 && (L.w[0] & 15) == 0 && (L.h[0] & 3) == 0;
+    const long items = fused ? (long)(L.w[0] >> 4) * (L.h[0] >> 2) : (long)L.w[0] * L.h[0] / 16;
+    const long citems = n_chroma > 0 ? (long)L.w[1] * L.h[1] / 16 : 0;
+    hipLaunchKernelGGL(k_unpack, dim3(nblk(std::max(items, citems), 512), n_chroma > 0 ? 3 : 1, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
                        slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0) | (sides && sides2 ? 4 : 0), slab2, L2 ? *L2 : dummy);
     if (pf) pf->end(st);
 }
