@@ -39,6 +39,23 @@ VALU_PEAK_GI = 530.0
 VALU_FAST_GI = 850.0
 
 
+def csrc_sha16():
+    """sha256 over the kernel / shim sources of THIS tree (tools/make_pmc_traffic.py stamps profiles/pmc_traffic.json with the same)"""
+    d = os.path.join(ROOT, "digital-subband-video-1_amd", "csrc")
+    names = sorted(n for n in os.listdir(d) if n.endswith((".hip", ".hpp")) or n == "Makefile")
+    h = hashlib.sha256()
+    for n in names + [os.path.join("..", "..", "include", "dsvg_rc.h")]:
+        h.update(os.path.basename(n).encode() + b"\0" + open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def traffic_stamp(T):
+    """is the committed counter file older than the kernels?  (verdict round 4: it was scaled silently)"""
+    now = csrc_sha16()
+    return {"traffic_commit": T.get("commit", "unstamped"), "traffic_csrc_sha16": T.get("csrc_sha16", "unstamped"), "csrc_sha16": now,
+            "traffic_stale": T.get("csrc_sha16") != now}
+
+
 def cpu_info():
     model = "unknown"
     try:
@@ -173,12 +190,12 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
         # call to call there, so the analysis of batch i + 1 overlaps the coding of batch i (DSV1_ABR_SERIAL=1: plain encode calls)
         piped = crf or os.environ.get("DSV1_ABR_SERIAL", "0") in ("", "0")
         if piped:
-            b.submit(d, on_device=True)                  # fill the pipeline (as the headline loop does)
+            b.submit(d, on_device=True, held=True)                  # fill the pipeline (as the headline loop does)
         b.sync()
         t0 = time.perf_counter()
         if piped:
             for _ in range(steps):
-                b.submit(d, on_device=True)
+                b.submit(d, on_device=True, held=True)
                 outs = b.collect(copy=False)
             b.sync()
             dt = time.perf_counter() - t0
@@ -219,40 +236,74 @@ def cfg4_sharded(pkg, A, shard, torch, dist, dev, rank, world, shared, steps, ng
     clip = A.gen_clip(w, h, fmt, 0x21600004, gop, style=0)
     cli = dict(qp=85, gop=gop, rc_mode_cli=1, scd=0)
     tmax, first = 0.0, []
-    if n > 0:
-        batch_in = np.empty((n, gop, A.frame_bytes(w, h, fmt)), dtype=np.uint8)
-        batch_in[:] = clip
-        b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), n, gop, device=dev)
+    b, err = None, None
+    # The leg is a collective (barrier, all_reduce, gather): a rank whose set-up fails (out of memory in Batch(), a failed upload)
+    # must not leave the others waiting in one.  Every rank reports its set-up, all agree to run or to skip (advisor round 4).
     try:
         if n > 0:
+            batch_in = np.empty((n, gop, A.frame_bytes(w, h, fmt)), dtype=np.uint8)
+            batch_in[:] = clip
+            b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), n, gop, device=dev)
             d = b.upload(batch_in)
             for s_ in range(n):
                 b.set_fnum(s_, (lo + s_) * gop)
             first = [(lo + s_, bytes(o)) for s_, o in enumerate(b.encode(d, on_device=True))]
-            b.submit(d, on_device=True)
+            b.submit(d, on_device=True, held=True)
             b.sync()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
+    except Exception as e:          # noqa: BLE001 -- reported, and agreed on below
+        err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+    if world > 1:
+        ok = torch.tensor([0 if err else 1], dtype=torch.int32, device="cpu" if shared else "cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        all_ok = bool(ok.item())
+    else:
+        all_ok = err is None
+    if not all_ok:
+        if b is not None:
+            try:
+                b.close()
+            except Exception:       # noqa: BLE001
+                pass
+        if err:
+            print("[bench] cfg4_sharded skipped: " + err, file=sys.stderr)
+        return {"skipped": err or "another rank failed its set-up"} if rank == 0 else None
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    try:                            # (a rank that fails here still meets the others in the barrier and the reductions below)
         if n > 0:
             for _ in range(steps):
-                b.submit(d, on_device=True)
+                b.submit(d, on_device=True, held=True)
                 b.collect(copy=False)
             b.sync()
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        tmax = time.perf_counter() - t0
-        if n > 0:
+    except Exception as e:          # noqa: BLE001
+        err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    tmax = time.perf_counter() - t0
+    try:
+        if n > 0 and not err:
             b.collect(copy=False)
+    except Exception as e:          # noqa: BLE001
+        err = "rank %d: %s: %s" % (rank, type(e).__name__, e)
     finally:
         if n > 0:
-            b.close()
+            try:
+                b.close()
+            except Exception:       # noqa: BLE001
+                pass
     if world > 1:
-        t = torch.tensor([tmax], dtype=torch.float64, device="cpu" if shared else "cuda")
+        t = torch.tensor([tmax, 1.0 if err else 0.0], dtype=torch.float64, device="cpu" if shared else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        tmax = float(t.item())
+        tmax, failed = float(t[0].item()), bool(t[1].item())
+    else:
+        failed = err is not None
+    if failed:
+        if err:
+            print("[bench] cfg4_sharded failed: " + err, file=sys.stderr)
+        return {"error": err or "another rank failed in the timed region"} if rank == 0 else None
     parts = shard.gather_streams(first, dist if world > 1 else None)
     if rank != 0:
         return None
@@ -321,10 +372,10 @@ def decode_bench(pkg, A, dev, streams, reps):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--steps", type=int, default=150, help="timed steps (default: a timed region of ~5 s, so that coarse GPU-busy sampling around the run can see it)")
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--gops", type=int, default=320, help="closed GOPs per GPU per step (same box, round 3: 160: 191.5, 256: 194.9, 320: 197.9, 384: 200.4, 416: 189 Gpix/s -- "
-                                                          "the per-step latency-bound kernels and host round trips amortise, beyond 400 the streams stop overlapping; 320 GOPs keep ~100 GB of HBM and 12 GB of host memory)")
+    ap.add_argument("--gops", type=int, default=320, help="closed GOPs per GPU per step (320 GOPs keep ~100 GB of HBM and 12 GB of host memory; tools/ab/gops_sweep.sh "
+                                                          "measures other sizes on the same box -- DESIGN.md section 7 has the round's table)")
     ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events (auto = the largest; none = no brackets, no roofline: counter passes)")
@@ -453,18 +504,21 @@ def main():
             prof_kernel = max(table, key=lambda k: table[k][0])
         b.code_streams(nstreams)
         b.prof_enable([prof_kernel])
-    b.submit(src, on_device=ondev)                  # fill the pipeline
+    b.submit(src, on_device=ondev, held=True)                  # fill the pipeline
     sync_all()
+    b.mark(0)
     t0 = time.perf_counter()
     if not ondev:
         b.stage(src)                                # host input: K uploads inside the timed region, queued back to back
     for i in range(args.steps):
         if not ondev and i + 1 < args.steps:
             b.stage(src)                            # the next step's upload follows this one's on the copy stream
-        b.submit(src, on_device=ondev)
+        b.submit(src, on_device=ondev, held=True)
         outs = b.collect(copy=False)                # the finished packets stay in the buffers they were assembled in
+    b.mark(1)                                       # (behind the last step's coding work on the first coding stream, which joins the others)
     sync_all()
     dt = time.perf_counter() - t0
+    gpu_ms = b.mark_ms()                            # the same region by HIP events on the device
     # the bytes the LAST TIMED step produced (all streams, in stream order), hashed before anything reuses their buffers;
     # compared further down with bytes derived from the reference encoder's output for the same clips and frame numbers
     timed_sha = timed_fnum = None
@@ -523,6 +577,7 @@ def main():
                 if "hbm_bytes_per_launch_raw" in e:      # FETCH_SIZE + WRITE_SIZE as reported, no read-side doubling
                     kinfo["traffic_raw"] = round(e["hbm_bytes_per_launch_raw"] * args.gops / T["gops"])
                 kinfo["traffic_source"] = T.get("source", "profiles/pmc_traffic.json")
+                kinfo.update(traffic_stamp(T))
             if e and e.get("valu_insts_per_launch") and ms > 0:
                 # integer/byte kernels can be bound by VALU issue rather than HBM: wave64 instructions of the kinds used here
                 # issue at VALU_PEAK_GI chip-wide (measured, see the constant)
@@ -625,6 +680,9 @@ def main():
             "unit": "Mpix/s",
             "n_gpus": world,
             "steps": args.steps,
+            "timed_region": {"host_clock_s": round(dt, 4), "gpu_events_s": round(gpu_ms / 1e3, 4),
+                             "note": "the K timed steps by the host clock (barrier + sync on both sides: what `value` uses) and by HIP events recorded on the first "
+                                     "coding stream at the region's start and behind its last coding work"},
             "warmup": args.warmup,
             "ms_per_step": round(1000.0 * tmax / args.steps, 3),
             "higher_is_better": True,
@@ -656,6 +714,7 @@ def main():
                                    "achieved": round(hb / (1e-3 * res["ms_per_step"]) / 1e9, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                    "frac": round(hb / (1e-3 * res["ms_per_step"]) / 1e9 / HBM_PEAK_GBS, 4),
                                    "algorithmic_bytes_per_step": round(41.2 * GOP * W * H * args.gops),
+                                   "traffic_stale": traffic_stamp(T)["traffic_stale"], "traffic_commit": T.get("commit", "unstamped"),
                                    "note": "counter bytes = (2 x FETCH_SIZE + WRITE_SIZE) of every kernel of a step (profiles/pmc_traffic.json, "
                                            "FETCH_SIZE tallies 128-byte requests at 64 bytes: profiles/r03_fetch_calib.txt); algorithmic = SURVEY 8(d)'s 41.2 B per luma pixel of the "
                                            "unfused reference pipeline -- the fused kernels move less than that"}

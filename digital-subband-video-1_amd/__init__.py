@@ -80,6 +80,10 @@ def lib():
         L.dsv1_decbatch_ctx.restype = _C.c_void_p
         L.dsv1_decbatch_ctx.argtypes = [_C.c_void_p]
         L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_ulonglong]
+        L.dsvg_ctx_mark.argtypes = [_C.c_void_p, _C.c_int]
+        L.dsvg_ctx_mark_ms.argtypes = [_C.c_void_p, _C.POINTER(_C.c_float)]
+        L.dsv1_batch_encoder.restype = _C.c_void_p
+        L.dsv1_batch_encoder.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_prof_reset.argtypes = [_C.c_void_p]
         L.dsvg_prof_get.argtypes = [_C.c_void_p, _C.c_int, _C.POINTER(_C.c_double), _C.POINTER(_C.c_long),
                                     _C.POINTER(_C.c_double)]
@@ -179,6 +183,13 @@ class Batch:
     def set_fnum(self, stream, fnum):
         self.L.dsv1_batch_set_fnum(self.h, stream, fnum)
 
+    def encoder(self, stream):
+        """the stream's DSV_ENCODER (owned by the batch): its public parameter fields may be changed between submits"""
+        p = self.L.dsv1_batch_encoder(self.h, stream)
+        if not p:
+            raise IndexError("no stream %d" % stream)
+        return Encoder.from_address(p)
+
     def upload(self, clip):
         """keep a raw clip (numpy uint8, any shape) resident in HBM; returns the device pointer"""
         a = _np.ascontiguousarray(clip, dtype=_np.uint8)
@@ -219,11 +230,12 @@ class Batch:
                 _chk(self.L.dsv1_batch_eos(self.h, s, _C.byref(bufs[s])), "dsv1_batch_eos")
         return [_take(bufs[s]) for s in range(self.nstreams)]
 
-    def submit(self, yuv, on_device=False, held=True):
+    def submit(self, yuv, on_device=False, held=False):
         """pipelined form: enqueue one batch (returns while its residual coding still runs on the GPU).
         At most two batches may be in flight: steady state is submit(i+1); collect(i).
-        held (device clips): the caller keeps the clip unchanged until collect() of this batch returned (DSV1_CLIP_HELD: its
-        chroma is read in place); held=False: the clip is copied whole and may change as soon as submit() returns"""
+        Device clips: by default (the contract of dsv1_api.h's plain yuv_on_device = 1) the clip is copied whole and may change
+        as soon as submit() returns; held=True (DSV1_CLIP_HELD, what bench.py times): the caller keeps the clip unchanged until
+        collect() of this batch returned -- its chroma is then read in place"""
         if on_device:
             ptr = yuv
         else:
@@ -264,6 +276,15 @@ class Batch:
 
     def kernel_names(self):
         return [self.L.dsvg_prof_kernel_name(i).decode() for i in range(self.L.dsvg_prof_kernels())]
+
+    def mark(self, which):
+        """HIP-event mark on the first coding stream (0: a timed region starts, 1: behind its last enqueued coding work)"""
+        _chk(self.L.dsvg_ctx_mark(self.ctx, which), "dsvg_ctx_mark")
+
+    def mark_ms(self):
+        ms = _C.c_float(0)
+        _chk(self.L.dsvg_ctx_mark_ms(self.ctx, _C.byref(ms)), "dsvg_ctx_mark_ms")
+        return ms.value
 
     def prof_enable(self, kernels):
         """kernels: iterable of kernel names whose launches get HIP-event brackets (empty = off)"""

@@ -7,6 +7,7 @@
 // results.  The host only ever sees: MV fields, mean luma, per-plane (DC, nruns, payload bytes).
 #include <stdlib.h>
 #include <algorithm>
+#include <cstddef>
 #include "dsvg_host.hpp"
 #include <ctime>
 extern "C" void dsv1_par_for(int S, void (*fn)(void *ctx, int s, int tid), void *ctx);     // host/dsv1_util.c: the worker pool
@@ -69,6 +70,37 @@ static int pick_streams(hipStream_t *out, int want)
     return good;
 }
 
+// A stream confined to a set of compute units (experiment, DESIGN section 8: the streaming kernels and the instruction-bound ones on
+// disjoint CUs instead of time slices).  spec: comma-separated bit ranges "a-b" / single bits of the 256-bit CU mask; "xA-B": every
+// bit whose index mod 8 lies in A..B (on this part bit i is a CU of XCD i mod 8, dealt over that XCD's shader engines in turn:
+// tools/ubench/cumask_probe.hip prints the placement); a leading '!' takes the complement.
+static bool cu_mask_stream(hipStream_t *out, const char *spec, const char *what)
+{
+    uint32_t m[8] = {};
+    const char *p = spec;
+    const bool inv = *p == '!';
+    if (inv) p++;
+    while (*p) {
+        const bool xcd = *p == 'x';
+        if (xcd) p++;
+        char *e = nullptr;
+        long a = strtol(p, &e, 10), b = a;
+        if (e == p) return false;
+        p = e;
+        if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1) return false; p = e; }
+        if (a < 0 || b < a || b > 255) return false;
+        for (int i = 0; i < 256; i++)
+            if (xcd ? ((i & 7) >= a && (i & 7) <= b) : (i >= a && i <= b)) m[i >> 5] |= 1u << (i & 31);
+        if (*p == ',') p++;
+    }
+    int n = 0;
+    for (int i = 0; i < 8; i++) { if (inv) m[i] = ~m[i]; n += __builtin_popcount(m[i]); }
+    if (!n) return false;
+    if (hipExtStreamCreateWithCUMask(out, 8, m) != hipSuccess) { (void)hipGetLastError(); return false; }
+    fprintf(stderr, "[dsvg] %s stream on %d CUs (mask %08x %08x %08x %08x %08x %08x %08x %08x)\n", what, n, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
+    return true;
+}
+
 struct dsvg_ctx {
     int device = 0;
     hipStream_t st = nullptr;        // residual-coding stream
@@ -82,6 +114,15 @@ struct dsvg_ctx {
     int code_streams = 1;
     int streams_apart = 0;           // how many of {coding, analysis, second coding, fetch} were found on hardware queues of their own
     hipStream_t st_a = nullptr;      // analysis stream (frame load, pyramid, HME): overlaps coding of the previous batch
+    hipStream_t st_l = nullptr;      // frame-load stream: st_a itself unless DSV1_CU_LOAD gives the streaming load kernels a CU-masked stream of their own
+    hipEvent_t ev_l = nullptr;       // load -> analysis / coding dependency when st_l is a stream of its own
+    // DSV1_TIMELINE=1: a batch-level timeline without a profiler in the way (rocprofv3 makes every launch cost the host ~70 us, which
+    // serialises a pipeline whose point is that the host runs ahead): timing events on the pipeline's own streams at the boundaries of
+    // load / motion search / coding / fetch plus the host clock at the moment each was enqueued; printed by dsvg_ctx_sync / destroy
+    struct TlMark { const char *what; hipEvent_t ev; double host_ms; };
+    std::vector<TlMark> tl;
+    bool tl_on = false;
+    hipEvent_t ev_mark[2] = {nullptr, nullptr};     // dsvg_ctx_mark
     int w = 0, h = 0, fmt = 0, bw = 0, bh = 0, nbh = 0, nbv = 0, nblk = 0, levels = 0;
     FrameLayout L[6];
     CoefLayout CL;
@@ -194,10 +235,37 @@ struct dsvg_ctx {
 
 static int dec_resolve(dsvg_ctx *c);     // decoder: settle the flags of the last call (defined with dsvg_decode_pictures)
 
+static double tl_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+static void tl_mark(dsvg_ctx *c, hipStream_t st, const char *what)
+{
+    if (!c->tl_on || c->tl.size() >= 4096) return;
+    hipEvent_t e = nullptr;
+    if (hipEventCreate(&e) != hipSuccess) return;
+    (void)hipEventRecord(e, st);
+    c->tl.push_back({what, e, tl_now()});
+}
+// (call with the streams idle: after the syncs of dsvg_ctx_sync / before the context goes)
+static void tl_dump(dsvg_ctx *c)
+{
+    if (!c->tl_on || c->tl.empty()) return;
+    fprintf(stderr, "[dsvg timeline] %zu marks; columns: device ms (event time), host ms (when it was enqueued), both from the first mark\n", c->tl.size());
+    for (size_t i = 0; i < c->tl.size(); i++) {
+        float ms = -1.f;
+        if (c->tl[i].ev && c->tl[0].ev) {
+            (void)hipEventSynchronize(c->tl[i].ev);
+            if (hipEventElapsedTime(&ms, c->tl[0].ev, c->tl[i].ev) != hipSuccess) { (void)hipGetLastError(); ms = -1.f; }
+        }
+        fprintf(stderr, "[dsvg timeline] %-10s dev %9.3f  host %9.3f\n", c->tl[i].what, ms, c->tl[i].host_ms - c->tl[0].host_ms);
+    }
+    for (auto &m : c->tl) if (m.ev) (void)hipEventDestroy(m.ev);
+    c->tl.clear();
+}
+
 static void ctx_free(dsvg_ctx *c)
 {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    if (c->tl_on) { (void)hipDeviceSynchronize(); tl_dump(c); }
     if (c->slot_cu_d) (void)hipFree(c->slot_cu_d);
     if (c->slot_cv_d) (void)hipFree(c->slot_cv_d);
     if (c->slot_cs_d) (void)hipFree(c->slot_cs_d);
@@ -214,6 +282,9 @@ static void ctx_free(dsvg_ctx *c)
     void *hh[] = {c->jobs_h, c->bits_h, c->psum_h, c->mv_h, c->stable_h, c->slots_h, c->luma_h, c->dec_h[0], c->dec_h[1], c->ilist_h, c->gtab_h, c->gath_h, c->aslots_h, c->amv_h, c->rcj_h};
     for (void *p : hh) if (p) (void)hipHostFree(p);
     if (c->st) (void)hipStreamDestroy(c->st);
+    for (int i = 0; i < 2; i++) if (c->ev_mark[i]) (void)hipEventDestroy(c->ev_mark[i]);
+    if (c->st_l && c->st_l != c->st_a) (void)hipStreamDestroy(c->st_l);
+    if (c->ev_l) (void)hipEventDestroy(c->ev_l);
     if (c->st_a) (void)hipStreamDestroy(c->st_a);
     for (int g = 0; g < DSVG_MAX_CODE_STREAMS; g++) {
         if (c->stx[g]) (void)hipStreamDestroy(c->stx[g]);
@@ -368,11 +439,27 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
         for (int g = 1; g < std::max(ncs, 2); g++)
             if (hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
         c->streams_apart = good;
+        // experiment: CU-masked streams -- DSV1_CU_ANALYSIS / DSV1_CU_CODE replace the analysis / every coding stream,
+        // DSV1_CU_LOAD gives the frame-load kernels (k_unpack, k_ds2x, k_extend16 of the sources, k_luma_sum) a stream of their own
+        auto masked = [&](const char *env, hipStream_t *s, const char *what, bool replace) {
+            const char *spec = getenv(env);
+            hipStream_t ns = nullptr;
+            if (!spec || !*spec) return;
+            if (!cu_mask_stream(&ns, spec, what)) { fprintf(stderr, "[dsvg] %s=%s: no masked stream (bad spec or not supported), ignored\n", env, spec); return; }
+            if (replace && *s) (void)hipStreamDestroy(*s);
+            *s = ns;
+        };
+        masked("DSV1_CU_ANALYSIS", &c->st_a, "analysis", true);
+        masked("DSV1_CU_CODE", &c->st, "coding", true);
+        for (int g = 1; g < std::max(ncs, 2); g++) masked(g == 1 && getenv("DSV1_CU_CODE2") ? "DSV1_CU_CODE2" : "DSV1_CU_CODE", &c->stx[g], "coding", true);
+        masked("DSV1_CU_LOAD", &c->st_l, "frame-load", false);
     } else if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->st_a, hipStreamNonBlocking) != hipSuccess ||
                hipStreamCreateWithFlags(&c->st_c, hipStreamNonBlocking) != hipSuccess) {
         dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP);      // one picture (or a few) at a time: streams as they come
     }
-    if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
+    if (!c->st_l) c->st_l = c->st_a;
+    c->tl_on = getenv("DSV1_TIMELINE") != nullptr;
+    if (hipEventCreateWithFlags(&c->ev_a, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_l, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
     c->ev_coded.resize((size_t)2 * c->nwin + 2);
     for (auto &e : c->ev_coded)
         if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
@@ -469,6 +556,23 @@ extern "C" void dsvg_ctx_destroy(dsvg_ctx *ctx) { if (ctx) { (void)hipDeviceSync
 extern "C" void dsvg_ctx_destroy(dsvg_ctx *ctx) { ctx_free(ctx); }
 #endif
 
+extern "C" int dsvg_ctx_mark(dsvg_ctx *c, int which)
+{
+    if (!c || which < 0 || which > 1) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    if (!c->ev_mark[which]) HIPCHK(hipEventCreate(&c->ev_mark[which]));
+    HIPCHK(hipEventRecord(c->ev_mark[which], c->st));
+    return DSVG_OK;
+}
+extern "C" int dsvg_ctx_mark_ms(dsvg_ctx *c, float *ms)
+{
+    if (!c || !ms || !c->ev_mark[0] || !c->ev_mark[1]) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    HIPCHK(hipEventSynchronize(c->ev_mark[1]));
+    HIPCHK(hipEventElapsedTime(ms, c->ev_mark[0], c->ev_mark[1]));
+    return DSVG_OK;
+}
+
 extern "C" int dsvg_ctx_geom(const dsvg_ctx *c, dsvg_geom *g)
 {
     if (!c || !g) return DSVG_ERR_ARG;
@@ -489,9 +593,11 @@ extern "C" int dsvg_ctx_sync(dsvg_ctx *c)
     OPCHK(dec_resolve(c));
     if (c->st_h) HIPCHK(hipStreamSynchronize(c->st_h));
     for (int g = 1; g < DSVG_MAX_CODE_STREAMS; g++) if (c->stx[g]) HIPCHK(hipStreamSynchronize(c->stx[g]));
+    if (c->st_l != c->st_a) HIPCHK(hipStreamSynchronize(c->st_l));
     HIPCHK(hipStreamSynchronize(c->st_a));
     HIPCHK(hipStreamSynchronize(c->st));
     HIPCHK(hipStreamSynchronize(c->st_c));
+    tl_dump(c);
     c->calls_since_sync = 0;
     HIPCHK(hipGetLastError());
     return DSVG_OK;
@@ -591,6 +697,7 @@ static int ingest_reserve(dsvg_ctx *c, size_t bytes, int *kout)
         if (c->ingest[k]) {                      // the old buffer may still be read by load kernels / an earlier copy
             HIPCHK(hipStreamSynchronize(c->st_h));
             HIPCHK(hipStreamSynchronize(c->st_a));
+            HIPCHK(hipStreamSynchronize(c->st_l));
             (void)hipFree(c->ingest[k]);
             c->ingest[k] = nullptr; c->ingest_bytes[k] = 0;
         }
@@ -649,7 +756,7 @@ static int ingest_acquire(dsvg_ctx *c, const void *dsrc)
         const uint8_t *b = c->ingest[k], *p = (const uint8_t *)dsrc;
         if (b && p >= b && p < b + c->ingest_bytes[k]) {
             if (c->up_pending[k]) {
-                if (hipStreamWaitEvent(c->st_a, c->ev_up[k], 0) != hipSuccess) return -2;
+                if (hipStreamWaitEvent(c->st_l, c->ev_up[k], 0) != hipSuccess) return -2;
                 c->up_pending[k] = false;
             }
             return k;
@@ -660,7 +767,7 @@ static int ingest_acquire(dsvg_ctx *c, const void *dsrc)
 static int ingest_release(dsvg_ctx *c, int k)
 {
     if (k < 0) return DSVG_OK;
-    HIPCHK(hipEventRecord(c->ev_used[k], c->st_a));
+    HIPCHK(hipEventRecord(c->ev_used[k], c->st_l));
     c->used_valid[k] = true;
     return DSVG_OK;
 }
@@ -679,9 +786,9 @@ static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, si
             }
         }
         if (changed) {
-            HIPCHK(hipMemcpyAsync(c->slot_cu_d, c->slot_cu_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
-            HIPCHK(hipMemcpyAsync(c->slot_cv_d, c->slot_cv_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
-            HIPCHK(hipMemcpyAsync(c->slot_cs_d, c->slot_cs_h, 4 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+            HIPCHK(hipMemcpyAsync(c->slot_cu_d, c->slot_cu_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
+            HIPCHK(hipMemcpyAsync(c->slot_cv_d, c->slot_cv_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
+            HIPCHK(hipMemcpyAsync(c->slot_cs_d, c->slot_cs_h, 4 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
         }
     }
     // the first pyramid level comes out of the unpack kernel when the luma plane allows it (one read of the frame less)
@@ -695,22 +802,28 @@ static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, si
     static const bool no_fuse2 = getenv("DSV1_NO_FUSE_LEVEL2") != nullptr;
     const bool fuse2 = fuse1 && !no_fuse2 && c->levels >= 2 && unpack_fuses_level2(c->L[0], c->L[1], c->L[2]);
     const bool sides2 = fuse2 && sides && !no_lsides && level_sides_ok(c->src[2].p, c->L[2]);
-    launch_unpack(c->st_a, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1,
+    tl_mark(c, c->st_l, "load0");
+    launch_unpack(c->st_l, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1,
                   fuse2 ? c->src[2].p : nullptr, fuse2 ? &c->L[2] : nullptr, sides2, n_chroma);
-    launch_extend(c->st_a, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
+    launch_extend(c->st_l, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
             const bool fused = (l == 1 && fuse1) || (l == 2 && fuse2);
             bool ls = fused ? (l == 1 ? sides1 : sides2) : false;
             if (!fused) {
                 ls = !no_lsides && level_sides_ok(c->src[l].p, c->L[l]);
-                launch_ds2x(c->st_a, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d, ls);
+                launch_ds2x(c->st_l, c->src[l - 1].p, c->L[l - 1], c->src[l].p, c->L[l], first_slot, n, &c->prof, tab_d, ls);
             }
-            launch_extend(c->st_a, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof, nullptr, ls);
+            launch_extend(c->st_l, c->src[l].p, c->L[l], first_slot, n, 1, tab_d, &c->prof, nullptr, ls);
         }
-        if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st_a));
-        else       HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st_a));
-        launch_luma_sum(c->st_a, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums, &c->prof, tab_d);
+        if (tab_d) HIPCHK(hipMemsetAsync(c->luma_sums, 0, sizeof(unsigned) * c->n_src, c->st_l));
+        else       HIPCHK(hipMemsetAsync(c->luma_sums + first_slot, 0, sizeof(unsigned) * n, c->st_l));
+        launch_luma_sum(c->st_l, c->src[c->levels].p, c->L[c->levels], first_slot, n, c->luma_sums, &c->prof, tab_d);
+    }
+    tl_mark(c, c->st_l, "load1");
+    if (c->st_l != c->st_a) {      // the motion search and the coding streams take the frames from the analysis stream's order
+        HIPCHK(hipEventRecord(c->ev_l, c->st_l));
+        HIPCHK(hipStreamWaitEvent(c->st_a, c->ev_l, 0));
     }
     HIPCHK(hipGetLastError());
     return DSVG_OK;
@@ -724,11 +837,11 @@ extern "C" int dsvg_load_frames(dsvg_ctx *c, int first_slot, int n, const void *
     const uint8_t *dsrc = (const uint8_t *)yuv;
     if (!yuv_on_device) {
         if (c->yuv_stage_bytes < fb * n) {
-            if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st_a)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
+            if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st_l)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
             HIPCHK(hipMalloc((void **)&c->yuv_stage, fb * n + 256));
             c->yuv_stage_bytes = fb * n;
         }
-        HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st_a));
+        HIPCHK(hipMemcpyAsync(c->yuv_stage, yuv, fb * n, hipMemcpyHostToDevice, c->st_l));
         dsrc = c->yuv_stage;
     }
     return load_core(c, first_slot, n, dsrc, fb, with_pyramid, nullptr);
@@ -778,11 +891,11 @@ extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, con
     if (changed) {
         // (the pinned mirrors are only rewritten here, and every load is followed by a host wait on this stream -- the luma
         // sums or the motion search -- before the next one: no copy of an older state is still in flight)
-        HIPCHK(hipMemcpyAsync(c->slot_cu_d, c->slot_cu_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
-        HIPCHK(hipMemcpyAsync(c->slot_cv_d, c->slot_cv_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
-        HIPCHK(hipMemcpyAsync(c->slot_cs_d, c->slot_cs_h, 4 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_a));
+        HIPCHK(hipMemcpyAsync(c->slot_cu_d, c->slot_cu_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
+        HIPCHK(hipMemcpyAsync(c->slot_cv_d, c->slot_cv_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
+        HIPCHK(hipMemcpyAsync(c->slot_cs_d, c->slot_cs_h, 4 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
     }
-    HIPCHK(hipMemcpyAsync(c->ltab_d, tab.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_a));   // pageable: staged by the runtime
+    HIPCHK(hipMemcpyAsync(c->ltab_d, tab.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_l));   // pageable: staged by the runtime
     const int k = ingest_acquire(c, yuv_dev);
     if (k == -2) { dsvg_set_error("hipStreamWaitEvent failed"); return DSVG_ERR_HIP; }
     const int rc = load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d, n - n_direct);
@@ -798,8 +911,8 @@ extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *
 {
     if (!c || !sums_out || first_slot < 0 || first_slot + n > c->n_src) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st_a));
-    HIPCHK(hipStreamSynchronize(c->st_a));
+    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st_l));
+    HIPCHK(hipStreamSynchronize(c->st_l));
     memcpy(sums_out, c->luma_h, sizeof(unsigned) * n);
     return DSVG_OK;
 }
@@ -808,8 +921,8 @@ extern "C" int dsvg_get_avg_luma(dsvg_ctx *c, int first_slot, int n, int *avg_ou
 {
     if (!c || !avg_out || first_slot < 0 || first_slot + n > c->n_src) return DSVG_ERR_ARG;
     HIPCHK(hipSetDevice(c->device));
-    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st_a));
-    HIPCHK(hipStreamSynchronize(c->st_a));
+    HIPCHK(hipMemcpyAsync(c->luma_h, c->luma_sums + first_slot, sizeof(unsigned) * n, hipMemcpyDeviceToHost, c->st_l));
+    HIPCHK(hipStreamSynchronize(c->st_l));
     const FrameLayout &L = c->L[c->levels];
     for (int i = 0; i < n; i++) avg_out[i] = (int)c->luma_h[i] / (L.w[0] * L.h[0]);     // frame.c:237
     return DSVG_OK;
@@ -837,7 +950,9 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
     A.csum = getenv("DSV1_NO_CHROMA_SUMS") ? nullptr : c->csum;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
+    tl_mark(c, c->st_a, "hme0");
     launch_hme(c->st_a, A, npairs, &c->prof);
+    tl_mark(c, c->st_a, "hme1");
     HIPCHK(hipMemcpy2DAsync(c->amv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
                             (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st_a));
     HIPCHK(hipStreamSynchronize(c->st_a));
@@ -1161,6 +1276,7 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
     HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs + (size_t)base * c->nblk, c->mv_h + (size_t)base * c->nblk, (size_t)c->nblk * total * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots + base, c->slots_h + base, sizeof(int) * total, hipMemcpyHostToDevice, c->st));
+    tl_mark(c, c->st, "code0");
     if (NG > 1) {
         if (!c->ev_fork) HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
         HIPCHK(hipEventRecord(c->ev_fork, c->st));            // tables uploaded, source frames ready (st waited for ev_a)
@@ -1228,13 +1344,18 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
         static const bool no_par_enqueue = getenv("DSV1_NO_PAR_ENQUEUE") != nullptr;      // (A/B)
         // (the event brackets of the profiling hooks are kept in one list: profiled calls are enqueued by this thread alone)
         if (NG > 1 && nsteps * 13 >= 100 && njobs < 64 && !c->prof.mask && !no_par_enqueue) {
-            struct PE { decltype(enqueue_steps) *f; int device, nsteps, rc[DSVG_MAX_CODE_STREAMS]; } pe = {&enqueue_steps, c->device, nsteps, {0}};
+            // (HIP's last error and this library's error text are per THREAD: each worker checks its own launches and hands its text over)
+            struct PE { decltype(enqueue_steps) *f; int device, nsteps, rc[DSVG_MAX_CODE_STREAMS]; char msg[DSVG_MAX_CODE_STREAMS][256]; } pe = {&enqueue_steps, c->device, nsteps, {0}, {{0}}};
             dsv1_par_for_long(NG, [](void *vp, int g, int) {
                 PE &P = *static_cast<PE *>(vp);
-                if (hipSetDevice(P.device) != hipSuccess) { P.rc[g] = DSVG_ERR_HIP; return; }      // (the current device is per thread)
+                if (hipSetDevice(P.device) != hipSuccess) { P.rc[g] = DSVG_ERR_HIP; snprintf(P.msg[g], sizeof P.msg[g], "hipSetDevice failed on an enqueue thread"); return; }      // (the current device is per thread)
+                (void)hipGetLastError();
                 P.rc[g] = (*P.f)(g, 0, P.nsteps);
+                const hipError_t e = hipGetLastError();
+                if (P.rc[g]) snprintf(P.msg[g], sizeof P.msg[g], "%s", dsvg_last_error());
+                else if (e != hipSuccess) { P.rc[g] = DSVG_ERR_HIP; snprintf(P.msg[g], sizeof P.msg[g], "launch failed on coding stream %d: %s", g, hipGetErrorString(e)); }
             }, &pe);
-            for (int g = 0; g < NG; g++) if (pe.rc[g]) return pe.rc[g];
+            for (int g = 0; g < NG; g++) if (pe.rc[g]) { dsvg_set_error("%s", pe.msg[g]); return pe.rc[g]; }
         } else {
             for (int t = 0; t < nsteps; t++)
                 for (int g = 0; g < NG; g++) OPCHK(enqueue_steps(g, t, t + 1));
@@ -1249,10 +1370,12 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
                 launch_hz_pack(st, c->jobs_d + base + t * njobs + k0, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : 0);
             }
         }
+    if (NG > 1) { tl_mark(c, c->st, "code1a"); tl_mark(c, c->stx[1], "code1b"); }
     for (int g = 1; g < NG; g++) {
         HIPCHK(hipEventRecord(c->ev_join[g], c->stx[g]));
         HIPCHK(hipStreamWaitEvent(c->st, c->ev_join[g], 0));
     }
+    tl_mark(c, c->st, "code1");
     if (cprof) fprintf(stderr, "[dsvg code_batch] %d jobs: tables %.2f ms, uploads + %d frame steps of launches %.2f ms\n", total, tc1 - tc0, nsteps, cnow() - tc1);
     {   // completion marker of this call; fetch waits on it from its own stream
         const int e = (int)(call % (long)c->ev_coded.size());
@@ -1268,6 +1391,18 @@ extern "C" int dsvg_code_batch_rc(dsvg_ctx *c, int nsteps, int njobs, const dsvg
 {
     if (!rc) { dsvg_set_error("dsvg_code_batch_rc without rate-control jobs"); return DSVG_ERR_ARG; }
     return code_batch_impl(c, nsteps, njobs, jobs, rc);
+}
+extern "C" int dsvg_rc_set_params(dsvg_ctx *c, int first_slot, int n, const dsvg_rc_state *states)
+{
+    if (!c || !states || first_slot < 0 || n < 1 || first_slot + n > c->rc_slots) { dsvg_set_error("bad rate-control slots"); return DSVG_ERR_ARG; }
+    HIPCHK(hipSetDevice(c->device));
+    const size_t off = offsetof(dsvg_rc_state, bitrate), wid = sizeof(dsvg_rc_state) - off;
+    // the tail of every record, behind the coding work already enqueued (the other coding streams join the first one at the end of
+    // every call and fork from it at the start of the next)
+    HIPCHK(hipMemcpy2DAsync((char *)(c->rc_state_d + first_slot) + off, sizeof(dsvg_rc_state), (const char *)states + off, sizeof(dsvg_rc_state), wid, (size_t)n,
+                            hipMemcpyHostToDevice, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));               // (pageable source; a parameter change is a rare event)
+    return DSVG_OK;
 }
 extern "C" int dsvg_rc_upload(dsvg_ctx *c, int first_slot, int n, const dsvg_rc_state *states)
 {
@@ -1402,6 +1537,7 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
         HIPCHK(hipMalloc((void **)&c->gath_d, c->gath_cap));
         HIPCHK(hipHostMalloc((void **)&c->gath_h, c->gath_cap, hipHostMallocDefault));
     }
+    tl_mark(c, c->st_c, "fetch0");
     HIPCHK(hipMemcpyAsync(c->gtab_d, c->gtab_h, sizeof(unsigned long long) * 9 * (size_t)n, hipMemcpyHostToDevice, c->st_c));
     launch_gather_bits(c->st_c, c->bits, c->gtab_d, 3 * n, c->gath_d);
     if (fprof) HIPCHK(hipStreamSynchronize(c->st_c));
@@ -1435,11 +1571,13 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
         if (o1 > o0) HIPCHK(hipMemcpyAsync(c->gath_h + o0, c->gath_d + o0, o1 - o0, hipMemcpyDeviceToHost, c->st_c));
         HIPCHK(hipEventRecord(c->ev_fetch[j], c->st_c));
     }
+    tl_mark(c, c->st_c, "fetch1");
     for (int j = 0; j < nchunks; j++) {
         HIPCHK(hipEventSynchronize(c->ev_fetch[j]));
         const int first = j ? cend[j - 1] : 0;
         if (cb && cend[j] > first) cb(arg, first, cend[j] - first);
     }
+    if (c->tl_on && c->tl.size() < 4096) c->tl.push_back({"asm_done", nullptr, tl_now()});
     if (fprof) fprintf(stderr, "[dsvg fetch] wait for coding + sizes %.2f ms, gather %.2f ms, D2H of %.1f MB (+ the caller's work on %d pieces) %.2f ms\n", tf1 - tf0, tf2 - tf1, total / 1e6, nchunks, tnow() - tf2);
     HIPCHK(hipGetLastError());
     return DSVG_OK;
@@ -1540,7 +1678,7 @@ extern "C" int dsvg_pack_recons(dsvg_ctx *c, int n, const int *recon_slots, void
     }
     const size_t sp = (fb + 255) & ~(size_t)255;
     if (c->yuv_stage_bytes < sp * n) {
-        if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipStreamSynchronize(c->st_a)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
+        if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipStreamSynchronize(c->st_a)); HIPCHK(hipStreamSynchronize(c->st_l)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
         HIPCHK(hipMalloc((void **)&c->yuv_stage, sp * n + 256));
         c->yuv_stage_bytes = sp * n;
     }

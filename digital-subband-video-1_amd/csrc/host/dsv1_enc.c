@@ -57,9 +57,12 @@ struct dsv1_batch {
     /* ABR with the rate control ON THE DEVICE (round 4, include/dsvg_rc.h + k_rc): the whole call is enqueued like a CRF call, k_rc
      * turns every packet's size into the next picture's quantiser tables; the host replays the same code when it assembles the
      * packets and refuses a batch whose quantisers differ.  DSV1_ABR_SERIAL=1: the frame-by-frame host path of rounds 1-3. */
+    int holds_recycler;              /* counted in dsv1_recycle_hold (dsv1_util.c): freed packet buffers are parked while a batch is open */
     int abr_dev;
     int rc_seeded;                   /* the device holds the streams' rate-control state (seeded from enc[] by the first call) */
     dsvg_rc_job *rcjobs;
+    dsvg_rc_state *rc_dev;           /* [nstreams] the rate-control PARAMETERS the device holds (re-sent when the caller changed a stream's: advisor round 4) */
+    dsvg_rc_state *rc_par;           /* [2][nstreams] the parameters each batch in flight was submitted with: what the host's replay of that batch uses */
     /* CHAIN MODE (dsv1_stream_open): ONE stream, the residual coding of a call's frames runs GOP-parallel.  A chain = an I
      * picture and the P pictures that follow it; `chains` = how many are coded side by side (0: the mode is off).  Everything
      * that decides what a chain is -- GOP starts, scene changes, forced-intra P pictures, the stability flags -- depends on
@@ -72,6 +75,7 @@ struct dsv1_batch {
 /* source slot of frame number g (per-stream counter) of stream s */
 /* host-side phase timing (DSV1_HOST_PROF=1): where a batch's wall time goes inside submit / collect */
 #include <time.h>
+#include <stddef.h>
 enum { HP_LOAD, HP_DECIDE, HP_ANALYSE, HP_SIDEINFO, HP_ENQUEUE, HP_PREFIX, HP_FETCH, HP_ASSEMBLE, HP_N };
 static double hp_acc[HP_N];
 static long hp_batches;
@@ -107,10 +111,21 @@ int dsv1_batch_recon_slot(const dsv1_batch *b, int stream)
     return stream + b->nstreams * b->rpar[stream];
 }
 
+/* the allocations of batch_open_on / dsv1_batch_open go through here so that a test can make the n-th one fail
+ * (dsv1_debug_fail_alloc_at: 0 = off) and watch the unwinding */
+static int b_alloc_fail_at, b_alloc_count;
+void dsv1_debug_fail_alloc_at(int n) { b_alloc_fail_at = n; b_alloc_count = 0; }
+static void *b_calloc(size_t n, size_t sz)
+{
+    if (b_alloc_fail_at && ++b_alloc_count == b_alloc_fail_at) return NULL;
+    return calloc(n ? n : 1, sz ? sz : 1);
+}
+
 void dsv1_batch_close(dsv1_batch *b)
 {
     hp_report();
     if (!b) return;
+    if (b->holds_recycler) dsv1_recycle_hold(-1);       /* the last batch out gives the parked packet buffers back */
     if (b->ctx) dsvg_ctx_destroy(b->ctx);
     if (b->own_enc && b->enc) {
         int s;
@@ -124,6 +139,7 @@ void dsv1_batch_close(dsv1_batch *b)
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
     free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->rcjobs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped);
     free(b->ch_start); free(b->ch_len); free(b->ch_pair); free(b->ch_cur);
+    free(b->rc_dev); free(b->rc_par);
     free(b);
 }
 
@@ -133,8 +149,8 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     const DSV_META *m = &encs[0].vidmeta;
     int rc, i, np;
     if (!out || nstreams < 1 || F < 1 || chains < 0 || (chains && nstreams != 1)) return DSVG_ERR_ARG;
-    b = (dsv1_batch *)calloc(1, sizeof(*b));
-    if (!b) return DSVG_ERR_ARG;
+    b = (dsv1_batch *)b_calloc(1, sizeof(*b));
+    if (!b) return DSVG_ERR_NOMEM;
     b->nstreams = nstreams; b->F = F; b->enc = encs; b->own_enc = own;
     if (chains > F) chains = F;
     b->chains = chains; b->carry_pair = -1; b->carry_cur = -1;
@@ -150,38 +166,51 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     b->small_w = (m->width + (1 << b->g.pyramid_levels) - 1) >> b->g.pyramid_levels;
     b->small_h = (m->height + (1 << b->g.pyramid_levels) - 1) >> b->g.pyramid_levels;
     b->prefix_cap = 128 + b->nblk * 24;
-    b->pics = (pic_t *)calloc((size_t)2 * np, sizeof(pic_t));
-    b->mvpool = (DSV_MV *)calloc((size_t)2 * np * b->nblk, sizeof(DSV_MV));
-    b->stabpool = (unsigned char *)calloc((size_t)2 * np * b->nblk, 1);
-    b->prefixpool = (uint8_t *)calloc((size_t)2 * np, (size_t)b->prefix_cap);
-    b->slots_cur = (int *)calloc((size_t)np, sizeof(int));
-    b->slots_ref = (int *)calloc((size_t)np, sizeof(int));
-    b->pair_pic = (int *)calloc((size_t)np, sizeof(int));
-    b->out_slots = (int *)calloc((size_t)np, sizeof(int));
-    b->rpar = (unsigned char *)calloc((size_t)nstreams, 1);
-    b->has_recon = (unsigned char *)calloc((size_t)nstreams, 1);
-    b->border_skipped = (unsigned char *)calloc((size_t)nstreams, 1);
-    b->luma = (unsigned *)calloc((size_t)b->rows * nstreams, sizeof(unsigned));
-    b->mv_tmp = (DSV_MV *)calloc((size_t)np * b->nblk, sizeof(DSV_MV));
-    b->jobs = (dsvg_pic_job *)calloc((size_t)np, sizeof(dsvg_pic_job));
-    b->outs = (dsvg_pic_out *)calloc((size_t)np, sizeof(dsvg_pic_out));
-    b->rcjobs = (dsvg_rc_job *)calloc((size_t)np, sizeof(dsvg_rc_job));
+    /* every allocation checked (verdict round 4): one failure unwinds the whole batch, context included */
+#define B_ALLOC(field, type, n, sz) do { b->field = (type *)b_calloc((size_t)(n), (size_t)(sz)); if (!b->field) goto nomem; } while (0)
+    B_ALLOC(pics, pic_t, 2 * (size_t)np, sizeof(pic_t));
+    B_ALLOC(mvpool, DSV_MV, 2 * (size_t)np * b->nblk, sizeof(DSV_MV));
+    B_ALLOC(stabpool, unsigned char, 2 * (size_t)np * b->nblk, 1);
+    B_ALLOC(prefixpool, uint8_t, 2 * (size_t)np, b->prefix_cap);
+    B_ALLOC(slots_cur, int, np, sizeof(int));
+    B_ALLOC(slots_ref, int, np, sizeof(int));
+    B_ALLOC(pair_pic, int, np, sizeof(int));
+    B_ALLOC(out_slots, int, np, sizeof(int));
+    B_ALLOC(rpar, unsigned char, nstreams, 1);
+    B_ALLOC(has_recon, unsigned char, nstreams, 1);
+    B_ALLOC(border_skipped, unsigned char, nstreams, 1);
+    B_ALLOC(luma, unsigned, (size_t)b->rows * nstreams, sizeof(unsigned));
+    B_ALLOC(mv_tmp, DSV_MV, (size_t)np * b->nblk, sizeof(DSV_MV));
+    B_ALLOC(jobs, dsvg_pic_job, np, sizeof(dsvg_pic_job));
+    B_ALLOC(outs, dsvg_pic_out, np, sizeof(dsvg_pic_out));
+    B_ALLOC(rcjobs, dsvg_rc_job, np, sizeof(dsvg_rc_job));
+    B_ALLOC(rc_dev, dsvg_rc_state, nstreams, sizeof(dsvg_rc_state));
+    B_ALLOC(rc_par, dsvg_rc_state, 2 * (size_t)nstreams, sizeof(dsvg_rc_state));
     { const char *e = getenv("DSV1_ABR_SERIAL"); b->abr_dev = !chains && !(e && atoi(e) != 0); }
     if (chains) {
-        b->ch_start = (int *)calloc((size_t)F + 1, sizeof(int));
-        b->ch_len = (int *)calloc((size_t)F + 1, sizeof(int));
-        b->ch_pair = (int *)calloc((size_t)F + 1, sizeof(int));
-        b->ch_cur = (int *)calloc((size_t)F + 1, sizeof(int));
+        B_ALLOC(ch_start, int, (size_t)F + 1, sizeof(int));
+        B_ALLOC(ch_len, int, (size_t)F + 1, sizeof(int));
+        B_ALLOC(ch_pair, int, (size_t)F + 1, sizeof(int));
+        B_ALLOC(ch_cur, int, (size_t)F + 1, sizeof(int));
     }
     b->sc0.cap = (size_t)b->prefix_cap + b->g.plane_out_cap[0] + 2 * b->g.plane_out_cap[1] + 256;
-    b->sc0.pkt = (uint8_t *)malloc(b->sc0.cap);
+    b->sc0.pkt = (uint8_t *)b_calloc(1, b->sc0.cap);
+    if (!b->sc0.pkt) goto nomem;
+#undef B_ALLOC
     for (i = 0; i < 2 * np; i++) {
         b->pics[i].mvs = b->mvpool + (size_t)i * b->nblk;
         b->pics[i].stable = b->stabpool + (size_t)i * b->nblk;
         b->pics[i].prefix = b->prefixpool + (size_t)i * b->prefix_cap;
     }
+    dsv1_recycle_hold(+1);
+    b->holds_recycler = 1;
     *out = b;
     return DSVG_OK;
+nomem:
+    dsv1_log(1, "out of host memory while opening a batch of %d streams x %d frames", nstreams, F);
+    b->enc = NULL;                                      /* the caller still owns encs */
+    dsv1_batch_close(b);
+    return DSVG_ERR_NOMEM;
 }
 
 int dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int nstreams, int frames_per_call)
@@ -189,14 +218,21 @@ int dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int ns
     DSV_ENCODER *encs;
     int s, rc;
     if (!cfg || nstreams < 1) return DSVG_ERR_ARG;
-    encs = (DSV_ENCODER *)calloc((size_t)nstreams, sizeof(DSV_ENCODER));
+    encs = (DSV_ENCODER *)b_calloc((size_t)nstreams, sizeof(DSV_ENCODER));
+    if (!encs) return DSVG_ERR_NOMEM;
     for (s = 0; s < nstreams; s++) {
         encs[s] = *cfg;
         encs[s].ref = NULL; encs[s].stability = NULL; encs[s].stable_blocks = NULL;
         dsv_enc_start(&encs[s]);
     }
     rc = batch_open_on(out, encs, 1, device, nstreams, frames_per_call, 0);
-    if (rc) free(encs);
+    if (rc) {
+        for (s = 0; s < nstreams; s++) {                /* what dsv_enc_start gave every stream */
+            if (encs[s].stability) dsv_free(encs[s].stability);
+            if (encs[s].stable_blocks) dsv_free(encs[s].stable_blocks);
+        }
+        free(encs);
+    }
     return rc;
 }
 
@@ -215,10 +251,15 @@ int dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int f
     enc->ref = NULL; enc->stability = NULL; enc->stable_blocks = NULL;
     dsv_enc_start(enc);
     rc = batch_open_on(out, enc, 1, device, 1, frames_per_call, max_chains);
-    if (rc) free(enc);
+    if (rc) {
+        if (enc->stability) dsv_free(enc->stability);
+        if (enc->stable_blocks) dsv_free(enc->stable_blocks);
+        free(enc);
+    }
     return rc;
 }
 
+DSV_ENCODER *dsv1_batch_encoder(dsv1_batch *b, int stream) { return b && stream >= 0 && stream < b->nstreams ? &b->enc[stream] : NULL; }
 void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum)
 {
     if (b && stream >= 0 && stream < b->nstreams) b->enc[stream].next_fnum = next_fnum;
@@ -235,34 +276,57 @@ static void rc_load(dsvg_rc_state *r, const DSV_ENCODER *e)
     r->rc_high_motion_nudge = e->rc_high_motion_nudge; r->max_q_step = e->max_q_step;
     r->min_quality = e->min_quality; r->max_quality = e->max_quality; r->min_I_frame_quality = e->min_I_frame_quality;
 }
-static void rc_store(DSV_ENCODER *e, const dsvg_rc_state *r)
+/* par: the parameter snapshot r was loaded with (NULL: the encoder's own fields).  quality2quant clamps max_q_step IN PLACE
+ * (dsv_encoder.c:128); with a snapshot the clamp goes back only while the public field still holds the value the snapshot was taken
+ * from -- a replay that runs after the caller has set a new max_q_step must not put the old one back */
+static void rc_store(DSV_ENCODER *e, const dsvg_rc_state *r, const dsvg_rc_state *par)
 {
     e->rc_quant = r->rc_quant; e->bpf_total = r->bpf_total; e->bpf_reset = r->bpf_reset;
     e->bpf_avg = r->bpf_avg; e->total_P_frame_q = r->total_P_frame_q; e->avg_P_frame_q = r->avg_P_frame_q;
     e->last_P_frame_over = r->last_P_frame_over; e->back_into_range = r->back_into_range;
-    e->max_q_step = r->max_q_step;
+    if (!par || e->max_q_step == par->max_q_step) e->max_q_step = r->max_q_step;
 }
-static int pick_quant(DSV_ENCODER *e, int isP, int forced_intra)
+/* the PARAMETER half of the state (what the caller may change between frames): everything from `bitrate` on */
+#define RC_PAR_OFF offsetof(dsvg_rc_state, bitrate)
+static void rc_par_set(dsvg_rc_state *r, const dsvg_rc_state *par)
+{
+    if (par) memcpy((char *)r + RC_PAR_OFF, (const char *)par + RC_PAR_OFF, sizeof(*r) - RC_PAR_OFF);
+}
+static void rc_par_to_enc(DSV_ENCODER *e, const dsvg_rc_state *r)      /* the parameter half back into the public fields (not the frame rate: vidmeta) */
+{
+    e->bitrate = r->bitrate; e->rc_high_motion_nudge = r->rc_high_motion_nudge; e->max_q_step = r->max_q_step;
+    e->min_quality = r->min_quality; e->max_quality = r->max_quality; e->min_I_frame_quality = r->min_I_frame_quality;
+}
+static int rc_par_differs(const dsvg_rc_state *a, const dsvg_rc_state *b)
+{
+    return memcmp((const char *)a + RC_PAR_OFF, (const char *)b + RC_PAR_OFF, sizeof(*a) - RC_PAR_OFF) != 0;
+}
+/* par: the parameters the picture's batch was submitted with (device-resident rate control: the replay must use what the
+ * device used, whatever the caller has done to the public fields since), or NULL: the encoder's fields as they are now */
+static int pick_quant_par(DSV_ENCODER *e, const dsvg_rc_state *par, int isP, int forced_intra)
 {
     if (e->rc_mode != DSV_RATE_CONTROL_CRF) {
         dsvg_rc_state r;
         int fq;
         rc_load(&r, e);
+        rc_par_set(&r, par);
         fq = dsvg_rc_pick(&r, isP, forced_intra);
-        rc_store(e, &r);
+        rc_store(e, &r, par);
         return fq;
     }
     e->rc_quant = (unsigned)e->quality;
     return DSV_MAX_QUALITY - ((DSV_MAX_QUALITY - 5) * e->quality / DSV_MAX_QUALITY);
 }
+static int pick_quant(DSV_ENCODER *e, int isP, int forced_intra) { return pick_quant_par(e, NULL, isP, forced_intra); }
 
-static void rc_after_packet(DSV_ENCODER *e, int isP, unsigned pkt_len)        /* dsv_encoder.c:816-848 */
+static void rc_after_packet(DSV_ENCODER *e, const dsvg_rc_state *par, int isP, unsigned pkt_len)        /* dsv_encoder.c:816-848 */
 {
     dsvg_rc_state r;
     if (e->rc_mode == DSV_RATE_CONTROL_CRF) return;
     rc_load(&r, e);
+    rc_par_set(&r, par);
     dsvg_rc_after(&r, isP, pkt_len);
-    rc_store(e, &r);
+    rc_store(e, &r, par);
 }
 
 /* ---- side information --------------------------------------------------------------------------- */
@@ -397,7 +461,7 @@ static void link_packet(DSV_ENCODER *e, uint8_t *pkt, unsigned len, int eos)   /
 
 /* picture packet = prefix + quantiser + three framed planes (encode_picture :518-536,
  * dsv_encode_plane hzcc.c:449-476); then metadata-first emission and RC statistics (dsv_enc :804-853) */
-static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV_BUF *out, pkt_scratch *sc)
+static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV_BUF *out, pkt_scratch *sc, const dsvg_rc_state *par)
 {
     DSV_ENCODER *e = &b->enc[s];
     bitw w;
@@ -415,10 +479,10 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     if (b->abr_dev && e->rc_mode != DSV_RATE_CONTROL_CRF) {
         /* the device chose this picture's quantiser (k_rc): replay the choice here -- it also advances this stream's host-side
          * state -- and refuse the batch if the two disagree (same code on both sides: include/dsvg_rc.h) */
-        pc->quant = pick_quant(e, pc->isP, pc->forced_intra);
+        pc->quant = pick_quant_par(e, par, pc->isP, pc->forced_intra);
         if (pc->quant != po->rc_quant) {
             dsv1_log(1, "rate control: stream %d picture %u: the device coded with quantiser %d, the host replay says %d", s, (unsigned)pc->fnum, (int)po->rc_quant, pc->quant);
-            return DSVG_ERR_HIP;
+            return DSVG_ERR_RC;
         }
     }
     /* the packet is built in place at the end of the stream buffer: the payloads (the bulk) are copied once, straight
@@ -451,9 +515,9 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     len = bw_bytes(&w);
     if (b->abr_dev && e->rc_mode != DSV_RATE_CONTROL_CRF && len != po->rc_pkt_len) {
         dsv1_log(1, "rate control: stream %d picture %u: packet of %u bytes, the device counted %u", s, (unsigned)pc->fnum, len, (unsigned)po->rc_pkt_len);
-        return DSVG_ERR_HIP;
+        return DSVG_ERR_RC;
     }
-    rc_after_packet(e, pc->isP, len);
+    rc_after_packet(e, par, pc->isP, len);
     link_packet(e, pkt, len, 0);
     out->len += len;
     return DSVG_OK;
@@ -625,7 +689,7 @@ static int code_chains(dsv1_batch *b, pic_t *pics, int nf, int par)
 }
 
 /* packet assembly of one stream of a collected batch (its own staging buffer per thread) */
-typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc, nf, s0; } asm_ctx;
+typedef struct { dsv1_batch *b; pic_t *pics; DSV_BUF *out; int rc, nf, s0; const dsvg_rc_state *par; } asm_ctx;
 static void asm_stream(void *ctx, int s, int tid)
 {
     asm_ctx *c = (asm_ctx *)ctx;
@@ -643,7 +707,7 @@ static void asm_stream(void *ctx, int s, int tid)
     }
     if (dsv1_buf_reserve(&c->out[s], (unsigned)need)) { c->rc = DSVG_ERR_ARG; return; }
     for (t = 0; t < c->nf; t++) {
-        const int rc = assemble(b, s, &c->pics[s * F + t], &b->outs[s * F + t], &c->out[s], &sc);
+        const int rc = assemble(b, s, &c->pics[s * F + t], &b->outs[s * F + t], &c->out[s], &sc, c->par ? &c->par[s] : NULL);
         if (rc) { c->rc = rc; break; }
     }
     free(sc.pkt);
@@ -835,19 +899,27 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                 for (s = 0; s < S; s++) b->out_slots[s] = pics[s * F + t].out_slot;
                 if ((rc = dsvg_fetch_pictures(b->ctx, S, b->out_slots, b->outs))) return rc;
                 for (s = 0; s < S; s++)
-                    if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s], &b->sc0))) return rc;
+                    if ((rc = assemble(b, s, &pics[s * F + t], &b->outs[s], &abr_out[s], &b->sc0, NULL))) return rc;
             }
         }
         if (devrc) {
             if (!b->rc_seeded) {                                /* the device takes over the streams' rate-control state */
-                dsvg_rc_state *st = (dsvg_rc_state *)calloc((size_t)S, sizeof(dsvg_rc_state));
-                if (!st) return DSVG_ERR_ARG;
-                for (s = 0; s < S; s++) rc_load(&st[s], &b->enc[s]);
-                rc = dsvg_rc_upload(b->ctx, 0, S, st);
-                free(st);
-                if (rc) return rc;
+                for (s = 0; s < S; s++) rc_load(&b->rc_dev[s], &b->enc[s]);
+                if ((rc = dsvg_rc_upload(b->ctx, 0, S, b->rc_dev))) return rc;
                 b->rc_seeded = 1;
+            } else {
+                /* the caller may have changed a stream's parameters since (bitrate, quality bounds, max_q_step, the nudge: the reference reads
+                 * them per frame, dsv_encoder.c:84-165): the pictures of THIS batch and later ones are coded with the new values -- the device's
+                 * parameter fields are rewritten behind the batches already enqueued, the state fields stay the device's (advisor round 4) */
+                int s0 = -1, s1 = -1;
+                for (s = 0; s < S; s++) {
+                    dsvg_rc_state now;
+                    rc_load(&now, &b->enc[s]);
+                    if (rc_par_differs(&now, &b->rc_dev[s])) { rc_par_set(&b->rc_dev[s], &now); if (s0 < 0) s0 = s; s1 = s; }
+                }
+                if (s0 >= 0 && (rc = dsvg_rc_set_params(b->ctx, s0, s1 - s0 + 1, b->rc_dev + s0))) return rc;
             }
+            memcpy(b->rc_par + (size_t)par * S, b->rc_dev, (size_t)S * sizeof(dsvg_rc_state));     /* what this batch's replay uses */
             if ((rc = dsvg_code_batch_rc(b->ctx, nf, S, b->jobs, b->rcjobs))) return rc;
         } else
         if (!serial && !b->chains && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
@@ -905,6 +977,7 @@ int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
             /* the copy comes in pieces of whole streams; the packets of a piece are assembled while the next is on the link */
             asm_ctx ac;
             ac.b = b; ac.pics = pics; ac.out = out; ac.rc = DSVG_OK; ac.nf = nf; ac.s0 = 0;
+            ac.par = b->abr_dev && b->rc_seeded ? b->rc_par + (size_t)par * S : NULL;
             if ((rc = dsvg_fetch_pictures_cb(b->ctx, S * nf, b->out_slots, b->outs, S >= 16 ? 4 : 1, nf, asm_piece, &ac))) return rc;
             if (ac.rc) return ac.rc;
         }
@@ -1026,7 +1099,8 @@ void dsv_enc_force_metadata(DSV_ENCODER *enc) { enc->force_metadata = 1; }
  * the reference does: metadata + picture, dsv_encoder.c:804-810).  A caller gets 0 buffers while the lookahead fills --
  * dsv_main.c:521-531 loops over whatever count comes back -- and dsv_enc_end_of_stream returns the rest of the backlog in
  * front of the EOS packet, in one buffer: the bytes that reach the file are those of the frame-synchronous encoder.  Changes
- * the caller makes to the encoder's public fields (quality, force_metadata) take effect up to F frames late.  ABR needs every
+ * the caller makes to the encoder's public fields (quality, rate-control parameters, force_metadata) take effect with the frame
+ * of the next call, as in the reference: the frames gathered so far are submitted as a short batch first.  ABR needs every
  * packet's size before the next quantiser: its pictures are coded one after the other, but 32 frames (DSV1_ENC_LOOKAHEAD) are
  * gathered and ANALYSED together first, and the group's packets come out of the call that completes it
  * (DSV1_ENC_PIPELINE=0: one frame per call, CRF and ABR).
@@ -1040,6 +1114,11 @@ typedef struct {
     size_t fb;
     DSV_BUF backlog;            /* finished packets not handed out yet */
     unsigned off;               /* first byte of the backlog not handed out */
+    /* what the frames gathered so far will be coded with: a change of the caller's (rate-control parameters, quality, a forced
+     * metadata packet) takes effect with the FRAME it precedes, as in the reference -- the frames gathered before it go to the
+     * device as a short batch first */
+    dsvg_rc_state par_cur;
+    int quality_cur, fm_seen;
 } enc_sess;
 
 static void sess_free(enc_sess *ss)
@@ -1110,22 +1189,25 @@ static int sess_pop(enc_sess *ss, DSV_BUF *bufs, int max)
     return n;
 }
 
-/* everything the session still holds -- frames waiting for a full batch, batches in flight -- coded and collected into the
- * backlog (end of stream, or the caller's flush calls dsv_enc(enc, NULL, bufs)) */
-static void sess_flush(enc_sess *ss)
+/* the way out of dsv_enc: what the caller finds in force_metadata now is what a later call compares with */
+static int sess_ret(DSV_ENCODER *enc, enc_sess *ss, DSV_BUF *bufs)
 {
-    if (ss && ss->pipelined && !ss->failed) {
-        /* flush: the frames still waiting for a full batch, then everything in flight, oldest first */
+    ss->fm_seen = enc->force_metadata;
+    return sess_pop(ss, bufs, 2);
+}
+
+/* the frames gathered so far go to the device as a short batch (end of stream, a flush call, or a change of the caller's to
+ * the encoder's parameters in mid-group); the batches in flight stay in flight */
+static void sess_push_partial(enc_sess *ss)
+{
+    if (ss && ss->pipelined && !ss->failed && ss->fill > 0) {
         int rc = DSVG_OK;
-        if (ss->fill > 0) {
-            if (ss->inflight == 2) rc = sess_collect(ss);
-            if (!rc) rc = sess_submit(ss);
-        }
-        while (!rc && ss->inflight > 0) rc = sess_collect(ss);
-        if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; }
+        if (ss->inflight == 2) rc = sess_collect(ss);
+        if (!rc) rc = sess_submit(ss);
+        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; }
     }
     if (ss && !ss->pipelined && !ss->failed && ss->fill > 0) {
-        /* ABR: the frames gathered since the last complete group */
+        /* ABR on the frame-serial host path: the frames gathered since the last complete group */
         DSV_BUF acc = {NULL, 0};
         int rc;
         if (ss->gathered && ss->dev) {
@@ -1136,7 +1218,19 @@ static void sess_flush(enc_sess *ss)
         if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
         dsv_buf_free(&acc);
         ss->fill = 0;
-        if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; }
+        if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); ss->failed = 1; }
+    }
+}
+
+/* everything the session still holds -- frames waiting for a full batch, batches in flight -- coded and collected into the
+ * backlog (end of stream, or the caller's flush calls dsv_enc(enc, NULL, bufs)) */
+static void sess_flush(enc_sess *ss)
+{
+    sess_push_partial(ss);
+    if (ss && ss->pipelined && !ss->failed) {
+        int rc = DSVG_OK;
+        while (!rc && ss->inflight > 0) rc = sess_collect(ss);          /* oldest first */
+        if (rc) { dsv1_log(1, "GPU encode failed at end of stream: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; }
     }
 }
 
@@ -1268,7 +1362,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
          * still holds, then hand out the packets owed like any other call -- at most two per call (metadata + picture), one
          * packet per DSV_BUF; 0 = drained.  After that dsv_enc_end_of_stream returns exactly one EOS packet. */
         sess_flush(ss);
-        return sess_pop(ss, bufs, 2);
+        return sess_ret(enc, ss, bufs);
     }
     if (ss->failed || ss->fill >= ss->F) {
         /* an earlier device error ended the session (never copy past the pinned batch) */
@@ -1276,6 +1370,27 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         dsv1_log(1, "GPU session failed earlier: frame dropped");
         dsv_frame_ref_dec(frame);
         return 0;
+    }
+    if (ss->pipelined || ss->gathered) {
+        /* the reference reads the encoder's public fields when it codes a frame (dsv_encoder.c:84-165,794-803): what the caller changed
+         * since the last call applies from THIS frame on -- the frames gathered before it are submitted as a short batch first */
+        dsvg_rc_state now;
+        rc_load(&now, enc);
+        if (ss->fill > 0 && (rc_par_differs(&now, &ss->par_cur) || enc->quality != ss->quality_cur || (enc->force_metadata && !ss->fm_seen))) {
+            /* the gathered frames are coded with what was in force when they arrived: the old values go back into the public fields for
+             * the duration of the short batch's submit (which reads them there), then the caller's new ones return */
+            const int newq = enc->quality, forced = enc->force_metadata && !ss->fm_seen;
+            rc_par_to_enc(enc, &ss->par_cur);
+            enc->quality = ss->quality_cur;
+            if (forced) enc->force_metadata = 0;
+            sess_push_partial(ss);
+            rc_par_to_enc(enc, &now);
+            enc->quality = newq;
+            if (forced) enc->force_metadata = 1;
+            if (ss->failed) { dsv_frame_ref_dec(frame); return sess_ret(enc, ss, bufs); }
+        }
+        rc_load(&ss->par_cur, enc);
+        ss->quality_cur = enc->quality;
     }
     /* the frame is copied now: the caller may reuse its pixel memory as soon as this returns */
     {
@@ -1292,12 +1407,12 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         rc = DSVG_OK;
         if (!ss->dev) rc = dsvg_ingest_open(ss->b->ctx, ss->fb * (size_t)ss->F, &ss->dev);
         if (!rc) rc = dsvg_ingest_part(ss->b->ctx, ss->dev, (size_t)ss->fill * ss->fb, ss->pin[ss->cur] + (size_t)ss->fill * ss->fb, ss->fb);
-        if (rc) { dsv1_log(1, "frame upload failed: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; return sess_pop(ss, bufs, 2); }
+        if (rc) { dsv1_log(1, "frame upload failed: %s", dsvg_last_error()); ss->failed = 1; ss->fill = 0; return sess_ret(enc, ss, bufs); }
     }
     ss->fill++;
     if (!ss->pipelined) {
         DSV_BUF acc = {NULL, 0};
-        if (ss->fill < ss->F) return sess_pop(ss, bufs, 2);     /* (ABR: the group is not complete yet) */
+        if (ss->fill < ss->F) return sess_ret(enc, ss, bufs);     /* (ABR: the group is not complete yet) */
         ss->fill = 0;
         if (ss->gathered) {                                     /* the group's frames are on the device already (or on their way) */
             rc = batch_submit_impl(ss->b, ss->dev, 1, &acc, ss->F, 0);
@@ -1307,7 +1422,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
         if (!rc && acc.len) rc = dsv1_buf_append(&ss->backlog, acc.data, acc.len) ? DSVG_ERR_ARG : DSVG_OK;
         dsv_buf_free(&acc);
         if (rc) { dsv1_log(1, "GPU encode failed: %s", dsvg_last_error()); ss->failed = 1; return 0; }
-        return sess_pop(ss, bufs, 2);
+        return sess_ret(enc, ss, bufs);
     }
     if (ss->fill == ss->F) {
         /* the pinned half about to be refilled next was used by the batch before last: it is collected first */
@@ -1319,8 +1434,8 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
             /* the session is over: no later call may copy into the batch or touch the device again */
             dsv1_log(1, "GPU encode failed: %s", dsvg_last_error());
             ss->failed = 1; ss->fill = 0;
-            return sess_pop(ss, bufs, 2);
+            return sess_ret(enc, ss, bufs);
         }
     }
-    return sess_pop(ss, bufs, 2);
+    return sess_ret(enc, ss, bufs);
 }

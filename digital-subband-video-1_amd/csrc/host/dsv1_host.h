@@ -81,6 +81,7 @@ int  dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n);
 int  dsv1_buf_reserve(DSV_BUF *b, unsigned n);
 /* dsv_alloc without the zeroing (a buffer the library fills itself); freed with dsv_free like any other */
 void *dsv1_alloc_raw(int size);
+int dsv1_recycle_hold(int delta);       /* dsv1_util.c: +1 a batch opens, -1 it closes (the last one out releases the parked blocks) */
 void dsv1_log(int level, const char *fmt, ...);
 extern int dsv1_device;
 /* parallel loop over S independent items on a persistent worker pool: fn(ctx, s, worker) for every s; DSV1_HOST_THREADS workers (default min(12,

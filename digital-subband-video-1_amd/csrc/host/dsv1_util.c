@@ -40,13 +40,22 @@ void dsv1_log(int level, const char *fmt, ...)
  * memory back, same box).  Blocks of DSV1_RECYCLE_MIN bytes and more keep their pages: dsv_free parks them by size class (bounded count
  * and bytes), dsv_alloc takes a parked block of at least the size asked for and at most twice that, and zeroes only what was
  * asked for -- or nothing, for the buffers the library fills itself (dsv1_alloc_raw).
+ * Blocks are parked only while an encoder batch / session is open (dsv1_recycle_hold, counted by dsv1_batch_open / _close): when the
+ * last one closes the parked blocks go back to the system, and a buffer the caller frees after that is freed for good -- a drop-in
+ * library must not sit on a gigabyte of a process that has finished encoding (advisor round 4).  DSV1_RECYCLE_MAX_MB bounds the
+ * parked bytes (default 1024).
  * Header (16 bytes in front of the data, dsv.c:41-96 has the size there): int32 size as requested, uint32 capacity of the block. */
 #define DSV1_RECYCLE_MIN (256u << 10)
 #define DSV1_RECYCLE_GRAIN_LOG 18                 /* capacities are multiples of 256 KB: class = capacity / 256 KB - 1 */
 #define DSV1_RECYCLE_CLASSES 256                  /* ... up to 64 MB; larger blocks go straight back to the system */
 #define DSV1_RECYCLE_DEPTH 96                     /* parked blocks per class */
-#define DSV1_RECYCLE_BYTES ((size_t)1 << 30)
-static struct { pthread_mutex_t mu; size_t bytes; int n[DSV1_RECYCLE_CLASSES]; uint8_t *p[DSV1_RECYCLE_CLASSES][DSV1_RECYCLE_DEPTH]; } g_park = {PTHREAD_MUTEX_INITIALIZER, 0, {0}, {{NULL}}};
+static struct { pthread_mutex_t mu; size_t bytes; int users; int n[DSV1_RECYCLE_CLASSES]; uint8_t *p[DSV1_RECYCLE_CLASSES][DSV1_RECYCLE_DEPTH]; } g_park = {PTHREAD_MUTEX_INITIALIZER, 0, 0, {0}, {{NULL}}};
+static size_t park_max_bytes(void)
+{
+    static size_t v = 0;
+    if (!v) { const char *e = getenv("DSV1_RECYCLE_MAX_MB"); long mb = e ? atol(e) : 1024; if (mb < 1) mb = 1; if (mb > 65536) mb = 65536; v = (size_t)mb << 20; }
+    return v;
+}
 
 static int park_on(void)                      /* DSV1_NO_RECYCLE=1: plain calloc / free (A/B switch, and for callers that want every byte back at once) */
 {
@@ -74,7 +83,7 @@ static int park_put(uint8_t *p)
     int ok = 0;
     if (k < 0 || k >= DSV1_RECYCLE_CLASSES || (cap & (((size_t)1 << DSV1_RECYCLE_GRAIN_LOG) - 1))) return 0;
     pthread_mutex_lock(&g_park.mu);
-    if (g_park.n[k] < DSV1_RECYCLE_DEPTH && g_park.bytes + cap <= DSV1_RECYCLE_BYTES) { g_park.p[k][g_park.n[k]++] = p; g_park.bytes += cap; ok = 1; }
+    if (g_park.users > 0 && g_park.n[k] < DSV1_RECYCLE_DEPTH && g_park.bytes + cap <= park_max_bytes()) { g_park.p[k][g_park.n[k]++] = p; g_park.bytes += cap; ok = 1; }
     pthread_mutex_unlock(&g_park.mu);
     return ok;
 }
@@ -113,15 +122,40 @@ void dsv_free(void *ptr)
     if (*(uint32_t *)(p + 4) >= DSV1_RECYCLE_MIN && park_on() && park_put(p)) return;
     free(p);
 }
-/* give the parked blocks back (tests; a caller that wants its memory) */
-void dsv1_release_parked(void)
+/* give the parked blocks back (a caller that wants its memory; the last batch / session closing) */
+static void release_parked_locked(void)
 {
     int k;
-    pthread_mutex_lock(&g_park.mu);
     for (k = 0; k < DSV1_RECYCLE_CLASSES; k++)
         while (g_park.n[k] > 0) free(g_park.p[k][--g_park.n[k]]);
     g_park.bytes = 0;
+}
+void dsv1_release_parked(void)
+{
+    pthread_mutex_lock(&g_park.mu);
+    release_parked_locked();
     pthread_mutex_unlock(&g_park.mu);
+}
+/* +1: an encoder batch / session opens (blocks freed from now on are parked); -1: it closes -- the last one out releases the
+ * parked blocks.  Returns the number of holders left. */
+int dsv1_recycle_hold(int delta)
+{
+    int n;
+    pthread_mutex_lock(&g_park.mu);
+    g_park.users += delta;
+    if (g_park.users < 0) g_park.users = 0;
+    if (g_park.users == 0) release_parked_locked();
+    n = g_park.users;
+    pthread_mutex_unlock(&g_park.mu);
+    return n;
+}
+size_t dsv1_parked_bytes(void)
+{
+    size_t b;
+    pthread_mutex_lock(&g_park.mu);
+    b = g_park.bytes;
+    pthread_mutex_unlock(&g_park.mu);
+    return b;
 }
 
 void dsv_memory_report(void)

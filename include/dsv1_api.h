@@ -16,6 +16,7 @@
 
 #include <limits.h>
 #include <stdint.h>
+#include <stddef.h>
 #include <stdio.h>
 #include "dsvg.h"
 
@@ -115,8 +116,10 @@ void dsv_enc_start(DSV_ENCODER *enc);
  * per call (metadata + picture, as the reference), always whole packets in stream order; dsv_enc_end_of_stream returns every
  * packet still owed followed by the EOS packet in bufs[0] (ONE buffer holding several packets: a caller that needs one
  * packet per DSV_BUF splits it on the packets' next-link words, or sets DSV1_ENC_PIPELINE=0 for the frame-synchronous
- * behaviour: one picture per call, same bytes).  Changes to the encoder's public fields between calls (quality,
- * dsv_enc_force_metadata) act on the frames not yet submitted, i.e. up to a lookahead late.  dsv_enc_free without
+ * behaviour: one picture per call, same bytes).  Changes to the encoder's public fields between calls (quality, bitrate,
+ * min_ / max_quality, min_I_frame_quality, max_q_step, rc_high_motion_nudge, dsv_enc_force_metadata) apply from the frame of
+ * the NEXT call on, exactly as in the reference (it reads them when it codes a frame, dsv_encoder.c:84-165,794-803): the frames
+ * gathered before the change are sent to the device as a short batch first (round 5).  dsv_enc_free without
  * dsv_enc_end_of_stream drops the frames still buffered (and logs it).  ABR streams (their pictures are coded one after the
  * other: every packet's size feeds the next quantiser) gather 32 frames (DSV1_ENC_LOOKAHEAD) for a common analysis pass: the same
  * contract with a shorter lookahead, the same bytes as the frame-synchronous encoder.
@@ -142,9 +145,15 @@ void dsv_frame_ref_dec(DSV_FRAME *frame);
 void dsv_mk_buf(DSV_BUF *buf, int size);
 void dsv_buf_free(DSV_BUF *buf);
 void *dsv_alloc(int size);
-/* Extension: dsv_free keeps blocks of 256 KB .. 64 MB (a batch's packet buffers) for the next dsv_alloc instead of returning their pages
- * to the system -- at most 1 GiB (DSV1_NO_RECYCLE=1: never); this gives them back. */
+/* Extension: while an encoder batch / session is open, dsv_free keeps blocks of 256 KB .. 64 MB (a batch's packet buffers) for the next
+ * dsv_alloc instead of returning their pages to the system -- at most DSV1_RECYCLE_MAX_MB (default 1024) megabytes, DSV1_NO_RECYCLE=1:
+ * never.  The parked blocks go back to the system when the last batch / session closes (and a block freed after that is freed for good);
+ * dsv1_release_parked gives them back at once, dsv1_parked_bytes says how much is parked.  dsv1_recycle_hold(+1 / -1) is the count
+ * behind that (a caller that wants parking without an open batch may hold it itself). */
 void dsv1_release_parked(void);
+size_t dsv1_parked_bytes(void);
+int dsv1_recycle_hold(int delta);
+void dsv1_debug_fail_alloc_at(int n);        /* tests: the n-th host allocation of the next dsv1_batch_open / dsv1_stream_open fails (0 = off) */
 void dsv_free(void *ptr);
 void dsv_memory_report(void);
 void dsv_set_log_level(int level);
@@ -172,6 +181,10 @@ int  dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int n
 int  dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int frames_per_call, int max_chains);
 void dsv1_batch_close(dsv1_batch *b);
 void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
+/* stream s's encoder struct (the batch owns it).  Its public parameter fields -- quality, bitrate, min_ / max_quality,
+ * min_I_frame_quality, max_q_step, rc_high_motion_nudge; dsv_enc_force_metadata -- may be changed between submits, as a caller of
+ * the reference changes them between dsv_enc calls; geometry, GOP structure and rate-control mode may not. */
+DSV_ENCODER *dsv1_batch_encoder(dsv1_batch *b, int stream);
 /* Encode frames_per_call frames of every stream.  yuv: [stream][frame] tightly packed planar frames,
  * host (yuv_on_device = 0) or device memory (1).  The call has finished with the clip when it returns (a device clip's chroma
  * planes are read in place by the coding kernels, dsvg_load_frames_map_ex, only luma is copied -- and the call returns after
@@ -185,9 +198,11 @@ int  dsv1_batch_encode(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BU
  * second HIP stream, and the host packet assembly overlaps both.  ABR streams pipeline the same way since round 4: every
  * quantiser still follows from the size of the packet before, but that chain runs on the device (k_rc, include/dsvg_rc.h) and
  * the streams' rate-control state stays there from call to call; the session layer replays it on the host when it assembles the
- * packets (the encoder structs stay in step) and fails the batch if the two ever disagree.  The rate-control PARAMETERS
- * (bitrate, quality bounds, max_q_step, rc_high_motion_nudge, frame rate) are taken from the configuration when the first
- * batch is submitted.  DSV1_ABR_SERIAL=1: rounds 1-3's path -- submit codes frame by frame, assembles into out, and collect
+ * packets (the encoder structs stay in step) and fails the batch (DSVG_ERR_RC) if the two ever disagree.  The rate-control
+ * PARAMETERS (bitrate, quality bounds, max_q_step, rc_high_motion_nudge) are read from every stream's encoder struct
+ * (dsv1_batch_encoder) at each submit: a change applies to every picture of the batches submitted after it -- the reference
+ * reads them per frame (dsv_encoder.c:84-165), a batch is the unit here; batches already in flight keep what they were
+ * submitted with, and so does their host-side replay.  DSV1_ABR_SERIAL=1: rounds 1-3's path -- submit codes frame by frame, assembles into out, and collect
  * only releases the slot. */
 /* yuv_on_device for dsv1_batch_submit: 0 = host memory, 1 = device memory, copied whole -- submit has finished with the clip
  * when it returns; DSV1_CLIP_HELD = device memory that the caller keeps UNCHANGED until dsv1_batch_collect of this batch has

@@ -36,6 +36,8 @@ extern "C" {
 #define DSVG_ERR_UNSUPPORTED (-3)   /* geometry outside what the kernels handle */
 #define DSVG_ERR_OVERFLOW    (-4)   /* packed plane exceeded its output bound */
 #define DSVG_ERR_NODEVICE    (-5)   /* no usable MI355X/HIP device */
+#define DSVG_ERR_NOMEM       (-7)   /* a host allocation failed (the object being built is unwound) */
+#define DSVG_ERR_RC          (-6)   /* device-resident rate control: the host's replay of a picture disagrees with what the device chose */
 
 #define DSVG_FRAME_BORDER 64        /* DSV_FRAME_BORDER dsv_internal.h:37 */
 #define DSVG_MAX_PYRAMID  5         /* DSV_MAX_PYRAMID_LEVELS dsv_encoder.h:35 */
@@ -234,6 +236,10 @@ struct dsvg_rc_state;
 int dsvg_code_batch_rc(dsvg_ctx *ctx, int nsteps, int njobs, const dsvg_pic_job *jobs, const dsvg_rc_job *rc);
 int dsvg_rc_upload(dsvg_ctx *ctx, int first_slot, int n, const struct dsvg_rc_state *states);
 int dsvg_rc_download(dsvg_ctx *ctx, int first_slot, int n, struct dsvg_rc_state *states);
+/* the PARAMETER fields of the streams' state only (bitrate, frame rate, nudge, max_q_step, quality bounds: everything from
+ * dsvg_rc_state.bitrate on) -- what a caller may change between calls (the reference reads them per frame, dsv_encoder.c:84-165);
+ * ordered on the coding stream: pictures enqueued before keep the old parameters, pictures enqueued after see the new ones */
+int dsvg_rc_set_params(dsvg_ctx *ctx, int first_slot, int n, const struct dsvg_rc_state *states);
 int dsvg_fetch_pictures(dsvg_ctx *ctx, int n, const int *out_slots, dsvg_pic_out *outs);
 /* The same with the device-to-host copy cut into `nchunks` pieces that end on multiples of `align` pictures: as soon as a
  * piece has arrived, cb(arg, first, count) is called for its pictures (outs[first .. first+count) are valid then) while the
@@ -283,6 +289,11 @@ long dsvg_ctx_decoder_redone(const dsvg_ctx *ctx);
  * dsvg_prof_get returns the summed event time (ms), launch count and the ALGORITHMIC bytes those
  * launches moved (compulsory traffic: each input read once, each output written once; the per-sample
  * figures are listed in DESIGN.md) since the last reset. */
+/* two marks on the first coding stream and the GPU-side time between them (HIP events): dsvg_ctx_mark(ctx, 0) when a timed region
+ * starts, dsvg_ctx_mark(ctx, 1) behind its last enqueued coding work; dsvg_ctx_mark_ms after a sync.  bench.py prints it beside its
+ * host clock so that the headline can be corroborated from the device side. */
+int dsvg_ctx_mark(dsvg_ctx *ctx, int which);
+int dsvg_ctx_mark_ms(dsvg_ctx *ctx, float *ms);
 int dsvg_prof_kernels(void);
 const char *dsvg_prof_kernel_name(int kid);
 int dsvg_prof_enable(dsvg_ctx *ctx, unsigned long long kernel_mask);

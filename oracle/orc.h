@@ -156,6 +156,9 @@ void orc_cfg_from_cli(orc_enc_cfg *cfg, int w, int h, int subsamp, int qp_pct, i
 
 orc_encoder *orc_enc_open(const orc_enc_cfg *cfg);
 void orc_enc_set_next_fnum(orc_encoder *e, unsigned fnum);
+/* a caller's change of the public fields between two frames (quality, bitrate, quality bounds, max_q_step, nudge) / dsv_enc_force_metadata */
+void orc_enc_set_params(orc_encoder *e, const orc_enc_cfg *cfg);
+void orc_enc_force_metadata(orc_encoder *e);
 /* encode one planar frame; appends 1 or 2 packets to *out (realloc'd), returns bytes appended.
  * if recon != NULL receives the encoder's reconstruction (planar, tightly packed) */
 size_t orc_enc_frame(orc_encoder *e, const uint8_t *yuv, uint8_t **out, size_t *outlen, size_t *outcap,

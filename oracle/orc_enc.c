@@ -103,6 +103,21 @@ orc_encoder *orc_enc_open(const orc_enc_cfg *cfg)
 
 void orc_enc_set_next_fnum(orc_encoder *e, unsigned fnum) { e->next_fnum = fnum; }
 
+/* what a library caller may do between two dsv_enc calls: rewrite the encoder's public fields (dsv_encoder.h:58-87).  The
+ * reference reads them when it codes the next frame (quality2quant dsv_encoder.c:84-165, the GOP test :794-803), so the
+ * change applies from that frame on.  Geometry and GOP structure stay what the encoder was opened with. */
+void orc_enc_set_params(orc_encoder *e, const orc_enc_cfg *cfg)
+{
+    e->c.quality = cfg->quality;
+    e->c.bitrate = cfg->bitrate;
+    e->c.rc_high_motion_nudge = cfg->rc_high_motion_nudge;
+    e->c.max_q_step = cfg->max_q_step;
+    e->c.min_quality = cfg->min_quality;
+    e->c.max_quality = cfg->max_quality;
+    e->c.min_I_frame_quality = cfg->min_I_frame_quality;
+}
+void orc_enc_force_metadata(orc_encoder *e) { e->force_meta = 1; }       /* dsv_enc_force_metadata dsv_encoder.c:760-764 */
+
 static void free_pic(pic_state *p)
 {
     orc_frame_free(p->padded);

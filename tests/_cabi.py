@@ -239,6 +239,8 @@ def load_orc():
         L.orc_enc_eos.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
         L.orc_enc_close.argtypes = [C.c_void_p]
         L.orc_enc_set_next_fnum.argtypes = [C.c_void_p, C.c_uint]
+        L.orc_enc_set_params.argtypes = [C.c_void_p, C.POINTER(EncCfg)]
+        L.orc_enc_force_metadata.argtypes = [C.c_void_p]
         L.orc_enc_last_mvs.restype = C.POINTER(MV)
         L.orc_enc_last_mvs.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
         L.orc_enc_last_stable.restype = C.POINTER(C.c_uint8)
@@ -322,7 +324,12 @@ def orc_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1, kbps=0, scd=1, ipct=50, pyr
     return cfg
 
 
-def orc_encode(clip, cfg, want_recon=False, start_fnum=0, eos=True):
+# a caller's changes of the encoder's public fields between two dsv_enc calls: {frame index: {field: value | "force_metadata": True}}
+# (the same table drives the oracle, the reference library and the product: orc_encode, drive_dsv_enc)
+PARAM_FIELDS = ("quality", "bitrate", "rc_high_motion_nudge", "max_q_step", "min_quality", "max_quality", "min_I_frame_quality")
+
+
+def orc_encode(clip, cfg, want_recon=False, start_fnum=0, eos=True, changes=None):
     """encode a clip with the oracle session layer; returns (stream bytes, [recon frames])"""
     L = load_orc()
     e = L.orc_enc_open(C.byref(cfg))
@@ -331,7 +338,17 @@ def orc_encode(clip, cfg, want_recon=False, start_fnum=0, eos=True):
     n = C.c_size_t(0)
     cap = C.c_size_t(0)
     recs = []
+    cur = EncCfg.from_buffer_copy(cfg)
     for t in range(clip.shape[0]):
+        ch = (changes or {}).get(t)
+        if ch:
+            for k, v in ch.items():
+                if k != "force_metadata":
+                    assert k in PARAM_FIELDS, k
+                    setattr(cur, k, v)
+            L.orc_enc_set_params(e, C.byref(cur))
+            if ch.get("force_metadata"):
+                L.orc_enc_force_metadata(e)
         rec = np.empty(clip.shape[1], dtype=np.uint8) if want_recon else None
         L.orc_enc_frame(e, clip[t].ctypes.data, C.byref(out), C.byref(n), C.byref(cap),
                         rec.ctypes.data if want_recon else None)
@@ -395,3 +412,49 @@ def ref_cli_decode(stream, tmpdir):
 
 
 FMT_CLI = {SUBSAMP_444: 0, SUBSAMP_422: 1, SUBSAMP_420: 2, SUBSAMP_411: 3}
+
+
+def drive_dsv_enc(L, enc, clip, w, h, fmt, changes=None, flush_calls=False):
+    """the reference's frame-at-a-time API (dsv_encoder.h:112-121) on library L (the product or oracle/_ref's libdsv1ref.so: same
+    struct layout) driven the way dsv_main.c:506-537 does; `changes` rewrites the encoder's public fields between calls.
+    Returns (stream bytes, buffers returned per call)."""
+    L.dsv_load_planar_frame.restype = C.c_void_p
+    L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    L.dsv_enc.restype = C.c_int
+    L.dsv_enc_start(C.byref(enc))
+    out = b""
+    counts = []
+    bufs = (Buf * 4)()
+    scratch = np.empty_like(clip[0])
+
+    def take(nb):
+        nonlocal out
+        for i in range(nb):
+            out += C.string_at(bufs[i].data, bufs[i].len)
+            L.dsv_buf_free(C.byref(bufs[i]))
+    for t in range(clip.shape[0]):
+        ch = (changes or {}).get(t)
+        if ch:
+            for k, v in ch.items():
+                if k == "force_metadata":
+                    L.dsv_enc_force_metadata(C.byref(enc))
+                else:
+                    assert k in PARAM_FIELDS, k
+                    setattr(enc, k, v)
+        scratch[...] = clip[t]                           # the caller reuses ONE picture buffer (dsv_main.c:506-520)
+        frame = L.dsv_load_planar_frame(fmt, scratch.ctypes.data, w, h)
+        nb = L.dsv_enc(C.byref(enc), frame, bufs) & 3
+        counts.append(nb)
+        take(nb)
+        scratch[...] = 0xA5                              # ... and overwrites it right after the call
+    if flush_calls:
+        while True:
+            nb = L.dsv_enc(C.byref(enc), None, bufs) & 3
+            if not nb:
+                break
+            take(nb)
+    L.dsv_enc_end_of_stream(C.byref(enc), bufs)
+    take(1)
+    L.dsv_enc_free(C.byref(enc))
+    return out, counts

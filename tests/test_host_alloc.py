@@ -12,12 +12,22 @@ def _lib():
     L.dsv_alloc.argtypes = [C.c_int]
     L.dsv_free.argtypes = [C.c_void_p]
     L.dsv1_release_parked.restype = None
+    L.dsv1_parked_bytes.restype = C.c_size_t
+    L.dsv1_recycle_hold.argtypes = [C.c_int]
     return L
 
 
 def test_recycled_blocks_come_back_zeroed_and_sized():
     L = _lib()
     L.dsv1_release_parked()
+    L.dsv1_recycle_hold(1)                     # (what an open batch does)
+    try:
+        _recycled_blocks(L)
+    finally:
+        L.dsv1_recycle_hold(-1)
+
+
+def _recycled_blocks(L):
     n = 3 << 20
     p = L.dsv_alloc(n)
     assert p
@@ -48,12 +58,36 @@ def test_recycled_blocks_come_back_zeroed_and_sized():
 def test_many_blocks_stay_bounded():
     L = _lib()
     L.dsv1_release_parked()
-    ps = [L.dsv_alloc(300 << 10) for _ in range(1200)]       # more than the 1024 slots
-    assert all(ps)
-    for p in ps:
-        L.dsv_free(p)
-    qs = [L.dsv_alloc(300 << 10) for _ in range(1200)]
-    assert all(qs) and len(set(qs)) == 1200
-    for q in qs:
-        L.dsv_free(q)
+    L.dsv1_recycle_hold(1)
+    try:
+        ps = [L.dsv_alloc(300 << 10) for _ in range(1200)]       # far more than the 96 blocks a size class parks
+        assert all(ps)
+        for p in ps:
+            L.dsv_free(p)
+        assert 0 < L.dsv1_parked_bytes() <= 96 * (512 << 10)
+        qs = [L.dsv_alloc(300 << 10) for _ in range(1200)]
+        assert all(qs) and len(set(qs)) == 1200
+        for q in qs:
+            L.dsv_free(q)
+    finally:
+        L.dsv1_recycle_hold(-1)
+    assert L.dsv1_parked_bytes() == 0
+
+
+def test_nothing_stays_parked_without_an_open_batch():
+    """a drop-in library must not keep a finished encoder's memory (advisor round 4): blocks are parked only while a batch /
+    session holds the recycler, and the last holder's release gives everything back"""
+    L = _lib()
     L.dsv1_release_parked()
+    p = L.dsv_alloc(3 << 20)
+    L.dsv_free(p)
+    assert L.dsv1_parked_bytes() == 0          # nobody holds: freed for good
+    assert L.dsv1_recycle_hold(1) == 1
+    assert L.dsv1_recycle_hold(1) == 2
+    p = L.dsv_alloc(3 << 20)
+    L.dsv_free(p)
+    assert L.dsv1_parked_bytes() >= 3 << 20
+    assert L.dsv1_recycle_hold(-1) == 1
+    assert L.dsv1_parked_bytes() >= 3 << 20    # one holder left
+    assert L.dsv1_recycle_hold(-1) == 0
+    assert L.dsv1_parked_bytes() == 0

@@ -25,9 +25,9 @@ d = b.upload(batch_in)
 b.encode(d, on_device=True)
 t0 = time.perf_counter()
 if rc == 1 or os.environ.get('DSV1_ABR_SERIAL', '0') in ('', '0'):      # ABR pipelines too since round 4 (rate control on the device)
-    b.submit(d, on_device=True)
+    b.submit(d, on_device=True, held=True)
     for _ in range(steps):
-        b.submit(d, on_device=True); outs = b.collect(copy=False)
+        b.submit(d, on_device=True, held=True); outs = b.collect(copy=False)
     b.collect(copy=False)
     n = steps + 1
 else:

@@ -17,11 +17,11 @@ cfg = pkg.make_encoder_cfg(W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1)
 b = pkg.Batch(cfg, gops, GOP, device=0)
 d = b.upload(batch_in)
 b.encode(d, on_device=True); b.encode(d, on_device=True)
-b.submit(d, on_device=True); b.sync()
+b.submit(d, on_device=True, held=True); b.sync()
 ts, tc = [], []
 t0 = time.perf_counter(); c0 = time.process_time()
 for _ in range(8):
-    a = time.perf_counter(); b.submit(d, on_device=True); c = time.perf_counter(); b.collect(); e = time.perf_counter()
+    a = time.perf_counter(); b.submit(d, on_device=True, held=True); c = time.perf_counter(); b.collect(); e = time.perf_counter()
     ts.append(c - a); tc.append(e - c)
 b.sync(); dt = (time.perf_counter() - t0) / 8; cpu = (time.process_time() - c0) / 8
 print("step %.2f ms wall, %.2f ms CPU time of this process; inside submit %.2f ms, collect %.2f ms (both include waiting for the GPU)" % (1e3 * dt, 1e3 * cpu, 1e3 * np.mean(ts), 1e3 * np.mean(tc)))

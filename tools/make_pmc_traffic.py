@@ -12,9 +12,23 @@ If the SQ summaries are given too, per-launch instruction counts and (second fil
 SQ_ACTIVE_INST_VALU / GRBM_GUI_ACTIVE) the VALU busy fraction by the counters are added.
 usage: make_pmc_traffic.py <pmc_hbm_per_kernel.csv> <gops> <out.json> [pmc_sq_per_kernel.csv [pmc_roof_per_kernel.csv]]"""
 import csv
+import hashlib
 import json
+import os
 import re
 import sys
+
+
+def csrc_sha16(root):
+    """what the counters were taken on: sha256 over the kernel / shim sources (the GPU box has no .git).  bench.py computes the same
+    over its own tree and says `traffic_stale` when they differ."""
+    d = os.path.join(root, "digital-subband-video-1_amd", "csrc")
+    names = sorted(n for n in os.listdir(d) if n.endswith((".hip", ".hpp")) or n == "Makefile")
+    h = hashlib.sha256()
+    for n in names + [os.path.join("..", "..", "include", "dsvg_rc.h")]:
+        h.update(os.path.basename(n).encode() + b"\0" + open(os.path.join(d, n), "rb").read())
+    return h.hexdigest()[:16]
+
 
 
 def kid(name):
@@ -73,5 +87,8 @@ out["step"] = {"steps_profiled": steps, "hbm_bytes": round(tot / steps), "hbm_by
 vi = sum(e.get("valu_insts_per_launch", 0.0) * e["launches"] for k, e in out["kernels"].items() if not k.startswith("__amd") and k != "k_spin")
 if vi:
     out["step"]["valu_insts"] = round(vi / steps)
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out["csrc_sha16"] = csrc_sha16(_root)
+out["commit"] = os.environ.get("DSV1_COMMIT", "unknown (set DSV1_COMMIT=$(git rev-parse --short HEAD) in the gpurun command)")
 json.dump(out, open(sys.argv[3], "w"), indent=1)
 print("wrote", sys.argv[3], len(out["kernels"]), "kernels")
