@@ -39,7 +39,9 @@ void launch_fwd_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
                     int general_whole = 1);   // mc: 0 = the caller knows that no block of these pictures is intra (the general kernel then only runs on the strips of the grid the geometry asks for)
 bool mc_fusable(const struct McGeo &MG);
 void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf = nullptr, int with_tail = 1,
-                    int insym = 0, int patch_kernel = 0);   // patch_kernel: sparse P pictures (flags valid, prediction given): unfiltered planes take k_inv_patch_c
+                    int insym = 0, int patch_kernel = 0,    // patch_kernel: sparse P pictures (flags valid, prediction given): unfiltered planes take k_inv_patch_c
+                    int fuse_border = 0);                   // the kernels also write the reconstruction's border (JobDev.ext) where inv_sbt_fuses_border says they can
+bool inv_sbt_fuses_border(const SbtGeo3 &G, int insym_c, int patch_kernel_c);   // the chroma patch kernel writes the borders of all three planes
 void launch_inv54_all(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, Prof *pf = nullptr);   // levels 5..4 of all planes: then launch_inv_sbt(.., with_tail | 2)
 void launch_sbt_tail(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int inverse, Prof *pf = nullptr);
 void launch_fwd_mid4(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, bool llq, Prof *pf = nullptr);   // levels 4..5: launch_fwd_sbt does it itself unless fused >= 3

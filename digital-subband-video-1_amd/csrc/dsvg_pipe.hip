@@ -1055,11 +1055,17 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
         launch_inv_sbt(st, jd, nI, c->G, 0, 1, 0, &c->prof, wt, insym & 1);
         launch_inv_sbt(st, jd, nI, c->G, 1, 2, 0, &c->prof, wt, insym & 1);
     }
+    bool fused = false;
     if (n > nI) {
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, wt, (insym >> 1) & 1, ((insym >> 1) & 1) && !c->no_patch_kernel);
-        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, wt, (insym >> 2) & 1, ((insym >> 2) & 1) && !c->no_patch_kernel);
+        const int symY = (insym >> 1) & 1, symC = (insym >> 2) & 1, pkY = symY && !c->no_patch_kernel, pkC = symC && !c->no_patch_kernel;
+        // round 5: where the chroma patch kernel covers its planes completely (1080p, 4K, 720p, CIF ...) its edge patches write the borders
+        // of all three planes -- k_extend16 then only serves the I pictures of the step: one launch less in the chain of every P frame step
+        fused = lazy_border && inv_sbt_fuses_border(c->G, symC, pkC);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, wt, symY, pkY);
+        launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, wt, symC, pkC, fused);
     }
-    launch_extend(st, c->recon.p, c->L[0], 0, n, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof, lazy_border ? jd : nullptr);
+    const int next = fused ? nI : n;                    // (device order: I jobs first)
+    if (next > 0) launch_extend(st, c->recon.p, c->L[0], 0, next, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof, lazy_border ? jd : nullptr);
     return DSVG_OK;
 }
 

@@ -2855,8 +2855,16 @@ __global__ __launch_bounds__(256) void k_inv_tile54_all(const JobDev *__restrict
 // levels 1 and 2 are complete for those rows and only level 3's last cell row is the odd one (sbt.c:392-431: LL and LH alone, outputs (LL +- LH) / 4):
 // the patch is the same closed computation with half of its rows.  Until now the whole last TILE row went to the general tile kernel for it --
 // 6 % of the plane at a quarter of this kernel's rate, and a launch per frame step.  -1: every patch of the launch is whole.
-__global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax,
-                                                     XcdGrid XG, int plain, int jpart)
+#ifndef INV_PATCH_C_WPE
+#define INV_PATCH_C_WPE 0           // 66 VGPRs with the border pass (64 without): seven waves per SIMD.  Pinned at eight (56 VGPRs, six scalars spilled) 2.7 -> 3.3 ms per step
+#endif
+#if INV_PATCH_C_WPE
+#define INV_PATCH_C_ATTR __attribute__((amdgpu_waves_per_eu(INV_PATCH_C_WPE, INV_PATCH_C_WPE)))
+#else
+#define INV_PATCH_C_ATTR
+#endif
+__global__ __launch_bounds__(256) INV_PATCH_C_ATTR void k_inv_patch_c(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, int imax, int jmax,
+                                                                      XcdGrid XG, int plain, int jpart, int fb)
 {
     Blk3 B;                                                 // one-dimensional launch in XCD order (d_xcd_blk3)
     if (!d_xcd_blk3(XG, B, plain != 0)) return;
@@ -2864,7 +2872,7 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
     d_job_plane(B.z, npl, c0, job, c);
     const SbtGeo g = G.g[c];
     const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
-    if (I >= imax || J >= jmax) return;
+    if ((I >= imax || J >= jmax) && !fb) return;          // (fb: the lanes beyond the plane help with its border below)
     // (the patch row is wave-uniform -- a wave is one row of patches: the partial row takes a body of its own, the whole patches' body
     // carries none of its tests)
     auto run = [&](auto PART_) {
@@ -2978,7 +2986,77 @@ __global__ __launch_bounds__(256) void k_inv_patch_c(const JobDev *__restrict__ 
         }
     }
     };
-    if (J == jpart) run(std::true_type{}); else run(std::false_type{});
+    if (I < imax && J < jmax) { if (J == jpart) run(std::true_type{}); else run(std::false_type{}); }
+    // fb (round 5): this launch covers every patch of the chroma planes, the luma plane of these pictures is finished (the luma inverse ran
+    // before it on this stream) -- the patches at the planes' edges write the reconstruction's BORDER, what k_extend16 did in a launch of its
+    // own behind the inverse transforms (one link of every frame step's chain, and a read of the edge columns that costs a 128-byte line per
+    // row for one byte).  They read their finished rows back -- their own stores, or the prediction the forward transform left in place --
+    // and replicate them over jb.ext's columns (units of 16) and rows (units of 8), k_extend16's units; the first chroma plane's edge patches
+    // do the same for the luma rows / columns they lie over.  One patch in twenty-five; the others leave here.  (In the luma kernel itself
+    // the border stores cost k_inv_p_tile the seventh wave per SIMD: 5 to 10 spilled registers whichever way they were written.)
+    if (!fb || J >= jmax) return;
+    {
+        // The side borders are a wave's work, not a thread's: the wave (= 64 patches of one patch row) that holds the row's first / last
+        // patch shares the rows out over its lanes -- a lane takes a pixel row of the chroma plane or of the luma rows beside it (and, in the
+        // plane's first / last patch row, the corner rows above / below): one 8-byte load of the row's edge pixels, then the stores.  As one
+        // thread's loop over 24 rows the edge patch kept its wave alive for 24 dependent round trips (k_inv_patch_c 2.0 -> 3.6 ms per step).
+        // The rows above / below the plane are each patch's own columns: every lane of the first / last patch row's waves.
+        // (offsets left of / above a plane's first pixel are negative: signed 64-bit pointer steps)
+        const JobDev &jb = jobs[job];
+        const int lane = (int)threadIdx.x;
+        const bool wl = B.x == 0, wr = (imax - 1) / 64 == B.x, top = J == 0, bot = J == jmax - 1;
+        if (!(wl || wr || top || bot)) return;                  // (wave-uniform: a wave is one patch row)
+        __threadfence_block();                                  // (a lane reads rows its neighbours in the wave have just stored)
+        const int nrow = J == jpart ? 4 : 8;
+        auto plane_sides = [&](const SbtGeo &q, const short *ex, int y0, int nr, int wpx) {      // wpx: the plane's width in pixels
+            const auto pl = dsvg_global((jb.recon ? jb.recon : jb.xf) + q.poff);
+            const long sl = (long)q.pstride;
+            const int el = min(DSVG_BORDER, (ex[0] + 15) & ~15), er_ = min(DSVG_BORDER, (ex[1] + 15) & ~15);
+            const int et = top ? min(DSVG_BORDER, (ex[2] + 7) & ~7) : 0, eb_ = bot ? min(DSVG_BORDER, (ex[3] + 7) & ~7) : 0;
+            const int nit = nr + et + eb_;                       // rows y0 - et .. y0 + nr - 1 + eb_
+            for (int side = 0; side < 2; side++) {
+                if (side ? !wr : !wl) continue;
+                const int n = side ? er_ : el;
+                if (!n) continue;
+                for (int i = lane; i < nit; i += 64) {
+                    const int y = i - et, ys = min(max(y, 0), nr - 1);                 // the row this border row copies its edge pixel from
+                    const uint2 w = dsvg_ld2(pl + ((y0 + ys) * sl + (side ? wpx - 8 : 0)));
+                    const unsigned v = (side ? (w.y >> 24) : (w.x & 0xffu)) * 0x01010101u;
+                    const auto d = pl + ((y0 + y) * sl + (side ? (long)wpx : -(long)n));
+                    for (int k = 0; k < n; k += 16) dsvg_st4(d + k, make_uint4(v, v, v, v));
+                }
+            }
+        };
+        auto plane_tb = [&](const SbtGeo &q, const short *ex, int x0, int ncol8, int y0, int nr) {
+            // this patch's columns (ncol8 groups of 8 pixels from x0) of the rows above the plane's first / below its last pixel row
+            const auto pl = dsvg_global((jb.recon ? jb.recon : jb.xf) + q.poff);
+            const long sl = (long)q.pstride;
+            const int et = top ? min(DSVG_BORDER, (ex[2] + 7) & ~7) : 0, eb_ = bot ? min(DSVG_BORDER, (ex[3] + 7) & ~7) : 0;
+            uint2 wt[4], wb[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                wt[k] = wb[k] = make_uint2(0u, 0u);
+                if (k < ncol8 && et) wt[k] = dsvg_ld2(pl + (y0 * sl + x0 + 8 * k));
+                if (k < ncol8 && eb_) wb[k] = dsvg_ld2(pl + ((y0 + nr - 1) * sl + x0 + 8 * k));
+            }
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                if (k >= ncol8) break;
+                for (int r = 1; r <= et; r++) dsvg_st2(pl + ((y0 - r) * sl + x0 + 8 * k), wt[k]);
+                for (int r = 1; r <= eb_; r++) dsvg_st2(pl + ((y0 + nr - 1 + r) * sl + x0 + 8 * k), wb[k]);
+            }
+        };
+        const SbtGeo &gy = G.g[0];
+        const int hr = gy.pw / g.pw, vr = gy.ph / g.ph;                      // luma pixels per chroma pixel (1, 2 or 4 across; 1 or 2 down)
+        if (wl || wr) {
+            plane_sides(g, jb.ext + 4, 8 * J, nrow, 8 * imax);
+            if (c == c0) plane_sides(gy, jb.ext, 8 * J * vr, nrow * vr, 8 * imax * hr);
+        }
+        if ((top || bot) && I < imax) {
+            plane_tb(g, jb.ext + 4, 8 * I, 1, 8 * J, nrow);
+            if (c == c0) plane_tb(gy, jb.ext, 8 * I * hr, hr, 8 * J * vr, nrow * vr);
+        }
+    }
 }
 
 // --------------------------------------------------------------------------------------------
@@ -3298,9 +3376,30 @@ void launch_inv54_all(hipStream_t st, const JobDev *jobs, int njobs, const SbtGe
     PE();
 }
 
-void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail,
-                    int insym, int patch_kernel)
+// Can the patch kernel of these pictures' chroma planes write the reconstruction's border (k_inv_patch_c, fb) -- its own planes' and the luma
+// plane's?  Every patch of the chroma planes must be the patch kernel's (no ragged strips for the tile kernel), both chroma planes alike, the
+// luma plane an exact multiple of them, and the widths / strides what the 16-byte border stores need.
+bool inv_sbt_fuses_border(const SbtGeo3 &G, int insym_c, int patch_kernel_c)
 {
+    static const bool off = getenv("DSV1_NO_FUSED_BORDER") != nullptr;         // (A/B)
+    if (off || !insym_c || !patch_kernel_c || getenv("DSV1_NO_PATCH_PART")) return false;
+    const SbtGeo &g = G.g[1], &gy = G.g[0];
+    for (int c = 1; c <= 2; c++) {
+        const SbtGeo &q = G.g[c];
+        if (q.pw != g.pw || q.ph != g.ph || q.w3 != g.w3 || q.h3 != g.h3 || (q.pw & 15) != 0 || (q.pstride & 15) != 0) return false;
+        const int fullc = q.pw / 8, fullr = q.ph / 8;
+        const bool part4 = fullr == q.h3 - 1 && fullr >= 1 && (q.ph & 7) == 4 && (q.H & 7) == 4;
+        if (fullc < q.w3 || !(fullr >= q.h3 || part4)) return false;
+    }
+    if (g.pw < 16 || g.ph < 8 || gy.pw % g.pw || gy.ph % g.ph || (gy.pstride & 15) != 0 || (gy.pw & 15) != 0) return false;
+    const int hr = gy.pw / g.pw, vr = gy.ph / g.ph;
+    return (hr == 1 || hr == 2 || hr == 4) && (vr == 1 || vr == 2);
+}
+
+void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3 &G, int c0, int npl, int isP, Prof *pf, int with_tail,
+                    int insym, int patch_kernel, int fuse_border)
+{
+    const int fb = (fuse_border && isP && c0 == 1 && npl == 2 && inv_sbt_fuses_border(G, insym, patch_kernel)) ? 1 : 0;
     const SbtGeo &g = G.g[c0];
     const int nz = njobs * npl;
     const double smp = (double)g.W * g.H * nz, s3 = (double)g.w3 * g.h3 * nz;
@@ -3336,7 +3435,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
                 PB(KID_INV_PATCH_C, 64.0 * imax * jmax * nz * 2.0);          // prediction in, reconstruction out (+ 5 B per patch: LL3, flag)
                 const int cgx = (imax + 63) / 64, cgy = (jmax + 3) / 4;
                 hipLaunchKernelGGL(k_inv_patch_c, tile_grid(cgx, cgy, nz), dim3(64, 4), 0, st, jobs, G, c0, npl, imax, jmax, mk_xcd_grid(cgx, cgy, nz), xcd_plain(),
-                                   part4 ? g.h3 - 1 : -1);
+                                   part4 ? g.h3 - 1 : -1, fb);
                 PE();
             }
             if (tcx < (int)tg.x || tcy < (int)tg.y) {
