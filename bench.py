@@ -56,6 +56,27 @@ def traffic_stamp(T):
             "traffic_stale": T.get("csrc_sha16") != now}
 
 
+def link_rates(torch, dev, nbytes=1 << 30, reps=3):
+    """the box's host <-> device link as this process sees it (pinned memory, one stream, 1 GiB copies): GB/s each way.  The host-fed
+    figures (value_host_pinned, config 2's packet egress) are quoted against it (verdict round 4: nobody could say which fraction of the
+    link 25.8 Gpix/s was)."""
+    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    h.fill_(7)
+    d = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % dev)
+    out = {}
+    for name, (dst, src) in (("h2d_GBs", (d, h)), ("d2h_GBs", (h, d))):
+        dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            dst.copy_(src, non_blocking=True)
+        torch.cuda.synchronize(dev)
+        out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 2)
+    del h, d
+    torch.cuda.empty_cache()
+    return out
+
+
 def cpu_info():
     model = "unknown"
     try:
@@ -172,7 +193,7 @@ def intra_block_pct(A, clip, w, h, fmt, **cli):
     return round(100.0 * intra / max(total, 1), 1)
 
 
-def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, style=0, **cli):
+def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, style=0, count_patches=False, **cli):
     """the same pipelined loop on another shape of BASELINE.json (dsv_main.c:463-489 flag mapping in make_encoder_cfg):
     `streams` x `frames` pictures per step, raw frames resident in HBM; CRF runs submit/collect, ABR (serial per frame)
     plain encode calls.  One stream is compared bit for bit with the CPU checker on its first `check_frames` frames."""
@@ -182,9 +203,23 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
     batch_in[:] = clip
     cfg = pkg.make_encoder_cfg(w, h, fmt, **cli)
     b = pkg.Batch(cfg, streams, frames, device=dev)
+    patches = None
     try:
         d = b.upload(batch_in)
         first = b.encode(d, on_device=True)
+        if count_patches:
+            # what the sparse inverse kernels find in this content: the 8x8 patches of the P pictures whose detail flags are up (counted by
+            # the kernels themselves in an untimed pass of their own: the counting costs atomics)
+            b.tile_stats()
+            b.encode(d, on_device=True)
+            ts = b.tile_stats(enable=False)
+            nP = streams * sum(1 for t in range(frames) if cli.get("gop", 12) > 0 and t % max(cli.get("gop", 12), 1) != 0)
+            cw_, ch_ = A.chroma_dims(w, h, fmt)
+            ly, lc = nP * ((w + 7) // 8) * ((h + 7) // 8), 2 * nP * ((cw_ + 7) // 8) * ((ch_ + 7) // 8)
+            patches = {"flagged_patches_luma": int(ts["flagged_patches_luma"]), "patches_luma": ly,
+                       "flagged_share_luma": round(ts["flagged_patches_luma"] / max(ly, 1), 4),
+                       "flagged_patches_chroma": int(ts["flagged_patches_chroma"]), "patches_chroma": lc,
+                       "flagged_share_chroma": round(ts["flagged_patches_chroma"] / max(lc, 1), 4)}
         crf = cli.get("rc_mode_cli", 1) == 1
         # ABR streams are pipelined like CRF ones since round 4: their rate control runs on the device (k_rc), the state goes from
         # call to call there, so the analysis of batch i + 1 overlaps the coding of batch i (DSV1_ABR_SERIAL=1: plain encode calls)
@@ -212,6 +247,8 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
     res = {"ms_per_step": round(1e3 * dt / n, 3), "Mpix_s": round(n * streams * frames * w * h / dt / 1e6, 1),
            "frames_per_s": round(n * streams * frames / dt, 1), "pictures_per_step": streams * frames,
            "dsv_bytes_per_step": int(sum(len(o) for o in outs))}
+    if patches:
+        res.update(patches)
     if check_frames:
         # a fresh single-stream GPU encode of the first check_frames frames against the CPU checker
         got = pkg.encode_clip(clip[:check_frames], w, h, fmt, device=dev, eos=False, **cli)
@@ -395,6 +432,10 @@ def main():
     shard = importlib.import_module("digital-subband-video-1_amd.shard")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     my_cores = shard.pin_rank_to_cores(local_rank, local_world)
+    numa_node = None
+    if local_world <= 1 and os.environ.get("DSV1_BENCH_NO_NUMA_PIN", "0") in ("", "0"):
+        # one process, one GPU: onto the cores of the GPU's NUMA node before anything touches the GPU (round 5; the host-fed figures depend on it)
+        my_cores, numa_node = shard.pin_single_rank(local_rank)
     import torch
     import torch.distributed as dist
     # debugging aid for boxes with fewer GPUs than ranks (never set by the driver): all ranks share device 0 and the
@@ -611,8 +652,10 @@ def main():
     # pre-loaded in host RAM"; the upload of each batch over PCIe rides inside the step), never `value`
     extras = rank == 0 and world == 1 and not args.no_extras and args.input == "hbm" and os.environ.get("DSV1_BENCH_SKIP_SHAPES") != "1"
     host_pinned = None
+    link = None
     if extras:
-        ps = 3
+        link = link_rates(torch, dev)
+        ps = 6
         host = b.pinned(batch_in.shape)
         host[...] = batch_in
         b.stage(host)
@@ -630,7 +673,10 @@ def main():
         b.collect(copy=False)
         host_pinned = {"value": round(args.gops * GOP * W * H * ps / dth / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(1e3 * dth / ps, 3),
                        "steps": ps, "note": "same workload, raw frames in pinned host memory, one %.2f GB upload per step inside the step (double-buffered ingest)"
-                                            % (batch_in.nbytes / 1e9)}
+                                            % (batch_in.nbytes / 1e9),
+                       # the step moves its raw frames host -> device: that rate against the link's own (measured in this run, same process, same NUMA placement)
+                       "upload_GBs": round(batch_in.nbytes * ps / dth / 1e9, 2), "link_GBs": link["h2d_GBs"],
+                       "frac_of_link": round(batch_in.nbytes * ps / dth / 1e9 / link["h2d_GBs"], 3)}
         del host
 
     tmax = dt
@@ -695,7 +741,7 @@ def main():
                                       "pinned": "raw frames uploaded from pinned host memory each step (PCIe inclusive, diagnostic)"}[args.input]),
                        "gops_per_gpu": args.gops, "frames_per_step": args.gops * GOP * world,
                        "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world,
-                       "host_cores_rank0": len(my_cores),
+                       "host_cores_rank0": len(my_cores), "numa_node_of_gpu_rank0": numa_node,
                        "streams_on_own_hw_queue": L.dsvg_ctx_streams_apart(b.ctx)},
             "bit_exact_vs_cpu": bit_exact,
             "bit_exact_timed_output": timed_check,
@@ -754,11 +800,23 @@ def main():
                                                        config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, %d closed GOPs x 12 frames per step, clip style 4 "
                                                               "(pan + texture with a flat square of a third of the height and a flat band over the bottom quarter, both changing every frame)" % args.gops,
                                                        intra_blocks_pct_of_P_pictures=intra_block_pct(A, wc, W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1, scd=0))
+                # the floor of the sparse kernels (verdict round 4): strong per-pixel noise that is new in every frame at -qp95 -- nearly every 8x8
+                # patch of every P picture carries level-1 symbols (the headline clip flags 5 % of its luma patches); same shape and batch
+                shapes["dense_residual"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 3, 0x10800003, 12, style=7, count_patches=True, qp=95, gop=GOP, rc_mode_cli=1, scd=0),
+                                                config="1920x1080 4:2:0 -gop12 -qp95 -rc_mode1 -scd0, %d closed GOPs x 12 frames per step, clip style 7 "
+                                                       "(the headline's pan + texture under per-pixel noise of +-24 luma / +-12 chroma that changes every frame)" % args.gops)
                 shapes["decode_1080p_batched"] = dict(decode_bench(pkg, A, dev, 64, 2),
                                                       config="1920x1080 4:2:0 GOP=12 stream, dsv1_decbatch_*: 64 streams side by side, one picture of each per call")
+                if link and "ms_per_step" in shapes["cfg2_1080p_intra"]:
+                    # config 2 hands the caller 239 MB of packets per step: its floor is that egress over the link (device -> host)
+                    c2 = shapes["cfg2_1080p_intra"]
+                    c2["egress_GBs"] = round(c2["dsv_bytes_per_step"] / (c2["ms_per_step"] * 1e-3) / 1e9, 2)
+                    c2["link_d2h_GBs"] = link["d2h_GBs"]
+                    c2["egress_frac_of_link"] = round(c2["egress_GBs"] / link["d2h_GBs"], 3)
             except Exception as e:                       # the headline stands on its own
                 shapes["error"] = repr(e)
             res["shapes"] = shapes
+            res["link"] = link
     b.close()
     # BASELINE config 4 (64 closed 4K GOPs over the node's GPUs): runs sharded over the ranks whenever there is more than one
     # (every rank takes part; the headline's context is closed first so the leg has each GPU to itself)

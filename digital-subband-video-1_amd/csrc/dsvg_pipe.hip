@@ -685,7 +685,15 @@ static int ingest_reserve(dsvg_ctx *c, size_t bytes, int *kout)
 {
     HIPCHK(hipSetDevice(c->device));
     if (!c->st_h) {
-        HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
+        // The copy stream is the context's FIFTH busy stream, and the runtime has four hardware queues for the streams it creates the plain way:
+        // it shared a queue with a coding stream, whose kernels then sat behind a batch's 12 GB upload (200 ms) and the next upload behind
+        // them -- upload and coding took turns (profiles/r05_hostpin_timeline.txt: 236 ms per step for a 211 ms upload).  A stream created
+        // with a CU mask gets a hardware queue of its own; the mask is all ones (a copy needs no CU).  DSV1_INGEST_PLAIN_STREAM=1: as before (A/B).
+        uint32_t all[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
+        if (getenv("DSV1_INGEST_PLAIN_STREAM") || hipExtStreamCreateWithCUMask(&c->st_h, 8, all) != hipSuccess) {
+            (void)hipGetLastError();
+            HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
+        }
         for (int i = 0; i < 2; i++) {
             HIPCHK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_used[i], hipEventDisableTiming));
@@ -715,7 +723,9 @@ extern "C" int dsvg_ingest_begin(dsvg_ctx *c, const void *yuv_host, size_t bytes
     if (!c || !yuv_host || !dptr || !bytes) { dsvg_set_error("bad ingest arguments"); return DSVG_ERR_ARG; }
     int k;
     OPCHK(ingest_reserve(c, bytes, &k));
+    tl_mark(c, c->st_h, "up0");
     HIPCHK(hipMemcpyAsync(c->ingest[k], yuv_host, bytes, hipMemcpyHostToDevice, c->st_h));
+    tl_mark(c, c->st_h, "up1");
     HIPCHK(hipEventRecord(c->ev_up[k], c->st_h));
     c->up_pending[k] = true;
     *dptr = c->ingest[k];

@@ -90,6 +90,45 @@ def split_cores(cores, local_rank, local_world, numa_of_rank=None, node_cpus=Non
     return list(cores[local_rank * per:(local_rank + 1) * per])
 
 
+def gpu_numa_node(dev):
+    """NUMA node of HIP device `dev` AS THIS PROCESS SEES IT (any *_VISIBLE_DEVICES mapping applied), or -1: the device's PCI bus id
+    is asked of the runtime in a short-lived child process -- the caller's own process must not have touched the GPU yet (its helper
+    threads and pinned buffers are to be created after the affinity is set) -- and looked up in sysfs."""
+    import os
+    import subprocess
+    import sys
+    code = ("import ctypes as C\n"
+            "h = C.CDLL('libamdhip64.so')\n"
+            "b = C.create_string_buffer(64)\n"
+            "print(b.value.decode() if h.hipDeviceGetPCIBusId(b, 64, %d) != 0 else b.value.decode())\n" % int(dev))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60)
+        bus = r.stdout.strip().splitlines()[-1].strip().lower() if r.stdout.strip() else ""
+        if not bus:
+            return -1
+        return int(open(os.path.join("/sys/bus/pci/devices", bus, "numa_node")).read().strip())
+    except (OSError, ValueError, subprocess.SubprocessError, IndexError):
+        return -1
+
+
+def pin_single_rank(dev, node=None, node_cpus=None):
+    """One process, one GPU (world == 1): stay on the cores of the GPU's NUMA node -- the pinned staging buffers (first touch), the
+    worker pool and the runtime's helper threads then sit on the socket the GPU's PCIe link hangs off; with the frames in HOST memory the
+    step is bound by that link, and a process that the scheduler happened to start on the other socket copied at 35-39 instead of 52 GB/s
+    (verdict round 4: the PCIe-inclusive figure was bimodal by box).  Returns (cores taken, node); nothing changes when sysfs does not
+    tell the node or none of its cores is allowed."""
+    import os
+    cores = sorted(os.sched_getaffinity(0))
+    if node is None:
+        node = gpu_numa_node(dev)
+    mine = sorted(set(cores) & set((node_cpus or _node_cpus)(node))) if node is not None and node >= 0 else []
+    if not mine or len(mine) == len(cores):
+        return cores, node
+    os.sched_setaffinity(0, mine)
+    os.environ["DSV1_CORES_PINNED"] = "1"
+    return mine, node
+
+
 def pin_rank_to_cores(local_rank, local_world):
     """Give this rank its share of the cores the process may run on (os.sched_setaffinity; split_cores: by the NUMA node of
     the rank's GPU where sysfs tells, else a contiguous slice) -- call it BEFORE anything touches the GPU, so that the

@@ -225,6 +225,8 @@ STREAMS = [
     (704, 480, A.SUBSAMP_420, 7, 2, ["-gop12", "-qp70", "-rc_mode1"], dict(qp=70, gop=12, rc_mode_cli=1)),
     # forced intra through the intra-block percentage threshold
     (352, 288, A.SUBSAMP_420, 6, 1, ["-gop12", "-qp85", "-rc_mode1", "-ipct20"], dict(qp=85, gop=12, rc_mode_cli=1, ipct=20)),
+    # dense residuals (clip style 7: strong noise that is new in every frame, -qp95): most patches of the P pictures carry level-1 symbols
+    (352, 288, A.SUBSAMP_420, 5, 7, ["-gop12", "-qp95", "-rc_mode1"], dict(qp=95, gop=12, rc_mode_cli=1)),
     # GOP longer than the stability refresh (stable_refresh = 14, gop 30) with ABR
     (176, 144, A.SUBSAMP_420, 34, 2, ["-gop30", "-qp85", "-w176"], dict(qp=85, gop=30, rc_mode_cli=0)),
 ]

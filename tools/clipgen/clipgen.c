@@ -20,6 +20,8 @@
  *   a third of the cells change between consecutive frames in a chosen subset of their four 8x8 quadrants (brightness +-60),
  *   the subset being a fixed function of the cell: every partial intra submask of hme.c:689-716 occurs, including "all four
  *   quadrants prefer the zero vector" (the whole cell changes by +-10 over a texture strong enough for intra_metric).
+ *   style 7 (round 5): style 0 with STRONG per-pixel noise that changes every frame (+-24 on luma, +-12 on chroma) -- at a high -qp nearly
+ *   every 8x8 patch of every P picture carries level-1 symbols: the dense-residual floor of the sparse inverse / list entropy kernels.
  *   style 3: style 0 with SCENE CUTS: every 7 frames the texture is another one and the brightness steps by 12 (the mean
  *   luma of the smallest pyramid level moves by more than the default scene_change_delta of 4: dsv_encoder.c:538-554).
  */
@@ -82,7 +84,9 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
     int big = 0;                                    /* style 4: style 1 with flat objects that cover a third of the frame */
     if (style == 4) { big = 1; style = 1; }
     int fast = 1;                                   /* style 5: style 3 with a pan of (6, 4) pixels per frame -- the stability */
-    if (style == 5) { fast = 4; style = 3; }        /* accumulators (|mv| >> 2 per block and picture, dsv_encoder.c:367-372) fill up */
+    if (style == 5) { fast = 4; style = 3; }
+    int noisy = 0;                                  /* style 7: style 0 with strong noise that is new in every frame */
+    if (style == 7) { noisy = 1; style = 0; }        /* accumulators (|mv| >> 2 per block and picture, dsv_encoder.c:367-372) fill up */
     if (style == 3) {
         const int scene = t / 7;
         seed ^= mix(0x5CE9Eu + (uint32_t)scene);
@@ -140,6 +144,7 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
             int tv = xfrac ? (tr[xi] + tr[xi + 1] + 1) >> 1 : tr[xi];
             int ramp = 64 + (tri(x, 74) * 128 / 37 + tri(y, 46) * 128 / 23) / 2;
             int d = (int)(hash3((uint32_t)x, (uint32_t)y, seed ^ (0xD17Du + (uint32_t)t * 977u)) & 3) - 1;
+            if (noisy) d = (int)((hash3((uint32_t)x, (uint32_t)y, seed ^ (0xD17Du + (uint32_t)t * 977u)) >> 8) % 49u) - 24;
             Y[(size_t)y * w + x] = sat8((3 * tv + 2 * ramp) / 5 + d + lift);
         }
     }
@@ -172,8 +177,10 @@ void clipgen_frame(uint8_t *out, int w, int h, int subsamp, uint32_t seed, int t
     for (int y = 0; y < ch; y++)
         for (int x = 0; x < cw; x++) {
             int tv = tex[(size_t)((y + MARGIN / 2) % TH) * TW + (x + MARGIN / 2) % TW];
-            U[(size_t)y * cw + x] = sat8(96 + tri(x + 3 * t, 64) * 2 + (tv >> 5) - 4);
-            V[(size_t)y * cw + x] = sat8(104 + tri(y - 2 * t, 48) * 2 + tri(x + y, 90) / 2 + (tv >> 6));
+            const uint32_t hn = noisy ? hash3((uint32_t)x, (uint32_t)y, seed ^ (0xC0DEu + (uint32_t)t * 613u)) : 0u;
+            const int nu = noisy ? (int)((hn >> 4) % 25u) - 12 : 0, nv = noisy ? (int)((hn >> 12) % 25u) - 12 : 0;
+            U[(size_t)y * cw + x] = sat8(96 + tri(x + 3 * t, 64) * 2 + (tv >> 5) - 4 + nu);
+            V[(size_t)y * cw + x] = sat8(104 + tri(y - 2 * t, 48) * 2 + tri(x + y, 90) / 2 + (tv >> 6) + nv);
         }
     if (style == 1) {
         int band = big ? ch / 4 : ch / 8;

@@ -19,7 +19,7 @@ def phases(a, b):
         if w == a: start = (dev, host)
         elif w == b and start is not None: out.append((start[0], dev, start[1], host)); start = None
     return out
-P = {"load": phases("load0", "load1"), "hme": phases("hme0", "hme1"), "code": phases("code0", "code1"), "fetch": phases("fetch0", "fetch1")}
+P = {"upload": phases("up0", "up1"), "load": phases("load0", "load1"), "hme": phases("hme0", "hme1"), "code": phases("code0", "code1"), "fetch": phases("fetch0", "fetch1")}
 for k, v in P.items():
     print("%-6s" % k, " ".join("[%.1f-%.1f | host enq %.1f-%.1f]" % x for x in v))
 def ov(a, b): return max(0.0, min(a[1], b[1]) - max(a[0], b[0]))
