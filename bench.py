@@ -424,6 +424,9 @@ def main():
                          "uploaded over PCIe inside the timed region (diagnostic, DESIGN.md section 7)")
     args = ap.parse_args()
 
+    # eight hardware queues for the runtime's streams (default four): the host-fed leg's copy stream needs one of its own;
+    # set before anything starts the HIP runtime -- torch does, further down -- and never over the caller's own setting
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))

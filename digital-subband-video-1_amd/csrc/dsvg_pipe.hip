@@ -685,12 +685,15 @@ static int ingest_reserve(dsvg_ctx *c, size_t bytes, int *kout)
 {
     HIPCHK(hipSetDevice(c->device));
     if (!c->st_h) {
-        // The copy stream is the context's FIFTH busy stream, and the runtime has four hardware queues for the streams it creates the plain way:
-        // it shared a queue with a coding stream, whose kernels then sat behind a batch's 12 GB upload (200 ms) and the next upload behind
-        // them -- upload and coding took turns (profiles/r05_hostpin_timeline.txt: 236 ms per step for a 211 ms upload).  A stream created
-        // with a CU mask gets a hardware queue of its own; the mask is all ones (a copy needs no CU).  DSV1_INGEST_PLAIN_STREAM=1: as before (A/B).
+        // The copy stream is the context's FIFTH busy stream, and the runtime has four hardware queues by default for the streams it creates:
+        // it shares a queue with a coding stream, whose kernels then sit behind a batch's 12 GB upload (200 ms) and the next upload behind
+        // them -- upload and coding take turns (profiles/r05_hostpin_timeline.txt: 236 ms per step for a 211 ms upload).  The cure is a
+        // hardware queue of its own: GPU_MAX_HW_QUEUES=8 in the environment before the runtime starts (this library's constructor sets it
+        // when nobody else has: dsvg_common.hip; bench.py does the same) -- 210 ms per step, the link's rate.  A stream created with a CU mask
+        // gets its own queue too and measured the same, but hung the frame-at-a-time ingest of dsv_enc once in three runs (many small copies
+        // on that stream; tests/test_gpu_stream.py -k drop_in): opt-in only, DSV1_INGEST_MASKED_STREAM=1.
         uint32_t all[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
-        if (getenv("DSV1_INGEST_PLAIN_STREAM") || hipExtStreamCreateWithCUMask(&c->st_h, 8, all) != hipSuccess) {
+        if (!getenv("DSV1_INGEST_MASKED_STREAM") || hipExtStreamCreateWithCUMask(&c->st_h, 8, all) != hipSuccess) {
             (void)hipGetLastError();
             HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
         }
@@ -1639,6 +1642,22 @@ extern "C" int dsvg_recon_border(dsvg_ctx *c, int recon_slot, short *ext_out)
     return DSVG_OK;
 }
 
+extern "C" int dsvg_host_free_on(int device, void *hptr)
+{
+    if (!hptr) return DSVG_OK;
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(hipHostFree(hptr));
+    return DSVG_OK;
+}
+extern "C" int dsvg_download_recon_frame(dsvg_ctx *c, int recon_slot, void *raw_out, size_t bytes)
+{
+    if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
+    HIPCHK(hipSetDevice(c->device));
+    OPCHK(dec_resolve(c));                               // (a flagged call is decoded again from int32 coefficients first)
+    HIPCHK(hipMemcpyAsync(raw_out, c->recon.p + (size_t)recon_slot * c->L[0].pitch, bytes, hipMemcpyDeviceToHost, c->st));
+    HIPCHK(hipStreamSynchronize(c->st));
+    return DSVG_OK;
+}
 extern "C" int dsvg_download_recon_asis(dsvg_ctx *c, int recon_slot, uint8_t *raw_out, size_t bytes)
 {
     if (!c || !raw_out || recon_slot < 0 || recon_slot >= c->n_recon || bytes > c->L[0].bytes) return DSVG_ERR_ARG;
@@ -1884,17 +1903,18 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
             off += ((size_t)j.plane_len[p] + 64 + 15) & ~(size_t)15;
         }
     }
+    const bool symI = sparse && c->dec_sym_ok[0] && c->dec_sym_ok[1] && !c->no_dec_sym_I && nI > 0;      // the call's I pictures are on the symbol path
+    const int insym = !sparse ? 0 : (symI ? 1 : 0) | (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
+    const int f0 = symI ? 0 : nI;                      // first job that may raise a flag / holds symbols to take down again
+    const bool anysym = ((insym & 6) && njobs > nI) || symI;
     HIPCHK(hipMemcpyAsync(c->dec_d[k], c->dec_h[k], off, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->jobs_d, c->jobs_h + hb, sizeof(JobDev) * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable, c->stable_h + hb * c->nblk, (size_t)c->nblk * njobs, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs, c->mv_h + hb * c->nblk, (size_t)c->nblk * njobs * sizeof(DMV), hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots, c->slots_h + hb, sizeof(int) * njobs, hipMemcpyHostToDevice, c->st));
-    HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
-    const bool symI = sparse && c->dec_sym_ok[0] && c->dec_sym_ok[1] && !c->no_dec_sym_I && nI > 0;      // the call's I pictures are on the symbol path
-    const int insym = !sparse ? 0 : (symI ? 1 : 0) | (c->dec_sym_ok[0] ? 2 : 0) | (c->dec_sym_ok[1] ? 4 : 0);
-    const int f0 = symI ? 0 : nI;                      // first job that may raise a flag / holds symbols to take down again
-    const bool anysym = ((insym & 6) && njobs > nI) || symI;
     if (anysym) HIPCHK(hipMemsetAsync(c->dec_flag_d + hb, 0, sizeof(int) * (size_t)njobs, c->st));
+    // (round 5, measured dead end: the six commands above as ONE kernel that reads the pinned tables in place -- 3 180-3 220 against 3 250 frames/s)
+    HIPCHK(hipEventRecord(c->ev_dec[k], c->st));
     launch_dec_clear(c->st, c->jobs_d, njobs);
     launch_hz_parse_scatter(c->st, c->jobs_d, njobs, 0, 3, max_entries, max_chunks, &c->prof, (insym & 6) == 6 && (nI == 0 || symI));
     if (anysym) {

@@ -5,6 +5,7 @@
  * a host DSV_FRAME); dsv1_decbatch_* decodes one picture of each of many independent streams per call.
  * Debug overlays (draw_info) are accepted and ignored. */
 #include <stdio.h>
+#include <time.h>
 #include "dsv1_host.h"
 #define DSV_MIN_BLOCK_SIZE 16          /* dsv.h:50-51 */
 #define DSV_MAX_BLOCK_SIZE 64
@@ -13,14 +14,25 @@ typedef struct {
     dsvg_ctx *ctx;
     dsvg_geom g;
     int have_ref, rpar;         /* rpar: which of the two reference slots holds the current reference picture */
+    dsv1_frame_pool *pool;      /* pinned output frames in the device's frame layout (round 5): a picture comes back by one asynchronous copy */
+    unsigned char *stable;      /* [nblk] side information of the picture being decoded (kept from call to call) */
+    DSV_MV *mvs;
 } dec_sess;
+
+static void sess_close(dec_sess *s)
+{
+    if (!s) return;
+    if (s->ctx) dsvg_ctx_destroy(s->ctx);
+    dsv1_pool_unref(s->pool);                           /* (frames the caller still holds keep their buffers alive) */
+    free(s->stable); free(s->mvs);
+    dsv1_recycle_hold(-1);
+    free(s);
+}
 
 void dsv_dec_free(DSV_DECODER *d)
 {
     if (d->ref) {
-        dec_sess *s = (dec_sess *)d->ref;
-        if (s->ctx) dsvg_ctx_destroy(s->ctx);
-        free(s);
+        sess_close((dec_sess *)d->ref);
         d->ref = NULL;
     }
 }
@@ -200,27 +212,43 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
             return DSV_DEC_ERROR;
         }
         dsvg_ctx_geom(ns->ctx, &ns->g);
+        dsv1_recycle_hold(+1);                           /* (frames that do not come from the pool: their blocks are parked, not unmapped) */
+        ns->stable = (unsigned char *)calloc((size_t)ns->g.nblocks_h * ns->g.nblocks_v, 1);
+        ns->mvs = (DSV_MV *)calloc((size_t)ns->g.nblocks_h * ns->g.nblocks_v, sizeof(DSV_MV));
+        if (!ns->stable || !ns->mvs) { dsv1_log(1, "out of memory"); sess_close(ns); dsv_buf_free(buffer); return DSV_DEC_ERROR; }
+        {
+            const char *e = getenv("DSV1_DEC_NO_POOL");    /* (A/B: the packed download + row copy of rounds 1-4) */
+            if (!(e && atoi(e) != 0)) ns->pool = dsv1_pool_new(ns->ctx, dsv1_device, ns->g.frame_alloc_bytes, DSV1_POOL_FRAMES);
+        }
         if (ss) {
             if (ss->have_ref) {
                 const size_t nb = ss->g.frame_alloc_bytes;
                 uint8_t *raw = (uint8_t *)malloc(nb);
                 if (!raw || dsvg_download_recon_raw(ss->ctx, ss->rpar, raw, nb) || dsvg_upload_recon_raw(ns->ctx, 0, raw, nb)) {
                     dsv1_log(1, "reference picture could not be carried over: %s", dsvg_last_error());
-                    free(raw); dsvg_ctx_destroy(ns->ctx); free(ns);
+                    free(raw); sess_close(ns);
                     dsv_buf_free(buffer);
                     return DSV_DEC_ERROR;
                 }
                 free(raw);
                 ns->have_ref = 1; ns->rpar = 0;
             }
-            dsvg_ctx_destroy(ss->ctx);
-            free(ss);
+            sess_close(ss);
         }
         d->ref = ss = ns;
     }
+    /* DSV1_DEC_PROF=1: where a call's time goes (side information parse / dsvg_decode_pictures = uploads + launches / the wait for the picture) */
+    static int prof = -1;
+    static double pt[4];
+    static long pn;
+    double t0 = 0, t1 = 0, t2 = 0;
+    if (prof < 0) { const char *e = getenv("DSV1_DEC_PROF"); prof = e && atoi(e) != 0; }
+#define DEC_NOW(v) do { if (prof) { struct timespec ts_; clock_gettime(CLOCK_MONOTONIC, &ts_); v = ts_.tv_sec * 1e6 + ts_.tv_nsec * 1e-3; } } while (0)
+    DEC_NOW(t0);
     nblk = ss->g.nblocks_h * ss->g.nblocks_v;
-    stable = (unsigned char *)calloc((size_t)nblk, 1);
-    mvs = (DSV_MV *)calloc((size_t)nblk, sizeof(DSV_MV));
+    stable = ss->stable; mvs = ss->mvs;
+    memset(stable, 0, (size_t)nblk);
+    memset(mvs, 0, (size_t)nblk * sizeof(DSV_MV));
     if (parse_picture_body(&r, buffer->data, buffer->len, &ss->g, has_ref, stable, mvs, &job)) goto done;
     if (has_ref && !ss->have_ref) {
         dsv1_log(2, "reference frame not found");
@@ -230,12 +258,35 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
      * slot its reconstruction will live in, dsvg_decode_pictures); other pictures go to slot 2 */
     job.ref_recon_slot = has_ref ? ss->rpar : -1;
     job.recon_slot = is_ref ? (ss->rpar ^ 1) : 2;
+    DEC_NOW(t1);
     if ((rc = dsvg_decode_pictures(ss->ctx, 1, &job))) {
         dsv1_log(1, "GPU decode failed: %s", dsvg_last_error());
         goto done;
     }
+    DEC_NOW(t2);
+    /* the picture as the device holds it -- the reference's own frame layout -- straight into a pinned frame of the pool: one copy */
+    f = dsv1_pool_frame(ss->pool, m->subsamp, m->width, m->height);
+    if (f) {
+        if ((rc = dsvg_download_recon_frame(ss->ctx, job.recon_slot, f->alloc, ss->g.frame_alloc_bytes))) {
+            dsv1_log(1, "GPU download failed: %s", dsvg_last_error());
+            dsv_frame_ref_dec(f);
+            goto done;
+        }
+        if (is_ref) { ss->have_ref = 1; ss->rpar ^= 1; }
+        *out = f;
+        ret = DSV_DEC_OK;
+        if (prof) {
+            double t3 = 0;
+            DEC_NOW(t3);
+            pt[0] += t1 - t0; pt[1] += t2 - t1; pt[2] += t3 - t2;
+            if (++pn % 24 == 0) fprintf(stderr, "[dsv_dec] %ld pictures: parse %.1f us, decode_pictures (uploads + launches) %.1f us, frame + download (wait) %.1f us per call\n",
+                                        pn, pt[0] / pn, pt[1] / pn, pt[2] / pn);
+        }
+        goto done;
+    }
+    /* (every pool frame is still with the caller, or no pool: the packed download and a frame of its own) */
     packed = (uint8_t *)malloc(ss->g.frame_bytes);
-    if ((rc = dsvg_download_recon(ss->ctx, job.recon_slot, packed))) {
+    if (!packed || (rc = dsvg_download_recon(ss->ctx, job.recon_slot, packed))) {
         dsv1_log(1, "GPU download failed: %s", dsvg_last_error());
         goto done;
     }
@@ -251,8 +302,6 @@ int dsv_dec(DSV_DECODER *d, DSV_BUF *buffer, DSV_FRAME **out, DSV_FNUM *fn)
     ret = DSV_DEC_OK;
 done:
     free(packed);
-    free(mvs);
-    free(stable);
     dsv_buf_free(buffer);
     return ret;
 }

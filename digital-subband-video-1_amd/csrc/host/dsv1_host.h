@@ -81,6 +81,12 @@ int  dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n);
 int  dsv1_buf_reserve(DSV_BUF *b, unsigned n);
 /* dsv_alloc without the zeroing (a buffer the library fills itself); freed with dsv_free like any other */
 void *dsv1_alloc_raw(int size);
+/* the decoder's pinned output frames (dsv1_util.c) */
+#define DSV1_POOL_FRAMES 6
+typedef struct dsv1_frame_pool dsv1_frame_pool;
+dsv1_frame_pool *dsv1_pool_new(dsvg_ctx *ctx, int device, size_t bytes, int n);
+void dsv1_pool_unref(dsv1_frame_pool *pl);
+DSV_FRAME *dsv1_pool_frame(dsv1_frame_pool *pl, int format, int width, int height);
 int dsv1_recycle_hold(int delta);       /* dsv1_util.c: +1 a batch opens, -1 it closes (the last one out releases the parked blocks) */
 void dsv1_log(int level, const char *fmt, ...);
 extern int dsv1_device;

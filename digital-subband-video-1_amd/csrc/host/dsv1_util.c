@@ -216,9 +216,21 @@ int dsv1_buf_append(DSV_BUF *b, const uint8_t *src, unsigned n)
 }
 
 /* ---- host frames ---------------------------------------------------------------------------- */
+/* Every frame this library hands out is a DSV_FRAME followed by two hidden words: the pinned pool its pixel memory belongs to (the
+ * decoder's output frames, dsv1_pool_frame) or NULL (pixel memory from dsv_alloc, or the caller's).  dsv_frame_ref_dec gives a pool
+ * frame's buffer back to its pool instead of freeing it. */
+typedef struct { DSV_FRAME f; dsv1_frame_pool *pool; int idx; } frame_ext;
+struct dsv1_frame_pool {
+    int refs;                       /* the session + every frame out (atomic) */
+    int n, device;
+    size_t bytes;
+    uint8_t *buf[DSV1_POOL_FRAMES];
+    int busy[DSV1_POOL_FRAMES];     /* (atomic) */
+};
+
 static DSV_FRAME *frame_shell(int format, int w, int h)
 {
-    DSV_FRAME *f = (DSV_FRAME *)dsv_alloc((int)sizeof(*f));
+    DSV_FRAME *f = (DSV_FRAME *)dsv_alloc((int)sizeof(frame_ext));      /* zeroed: no pool */
     f->refcount = 1;
     f->format = format;
     f->width = w;
@@ -287,9 +299,81 @@ void dsv_frame_ref_dec(DSV_FRAME *frame)
         exit(-1);
     }
     if (--frame->refcount == 0) {
-        if (frame->alloc) dsv_free(frame->alloc);
+        frame_ext *x = (frame_ext *)frame;
+        if (x->pool) {                                   /* the pixel memory goes back to the decoder's pinned pool */
+            dsv1_frame_pool *pl = x->pool;
+            __atomic_store_n(&pl->busy[x->idx], 0, __ATOMIC_RELEASE);
+            dsv1_pool_unref(pl);
+        } else if (frame->alloc) dsv_free(frame->alloc);
         dsv_free(frame);
     }
+}
+
+/* ---- the decoder's output frames: a few buffers of PINNED host memory in the reference's frame layout (frame.c:63-120 -- the layout
+ * the device keeps its reconstructions in), so that a decoded picture reaches the caller by ONE asynchronous device-to-host copy of the
+ * reconstruction slot: no packing kernel, no staging copy, no row-by-row copy into a freshly zeroed frame (dsv_dec spent most of a
+ * call's 700 us there).  A frame the caller still holds keeps its buffer; with every buffer out the decoder falls back to plain frames. */
+dsv1_frame_pool *dsv1_pool_new(dsvg_ctx *ctx, int device, size_t bytes, int n)
+{
+    dsv1_frame_pool *pl = (dsv1_frame_pool *)calloc(1, sizeof(*pl));
+    int i;
+    if (!pl) return NULL;
+    if (n > DSV1_POOL_FRAMES) n = DSV1_POOL_FRAMES;
+    pl->refs = 1; pl->device = device; pl->bytes = bytes;
+    for (i = 0; i < n; i++) {
+        void *p = NULL;
+        if (dsvg_host_alloc(ctx, &p, bytes)) break;
+        memset(p, 0, bytes);
+        pl->buf[pl->n++] = (uint8_t *)p;
+    }
+    if (!pl->n) { free(pl); return NULL; }
+    return pl;
+}
+void dsv1_pool_unref(dsv1_frame_pool *pl)
+{
+    int i;
+    if (!pl || __atomic_sub_fetch(&pl->refs, 1, __ATOMIC_ACQ_REL) > 0) return;
+    for (i = 0; i < pl->n; i++) dsvg_host_free_on(pl->device, pl->buf[i]);
+    free(pl);
+}
+/* a frame in the reference layout (dsv_mk_frame with a border) on a free buffer of the pool, or NULL when every buffer is out */
+DSV_FRAME *dsv1_pool_frame(dsv1_frame_pool *pl, int format, int width, int height)
+{
+    const int ext = DSVG_FRAME_BORDER, hs = (format >> 2) & 3, vs = format & 3;
+    DSV_FRAME *f;
+    frame_ext *x;
+    size_t off = 0;
+    int i, c, idx = -1;
+    if (!pl) return NULL;
+    for (i = 0; i < pl->n && idx < 0; i++) {
+        int zero = 0;
+        if (__atomic_compare_exchange_n(&pl->busy[i], &zero, 1, 0, __ATOMIC_ACQ_REL, __ATOMIC_ACQUIRE)) idx = i;
+    }
+    if (idx < 0) return NULL;
+    f = frame_shell(format, width, height);
+    f->border = 1;
+    for (c = 0; c < 3; c++) {
+        DSV_PLANE *p = &f->planes[c];
+        p->format = format;
+        p->w = c ? (width + (1 << hs) - 1) >> hs : width;
+        p->h = c ? (height + (1 << vs) - 1) >> vs : height;
+        p->hs = c ? hs : 0;
+        p->vs = c ? vs : 0;
+        p->stride = (p->w + 2 * ext + 15) & ~15;
+        p->len = p->stride * (p->h + 2 * ext);
+        p->data = pl->buf[idx] + off + (size_t)p->stride * ext + ext;
+        off += (size_t)p->len;
+    }
+    if (off > pl->bytes) {                               /* (not this pool's geometry) */
+        __atomic_store_n(&pl->busy[idx], 0, __ATOMIC_RELEASE);
+        dsv_free(f);
+        return NULL;
+    }
+    f->alloc = pl->buf[idx];
+    x = (frame_ext *)f;
+    x->pool = pl; x->idx = idx;
+    __atomic_add_fetch(&pl->refs, 1, __ATOMIC_ACQ_REL);
+    return f;
 }
 
 /* ---- planar YUV files ------------------------------------------------------------------------- */

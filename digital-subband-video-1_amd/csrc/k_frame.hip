@@ -496,3 +496,4 @@ void launch_frame_add(hipStream_t st, uint8_t *dst, const FrameLayout &DL, const
 {
     hipLaunchKernelGGL(k_frame_add, dim3(nblk((long)DL.w[0] * DL.h[0], 1024), 3, 1), dim3(256), 0, st, dst, DL, src, SL);
 }
+

@@ -149,6 +149,11 @@ int dsvg_dev_download(dsvg_ctx *ctx, void *dst, const void *dptr, size_t bytes);
  * and is staged by the runtime inside the call.  At most two ingests may be outstanding. */
 int dsvg_host_alloc(dsvg_ctx *ctx, void **hptr, size_t bytes);
 int dsvg_host_free(dsvg_ctx *ctx, void *hptr);
+/* the same without a context (a buffer that outlives the context it was allocated through: the decoder's pinned frame pool) */
+int dsvg_host_free_on(int device, void *hptr);
+/* the raw allocation of reconstruction slot `recon_slot` -- the reference's frame layout, borders as the device left them, dsvg_geom.frame_alloc_bytes
+ * bytes -- into host memory (pinned: one asynchronous copy) behind the decoding work on the coding stream; waits for the copy, for nothing else */
+int dsvg_download_recon_frame(dsvg_ctx *ctx, int recon_slot, void *raw_out, size_t bytes);
 int dsvg_ingest_begin(dsvg_ctx *ctx, const void *yuv_host, size_t bytes, void **dptr);
 /* The same for a clip that arrives piece by piece (dsv_enc takes a frame per call): dsvg_ingest_open reserves the next of the
  * two buffers for `bytes` bytes and returns it; dsvg_ingest_part queues the upload of one piece (host memory, pinned for an
