@@ -2873,6 +2873,67 @@ __global__ __launch_bounds__(256) INV_PATCH_C_ATTR void k_inv_patch_c(const JobD
     const SbtGeo g = G.g[c];
     const int I = B.x * 64 + threadIdx.x, J = B.y * 4 + threadIdx.y;
     if ((I >= imax || J >= jmax) && !fb) return;          // (fb: the lanes beyond the plane help with its border below)
+    // fb (round 5): this launch covers every patch of the chroma planes, the luma plane of these pictures is finished (the luma inverse ran
+    // before it on this stream) -- the waves at the planes' edges write the reconstruction's BORDER, what k_extend16 did in a launch of its
+    // own behind the inverse transforms (one link of every frame step's chain).  The side borders are a wave's work, not a thread's: the
+    // wave (= 64 patches of one patch row) that holds the row's first / last patch shares the rows out over its lanes -- a lane takes a
+    // pixel row of the chroma plane or of the luma rows beside it (and, in the plane's first / last patch row, the corner rows above /
+    // below): one 8-byte load of the row's edge pixels, then the stores, in jb.ext's columns (units of 16) and rows (units of 8): k_extend16's
+    // units.  The rows above / below a plane are each patch's own columns: every lane of the first / last patch row's waves.  The LUMA part
+    // -- two thirds of it -- is done first, under the patch body's own loads (the plane is complete); the chroma part after the body, behind
+    // a fence (a lane reads rows its neighbours in the wave have just stored).  As one thread's loop over its 24 rows the edge patch kept its
+    // wave alive for 24 dependent round trips (k_inv_patch_c 2.0 -> 3.6 ms per step); as one section behind the body 2.0 -> 2.5.  In the luma
+    // kernel itself the border stores cost k_inv_p_tile its seventh wave per SIMD (5 to 10 spilled registers whichever way they were written).
+    // (offsets left of / above a plane's first pixel are negative: signed 64-bit pointer steps)
+    const bool bwl = B.x == 0, bwr = (imax - 1) / 64 == B.x, btop = J == 0, bbot = J == jmax - 1;
+    const int bnrow = J == jpart ? 4 : 8;
+    const int lane = (int)threadIdx.x;
+    const bool top = btop, bot = bbot, wl = bwl, wr = bwr;
+    const JobDev &jb = jobs[job];
+    auto plane_sides = [&](const SbtGeo &q, const short *ex, int y0, int nr, int wpx) {      // wpx: the plane's width in pixels
+        const auto pl = dsvg_global((jb.recon ? jb.recon : jb.xf) + q.poff);
+        const long sl = (long)q.pstride;
+        const int el = min(DSVG_BORDER, (ex[0] + 15) & ~15), er_ = min(DSVG_BORDER, (ex[1] + 15) & ~15);
+        const int et = top ? min(DSVG_BORDER, (ex[2] + 7) & ~7) : 0, eb_ = bot ? min(DSVG_BORDER, (ex[3] + 7) & ~7) : 0;
+        const int nit = nr + et + eb_;                       // rows y0 - et .. y0 + nr - 1 + eb_
+        for (int side = 0; side < 2; side++) {
+            if (side ? !wr : !wl) continue;
+            const int n = side ? er_ : el;
+            if (!n) continue;
+            for (int i = lane; i < nit; i += 64) {
+                const int y = i - et, ys = min(max(y, 0), nr - 1);                 // the row this border row copies its edge pixel from
+                const uint2 w = dsvg_ld2(pl + ((y0 + ys) * sl + (side ? wpx - 8 : 0)));
+                const unsigned v = (side ? (w.y >> 24) : (w.x & 0xffu)) * 0x01010101u;
+                const auto d = pl + ((y0 + y) * sl + (side ? (long)wpx : -(long)n));
+                for (int k = 0; k < n; k += 16) dsvg_st4(d + k, make_uint4(v, v, v, v));
+            }
+        }
+    };
+    auto plane_tb = [&](const SbtGeo &q, const short *ex, int x0, int ncol8, int y0, int nr) {
+        // this patch's columns (ncol8 groups of 8 pixels from x0) of the rows above the plane's first / below its last pixel row
+        const auto pl = dsvg_global((jb.recon ? jb.recon : jb.xf) + q.poff);
+        const long sl = (long)q.pstride;
+        const int et = top ? min(DSVG_BORDER, (ex[2] + 7) & ~7) : 0, eb_ = bot ? min(DSVG_BORDER, (ex[3] + 7) & ~7) : 0;
+        uint2 wt[4], wb[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            wt[k] = wb[k] = make_uint2(0u, 0u);
+            if (k < ncol8 && et) wt[k] = dsvg_ld2(pl + (y0 * sl + x0 + 8 * k));
+            if (k < ncol8 && eb_) wb[k] = dsvg_ld2(pl + ((y0 + nr - 1) * sl + x0 + 8 * k));
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if (k >= ncol8) break;
+            for (int r = 1; r <= et; r++) dsvg_st2(pl + ((y0 - r) * sl + x0 + 8 * k), wt[k]);
+            for (int r = 1; r <= eb_; r++) dsvg_st2(pl + ((y0 + nr - 1 + r) * sl + x0 + 8 * k), wb[k]);
+        }
+    };
+    if (fb && J < jmax && c == c0 && (bwl || bwr || btop || bbot)) {
+        const SbtGeo &gy = G.g[0];
+        const int hr = gy.pw / g.pw, vr = gy.ph / g.ph;                      // luma pixels per chroma pixel (1, 2 or 4 across; 1 or 2 down)
+        if (bwl || bwr) plane_sides(gy, jb.ext, 8 * J * vr, bnrow * vr, 8 * imax * hr);
+        if ((btop || bbot) && I < imax) plane_tb(gy, jb.ext, 8 * I * hr, hr, 8 * J * vr, bnrow * vr);
+    }
     // (the patch row is wave-uniform -- a wave is one row of patches: the partial row takes a body of its own, the whole patches' body
     // carries none of its tests)
     auto run = [&](auto PART_) {
@@ -2987,76 +3048,11 @@ __global__ __launch_bounds__(256) INV_PATCH_C_ATTR void k_inv_patch_c(const JobD
     }
     };
     if (I < imax && J < jmax) { if (J == jpart) run(std::true_type{}); else run(std::false_type{}); }
-    // fb (round 5): this launch covers every patch of the chroma planes, the luma plane of these pictures is finished (the luma inverse ran
-    // before it on this stream) -- the patches at the planes' edges write the reconstruction's BORDER, what k_extend16 did in a launch of its
-    // own behind the inverse transforms (one link of every frame step's chain, and a read of the edge columns that costs a 128-byte line per
-    // row for one byte).  They read their finished rows back -- their own stores, or the prediction the forward transform left in place --
-    // and replicate them over jb.ext's columns (units of 16) and rows (units of 8), k_extend16's units; the first chroma plane's edge patches
-    // do the same for the luma rows / columns they lie over.  One patch in twenty-five; the others leave here.  (In the luma kernel itself
-    // the border stores cost k_inv_p_tile the seventh wave per SIMD: 5 to 10 spilled registers whichever way they were written.)
     if (!fb || J >= jmax) return;
-    {
-        // The side borders are a wave's work, not a thread's: the wave (= 64 patches of one patch row) that holds the row's first / last
-        // patch shares the rows out over its lanes -- a lane takes a pixel row of the chroma plane or of the luma rows beside it (and, in the
-        // plane's first / last patch row, the corner rows above / below): one 8-byte load of the row's edge pixels, then the stores.  As one
-        // thread's loop over 24 rows the edge patch kept its wave alive for 24 dependent round trips (k_inv_patch_c 2.0 -> 3.6 ms per step).
-        // The rows above / below the plane are each patch's own columns: every lane of the first / last patch row's waves.
-        // (offsets left of / above a plane's first pixel are negative: signed 64-bit pointer steps)
-        const JobDev &jb = jobs[job];
-        const int lane = (int)threadIdx.x;
-        const bool wl = B.x == 0, wr = (imax - 1) / 64 == B.x, top = J == 0, bot = J == jmax - 1;
-        if (!(wl || wr || top || bot)) return;                  // (wave-uniform: a wave is one patch row)
-        __threadfence_block();                                  // (a lane reads rows its neighbours in the wave have just stored)
-        const int nrow = J == jpart ? 4 : 8;
-        auto plane_sides = [&](const SbtGeo &q, const short *ex, int y0, int nr, int wpx) {      // wpx: the plane's width in pixels
-            const auto pl = dsvg_global((jb.recon ? jb.recon : jb.xf) + q.poff);
-            const long sl = (long)q.pstride;
-            const int el = min(DSVG_BORDER, (ex[0] + 15) & ~15), er_ = min(DSVG_BORDER, (ex[1] + 15) & ~15);
-            const int et = top ? min(DSVG_BORDER, (ex[2] + 7) & ~7) : 0, eb_ = bot ? min(DSVG_BORDER, (ex[3] + 7) & ~7) : 0;
-            const int nit = nr + et + eb_;                       // rows y0 - et .. y0 + nr - 1 + eb_
-            for (int side = 0; side < 2; side++) {
-                if (side ? !wr : !wl) continue;
-                const int n = side ? er_ : el;
-                if (!n) continue;
-                for (int i = lane; i < nit; i += 64) {
-                    const int y = i - et, ys = min(max(y, 0), nr - 1);                 // the row this border row copies its edge pixel from
-                    const uint2 w = dsvg_ld2(pl + ((y0 + ys) * sl + (side ? wpx - 8 : 0)));
-                    const unsigned v = (side ? (w.y >> 24) : (w.x & 0xffu)) * 0x01010101u;
-                    const auto d = pl + ((y0 + y) * sl + (side ? (long)wpx : -(long)n));
-                    for (int k = 0; k < n; k += 16) dsvg_st4(d + k, make_uint4(v, v, v, v));
-                }
-            }
-        };
-        auto plane_tb = [&](const SbtGeo &q, const short *ex, int x0, int ncol8, int y0, int nr) {
-            // this patch's columns (ncol8 groups of 8 pixels from x0) of the rows above the plane's first / below its last pixel row
-            const auto pl = dsvg_global((jb.recon ? jb.recon : jb.xf) + q.poff);
-            const long sl = (long)q.pstride;
-            const int et = top ? min(DSVG_BORDER, (ex[2] + 7) & ~7) : 0, eb_ = bot ? min(DSVG_BORDER, (ex[3] + 7) & ~7) : 0;
-            uint2 wt[4], wb[4];
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                wt[k] = wb[k] = make_uint2(0u, 0u);
-                if (k < ncol8 && et) wt[k] = dsvg_ld2(pl + (y0 * sl + x0 + 8 * k));
-                if (k < ncol8 && eb_) wb[k] = dsvg_ld2(pl + ((y0 + nr - 1) * sl + x0 + 8 * k));
-            }
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                if (k >= ncol8) break;
-                for (int r = 1; r <= et; r++) dsvg_st2(pl + ((y0 - r) * sl + x0 + 8 * k), wt[k]);
-                for (int r = 1; r <= eb_; r++) dsvg_st2(pl + ((y0 + nr - 1 + r) * sl + x0 + 8 * k), wb[k]);
-            }
-        };
-        const SbtGeo &gy = G.g[0];
-        const int hr = gy.pw / g.pw, vr = gy.ph / g.ph;                      // luma pixels per chroma pixel (1, 2 or 4 across; 1 or 2 down)
-        if (wl || wr) {
-            plane_sides(g, jb.ext + 4, 8 * J, nrow, 8 * imax);
-            if (c == c0) plane_sides(gy, jb.ext, 8 * J * vr, nrow * vr, 8 * imax * hr);
-        }
-        if ((top || bot) && I < imax) {
-            plane_tb(g, jb.ext + 4, 8 * I, 1, 8 * J, nrow);
-            if (c == c0) plane_tb(gy, jb.ext, 8 * I * hr, hr, 8 * J * vr, nrow * vr);
-        }
-    }
+    if (!(bwl || bwr || btop || bbot)) return;              // (wave-uniform: a wave is one patch row)
+    __threadfence_block();                                  // (a lane reads rows its neighbours in the wave have just stored)
+    if (bwl || bwr) plane_sides(g, jobs[job].ext + 4, 8 * J, bnrow, 8 * imax);
+    if ((btop || bbot) && I < imax) plane_tb(g, jobs[job].ext + 4, 8 * I, 1, 8 * J, bnrow);
 }
 
 // --------------------------------------------------------------------------------------------
