@@ -67,6 +67,7 @@ def lib():
         L.dsvg_ctx_sync.argtypes = [_C.c_void_p]
         L.dsvg_ctx_code_streams.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_ctx_streams_apart.argtypes = [_C.c_void_p]
+        L.dsvg_ctx_copy_queue.argtypes = [_C.c_void_p]
         L.dsvg_ctx_tile_stats.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
         L.dsvg_ctx_tile_stats2.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
         L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]

@@ -5,13 +5,9 @@
 
 static thread_local char g_err[512] = "";
 
-// The HIP runtime maps the streams it creates onto GPU_MAX_HW_QUEUES hardware queues (4 by default).  A throughput context keeps four
-// streams busy (two coding, analysis, fetch) and a host-fed one a fifth (the copy stream): on four queues the fifth shares one with a
-// coding stream and a batch's upload and its coding take turns (dsvg_pipe.hip, ingest_reserve).  Eight queues, unless the environment
-// already says otherwise -- read by the runtime when it starts, i.e. at the process's first HIP call: a constructor of this library is
-// early enough for a C caller that links it; a host framework that has started the runtime before loading the library sets the
-// variable itself (bench.py does).
-__attribute__((constructor)) static void dsvg_more_hw_queues() { (void)setenv("GPU_MAX_HW_QUEUES", "8", 0); }
+// (round 5: the library does NOT touch GPU_MAX_HW_QUEUES -- in a fresh process small contexts ran 2.4 times slower with eight hardware queues
+// (config 5: 6.2 -> 15 ms per step, profiles/r05_hw_queues_small_shapes.txt).  What a host-fed context needs of the queues it arranges itself:
+// pick_streams, dsvg_pipe.hip.)
 
 void dsvg_set_error(const char *fmt, ...)
 {

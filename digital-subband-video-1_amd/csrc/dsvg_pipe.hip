@@ -42,7 +42,16 @@ static bool streams_concurrent(hipStream_t a, hipStream_t b, hipEvent_t e0, hipE
 }
 // `want` streams that run concurrently with each other (as many as can be found among 12 candidates; the rest in
 // creation order); returns the number of mutually concurrent ones at the front of out[]
-static int pick_streams(hipStream_t *out, int want)
+// copy_out (round 5): a stream for the host-to-device copies of a host-fed context -- its FIFTH busy stream, and the runtime has four hardware
+// queues by default (GPU_MAX_HW_QUEUES).  Created lazily it landed wherever the runtime put it: behind a coding stream's kernels a batch's 12 GB
+// upload (210 ms) and the coding phase (25 ms) took turns -- 236 ms per step, profiles/r05_hostpin_timeline.txt -- elsewhere they did not, and
+// which it was changed from run to run (value_host_pinned 0.81 / 0.95 / 0.95 of the link in three runs of one tree).  Now it is probed like the
+// others: a queue of its own where the runtime has one left, else one that shares the ANALYSIS stream's queue and no other of ours (the upload in
+// front of the same batch's load and motion search: they wait for it anyway).  210 ms per step = the link's rate, three runs of three, with four
+// queues and with eight.
+// *copy_shared: 0 = own queue, 2 / 3 = own queue as a stream of the lowest / highest priority, 1 = shares the analysis stream's, -1 = no such
+// candidate (the caller creates a stream the plain way).
+static int pick_streams(hipStream_t *out, int want, hipStream_t *copy_out = nullptr, int *copy_shared = nullptr)
 {
     const int NC = 12;
     hipStream_t cand[NC] = {};
@@ -63,6 +72,42 @@ static int pick_streams(hipStream_t *out, int want)
     }
     const int good = n;
     for (int i = 0; i < nc && n < want; i++) if (!used[i]) { out[n++] = cand[i]; used[i] = true; }
+    if (copy_out) {
+        *copy_out = nullptr;
+        if (copy_shared) *copy_shared = -1;
+        if (probe && good == want && want >= 2) {
+            int with_analysis = -1;
+            for (int i = 0; i < nc && !*copy_out; i++) {
+                if (used[i]) continue;
+                bool all = true, others = true;          // concurrent with every picked stream / with every one but the analysis stream (out[1])
+                for (int k = 0; k < want && others; k++) {
+                    const bool cc = streams_concurrent(out[k], cand[i], e0, ea, eb);
+                    all = all && cc;
+                    if (k != 1) others = others && cc;
+                }
+                if (all) { *copy_out = cand[i]; used[i] = true; if (copy_shared) *copy_shared = 0; }
+                else if (others && with_analysis < 0) with_analysis = i;
+            }
+            if (!*copy_out && !getenv("DSV1_NO_PRIO_COPY_STREAM")) {
+                // none left among the plain streams (four hardware queues, all taken): the runtime keeps the queues of the other stream
+                // PRIORITIES apart from those -- a stream of the lowest, else the highest priority is probed the same way (a copy engine does
+                // not care about the priority of the queue that feeds it)
+                int lo = 0, hi = 0;
+                if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) {
+                    const int prios[2] = {lo, hi};
+                    for (int t = 0; t < 2 && !*copy_out; t++) {
+                        hipStream_t ps_ = nullptr;
+                        if (hipStreamCreateWithPriority(&ps_, hipStreamNonBlocking, prios[t]) != hipSuccess) { (void)hipGetLastError(); continue; }
+                        bool all = true;
+                        for (int k = 0; k < want && all; k++) all = streams_concurrent(out[k], ps_, e0, ea, eb);
+                        if (all) { *copy_out = ps_; if (copy_shared) *copy_shared = 2 + t; }
+                        else (void)hipStreamDestroy(ps_);
+                    }
+                } else (void)hipGetLastError();
+            }
+            if (!*copy_out && with_analysis >= 0) { *copy_out = cand[with_analysis]; used[with_analysis] = true; if (copy_shared) *copy_shared = 1; }
+        }
+    }
     for (int i = 0; i < nc; i++) if (!used[i]) (void)hipStreamDestroy(cand[i]);
     if (e0) (void)hipEventDestroy(e0);
     if (ea) (void)hipEventDestroy(ea);
@@ -112,6 +157,7 @@ struct dsvg_ctx {
     hipStream_t stx[DSVG_MAX_CODE_STREAMS] = {};   // further coding streams (a share of the pictures of every frame step each), created on first use
     hipEvent_t ev_fork = nullptr, ev_join[DSVG_MAX_CODE_STREAMS] = {};
     int code_streams = 1;
+    int copy_queue = -1;             // the copy stream's hardware queue: 0 its own, 1 the analysis stream's, -1 wherever the runtime put it (pick_streams)
     int streams_apart = 0;           // how many of {coding, analysis, second coding, fetch} were found on hardware queues of their own
     hipStream_t st_a = nullptr;      // analysis stream (frame load, pyramid, HME): overlaps coding of the previous batch
     hipStream_t st_l = nullptr;      // frame-load stream: st_a itself unless DSV1_CU_LOAD gives the streaming load kernels a CU-masked stream of their own
@@ -416,7 +462,11 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
         const int ncs = std::max(1, std::min(c->code_streams, DSVG_MAX_CODE_STREAMS));
         hipStream_t ps[3 + DSVG_MAX_CODE_STREAMS] = {};
         const int want = 2 + std::max(ncs, 2);
-        const int good = pick_streams(ps, want);
+        int copy_shared = -1;
+        const int good = pick_streams(ps, want, &c->st_h, &copy_shared);
+        c->copy_queue = copy_shared;
+        if (getenv("DSV1_STREAM_DEBUG")) fprintf(stderr, "[dsvg] %d of %d streams on hardware queues of their own; copy stream: %s\n", good, want,
+                                                 copy_shared == 0 ? "a queue of its own" : (copy_shared >= 2 ? "a queue of its own (priority stream)" : (copy_shared == 1 ? "shares the analysis stream's queue" : "as the runtime places it")));
         if (good < 0) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
         c->st = ps[0]; c->st_a = ps[1];
         if (const char *pr = getenv("DSV1_ANALYSIS_PRIO")) {    // experiment: the analysis stream at another priority (-1 high, 1 low)
@@ -610,6 +660,7 @@ extern "C" int dsvg_ctx_code_streams(dsvg_ctx *c, int n)
     return old;
 }
 extern "C" int dsvg_ctx_streams_apart(const dsvg_ctx *c) { return c ? c->streams_apart : 0; }
+extern "C" int dsvg_ctx_copy_queue(const dsvg_ctx *c) { return c ? c->copy_queue : -1; }
 extern "C" int dsvg_ctx_tile_stats2(dsvg_ctx *c, unsigned long long out[8], int enable)
 {
     if (!c || !out) return DSVG_ERR_ARG;
@@ -685,18 +736,16 @@ static int ingest_reserve(dsvg_ctx *c, size_t bytes, int *kout)
 {
     HIPCHK(hipSetDevice(c->device));
     if (!c->st_h) {
-        // The copy stream is the context's FIFTH busy stream, and the runtime has four hardware queues by default for the streams it creates:
-        // it shares a queue with a coding stream, whose kernels then sit behind a batch's 12 GB upload (200 ms) and the next upload behind
-        // them -- upload and coding take turns (profiles/r05_hostpin_timeline.txt: 236 ms per step for a 211 ms upload).  The cure is a
-        // hardware queue of its own: GPU_MAX_HW_QUEUES=8 in the environment before the runtime starts (this library's constructor sets it
-        // when nobody else has: dsvg_common.hip; bench.py does the same) -- 210 ms per step, the link's rate.  A stream created with a CU mask
-        // gets its own queue too and measured the same, but hung the frame-at-a-time ingest of dsv_enc once in three runs (many small copies
-        // on that stream; tests/test_gpu_stream.py -k drop_in): opt-in only, DSV1_INGEST_MASKED_STREAM=1.
+        // (small contexts, or no probed candidate: pick_streams placed none)  DSV1_INGEST_MASKED_STREAM=1: a stream created with a CU mask of
+        // all ones gets a hardware queue of its own whatever GPU_MAX_HW_QUEUES says -- and hung dsv_enc's frame-at-a-time ingest (many small
+        // copies) in a third of the runs of tests/test_gpu_stream.py -k drop_in: opt-in only
         uint32_t all[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
         if (!getenv("DSV1_INGEST_MASKED_STREAM") || hipExtStreamCreateWithCUMask(&c->st_h, 8, all) != hipSuccess) {
             (void)hipGetLastError();
             HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
         }
+    }
+    if (!c->ev_up[0]) {
         for (int i = 0; i < 2; i++) {
             HIPCHK(hipEventCreateWithFlags(&c->ev_up[i], hipEventDisableTiming));
             HIPCHK(hipEventCreateWithFlags(&c->ev_used[i], hipEventDisableTiming));

@@ -122,6 +122,10 @@ int dsvg_ctx_code_streams(dsvg_ctx *ctx, int n);
 /* how many of the context's four streams (coding, analysis, second coding, fetch) were placed on hardware queues of
  * their own by the probe at creation (4 = all apart; 0 = probe switched off with DSV1_NO_STREAM_PROBE) */
 int dsvg_ctx_streams_apart(const dsvg_ctx *ctx);
+/* where a throughput context's host-to-device copy stream sits: 0 = a hardware queue of its own (2 / 3: as a stream of the lowest / highest
+ * priority, whose queues the runtime keeps apart from the plain streams' four), 1 = it shares the analysis stream's queue, -1 = wherever the
+ * runtime put it (small contexts, probe off) */
+int dsvg_ctx_copy_queue(const dsvg_ctx *ctx);
 void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the first coding hipStream_t (operator-style callers: dsvg_download_recon, dsvg_pack_recons run on it) */
 /* Sparse P pictures: tiles of the fused inverse transform (128x64 pixels) counted since the previous call --
  * out[0], out[1] = tiles that took the general path (luma, chroma), out[2], out[3] = tiles found empty (no detail symbol,

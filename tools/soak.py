@@ -31,7 +31,7 @@ for k in range(N):
     n = rng.choice([3, 4, 5, 7])
     S = rng.choice([1, 1, 2, 5, 17, 33, 64])
     F = rng.choice([f for f in (1, 2, 3, n) if n % f == 0])        # (the batch API takes whole batches)
-    style = rng.choice([0, 1, 2, 3, 4, 5, 6])
+    style = rng.choice([0, 1, 2, 3, 4, 5, 6, 7])
     mode = rng.choice(['host', 'host', 'device', 'chain'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode
     cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
     if mode != 'chain' and rng.random() < 0.3:                 # round 4: ABR streams (rate control on the device; chain mode refuses them)
