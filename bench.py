@@ -793,24 +793,24 @@ def main():
             res["value_host_pinned"] = host_pinned
             shapes = {}
             try:
-                shapes["cfg2_1080p_intra"] = dict(shape_bench(pkg, A, dev, 1920, 1080, 0x5, 64, 12, 4, 0x10800001, 12, qp=85, gop=0, rc_mode_cli=1),
+                shapes["cfg2_1080p_intra"] = dict(shape_bench(pkg, A, dev, 1920, 1080, 0x5, 64, 12, 20, 0x10800001, 12, qp=85, gop=0, rc_mode_cli=1),
                                                   config="1920x1080 4:2:0 -gop0 -qp85 -rc_mode1, 64 streams x 12 frames per step")
-                shapes["cfg4_4k_gop12"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 16, 12, 4, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
+                shapes["cfg4_4k_gop12"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 16, 12, 16, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
                                                config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 16 closed GOPs x 12 frames per step")
-                shapes["cfg4_8gops"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 8, 12, 6, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
+                shapes["cfg4_8gops"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 8, 12, 24, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
                                             config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 8 closed GOPs x 12 frames per step: one GPU's share of config 4's 64 GOPs on an 8-GPU node")
-                shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 2, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
+                shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 12, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
                                                  config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: every quantiser from the packet before, rate control on the device), 2 streams x 30 frames per step")
                 # the content that leaves the lean kernels: flat moving objects force a third of the blocks intra (whole-grid
                 # k_fwd_mc_pix, k_mc for the intra blocks, dense symbols) -- same shape and batch as the headline
                 wc = A.gen_clip(W, H, FMT, 0x10800003, 4, style=4)
-                shapes["cfg3_worstcase"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 3, 0x10800003, 12, style=4, qp=QP, gop=GOP, rc_mode_cli=1, scd=0),
+                shapes["cfg3_worstcase"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 6, 0x10800003, 12, style=4, qp=QP, gop=GOP, rc_mode_cli=1, scd=0),
                                                        config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, %d closed GOPs x 12 frames per step, clip style 4 "
                                                               "(pan + texture with a flat square of a third of the height and a flat band over the bottom quarter, both changing every frame)" % args.gops,
                                                        intra_blocks_pct_of_P_pictures=intra_block_pct(A, wc, W, H, FMT, qp=QP, gop=GOP, rc_mode_cli=1, scd=0))
                 # the floor of the sparse kernels (verdict round 4): strong per-pixel noise that is new in every frame at -qp95 -- nearly every 8x8
                 # patch of every P picture carries level-1 symbols (the headline clip flags 5 % of its luma patches); same shape and batch
-                shapes["dense_residual"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 3, 0x10800003, 12, style=7, count_patches=True, qp=95, gop=GOP, rc_mode_cli=1, scd=0),
+                shapes["dense_residual"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 6, 0x10800003, 12, style=7, count_patches=True, qp=95, gop=GOP, rc_mode_cli=1, scd=0),
                                                 config="1920x1080 4:2:0 -gop12 -qp95 -rc_mode1 -scd0, %d closed GOPs x 12 frames per step, clip style 7 "
                                                        "(the headline's pan + texture under per-pixel noise of +-24 luma / +-12 chroma that changes every frame)" % args.gops)
                 shapes["decode_1080p_batched"] = dict(decode_bench(pkg, A, dev, 64, 2),
