@@ -25,6 +25,11 @@ struct HmeArgs {
     DMV *mvf;                // [pair][level][nblk]
     unsigned *aux_tex;       // [pair][nblk] block texture (for the high_detail pass)
     int *aux_var;            // [pair][nblk] centre-window variance
+    // (round 5) per source slot: the frame's luma plane in the caller's packed clip (row stride = the picture's width), or 0: the level-0 search
+    // reads a block's source and reference rows there when everything it can touch lies inside the picture (hme_block, `deep`) -- of the
+    // bordered copies only a ring exists for such frames (k_unpack, slot-table bit 29)
+    const unsigned long long *slot_y;
+    int deep_r;
     // [slot][nblk][4]: sum / sum of squares of the U and of the V block of every FULL block of a source slot (k_hme_csum), or nullptr:
     // level 0's chroma variance test then fetches the blocks itself
     unsigned *csum;
@@ -69,7 +74,8 @@ void launch_mc(hipStream_t st, const JobDev *jobs, int njobs, const McGeo &G, in
 int  unpack_fuses_level1(const FrameLayout &L);
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr,
                    uint8_t *slab1 = nullptr, const FrameLayout *L1 = nullptr, bool sides = false, bool sides1 = false,
-                   uint8_t *slab2 = nullptr, const FrameLayout *L2 = nullptr, bool sides2 = false, int n_chroma = -1);
+                   uint8_t *slab2 = nullptr, const FrameLayout *L2 = nullptr, bool sides2 = false, int n_chroma = -1,
+                   int ring_x16 = 0, int ring_y4 = 0);    // slot-table entries with bit 29: only the luma plane's outer ring_x16 x 16 columns / ring_y4 x 4 rows are copied
 int  unpack_fuses_level2(const FrameLayout &L, const FrameLayout &L1, const FrameLayout &L2);
 bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *slab, const FrameLayout &L);
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);

@@ -239,6 +239,13 @@ struct dsvg_ctx {
     std::vector<const uint8_t *> slot_cu, slot_cv;
     std::vector<int> slot_cs;
     unsigned long long *slot_cu_h = nullptr, *slot_cv_h = nullptr, *slot_cu_d = nullptr, *slot_cv_d = nullptr;
+    // (round 5) luma in place: per source slot the frame's luma plane in the caller's clip or null (HmeArgs.slot_y, JobDev.srcp[0]); of such a
+    // frame's bordered copy k_unpack writes a ring only (ring_x16 x 16 columns, ring_y4 x 4 rows in from each edge)
+    std::vector<const uint8_t *> slot_y;
+    unsigned long long *slot_y_h = nullptr, *slot_y_d = nullptr;
+    bool ydirect_ok = false;
+    int deep_r = 0, ring_x16 = 0, ring_y4 = 0;
+    long ydirect_frames = 0;
     int *slot_cs_h = nullptr, *slot_cs_d = nullptr;
     bool cdirect_ok = false;         // the geometry allows in-place chroma (even chroma planes, rows of whole 8-byte patches)
     long cdirect_frames = 0;         // frames loaded that way (tests)
@@ -312,6 +319,8 @@ static void ctx_free(dsvg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->tl_on) { (void)hipDeviceSynchronize(); tl_dump(c); }
+    if (c->slot_y_d) (void)hipFree(c->slot_y_d);
+    if (c->slot_y_h) (void)hipHostFree(c->slot_y_h);
     if (c->slot_cu_d) (void)hipFree(c->slot_cu_d);
     if (c->slot_cv_d) (void)hipFree(c->slot_cv_d);
     if (c->slot_cs_d) (void)hipFree(c->slot_cs_d);
@@ -588,8 +597,20 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
             hipMemcpy(c->slot_cs_d, c->slot_cs_h, 4 * ns, hipMemcpyHostToDevice) != hipSuccess) { dsvg_set_error("slot tables: upload failed"); return fail(DSVG_ERR_HIP); }
         // in place: the forward transforms read whole 8-byte patch rows and never leave the picture when the chroma planes are
         // even (no extra coefficient column: frame.c:39-42) and a multiple of 8 wide; both chroma planes alike
+        c->slot_y.assign(ns, nullptr);
+        if (hipHostMalloc((void **)&c->slot_y_h, 8 * ns + 64, hipHostMallocDefault) != hipSuccess || hipMalloc((void **)&c->slot_y_d, 8 * ns + 64) != hipSuccess) { dsvg_set_error("slot tables: out of memory"); return fail(DSVG_ERR_HIP); }
+        memset(c->slot_y_h, 0, 8 * ns);
+        if (hipMemset(c->slot_y_d, 0, 8 * ns + 64) != hipSuccess) { dsvg_set_error("slot tables: upload failed"); return fail(DSVG_ERR_HIP); }
         c->cdirect_ok = (c->L[0].w[1] % 8) == 0 && (c->L[0].h[1] % 2) == 0 && c->L[0].w[1] == c->L[0].w[2] && c->L[0].h[1] == c->L[0].h[2] &&
                         c->L[0].stride[1] == c->L[0].stride[2] && !getenv("DSV1_NO_CHROMA_IN_PLACE");
+        // luma in place (round 5): the geometry must take the motion search's full-block body and k_unpack's fused pyramid levels 1 and 2
+        // (the bordered copy is then read by the level-0 search alone), and the ring must leave an interior worth the trouble
+        c->deep_r = (2 << c->levels) + 8;               // a level-0 vector's reach (k_hme.hip, `deep`) + the nine-point search, half-pel lattice, window slack
+        c->ring_x16 = (c->bw + 2 * c->deep_r + 15) / 16;
+        c->ring_y4 = (c->bh + 2 * c->deep_r + 3) / 4;
+        c->ydirect_ok = c->cdirect_ok && c->levels >= 2 && (c->L[0].w[0] % 16) == 0 && (c->L[0].h[0] % 4) == 0 && unpack_fuses_level1(c->L[0]) &&
+                        unpack_fuses_level2(c->L[0], c->L[1], c->L[2]) && 2 * 16 * c->ring_x16 + 64 <= c->L[0].w[0] && 2 * 4 * c->ring_y4 + 64 <= c->L[0].h[0] &&
+                        c->ring_x16 < 256 && c->ring_y4 < 256 && !getenv("DSV1_NO_LUMA_IN_PLACE") && !getenv("DSV1_NO_FUSE_LEVEL2");
     }
     (void)J;
     // the pipeline streams are non-blocking (no implicit ordering against the NULL stream the memsets above ran on)
@@ -838,7 +859,10 @@ static int ingest_release(dsvg_ctx *c, int k)
 static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d, int n_chroma = -1)
 {
     if (!tab_d) {       // contiguous slots, chroma copied: those slots' chroma is the bordered copy (again)
-        bool changed = false;
+        bool changed = false, ychanged = false;
+        for (int sl = first_slot; sl < first_slot + n; sl++)
+            if (c->slot_y[sl]) { c->slot_y[sl] = nullptr; c->slot_y_h[sl] = 0; ychanged = true; }
+        if (ychanged) HIPCHK(hipMemcpyAsync(c->slot_y_d, c->slot_y_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
         for (int sl = first_slot; sl < first_slot + n; sl++) {
             const uint8_t *u = c->src[0].p + (size_t)sl * c->L[0].pitch + c->L[0].off[1], *v = c->src[0].p + (size_t)sl * c->L[0].pitch + c->L[0].off[2];
             if (c->slot_cu[sl] != u || c->slot_cs[sl] != c->L[0].stride[1]) {
@@ -866,7 +890,7 @@ static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, si
     const bool sides2 = fuse2 && sides && !no_lsides && level_sides_ok(c->src[2].p, c->L[2]);
     tl_mark(c, c->st_l, "load0");
     launch_unpack(c->st_l, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1,
-                  fuse2 ? c->src[2].p : nullptr, fuse2 ? &c->L[2] : nullptr, sides2, n_chroma);
+                  fuse2 ? c->src[2].p : nullptr, fuse2 ? &c->L[2] : nullptr, sides2, n_chroma, c->ring_x16, c->ring_y4);
     launch_extend(c->st_l, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
@@ -932,7 +956,7 @@ extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, con
     const size_t ysz = (size_t)c->L[0].w[0] * c->L[0].h[0], csz = (size_t)c->L[0].w[1] * c->L[0].h[1];
     const bool can = chroma_in_place && c->cdirect_ok && ((uintptr_t)yuv_dev % 16) == 0 && (frame_pitch % 16) == 0 && (ysz % 16) == 0 && (csz % 16) == 0;
     std::vector<int> tab((size_t)n);
-    bool changed = false;
+    bool changed = false, ychanged = false;
     int n_direct = 0;
     for (int i = 0; i < n; i++) {
         const int sl = slots[i];
@@ -947,9 +971,15 @@ extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, con
             c->slot_cu_h[sl] = (unsigned long long)(uintptr_t)u; c->slot_cv_h[sl] = (unsigned long long)(uintptr_t)v; c->slot_cs_h[sl] = st;
             changed = true;
         }
-        tab[(size_t)i] = sl | (direct ? 0x40000000 : 0);
+        // ... and its luma plane (round 5): the level-0 search and the forward transforms read it in the clip, the bordered copy gets its ring
+        const bool ydirect = direct && c->ydirect_ok && with_pyramid;
+        const uint8_t *yp = ydirect ? fr : nullptr;
+        if (c->slot_y[sl] != yp) { c->slot_y[sl] = yp; c->slot_y_h[sl] = (unsigned long long)(uintptr_t)yp; ychanged = true; }
+        tab[(size_t)i] = sl | (direct ? 0x40000000 : 0) | (ydirect ? 0x20000000 : 0);
         c->cdirect_frames += direct;
+        c->ydirect_frames += ydirect;
     }
+    if (ychanged) HIPCHK(hipMemcpyAsync(c->slot_y_d, c->slot_y_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
     if (changed) {
         // (the pinned mirrors are only rewritten here, and every load is followed by a host wait on this stream -- the luma
         // sums or the motion search -- before the next one: no copy of an older state is still in flight)
@@ -968,6 +998,7 @@ extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const 
     return dsvg_load_frames_map_ex(c, n, slots, yuv_dev, frame_pitch, with_pyramid, nullptr);
 }
 extern "C" long dsvg_ctx_chroma_in_place_frames(const dsvg_ctx *c) { return c ? c->cdirect_frames : 0; }
+extern "C" long dsvg_ctx_luma_in_place_frames(const dsvg_ctx *c) { return c ? c->ydirect_frames : 0; }
 
 extern "C" int dsvg_get_luma_sums(dsvg_ctx *c, int first_slot, int n, unsigned *sums_out)
 {
@@ -1009,6 +1040,7 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
     A.slot_cu = c->slot_cu_d; A.slot_cv = c->slot_cv_d; A.slot_cs = c->slot_cs_d;
+    A.slot_y = c->ydirect_ok ? c->slot_y_d : nullptr; A.deep_r = c->deep_r;
     A.mvf = c->mvf; A.aux_tex = c->aux_tex; A.aux_var = c->aux_var;
     A.csum = getenv("DSV1_NO_CHROMA_SUMS") ? nullptr : c->csum;
     A.levels = c->levels; A.nxb = c->nbh; A.nyb = c->nbv; A.nblk = c->nblk; A.blk_w = c->bw; A.blk_h = c->bh;
@@ -1283,6 +1315,7 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
             jb.bits = c->bits + (size_t)j.out_slot * c->bits_per_job;
             jb.src = c->src[0].p + (size_t)j.src_slot * c->L[0].pitch;
             jb.srcp[0] = jb.src + c->L[0].off[0]; jb.srcs[0] = c->L[0].stride[0];
+            if (c->slot_y[(size_t)j.src_slot]) { jb.srcp[0] = c->slot_y[(size_t)j.src_slot]; jb.srcs[0] = c->L[0].w[0]; }      // luma in place (round 5)
             jb.srcp[1] = c->slot_cu[(size_t)j.src_slot]; jb.srcp[2] = c->slot_cv[(size_t)j.src_slot]; jb.srcs[1] = jb.srcs[2] = c->slot_cs[(size_t)j.src_slot];
             jb.ref = isP ? c->recon.p + (size_t)j.ref_recon_slot * c->L[0].pitch : nullptr;
             jb.recon = j.recon_slot >= 0 ? c->recon.p + (size_t)j.recon_slot * c->L[0].pitch : nullptr;

@@ -11,9 +11,10 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // tightly packed planar frames -> interiors of bordered frames (grid.y = plane, grid.z = frame)
 __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv, size_t yuv_pitch,
                                                 uint8_t *__restrict__ slab, FrameLayout L, int first_slot,
-                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1, int sides,
+                                                const int *__restrict__ slot_tab, uint8_t *__restrict__ slab1, FrameLayout L1, int sides_ring,
                                                 uint8_t *__restrict__ slab2, FrameLayout L2)
 {
+    const int sides = sides_ring & 7;                   // (bits 8..23: the ring's extents, below)
     // sides: the 64-byte left / right borders of every row are written here too (launch_unpack checked that every plane
     // takes a 16-byte path): they complete the 128-byte lines the row's first and last pixels lie in, where a separate
     // border kernel writes half lines; the rows above and below the picture are left to k_extend16
@@ -21,8 +22,14 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
     // slot table entries: bit 30 = this frame's chroma stays where the caller has it (dsvg_load_frames_map_ex, "in place"):
     // only its luma plane is unpacked, bordered and fed to the pyramid
     const int raw = slot_tab ? slot_tab[f] : first_slot + f;
-    const int slot = raw & 0x3fffffff;
+    const int slot = raw & 0x1fffffff;
     if ((raw & 0x40000000) && c > 0) return;
+    // bit 29 (round 5): the frame's LUMA stays in the caller's clip too -- of the bordered copy only a ring is written, the picture's outer
+    // (sides_ring >> 8 & 0xff) x 16 columns and (sides_ring >> 16 & 0xff) x 4 rows (+ the border itself): what the level-0 motion search reads of a
+    // frame through the bordered layout (blocks near an edge, whose candidates may leave the picture); every other block reads the clip
+    // (hme_block, `deep`), and so do the forward transforms (JobDev.srcp).  The pyramid levels are produced as ever.
+    const bool ring = (raw & 0x20000000) != 0;
+    const int ring_x = (sides_ring >> 8) & 0xff, ring_y = (sides_ring >> 16) & 0xff;
     const int w = L.w[c], h = L.h[c];
     size_t poff = 0;
     for (int k = 0; k < c; k++) poff += (size_t)L.w[k] * L.h[k];
@@ -41,8 +48,10 @@ __global__ __launch_bounds__(256) void k_unpack(const uint8_t *__restrict__ yuv,
             u32x4 q[4];
 #pragma unroll
             for (int r = 0; r < 4; r++) q[r] = __builtin_nontemporal_load(reinterpret_cast<const u32x4 *>(src + (size_t)(4 * y4 + r) * w) + x);
+            if (!ring || ring_x == 0 || x < ring_x || x >= nv - ring_x || y4 < ring_y || y4 >= hq - ring_y) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) __builtin_nontemporal_store(q[r], reinterpret_cast<u32x4 *>(dst + (size_t)(4 * y4 + r) * L.stride[0]) + x);
+                for (int r = 0; r < 4; r++) __builtin_nontemporal_store(q[r], reinterpret_cast<u32x4 *>(dst + (size_t)(4 * y4 + r) * L.stride[0]) + x);
+            }
             const bool edge = x == 0 || x == nv - 1;
             if (sides && edge) {
 #pragma unroll
@@ -225,7 +234,7 @@ __global__ __launch_bounds__(256) void k_extend(uint8_t *__restrict__ slab, Fram
     if (c >= nplanes) return;
     const int raw = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
     if (raw < 0) return;
-    const int f = raw & 0x3fffffff;
+    const int f = raw & 0x1fffffff;
     if ((raw & 0x40000000) && c > 0) return;            // (source frames whose chroma stays in the caller's clip: see k_unpack)
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
@@ -281,7 +290,7 @@ __global__ __launch_bounds__(256) void k_extend16(uint8_t *__restrict__ slab, Fr
     if (c >= nplanes) return;
     const int raw = slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z;
     if (raw < 0) return;
-    const int f = raw & 0x3fffffff;
+    const int f = raw & 0x1fffffff;
     if ((raw & 0x40000000) && c > 0) return;            // (source frames whose chroma stays in the caller's clip: see k_unpack)
     const int w = L.w[c], h = L.h[c], s = L.stride[c];
     uint8_t *p = slab + (size_t)f * L.pitch + L.off[c];
@@ -333,7 +342,7 @@ __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab,
 {
     // sides: the level's width is a multiple of 16: the threads of a row's first and last pixels also write its 64-byte side
     // borders (whole 128-byte lines; k_extend16 then adds the rows above and below only)
-    const int f = (slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z) & 0x3fffffff;
+    const int f = (slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z) & 0x1fffffff;
     const uint8_t *sp = sslab + (size_t)f * SL.pitch + SL.off[0];
     uint8_t *dp = dslab + (size_t)f * DL.pitch + DL.off[0];
     const int dw = DL.w[0], dh = DL.h[0];
@@ -376,7 +385,7 @@ __global__ __launch_bounds__(256) void k_ds2x(const uint8_t *__restrict__ sslab,
 __global__ __launch_bounds__(256) void k_luma_sum(const uint8_t *__restrict__ slab, FrameLayout L, int first,
                                                   unsigned *__restrict__ sums, const int *__restrict__ slot_tab)
 {
-    const int f = (slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z) & 0x3fffffff;
+    const int f = (slot_tab ? slot_tab[blockIdx.z] : first + (int)blockIdx.z) & 0x1fffffff;
     const uint8_t *p = slab + (size_t)f * L.pitch + L.off[0];
     const int w = L.w[0], h = L.h[0];
     unsigned acc = 0;
@@ -433,7 +442,7 @@ bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *sl
     return ok;
 }
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
-                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2, int n_chroma)
+                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2, int n_chroma, int ring_x16, int ring_y4)
 {
     FrameLayout dummy = L;
     // algorithmic bytes: every copied plane read once and written once (n_chroma: the frames whose chroma is copied too -- the
@@ -447,7 +456,7 @@ void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t
     const long items = fused ? (long)(L.w[0] >> 4) * (L.h[0] >> 2) : (long)L.w[0] * L.h[0] / 16;
     const long citems = n_chroma > 0 ? (long)L.w[1] * L.h[1] / 16 : 0;
     hipLaunchKernelGGL(k_unpack, dim3(nblk(std::max(items, citems), 512), n_chroma > 0 ? 3 : 1, n), dim3(256), 0, st, yuv, yuv_pitch, slab, L, first, slot_tab,
-                       slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0) | (sides && sides2 ? 4 : 0), slab2, L2 ? *L2 : dummy);
+                       slab1, L1 ? *L1 : dummy, (sides ? 1 : 0) | (sides && sides1 ? 2 : 0) | (sides && sides2 ? 4 : 0) | ((ring_x16 & 0xff) << 8) | ((ring_y4 & 0xff) << 16), slab2, L2 ? *L2 : dummy);
     if (pf) pf->end(st);
 }
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L)

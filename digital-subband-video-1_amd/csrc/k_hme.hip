@@ -307,7 +307,8 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     const int cg = tid & 15, rg = tid >> 4;             // column group (4 px) / row group
     const int step = 1 << level;
     const FrameLayout &L = A.L[level];
-    const int fw = L.w[0], fh = L.h[0], stride = L.stride[0];
+    const int fw = L.w[0], fh = L.h[0];
+    int stride = L.stride[0];
     const int BW = A.blk_w, BH = A.blk_h;
     const int bx = (i * BW) >> level, by = (j * BH) >> level;
     // (the slot tables were written by the host before the launch: read through the constant address space they come by scalar
@@ -317,6 +318,26 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     const uint8_t *sp = A.slab[level] + (size_t)cur * L.pitch + L.off[0];
     const uint8_t *rp = A.slab[level] + (size_t)rf * L.pitch + L.off[0];
     const int bw = FAST ? 64 : min(max(fw - bx, 0), BW), bh = FAST ? 4 * NKB : min(max(fh - by, 0), BH);
+    int sstride = stride;                               // the SOURCE frame's row stride (its rows are read inside the picture only)
+    if constexpr (LEVEL0) {
+        // Round 5: frames whose luma stays in the caller's clip (HmeArgs.slot_y; of their bordered copies only a ring exists).  The block's
+        // SOURCE rows come from the clip whenever the frame has it there (row stride = the picture's width).  Its REFERENCE rows do when
+        // the reference frame has it too and the block lies `deep_r` pixels or more from every edge: it can then touch no pixel outside the
+        // picture -- a level-0 vector is at most 2^(levels+1) - 1 full pixels long (a level adds +-1 of its own pixels to twice its parent's
+        // vector, hme.c:452-541), the nine-point search, the half-pel lattice and the windows' slack add a few.  Every other block reads the
+        // reference's bordered copy, whose ring reaches a block and twice deep_r in from each edge.  One stride per frame for the whole block,
+        // so every site below is as it was.  Wave-uniform: a wave is a block.
+        if (A.slot_y) {
+            typedef const __attribute__((address_space(4))) unsigned long long *HmeCU64;
+            const unsigned long long cy = ((HmeCU64)A.slot_y)[cur], ry = ((HmeCU64)A.slot_y)[rf];
+            const int R = A.deep_r;
+            // (the 14x14 statistics window around the block's centre leaves the picture beside a narrow edge block: those blocks keep the
+            // bordered copy, whose ring holds them)
+            const int wx0 = bx + (bw >> 1) - WIN / 2, wy0 = by + (bh >> 1) - WIN / 2;
+            if (cy && wx0 >= 0 && wy0 >= 0 && wx0 + WIN <= fw && wy0 + WIN <= fh) { sp = reinterpret_cast<const uint8_t *>(cy); sstride = fw; }
+            if (ry && bx >= R && by >= R && bx + bw + R <= fw && by + bh + R <= fh) { rp = reinterpret_cast<const uint8_t *>(ry); stride = fw; }
+        }
+    }
     DMV *mf = A.mvf + ((size_t)pair * (A.levels + 1) + level) * A.nblk;
     const DMV *parent = level < A.levels ? A.mvf + ((size_t)pair * (A.levels + 1) + level + 1) * A.nblk : nullptr;
 
@@ -351,17 +372,17 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
     }
     unsigned srcw[NKR];
     if constexpr (FAST) {
-        auto sq = dsvg_global(sp + (long)by * stride + bx);
-        unsigned lro = lane_ro;
+        auto sq = dsvg_global(sp + (long)by * sstride + bx);
+        unsigned lro = (unsigned)(r0 * sstride + xcol);          // (lane_ro with the source frame's stride)
         HME_LRO_BARRIER(1, lro);
 #pragma unroll
-        for (int k = 0; k < NKR; k++) { srcw[k] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(sq + lro); sq += stride; }
+        for (int k = 0; k < NKR; k++) { srcw[k] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(sq + lro); sq += sstride; }
     } else {
 #pragma unroll
         for (int k = 0; k < NKR; k++) {
             const int r = r0 + k;
             srcw[k] = 0;
-            if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * stride + bx + xcol);
+            if (cmask && ROWOK(k)) srcw[k] = *reinterpret_cast<const unsigned *>(sp + (size_t)(by + r) * sstride + bx + xcol);
             srcw[k] &= cmask;
         }
     }
@@ -866,7 +887,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             }
         }
         smis = 1;                                              // pixel wx = bx + 25 sits at byte 1 of the staged dwords
-    } else smis = load_win<8, WIN>(S.swin, 24, sp, stride, wx, wy, WIN, WIN);
+    } else smis = load_win<8, WIN>(S.swin, 24, sp, sstride, wx, wy, WIN, WIN);
     if (UNI && have_win) {
         // ... and the reference patch (19x20 around the vector for the lattice, or the full-pel 14x14 window) lies inside the union
         // window: taken out of it through registers (the patch's storage overlaps the window's)
@@ -1241,7 +1262,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
             for (int b4 = 0; b4 < 4; b4++) {
                 const int x = xcol + b4;
                 if (x >= bw) continue;
-                const uint8_t *sx = sp + (size_t)(by + r) * stride + bx + x;     // rare path: source pixels straight from global
+                const uint8_t *sx = sp + (size_t)(by + r) * sstride + bx + x;    // rare path: source pixels straight from global
                 const uint8_t *zx = rp + (size_t)(by + r) * stride + bx + x;     // and the co-located reference pixels
                 const int pa = sx[0], pb = zx[0];
                 const int back = d_sat8(mean + d_sat8(pa - mean + 128) - 128);
@@ -1250,7 +1271,7 @@ static __device__ __forceinline__ void hme_block(const HmeArgs &A, int level, in
                     const int qx = x >= qw, qy = r >= qh;
                     const int lx = x - qx * qw, ly = r - qy * qh;        // position inside the quadrant
                     const int la = lx ? sx[-1] : pa, lb = lx ? zx[-1] : pb;
-                    const int ua = ly ? sx[-stride] : pa, ub = ly ? zx[-stride] : pb;
+                    const int ua = ly ? sx[-sstride] : pa, ub = ly ? zx[-stride] : pb;
                     const int dif = abs(pa - pb);
                     unsigned good = (unsigned)(abs(pa - la) + abs(pa - ua) + abs(pb - lb) + abs(pb - ub));
                     unsigned evil = 0;

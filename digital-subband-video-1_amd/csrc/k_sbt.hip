@@ -1310,8 +1310,11 @@ __global__ __launch_bounds__(256) FWD_B4T_ATTR void k_fwd_b4t(const JobDev *__re
                 y = y < 0 ? 1 : (y > H - 1 ? H - 1 : y);            // top mirror / bottom clamp (sbt.c:171-175,193-195)
                 const unsigned ro = (unsigned)(min(y, g.ph - 1) * pxs + 8 * I);
                 mmv[r] = dsvg_ld2(pxg + ro);
-                lfv[r] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro - 4u);
-                rgv[r] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + ro + 8u);
+                // (the dword left of the row's first patch / right of its last one is replaced by the mirror / clamp fix-up below: it is not
+                // fetched from outside the plane -- a plane that lives in the caller's packed clip has no border, and the first row of the
+                // clip's first frame nothing in front of it)
+                lfv[r] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + (ledge ? ro : ro - 4u));
+                rgv[r] = *reinterpret_cast<const DSVG_GLOBAL unsigned *>(pxg + (redge ? ro + 4u : ro + 8u));
             };
 #pragma unroll
             for (int r = 0; r < FB4T_AHEAD && r < 10; r++) request(r);
@@ -1404,8 +1407,8 @@ __global__ __launch_bounds__(256) FWD_B4T_ATTR void k_fwd_b4t(const JobDev *__re
         if (y < g.ph) {
             const uint8_t *row = px + (size_t)y * pxs + 8 * I;
             const uint2 m = *reinterpret_cast<const uint2 *>(row);
-            const unsigned lft = *reinterpret_cast<const unsigned *>(row - 4);
-            const unsigned rgt = *reinterpret_cast<const unsigned *>(row + 8);
+            const unsigned lft = *reinterpret_cast<const unsigned *>(I == 0 ? row : row - 4);                  // (replaced below where it lies outside the plane: not fetched from there)
+            const unsigned rgt = *reinterpret_cast<const unsigned *>((8 * I + 8 > W - 1) ? row + 4 : row + 8);
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 v[1 + i] = (int)((m.x >> (8 * i)) & 0xff) - 128;

@@ -180,10 +180,17 @@ int dsvg_load_frames_map(dsvg_ctx *ctx, int n, const int *slots, const void *yuv
  * the pyramid (what a frame needs as a motion search REFERENCE; frame.c:122-164,240-327, hme.c:667-681).  The clip must stay
  * unchanged until the pictures coded from those slots have been fetched AND the frame that follows each of them in its stream
  * has been analysed.  Needs even chroma planes a multiple of 8 wide and a 16-byte aligned clip; otherwise (or with
- * DSV1_NO_CHROMA_IN_PLACE) the frames are copied whole.  dsvg_ctx_chroma_in_place_frames: how many frames took it (tests). */
+ * DSV1_NO_CHROMA_IN_PLACE) the frames are copied whole.  dsvg_ctx_chroma_in_place_frames: how many frames took it (tests).
+ * Round 5, luma in place: where the geometry allows (luma a multiple of 16 wide and 4 high, two or more pyramid levels, a picture
+ * wider and taller than twice the ring below + 64) a flagged frame's LUMA stays in the clip as well -- same contract, nothing
+ * new for the caller.  The forward transforms read it there, and so does the level-0 motion search for every block that cannot
+ * leave the picture; of the bordered copy only a ring is written (a block + twice the search's reach in from each edge, plus
+ * the border), which blocks near an edge read.  The pyramid levels are built as ever.  DSV1_NO_LUMA_IN_PLACE switches it
+ * off; dsvg_ctx_luma_in_place_frames counts the frames that took it. */
 int dsvg_load_frames_map_ex(dsvg_ctx *ctx, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid,
                             const unsigned char *chroma_in_place);
 long dsvg_ctx_chroma_in_place_frames(const dsvg_ctx *ctx);
+long dsvg_ctx_luma_in_place_frames(const dsvg_ctx *ctx);
 int dsvg_get_luma_sums(dsvg_ctx *ctx, int first_slot, int n, unsigned *sums_out);   /* raw sums, syncs */
 int dsvg_get_avg_luma(dsvg_ctx *ctx, int first_slot, int n, int *avg_out);           /* syncs */
 

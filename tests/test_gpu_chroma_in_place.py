@@ -94,3 +94,38 @@ def test_plain_device_clip_may_change_right_after_submit(pkg, orc):
         b.close()
     for s in range(S):
         assert got[s] == want[s], "stream %d differs" % s
+
+
+@pytest.mark.parametrize("w,h,fmt,S,F", [(704, 480, A.SUBSAMP_420, 2, 6),      # 24-pixel blocks: the last column is 8 wide, its statistics window leaves the picture
+                                         (704, 480, A.SUBSAMP_422, 2, 6),
+                                         (1280, 720, A.SUBSAMP_420, 1, 4),
+                                         (1920, 1080, A.SUBSAMP_420, 1, 3),    # full 64x48 blocks: the motion search's register body
+                                         (1920, 1088, A.SUBSAMP_444, 1, 3)])
+def test_luma_in_place_equals_oracle_and_the_switch(pkg, orc, monkeypatch, w, h, fmt, S, F):
+    """round 5: a held device clip keeps its LUMA where it is too (include/dsvg.h, dsvg_load_frames_map_ex): the forward transforms and the
+    level-0 motion search's interior blocks read the clip, the bordered copy is a ring.  Same bytes as the oracle and as with the
+    switch off; the clip is overwritten as soon as its batch is collected."""
+    L = pkg.lib()
+    L.dsvg_ctx_luma_in_place_frames.restype = C.c_long
+    L.dsvg_ctx_luma_in_place_frames.argtypes = [C.c_void_p]
+    kw = dict(qp=80, gop=2 * F, rc_mode_cli=1)
+    clips = [A.gen_clip(w, h, fmt, 0x1A7A0 + s, 2 * F, style=1 + s) for s in range(S)]
+    want = [A.orc_encode(clips[s], A.orc_cfg(w, h, fmt, **kw), eos=False)[0] for s in range(S)]
+    garbage = np.full(S * F * clips[0].shape[1], 0x5A, dtype=np.uint8)
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("DSV1_NO_LUMA_IN_PLACE", "1")
+        b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **kw), S, F)
+        try:
+            got = [b""] * S
+            dev = [b.upload(np.stack([clips[s][k * F:(k + 1) * F] for s in range(S)])) for k in range(2)]
+            for k in range(2):
+                part = b.encode(dev[k], on_device=True)
+                got = [g + p for g, p in zip(got, part)]
+                A.chk(L, L.dsvg_dev_upload(b.ctx, dev[k], garbage.ctypes.data, garbage.nbytes))
+            n = L.dsvg_ctx_luma_in_place_frames(b.ctx)
+        finally:
+            b.close()
+        for s in range(S):
+            assert got[s] == want[s], "stream %d differs (luma in place %s)" % (s, "off" if off else "on")
+        assert n == (0 if off else 2 * S * (F - 1)), n
