@@ -3,7 +3,7 @@
 tiles of the fast inverse kernel and the 16-byte border paths apply), formats, quantisers, GOP lengths, content styles and
 batch shapes (several streams side by side, frames per call; host clips, device clips with in-place chroma, one stream in
 GOP-parallel chain mode) -- product stream against the oracle's, byte for byte.
-usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case)"""
+usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case; SOAK_MODE=host|device|chain: every case in that mode)"""
 import importlib, os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -32,7 +32,7 @@ for k in range(N):
     S = rng.choice([1, 1, 2, 5, 17, 33, 64])
     F = rng.choice([f for f in (1, 2, 3, n) if n % f == 0])        # (the batch API takes whole batches)
     style = rng.choice([0, 1, 2, 3, 4, 5, 6, 7])
-    mode = rng.choice(['host', 'host', 'device', 'chain'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode
+    mode = os.environ.get('SOAK_MODE') or rng.choice(['host', 'host', 'device', 'chain'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode
     cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
     if mode != 'chain' and rng.random() < 0.3:                 # round 4: ABR streams (rate control on the device; chain mode refuses them)
         cli['rc_mode_cli'] = 0
