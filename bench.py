@@ -547,6 +547,7 @@ def main():
         b.prof_enable([prof_kernel])
     b.submit(src, on_device=ondev, held=True)                  # fill the pipeline
     sync_all()
+    dropped0 = b.dropped_recons()[0]
     b.mark(0)
     t0 = time.perf_counter()
     if not ondev:
@@ -559,6 +560,7 @@ def main():
     b.mark(1)                                       # (behind the last step's coding work on the first coding stream, which joins the others)
     sync_all()
     dt = time.perf_counter() - t0
+    dropped_per_step = (b.dropped_recons()[0] - dropped0) / float(max(args.steps, 1))
     gpu_ms = b.mark_ms()                            # the same region by HIP events on the device
     # the bytes the LAST TIMED step produced (all streams, in stream order), hashed before anything reuses their buffers;
     # compared further down with bytes derived from the reference encoder's output for the same clips and frame numbers
@@ -750,7 +752,11 @@ def main():
                        "host_cores_rank0": len(my_cores), "numa_node_of_gpu_rank0": numa_node,
                        "streams_on_own_hw_queue": L.dsvg_ctx_streams_apart(b.ctx),
                        "copy_stream_queue": {0: "own", 2: "own (lowest-priority stream)", 3: "own (highest-priority stream)", 1: "shares the analysis stream's", -1: "as the runtime placed it"}.get(L.dsvg_ctx_copy_queue(b.ctx), "?"),
-                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES")},
+                       "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "pictures_without_reconstruction_per_step_rank0": dropped_per_step,
+                       "pictures_without_reconstruction_note": "the last picture of a closed GOP is a reference picture nobody predicts from: the reference encoder "
+                                                               "reconstructs it and never reads it (dsv_encoder.c:665-708); here it is coded without the inverse "
+                                                               "transform -- same packets (bit_exact_timed_output); DSV1_RECON_ALL=1 reconstructs every picture"},
             "bit_exact_vs_cpu": bit_exact,
             "bit_exact_timed_output": timed_check,
             "roofline": kinfo,

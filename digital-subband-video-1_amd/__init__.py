@@ -51,6 +51,8 @@ def lib():
         L.dsv1_batch_open.argtypes = [_C.POINTER(_C.c_void_p), _C.POINTER(Encoder), _C.c_int, _C.c_int, _C.c_int]
         L.dsv1_batch_close.argtypes = [_C.c_void_p]
         L.dsv1_batch_set_fnum.argtypes = [_C.c_void_p, _C.c_int, _C.c_uint32]
+        L.dsv1_batch_dropped_recons.restype = _C.c_long
+        L.dsv1_batch_dropped_recons.argtypes = [_C.c_void_p, _C.POINTER(_C.c_long)]
         L.dsv1_batch_encode.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
         L.dsv1_batch_submit.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
         L.dsv1_batch_collect.argtypes = [_C.c_void_p, _C.POINTER(Buf)]
@@ -183,6 +185,13 @@ class Batch:
 
     def set_fnum(self, stream, fnum):
         self.L.dsv1_batch_set_fnum(self.h, stream, fnum)
+
+    def dropped_recons(self):
+        """(dropped, remedied): reference pictures coded without a reconstruction because nobody predicts from them / coded again
+        because a renumbered stream did after all (include/dsv1_api.h, dsv1_batch_dropped_recons)"""
+        r = _C.c_long(0)
+        n = self.L.dsv1_batch_dropped_recons(self.h, _C.byref(r))
+        return int(n), int(r.value)
 
     def encoder(self, stream):
         """the stream's DSV_ENCODER (owned by the batch): its public parameter fields may be changed between submits"""

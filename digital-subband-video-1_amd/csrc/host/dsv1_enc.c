@@ -49,6 +49,16 @@ struct dsv1_batch {
     unsigned char *rpar;             /* per stream: which of its two reconstruction slots holds the current reference */
     unsigned char *has_recon;        /* per stream: a reference picture has been coded */
     unsigned char *border_skipped;   /* per stream: the last reconstruction was coded with border_hint (next picture: a GOP start) */
+    /* Round 5: a picture nobody predicts from gets no reconstruction (dsvg_pic_job.recon_slot = -1: no inverse transform).  Inside a call
+     * that is known exactly (the next picture of the stream has no reference: it starts a GOP or a scene).  For a call's LAST picture it
+     * is known when the next frame number starts a GOP (dsv_encoder.c:702-708) -- unless the caller renumbers the stream in between
+     * (dsv1_batch_set_fnum); the next submit then finds a P picture where a GOP start was promised and codes the dropped picture once
+     * more, this time keeping its reconstruction (remedy_dropped: same source slot, vectors, flags and quantiser -- they are still in
+     * the other half of pics[] -- the packet is discarded).  ABR streams keep their last reconstruction (their quantisers live on the device). */
+    unsigned char *recon_dropped;    /* per stream: the last picture of the batch before was coded without a reconstruction */
+    int nf_prev;                     /* frames per stream of the batch before */
+    int keep_all;                    /* DSV1_RECON_ALL=1: reconstruct every reference picture, read or not */
+    long n_dropped, n_remedied;
     unsigned *luma;
     DSV_MV *mv_tmp;
     dsvg_pic_job *jobs;
@@ -137,7 +147,7 @@ void dsv1_batch_close(dsv1_batch *b)
     }
     free(b->pics); free(b->mvpool); free(b->stabpool); free(b->prefixpool);
     free(b->slots_cur); free(b->slots_ref); free(b->pair_pic); free(b->out_slots);
-    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->rcjobs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped);
+    free(b->luma); free(b->mv_tmp); free(b->jobs); free(b->outs); free(b->rcjobs); free(b->sc0.pkt); free(b->rpar); free(b->has_recon); free(b->border_skipped); free(b->recon_dropped);
     free(b->ch_start); free(b->ch_len); free(b->ch_pair); free(b->ch_cur);
     free(b->rc_dev); free(b->rc_par);
     free(b);
@@ -179,6 +189,7 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     B_ALLOC(rpar, unsigned char, nstreams, 1);
     B_ALLOC(has_recon, unsigned char, nstreams, 1);
     B_ALLOC(border_skipped, unsigned char, nstreams, 1);
+    B_ALLOC(recon_dropped, unsigned char, nstreams, 1);
     B_ALLOC(luma, unsigned, (size_t)b->rows * nstreams, sizeof(unsigned));
     B_ALLOC(mv_tmp, DSV_MV, (size_t)np * b->nblk, sizeof(DSV_MV));
     B_ALLOC(jobs, dsvg_pic_job, np, sizeof(dsvg_pic_job));
@@ -187,6 +198,7 @@ static int batch_open_on(dsv1_batch **out, DSV_ENCODER *encs, int own, int devic
     B_ALLOC(rc_dev, dsvg_rc_state, nstreams, sizeof(dsvg_rc_state));
     B_ALLOC(rc_par, dsvg_rc_state, 2 * (size_t)nstreams, sizeof(dsvg_rc_state));
     { const char *e = getenv("DSV1_ABR_SERIAL"); b->abr_dev = !chains && !(e && atoi(e) != 0); }
+    { const char *e = getenv("DSV1_RECON_ALL"); b->keep_all = e && atoi(e) != 0; }
     if (chains) {
         B_ALLOC(ch_start, int, (size_t)F + 1, sizeof(int));
         B_ALLOC(ch_len, int, (size_t)F + 1, sizeof(int));
@@ -728,9 +740,52 @@ static void asm_piece(void *ctx, int first, int count)
 static int stage_n(dsv1_batch *b, const void *yuv_host, int nf);
 static int code_chains(dsv1_batch *b, pic_t *pics, int nf, int par);
 static void prefix_picture(void *ctx, int t, int tid);
+/* the streams listed in b->out_slots[0..n) had the reconstruction of their last picture dropped and need it after all (struct dsv1_batch,
+ * recon_dropped): code those pictures again, each into the free slot of its stream's pair.  Everything a picture was coded from is still
+ * there -- its source frame (the ring keeps a call's last frames for the next call's motion search, copied whole), the reconstruction it
+ * predicted from (its stream's current slot: nothing has been kept since), its vectors, flags and quantiser (the other half of pics[]).
+ * The packets go to the first out slots of the half this submit is about to use and are never fetched.  Rare (a renumbered stream): the
+ * device is drained before and after instead of ordering the extra call against the streams of its neighbours. */
+static int remedy_dropped(dsv1_batch *b, int n, int par)
+{
+    const int S = b->nstreams, F = b->F;
+    const pic_t *prev = b->pics + (size_t)(par ^ 1) * S * F;
+    int i, rc;
+    if (b->nf_prev < 1) return DSVG_ERR_ARG;
+    if ((rc = dsvg_ctx_sync(b->ctx))) return rc;
+    for (i = 0; i < n; i++) {
+        const int s = b->out_slots[i];
+        const pic_t *pp = &prev[s * F + b->nf_prev - 1];
+        dsvg_pic_job *j = &b->jobs[i];
+        memset(j, 0, sizeof(*j));
+        j->src_slot = pp->cur_slot;
+        j->ref_recon_slot = pp->isP ? s + S * b->rpar[s] : -1;
+        b->rpar[s] ^= 1;
+        b->has_recon[s] = 1;
+        j->recon_slot = s + S * b->rpar[s];
+        j->quant = pp->quant;
+        j->mvs = (const dsvg_mv *)pp->mvs;
+        j->stable_blocks = pp->stable;
+        j->out_slot = par * S * F + i;
+        j->no_intra_blocks = pp->isP && pp->n_intra == 0;
+        j->has_reach = 0;
+        j->border_hint = 0;                          /* the whole border */
+        b->n_remedied++;
+    }
+    /* (I and P pictures may be mixed here: one frame step of n jobs on one coding stream) */
+    if ((rc = dsvg_code_batch(b->ctx, 1, n, b->jobs))) return rc;
+    return dsvg_ctx_sync(b->ctx);
+}
+long dsv1_batch_dropped_recons(const dsv1_batch *b, long *remedied)
+{
+    if (!b) return 0;
+    if (remedied) *remedied = b->n_remedied;
+    return b->n_dropped;
+}
+
 static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, DSV_BUF *abr_out, int nf, int inplace_ok)
 {
-    int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0, par;
+    int S, F, nblk, with_pyr, s, t, k, rc, npairs = 0, par, nremedy = 0;
     size_t fb;
     const DSV_ENCODER *e0;
     const uint8_t *dyuv = (const uint8_t *)yuv;
@@ -818,6 +873,11 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                 if ((rc = dsvg_extend_recon(b->ctx, b->chains ? b->carry_cur : s + S * b->rpar[s]))) return rc;
             }
             if (t == 0) b->border_skipped[s] = 0;
+            if (t == 0 && b->recon_dropped[s]) {
+                /* ... and a reconstruction it dropped: coded once more below, kept this time */
+                if (pc->has_ref) b->out_slots[nremedy++] = s;
+                b->recon_dropped[s] = 0;
+            }
             if (pc->has_ref) {
                 b->slots_cur[npairs] = pc->cur_slot;
                 b->slots_ref[npairs] = pc->ref_slot;
@@ -826,6 +886,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
             }
         }
     }
+    if (nremedy && (rc = remedy_dropped(b, nremedy, par))) return rc;
     HP_MARK(HP_DECIDE);
     /* 3. motion estimation for every inter candidate of the batch in one go */
     if (npairs) {
@@ -876,11 +937,23 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
                  * into the slot its reconstruction will live in (the reference sits in the other one), so the inverse
                  * transform only touches the tiles that carry a residual (dsvg_code_batch) */
                 j->ref_recon_slot = pc->isP ? s + S * b->rpar[s] : -1;
-                if (pc->is_ref) {
-                    b->rpar[s] ^= 1;
-                    b->has_recon[s] = 1;
-                    j->recon_slot = s + S * b->rpar[s];
-                } else j->recon_slot = -1;
+                {
+                    /* who predicts from this picture?  The stream's next one -- when it has a reference at all.  Nobody: no reconstruction
+                     * (struct dsv1_batch, recon_dropped; the reference builds it and never looks at it, dsv_encoder.c:665-700) */
+                    int dead = 0;
+                    if (pc->is_ref && !serial && !b->keep_all) {
+                        const DSV_ENCODER *e = &b->enc[s];
+                        if (t + 1 < nf) dead = !pics[s * F + t + 1].has_ref;
+                        else dead = !abr && (e->force_metadata || (DSV_FNUM)(e->prev_gop + (DSV_FNUM)e->gop) <= e->next_fnum);
+                    }
+                    if (t + 1 == nf) b->recon_dropped[s] = (unsigned char)dead;
+                    b->n_dropped += dead;
+                    if (pc->is_ref && !dead) {
+                        b->rpar[s] ^= 1;
+                        b->has_recon[s] = 1;
+                        j->recon_slot = s + S * b->rpar[s];
+                    } else j->recon_slot = -1;
+                }
                 j->quant = pc->quant;
                 j->mvs = (const dsvg_mv *)pc->mvs;
                 j->stable_blocks = pc->stable;
@@ -935,6 +1008,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
     hp_batches++;
     b->gcount += (unsigned)nf;
     b->parity ^= 1;
+    b->nf_prev = nf;
     return DSVG_OK;
 }
 

@@ -181,6 +181,12 @@ int  dsv1_batch_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int n
 int  dsv1_stream_open(dsv1_batch **out, const DSV_ENCODER *cfg, int device, int frames_per_call, int max_chains);
 void dsv1_batch_close(dsv1_batch *b);
 void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
+/* Round 5: reference pictures nobody predicts from are coded without their reconstruction (no inverse transform; the packets are the
+ * same -- the reference encoder builds that picture and never reads it, dsv_encoder.c:665-708).  Known exactly inside a call; for a call's
+ * last picture when the next frame number starts a GOP, and if dsv1_batch_set_fnum then turns that GOP start into a P picture the next
+ * submit codes the dropped picture again with its reconstruction kept (remedied) before it goes on.  Returns how many reconstructions
+ * were dropped so far.  DSV1_RECON_ALL=1: every reference picture is reconstructed. */
+long dsv1_batch_dropped_recons(const dsv1_batch *b, long *remedied);
 /* stream s's encoder struct (the batch owns it).  Its public parameter fields -- quality, bitrate, min_ / max_quality,
  * min_I_frame_quality, max_q_step, rc_high_motion_nudge; dsv_enc_force_metadata -- may be changed between submits, as a caller of
  * the reference changes them between dsv_enc calls; geometry, GOP structure and rate-control mode may not. */
