@@ -666,6 +666,12 @@ static int code_chains(dsv1_batch *b, pic_t *pics, int nf, int par)
                     memset(j, 0, sizeof(*j));
                     j->src_slot = pc->cur_slot;
                     j->ref_recon_slot = pc->isP ? b->ch_cur[c] : -1;
+                    /* (a chain's last picture whose successor starts the next chain of this submit has no reader: no reconstruction,
+                     * struct dsv1_batch, recon_dropped) */
+                    if (pc->is_ref && kk + 1 == b->ch_len[c] && tt + 1 < nf && !b->keep_all) {
+                        j->recon_slot = -1;
+                        b->n_dropped++;
+                    } else
                     if (pc->is_ref) {
                         /* the pair's other slot: the prediction is written straight into it (dsvg_code_batch) */
                         b->ch_cur[c] = 2 * b->ch_pair[c] + (b->ch_cur[c] == 2 * b->ch_pair[c] ? 1 : 0);
