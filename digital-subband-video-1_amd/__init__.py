@@ -361,7 +361,9 @@ class DecBatch:
             bufs[s].len = len(packets[s])
         status = (_C.c_int * S)()
         fnum = (_C.c_uint32 * S)()
-        if on_device:
+        if on_device and out is not None:
+            dst = out                                  # a device buffer of the caller's (nstreams x frame_bytes: dev_alloc())
+        elif on_device:
             if self._dev is None:
                 self._dev = _C.c_void_p(None)
                 _chk(self.L.dsvg_dev_alloc(self.ctx, _C.byref(self._dev), self.frame_bytes * S), "dsvg_dev_alloc")
@@ -371,16 +373,22 @@ class DecBatch:
                 out = _np.zeros((S, self.frame_bytes), dtype=_np.uint8)
             dst = out.ctypes.data
         _chk(self.L.dsv1_decbatch_decode(self.h, bufs, dst, self.frame_bytes, 1 if on_device else 0, status, fnum), "dsv1_decbatch_decode")
-        return (self._dev if on_device else out), list(status), list(fnum)
+        return (dst if on_device else out), list(status), list(fnum)
 
     def sync(self):
         _chk(self.L.dsvg_ctx_sync(self.ctx), "dsvg_ctx_sync")
 
-    def download(self):
-        """host copy of the device output buffer of the last decode(on_device=True)"""
+    def dev_alloc(self):
+        """a device buffer for one call's frames (decode(.., out=buffer, on_device=True)); freed with the context"""
+        p = _C.c_void_p(None)
+        _chk(self.L.dsvg_dev_alloc(self.ctx, _C.byref(p), self.frame_bytes * self.nstreams), "dsvg_dev_alloc")
+        return p
+
+    def download(self, dev=None):
+        """host copy of the device output buffer of the last decode(on_device=True), or of `dev`"""
         self.sync()
         out = _np.zeros((self.nstreams, self.frame_bytes), dtype=_np.uint8)
-        _chk(self.L.dsvg_dev_download(self.ctx, out.ctypes.data, self._dev, out.nbytes), "dsvg_dev_download")
+        _chk(self.L.dsvg_dev_download(self.ctx, out.ctypes.data, dev if dev is not None else self._dev, out.nbytes), "dsvg_dev_download")
         return out
 
     def close(self):

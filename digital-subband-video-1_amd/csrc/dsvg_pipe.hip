@@ -233,6 +233,8 @@ struct dsvg_ctx {
     uint8_t *dec_h[2] = {nullptr, nullptr}, *dec_d[2] = {nullptr, nullptr};   // decoder: payload blob of one call (pinned / device), by call parity
     size_t dec_cap[2] = {0, 0};
     hipEvent_t ev_dec[2] = {nullptr, nullptr};   // uploads of the call that last used that parity
+    hipEvent_t ev_pack[2] = {nullptr, nullptr};  // decoder, round 5: the packing pass runs on the second coding stream ([0]: the reconstructions are there, [1]: the pass is done)
+    bool pack_pending = false;                   // ... and the first stream has not yet been told to wait for it
     // Chroma planes of every source slot: the bordered copy in the source slab, or -- frames loaded "in place"
     // (dsvg_load_frames_map_ex) -- the caller's packed planar clip: pixel (0,0) of U / V and the row stride, host truth + the
     // device tables the motion search reads (HmeArgs.slot_cu ..)
@@ -354,6 +356,7 @@ static void ctx_free(dsvg_ctx *c)
         if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
         if (c->ev_used[i]) (void)hipEventDestroy(c->ev_used[i]);
         if (c->ev_dec[i]) (void)hipEventDestroy(c->ev_dec[i]);
+        if (c->ev_pack[i]) (void)hipEventDestroy(c->ev_pack[i]);
         if (c->ev_flag[i]) (void)hipEventDestroy(c->ev_flag[i]);
     }
     for (hipEvent_t e : c->ev_coded) (void)hipEventDestroy(e);
@@ -1787,12 +1790,27 @@ extern "C" int dsvg_pack_recons(dsvg_ctx *c, int n, const int *recon_slots, void
         c->dec_pending.pack_out = yuv_out; c->dec_pending.pack_pitch = out_pitch;
     } else if (c->dec_pending.active && !c->dec_pending.in_redo) OPCHK(dec_resolve(c));   // a second pack of the same call: settle it now
     if (!c->ptab_d) HIPCHK(hipMalloc((void **)&c->ptab_d, sizeof(int) * (size_t)c->n_recon + 64));
-    HIPCHK(hipMemcpyAsync(c->ptab_d, recon_slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st));   // pageable: staged by the runtime
     if (out_on_device) {
-        launch_pack_n(c->st, (uint8_t *)yuv_out, out_pitch, c->recon.p, c->L[0], c->ptab_d, n, &c->prof);
+        // Round 5: device output is packed on the second coding stream -- beside the next call's entropy decoding, which touches neither the
+        // reconstructions nor the caller's frames (70 us of a 620 us step of 64 pictures).  Whatever rewrites a reconstruction slot next waits
+        // for the pass (dsvg_decode_pictures, in front of its inverse transform); dsvg_ctx_sync waits for every stream.
+        static const bool one_stream = getenv("DSV1_DEC_ONE_STREAM") != nullptr;      // (A/B)
+        hipStream_t sp_ = c->st;
+        if (!one_stream && n >= 4 && !c->dec_pending.in_redo && !c->prof.mask && c->stx[1]) {
+            for (int i = 0; i < 2; i++) if (!c->ev_pack[i]) HIPCHK(hipEventCreateWithFlags(&c->ev_pack[i], hipEventDisableTiming));
+            if (c->pack_pending) HIPCHK(hipStreamWaitEvent(c->st, c->ev_pack[1], 0));      // (a second pass before the next decode call: keep the passes in order)
+            sp_ = c->stx[1];
+            HIPCHK(hipEventRecord(c->ev_pack[0], c->st));
+            HIPCHK(hipStreamWaitEvent(sp_, c->ev_pack[0], 0));
+        }
+        HIPCHK(hipMemcpyAsync(c->ptab_d, recon_slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, sp_));   // pageable: staged by the runtime
+        launch_pack_n(sp_, (uint8_t *)yuv_out, out_pitch, c->recon.p, c->L[0], c->ptab_d, n, &c->prof);
+        if (sp_ != c->st) { HIPCHK(hipEventRecord(c->ev_pack[1], sp_)); c->pack_pending = true; }
         HIPCHK(hipGetLastError());
         return DSVG_OK;
     }
+    if (c->pack_pending) { HIPCHK(hipStreamWaitEvent(c->st, c->ev_pack[1], 0)); c->pack_pending = false; }
+    HIPCHK(hipMemcpyAsync(c->ptab_d, recon_slots, sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st));   // pageable: staged by the runtime
     const size_t sp = (fb + 255) & ~(size_t)255;
     if (c->yuv_stage_bytes < sp * n) {
         if (c->yuv_stage) { HIPCHK(hipStreamSynchronize(c->st)); HIPCHK(hipStreamSynchronize(c->st_a)); HIPCHK(hipStreamSynchronize(c->st_l)); (void)hipFree(c->yuv_stage); c->yuv_stage = nullptr; }
@@ -2007,6 +2025,18 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
         HIPCHK(hipEventRecord(c->ev_flag[k], c->st));
         if (!was_redo) { P.active = true; P.parity = k; P.njobs = njobs; }
     } else if (!was_redo) P.active = false;
+    // Round 5: the motion compensation of a step depends on the step before (its reconstructions) and on this call's tables, not on this
+    // call's entropy decoding: it runs on the second coding stream beside the parse chain (five latency-bound kernels, 160 us of a 620 us
+    // step of 64 pictures) and joins in front of the inverse transform.  The fork waits for ev_dec -- recorded on the first stream behind
+    // this call's uploads, i.e. behind everything of the step before -- so nothing of that step still reads the prediction frames.
+    hipStream_t sm = c->st;
+    {
+        static const bool one_stream = getenv("DSV1_DEC_ONE_STREAM") != nullptr;      // (A/B)
+        if (njobs > nI && njobs >= 4 && !one_stream && !c->prof.mask && c->stx[1] && c->ev_join[1]) {      // (a call of one picture gains nothing: 3 110-3 230 against 3 160-3 340 frames/s)
+            sm = c->stx[1];
+            HIPCHK(hipStreamWaitEvent(sm, c->ev_dec[k], 0));
+        }
+    }
     if (njobs > nI) {
         static const bool no_mc_patch = getenv("DSV1_NO_MC_PATCH") != nullptr;
         if (c->mc_fused && c->ilist_h && !no_mc_patch) {
@@ -2028,11 +2058,19 @@ static int decode_impl(dsvg_ctx *c, int njobs, const dsvg_dec_job *jobs, bool fo
             }
             const DMV *mv0 = c->mvs + (size_t)nI * c->nblk;
             if (iln) {
-                HIPCHK(hipMemcpyAsync(c->ilist_d + hb * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
-                launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof, mv0, c->ilist_d + hb * c->nblk, iln);
+                HIPCHK(hipMemcpyAsync(c->ilist_d + hb * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, sm));
+                launch_mc(sm, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof, mv0, c->ilist_d + hb * c->nblk, iln);
             }
-            launch_mc_patch(c->st, c->jobs_d + nI, njobs - nI, c->G, c->MG, mv0, ex0, ey0, &c->prof);
-        } else launch_mc(c->st, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
+            launch_mc_patch(sm, c->jobs_d + nI, njobs - nI, c->G, c->MG, mv0, ex0, ey0, &c->prof);
+        } else launch_mc(sm, c->jobs_d + nI, njobs - nI, c->MG, 0, &c->prof);
+        if (sm != c->st) {
+            HIPCHK(hipEventRecord(c->ev_join[1], sm));
+            HIPCHK(hipStreamWaitEvent(c->st, c->ev_join[1], 0));
+        }
+    }
+    if (c->pack_pending) {               // the packing pass of the call before (dsvg_pack_recons) may still read the slot this call's inverse transform writes
+        HIPCHK(hipStreamWaitEvent(c->st, c->ev_pack[1], 0));
+        c->pack_pending = false;
     }
     OPCHK(enqueue_recon(c, nI, njobs, 0, insym));
     if (anysym) launch_hz_unscatter(c->st, c->jobs_d + f0, njobs - f0, max_entries);

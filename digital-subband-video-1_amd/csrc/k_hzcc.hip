@@ -1444,92 +1444,65 @@ __global__ __launch_bounds__(PARSE_THREADS) void k_hz_parse(JobDev *__restrict__
     if (tid == 0) { jb.dec_npass[c] = npass; jb.dec_ncode[c] = s_ncode; jb.dec_s0[c] = S0; }
 }
 
-// B. every chunk on its own: the codes that END in it go into the run / value arrays.  A code is at most
+// B. every chunk on its own: the codes that END in it go straight into the run / value arrays.  A code is at most
 // 63 bits, so it starts no earlier than the second word of the chunk before: three words of payload per thread.
-// Round 5: the values go through LDS.  A thread's codes are consecutive entries, its neighbour's follow on -- a store instruction
-// of the decode loop therefore touched 64 lines, and the batched decoder spent a sixth of its time here.  Code j of the plane is
-// staged at j - (the workgroup's first code); behind a barrier the workgroup writes runs and values out side by side, 32 + 32
-// consecutive entries per store instruction.  What does not fit the staging area (8192 codes; a workgroup's 256 chunks of a P
-// picture hold about that many) is stored directly as before, as is the plane's last code (its value has a place of its own).
-#define HZ_CODES_CAP 8192
-template <bool STAGE>                                   // (false: DSV1_NO_CODES_STAGE, the direct stores of rounds 1-4 for A/B)
 __global__ __launch_bounds__(256) void k_hz_codes(JobDev *__restrict__ jobs, int c0)
 {
-    __shared__ int s_stage[STAGE ? HZ_CODES_CAP : 1];
-    __shared__ int s_j0, s_jend;
     const int c = c0 + (int)blockIdx.z;
     JobDev &jb = jobs[blockIdx.y];
     const int i = blockIdx.x * 256 + threadIdx.x;
-    if (blockIdx.x * 256 >= jb.dec_npass[c] * PARSE_THREADS) return;         // (the whole workgroup: the grid is sized for the largest payload)
+    if (i >= jb.dec_npass[c] * PARSE_THREADS) return;
     const int dlen = jb.dec_len[c];
     const long long endbits = 8ll * dlen;
     const long long B = jb.dec_s0[c] + (long long)i * PARSE_BITS;
+    if (B >= endbits) return;
     const HzPlane &hp = jb.hz[c];
     const int n = min(jb.dec_runs[c], hp.nchunks * HZ_CHUNK - 1);
     const int ncodes = 2 * n - 1;
     const uint8_t *pay = jb.bits + jb.bits_off[c];
     int32_t *R = jb.nzpos + jb.nz_off[c];
     int32_t *V = jb.nzval + jb.nz_off[c];
-    const bool inr = i < jb.dec_npass[c] * PARSE_THREADS && B < endbits;
-    HzParseChunk mc;
-    mc.m0 = mc.m1 = 0ull; mc.cbase = 0; mc.prev_end = 0;
-    if (inr) mc = jb.dec_meta[c][i];
-    if (threadIdx.x == 0) { s_j0 = inr ? mc.cbase : 0x7fffffff; s_jend = 0; }
-    __syncthreads();
-    const int j0 = s_j0;
+    const HzParseChunk mc = jb.dec_meta[c][i];
     int j = mc.cbase;
-    const bool work = inr && j < ncodes && (mc.m0 | mc.m1);
-    if (work) atomicMax(&s_jend, min(j + __popcll(mc.m0) + __popcll(mc.m1), ncodes));
+    if (j >= ncodes || !(mc.m0 | mc.m1)) return;
+    unsigned long long w0, w1;
+    parse_chunk_bits(pay, B, endbits, w0, w1);
+    const unsigned long long wp = B >= 64 ? bits_at(pay, (unsigned long long)(B - 64)) : 0ull;
+    long long prev_end = mc.prev_end;
     int first_bad = 0x7fffffff;
-    if (work) {
-        unsigned long long w0, w1;
-        parse_chunk_bits(pay, B, endbits, w0, w1);
-        const unsigned long long wp = B >= 64 ? bits_at(pay, (unsigned long long)(B - 64)) : 0ull;
-        long long prev_end = mc.prev_end;
-        for (int half = 0; half < 2 && j < ncodes; half++) {
-            unsigned long long m = half ? mc.m1 : mc.m0;
-            while (m && j < ncodes) {
-                const int hb = 63 - __clzll((long long)m);                   // highest set bit = earliest end
-                m &= ~(1ull << hb);
-                const long long endp = B + half * 64 + (63 - hb) + 1;         // bit after the code
-                const int len = (int)min(endp - prev_end, 63ll);
-                const int rel = (int)(prev_end - (B - 64));
-                unsigned long long w;
-                if (rel >= 0) {
-                    const int idx = rel >> 6, sh = rel & 63;
-                    const unsigned long long wa = idx == 0 ? wp : (idx == 1 ? w0 : w1);
-                    const unsigned long long wb = idx == 0 ? w0 : (idx == 1 ? w1 : 0ull);
-                    w = sh ? (wa << sh) | (wb >> (64 - sh)) : wa;
-                } else {
-                    w = bits_at(pay, (unsigned long long)prev_end);           // over-long code of a damaged stream
-                }
-                // one body for both code kinds: U(run) is all magnitude; N(value) is magnitude + sign bit, except the final N
-                // of the plane, which arrives where a U was due (its U part ends here, the sign is the next bit)
-                const bool last = j == ncodes - 1, isN = (j & 1) != 0;
-                const int ulen = isN ? len - 1 : len;                         // bits of the U part
-                const unsigned mag = ulen <= 31 ? ueg_value32((unsigned)(w >> 32), ulen) : ueg_value(w, ulen);
-                int sign = (int)((w >> (64 - len)) & 1);
-                if (last) sign = (int)((bits_at(pay, (unsigned long long)endp) >> 63) & 1);
-                const int mi = last ? n : (j + 1) >> 1;
-                const bool val = isN || last;
-                const int v1 = (int)mag + 1;
-                const int out = val ? (sign ? -v1 : v1) : (int)mag;
-                const int k = j - j0;
-                if (STAGE && !last && k >= 0 && k < HZ_CODES_CAP) s_stage[k] = out;
-                else *(val ? V + mi : R + (j >> 1) + 2) = out;
-                if (val && ((endp + (last ? 1 : 0)) >> 3) >= dlen) first_bad = min(first_bad, mi);   // hzcc.c:337-339
-                prev_end = endp;
-                j++;
+    for (int half = 0; half < 2 && j < ncodes; half++) {
+        unsigned long long m = half ? mc.m1 : mc.m0;
+        while (m && j < ncodes) {
+            const int hb = 63 - __clzll((long long)m);                   // highest set bit = earliest end
+            m &= ~(1ull << hb);
+            const long long endp = B + half * 64 + (63 - hb) + 1;         // bit after the code
+            const int len = (int)min(endp - prev_end, 63ll);
+            const int rel = (int)(prev_end - (B - 64));
+            unsigned long long w;
+            if (rel >= 0) {
+                const int idx = rel >> 6, sh = rel & 63;
+                const unsigned long long wa = idx == 0 ? wp : (idx == 1 ? w0 : w1);
+                const unsigned long long wb = idx == 0 ? w0 : (idx == 1 ? w1 : 0ull);
+                w = sh ? (wa << sh) | (wb >> (64 - sh)) : wa;
+            } else {
+                w = bits_at(pay, (unsigned long long)prev_end);           // over-long code of a damaged stream
             }
+            // one body for both code kinds: U(run) is all magnitude; N(value) is magnitude + sign bit, except the final N
+            // of the plane, which arrives where a U was due (its U part ends here, the sign is the next bit)
+            const bool last = j == ncodes - 1, isN = (j & 1) != 0;
+            const int ulen = isN ? len - 1 : len;                         // bits of the U part
+            const unsigned mag = ulen <= 31 ? ueg_value32((unsigned)(w >> 32), ulen) : ueg_value(w, ulen);
+            int sign = (int)((w >> (64 - len)) & 1);
+            if (last) sign = (int)((bits_at(pay, (unsigned long long)endp) >> 63) & 1);
+            const int mi = last ? n : (j + 1) >> 1;
+            const bool val = isN || last;
+            int32_t *dst = val ? V + mi : R + (j >> 1) + 2;
+            const int v1 = (int)mag + 1;
+            *dst = val ? (sign ? -v1 : v1) : (int)mag;
+            if (val && ((endp + (last ? 1 : 0)) >> 3) >= dlen) first_bad = min(first_bad, mi);   // hzcc.c:337-339
+            prev_end = endp;
+            j++;
         }
-    }
-    __syncthreads();
-    // staged code j0 + k: an even j is a run -> R[j / 2 + 2], an odd j a value -> V[(j + 1) / 2]; neighbouring threads alternate
-    const int nst = STAGE ? min(s_jend - j0, HZ_CODES_CAP) : 0;
-    for (int k = threadIdx.x; k < nst; k += 256) {
-        const int jj = j0 + k;
-        if (jj == ncodes - 1) continue;                                       // (stored by its thread)
-        *((jj & 1) ? V + ((jj + 1) >> 1) : R + (jj >> 1) + 2) = s_stage[k];
     }
     if (first_bad != 0x7fffffff) atomicMin(&jb.dec_first_bad[c], first_bad);
 }
@@ -1822,9 +1795,7 @@ void launch_hz_parse_scatter(hipStream_t st, JobDev *jobs, int njobs, int c, int
     PE();
     if (max_chunks > 0) {
         PB(KID_HZ_CODES, 0.0);
-        static const bool no_stage = getenv("DSV1_NO_CODES_STAGE") != nullptr;
-        if (no_stage) hipLaunchKernelGGL(k_hz_codes<false>, dim3((max_chunks + 255) / 256, njobs, nplanes), dim3(256), 0, st, jobs, c);
-        else hipLaunchKernelGGL(k_hz_codes<true>, dim3((max_chunks + 255) / 256, njobs, nplanes), dim3(256), 0, st, jobs, c);
+        hipLaunchKernelGGL(k_hz_codes, dim3((max_chunks + 255) / 256, njobs, nplanes), dim3(256), 0, st, jobs, c);
         PE();
     }
     PB(KID_HZ_POSITIONS, 0.0);

@@ -448,3 +448,40 @@ def test_device_clip_at_an_odd_address(pkg, shift):
     finally:
         b.close()
     assert got == want
+
+
+@pytest.mark.parametrize("rep", [0, 1, 2])
+def test_batched_decoder_back_to_back_calls_on_two_streams(pkg, orc, rep):
+    """round 5: the batched decoder runs a call's motion compensation and the packing pass of device output on the second coding stream,
+    beside the entropy decoding of the same / the next call (dsvg_decode_pictures, dsvg_pack_recons).  Sixteen streams, GOPs of
+    different lengths, every call enqueued without waiting for the one before and packed into a device buffer of its own; all of
+    them read back after ONE synchronisation at the end -- an ordering mistake between the streams shows as a wrong frame."""
+    w, h, fmt, S, n = 352, 288, A.SUBSAMP_420, 16, 12
+    streams, want = [], []
+    for s in range(4):                                  # four distinct streams, repeated
+        clip = A.gen_clip(w, h, fmt, 0xB2B0 + 7 * s + rep, n, style=(0, 1, 2, 5)[s])
+        st, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=(85, 60, 90, 75)[s], gop=(12, 5, 4, 7)[s], rc_mode_cli=1))
+        pk_ = A.split_packets(st)
+        streams.append(pk_[:1] + [p for p in pk_ if p[5] & 4])      # the first metadata packet, then the pictures (a GOP's repeated metadata left out: the streams stay in step)
+        want.append(A.orc_decode(st, w, h, fmt))
+    d = pkg.DecBatch(w, h, fmt, S)
+    try:
+        ncalls = len(streams[0])
+        assert ncalls == n + 1 and all(len(p) == ncalls for p in streams)
+        bufs, stat = [], []
+        for k in range(ncalls):
+            pk = [streams[s % 4][k] for s in range(S)]
+            if not (pk[0][5] & 4):
+                d.decode(pk)                            # metadata: nothing to pack
+                continue
+            buf = d.dev_alloc()
+            _, status, fnum = d.decode(pk, out=buf, on_device=True)
+            assert all(x == 0 for x in status), status
+            bufs.append(buf)
+        frames = [d.download(b) for b in bufs]          # (the first download synchronises)
+    finally:
+        d.close()
+    assert len(frames) == n
+    for t in range(n):
+        for s in range(S):
+            A.assert_same("stream %d frame %d" % (s, t), frames[t][s], want[s % 4][t])
