@@ -75,7 +75,7 @@ int  unpack_fuses_level1(const FrameLayout &L);
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf = nullptr, const int *slot_tab = nullptr,
                    uint8_t *slab1 = nullptr, const FrameLayout *L1 = nullptr, bool sides = false, bool sides1 = false,
                    uint8_t *slab2 = nullptr, const FrameLayout *L2 = nullptr, bool sides2 = false, int n_chroma = -1,
-                   int ring_x16 = 0, int ring_y4 = 0);    // slot-table entries with bit 29: only the luma plane's outer ring_x16 x 16 columns / ring_y4 x 4 rows are copied
+                   int ring_x16 = 0, int ring_y4 = 0, int n_ring = 0);    // slot-table entries with bit 29: only the luma plane's outer ring_x16 x 16 columns / ring_y4 x 4 rows are copied
 int  unpack_fuses_level2(const FrameLayout &L, const FrameLayout &L1, const FrameLayout &L2);
 bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *slab, const FrameLayout &L);
 void launch_pack(hipStream_t st, uint8_t *yuv, const uint8_t *frame, const FrameLayout &L);

@@ -859,7 +859,7 @@ static int ingest_release(dsvg_ctx *c, int k)
 }
 
 // ------------------------------------------------------------------------------------------------
-static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d, int n_chroma = -1)
+static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, size_t pitch, int with_pyramid, const int *tab_d, int n_chroma = -1, int n_ring = 0)
 {
     if (!tab_d) {       // contiguous slots, chroma copied: those slots' chroma is the bordered copy (again)
         bool changed = false, ychanged = false;
@@ -893,7 +893,7 @@ static int load_core(dsvg_ctx *c, int first_slot, int n, const uint8_t *dsrc, si
     const bool sides2 = fuse2 && sides && !no_lsides && level_sides_ok(c->src[2].p, c->L[2]);
     tl_mark(c, c->st_l, "load0");
     launch_unpack(c->st_l, dsrc, pitch, c->src[0].p, c->L[0], first_slot, n, &c->prof, tab_d, fuse1 ? c->src[1].p : nullptr, fuse1 ? &c->L[1] : nullptr, sides, sides1,
-                  fuse2 ? c->src[2].p : nullptr, fuse2 ? &c->L[2] : nullptr, sides2, n_chroma, c->ring_x16, c->ring_y4);
+                  fuse2 ? c->src[2].p : nullptr, fuse2 ? &c->L[2] : nullptr, sides2, n_chroma, c->ring_x16, c->ring_y4, n_ring);
     launch_extend(c->st_l, c->src[0].p, c->L[0], first_slot, n, 3, tab_d, &c->prof, nullptr, sides);
     if (with_pyramid) {
         for (int l = 1; l <= c->levels; l++) {
@@ -960,7 +960,7 @@ extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, con
     const bool can = chroma_in_place && c->cdirect_ok && ((uintptr_t)yuv_dev % 16) == 0 && (frame_pitch % 16) == 0 && (ysz % 16) == 0 && (csz % 16) == 0;
     std::vector<int> tab((size_t)n);
     bool changed = false, ychanged = false;
-    int n_direct = 0;
+    int n_direct = 0, n_ydirect = 0;
     for (int i = 0; i < n; i++) {
         const int sl = slots[i];
         const bool direct = can && chroma_in_place[i];
@@ -981,6 +981,7 @@ extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, con
         tab[(size_t)i] = sl | (direct ? 0x40000000 : 0) | (ydirect ? 0x20000000 : 0);
         c->cdirect_frames += direct;
         c->ydirect_frames += ydirect;
+        n_ydirect += ydirect;
     }
     if (ychanged) HIPCHK(hipMemcpyAsync(c->slot_y_d, c->slot_y_h, 8 * (size_t)c->n_src, hipMemcpyHostToDevice, c->st_l));
     if (changed) {
@@ -993,7 +994,7 @@ extern "C" int dsvg_load_frames_map_ex(dsvg_ctx *c, int n, const int *slots, con
     HIPCHK(hipMemcpyAsync(c->ltab_d, tab.data(), sizeof(int) * (size_t)n, hipMemcpyHostToDevice, c->st_l));   // pageable: staged by the runtime
     const int k = ingest_acquire(c, yuv_dev);
     if (k == -2) { dsvg_set_error("hipStreamWaitEvent failed"); return DSVG_ERR_HIP; }
-    const int rc = load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d, n - n_direct);
+    const int rc = load_core(c, 0, n, (const uint8_t *)yuv_dev, frame_pitch, with_pyramid, c->ltab_d, n - n_direct, n_ydirect);
     return rc ? rc : ingest_release(c, k);
 }
 extern "C" int dsvg_load_frames_map(dsvg_ctx *c, int n, const int *slots, const void *yuv_dev, size_t frame_pitch, int with_pyramid)

@@ -442,13 +442,19 @@ bool unpack_writes_sides(const uint8_t *yuv, size_t yuv_pitch, const uint8_t *sl
     return ok;
 }
 void launch_unpack(hipStream_t st, const uint8_t *yuv, size_t yuv_pitch, uint8_t *slab, const FrameLayout &L, int first, int n, Prof *pf, const int *slot_tab,
-                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2, int n_chroma, int ring_x16, int ring_y4)
+                   uint8_t *slab1, const FrameLayout *L1, bool sides, bool sides1, uint8_t *slab2, const FrameLayout *L2, bool sides2, int n_chroma, int ring_x16, int ring_y4, int n_ring)
 {
     FrameLayout dummy = L;
     // algorithmic bytes: every copied plane read once and written once (n_chroma: the frames whose chroma is copied too -- the
     // others keep it in the caller's clip), + the pyramid levels written
     if (n_chroma < 0) n_chroma = n;
-    if (pf) pf->begin(st, KID_UNPACK, 2.0 * ((double)n * L.w[0] * L.h[0] + 2.0 * n_chroma * L.w[1] * L.h[1]) + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0) + (slab2 ? 0.0625 * n * L.w[0] * L.h[0] : 0.0));
+    // (n_ring, round 5: the frames whose luma stays in the clip as well -- read once for the pyramid, written only as the ring)
+    double ring_saved = 0.0;
+    if (n_ring > 0 && ring_x16 > 0) {
+        const double iw = std::max(0, L.w[0] - 2 * 16 * ring_x16), ih = std::max(0, L.h[0] - 2 * 4 * ring_y4);
+        ring_saved = (double)n_ring * iw * ih;                              // the interior that is not written
+    }
+    if (pf) pf->begin(st, KID_UNPACK, 2.0 * ((double)n * L.w[0] * L.h[0] + 2.0 * n_chroma * L.w[1] * L.h[1]) - ring_saved + (slab1 ? 0.25 * n * L.w[0] * L.h[0] : 0.0) + (slab2 ? 0.0625 * n * L.w[0] * L.h[0] : 0.0));
     // The grid is sized for the work there is (the kernel's loops stride by the grid, so any size is correct): the fused luma body takes
     // 4 rows x 16 pixels per thread, and a batch whose chroma stays in the caller's clip has no chroma planes to copy -- sized for 16
     // pixels per thread and three planes, five workgroups in six of the bench's launch found nothing to do (2.4 million per step).
