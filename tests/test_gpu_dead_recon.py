@@ -109,3 +109,62 @@ def test_renumbered_stream_gets_its_dropped_reconstruction_back(pkg, orc, pipeli
     for s in range(S):
         assert got[s] == want[s], "stream %d differs" % s
     assert remedied == 1 and dropped >= 3, (dropped, remedied)
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13, 14, 15, 16, 17, 18])
+def test_random_renumbering_against_the_oracle(pkg, orc, seed):
+    """random GOP lengths, frames per call and renumberings between calls (forwards, backwards, onto and off GOP boundaries), two
+    streams renumbered independently, plain and pipelined calls: whatever was dropped and whatever had to be made again, the
+    streams are the oracle's, renumbered the same way"""
+    import random
+    rng = random.Random(seed)
+    w, h, fmt, S = 352, 288, A.SUBSAMP_420, 2
+    gop, F = rng.choice([2, 3, 4, 5, 6, 7]), rng.choice([1, 2, 3, 4, 6])
+    ncalls = rng.choice([5, 6, 8])
+    cli = dict(qp=rng.choice([60, 85]), gop=gop, rc_mode_cli=1, scd=rng.choice([0, 1]))
+    n = F * ncalls
+    clips = [A.gen_clip(w, h, fmt, 0xF00D0 + 97 * seed + s, n, style=rng.choice([0, 1, 2, 5])) for s in range(S)]
+    # renumberings: before call k stream s continues at frame number renum[(k, s)]
+    renum = {}
+    for k in range(1, ncalls):
+        for s in range(S):
+            if rng.random() < 0.4:
+                renum[(k, s)] = rng.choice([0, 1, gop - 1, gop, gop + 1, 2 * gop, k * F, k * F - 1, rng.randrange(0, 40)])
+    Lo = A.load_orc()
+    want = []
+    for s in range(S):
+        cfg = A.orc_cfg(w, h, fmt, **cli)
+        e = Lo.orc_enc_open(C.byref(cfg))
+        out, n_, cap = C.c_void_p(None), C.c_size_t(0), C.c_size_t(0)
+        Lo.orc_enc_set_next_fnum(e, 0)
+        for t in range(n):
+            if t % F == 0 and (t // F, s) in renum:
+                Lo.orc_enc_set_next_fnum(e, max(renum[(t // F, s)], 0))
+            Lo.orc_enc_frame(e, clips[s][t].ctypes.data, C.byref(out), C.byref(n_), C.byref(cap), None)
+        want.append(C.string_at(out.value, n_.value))
+        C.CDLL(None).free(out)
+        Lo.orc_enc_close(e)
+    pipelined = rng.random() < 0.5
+    b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), S, F)
+    try:
+        calls = [np.stack([clips[s][k * F:(k + 1) * F] for s in range(S)]) for k in range(ncalls)]
+        parts = []
+        for k in range(ncalls):
+            for s in range(S):
+                if (k, s) in renum:
+                    b.set_fnum(s, max(renum[(k, s)], 0))
+            if pipelined:
+                b.submit(calls[k])
+                if k > 0:
+                    parts.append(b.collect())
+            else:
+                parts.append(b.encode(calls[k]))
+        if pipelined:
+            parts.append(b.collect())
+        dropped, remedied = b.dropped_recons()
+    finally:
+        b.close()
+    got = [b"".join(p[s] for p in parts) for s in range(S)]
+    for s in range(S):
+        assert got[s] == want[s], "stream %d differs (gop %d, F %d, %d calls, pipelined %s, renumberings %s; dropped %d, made again %d)" % (
+            s, gop, F, ncalls, pipelined, renum, dropped, remedied)
