@@ -13,7 +13,7 @@ kbps = int(sys.argv[8]) if len(sys.argv) > 8 else 0
 steps = int(sys.argv[9]) if len(sys.argv) > 9 else 4
 FMT = {0: A.SUBSAMP_444, 1: A.SUBSAMP_422, 2: A.SUBSAMP_420, 3: A.SUBSAMP_411}[fcli]
 F = gop if gop > 0 else 12
-clip = A.gen_clip(W, H, FMT, 0x21600004, F, style=0)
+clip = A.gen_clip(W, H, FMT, 0x21600004, F, style=int(os.environ.get("SHAPE_STYLE", "0")))      # (SHAPE_STYLE=7: dense residuals)
 batch_in = np.empty((gops, F, A.frame_bytes(W, H, FMT)), dtype=np.uint8)
 batch_in[:] = clip
 kw = dict(qp=qp, gop=gop, rc_mode_cli=rc)
