@@ -574,6 +574,7 @@ def main():
     b.collect(copy=False)                           # drain
     kinfo = None
     if rank == 0 and prof_kernel != "none":
+        whole_step = False
         ms, nl, by = b.prof_get(prof_kernel)
         b.prof_enable([])
         if prof_kernel in table and table[prof_kernel][1] and nl:
@@ -582,13 +583,15 @@ def main():
             # (a coding-stream kernel's launch covers 1 / coding_streams of a frame step there; an analysis kernel's the whole step)
             xm_, xn_, xb_ = table[prof_kernel]
             by = xb_ * (args.steps + 1)                   # (the brackets also cover the batch that fills the pipeline)
+            whole_step = abs(nl / float(args.steps + 1) - xn_) < 0.5      # as many launches per step as with one coding stream: an analysis-stream kernel
         ach = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
         kinfo = {"kernel": prof_kernel, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                  "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": nl,
                  "avg_launch_us": round(1000.0 * ms / max(nl, 1), 2),
                  "alg_bytes_per_launch": round(by / max(nl, 1)),
                  "coding_streams": nstreams,
-                 "regime": "timed region: %d coding streams + the analysis and fetch streams share the chip (a launch covers 1/%d of a frame step's pictures)" % (nstreams, nstreams),
+                 "regime": "timed region: %d coding streams + the analysis and fetch streams share the chip (%s)" % (
+                     nstreams, "a kernel of the analysis stream: a launch covers all pictures of a step" if whole_step else "a launch covers 1/%d of a frame step's pictures" % nstreams),
                  "all_kernels_ms_one_step_regime": "exclusive: one coding stream, the untimed selection step, each kernel alone on the chip",
                  "all_kernels_ms_one_step": {k: round(v[0], 3) for k, v in table.items() if v[1]},
                  "sparse_inverse_tiles_one_step": tiles}
