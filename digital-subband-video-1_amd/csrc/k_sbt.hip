@@ -708,6 +708,51 @@ struct FwdFastQ {
 };
 // trunc(v / 2^sh) == sign(v) * (|v| >> sh): the level-1 symbol
 static __device__ __forceinline__ int sym_shift(int v, int sh) { return (v + ((v >> 31) & ((1 << sh) - 1))) >> sh; }
+// the four level-1 symbols of one cell row and band of a patch are neighbours in the symbol plane (scan positions pos .. pos + 3): ONE 8-byte
+// store and one flag byte of each kind when the group is aligned (band widths and scan bases that are multiples of 4: every broadcast size),
+// instead of a 2-byte store and two flag stores per non-zero symbol -- with every patch of a picture flagged (the dense-residual shape) the
+// lean kernel spent its time issuing up to 189 stores per patch.  Zeros may be stored: the plane is zero between pictures, the bytes in
+// memory are the same either way.  (DSV1 A/B: -DFWD_FAST_NO_ROW4)
+static __device__ __forceinline__ void put_row4(const QCtx &q, int pos, s16x2 ab, s16x2 cd)      // the same with the symbols as int16 pairs (cells 0, 1 / 2, 3)
+{
+    const unsigned x = __builtin_bit_cast(unsigned, ab), y = __builtin_bit_cast(unsigned, cd);
+    if (!(x | y)) return;
+#ifndef FWD_FAST_NO_ROW4
+    if ((pos & 3) == 0) {
+        typedef unsigned row4_t __attribute__((ext_vector_type(2)));
+        row4_t v;
+        v.x = x; v.y = y;
+        *reinterpret_cast<DSVG_GLOBAL row4_t *>(q.sym + pos) = v;
+        q.nzf[pos >> 2] = 1;
+        q.cfl[pos >> 11] = 1;
+        return;
+    }
+#endif
+    if (ab.x) q.put_sparse(pos, ab.x);
+    if (ab.y) q.put_sparse(pos + 1, ab.y);
+    if (cd.x) q.put_sparse(pos + 2, cd.x);
+    if (cd.y) q.put_sparse(pos + 3, cd.y);
+}
+static __device__ __forceinline__ void put_row4(const QCtx &q, int pos, int a, int b, int c, int d)
+{
+    if (!(a | b | c | d)) return;
+#ifndef FWD_FAST_NO_ROW4
+    if ((pos & 3) == 0) {
+        typedef unsigned row4_t __attribute__((ext_vector_type(2)));
+        row4_t v;
+        v.x = ((unsigned)a & 0xffffu) | ((unsigned)b << 16);
+        v.y = ((unsigned)c & 0xffffu) | ((unsigned)d << 16);
+        *reinterpret_cast<DSVG_GLOBAL row4_t *>(q.sym + pos) = v;
+        q.nzf[pos >> 2] = 1;
+        q.cfl[pos >> 11] = 1;
+        return;
+    }
+#endif
+    if (a) q.put_sparse(pos, a);
+    if (b) q.put_sparse(pos + 1, b);
+    if (c) q.put_sparse(pos + 2, c);
+    if (d) q.put_sparse(pos + 3, d);
+}
 
 // level 1 of one pair of residual rows (cell row cy1 of the plane, cells cx1 .. cx1 + 3) -> LL row + sparse symbols
 static __device__ __forceinline__ void fwd_fast_rows1(const QCtx &q, const QLevel &L1, int sh1, int cx1, int cy1,
@@ -735,12 +780,9 @@ static __device__ __forceinline__ void fwd_fast_rows1(const QCtx &q, const QLeve
     if (any) {
         q.nz_any = 1;
         const int pr = cy1 * L1.sw + cx1;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (slh[i]) q.put_sparse(L1.base0 + pr + i, slh[i]);
-            if (shl[i]) q.put_sparse(L1.base1 + pr + i, shl[i]);
-            if (shh[i]) q.put_sparse(L1.base2 + pr + i, shh[i]);
-        }
+        put_row4(q, L1.base0 + pr, slh[0], slh[1], slh[2], slh[3]);
+        put_row4(q, L1.base1 + pr, shl[0], shl[1], shl[2], shl[3]);
+        put_row4(q, L1.base2 + pr, shh[0], shh[1], shh[2], shh[3]);
     }
 }
 // the same on packed rows: 16 v_pk instructions for the four cells; the all-zero test is exact (a symbol is zero iff
@@ -758,15 +800,15 @@ static __device__ __forceinline__ void fwd_fast_rows1_pk(const QCtx &q, const QL
     const s16x2 am = pk_max(mx, s16x2{0, 0} - mn);
     if ((pk_b(am) & ~(((1u << min(sh1, 15)) - 1u) * 0x00010001u)) == 0) return;
     q.nz_any = 1;
-    const int lh[4] = {lha.x, lha.y, lhb.x, lhb.y}, hl[4] = {hla.x, hla.y, hlb.x, hlb.y}, hh[4] = {hha.x, hha.y, hhb.x, hhb.y};
     const int pr = cy1 * L1.sw + cx1;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const int slh = sym_shift(lh[i], sh1), shl = sym_shift(hl[i], sh1), shh = sym_shift(hh[i], sh1);
-        if (slh) q.put_sparse(L1.base0 + pr + i, slh);
-        if (shl) q.put_sparse(L1.base1 + pr + i, shl);
-        if (shh) q.put_sparse(L1.base2 + pr + i, shh);
-    }
+    // (sh1 <= 10 here: with a larger shift every symbol is zero and the test above has returned; the symbols of a cell pair by packed
+    // instructions -- trunc(v / 2^sh) as in sym_shift -- are the two halves of the dword that is stored)
+    const short ms = (short)((1 << sh1) - 1), ss = (short)sh1;
+    const s16x2 mm = {ms, ms}, sv = {ss, ss}, s15 = {15, 15};
+    auto pks = [&](s16x2 v) { return (v + ((v >> s15) & mm)) >> sv; };
+    put_row4(q, L1.base0 + pr, pks(lha), pks(lhb));
+    put_row4(q, L1.base1 + pr, pks(hla), pks(hlb));
+    put_row4(q, L1.base2 + pr, pks(hha), pks(hhb));
 }
 // one scaled level (transform levels 2, 3: scan levels 1, 0) on an NxN patch of LL values -> LL patch + sparse symbols
 template <int N, int HZL>
