@@ -56,24 +56,29 @@ def traffic_stamp(T):
             "traffic_stale": T.get("csrc_sha16") != now}
 
 
-def link_rates(torch, dev, nbytes=1 << 30, reps=3):
-    """the box's host <-> device link as this process sees it (pinned memory, one stream, 1 GiB copies): GB/s each way.  The host-fed
-    figures (value_host_pinned, config 2's packet egress) are quoted against it (verdict round 4: nobody could say which fraction of the
-    link 25.8 Gpix/s was)."""
-    h = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
-    h.fill_(7)
-    d = torch.empty(nbytes, dtype=torch.uint8, device="cuda:%d" % dev)
+def link_rates(shard, dev, placement=None):
+    """the box's host <-> device link, measured through the LIBRARY's own copy path (dsvg_link_probe: hipHostMalloc'd memory, asynchronous 1 GiB copies
+    timed by HIP events, in a child process of this process's affinity) -- round 5's figure came from another allocator's pinned memory and read 29 GB/s
+    on a box where the staged clip upload then ran at 37.5 (`frac_of_link` 1.29).  When the placement probe already measured the chosen placement
+    before the GPU was touched, that measurement is the one reported."""
+    if placement and placement.get("chosen") and placement["measured"].get(placement["chosen"]):
+        return dict(placement["measured"][placement["chosen"]], source="dsvg_link_probe in a fresh child process on the chosen cores, before this process touched the GPU")
+    r = shard.link_probe(dev)
+    return dict(r, source="dsvg_link_probe in a child process of this process's affinity") if r else None
+
+
+def box_info():
+    """what the host looked like while this ran: other tenants' load, this container's CPU quota (a box is one GPU of a shared 8-GPU host)"""
     out = {}
-    for name, (dst, src) in (("h2d_GBs", (d, h)), ("d2h_GBs", (h, d))):
-        dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize(dev)
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            dst.copy_(src, non_blocking=True)
-        torch.cuda.synchronize(dev)
-        out[name] = round(nbytes * reps / (time.perf_counter() - t0) / 1e9, 2)
-    del h, d
-    torch.cuda.empty_cache()
+    try:
+        out["loadavg"] = open("/proc/loadavg").read().split()[:3]
+    except OSError:
+        pass
+    for name, path in (("cgroup_cpu_max", "/sys/fs/cgroup/cpu.max"), ("cgroup_cpuset", "/sys/fs/cgroup/cpuset.cpus.effective")):
+        try:
+            out[name] = open(path).read().strip()
+        except OSError:
+            pass
     return out
 
 
@@ -193,14 +198,21 @@ def intra_block_pct(A, clip, w, h, fmt, **cli):
     return round(100.0 * intra / max(total, 1), 1)
 
 
-def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, style=0, count_patches=False, **cli):
+def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_frames, style=0, count_patches=False, styles=None, **cli):
     """the same pipelined loop on another shape of BASELINE.json (dsv_main.c:463-489 flag mapping in make_encoder_cfg):
     `streams` x `frames` pictures per step, raw frames resident in HBM; CRF runs submit/collect, ABR (serial per frame)
     plain encode calls.  One stream is compared bit for bit with the CPU checker on its first `check_frames` frames."""
     fb = A.frame_bytes(w, h, fmt)
     clip = A.gen_clip(w, h, fmt, seed, frames, style=style)
     batch_in = np.empty((streams, frames, fb), dtype=np.uint8)
-    batch_in[:] = clip
+    if styles:
+        # `styles`: one distinct clip per entry (its own seed), dealt over the streams in turn -- the batch's branch behaviour is as mixed as the list
+        clips = [clip if k == 0 and st_ == style else A.gen_clip(w, h, fmt, seed + 7919 * k, frames, style=st_) for k, st_ in enumerate(styles)]
+        for s_ in range(streams):
+            batch_in[s_] = clips[s_ % len(clips)]
+    else:
+        clips = [clip]
+        batch_in[:] = clip
     cfg = pkg.make_encoder_cfg(w, h, fmt, **cli)
     b = pkg.Batch(cfg, streams, frames, device=dev)
     patches = None
@@ -258,6 +270,12 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
         # ... and the batch's own first stream starts with the same packets (CRF: streams are independent of the batch)
         if crf and check_frames >= frames:
             res["bit_exact_vs_cpu"] = res["bit_exact_vs_cpu"] and bytes(first[0]) == want
+            if styles:
+                # ... and three more of the distinct clips, each against the reference's encode of that clip
+                for k in sorted(set((len(clips) // 3, 2 * len(clips) // 3, len(clips) - 1)) - {0}):
+                    wk, _ = ref_encode(pkg, A, clips[k], w, h, fmt, **cli)
+                    res["bit_exact_vs_cpu"] = res["bit_exact_vs_cpu"] and bytes(first[k]) == wk
+                res["checked"] += "; the batch's streams 0, %s vs the reference's encodes of their clips" % ", ".join(str(k) for k in sorted(set((len(clips) // 3, 2 * len(clips) // 3, len(clips) - 1)) - {0}))
     return res
 
 
@@ -424,18 +442,42 @@ def main():
                          "uploaded over PCIe inside the timed region (diagnostic, DESIGN.md section 7)")
     args = ap.parse_args()
 
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # started plainly with --gpus N: be the launcher (verdict round 5: the flag was parsed and never used).  Nothing has touched the
+        # GPU yet, and the ranks are CHILDREN of this process (one per GPU, torch.distributed.run over 127.0.0.1), never an exec.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but the launcher started WORLD_SIZE=%d ranks: the line would claim the wrong n_gpus" % (args.gpus, world))
     # one process per GPU: before anything touches the GPU, take this rank's share of the host cores (the session
     # layer's worker threads, the runtime's helper threads and the first touch of the pinned buffers stay on it)
     shard = importlib.import_module("digital-subband-video-1_amd.shard")
     local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
     my_cores = shard.pin_rank_to_cores(local_rank, local_world)
     numa_node = None
+    placement = None
     if local_world <= 1 and os.environ.get("DSV1_BENCH_NO_NUMA_PIN", "0") in ("", "0"):
         # one process, one GPU: onto the cores of the GPU's NUMA node before anything touches the GPU (round 5; the host-fed figures depend on it)
-        my_cores, numa_node = shard.pin_single_rank(local_rank)
+        forced = os.environ.get("DSV1_BENCH_NUMA_NODE")            # diagnostic: pin to THIS node whatever sysfs says (tools/ab/r06_repro.sh)
+        if forced not in (None, ""):
+            my_cores, numa_node = shard.pin_single_rank(local_rank, node=int(forced))
+        elif os.environ.get("DSV1_BENCH_SYSFS_PIN", "0") not in ("", "0"):
+            my_cores, numa_node = shard.pin_single_rank(local_rank)       # round 5: trust sysfs
+        else:
+            # round 6: ask the LINK -- the host <-> device rates from fresh child processes on the sysfs node's cores, on the other node's, and
+            # unpinned, before this process touches the GPU; the process moves to the best (the sysfs node unless another is > 5 % better)
+            my_cores, numa_node, placement = shard.pin_single_rank_measured(local_rank)
     import torch
     import torch.distributed as dist
     # debugging aid for boxes with fewer GPUs than ranks (never set by the driver): all ranks share device 0 and the
@@ -548,6 +590,8 @@ def main():
     b.submit(src, on_device=ondev, held=True)                  # fill the pipeline
     sync_all()
     dropped0 = b.dropped_recons()[0]
+    if rank == 0:
+        b.breakdown_start()                         # ten HIP events and a dozen clock reads per batch (DSV1_BENCH_NO_BREAKDOWN has no A/B difference: DESIGN.md section 7)
     b.mark(0)
     t0 = time.perf_counter()
     if not ondev:
@@ -562,6 +606,7 @@ def main():
     dt = time.perf_counter() - t0
     dropped_per_step = (b.dropped_recons()[0] - dropped0) / float(max(args.steps, 1))
     gpu_ms = b.mark_ms()                            # the same region by HIP events on the device
+    breakdown = b.breakdown_stop(args.steps) if rank == 0 else None
     # the bytes the LAST TIMED step produced (all streams, in stream order), hashed before anything reuses their buffers;
     # compared further down with bytes derived from the reference encoder's output for the same clips and frame numbers
     timed_sha = timed_fnum = None
@@ -572,6 +617,31 @@ def main():
         timed_sha = hh.hexdigest()
         timed_fnum = first_picture_fnum(A, outs[0].view())
     b.collect(copy=False)                           # drain
+    # the same loop with EVERY reference picture reconstructed (verdict round 5: the headline drops the inverse transform of each closed GOP's
+    # last picture -- 320 of 3 840 --, which nobody predicts from; same packets): a few steps, never `value`
+    recon_all = None
+    if rank == 0 and world == 1 and not args.no_extras and args.input == "hbm":
+        b.sync()
+        b.recon_all(True)
+        b.submit(src, on_device=True, held=True)
+        b.sync()
+        ra_steps = max(2, min(args.steps, 8))
+        t1 = time.perf_counter()
+        for _ in range(ra_steps):
+            b.submit(src, on_device=True, held=True)
+            ra_outs = b.collect(copy=False)
+        b.sync()
+        dtr = time.perf_counter() - t1
+        hr = hashlib.sha256()
+        for o in ra_outs:
+            hr.update(o.view())
+        ra_fnum = first_picture_fnum(A, ra_outs[0].view())
+        b.collect(copy=False)
+        b.recon_all(False)
+        recon_all = {"value": round(args.gops * GOP * W * H * ra_steps / dtr / 1e6, 1), "unit": "Mpix/s", "ms_per_step": round(1e3 * dtr / ra_steps, 3), "steps": ra_steps,
+                     "sha256_last_step": hr.hexdigest(), "first_frame_number": ra_fnum,
+                     "note": "dsv1_batch_recon_all(1): every reference picture reconstructed, as the reference encoder does (dsv_encoder.c:665-708)"}
+        del ra_outs
     kinfo = None
     if rank == 0 and prof_kernel != "none":
         whole_step = False
@@ -659,7 +729,7 @@ def main():
     host_pinned = None
     link = None
     if extras:
-        link = link_rates(torch, dev)
+        link = link_rates(shard, dev, placement)
         ps = 6
         host = b.pinned(batch_in.shape)
         host[...] = batch_in
@@ -686,8 +756,8 @@ def main():
                        "steps": ps, "note": "same workload, raw frames in pinned host memory, one %.2f GB upload per step inside the step (double-buffered ingest)"
                                             % (batch_in.nbytes / 1e9),
                        # the step moves its raw frames host -> device: that rate against the link's own (measured in this run, same process, same NUMA placement)
-                       "upload_GBs": round(batch_in.nbytes * ps / dth / 1e9, 2), "link_GBs": link["h2d_GBs"],
-                       "frac_of_link": round(batch_in.nbytes * ps / dth / 1e9 / link["h2d_GBs"], 3)}
+                       "upload_GBs": round(batch_in.nbytes * ps / dth / 1e9, 2), "link_GBs": link["h2d_GBs"] if link else None,
+                       "frac_of_link": round(batch_in.nbytes * ps / dth / 1e9 / link["h2d_GBs"], 3) if link else None}
         del host
 
     tmax = dt
@@ -728,6 +798,13 @@ def main():
                            "expected_from": "the reference encoder (%s) on the %d distinct clips at the timed step's frame numbers; prev_link of each GOP's first "
                                             "picture packet set to the length of the GOP's last packet (the GOP before holds the same clip)" % (cpu["kind"], nd)}
             bit_exact = bit_exact and timed_check["equal"]
+            if recon_all:
+                want_r = [continuing_gop(A, ref_encode(pkg, A, distinct[g], W, H, FMT, start_fnum=recon_all["first_frame_number"], qp=QP, gop=GOP, rc_mode_cli=1)[0]) for g in range(nd)]
+                hw = hashlib.sha256()
+                for s in range(args.gops):
+                    hw.update(want_r[s % nd])
+                recon_all["bit_exact_vs_cpu"] = recon_all["sha256_last_step"] == hw.hexdigest()
+                bit_exact = bit_exact and recon_all["bit_exact_vs_cpu"]
             if world > 1:
                 cpu = None
         out_bytes = sum(len(o) for o in outs)
@@ -740,6 +817,9 @@ def main():
             "timed_region": {"host_clock_s": round(dt, 4), "gpu_events_s": round(gpu_ms / 1e3, 4),
                              "note": "the K timed steps by the host clock (barrier + sync on both sides: what `value` uses) and by HIP events recorded on the first "
                                      "coding stream at the region's start and behind its last coding work"},
+            "step_breakdown": breakdown,
+            "box": dict(box_info(), placement=placement),
+            "value_recon_all": recon_all,
             "warmup": args.warmup,
             "ms_per_step": round(1000.0 * tmax / args.steps, 3),
             "higher_is_better": True,
@@ -808,8 +888,19 @@ def main():
                                                config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 16 closed GOPs x 12 frames per step")
                 shapes["cfg4_8gops"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x5, 8, 12, 24, 0x21600004, 12, qp=85, gop=12, rc_mode_cli=1, scd=0),
                                             config="3840x2160 4:2:0 -gop12 -qp85 -rc_mode1 -scd0, 8 closed GOPs x 12 frames per step: one GPU's share of config 4's 64 GOPs on an 8-GPU node")
+                shapes["cfg3_4gops"] = dict(shape_bench(pkg, A, dev, W, H, FMT, 4, GOP, 60, 0x10800003, 12, qp=QP, gop=GOP, rc_mode_cli=1),
+                                            config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1, 4 closed GOPs x 12 frames = 48 frames per step: SURVEY 8(d)'s config 3 verbatim (the small-batch regime)")
                 shapes["cfg5_4k_444_abr"] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, 2, 30, 12, 0x21600005, 6, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
                                                  config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000 (ABR: every quantiser from the packet before, rate control on the device), 2 streams x 30 frames per step")
+                # config 5 at replica scale (ABR streams are "replicas only" -- several independent streams side by side are how that config fills a chip)
+                for nst in (8, 16):
+                    shapes["cfg5_abr_x%d" % nst] = dict(shape_bench(pkg, A, dev, 3840, 2160, 0x0, nst, 30, 4, 0x21600005, 0, qp=85, gop=30, rc_mode_cli=0, kbps=20000),
+                                                        config="3840x2160 4:4:4 -gop30 -qp85 -rc_mode0 -kbps20000, %d independent ABR streams x 30 frames per step (same clip in every stream; bytes checked on the 2-stream shape)" % nst)
+                # the headline's shape and batch on MIXED content: 16 distinct clips of five styles dealt over the 320 GOPs (verdict round 5: the timed batch is 4 clips of one style)
+                mix = [0, 1, 2, 4, 7, 0, 1, 2, 4, 7, 0, 1, 2, 4, 0, 0]
+                shapes["headline_mixed16"] = dict(shape_bench(pkg, A, dev, W, H, FMT, args.gops, GOP, 6, 0x10800003, 12, style=0, styles=mix, qp=QP, gop=GOP, rc_mode_cli=1),
+                                                  config="1920x1080 4:2:0 -gop12 -qp85 -rc_mode1 (the headline's flags), %d closed GOPs x 12 frames per step from 16 distinct clips of clip styles %s "
+                                                         "(0 pan + texture, 1 / 4 + flat moving objects: intra blocks, 2 static + textured square, 7 + per-pixel noise)" % (args.gops, mix))
                 # the content that leaves the lean kernels: flat moving objects force a third of the blocks intra (whole-grid
                 # k_fwd_mc_pix, k_mc for the intra blocks, dense symbols) -- same shape and batch as the headline
                 wc = A.gen_clip(W, H, FMT, 0x10800003, 4, style=4)

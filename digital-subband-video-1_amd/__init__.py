@@ -52,6 +52,7 @@ def lib():
         L.dsv1_batch_close.argtypes = [_C.c_void_p]
         L.dsv1_batch_set_fnum.argtypes = [_C.c_void_p, _C.c_int, _C.c_uint32]
         L.dsv1_batch_dropped_recons.restype = _C.c_long
+        L.dsv1_batch_recon_all.argtypes = [_C.c_void_p, _C.c_int]
         L.dsv1_batch_dropped_recons.argtypes = [_C.c_void_p, _C.POINTER(_C.c_long)]
         L.dsv1_batch_encode.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
         L.dsv1_batch_submit.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_int, _C.POINTER(Buf)]
@@ -70,6 +71,9 @@ def lib():
         L.dsvg_ctx_code_streams.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_ctx_streams_apart.argtypes = [_C.c_void_p]
         L.dsvg_ctx_copy_queue.argtypes = [_C.c_void_p]
+        L.dsvg_ctx_stream.restype = _C.c_void_p
+        L.dsvg_ctx_stream.argtypes = [_C.c_void_p]
+        L.dsvg_ctx_join.argtypes = [_C.c_void_p, _C.c_void_p]
         L.dsvg_ctx_tile_stats.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
         L.dsvg_ctx_tile_stats2.argtypes = [_C.c_void_p, _C.POINTER(_C.c_ulonglong), _C.c_int]
         L.dsvg_dev_download.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_void_p, _C.c_size_t]
@@ -85,6 +89,15 @@ def lib():
         L.dsvg_prof_enable.argtypes = [_C.c_void_p, _C.c_ulonglong]
         L.dsvg_ctx_mark.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_ctx_mark_ms.argtypes = [_C.c_void_p, _C.POINTER(_C.c_float)]
+        L.dsvg_ctx_timeline.argtypes = [_C.c_void_p, _C.c_int]
+        L.dsvg_ctx_timeline_get.argtypes = [_C.c_void_p, _C.POINTER(_C.c_double)]
+        L.dsvg_ctx_fetch_prof.argtypes = [_C.c_void_p, _C.POINTER(_C.c_double), _C.c_int]
+        L.dsv1_host_prof_enable.argtypes = [_C.c_int]
+        L.dsv1_host_prof_enable.restype = None
+        L.dsv1_host_prof_get.argtypes = [_C.POINTER(_C.c_double), _C.c_int, _C.POINTER(_C.c_long)]
+        L.dsv1_host_prof_name.restype = _C.c_char_p
+        L.dsv1_host_prof_name.argtypes = [_C.c_int]
+        L.dsvg_link_probe.argtypes = [_C.c_int, _C.c_size_t, _C.c_int, _C.POINTER(_C.c_double)]
         L.dsv1_batch_encoder.restype = _C.c_void_p
         L.dsv1_batch_encoder.argtypes = [_C.c_void_p, _C.c_int]
         L.dsvg_prof_reset.argtypes = [_C.c_void_p]
@@ -193,6 +206,10 @@ class Batch:
         n = self.L.dsv1_batch_dropped_recons(self.h, _C.byref(r))
         return int(n), int(r.value)
 
+    def recon_all(self, on=True):
+        """reconstruct every reference picture (on) / drop the ones nobody predicts from (off, the default); between batches"""
+        _chk(self.L.dsv1_batch_recon_all(self.h, 1 if on else 0), "dsv1_batch_recon_all")
+
     def encoder(self, stream):
         """the stream's DSV_ENCODER (owned by the batch): its public parameter fields may be changed between submits"""
         p = self.L.dsv1_batch_encoder(self.h, stream)
@@ -295,6 +312,39 @@ class Batch:
         ms = _C.c_float(0)
         _chk(self.L.dsvg_ctx_mark_ms(self.ctx, _C.byref(ms)), "dsvg_ctx_mark_ms")
         return ms.value
+
+    def breakdown_start(self):
+        """start the per-step accounting of a timed loop: host phases of submit / collect (process-wide), the fetch's host side and the
+        device-side marks of the pipeline's streams (dsvg_ctx_timeline)"""
+        self.L.dsv1_host_prof_enable(1)
+        v = (_C.c_double * 5)()
+        _chk(self.L.dsvg_ctx_fetch_prof(self.ctx, v, 1), "dsvg_ctx_fetch_prof")
+        _chk(self.L.dsvg_ctx_timeline(self.ctx, 1), "dsvg_ctx_timeline")
+
+    def breakdown_stop(self, steps):
+        """-> dict of ms per step (call after sync()): where the host thread spent a step, what the pipeline's streams did meanwhile"""
+        n = self.L.dsv1_host_prof_get(None, 0, None)
+        ms = (_C.c_double * n)()
+        nb = _C.c_long(0)
+        self.L.dsv1_host_prof_get(ms, n, _C.byref(nb))
+        f = (_C.c_double * 5)()
+        _chk(self.L.dsvg_ctx_fetch_prof(self.ctx, f, 1), "dsvg_ctx_fetch_prof")
+        t = (_C.c_double * 12)()
+        _chk(self.L.dsvg_ctx_timeline_get(self.ctx, t), "dsvg_ctx_timeline_get")
+        _chk(self.L.dsvg_ctx_timeline(self.ctx, 0), "dsvg_ctx_timeline")
+        self.L.dsv1_host_prof_enable(0)
+        k = float(max(steps, 1))
+        host = {self.L.dsv1_host_prof_name(i).decode(): round(ms[i], 3) for i in range(n)}
+        nph = max(t[0], 1.0)
+        return {"host_ms_per_batch": host, "host_batches": int(nb.value),
+                "fetch_host_ms_per_call": {"wait_for_coding": round(f[0], 3), "sizes_round_trip": round(f[1], 3), "gather_copy_assembly": round(f[2], 3)},
+                "fetch_bytes_per_call": int(f[3]), "fetch_calls": int(f[4]),
+                "device_ms_per_batch": {"coding_phases_seen": int(t[0]), "clip_upload": round(t[2] / nph, 3), "load_pyramid": round(t[3] / nph, 3), "motion_search": round(t[4] / nph, 3),
+                                        "table_uploads": round(t[5] / nph, 3), "coding_stream0": round(t[6] / nph, 3), "coding_stream1": round(t[7] / nph, 3),
+                                        "fetch_gather_copy": round(t[8] / nph, 3), "coding_overlapped_by_load_or_search": round(t[11] / nph, 3)},
+                "device_span_ms": round(t[1], 3),
+                "device_idle_ms_per_batch": round(t[10] / nph, 3),
+                "device_idle_note": "device time inside [first coding start, last coding end] with no load / motion-search / table-upload / coding phase in flight on any pipeline stream: the chip waiting for the host"}
 
     def prof_enable(self, kernels):
         """kernels: iterable of kernel names whose launches get HIP-event brackets (empty = off)"""

@@ -98,14 +98,30 @@ static double hp_now(void)
 }
 #define HP_BEGIN() double hp_t0_ = hp_on > 0 ? hp_now() : 0.0
 #define HP_MARK(k) do { if (hp_on > 0) { const double n_ = hp_now(); hp_acc[k] += n_ - hp_t0_; hp_t0_ = n_; } } while (0)
+static const char *const hp_nm[HP_N] = {"load+pyramid (enqueue, luma sums wait)", "GOP / scene-change decisions", "motion search (enqueue + GPU wait + D2H)",
+                                         "intra decisions + stability flags", "job tables + coding enqueue", "packet prefixes (stability / motion bits)", "fetch (GPU wait + gather + D2H)", "packet assembly"};
 static void hp_report(void)
 {
-    static const char *nm[HP_N] = {"load+pyramid (enqueue, luma sums wait)", "GOP / scene-change decisions", "motion search (enqueue + GPU wait + D2H)",
-                                   "intra decisions + stability flags", "job tables + coding enqueue", "packet prefixes (stability / motion bits)", "fetch (GPU wait + gather + D2H)", "packet assembly"};
     int k;
-    if (hp_on <= 0 || !hp_batches) return;
-    for (k = 0; k < HP_N; k++) fprintf(stderr, "[dsv1 host] %-44s %8.3f ms / batch\n", nm[k], hp_acc[k] / (double)hp_batches);
+    if (hp_on != 1 || !hp_batches) return;              /* (1: DSV1_HOST_PROF, printed; 2: switched on by dsv1_host_prof_enable, read with dsv1_host_prof_get) */
+    for (k = 0; k < HP_N; k++) fprintf(stderr, "[dsv1 host] %-44s %8.3f ms / batch\n", hp_nm[k], hp_acc[k] / (double)hp_batches);
 }
+/* the same figures as an API (verdict round 5: the bench line carries them): enable (clears the sums), then ms per submitted batch and phase */
+void dsv1_host_prof_enable(int on)
+{
+    int k;
+    for (k = 0; k < HP_N; k++) hp_acc[k] = 0.0;
+    hp_batches = 0;
+    hp_on = on ? 2 : (getenv("DSV1_HOST_PROF") != NULL);
+}
+int dsv1_host_prof_get(double *ms_per_batch, int n, long *batches)
+{
+    int k;
+    if (batches) *batches = hp_batches;
+    for (k = 0; ms_per_batch && k < n && k < HP_N; k++) ms_per_batch[k] = hp_batches ? hp_acc[k] / (double)hp_batches : 0.0;
+    return HP_N;
+}
+const char *dsv1_host_prof_name(int k) { return k >= 0 && k < HP_N ? hp_nm[k] : NULL; }
 
 /* The per-stream host phases (side info, packet assembly) are independent across streams: a
  * parallel loop over them on the worker pool (dsv1_par_for).  Workers: DSV1_HOST_THREADS, else min(12, cores / ranks on the node / 2); never more than streams. */
@@ -781,6 +797,13 @@ static int remedy_dropped(dsv1_batch *b, int n, int par)
     /* (I and P pictures may be mixed here: one frame step of n jobs on one coding stream) */
     if ((rc = dsvg_code_batch(b->ctx, 1, n, b->jobs))) return rc;
     return dsvg_ctx_sync(b->ctx);
+}
+int dsv1_batch_recon_all(dsv1_batch *b, int on)
+{
+    if (!b) return DSVG_ERR_ARG;
+    if (b->pending[0] || b->pending[1]) { dsv1_log(1, "dsv1_batch_recon_all with batches in flight"); return DSVG_ERR_ARG; }
+    b->keep_all = on != 0;
+    return DSVG_OK;
 }
 long dsv1_batch_dropped_recons(const dsv1_batch *b, long *remedied)
 {

@@ -3422,8 +3422,8 @@ void launch_inv54_all(hipStream_t st, const JobDev *jobs, int njobs, const SbtGe
 // luma plane an exact multiple of them, and the widths / strides what the 16-byte border stores need.
 bool inv_sbt_fuses_border(const SbtGeo3 &G, int insym_c, int patch_kernel_c)
 {
-    static const bool off = getenv("DSV1_NO_FUSED_BORDER") != nullptr;         // (A/B)
-    if (off || !insym_c || !patch_kernel_c || getenv("DSV1_NO_PATCH_PART")) return false;
+    static const bool off = getenv("DSV1_NO_FUSED_BORDER") != nullptr || getenv("DSV1_NO_PATCH_PART") != nullptr;   // (A/B; read once: this sits on the enqueue path)
+    if (off || !insym_c || !patch_kernel_c) return false;
     const SbtGeo &g = G.g[1], &gy = G.g[0];
     for (int c = 1; c <= 2; c++) {
         const SbtGeo &q = G.g[c];

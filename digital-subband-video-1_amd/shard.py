@@ -100,15 +100,117 @@ def gpu_numa_node(dev):
     code = ("import ctypes as C\n"
             "h = C.CDLL('libamdhip64.so')\n"
             "b = C.create_string_buffer(64)\n"
-            "print(b.value.decode() if h.hipDeviceGetPCIBusId(b, 64, %d) != 0 else b.value.decode())\n" % int(dev))
+            "rc = h.hipDeviceGetPCIBusId(b, 64, %d)\n"
+            "print('BUSID ' + b.value.decode() if rc == 0 else 'BUSID-FAILED %%d' %% rc)\n" % int(dev))
+    # the child must not inherit a profiler's preload (rocprofv3 -- python3 bench.py: it would write an output directory of its own beside
+    # the parent's, and tools that pick "the" trace file would pick the child's -- advisor round 5)
+    env = _scrubbed_env()
     try:
-        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60)
-        bus = r.stdout.strip().splitlines()[-1].strip().lower() if r.stdout.strip() else ""
-        if not bus:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=60, env=env)
+        bus = ""
+        for ln in r.stdout.splitlines():
+            if ln.startswith("BUSID "):
+                bus = ln[6:].strip().lower()
+        if r.returncode != 0 or not bus or "/" in bus or ".." in bus:
             return -1
         return int(open(os.path.join("/sys/bus/pci/devices", bus, "numa_node")).read().strip())
     except (OSError, ValueError, subprocess.SubprocessError, IndexError):
         return -1
+
+
+def _scrubbed_env():
+    """the environment for a short-lived helper child: no profiler preload (a child under rocprofv3's preload writes an output directory of its own)"""
+    import os
+    return {k: v for k, v in os.environ.items()
+            if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTRACER_", "RPD_"))}
+
+
+def link_probe(dev, cores=None, nbytes=1 << 29, reps=4, timeout=120):
+    """The host <-> device link of HIP device `dev` as a process running on `cores` (None: this process's mask) sees it, measured through the
+    library's own copy path (dsvg_link_probe: hipHostMalloc'd memory first touched on those cores, asynchronous copies, HIP events) in a
+    short-lived CHILD process -- the caller need not have touched the GPU, and its own affinity does not change.
+    Returns {"h2d_GBs": .., "d2h_GBs": ..} or None when the child failed (no device, no library)."""
+    import os
+    import subprocess
+    import sys
+    so = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libdsv1_mi355x.so")
+    code = ("import ctypes as C, os, sys\n"
+            "cores = %r\n"
+            "if cores: os.sched_setaffinity(0, cores)\n"
+            "L = C.CDLL(%r)\n"
+            "g = (C.c_double * 2)()\n"
+            "L.dsvg_link_probe.argtypes = [C.c_int, C.c_size_t, C.c_int, C.POINTER(C.c_double)]\n"
+            "rc = L.dsvg_link_probe(%d, %d, %d, g)\n"
+            "print('LINK %%d %%.3f %%.3f' %% (rc, g[0], g[1]))\n" % (sorted(cores) if cores else None, so, int(dev), int(nbytes), int(reps)))
+    try:
+        r = subprocess.run([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, timeout=timeout, env=_scrubbed_env())
+        for ln in r.stdout.splitlines():
+            if ln.startswith("LINK "):
+                f = ln.split()
+                if int(f[1]) == 0 and float(f[2]) > 0 and float(f[3]) > 0:
+                    return {"h2d_GBs": round(float(f[2]), 2), "d2h_GBs": round(float(f[3]), 2)}
+    except (OSError, ValueError, subprocess.SubprocessError, IndexError):
+        pass
+    return None
+
+
+def host_nodes():
+    """the NUMA nodes of the host that have cores, from sysfs ([] if it does not tell)"""
+    import glob
+    import os
+    out = []
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try:
+            n = int(os.path.basename(d)[4:])
+        except ValueError:
+            continue
+        if _node_cpus(n):
+            out.append(n)
+    return sorted(out)
+
+
+def choose_placement(cands, margin=1.05):
+    """cands: [(name, cores, rates-or-None)] in order of preference (the sysfs node first).  Keeps the first candidate unless a later one's
+    link (the slower direction counts: a step uploads frames AND fetches packets) is better by more than `margin` -- box-to-box noise must
+    not move the process off the node sysfs names.  Returns the index, or -1 when nothing was measured."""
+    best, best_v = -1, 0.0
+    for i, (_, _, r) in enumerate(cands):
+        if not r:
+            continue
+        v = min(r["h2d_GBs"], r["d2h_GBs"])
+        if best < 0 or v > best_v * margin:
+            best, best_v = i, v
+    return best
+
+
+def pin_single_rank_measured(dev, probe=link_probe, nodes=None, node_cpus=None, sysfs_node=None):
+    """pin_single_rank with the question ASKED OF THE LINK (verdict round 5: the driver's box read 29 GB/s pinned to the node sysfs named, half of what
+    the builder's boxes read -- nobody could say whether the pin or the box was slow).  Before the caller touches the GPU: the link is measured
+    from fresh child processes running (a) on the cores of the node sysfs names for the GPU, (b) on each other node's cores, (c) unpinned; the
+    process moves to the best placement (choose_placement: the sysfs node unless another is > 5 % better).
+    Returns (cores taken, node or None for unpinned, report dict with every measurement)."""
+    import os
+    allowed = sorted(os.sched_getaffinity(0))
+    ncpus = node_cpus or _node_cpus
+    sysn = gpu_numa_node(dev) if sysfs_node is None else sysfs_node
+    cands = []
+    order = ([sysn] if sysn is not None and sysn >= 0 else []) + [n for n in (host_nodes() if nodes is None else nodes) if n != sysn]
+    for n in order:
+        cores = sorted(set(allowed) & set(ncpus(n)))
+        if cores and len(cores) < len(allowed):
+            cands.append(("node%d" % n, cores, None))
+    cands.append(("unpinned", allowed, None))
+    cands = [(nm, cores, probe(dev, cores)) for nm, cores, _ in cands]
+    k = choose_placement(cands)
+    report = {"sysfs_node": sysn, "measured": {nm: r for nm, _, r in cands}, "chosen": cands[k][0] if k >= 0 else None}
+    if k < 0:
+        return allowed, None, report
+    name, cores, _ = cands[k]
+    if name != "unpinned":
+        os.sched_setaffinity(0, cores)
+        os.environ["DSV1_CORES_PINNED"] = "1"
+        return cores, int(name[4:]), report
+    return allowed, None, report
 
 
 def pin_single_rank(dev, node=None, node_cpus=None):

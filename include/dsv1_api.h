@@ -153,6 +153,11 @@ void *dsv_alloc(int size);
 void dsv1_release_parked(void);
 size_t dsv1_parked_bytes(void);
 int dsv1_recycle_hold(int delta);
+/* host phases of dsv1_batch_submit / _collect (round 6): dsv1_host_prof_enable(1) clears and starts the sums, dsv1_host_prof_get returns the
+ * number of phases and fills ms per submitted batch for the first n of them (dsv1_host_prof_name(k) says what phase k is); process-wide. */
+void dsv1_host_prof_enable(int on);
+int dsv1_host_prof_get(double *ms_per_batch, int n, long *batches);
+const char *dsv1_host_prof_name(int k);
 void dsv1_debug_fail_alloc_at(int n);        /* tests: the n-th host allocation of the next dsv1_batch_open / dsv1_stream_open fails (0 = off) */
 void dsv_free(void *ptr);
 void dsv_memory_report(void);
@@ -187,6 +192,8 @@ void dsv1_batch_set_fnum(dsv1_batch *b, int stream, DSV_FNUM next_fnum);
  * submit codes the dropped picture again with its reconstruction kept (remedied) before it goes on.  Returns how many reconstructions
  * were dropped so far.  DSV1_RECON_ALL=1: every reference picture is reconstructed. */
 long dsv1_batch_dropped_recons(const dsv1_batch *b, long *remedied);
+/* the same switch as a call (between batches: nothing in flight): on != 0 reconstructs every reference picture from the next submit on */
+int  dsv1_batch_recon_all(dsv1_batch *b, int on);
 /* stream s's encoder struct (the batch owns it).  Its public parameter fields -- quality, bitrate, min_ / max_quality,
  * min_I_frame_quality, max_q_step, rc_high_motion_nudge; dsv_enc_force_metadata -- may be changed between submits, as a caller of
  * the reference changes them between dsv_enc calls; geometry, GOP structure and rate-control mode may not. */

@@ -67,6 +67,10 @@ typedef struct {                                                                
 const char *dsvg_last_error(void);          /* thread-local description of the last failure */
 int dsvg_device_count(void);                /* number of HIP devices (0 = none) */
 int dsvg_set_device(int device);            /* device used by the operator-level calls (default 0) */
+/* the host <-> device link as the pipeline's own copies use it: hipHostMalloc'd memory first touched by the calling thread, `reps` asynchronous
+ * copies of `bytes` each way on a stream of their own, timed by HIP events.  gbs[0] = host -> device, gbs[1] = device -> host, GB/s.  A
+ * diagnostic (bench.py's `link`, shard.py's choice of the NUMA node to run on): call it from a short-lived process of the affinity in question. */
+int dsvg_link_probe(int device, size_t bytes, int reps, double gbs[2]);
 
 /* ---------------------------------------------------------------------------------------------
  * 1. operator level -- twins of the reference operator API
@@ -126,7 +130,15 @@ int dsvg_ctx_streams_apart(const dsvg_ctx *ctx);
  * priority, whose queues the runtime keeps apart from the plain streams' four), 1 = it shares the analysis stream's queue, -1 = wherever the
  * runtime put it (small contexts, probe off) */
 int dsvg_ctx_copy_queue(const dsvg_ctx *ctx);
-void *dsvg_ctx_stream(dsvg_ctx *ctx);        /* the first coding hipStream_t (operator-style callers: dsvg_download_recon, dsvg_pack_recons run on it) */
+/* The first coding hipStream_t (operator-style callers: dsvg_download_recon and the host-output dsvg_pack_recons run on it).  ORDERING: work put on
+ * the handle after this call runs behind everything the context has enqueued so far, including a device-output packing pass that dsvg_pack_recons
+ * placed on the second coding stream (round 5): the call itself makes the first stream wait for that pass.  A handle fetched BEFORE a later
+ * dsvg_pack_recons says nothing about that later pass -- ask again after it (cheap), or use dsvg_ctx_join.  NULL on error. */
+void *dsvg_ctx_stream(dsvg_ctx *ctx);
+/* make `stream` (a hipStream_t of the caller's on the context's device; NULL or the first coding stream itself: only the join below) wait for
+ * everything the context has enqueued so far on its first coding stream and for a pending device-output packing pass: what a consumer of
+ * dsvg_pack_recons(.., out_on_device=1) calls before it reads yuv_out in stream order, without a whole-context dsvg_ctx_sync. */
+int dsvg_ctx_join(dsvg_ctx *ctx, void *stream);
 /* Sparse P pictures: tiles of the fused inverse transform (128x64 pixels) counted since the previous call --
  * out[0], out[1] = tiles that took the general path (luma, chroma), out[2], out[3] = tiles found empty (no detail symbol,
  * LL3 zero: reconstruction = prediction, nothing computed).  Counting is off until a call with enable != 0 and stops
@@ -278,7 +290,9 @@ int dsvg_extend_recon(dsvg_ctx *ctx, int recon_slot);
  * carries its reference picture over when the stream changes its block size and a new context is needed.  Syncs. */
 int dsvg_upload_recon_raw(dsvg_ctx *ctx, int recon_slot, const uint8_t *raw, size_t bytes);
 /* n reconstruction slots -> tightly packed planar frames, frame i at yuv_out + i*out_pitch.  Device output: enqueued
- * on the pipeline stream, no sync (dsvg_ctx_sync before reading it).  Host output: copied back and synchronised. */
+ * without a sync: on the first coding stream, or -- n >= 4, decoder contexts -- on the second one beside the next call's entropy decoding.
+ * Before reading it: dsvg_ctx_sync, or order the consumer behind the pass with dsvg_ctx_join(ctx, consumer_stream) / a dsvg_ctx_stream()
+ * handle fetched AFTER this call.  Host output: copied back and synchronised. */
 int dsvg_pack_recons(dsvg_ctx *ctx, int n, const int *recon_slots, void *yuv_out, size_t out_pitch, int out_on_device);
 
 /* Decoder side: coefficient (run,value) pairs parsed on the host are scattered + dequantised,
@@ -310,6 +324,17 @@ long dsvg_ctx_decoder_redone(const dsvg_ctx *ctx);
  * host clock so that the headline can be corroborated from the device side. */
 int dsvg_ctx_mark(dsvg_ctx *ctx, int which);
 int dsvg_ctx_mark_ms(dsvg_ctx *ctx, float *ms);
+/* Where a step's time goes, from the pipeline's own streams (round 6): dsvg_ctx_timeline(ctx, 1) starts collecting timing marks at the boundaries of
+ * clip upload / frame load + pyramid / motion search / table uploads / coding (both coding streams) / fetch (one HIP event per mark, ten per batch;
+ * 0 stops and clears).  dsvg_ctx_timeline_get (context synchronised) sums them: out[0] = coding phases seen, [1] = device ms first mark .. last mark,
+ * [2] upload, [3] load, [4] motion search, [5] table uploads, [6] coding on the first stream, [7] on the second, [8] fetch (gather + copies) --
+ * device ms summed over the phases --, [9] = ms during which none of load / search / tables / coding was in flight (the chip waits for the host),
+ * [10] = the same inside [first coding start, last coding end], [11] = ms of coding overlapped by a load / search phase. */
+int dsvg_ctx_timeline(dsvg_ctx *ctx, int on);
+int dsvg_ctx_timeline_get(dsvg_ctx *ctx, double out[12]);
+/* the host's side of dsvg_fetch_pictures(_cb) per call since the last reset: out[0] = ms waiting for the coding calls behind the slots, [1] = ms for
+ * the plane summaries (a small device-to-host round trip), [2] = ms for gather + the copy in pieces + the callback's work, [3] = bytes copied, [4] = calls */
+int dsvg_ctx_fetch_prof(dsvg_ctx *ctx, double out[5], int reset);
 int dsvg_prof_kernels(void);
 const char *dsvg_prof_kernel_name(int kid);
 int dsvg_prof_enable(dsvg_ctx *ctx, unsigned long long kernel_mask);

@@ -485,3 +485,51 @@ def test_batched_decoder_back_to_back_calls_on_two_streams(pkg, orc, rep):
     for t in range(n):
         for s in range(S):
             A.assert_same("stream %d frame %d" % (s, t), frames[t][s], want[s % 4][t])
+
+
+@pytest.mark.parametrize("how", ["handle_after_pack", "join_own_stream"])
+def test_packed_device_output_is_consumed_in_stream_order(pkg, orc, how):
+    """advisor round 5: the packing pass of device output runs on the SECOND coding stream (n >= 4); include/dsvg.h promises that a consumer
+    ordered on a dsvg_ctx_stream() handle fetched after the pass -- or on its own stream after dsvg_ctx_join -- reads finished frames.
+    No dsvg_ctx_sync anywhere between the decode call and the read: an asynchronous copy on that stream, then a wait for THAT stream only."""
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
+    hip.hipStreamSynchronize.argtypes = [C.c_void_p]
+    hip.hipStreamCreateWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_uint]
+    hip.hipStreamDestroy.argtypes = [C.c_void_p]
+    w, h, fmt, S, n = 1280, 720, A.SUBSAMP_420, 16, 6
+    clip = A.gen_clip(w, h, fmt, 0x0CDE5, n, style=2)
+    st, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, qp=85, gop=12, rc_mode_cli=1))
+    pks = [p for p in A.split_packets(st) if (p[5] & 4) or p[5] == 0]
+    want = A.orc_decode(st, w, h, fmt)
+    d = pkg.DecBatch(w, h, fmt, S)
+    L = pkg.lib()
+    own = C.c_void_p(None)
+    try:
+        if how == "join_own_stream":
+            assert hip.hipStreamCreateWithFlags(C.byref(own), 1) == 0          # hipStreamNonBlocking
+        k = 0
+        for p in pks:
+            if not (p[5] & 4):
+                d.decode([p] * S)
+                continue
+            buf = d.dev_alloc()
+            _, status, _ = d.decode([p] * S, out=buf, on_device=True)
+            assert all(x == 0 for x in status), status
+            if how == "handle_after_pack":
+                s_ = L.dsvg_ctx_stream(d.ctx)
+                assert s_
+            else:
+                assert L.dsvg_ctx_join(d.ctx, own) == 0, L.dsvg_last_error()
+                s_ = own.value
+            got = np.empty((S, d.frame_bytes), dtype=np.uint8)
+            assert hip.hipMemcpyAsync(got.ctypes.data, buf, got.nbytes, 2, s_) == 0
+            assert hip.hipStreamSynchronize(s_) == 0
+            for s in (0, 7, S - 1):
+                A.assert_same("picture %d stream %d" % (k, s), got[s], want[k])
+            k += 1
+        assert k == len(want)
+    finally:
+        d.close()
+        if own:
+            hip.hipStreamDestroy(own)
