@@ -272,10 +272,12 @@ def shape_bench(pkg, A, dev, w, h, fmt, streams, frames, steps, seed, check_fram
             res["bit_exact_vs_cpu"] = res["bit_exact_vs_cpu"] and bytes(first[0]) == want
             if styles:
                 # ... and three more of the distinct clips, each against the reference's encode of that clip
-                for k in sorted(set((len(clips) // 3, 2 * len(clips) // 3, len(clips) - 1)) - {0}):
+                nc = min(len(clips), streams)
+                ks = sorted(set((nc // 3, 2 * nc // 3, nc - 1)) - {0})
+                for k in ks:
                     wk, _ = ref_encode(pkg, A, clips[k], w, h, fmt, **cli)
                     res["bit_exact_vs_cpu"] = res["bit_exact_vs_cpu"] and bytes(first[k]) == wk
-                res["checked"] += "; the batch's streams 0, %s vs the reference's encodes of their clips" % ", ".join(str(k) for k in sorted(set((len(clips) // 3, 2 * len(clips) // 3, len(clips) - 1)) - {0}))
+                res["checked"] += "; the batch's streams 0, %s vs the reference's encodes of their clips" % ", ".join(str(k) for k in ks)
     return res
 
 

@@ -115,37 +115,6 @@ static int pick_streams(hipStream_t *out, int want, hipStream_t *copy_out = null
     return good;
 }
 
-// A stream confined to a set of compute units (experiment, DESIGN section 8: the streaming kernels and the instruction-bound ones on
-// disjoint CUs instead of time slices).  spec: comma-separated bit ranges "a-b" / single bits of the 256-bit CU mask; "xA-B": every
-// bit whose index mod 8 lies in A..B (on this part bit i is a CU of XCD i mod 8, dealt over that XCD's shader engines in turn:
-// tools/ubench/cumask_probe.hip prints the placement); a leading '!' takes the complement.
-static bool cu_mask_stream(hipStream_t *out, const char *spec, const char *what)
-{
-    uint32_t m[8] = {};
-    const char *p = spec;
-    const bool inv = *p == '!';
-    if (inv) p++;
-    while (*p) {
-        const bool xcd = *p == 'x';
-        if (xcd) p++;
-        char *e = nullptr;
-        long a = strtol(p, &e, 10), b = a;
-        if (e == p) return false;
-        p = e;
-        if (*p == '-') { b = strtol(p + 1, &e, 10); if (e == p + 1) return false; p = e; }
-        if (a < 0 || b < a || b > 255) return false;
-        for (int i = 0; i < 256; i++)
-            if (xcd ? ((i & 7) >= a && (i & 7) <= b) : (i >= a && i <= b)) m[i >> 5] |= 1u << (i & 31);
-        if (*p == ',') p++;
-    }
-    int n = 0;
-    for (int i = 0; i < 8; i++) { if (inv) m[i] = ~m[i]; n += __builtin_popcount(m[i]); }
-    if (!n) return false;
-    if (hipExtStreamCreateWithCUMask(out, 8, m) != hipSuccess) { (void)hipGetLastError(); return false; }
-    fprintf(stderr, "[dsvg] %s stream on %d CUs (mask %08x %08x %08x %08x %08x %08x %08x %08x)\n", what, n, m[0], m[1], m[2], m[3], m[4], m[5], m[6], m[7]);
-    return true;
-}
-
 struct dsvg_ctx {
     int device = 0;
     hipStream_t st = nullptr;        // residual-coding stream
@@ -192,7 +161,6 @@ struct dsvg_ctx {
     int32_t *llsym = nullptr;        // per work job: LL-region symbols of the encoder (JobDev.llsym)
     int ll_off[3] = {0, 0, 0};
     size_t ll_total = 0;
-    int defer_T = 0;                 // DSV1_DEFER_ENTROPY=<frame steps>: the entropy stage of P frame steps runs after the call's last reconstruction (symbol / flag planes per step)
     bool llq = true;                 // the LL quantiser runs inside k_fwd_haar_mid<4> / k_tail_q (DSV1_NO_LLQ=1: k_hz_quant<true>, A/B)
     int16_t *symP = nullptr;         // the same for P pictures: kept ZERO between pictures (sparse stores, k_hz_collect clears)
     uint8_t *pflag = nullptr;        // per work job: flag byte per 8x8-pixel patch and plane (indexed like s3)
@@ -203,7 +171,6 @@ struct dsvg_ctx {
     bool no_dec_sym_I = false;       // DSV1_NO_DEC_SYM_I: the decoder's I pictures keep int32 coefficients (A/B switch)
     bool no_dec_sym = false;         // DSV1_NO_DEC_SYM: the decoder keeps int32 coefficients for P pictures too (A/B switch)
     bool dec_sym_ok[2] = {false, false};   // luma / chroma planes have no cell shared between scan regions
-    bool fetch_shared = false;       // DSV1_FETCH_ON_ANALYSIS: st_c is st_a           // counted only between dsvg_ctx_tile_stats(.., enable) calls (bench, tests)
     HzPlaneSum *psum = nullptr;
     uint8_t *bits = nullptr;
     DMV *mvs = nullptr;
@@ -449,7 +416,7 @@ static void ctx_free(dsvg_ctx *c)
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     for (hipEvent_t e : c->ev_fetch) (void)hipEventDestroy(e);
     if (c->ev_a) (void)hipEventDestroy(c->ev_a);
-    if (c->st_c && !c->fetch_shared) (void)hipStreamDestroy(c->st_c);
+    if (c->st_c) (void)hipStreamDestroy(c->st_c);
     if (c->st_h) (void)hipStreamDestroy(c->st_h);
     for (int i = 0; i < 2; i++) {
         if (c->ev_up[i]) (void)hipEventDestroy(c->ev_up[i]);
@@ -581,40 +548,11 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
                                                  copy_shared == 0 ? "a queue of its own" : (copy_shared >= 2 ? "a queue of its own (priority stream)" : (copy_shared == 1 ? "shares the analysis stream's queue" : "as the runtime places it")));
         if (good < 0) { dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP); }
         c->st = ps[0]; c->st_a = ps[1];
-        if (const char *pr = getenv("DSV1_ANALYSIS_PRIO")) {    // experiment: the analysis stream at another priority (-1 high, 1 low)
-            int lo = 0, hi = 0;
-            hipStream_t hs = nullptr;
-            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess &&
-                hipStreamCreateWithPriority(&hs, hipStreamNonBlocking, atoi(pr) < 0 ? hi : lo) == hipSuccess) {
-                (void)hipStreamDestroy(c->st_a);
-                c->st_a = hs;
-                fprintf(stderr, "[dsvg] analysis stream priority %d (range %d..%d)\n", atoi(pr) < 0 ? hi : lo, lo, hi);
-            }
-        }
         for (int g = 1; g < std::max(ncs, 2); g++) c->stx[g] = ps[1 + g];      // every stream is owned by the ctx before anything can fail
         c->st_c = ps[want - 1];
-        if (getenv("DSV1_FETCH_ON_ANALYSIS")) {                 // experiment: the fetch copies share the analysis stream (one busy stream fewer)
-            (void)hipStreamDestroy(c->st_c);
-            c->st_c = c->st_a;
-            c->fetch_shared = true;
-        }
         for (int g = 1; g < std::max(ncs, 2); g++)
             if (hipEventCreateWithFlags(&c->ev_join[g], hipEventDisableTiming) != hipSuccess) { dsvg_set_error("hipEventCreate failed"); return fail(DSVG_ERR_HIP); }
         c->streams_apart = good;
-        // experiment: CU-masked streams -- DSV1_CU_ANALYSIS / DSV1_CU_CODE replace the analysis / every coding stream,
-        // DSV1_CU_LOAD gives the frame-load kernels (k_unpack, k_ds2x, k_extend16 of the sources, k_luma_sum) a stream of their own
-        auto masked = [&](const char *env, hipStream_t *s, const char *what, bool replace) {
-            const char *spec = getenv(env);
-            hipStream_t ns = nullptr;
-            if (!spec || !*spec) return;
-            if (!cu_mask_stream(&ns, spec, what)) { fprintf(stderr, "[dsvg] %s=%s: no masked stream (bad spec or not supported), ignored\n", env, spec); return; }
-            if (replace && *s) (void)hipStreamDestroy(*s);
-            *s = ns;
-        };
-        masked("DSV1_CU_ANALYSIS", &c->st_a, "analysis", true);
-        masked("DSV1_CU_CODE", &c->st, "coding", true);
-        for (int g = 1; g < std::max(ncs, 2); g++) masked(g == 1 && getenv("DSV1_CU_CODE2") ? "DSV1_CU_CODE2" : "DSV1_CU_CODE", &c->stx[g], "coding", true);
-        masked("DSV1_CU_LOAD", &c->st_l, "frame-load", false);
     } else if (hipStreamCreateWithFlags(&c->st, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->st_a, hipStreamNonBlocking) != hipSuccess ||
                hipStreamCreateWithFlags(&c->st_c, hipStreamNonBlocking) != hipSuccess) {
         dsvg_set_error("hipStreamCreate failed"); return fail(DSVG_ERR_HIP);      // one picture (or a few) at a time: streams as they come
@@ -641,8 +579,7 @@ extern "C" int dsvg_ctx_create_blk(dsvg_ctx **out, int device, int width, int he
     if ((rc = dmalloc(&c->nzval, c->nz_total * J, false))) return fail(rc);
     if ((rc = dmalloc(&c->chunks, (size_t)c->chunks_per_job * J, true))) return fail(rc);
     if ((rc = dmalloc(&c->sym, c->nz_total * J, true))) return fail(rc);
-    { const char *e = getenv("DSV1_DEFER_ENTROPY"); c->defer_T = e ? std::max(0, atoi(e)) : 0; }
-    const size_t DT = (size_t)std::max(1, c->defer_T);
+    const size_t DT = 1;        // (one set of symbol / flag planes per work job; round 3's deferred entropy stage kept one per frame step: a measured dead end)
     if ((rc = dmalloc(&c->nzf, (c->nz_total >> 2) * J * DT, true))) return fail(rc);
     if ((rc = dmalloc(&c->symP, c->nz_total * J * DT, true))) return fail(rc);
     if ((rc = dmalloc(&c->pflag, CL.s3total * J, true))) return fail(rc);
@@ -882,14 +819,9 @@ static int ingest_reserve(dsvg_ctx *c, size_t bytes, int *kout)
 {
     HIPCHK(hipSetDevice(c->device));
     if (!c->st_h) {
-        // (small contexts, or no probed candidate: pick_streams placed none)  DSV1_INGEST_MASKED_STREAM=1: a stream created with a CU mask of
-        // all ones gets a hardware queue of its own whatever GPU_MAX_HW_QUEUES says -- and hung dsv_enc's frame-at-a-time ingest (many small
-        // copies) in a third of the runs of tests/test_gpu_stream.py -k drop_in: opt-in only
-        uint32_t all[8] = {~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u, ~0u};
-        if (!getenv("DSV1_INGEST_MASKED_STREAM") || hipExtStreamCreateWithCUMask(&c->st_h, 8, all) != hipSuccess) {
-            (void)hipGetLastError();
-            HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
-        }
+        // (small contexts, or no probed candidate: pick_streams placed none.  A stream with a CU mask of all ones would get a hardware queue of its
+        // own and hung dsv_enc's frame-at-a-time ingest in a third of the runs: DESIGN section 7, dead ends)
+        HIPCHK(hipStreamCreateWithFlags(&c->st_h, hipStreamNonBlocking));
     }
     if (!c->ev_up[0]) {
         for (int i = 0; i < 2; i++) {
@@ -1161,7 +1093,6 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     const size_t per = (size_t)(c->levels + 1) * c->nblk;
     // (every vector a later level, k_hme_detail or the copy below reads is written by the launch of its level -- blocks beyond a
     // pyramid level's frame write their zero vector themselves: no clearing of the field, 116 MB per 320-GOP step through a slow fill)
-    if (getenv("DSV1_CLEAR_MVF")) HIPCHK(hipMemsetAsync(c->mvf, 0, per * npairs * sizeof(DMV), c->st_a));
     HmeArgs A; memset(&A, 0, sizeof(A));
     for (int l = 0; l <= c->levels; l++) { A.L[l] = c->L[l]; A.slab[l] = c->src[l].p; }
     A.cur_slots = c->slots_d; A.ref_slots = c->slots_d + c->out_slots;
@@ -1375,7 +1306,6 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
             for (int r = 0; r < c->n_recon; r++) if (now[r] >= 0) writer[r] = now[r];
         }
     }
-    const bool defer = c->defer_T > 0 && nsteps > 1 && nsteps <= c->defer_T && !rcj;     // (experiment: DSV1_DEFER_ENTROPY)
     int gk[DSVG_MAX_CODE_STREAMS + 1];                        // device jobs [gk[g], gk[g+1]) of every step -> stream g
     for (int g = 0; g <= NG; g++) gk[g] = (int)((long)njobs * g / NG);
     std::vector<int> ioff((size_t)NG * nsteps, 0), icnt((size_t)NG * nsteps, 0);
@@ -1418,7 +1348,7 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
     }
     {   // the job records themselves (quantiser tables of three planes, pointers, copies of the block tables): independent per
         // job, built on the session layer's worker pool (1 920 jobs: 1.5 ms on one thread)
-        struct BuildCtx { dsvg_ctx *c; const std::vector<const dsvg_pic_job *> *dj; int base, njobs; bool defer; } bc = {c, &dj, base, njobs, defer};
+        struct BuildCtx { dsvg_ctx *c; const std::vector<const dsvg_pic_job *> *dj; int base, njobs; } bc = {c, &dj, base, njobs};
         dsv1_par_for(total, [](void *vp, int idx, int) {
             BuildCtx &B = *static_cast<BuildCtx *>(vp);
             dsvg_ctx *c = B.c;
@@ -1429,8 +1359,7 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
             fill_job(c, jb, k, isP, j.quant, d);
             jb.fused = 1;                      // quantisation fused into the forward transform (I and P pictures)
             jb.llq = c->llq ? 1 : 0;           // ... and the LL region's into the kernels that produce it
-            // (deferred entropy stage: every frame step of the call has symbol / flag planes of its own)
-            const size_t kk = B.defer ? (size_t)(idx / B.njobs) * (size_t)c->max_jobs + (size_t)k : (size_t)k;
+            const size_t kk = (size_t)k;
             jb.llsym = c->llsym + kk * c->ll_total;
             for (int p = 0; p < 3; p++) jb.ll_off[p] = c->ll_off[p];
             jb.cflag = c->cflag + kk * c->chunks_per_job;
@@ -1562,7 +1491,7 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
             bool keeps = false;
             for (int k = k0; k < k0 + n && !keeps; k++) keeps = dj[(size_t)t * njobs + k]->recon_slot >= 0;
             if (keeps) OPCHK(enqueue_recon(c, nI, n, d0, 7, st, true, c->llq));
-            if (!(defer && nIs[t] == 0)) launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
+            launch_hz_pack(st, jd, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : nI);
             // rate control: the sizes of these packets -> the quantiser tables of the same streams' pictures of the next step
             if (rcj) launch_rc(st, c->jobs_d, c->rcj_d, c->rc_state_d, d0, n, 1);
         }
@@ -1589,15 +1518,6 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
                 for (int g = 0; g < NG; g++) OPCHK(enqueue_steps(g, t, t + 1));
         }
     }
-    if (defer)      // the entropy stage of the P frame steps, off the chain reconstruction(t) -> forward(t + 1)
-        for (int t = 0; t < nsteps; t++) {
-            if (nIs[t] != 0) continue;
-            for (int g = 0; g < NG; g++) {
-                hipStream_t st = g ? c->stx[g] : c->st;
-                const int k0 = gk[g], n = gk[g + 1] - gk[g];
-                launch_hz_pack(st, c->jobs_d + base + t * njobs + k0, n, c->chunks_per_job, &c->prof, (double)c->CL.total, 0, c->no_list_pack ? -1 : 0);
-            }
-        }
     if (NG > 1) { tl_mark(c, c->st, "code1a"); tl_mark(c, c->stx[1], "code1b"); }
     for (int g = 1; g < NG; g++) {
         HIPCHK(hipEventRecord(c->ev_join[g], c->stx[g]));

@@ -931,11 +931,6 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         dsv1_par_for(S, side_stream, &sc_);
     }
     HP_MARK(HP_SIDEINFO);
-    {   /* experiment ("the host is co-critical"): extra host time in front of the coding enqueue */
-        static int delay_us = -1;
-        if (delay_us < 0) { const char *e = getenv("DSV1_DEBUG_HOST_DELAY_US"); delay_us = e ? atoi(e) : 0; }
-        if (delay_us > 0) { struct timespec ts; ts.tv_sec = 0; ts.tv_nsec = 1000L * delay_us; nanosleep(&ts, NULL); }
-    }
     /* 5. residual coding, frame step by frame step across all streams */
     {
         const int abr = e0->rc_mode != DSV_RATE_CONTROL_CRF;

@@ -48,9 +48,20 @@ def test_bench_line_carries_the_other_shapes():
     assert d["value_host_pinned"]["value"] > 0 and d["value_host_pinned"]["value"] < d["value"] * 1.5
     sh = d["shapes"]
     assert "error" not in sh, sh
-    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg4_8gops", "cfg5_4k_444_abr", "cfg3_worstcase", "decode_1080p_batched"):
+    for k in ("cfg2_1080p_intra", "cfg4_4k_gop12", "cfg4_8gops", "cfg3_4gops", "cfg5_4k_444_abr", "headline_mixed16", "cfg3_worstcase", "decode_1080p_batched"):
         assert sh[k]["Mpix_s"] > 0 and sh[k]["bit_exact_vs_cpu"] is True, (k, sh[k])
     assert sh["cfg3_worstcase"]["intra_blocks_pct_of_P_pictures"] > 25          # the clip really leaves the lean path
+    for k in ("cfg5_abr_x8", "cfg5_abr_x16"):
+        assert sh[k]["Mpix_s"] > 0, (k, sh[k])
+    # round 6: the line explains itself -- host phases, device-side phase sums and idle time, the link as the library's copies see it
+    sb = d["step_breakdown"]
+    assert sb["host_batches"] == 1 and sb["device_ms_per_batch"]["coding_phases_seen"] == 1
+    assert sb["device_ms_per_batch"]["coding_stream0"] > 0 and sb["device_ms_per_batch"]["motion_search"] > 0 and sb["device_idle_ms_per_batch"] >= 0
+    assert sum(sb["host_ms_per_batch"].values()) > 0 and sb["fetch_bytes_per_call"] > 0
+    assert d["link"]["h2d_GBs"] > 1 and d["link"]["d2h_GBs"] > 1
+    assert d["value_host_pinned"]["frac_of_link"] <= 1.05
+    assert d["box"]["placement"]["chosen"] in d["box"]["placement"]["measured"]
+    assert d["value_recon_all"]["value"] > 0 and d["value_recon_all"]["bit_exact_vs_cpu"] is True
     if "pipeline" in d:                                  # (needs profiles/pmc_traffic.json with the per-step sum)
         assert d["pipeline"]["bound"] == "hbm" and 0 < d["pipeline"]["frac"] < 1
         assert d["pipeline"]["valu"]["wave_instr_per_step"] > 0 and d["pipeline"]["binding_roof"] in ("valu", "hbm")
