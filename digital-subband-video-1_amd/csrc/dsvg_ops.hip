@@ -369,6 +369,19 @@ extern "C" int dsvg_op_frame_avg_luma(const dsvg_frame *f, int *avg)
     return DSVG_OK;
 }
 
+// Memory the operator calls hand to their caller (dsvg_op_hme's motion fields) comes from the allocator the caller FREES with: the reference's
+// caller releases hme.mvf[] with dsv_free (dsv_encoder.c:239-244).  Default: the library's own dsv_alloc / dsv_free (dsv1_util.c); a build that
+// keeps the reference's dsv.c -- whose dsv_free steps back over a 16-byte header when DSV_MEMORY_STATS is on (dsv.c:41-66) -- passes its own pair.
+extern "C" void *dsv_alloc(int size);
+extern "C" void dsv_free(void *ptr);
+static void *(*g_op_alloc)(int) = dsv_alloc;
+static void (*g_op_free)(void *) = dsv_free;
+extern "C" void dsvg_set_allocator(void *(*alloc_fn)(int), void (*free_fn)(void *))
+{
+    g_op_alloc = alloc_fn && free_fn ? alloc_fn : dsv_alloc;
+    g_op_free = alloc_fn && free_fn ? free_fn : dsv_free;
+}
+
 extern "C" int dsvg_op_hme(dsvg_hme *h, int *intra_pct)
 {
     if (!h || !h->params || !h->params->vidmeta) { dsvg_set_error("null argument"); return DSVG_ERR_ARG; }
@@ -411,11 +424,14 @@ extern "C" int dsvg_op_hme(dsvg_hme *h, int *intra_pct)
     OPCHK(S.dev(&A.aux_tex, (size_t)nblk));
     OPCHK(S.dev(&A.aux_var, (size_t)nblk));
     launch_hme(S.st, A, 1);
+    for (int l = 0; l <= h->levels; l++) h->mvf[l] = nullptr;
+    auto drop = [&](int rc) { for (int l = 0; l <= h->levels; l++) { if (h->mvf[l]) g_op_free(h->mvf[l]); h->mvf[l] = nullptr; } return rc; };
     for (int l = 0; l <= h->levels; l++) {
-        h->mvf[l] = (dsvg_mv *)calloc((size_t)nblk, sizeof(dsvg_mv));
-        HIPCHK(hipMemcpyAsync(h->mvf[l], A.mvf + (size_t)l * nblk, (size_t)nblk * sizeof(DMV), hipMemcpyDeviceToHost, S.st));
+        h->mvf[l] = (dsvg_mv *)g_op_alloc((int)((size_t)nblk * sizeof(dsvg_mv)));       // (as hme.c:736-741: the caller owns them)
+        if (!h->mvf[l]) { dsvg_set_error("out of host memory for the motion field of level %d", l); return drop(DSVG_ERR_NOMEM); }
+        if (hipMemcpyAsync(h->mvf[l], A.mvf + (size_t)l * nblk, (size_t)nblk * sizeof(DMV), hipMemcpyDeviceToHost, S.st) != hipSuccess) { dsvg_set_error("copying the motion field back failed"); return drop(DSVG_ERR_HIP); }
     }
-    OPCHK(S.sync());
+    { const int rc_ = S.sync(); if (rc_) return drop(rc_); }
     if (intra_pct) {
         int n = 0;
         for (int i = 0; i < nblk; i++) n += h->mvf[0][i].mode != 0;

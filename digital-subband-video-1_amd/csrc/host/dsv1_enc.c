@@ -1155,8 +1155,40 @@ int dsv1_concat_gops(const DSV_BUF *gops, int ngops, DSV_BUF *out)
 /* =================================================================================================
  * drop-in frame-at-a-time API (dsv_encoder.h:112-121)
  * ================================================================================================= */
+/* dsv1_enc_set_strict_packets (verdict round 5): the reference's packet contract as an API call instead of an environment variable.  The public
+ * struct has no spare field (its layout is the reference's), so the wish is noted per encoder ADDRESS until the session is created by the first
+ * dsv_enc; dsv_enc_init / dsv_enc_free forget the address. */
+#define STRICT_SLOTS 64
+static struct { const DSV_ENCODER *enc; int on; } strict_tab[STRICT_SLOTS];
+static pthread_mutex_t strict_mu = PTHREAD_MUTEX_INITIALIZER;
+static int strict_take(const DSV_ENCODER *enc, int remove_only)
+{
+    int i, on = -1;
+    pthread_mutex_lock(&strict_mu);
+    for (i = 0; i < STRICT_SLOTS; i++)
+        if (strict_tab[i].enc == enc) { on = remove_only ? -1 : strict_tab[i].on; strict_tab[i].enc = NULL; }
+    pthread_mutex_unlock(&strict_mu);
+    return on;
+}
+int dsv1_enc_set_strict_packets(DSV_ENCODER *enc, int on)
+{
+    int i, slot = -1;
+    if (!enc) return DSVG_ERR_ARG;
+    if (enc->ref) { dsv1_log(1, "dsv1_enc_set_strict_packets after the first dsv_enc call: the session exists already"); return DSVG_ERR_ARG; }
+    pthread_mutex_lock(&strict_mu);
+    for (i = 0; i < STRICT_SLOTS; i++) {
+        if (strict_tab[i].enc == enc) { slot = i; break; }
+        if (!strict_tab[i].enc && slot < 0) slot = i;
+    }
+    if (slot >= 0) { strict_tab[slot].enc = enc; strict_tab[slot].on = on != 0; }
+    pthread_mutex_unlock(&strict_mu);
+    if (slot < 0) { dsv1_log(1, "dsv1_enc_set_strict_packets: more than %d encoders waiting for their first frame", STRICT_SLOTS); return DSVG_ERR_NOMEM; }
+    return DSVG_OK;
+}
+
 void dsv_enc_init(DSV_ENCODER *enc)                        /* dsv_encoder.c:696-722 */
 {
+    strict_take(enc, 1);
     memset(enc, 0, sizeof(*enc));
     enc->prev_gop = (DSV_FNUM)-1;
     enc->quality = DSV_QUALITY_PERCENT(85);
@@ -1234,6 +1266,7 @@ static void sess_free(enc_sess *ss)
 
 void dsv_enc_free(DSV_ENCODER *enc)
 {
+    strict_take(enc, 1);
     if (enc->ref) {
         enc_sess *ss = (enc_sess *)enc->ref;
         if ((ss->pipelined || ss->gathered) && !ss->failed && (ss->fill > 0 || ss->inflight > 0 || ss->backlog.len > ss->off))
@@ -1395,7 +1428,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
              * frame-by-frame path of round 3) */
             const char *as = getenv("DSV1_ABR_SERIAL");
             const int abr_dev = enc->rc_mode != DSV_RATE_CONTROL_CRF && !(as && atoi(as) != 0);
-            ss->pipelined = (enc->rc_mode == DSV_RATE_CONTROL_CRF || abr_dev) && !(e && atoi(e) == 0);
+            ss->pipelined = (enc->rc_mode == DSV_RATE_CONTROL_CRF || abr_dev) && !(e && atoi(e) == 0) && strict_take(enc, 0) != 1;
         }
         ss->F = 1;
         if (ss->pipelined && enc->rc_mode != DSV_RATE_CONTROL_CRF) {

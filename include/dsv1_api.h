@@ -128,7 +128,12 @@ void dsv_enc_start(DSV_ENCODER *enc);
  *     while ((n = dsv_enc(enc, NULL, bufs)) > 0) { ...write bufs[0 .. n-1]... }
  * -- a FLUSH CALL (frame == NULL, an extension: the reference would crash on it).  The first one codes and collects everything
  * the session still holds; each returns up to two whole packets, one per DSV_BUF, in stream order; 0 = drained.
- * dsv_enc_end_of_stream then returns the 14-byte EOS packet alone. */
+ * dsv_enc_end_of_stream then returns the 14-byte EOS packet alone.
+ * OR ask for the reference's contract outright: dsv1_enc_set_strict_packets(enc, 1) after dsv_enc_init / dsv_enc_start and BEFORE the first
+ * dsv_enc (an extension, round 6; an error once the session exists): the session then runs frame-synchronously -- every dsv_enc call codes its
+ * frame and returns that frame's packets (metadata + picture, one per DSV_BUF), dsv_enc_end_of_stream returns the EOS packet alone, exactly
+ * dsv_encoder.c:766-810 -- at the frame-at-a-time rate instead of the lookahead's. */
+int  dsv1_enc_set_strict_packets(DSV_ENCODER *enc, int on);
 int  dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs);
 void dsv_enc_end_of_stream(DSV_ENCODER *enc, DSV_BUF *bufs);
 

@@ -82,7 +82,11 @@ int dsvg_link_probe(int device, size_t bytes, int reps, double gbs[2]);
 /* dsv_sub_pred bmc.c:318   */ int dsvg_op_sub_pred(const dsvg_mv *mv, const dsvg_params *p, dsvg_frame *dif, dsvg_frame *inp, const dsvg_frame *ref);
 /* dsv_add_pred bmc.c:333   */ int dsvg_op_add_pred(const dsvg_mv *mv, const dsvg_params *p, dsvg_frame *dif, dsvg_frame *out, const dsvg_frame *ref);
 /* dsv_frame_add bmc.c:304  */ int dsvg_op_frame_add(dsvg_frame *dst, const dsvg_frame *src);
-/* dsv_hme      hme.c:730   */ int dsvg_op_hme(dsvg_hme *hme, int *intra_pct); /* mvf[0..levels] malloc'd, caller frees with free() */
+/* dsv_hme      hme.c:730   */ int dsvg_op_hme(dsvg_hme *hme, int *intra_pct); /* mvf[0..levels] from dsv_alloc: the caller frees them with dsv_free, as dsv_encoder.c:239-244 does */
+/* the allocator behind memory the operator calls hand to their caller (the motion fields above).  Default (or NULLs): this library's dsv_alloc /
+ * dsv_free.  A build that keeps the reference's own dsv.c passes ITS pair, so that its dsv_free -- which steps back over a 16-byte header when
+ * DSV_MEMORY_STATS is on, dsv.c:41-66 -- gets blocks its dsv_alloc made (oracle/opswap_shim.c does). */
+void dsvg_set_allocator(void *(*alloc_fn)(int), void (*free_fn)(void *));
 /* dsv_extend_frame frame.c:263 */ int dsvg_op_extend_frame(dsvg_frame *f);
 /* dsv_extend_frame_luma frame.c:297 */ int dsvg_op_extend_frame_luma(dsvg_frame *f);
 /* dsv_ds2x_frame_luma frame.c:240 */ int dsvg_op_ds2x_frame_luma(dsvg_frame *dst, const dsvg_frame *src);

@@ -264,6 +264,8 @@ def load_prod():
         L.dsvg_last_error.restype = C.c_char_p
         L.dsvg_ctx_create.argtypes = [C.POINTER(C.c_void_p), C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
         L.dsvg_ctx_destroy.argtypes = [C.c_void_p]
+        L.dsv_free.argtypes = [C.c_void_p]
+        L.dsv_free.restype = None
         _libs["prod"] = L
     return _libs["prod"]
 

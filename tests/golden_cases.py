@@ -238,4 +238,6 @@ def run_op_case(case, impl, L, orc=None):
             a = np.ctypeslib.as_array(C.cast(hm.mvf[l], C.POINTER(C.c_uint8)), shape=(nbh * nbv * 12,)).copy().view(A.MV_DTYPE)
             fields = np.stack([a[k].astype(np.int32) for k in ("x", "y", "mode", "submask", "lo_var", "lo_tex", "high_detail")])
             out["mv_level%d" % l] = _sha(fields)
+            if impl == "prod":
+                L.dsv_free(C.cast(hm.mvf[l], C.c_void_p))
     return out

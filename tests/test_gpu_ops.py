@@ -335,4 +335,4 @@ def test_hme(prod, orc, w, h, style, levels):
         assert pa == pb.value
         for l in range(levels + 1):
             C.CDLL(None).free(ha.mvf[l])
-            C.CDLL(None).free(hb.mvf[l])
+            prod.dsv_free(C.cast(hb.mvf[l], C.c_void_p))       # the product's fields come from its dsv_alloc, as the reference's do (dsv_encoder.c:239-244)

@@ -291,6 +291,45 @@ def test_drop_in_dsv_enc_unpipelined_switch(pkg, orc, monkeypatch, rc):
     assert out == want and all(c >= 1 for c in counts)
 
 
+@pytest.mark.parametrize("cli", [dict(qp=85, gop=6, rc_mode_cli=1), dict(qp=60, gop=12, rc_mode_cli=0, kbps=900)])
+def test_drop_in_strict_packet_contract_by_api_call(pkg, orc, cli):
+    """dsv1_enc_set_strict_packets(enc, 1) (round 6; no environment variable): the session is the reference's own contract, dsv_encoder.c:766-810 --
+    EVERY dsv_enc call returns its frame's packets (metadata + picture at a GOP start, the picture otherwise), one whole packet per DSV_BUF, and
+    dsv_enc_end_of_stream returns the 14-byte EOS packet alone.  After the first frame the switch is refused."""
+    w, h, fmt, n = 352, 288, A.SUBSAMP_420, 14
+    clip = A.gen_clip(w, h, fmt, 0xD2A9, n, style=2)
+    want, _ = A.orc_encode(clip, A.orc_cfg(w, h, fmt, **cli))
+    wantpk = A.split_packets(want)
+    L = pkg.lib()
+    L.dsv1_enc_set_strict_packets.argtypes = [C.c_void_p, C.c_int]
+    enc = pkg.make_encoder_cfg(w, h, fmt, **cli)
+    L.dsv_enc_start(C.byref(enc))
+    assert L.dsv1_enc_set_strict_packets(C.byref(enc), 1) == 0
+    L.dsv_load_planar_frame.restype = C.c_void_p
+    L.dsv_load_planar_frame.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_int]
+    L.dsv_enc.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    bufs = (pkg.Buf * 4)()
+    pk, k = [], 0
+    for t in range(n):
+        nb = L.dsv_enc(C.byref(enc), L.dsv_load_planar_frame(fmt, clip[t].ctypes.data, w, h), bufs) & 3
+        expect = 2 if wantpk[k][5] == 0 else 1               # a metadata packet in front of the picture where the reference sends one
+        assert nb == expect, (t, nb, expect)
+        for i in range(nb):
+            b_ = C.string_at(bufs[i].data, bufs[i].len)
+            assert b_ == wantpk[k], "frame %d buffer %d" % (t, i)
+            pk.append(b_)
+            k += 1
+            L.dsv_buf_free(C.byref(bufs[i]))
+        if t == 0:
+            assert L.dsv1_enc_set_strict_packets(C.byref(enc), 0) != 0      # the session exists: refused
+    L.dsv_enc_end_of_stream(C.byref(enc), bufs)
+    eos = C.string_at(bufs[0].data, bufs[0].len)
+    L.dsv_buf_free(C.byref(bufs[0]))
+    L.dsv_enc_free(C.byref(enc))
+    assert len(eos) == 14 and eos[5] == 0x10
+    assert b"".join(pk) + eos == want
+
+
 class Decoder(C.Structure):
     _fields_ = [("vidmeta", A.Meta), ("ref", C.c_void_p), ("draw_info", C.c_int), ("got_metadata", C.c_int)]
 
