@@ -261,6 +261,10 @@ struct dsvg_ctx {
 
 static int dec_resolve(dsvg_ctx *c);     // decoder: settle the flags of the last call (defined with dsvg_decode_pictures)
 
+// DSV1_DEBUG_LINK_REPEAT=n (diagnostic, round 6): every large host <-> device copy of the batched pipeline (the packet fetch, the motion fields down, the
+// job / flag / vector tables up) is issued n times -- the same bytes arrive, the link carries n times the traffic: how a box whose link runs at 1/n of the
+// usual rate would time a step (bench.py's `step_breakdown` on the driver's slow box of round 5 read 25-29 GB/s against 57)
+static int link_repeat() { static const int n = [] { const char *e = getenv("DSV1_DEBUG_LINK_REPEAT"); const int v = e ? atoi(e) : 1; return v < 1 ? 1 : (v > 16 ? 16 : v); }(); return n; }
 static double tl_now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
 static void tl_mark(dsvg_ctx *c, hipStream_t st, const char *what)
 {
@@ -1104,6 +1108,7 @@ extern "C" int dsvg_analyse(dsvg_ctx *c, int npairs, const int *cur_slots, const
     tl_mark(c, c->st_a, "hme0");
     launch_hme(c->st_a, A, npairs, &c->prof);
     tl_mark(c, c->st_a, "hme1");
+    for (int r = 0; r < link_repeat(); r++)
     HIPCHK(hipMemcpy2DAsync(c->amv_h, (size_t)c->nblk * sizeof(DMV), c->mvf, per * sizeof(DMV),
                             (size_t)c->nblk * sizeof(DMV), (size_t)npairs, hipMemcpyDeviceToHost, c->st_a));
     HIPCHK(hipStreamSynchronize(c->st_a));
@@ -1429,9 +1434,11 @@ static int code_batch_impl(dsvg_ctx *c, int nsteps, int njobs, const dsvg_pic_jo
     const double tc1 = cprof ? cnow() : 0.0;
     tl_mark(c, c->st, "tab0");
     if (iln) HIPCHK(hipMemcpyAsync(c->ilist_d + (size_t)base * c->nblk, il, sizeof(int) * (size_t)iln, hipMemcpyHostToDevice, c->st));
+    for (int r = 0; r < link_repeat(); r++) {
     HIPCHK(hipMemcpyAsync(c->jobs_d + base, c->jobs_h + base, sizeof(JobDev) * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->stable + (size_t)base * c->nblk, c->stable_h + (size_t)base * c->nblk, (size_t)c->nblk * total, hipMemcpyHostToDevice, c->st));
     HIPCHK(hipMemcpyAsync(c->mvs + (size_t)base * c->nblk, c->mv_h + (size_t)base * c->nblk, (size_t)c->nblk * total * sizeof(DMV), hipMemcpyHostToDevice, c->st));
+    }
     HIPCHK(hipMemcpyAsync(c->slots_d + 2 * c->out_slots + base, c->slots_h + base, sizeof(int) * total, hipMemcpyHostToDevice, c->st));
     tl_mark(c, c->st, "code0");
     if (NG > 1) {
@@ -1719,6 +1726,7 @@ extern "C" int dsvg_fetch_pictures_cb(dsvg_ctx *c, int n, const int *out_slots, 
         const int first = j ? cend[j - 1] : 0;
         const size_t o0 = first < n ? (size_t)c->gtab_h[3 * (3 * (size_t)first) + 1] : total;
         const size_t o1 = cend[j] < n ? (size_t)c->gtab_h[3 * (3 * (size_t)cend[j]) + 1] : total;
+        for (int r = 0; r < link_repeat(); r++)
         if (o1 > o0) HIPCHK(hipMemcpyAsync(c->gath_h + o0, c->gath_d + o0, o1 - o0, hipMemcpyDeviceToHost, c->st_c));
         HIPCHK(hipEventRecord(c->ev_fetch[j], c->st_c));
     }

@@ -1419,6 +1419,8 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
     if (!frame && !enc->ref) return 0;                   /* a flush call before the first frame: nothing is owed */
     if (!enc->ref) {
         const char *e = getenv("DSV1_ENC_PIPELINE"), *la = getenv("DSV1_ENC_LOOKAHEAD");
+        /* frame-synchronous session (one frame in, its packets out: the reference's contract): asked for by dsv1_enc_set_strict_packets or DSV1_ENC_PIPELINE=0 */
+        const int sync_mode = strict_take(enc, 0) == 1 || (e && atoi(e) == 0);
         int chains = 0;
         ss = (enc_sess *)calloc(1, sizeof(*ss));
         if (!ss) { dsv1_log(1, "out of memory"); dsv_frame_ref_dec(frame); return 0; }
@@ -1428,7 +1430,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
              * frame-by-frame path of round 3) */
             const char *as = getenv("DSV1_ABR_SERIAL");
             const int abr_dev = enc->rc_mode != DSV_RATE_CONTROL_CRF && !(as && atoi(as) != 0);
-            ss->pipelined = (enc->rc_mode == DSV_RATE_CONTROL_CRF || abr_dev) && !(e && atoi(e) == 0) && strict_take(enc, 0) != 1;
+            ss->pipelined = (enc->rc_mode == DSV_RATE_CONTROL_CRF || abr_dev) && !sync_mode;
         }
         ss->F = 1;
         if (ss->pipelined && enc->rc_mode != DSV_RATE_CONTROL_CRF) {
@@ -1455,7 +1457,7 @@ int dsv_enc(DSV_ENCODER *enc, DSV_FRAME *frame, DSV_BUF *bufs)
             ss->F = (int)want;
             chains = enc->gop > 0 ? (ss->F + g - 1) / g + 1 : ss->F;
             if (chains > 64) chains = 64;
-        } else if (enc->rc_mode != DSV_RATE_CONTROL_CRF && !(e && atoi(e) == 0)) {
+        } else if (enc->rc_mode != DSV_RATE_CONTROL_CRF && !sync_mode) {
             /* ABR (the reference CLI's default): every packet's size feeds the next quantiser, so the pictures are coded one after
              * the other -- but padding, pyramid, motion search and the GOP / scene-change decisions depend on source pixels only:
              * frames are gathered 32 at a time (DSV1_ENC_LOOKAHEAD, within 256 MB) and analysed in one go, as dsv1_batch_encode

@@ -27,7 +27,8 @@ SWITCHES = {
 }
 CODE_STREAMS = ("1", "3", "4")            # DSV1_CODE_STREAMS: the default is 2
 # switches that only print / time: set together
-DEBUG = {"DSV1_BORDER_DEBUG": "1", "DSV1_STREAM_DEBUG": "1", "DSV1_DEC_VERBOSE": "1", "DSV1_DEC_PROF": "1", "DSV1_HOST_PROF": "1", "DSV1_TIMELINE": "1"}
+DEBUG = {"DSV1_BORDER_DEBUG": "1", "DSV1_STREAM_DEBUG": "1", "DSV1_DEC_VERBOSE": "1", "DSV1_DEC_PROF": "1", "DSV1_HOST_PROF": "1", "DSV1_TIMELINE": "1",
+         "DSV1_DEBUG_LINK_REPEAT": "2"}        # (the large copies issued twice: a slow link emulated, same bytes)
 # not the library's own: set by launchers (shard.py / torch.distributed.run), covered by tests/test_rank_cores.py
 LAUNCHER = {"DSV1_CORES_PINNED", "LOCAL_WORLD_SIZE"}
 

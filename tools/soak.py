@@ -3,7 +3,10 @@
 tiles of the fast inverse kernel and the 16-byte border paths apply), formats, quantisers, GOP lengths, content styles and
 batch shapes (several streams side by side, frames per call; host clips, device clips with in-place chroma, one stream in
 GOP-parallel chain mode) -- product stream against the oracle's, byte for byte.
-usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case; SOAK_MODE=host|device|chain: every case in that mode)"""
+usage: soak.py [cases] [seed]      (the oracle is the slow side: ~0.1-1 s per case; SOAK_MODE=host|device|chain|piped: every case in that mode)
+piped (round 6, advisor round 5): the loop bench.py times -- submit(held=True) / collect with TWO batches in flight on two device clips that are
+rewritten in place, each scribbled over as soon as its collect has returned -- on geometries around the limits of the in-place luma ring
+(width a multiple of 16 near 2*16*ring_x16 + 64, height a multiple of 4 near 2*4*ring_y4 + 64, partial edge blocks, two pyramid levels)."""
 import importlib, os, random, sys, time
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "tests"))
 sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
@@ -32,7 +35,14 @@ for k in range(N):
     S = rng.choice([1, 1, 2, 5, 17, 33, 64])
     F = rng.choice([f for f in (1, 2, 3, n) if n % f == 0])        # (the batch API takes whole batches)
     style = rng.choice([0, 1, 2, 3, 4, 5, 6, 7])
-    mode = os.environ.get('SOAK_MODE') or rng.choice(['host', 'host', 'device', 'chain'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode
+    mode = os.environ.get('SOAK_MODE') or rng.choice(['host', 'host', 'device', 'chain', 'piped'])      # batch from host memory / from a device clip (in-place chroma) / one stream in chain mode / the pipelined held loop
+    if mode == 'piped':
+        w, h = 16 * rng.randrange(9, 30), 4 * rng.randrange(36, 110)     # 144 .. 464 x 144 .. 436: both sides of the ring limits of 16 / 24-pixel blocks
+        fmt = rng.choice([A.SUBSAMP_420, A.SUBSAMP_420, A.SUBSAMP_422, A.SUBSAMP_444])
+        bw, bh = A.block_dims(w, h)[:2]
+        cw, ch = A.chroma_dims(w, h, fmt)
+        if cw % max(1, bw >> A.hshift(fmt)) == 1 or ch % max(1, bh >> A.vshift(fmt)) == 1 or w % bw == 1 or h % bh == 1:
+            continue
     cli = dict(qp=rng.choice([20, 50, 70, 85, 95]), gop=rng.choice([0, 3, 12]), rc_mode_cli=1, scd=rng.choice([0, 1]))
     if mode != 'chain' and rng.random() < 0.3:                 # round 4: ABR streams (rate control on the device; chain mode refuses them)
         cli['rc_mode_cli'] = 0
@@ -58,6 +68,49 @@ for k in range(N):
         if got1 != want1:
             bad += 1
             print("CHAIN MISMATCH case %d: %dx%d fmt %d n %d F %d style %d %s seed %d" % (k, w, h, fmt, n2, Fc, style, cli, seed))
+        continue
+    if mode == 'piped':
+        cli.pop('kbps', None); cli['rc_mode_cli'] = 1
+        cli['gop'] = rng.choice([3, 4, 12])
+        if rng.random() < 0.4:
+            cli['pyrlevels'] = 2
+        Fp, ncalls, Sp = rng.choice([2, 3, 4]), rng.choice([3, 4, 5]), rng.choice([1, 2, 5, 17])
+        clipsP = [A.gen_clip(w, h, fmt, seed + s, Fp * ncalls, style=style) for s in range(min(Sp, 3))]
+        try:
+            wantP = [A.orc_encode(c, A.orc_cfg(w, h, fmt, **cli), eos=False)[0] for c in clipsP]
+        except Exception as e:
+            print("case %d skipped (oracle: %s)" % (k, e)); continue
+        b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), Sp, Fp)
+        try:
+            fbp = A.frame_bytes(w, h, fmt)
+            junk = np.full((Sp, Fp, fbp), 0xA5, dtype=np.uint8)
+            dev = [b.upload(junk), b.upload(junk)]
+            gotP = [b""] * Sp
+            def fill(c):
+                fr = np.ascontiguousarray(np.stack([clipsP[s % len(clipsP)][c * Fp:(c + 1) * Fp] for s in range(Sp)]).reshape(Sp, Fp, -1))
+                pkg._chk(b.L.dsvg_dev_upload(b.ctx, dev[c & 1], fr.ctypes.data, fr.nbytes), "dsvg_dev_upload")
+            def scribble(c):
+                junk[...] = rng.randrange(256)
+                pkg._chk(b.L.dsvg_dev_upload(b.ctx, dev[c & 1], junk.ctypes.data, junk.nbytes), "dsvg_dev_upload")
+            fill(0)
+            b.submit(dev[0], on_device=True, held=True)
+            for c in range(1, ncalls):
+                fill(c)
+                b.submit(dev[c & 1], on_device=True, held=True)
+                pk = b.collect()                      # batch c - 1: its clip is the caller's again ...
+                scribble(c - 1)                       # ... and is overwritten while batch c is in flight
+                for s in range(Sp):
+                    gotP[s] += pk[s]
+            pk = b.collect()
+            for s in range(Sp):
+                gotP[s] += pk[s]
+            for s in range(Sp):
+                if gotP[s] != wantP[s % len(clipsP)]:
+                    bad += 1
+                    print("PIPED MISMATCH case %d: %dx%d fmt %d F %d calls %d S %d style %d %s seed %d stream %d" % (k, w, h, fmt, Fp, ncalls, Sp, style, cli, seed, s))
+                    break
+        finally:
+            b.close()
         continue
     b = pkg.Batch(pkg.make_encoder_cfg(w, h, fmt, **cli), S, F)
     try:
