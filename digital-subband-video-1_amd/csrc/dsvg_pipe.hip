@@ -137,6 +137,7 @@ struct dsvg_ctx {
     struct TlMark { const char *what; hipEvent_t ev; double host_ms; };
     std::vector<TlMark> tl;
     bool tl_on = false;
+    unsigned long long border_bytes = 0;   // dsvg_ctx_tile_stats2 out[7]
     bool tl_quiet = false;           // switched on through dsvg_ctx_timeline (the marks are read with dsvg_ctx_timeline_get, nothing is printed)
     double fetch_acc[4] = {0, 0, 0, 0};   // dsvg_fetch_pictures_cb, per call: host ms waiting for the coding, for the sizes, for gather + copy + the caller's pieces; bytes copied
     long fetch_n = 0;
@@ -739,6 +740,8 @@ extern "C" int dsvg_ctx_tile_stats2(dsvg_ctx *c, unsigned long long out[8], int 
         out[i] = 0;
         for (int k = 0; k < 64; k++) out[i] += v[64 * i + k];
     }
+    out[7] = c->border_bytes;          // bytes of reconstruction border written by the fused inverse kernels (host-side tally)
+    c->border_bytes = 0;
     c->stats_on = enable != 0;
     return DSVG_OK;
 }
@@ -1219,6 +1222,18 @@ static int enqueue_recon(dsvg_ctx *c, int nI, int n, int d0 = 0, int insym = 0, 
         fused = lazy_border && inv_sbt_fuses_border(c->G, symC, pkC);
         launch_inv_sbt(st, jd + nI, n - nI, c->G, 0, 1, 1, &c->prof, wt, symY, pkY);
         launch_inv_sbt(st, jd + nI, n - nI, c->G, 1, 2, 1, &c->prof, wt, symC, pkC, fused);
+    }
+    if (fused && c->stats_on) {
+        // what the fused border writes (counted beside the tiles: bench.py prices k_inv_patch_c with it): per plane the rows above / below over the
+        // widened width and the columns left / right of the picture's own rows, by the extents border_reach left in the jobs
+        for (int k = nI; k < n; k++) {
+            const short *e = c->jobs_h[d0 + k].ext;
+            for (int pl = 0; pl < 3; pl++) {
+                const short *x = e + (pl ? 4 : 0);
+                const long long w = c->L[0].w[pl ? 1 : 0], h = c->L[0].h[pl ? 1 : 0];
+                c->border_bytes += (unsigned long long)((w + x[0] + x[1]) * (long long)(x[2] + x[3]) + h * (long long)(x[0] + x[1]));
+            }
+        }
     }
     const int next = fused ? nI : n;                    // (device order: I jobs first)
     if (next > 0) launch_extend(st, c->recon.p, c->L[0], 0, next, 3, c->slots_d + 2 * c->out_slots + d0, &c->prof, lazy_border ? jd : nullptr);

@@ -27,7 +27,12 @@ typedef struct {
 } pic_t;
 
 typedef struct { uint8_t *pkt; size_t cap; } pkt_scratch;   /* packet staging buffer (one per assembling thread) */
+typedef struct { dsv1_batch *b; pic_t *pics; volatile int rc; int nf; } side_ctx;   /* rc: a worker's failure (scratch allocation), checked after the parallel loop; nf: the frames of THIS batch (a background loop outlives the submit call) */
 struct dsv1_batch {
+    /* round 6: the packet prefixes of a CRF batch are written by a BACKGROUND loop of the worker pool (dsv1_par_bg_begin) that starts when the batch's coding
+     * work has been enqueued and is joined when the batch is collected: bg_sc[parity] is that loop's context, bg_on[parity] says it has not been joined */
+    side_ctx bg_sc[2];
+    int bg_on[2];
     dsvg_ctx *ctx;
     dsvg_geom g;
     int nstreams, F, own_enc, nblk, prefix_cap, small_w, small_h;
@@ -86,7 +91,7 @@ struct dsv1_batch {
 /* host-side phase timing (DSV1_HOST_PROF=1): where a batch's wall time goes inside submit / collect */
 #include <time.h>
 #include <stddef.h>
-enum { HP_LOAD, HP_DECIDE, HP_ANALYSE, HP_SIDEINFO, HP_ENQUEUE, HP_PREFIX, HP_FETCH, HP_ASSEMBLE, HP_N };
+enum { HP_LOAD, HP_DECIDE, HP_ANALYSE, HP_SIDEINFO, HP_ENQUEUE, HP_PREFIX, HP_FETCH, HP_ASSEMBLE, HP_JOIN, HP_N };
 static double hp_acc[HP_N];
 static long hp_batches;
 static int hp_on = -1;
@@ -99,7 +104,8 @@ static double hp_now(void)
 #define HP_BEGIN() double hp_t0_ = hp_on > 0 ? hp_now() : 0.0
 #define HP_MARK(k) do { if (hp_on > 0) { const double n_ = hp_now(); hp_acc[k] += n_ - hp_t0_; hp_t0_ = n_; } } while (0)
 static const char *const hp_nm[HP_N] = {"load+pyramid (enqueue, luma sums wait)", "GOP / scene-change decisions", "motion search (enqueue + GPU wait + D2H)",
-                                         "intra decisions + stability flags", "job tables + coding enqueue", "packet prefixes (stability / motion bits)", "fetch (GPU wait + gather + D2H)", "packet assembly"};
+                                         "intra decisions + stability flags", "job tables + coding enqueue", "packet prefixes (stability / motion bits; CRF batches: the start of the background loop)", "fetch (GPU wait + gather + D2H)", "packet assembly",
+                                         "packet prefixes: joining the background loop at collect"};
 static void hp_report(void)
 {
     int k;
@@ -151,6 +157,7 @@ void dsv1_batch_close(dsv1_batch *b)
 {
     hp_report();
     if (!b) return;
+    if (b->bg_on[0] || b->bg_on[1]) dsv1_par_bg_end();  /* a background prefix loop still reads this batch's pictures */
     if (b->holds_recycler) dsv1_recycle_hold(-1);       /* the last batch out gives the parked packet buffers back */
     if (b->ctx) dsvg_ctx_destroy(b->ctx);
     if (b->own_enc && b->enc) {
@@ -551,7 +558,6 @@ static int assemble(dsv1_batch *b, int s, pic_t *pc, const dsvg_pic_out *po, DSV
     return DSVG_OK;
 }
 
-typedef struct { dsv1_batch *b; pic_t *pics; volatile int rc; } side_ctx;   /* rc: a worker's failure (scratch allocation), checked after the parallel loop */
 /* what the coding work needs of the side information, per stream in coding order: intra decisions, the stability flags
  * (accumulators), the vectors' reach.  The bits of the packet prefix are written by prefix_stream AFTER the coding work
  * has been enqueued: the GPU has nothing else to do while this runs. */
@@ -599,7 +605,7 @@ static void prefix_stream(void *ctx, int s, int tid)
     int t;
     (void)tid;
     if (!tmp) { c->rc = DSVG_ERR_ARG; return; }         /* (a stale prefix would go out as a corrupt packet: the submit fails instead) */
-    for (t = 0; t < b->nf_cur; t++) prefix_one(b, &c->pics[s * F + t], tmp);
+    for (t = 0; t < c->nf; t++) prefix_one(b, &c->pics[s * F + t], tmp);
     free(tmp);
 }
 
@@ -937,7 +943,7 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         const int devrc = abr && b->abr_dev;                    /* rate control on the device: enqueued like a CRF call */
         const int serial = abr && !devrc;
         side_ctx sc_;
-        sc_.b = b; sc_.pics = pics; sc_.rc = DSVG_OK;
+        sc_.b = b; sc_.pics = pics; sc_.rc = DSVG_OK; sc_.nf = nf;
         if (serial && !abr_out) return DSVG_ERR_ARG;
         if (abr && b->chains) return DSVG_ERR_ARG;
         if (abr) {                                              /* ABR: the length of every packet prefix feeds the rate control */
@@ -1023,7 +1029,14 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         HP_MARK(HP_ENQUEUE);
         /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
         if (b->chains) dsv1_par_for(nf, prefix_picture, &sc_);      /* (one stream: the pictures are the independent items) */
-        else if (!abr) dsv1_par_for(S, prefix_stream, &sc_);
+        else if (!abr) {
+            /* round 6: in the BACKGROUND -- idle workers write them while this thread waits for the GPU in the next calls (the fetch of the batch
+             * before, the load and motion search of the batch after); dsv1_batch_collect of THIS batch joins.  Synchronous, the loop sat between the
+             * coding enqueue and the fetch on every step: 1.9 ms with 12 workers, 11.7 ms of a 43 ms step on 4 cores (profiles/r06_cpu_starved.txt) */
+            b->bg_sc[par] = sc_;
+            b->bg_on[par] = 1;
+            dsv1_par_bg_begin(S, prefix_stream, &b->bg_sc[par]);
+        }
         if (sc_.rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); return sc_.rc; }
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
         b->nf_pending[par] = nf;
@@ -1067,6 +1080,14 @@ int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
     if (!b->pending[par]) { dsv1_log(1, "nothing to collect"); return DSVG_ERR_ARG; }
     pics = b->pics + (size_t)par * S * F;
     nf = b->nf_pending[par];
+    if (b->bg_on[par]) {
+        /* the batch's packet prefixes (background loop started by its submit): whatever is left is finished here with this thread's help */
+        HP_BEGIN();
+        dsv1_par_bg_end();
+        b->bg_on[par] = 0;
+        HP_MARK(HP_JOIN);
+        if (b->bg_sc[par].rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); b->pending[par] = 0; return b->bg_sc[par].rc; }
+    }
     if (b->pending[par] == 1) {
         HP_BEGIN();
         /* a short batch (nf < F) has a single stream: its pictures are the first nf entries */

@@ -95,6 +95,11 @@ extern int dsv1_device;
 typedef void (*dsv1_par_fn)(void *ctx, int s, int tid);
 void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx);
 void dsv1_par_for_long(int S, dsv1_par_fn fn, void *ctx);      /* the same for a few long items (two already run in parallel) */
+/* ONE background loop beside the foreground ones (round 6): begin returns at once, idle workers take the items (foreground loops go first), end joins
+ * with the caller's help; a second begin joins the first.  fn / ctx must stay valid until the end call. */
+void dsv1_par_bg_begin(int S, dsv1_par_fn fn, void *ctx);
+void dsv1_par_bg_end(void);
+int dsv1_par_bg_pending(void);
 /* the default size of that pool as a function of the host (dsv1_util.c); exported so that the rule can be tested without the host it is for */
 int dsv1_host_threads_rule(long online, long allowed, long ranks, int pinned_by_launcher);
 

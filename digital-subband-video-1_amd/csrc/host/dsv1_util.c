@@ -478,7 +478,9 @@ int dsv1_host_threads_rule(long online, long allowed, long ranks, int pinned_by_
     if (allowed < 1 || allowed > online) allowed = online;
     cores = pinned_by_launcher ? allowed : allowed / ranks;
     if (cores < 1) cores = 1;
-    n = cores / 2;
+    /* round 6: a small share is used whole (one core left to the runtime's helper threads) -- with 4 cores the old rule (half of them)
+     * left the session layer 2 threads and the GPU idle a fifth of every step (profiles/r06_cpu_starved.txt) */
+    n = cores <= 16 ? cores - 1 : cores / 2;
     if (n > 12) n = 12;
     if (n < 1) n = 1;
     return (int)n;
@@ -513,14 +515,34 @@ static struct {
     dsv1_par_fn fn; void *ctx; int S;
     volatile int next;              /* next item to hand out */
     int active;                     /* workers still inside the current job */
-} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, NULL, NULL, 0, 0, 0};
+    /* ONE background job beside the foreground ones (round 6, dsv1_par_bg_begin / _end): its items are taken by workers that have nothing
+     * else to do -- while the session thread waits for the GPU -- and by the session thread itself when it joins; all fields under mu */
+    dsv1_par_fn bg_fn; void *bg_ctx; int bg_S, bg_next, bg_done;
+    pthread_cond_t bg_cv;
+} g_pool = {PTHREAD_MUTEX_INITIALIZER, PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, NULL, NULL, 0, 0, 0,
+            NULL, NULL, 0, 0, 0, PTHREAD_COND_INITIALIZER};
 
 /* a forked child has none of the workers: it starts its own on first need */
 static void pool_after_fork_child(void)
 {
     pthread_mutex_init(&g_pool.mu, NULL); pthread_mutex_init(&g_pool.call, NULL);
-    pthread_cond_init(&g_pool.go, NULL); pthread_cond_init(&g_pool.done, NULL);
+    pthread_cond_init(&g_pool.go, NULL); pthread_cond_init(&g_pool.done, NULL); pthread_cond_init(&g_pool.bg_cv, NULL);
     g_pool.started = 0; g_pool.nworkers = 0; g_pool.active = 0; g_pool.gen = 0;
+    g_pool.bg_fn = NULL; g_pool.bg_S = g_pool.bg_next = g_pool.bg_done = 0;       /* (the parent's background job is the parent's) */
+}
+/* take background items until none is left to hand out; called and left with mu HELD */
+static void pool_run_bg_locked(int tid)
+{
+    while (g_pool.bg_fn && g_pool.bg_next < g_pool.bg_S) {
+        const int s = g_pool.bg_next++;
+        const dsv1_par_fn fn = g_pool.bg_fn;
+        void *ctx = g_pool.bg_ctx;
+        pthread_mutex_unlock(&g_pool.mu);
+        fn(ctx, s, tid);
+        pthread_mutex_lock(&g_pool.mu);
+        if (++g_pool.bg_done == g_pool.bg_S) pthread_cond_broadcast(&g_pool.bg_cv);
+        if (g_pool.gen != 0 && g_pool.active > 0 && g_pool.next < g_pool.S) break;      /* a foreground job has items waiting: it goes first */
+    }
 }
 static void pool_run_items(int tid)
 {
@@ -536,13 +558,18 @@ static void *pool_worker(void *p)
     unsigned long seen = 0;
     pthread_mutex_lock(&g_pool.mu);
     for (;;) {
-        while (g_pool.gen == seen) pthread_cond_wait(&g_pool.go, &g_pool.mu);
-        seen = g_pool.gen;
-        if (tid > g_pool.nworkers) continue;            /* this job uses fewer workers */
-        pthread_mutex_unlock(&g_pool.mu);
-        pool_run_items(tid);
-        pthread_mutex_lock(&g_pool.mu);
-        if (--g_pool.active == 0) pthread_cond_signal(&g_pool.done);
+        while (g_pool.gen == seen && !(g_pool.bg_fn && g_pool.bg_next < g_pool.bg_S)) pthread_cond_wait(&g_pool.go, &g_pool.mu);
+        if (g_pool.gen != seen) {
+            seen = g_pool.gen;
+            if (tid <= g_pool.nworkers) {                /* (else: this job uses fewer workers) */
+                pthread_mutex_unlock(&g_pool.mu);
+                pool_run_items(tid);
+                pthread_mutex_lock(&g_pool.mu);
+                if (--g_pool.active == 0) pthread_cond_signal(&g_pool.done);
+            }
+            continue;                                   /* (a newer foreground job may have come in meanwhile: look again before background work) */
+        }
+        pool_run_bg_locked(tid);
     }
     return NULL;
 }
@@ -550,18 +577,12 @@ static void par_for_min(int S, dsv1_par_fn fn, void *ctx, int min_items);
 void dsv1_par_for(int S, dsv1_par_fn fn, void *ctx) { par_for_min(S, fn, ctx, 4); }   /* (a wake-up costs ~30 us: small loops stay on the caller) */
 /* the same for a FEW LONG items (the coding streams' launch sequences of a call: milliseconds each): two items already go parallel */
 void dsv1_par_for_long(int S, dsv1_par_fn fn, void *ctx) { par_for_min(S, fn, ctx, 2); }
-static void par_for_min(int S, dsv1_par_fn fn, void *ctx, int min_items)
+/* workers are created on first need and never leave; called with mu held */
+static void pool_start_workers_locked(int nthr)
 {
-    const int nthr = par_threads(S);
-    int i;
-    if (nthr <= 1 || S < min_items) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }
-    pthread_mutex_lock(&g_pool.call);
-    pthread_mutex_lock(&g_pool.mu);
-    {
-        static int atfork_set = 0;
-        if (!atfork_set) { atfork_set = 1; pthread_atfork(NULL, NULL, pool_after_fork_child); }
-    }
-    while (g_pool.started < nthr - 1) {                 /* workers are created on first need and never leave */
+    static int atfork_set = 0;
+    if (!atfork_set) { atfork_set = 1; pthread_atfork(NULL, NULL, pool_after_fork_child); }
+    while (g_pool.started < nthr - 1) {
         pthread_t th;
         pthread_attr_t at;
         pthread_attr_init(&at);
@@ -570,6 +591,56 @@ static void par_for_min(int S, dsv1_par_fn fn, void *ctx, int min_items)
         pthread_attr_destroy(&at);
         g_pool.started++;
     }
+}
+/* A BACKGROUND loop over S items (round 6): returns at once; the items are run by workers that have no foreground work -- i.e. while the
+ * session thread waits for the GPU or runs serial code -- and whatever is left when dsv1_par_bg_end is called is finished there with the
+ * caller's help.  One at a time (a second begin joins the first); fn / ctx must stay valid until the end call.  A host that was short of
+ * cores spent every step's packet prefixes (23 core-ms per 320-GOP batch) between the coding enqueue and the fetch, with the GPU waiting. */
+void dsv1_par_bg_end(void)
+{
+    pthread_mutex_lock(&g_pool.mu);
+    if (g_pool.bg_fn) {
+        while (g_pool.bg_next < g_pool.bg_S) {
+            const int s = g_pool.bg_next++;
+            const dsv1_par_fn fn = g_pool.bg_fn;
+            void *ctx = g_pool.bg_ctx;
+            pthread_mutex_unlock(&g_pool.mu);
+            fn(ctx, s, 0);
+            pthread_mutex_lock(&g_pool.mu);
+            g_pool.bg_done++;
+        }
+        while (g_pool.bg_done < g_pool.bg_S) pthread_cond_wait(&g_pool.bg_cv, &g_pool.mu);
+        g_pool.bg_fn = NULL; g_pool.bg_ctx = NULL; g_pool.bg_S = g_pool.bg_next = g_pool.bg_done = 0;
+    }
+    pthread_mutex_unlock(&g_pool.mu);
+}
+int dsv1_par_bg_pending(void) { int r; pthread_mutex_lock(&g_pool.mu); r = g_pool.bg_fn != NULL; pthread_mutex_unlock(&g_pool.mu); return r; }
+void dsv1_par_bg_begin(int S, dsv1_par_fn fn, void *ctx)
+{
+    const int nthr = par_threads(S);
+    int i;
+    dsv1_par_bg_end();
+    if (S <= 0 || !fn) return;
+    if (nthr <= 1) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }      /* no workers: now */
+    pthread_mutex_lock(&g_pool.mu);
+    pool_start_workers_locked(nthr);
+    if (g_pool.started < 1) {                            /* (thread creation failed) */
+        pthread_mutex_unlock(&g_pool.mu);
+        for (i = 0; i < S; i++) fn(ctx, i, 0);
+        return;
+    }
+    g_pool.bg_fn = fn; g_pool.bg_ctx = ctx; g_pool.bg_S = S; g_pool.bg_next = 0; g_pool.bg_done = 0;
+    pthread_cond_broadcast(&g_pool.go);
+    pthread_mutex_unlock(&g_pool.mu);
+}
+static void par_for_min(int S, dsv1_par_fn fn, void *ctx, int min_items)
+{
+    const int nthr = par_threads(S);
+    int i;
+    if (nthr <= 1 || S < min_items) { for (i = 0; i < S; i++) fn(ctx, i, 0); return; }
+    pthread_mutex_lock(&g_pool.call);
+    pthread_mutex_lock(&g_pool.mu);
+    pool_start_workers_locked(nthr);
     g_pool.fn = fn; g_pool.ctx = ctx; g_pool.S = S; g_pool.next = 0;
     g_pool.nworkers = g_pool.started < nthr - 1 ? g_pool.started : nthr - 1;
     g_pool.active = g_pool.nworkers;
