@@ -834,7 +834,7 @@ def main():
                                       "pinned": "raw frames uploaded from pinned host memory each step (PCIe inclusive, diagnostic)"}[args.input]),
                        "gops_per_gpu": args.gops, "frames_per_step": args.gops * GOP * world,
                        "dsv_bytes_per_step_rank0": out_bytes, "parallelism": "gop-shard x%d, no collectives" % world,
-                       "host_cores_rank0": len(my_cores), "numa_node_of_gpu_rank0": numa_node,
+                       "host_cores_rank0": len(my_cores), "host_threads_rank0": L.dsv1_host_threads(), "numa_node_of_gpu_rank0": numa_node,
                        "streams_on_own_hw_queue": L.dsvg_ctx_streams_apart(b.ctx),
                        "copy_stream_queue": {0: "own", 2: "own (lowest-priority stream)", 3: "own (highest-priority stream)", 1: "shares the analysis stream's", -1: "as the runtime placed it"}.get(L.dsvg_ctx_copy_queue(b.ctx), "?"),
                        "GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"),

@@ -1035,7 +1035,8 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
              * coding enqueue and the fetch on every step: 1.9 ms with 12 workers, 11.7 ms of a 43 ms step on 4 cores (profiles/r06_cpu_starved.txt) */
             b->bg_sc[par] = sc_;
             b->bg_on[par] = 1;
-            dsv1_par_bg_begin(S, prefix_stream, &b->bg_sc[par]);
+            dsv1_par_bg_begin(S, prefix_stream, &b->bg_sc[par]);      /* (one loop at a time: this joins the loop of the batch before, if it still runs) */
+            b->bg_on[par ^ 1] = 0;
         }
         if (sc_.rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); return sc_.rc; }
         b->pending[par] = serial ? 2 : 1;               /* 2 = already assembled */
@@ -1086,7 +1087,13 @@ int dsv1_batch_collect(dsv1_batch *b, DSV_BUF *out)
         dsv1_par_bg_end();
         b->bg_on[par] = 0;
         HP_MARK(HP_JOIN);
-        if (b->bg_sc[par].rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); b->pending[par] = 0; return b->bg_sc[par].rc; }
+    }
+    if (b->bg_sc[par].rc) {                             /* (set by a worker of the batch's loop, whoever joined it) */
+        const int rc_ = b->bg_sc[par].rc;
+        b->bg_sc[par].rc = 0;
+        dsv1_log(1, "out of memory while writing the packet prefixes");
+        b->pending[par] = 0;
+        return rc_;
     }
     if (b->pending[par] == 1) {
         HP_BEGIN();

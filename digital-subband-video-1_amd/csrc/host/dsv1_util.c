@@ -480,10 +480,27 @@ int dsv1_host_threads_rule(long online, long allowed, long ranks, int pinned_by_
     if (cores < 1) cores = 1;
     /* round 6: a small share is used whole (one core left to the runtime's helper threads) -- with 4 cores the old rule (half of them)
      * left the session layer 2 threads and the GPU idle a fifth of every step (profiles/r06_cpu_starved.txt) */
-    n = cores <= 16 ? cores - 1 : cores / 2;
+    n = cores <= 2 ? cores : (cores <= 16 ? cores - 1 : cores / 2);
     if (n > 12) n = 12;
     if (n < 1) n = 1;
     return (int)n;
+}
+/* the CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cpu.cfs_quota_us): a box can show 256 cores and grant 4 -- twelve busy
+ * threads on such a quota are throttled for the rest of every 100 ms period, the GPU with them.  0 = no limit / unknown. */
+static long cgroup_cpu_limit(void)
+{
+    long quota = -1, period = 0;
+    FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (f) {
+        char q[64];
+        if (fscanf(f, "%63s %ld", q, &period) == 2 && strcmp(q, "max") != 0) quota = atol(q);
+        fclose(f);
+    } else {
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r"))) { if (fscanf(f, "%ld", &quota) != 1) quota = -1; fclose(f); }
+        if ((f = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r"))) { if (fscanf(f, "%ld", &period) != 1) period = 0; fclose(f); }
+    }
+    if (quota <= 0 || period <= 0) return 0;
+    return (quota + period - 1) / period;
 }
 static int par_threads(int S)
 {
@@ -496,6 +513,12 @@ static int par_threads(int S)
             long online = sysconf(_SC_NPROCESSORS_ONLN), allowed = online;
             cpu_set_t set;
             if (sched_getaffinity(0, sizeof(set), &set) == 0) allowed = CPU_COUNT(&set);
+            {
+                /* a CPU quota below the visible cores is what the process really has; with the launcher's pinning it is still the CONTAINER's (all
+                 * ranks'), so it only caps this rank's own share there */
+                const long lim = cgroup_cpu_limit();
+                if (lim > 0 && lim < allowed) allowed = lim;
+            }
             n = dsv1_host_threads_rule(online, allowed, lw ? atol(lw) : 1, pin && atoi(pin) != 0);
         }
         if (n < 1) n = 1;
@@ -503,6 +526,7 @@ static int par_threads(int S)
     }
     return n < S ? n : S;
 }
+int dsv1_host_threads(void) { return par_threads(1 << 20); }      /* how many threads (the caller's included) a parallel loop of the session layer uses */
 /* A pool of workers that lives as long as the process: a fork/join per call spent ~40 us per thread in pthread_create /
  * join, five times per batch.  Items are handed out one at a time (atomic counter): the streams of a batch differ in work.
  * The calling thread works too and waits for the stragglers; calls are serialised (one session thread per process is the

@@ -160,6 +160,9 @@ size_t dsv1_parked_bytes(void);
 int dsv1_recycle_hold(int delta);
 /* host phases of dsv1_batch_submit / _collect (round 6): dsv1_host_prof_enable(1) clears and starts the sums, dsv1_host_prof_get returns the
  * number of phases and fills ms per submitted batch for the first n of them (dsv1_host_prof_name(k) says what phase k is); process-wide. */
+/* threads (the calling one included) the session layer's parallel loops use in this process: DSV1_HOST_THREADS, else by the cores the process may
+ * run on -- affinity mask, the container's CPU quota, the node's ranks (csrc/host/dsv1_util.c: dsv1_host_threads_rule) */
+int dsv1_host_threads(void);
 void dsv1_host_prof_enable(int on);
 int dsv1_host_prof_get(double *ms_per_batch, int n, long *batches);
 const char *dsv1_host_prof_name(int k);
