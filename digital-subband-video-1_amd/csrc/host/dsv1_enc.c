@@ -1028,14 +1028,14 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         if (!serial && !b->chains && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
         HP_MARK(HP_ENQUEUE);
         /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
-        if (b->chains) dsv1_par_for(nf, prefix_picture, &sc_);      /* (one stream: the pictures are the independent items) */
-        else if (!abr) {
+        if (!abr) {
             /* round 6: in the BACKGROUND -- idle workers write them while this thread waits for the GPU in the next calls (the fetch of the batch
              * before, the load and motion search of the batch after); dsv1_batch_collect of THIS batch joins.  Synchronous, the loop sat between the
              * coding enqueue and the fetch on every step: 1.9 ms with 12 workers, 11.7 ms of a 43 ms step on 4 cores (profiles/r06_cpu_starved.txt) */
             b->bg_sc[par] = sc_;
             b->bg_on[par] = 1;
-            dsv1_par_bg_begin(S, prefix_stream, &b->bg_sc[par]);      /* (one loop at a time: this joins the loop of the batch before, if it still runs) */
+            if (b->chains) dsv1_par_bg_begin(nf, prefix_picture, &b->bg_sc[par]);      /* (one stream: the pictures are the independent items) */
+            else dsv1_par_bg_begin(S, prefix_stream, &b->bg_sc[par]);      /* (one loop at a time: this joins the loop of the batch before, if it still runs) */
             b->bg_on[par ^ 1] = 0;
         }
         if (sc_.rc) { dsv1_log(1, "out of memory while writing the packet prefixes"); return sc_.rc; }
