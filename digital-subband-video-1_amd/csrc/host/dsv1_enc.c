@@ -1028,6 +1028,11 @@ static int batch_submit_impl(dsv1_batch *b, const void *yuv, int yuv_on_device, 
         if (!serial && !b->chains && (rc = dsvg_code_batch(b->ctx, nf, S, b->jobs))) return rc;   /* whole batch, one upload */
         HP_MARK(HP_ENQUEUE);
         /* the bits of the packet prefixes: nobody waits for them before the packets are assembled, and the GPU is busy now */
+#ifdef AB_SYNC_PREFIX                                                 /* (A/B: tools/ab/variant.sh syncprefix host_dsv1_enc "" -DAB_SYNC_PREFIX) */
+        if (b->chains) dsv1_par_for(nf, prefix_picture, &sc_);
+        else if (!abr) dsv1_par_for(S, prefix_stream, &sc_);
+        if (0)
+#endif
         if (!abr) {
             /* round 6: in the BACKGROUND -- idle workers write them while this thread waits for the GPU in the next calls (the fetch of the batch
              * before, the load and motion search of the batch after); dsv1_batch_collect of THIS batch joins.  Synchronous, the loop sat between the

@@ -5,12 +5,12 @@
 # The shipped build directory is copied, so only the named objects are recompiled; the shipped library is never touched.
 set -e
 REPO=$(cd "$(dirname "$0")/../.." && pwd)
-N=$1; OBJS=$2; FLAGS=$3
+N=$1; OBJS=$2; FLAGS=$3; CFL=$4          # $4: extra flags for the C session layer (objects host_dsv1_enc, host_dsv1_util, host_dsv1_dec)
 SRC=$REPO/digital-subband-video-1_amd/csrc
 V=$REPO/digital-subband-video-1_amd/variants/$N
 mkdir -p "$V"
 rm -rf "$V/build"; cp -r "$SRC/build" "$V/build"
 for o in $OBJS; do rm -f "$V/build/$o.o"; done
-make -C "$SRC" -j8 BUILD="$V/build" OUT="$V/libdsv1_mi355x.so" EXTRA="$FLAGS" > "$V/build.log" 2>&1 || { tail -20 "$V/build.log"; exit 1; }
+make -C "$SRC" -j8 BUILD="$V/build" OUT="$V/libdsv1_mi355x.so" EXTRA="$FLAGS" EXTRA_C="$CFL" > "$V/build.log" 2>&1 || { tail -20 "$V/build.log"; exit 1; }
 rm -rf "$V/build"
 echo "$V/libdsv1_mi355x.so"
