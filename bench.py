@@ -584,7 +584,9 @@ def main():
             m_, n_, by_ = table[kname]
             npatch = by_ / 128.0
             fl, mv = tiles["flagged_patches_chroma"], tiles["moved_unflagged_patches_chroma"]
-            table[kname] = (m_, n_, npatch * 5.0 + (fl + mv) * 128.0 + fl * 126.0)
+            # round 6: + the reconstruction borders the kernel writes for all three planes (fused border, by the extents the motion vectors ask for:
+            # `fused_border_bytes`, tallied on the host from the jobs' extents in the same counting step) -- output it cannot avoid writing
+            table[kname] = (m_, n_, npatch * 5.0 + (fl + mv) * 128.0 + fl * 126.0 + float(tiles.get("fused_border_bytes", 0)))
         if prof_kernel == "auto":
             prof_kernel = max(table, key=lambda k: table[k][0])
         b.code_streams(nstreams)

@@ -299,7 +299,8 @@ class Batch:
         v = (_C.c_ulonglong * 8)()
         _chk(self.L.dsvg_ctx_tile_stats2(self.ctx, v, 1 if enable else 0), "dsvg_ctx_tile_stats2")
         return {"general_luma": v[0], "general_chroma": v[1], "zero_luma": v[2], "zero_chroma": v[3],
-                "flagged_patches_luma": v[4], "flagged_patches_chroma": v[5], "moved_unflagged_patches_chroma": v[6]}
+                "flagged_patches_luma": v[4], "flagged_patches_chroma": v[5], "moved_unflagged_patches_chroma": v[6],
+                "fused_border_bytes": v[7]}
 
     def kernel_names(self):
         return [self.L.dsvg_prof_kernel_name(i).decode() for i in range(self.L.dsvg_prof_kernels())]

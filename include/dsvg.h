@@ -153,7 +153,7 @@ int dsvg_ctx_tile_stats(dsvg_ctx *ctx, unsigned long long out[4], int enable);
  * must move): out[4] = 8x8 luma patches of computed tiles whose flag was up (their 96 bytes of level-1 symbols were fetched by
  * k_inv_p_tile), out[5] = chroma patches with a flag (k_inv_patch_c fetched their 126 bytes of symbols of the three levels),
  * out[6] = chroma patches without a flag that were still rewritten (non-zero LL3 residual, or prediction not in place: 64 bytes
- * in, 64 out), out[7] = 0. */
+ * in, 64 out), out[7] = bytes of reconstruction border written by the fused inverse kernels (round 6; tallied on the host from the jobs' extents). */
 int dsvg_ctx_tile_stats2(dsvg_ctx *ctx, unsigned long long out[8], int enable);
 
 /* device memory helpers for callers that keep the raw clip in HBM (bench.py) */
