@@ -3103,8 +3103,16 @@ __global__ __launch_bounds__(256) INV_PATCH_C_ATTR void k_inv_patch_c(const JobD
 // --------------------------------------------------------------------------------------------
 // inverse, I pictures: level 1 biorthogonal, columns then rows (inv_b4t_2d sbt.c:253-265) + sbc2int
 // --------------------------------------------------------------------------------------------
-#define BT_C 32                 // level-1 cells per tile edge -> 64x64 px
-#define BT_VW (BT_C + 2)        // columns k0-1 .. k0+BT_C of each half
+// level-1 cells per tile: BT_CX x BT_CY (-> 2 BT_CX x 2 BT_CY pixels).  Round 6: 60 x 32 instead of 32 x 32 -- the column pass has 2 (BT_CX + 2) x BT_CY / BT_SEG
+// items for the workgroup's 256 threads: 136 with the square tile (the third and fourth wave idled through the kernel's heavier half), 248 now; the halo
+// columns are 3 % instead of 6 % of the loads, and 960 / 480 cells (1080p luma / chroma) and 1920 (4K) are whole numbers of tiles
+#ifndef BT_CX
+#define BT_CX 60
+#endif
+#ifndef BT_CY
+#define BT_CY 32
+#endif
+#define BT_VW (BT_CX + 2)       // columns k0-1 .. k0+BT_CX of each half
 #ifndef BT_SEG
 #define BT_SEG 16               // cell rows per item of the column pass (160 I pictures: cell by cell 1.155 ms, 4: 0.92, 8: 0.81, 16: 0.75; 32 spills)
 #endif
@@ -3123,8 +3131,9 @@ __global__ __launch_bounds__(256) INV_PATCH_C_ATTR void k_inv_patch_c(const JobD
 template <bool SYM>
 __global__ __launch_bounds__(256) INV_B4T_ATTR void k_inv_b4t(const JobDev *__restrict__ jobs, SbtGeo3 G, int c0, int npl, XcdGrid XG, int plain)
 {
-    __shared__ int VL[2 * BT_C][BT_VW];     // column-pass output, low-horizontal half
-    __shared__ int VH[2 * BT_C][BT_VW];     // column-pass output, high-horizontal half
+    static_assert(BT_CX % 4 == 0 && BT_CY % BT_SEG == 0, "phase B works on four cells, phase A on BT_SEG cell rows");
+    __shared__ int VL[2 * BT_CY][BT_VW];    // column-pass output, low-horizontal half
+    __shared__ int VH[2 * BT_CY][BT_VW];    // column-pass output, high-horizontal half
     Blk3 B;                                 // one-dimensional launch in XCD order (d_xcd_blk3): a tile shares its halo columns / rows and
     if (!d_xcd_blk3(XG, B, plain != 0)) return;     // the lines its rows straddle with the neighbours in the same L2
     int job, c;
@@ -3134,14 +3143,14 @@ __global__ __launch_bounds__(256) INV_B4T_ATTR void k_inv_b4t(const JobDev *__re
     const int W = g.W, H = g.H, hw = W >> 1, hh = H >> 1;
     const int32_t *coef = jb.coef + g.coff;
     const int32_t *s1 = jb.s1 + g.s1off;
-    const int k0 = B.x * BT_C, m0 = B.y * BT_C;
+    const int k0 = B.x * BT_CX, m0 = B.y * BT_CY;
     const int tid = threadIdx.x;
 
-    // phase A: vertical pass for columns k0-1..k0+BT_C (clamped) of both halves, rows 2*m0 .. 2*m0+2*BT_C-1.
+    // phase A: vertical pass for columns k0-1..k0+BT_CX (clamped) of both halves, rows 2*m0 .. 2*m0+2*BT_CY-1.
     // One item = BT_SEG consecutive cell rows of one column: the BT_SEG + 2 rows it needs (X and Y values, the rows' shift
     // flags) are requested in ONE batch and each serves the three outputs around it -- a third of the loads of a cell-by-cell
     // walk and one memory round trip per item instead of one per cell (the kernel waits on memory, not on the VALUs)
-    constexpr int NSEG = BT_C / BT_SEG, NCOL = 2 * BT_VW;
+    constexpr int NSEG = BT_CY / BT_SEG, NCOL = 2 * BT_VW;
     for (int i = tid; i < NCOL * NSEG; i += 256) {
         const int seg = i / NCOL, r = i - seg * NCOL;
         const int half = r >= BT_VW, kl = r - half * BT_VW;
@@ -3195,8 +3204,8 @@ __global__ __launch_bounds__(256) INV_B4T_ATTR void k_inv_b4t(const JobDev *__re
 
     // phase B: horizontal pass, 4 cells (8 px) per work item
     uint8_t *outp = (jb.recon ? jb.recon : jb.xf) + g.poff;
-    for (int it = tid; it < 2 * BT_C * (BT_C / 4); it += 256) {
-        const int yl = it / (BT_C / 4), gx = it - yl * (BT_C / 4);
+    for (int it = tid; it < 2 * BT_CY * (BT_CX / 4); it += 256) {
+        const int yl = it / (BT_CX / 4), gx = it - yl * (BT_CX / 4);
         const int y = 2 * m0 + yl;
         if (y >= H || y >= g.ph) continue;
         unsigned lo = 0, hi = 0;
@@ -3534,7 +3543,7 @@ void launch_inv_sbt(hipStream_t st, const JobDev *jobs, int njobs, const SbtGeo3
             else      hipLaunchKernelGGL((k_inv_haar_tile<false, 1, false>), tg, dim3(256), 0, st, jobs, G, c0, npl, 0, 0);
         }
         PE();
-        const dim3 bg(((g.W >> 1) + BT_C - 1) / BT_C, ((g.H >> 1) + BT_C - 1) / BT_C, nz);
+        const dim3 bg(((g.W >> 1) + BT_CX - 1) / BT_CX, ((g.H >> 1) + BT_CY - 1) / BT_CY, nz);
         PB(insym ? KID_INV_B4T_SYM : KID_INV_B4T, smp * (insym ? 3.5 : 5.0));           // LL1 1 + details 3 (symbols: 1.5) in, 1 out
         if (insym) hipLaunchKernelGGL((k_inv_b4t<true>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, mk_xcd_grid((int)bg.x, (int)bg.y, (int)bg.z), xcd_plain());
         else       hipLaunchKernelGGL((k_inv_b4t<false>), tile_grid(bg.x, bg.y, bg.z), dim3(256), 0, st, jobs, G, c0, npl, mk_xcd_grid((int)bg.x, (int)bg.y, (int)bg.z), xcd_plain());
