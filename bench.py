@@ -433,7 +433,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--gops", type=int, default=320, help="closed GOPs per GPU per step (320 GOPs keep ~100 GB of HBM and 12 GB of host memory; tools/ab/gops_sweep.sh "
                                                           "measures other sizes on the same box -- DESIGN.md section 7 has the round's table)")
-    ap.add_argument("--distinct", type=int, default=4, help="distinct synthetic GOP clips generated per rank")
+    ap.add_argument("--distinct", type=int, default=16, help="distinct synthetic GOP clips generated per rank (round 6: 16, was 4 -- the timed batch's branch behaviour is 16-valued; "
+                                                                 "every one of them is checked against the reference's encode; `shapes.headline_mixed16` mixes clip STYLES as well)")
     ap.add_argument("--cpu-gops", type=int, default=32, help="GOP encodes in the CPU baseline sample, ~0.3 s each (0 = skip)")
     ap.add_argument("--prof-kernel", default="auto", help="kernel whose launches are timed with HIP events (auto = the largest; none = no brackets, no roofline: counter passes)")
     ap.add_argument("--no-extras", action="store_true", help="skip the PCIe-inclusive figure and the other shapes (configs 2, 4, 5, batched decode) reported after the headline")
