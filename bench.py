@@ -630,7 +630,7 @@ def main():
         b.recon_all(True)
         b.submit(src, on_device=True, held=True)
         b.sync()
-        ra_steps = max(2, min(args.steps, 8))
+        ra_steps = max(2, min(args.steps, 20))      # (the region ends with a sync that drains the last batch: over 8 steps that tail read as +2.5 ms per step)
         t1 = time.perf_counter()
         for _ in range(ra_steps):
             b.submit(src, on_device=True, held=True)

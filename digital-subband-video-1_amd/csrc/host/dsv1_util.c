@@ -554,10 +554,11 @@ static void pool_after_fork_child(void)
     g_pool.started = 0; g_pool.nworkers = 0; g_pool.active = 0; g_pool.gen = 0;
     g_pool.bg_fn = NULL; g_pool.bg_S = g_pool.bg_next = g_pool.bg_done = 0;       /* (the parent's background job is the parent's) */
 }
-/* take background items until none is left to hand out; called and left with mu HELD */
-static void pool_run_bg_locked(int tid)
+/* take background items until none is left to hand out or a foreground loop this worker has not looked at yet has started (`seen`: the
+ * generation it served last) -- foreground loops go first, the session thread waits for them; called and left with mu HELD */
+static void pool_run_bg_locked(int tid, unsigned long seen)
 {
-    while (g_pool.bg_fn && g_pool.bg_next < g_pool.bg_S) {
+    while (g_pool.bg_fn && g_pool.bg_next < g_pool.bg_S && g_pool.gen == seen) {
         const int s = g_pool.bg_next++;
         const dsv1_par_fn fn = g_pool.bg_fn;
         void *ctx = g_pool.bg_ctx;
@@ -565,7 +566,6 @@ static void pool_run_bg_locked(int tid)
         fn(ctx, s, tid);
         pthread_mutex_lock(&g_pool.mu);
         if (++g_pool.bg_done == g_pool.bg_S) pthread_cond_broadcast(&g_pool.bg_cv);
-        if (g_pool.gen != 0 && g_pool.active > 0 && g_pool.next < g_pool.S) break;      /* a foreground job has items waiting: it goes first */
     }
 }
 static void pool_run_items(int tid)
@@ -593,7 +593,7 @@ static void *pool_worker(void *p)
             }
             continue;                                   /* (a newer foreground job may have come in meanwhile: look again before background work) */
         }
-        pool_run_bg_locked(tid);
+        pool_run_bg_locked(tid, seen);
     }
     return NULL;
 }
