@@ -516,8 +516,13 @@ static int par_threads(int S)
             {
                 /* a CPU quota below the visible cores is what the process really has; with the launcher's pinning it is still the CONTAINER's (all
                  * ranks'), so it only caps this rank's own share there */
-                const long lim = cgroup_cpu_limit();
-                if (lim > 0 && lim < allowed) allowed = lim;
+                const long lim = cgroup_cpu_limit(), ranks = lw && atol(lw) > 0 ? atol(lw) : 1;
+                if (lim > 0) {
+                    if (pin && atoi(pin) != 0) {                     /* this rank's own mask: its share of the container's quota caps it */
+                        const long share = lim / ranks > 0 ? lim / ranks : 1;
+                        if (share < allowed) allowed = share;
+                    } else if (lim < allowed) allowed = lim;        /* everybody's cores: the rule divides by the ranks */
+                }
             }
             n = dsv1_host_threads_rule(online, allowed, lw ? atol(lw) : 1, pin && atoi(pin) != 0);
         }
