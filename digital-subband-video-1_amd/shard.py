@@ -125,7 +125,7 @@ def _scrubbed_env():
             if k != "LD_PRELOAD" and not k.startswith(("ROCP_", "ROCPROF", "ROCPROFILER_", "HSA_TOOLS_", "ROCTRACER_", "RPD_"))}
 
 
-def link_probe(dev, cores=None, nbytes=1 << 29, reps=4, timeout=120):
+def link_probe(dev, cores=None, nbytes=1 << 30, reps=3, timeout=45):
     """The host <-> device link of HIP device `dev` as a process running on `cores` (None: this process's mask) sees it, measured through the
     library's own copy path (dsvg_link_probe: hipHostMalloc'd memory first touched on those cores, asynchronous copies, HIP events) in a
     short-lived CHILD process -- the caller need not have touched the GPU, and its own affinity does not change.
